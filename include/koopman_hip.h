@@ -1,0 +1,195 @@
+/* koopman_hip.h — C ABI of libkoopman_hip.so (MI355X / gfx950, HIP).
+ *
+ * Drop-in boundary for ONE hot path of roahmlab/koopman-realizations: the EDMD fit of
+ * Ksysid.m and the per-step MPC solve of Kmpc.m.  The reference has no FFI (it is pure
+ * MATLAB); the seam is its class-method signatures.  Each entry point below names the
+ * reference code it replaces (file:line under the reference checkout).  A MATLAB host
+ * binds these with loadlibrary/calllib or a thin MEX gateway.
+ *
+ * Conventions
+ *   - all matrices are IEEE f64, COLUMN-MAJOR (MATLAB layout), rows = snapshots/time;
+ *   - every pointer is a HOST pointer unless the name ends in _dev or the type is an
+ *     opaque handle; the library copies in/out and never keeps caller pointers;
+ *   - every function returns KP_OK (0) or a negative kp_status; kp_last_error() gives text;
+ *   - handles own device memory and are freed by the matching *_destroy;
+ *   - calls on one kp_ctx are serialised by the caller (MATLAB is single threaded);
+ *     the library synchronises its stream before returning host results.
+ */
+#ifndef KOOPMAN_HIP_H
+#define KOOPMAN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  KP_OK = 0,
+  KP_ERR_ARG = -1,        /* bad argument / unsupported configuration            */
+  KP_ERR_HIP = -2,        /* HIP runtime failure (no device, OOM, launch error)   */
+  KP_ERR_NOT_SPD = -3,    /* Gram matrix not numerically SPD (rank deficient Psi) */
+  KP_ERR_QP_FAIL = -4,    /* QP infeasible / iteration cap: caller maps to NaN U  */
+  KP_ERR_NOT_CONVERGED = -5
+} kp_status;
+
+typedef struct kp_ctx kp_ctx;             /* device, stream, workspaces            */
+typedef struct kp_basis kp_basis;         /* dictionary of observables on device   */
+typedef struct kp_snapshots kp_snapshots; /* snapshot pairs resident in HBM        */
+typedef struct kp_mpc kp_mpc;             /* condensed MPC problem on device       */
+
+/* ---- context ------------------------------------------------------------------- */
+int kp_create(int device_id, kp_ctx** ctx);
+int kp_destroy(kp_ctx* ctx);
+const char* kp_last_error(const kp_ctx* ctx);   /* ctx may be NULL: last global error */
+/* name (<=255 chars), number of CUs, total HBM bytes of the bound device */
+int kp_device_info(const kp_ctx* ctx, char* name, int name_len, int* num_cu, int64_t* hbm_bytes);
+/* milliseconds spent in the device part of the most recent call of each kind
+ * (HIP events on the library stream): which = 0 gram, 1 solve, 2 mpc step, 3 lasso, 4 lift, 5 rollout */
+int kp_timer_get(const kp_ctx* ctx, int which, double* ms);
+/* Device pointer + byte size of the library stream's raw handle, for profilers/benchmarks
+ * that want to bracket work with their own HIP events: returns hipStream_t as void*. */
+void* kp_stream(const kp_ctx* ctx);
+
+/* ---- dictionary ------------------------------------------------------------------
+ * Replaces the symbolic dictionary of Ksysid.def_observables (Ksysid.m:455-536),
+ * def_polyLift (:629-677, monomial order from partitions.m:206-219), def_fourierLift
+ * (:694-731), def_gaussianLift (:790-817) and the reduced basis of get_econ_observables
+ * (:1435-1577, econ_full :1615, econ_full_input :1594).  matlabFunction closures cannot
+ * cross a C ABI, so the dictionary is carried as data.
+ *
+ * fullBasis = [ v ; block_1 ; ... ; block_nb ; 1 ] over nvars variables v, where
+ * nvars = nzeta for 'linear'/'bilinear' and nzeta+m for 'nonlinear' (u appended,
+ * Ksysid.m:475-477).  Blocks, in obs_type order:
+ *   KP_BLOCK_POLY      count = rows of exponents (nvars bytes each), i.e. the monomials
+ *                      AFTER the first nvars (Ksysid.m:488); data: exponents in poly_exps
+ *   KP_BLOCK_FOURIER   count = degree; (1+2deg)^nvars - 1 functions, last variable fastest
+ *   KP_BLOCK_GAUSSIAN  count = number of centres; data: nvars doubles per centre
+ * pcs (Nfull x k, column-major) may be NULL (dim_red = false).
+ */
+enum { KP_MODEL_LINEAR = 0, KP_MODEL_BILINEAR = 1, KP_MODEL_NONLINEAR = 2 };
+enum { KP_BLOCK_POLY = 0, KP_BLOCK_FOURIER = 1, KP_BLOCK_GAUSSIAN = 2 };
+
+typedef struct {
+  int32_t model_type;          /* KP_MODEL_*                                         */
+  int32_t nzeta;               /* n*(nd+1)+m*nd, Ksysid.m:86                         */
+  int32_t m;                   /* number of inputs                                   */
+  int32_t n_blocks;
+  const int32_t* block_type;   /* n_blocks                                           */
+  const int32_t* block_count;  /* n_blocks                                           */
+  const uint8_t* poly_exps;    /* all POLY blocks' exponent rows, concatenated       */
+  const double* gauss_centres; /* all GAUSSIAN blocks' centres, concatenated         */
+  int32_t k_pcs;               /* 0 => no dimension reduction                        */
+  const double* pcs;           /* Nfull x k_pcs column-major, or NULL                */
+} kp_basis_desc;
+
+int kp_basis_create(kp_ctx* ctx, const kp_basis_desc* desc, kp_basis** basis);
+int kp_basis_destroy(kp_basis* basis);
+/* Nfull = length(basis.full) (Ksysid.m:534); N = params.N after dim_red (:1512-1516);
+ * W = width of Px (:1019-1028): N+m linear, N(m+1) bilinear, N nonlinear. */
+int kp_basis_dims(const kp_basis* basis, int* nvars, int* nfull, int* N, int* W);
+
+/* ---- lifting ----------------------------------------------------------------------
+ * what = KP_LIFT_FULL : lift.full      (Ksysid.m:533; rows x Nfull)  [lift_snapshots :1417-1431]
+ *        KP_LIFT_ECON : lift.econ_full (Ksysid.m:1615-1618 / :1443-1491; rows x N)
+ *        KP_LIFT_ROW  : one row block of Px as built in get_Koopman (Ksysid.m:1034-1064;
+ *                       rows x W): [psi,u] / psi (x) [1;u] / psi([zeta;u])
+ * zeta: rows x nzeta, u: rows x m (u may be NULL for FULL/ECON of linear/bilinear).
+ * out: rows x width, column-major, caller allocated.
+ */
+enum { KP_LIFT_FULL = 0, KP_LIFT_ECON = 1, KP_LIFT_ROW = 2 };
+int kp_lift(kp_ctx* ctx, const kp_basis* basis, int what, const double* zeta, const double* u,
+            int64_t rows, double* out);
+
+/* ---- snapshot pairs resident on the device ----------------------------------------
+ * snapshotPairs.alpha / .beta (Ns x nzeta) and .u (Ns x m) of Ksysid.get_snapshotPairs
+ * (Ksysid.m:977-979).  The random draw (:974-975) stays on the MATLAB host. */
+int kp_snapshots_upload(kp_ctx* ctx, const double* alpha, const double* beta, const double* u,
+                        int64_t Ns, int nzeta, int m, kp_snapshots** snaps);
+int kp_snapshots_destroy(kp_snapshots* snaps);
+
+/* ---- EDMD fit ---------------------------------------------------------------------
+ * kp_fit_gram: the fused per-row lift loop of get_Koopman (Ksysid.m:1030-1065) and the
+ *   accumulations PxTPx = Px'*Px (:1114), PxTPy = Px'*Py (:1125).  Px/Py are never
+ *   materialised.  G, C: W x W column-major (either may be NULL to leave the result on
+ *   the device only, for kp_fit_solve_dev).
+ * kp_fit_solve: K = Px \ Py (Ksysid.m:1069) from the normal equations G K = C by Cholesky.
+ *   ncols = columns of C.  KP_ERR_NOT_SPD when Psi is rank deficient (MATLAB warns and
+ *   returns a basic solution there, which is not reproducible).
+ * kp_fit_lasso: solve_KoopmanQP (Ksysid.m:1095-1176, delays = 0):
+ *   min 1/2||Px K - Py||_F^2  s.t. ||vec K||_1 <= t,  t = lasso * N (:996).
+ * kp_fit: get_Koopman end to end for n_lasso values (train_models loop :1372-1387) on
+ *   resident snapshots; lasso[i] >= 1e6 (or +Inf) selects the least-squares branch (:1068).
+ *   K_out: n_lasso matrices W x W, column-major, back to back (may be NULL: results stay
+ *   on the device; fetch with kp_fit_get_K).
+ * kp_fit_refine: one step of iterative refinement K += G^-1 Px'(Py - Px K) with the
+ *   residual Gram accumulated in a second fused pass (recovers QR-level accuracy for
+ *   ill-conditioned dictionaries).
+ */
+int kp_fit_gram(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* snaps, double* G, double* C);
+int kp_fit_solve(kp_ctx* ctx, const double* G, const double* C, int W, int ncols, double* K);
+int kp_fit_lasso(kp_ctx* ctx, const double* G, const double* C, int W, int ncols, double t,
+                 int max_iter, double tol, double* K, int* iters);
+int kp_fit(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* snaps, const double* lasso,
+           int n_lasso, double* K_out);
+int kp_fit_get_K(kp_ctx* ctx, int index, int W, double* K);
+
+/* Model extraction with the M-projection of get_model (Ksysid.m:1206-1225): from K and
+ * the Grams (no second pass over the data): L'L = [A B] G [A B]', L'R = [A B] C(:,1:N).
+ * A_out N x N, B_out N x m (= M*A, M*B), M_out N x N.  Linear models only. */
+int kp_model_project(kp_ctx* ctx, const double* K, const double* G, const double* C, int N, int m,
+                     double* A_out, double* B_out, double* M_out);
+
+/* ---- validation rollouts ------------------------------------------------------------
+ * val_model (Ksysid.m:1678-1689) z+ = A z + B u ; val_BLmodel (:1772-1787)
+ * z+ = A z + B kron(I_m,z) u.  z0: N, U: T x m (rows = steps), Y: T x n_out with
+ * Y(1,:) = Cz0 ... (C = first n_out entries of z, Ksysid.m:1203).  batch independent
+ * models may be rolled out at once (arrays back to back). */
+int kp_rollout(kp_ctx* ctx, int model_type, int batch, const double* A, const double* B, int N, int m,
+               const double* z0, const double* U, int T, int n_out, double* Y);
+
+/* ---- MPC --------------------------------------------------------------------------
+ * kp_mpc_create: Kmpc constructor for the linear-MPC types: get_costMatrices
+ *   (Kmpc.m:157-211) / get_costMatrices_bilinear (:517-559) and
+ *   get_constraintMatrices(_bilinear) (:214-326, :626-738).
+ *   A: N x N; B: N x m (linear) or N x (N*m) (bilinear, blocks B_i, Ksysid.m:1259);
+ *   proj: nproj x N (projmtx); q_run, q_term (cost_running/terminal, :197-198);
+ *   r: m input weights = diag of eye(m).*cost_input (:201);
+ *   lo, hi: m scaled-down input bounds (:247,659) or NULL; slope_lim =
+ *   input_slopeConst*mean(u_factor) (:272,684) or NaN; smooth_lim (:294,706) or NaN.
+ *   State bounds (:300-318) are not supported (KP_ERR_ARG).
+ * kp_mpc_step: one get_mpcInput (Kmpc.m:329-387) / get_mpcInput_bilinear_iter
+ *   (:817-904) call: z is the lifted state (N), u_prev = traj.u(end,:) (m), Yr the
+ *   padded, vectorised reference (nproj*(Np+1), :354-365); iters as in :874.
+ *   U_out: Np x m column-major (row 1 = pinned current input; Ksim applies row 2,
+ *   Ksim.m:225).  On QP failure U_out is filled with NaN and *status = KP_ERR_QP_FAIL
+ *   (quadprog_gurobi.m:18-23, Ksim.m:220-222); the function itself still returns KP_OK.
+ * kp_mpc_step_zeta: same, with the lift z = lift.econ_full(zeta) (Kmpc.m:842) fused in
+ *   front (one launch); z_out (N) may be NULL.
+ * kp_mpc_step_batch: nb independent problems of the same controller (random-system
+ *   sweeps, Monte-Carlo closed loops); arrays are column-major with nb columns.
+ * kp_qp_solve: generic shim with the signature of quadprog_gurobi(H,f,A,b)
+ *   (quadprog_gurobi.m:1; call sites Kmpc.m:382,809,882): min 1/2 x'Hx + f'x, Ax <= b.
+ */
+int kp_mpc_create(kp_ctx* ctx, int model_type, const double* A, const double* B, int N, int m, int Np,
+                  const double* proj, int nproj, double q_run, double q_term, const double* r,
+                  const double* lo, const double* hi, double slope_lim, double smooth_lim,
+                  kp_mpc** mpc);
+int kp_mpc_destroy(kp_mpc* mpc);
+int kp_mpc_dims(const kp_mpc* mpc, int* nvar, int* nrows);
+int kp_mpc_step(kp_mpc* mpc, const double* z, const double* u_prev, const double* Yr, int iters,
+                double* U_out, int* status);
+int kp_mpc_step_zeta(kp_mpc* mpc, const kp_basis* basis, const double* zeta, const double* u_prev,
+                     const double* Yr, int iters, double* U_out, double* z_out, int* status);
+int kp_mpc_step_batch(kp_mpc* mpc, int nb, const double* z, const double* u_prev, const double* Yr,
+                      double* U_out, int* status);
+/* The QP data (2H, f, A_ineq, b) of the most recent kp_mpc_step, for parity checks against
+ * the literal assembly of Kmpc.m:861-883.  Hq: nvar x nvar, Aq: nrows x nvar (column-major). */
+int kp_mpc_last_qp(kp_mpc* mpc, double* Hq, double* f, double* Aq, double* bq);
+int kp_qp_solve(kp_ctx* ctx, const double* H, const double* f, const double* A, const double* b, int n,
+                int mrows, double* x, int* status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KOOPMAN_HIP_H */

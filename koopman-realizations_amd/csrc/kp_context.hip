@@ -1,0 +1,368 @@
+// Context, dictionary upload, snapshot upload and the standalone lift kernel.
+#include <cmath>
+#include <cstring>
+#include <mutex>
+
+#include "kp_internal.h"
+
+static std::mutex g_err_mu;
+static std::string g_err;
+
+void kp_set_global_error(const std::string& s) {
+  std::lock_guard<std::mutex> l(g_err_mu);
+  g_err = s;
+}
+
+void* kp_ctx::workspace(int slot, size_t bytes) {
+  if (ws_bytes[slot] >= bytes && ws[slot]) return ws[slot];
+  if (ws[slot]) (void)hipFree(ws[slot]);
+  ws[slot] = nullptr;
+  ws_bytes[slot] = 0;
+  size_t want = bytes + bytes / 4 + 256;
+  if (hipMalloc(&ws[slot], want) != hipSuccess) return nullptr;
+  ws_bytes[slot] = want;
+  return ws[slot];
+}
+
+extern "C" int kp_create(int device_id, kp_ctx** out) {
+  if (!out) return KP_ERR_ARG;
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) {
+    kp_set_global_error(std::string("kp_create: no HIP device: ") + hipGetErrorString(e));
+    return KP_ERR_HIP;
+  }
+  if (device_id < 0 || device_id >= ndev) {
+    kp_set_global_error("kp_create: device_id out of range");
+    return KP_ERR_ARG;
+  }
+  kp_ctx* c = new kp_ctx();
+  c->device = device_id;
+  if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
+      (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess) {
+    kp_set_global_error(std::string("kp_create: ") + hipGetErrorString(e));
+    delete c;
+    return KP_ERR_HIP;
+  }
+  hipDeviceProp_t p;
+  if (hipGetDeviceProperties(&p, device_id) == hipSuccess) {
+    c->num_cu = p.multiProcessorCount;
+    c->hbm_bytes = (int64_t)p.totalGlobalMem;
+    c->name = std::string(p.name) + " (" + p.gcnArchName + ")";
+  }
+  *out = c;
+  return KP_OK;
+}
+
+extern "C" int kp_destroy(kp_ctx* c) {
+  if (!c) return KP_OK;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  for (int i = 0; i < 8; ++i)
+    if (c->ws[i]) (void)hipFree(c->ws[i]);
+  if (c->Kres) (void)hipFree(c->Kres);
+  if (c->GC) (void)hipFree(c->GC);
+  (void)hipEventDestroy(c->ev0);
+  (void)hipEventDestroy(c->ev1);
+  (void)hipStreamDestroy(c->stream);
+  delete c;
+  return KP_OK;
+}
+
+extern "C" const char* kp_last_error(const kp_ctx* c) {
+  if (c) return c->err.c_str();
+  std::lock_guard<std::mutex> l(g_err_mu);
+  static thread_local std::string copy;
+  copy = g_err;
+  return copy.c_str();
+}
+
+extern "C" int kp_device_info(const kp_ctx* c, char* name, int name_len, int* num_cu, int64_t* hbm) {
+  if (!c) return KP_ERR_ARG;
+  if (name && name_len > 0) {
+    std::strncpy(name, c->name.c_str(), (size_t)name_len - 1);
+    name[name_len - 1] = 0;
+  }
+  if (num_cu) *num_cu = c->num_cu;
+  if (hbm) *hbm = c->hbm_bytes;
+  return KP_OK;
+}
+
+extern "C" int kp_timer_get(const kp_ctx* c, int which, double* ms) {
+  if (!c || !ms || which < 0 || which >= 8) return KP_ERR_ARG;
+  *ms = c->timers[which];
+  return KP_OK;
+}
+
+extern "C" void* kp_stream(const kp_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+// ------------------------------------------------------------------------------------
+// dictionary
+// ------------------------------------------------------------------------------------
+
+static int upload(kp_ctx* ctx, void** dst, const void* src, size_t bytes) {
+  *dst = nullptr;
+  if (bytes == 0) return KP_OK;
+  KP_HIP(ctx, hipMalloc(dst, bytes));
+  KP_HIP(ctx, hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+  return KP_OK;
+}
+
+extern "C" int kp_basis_create(kp_ctx* ctx, const kp_basis_desc* d, kp_basis** out) {
+  if (!ctx || !d || !out) return KP_ERR_ARG;
+  *out = nullptr;
+  KP_HIP(ctx, hipSetDevice(ctx->device));
+  if (d->model_type < 0 || d->model_type > 2) return ctx->fail(KP_ERR_ARG, "kp_basis_create: model_type");
+  if (d->nzeta < 1 || d->m < 0) return ctx->fail(KP_ERR_ARG, "kp_basis_create: nzeta/m");
+  int nvars = d->nzeta + (d->model_type == KP_MODEL_NONLINEAR ? d->m : 0);
+  if (nvars > KP_MAX_VARS) return ctx->fail(KP_ERR_ARG, "kp_basis_create: too many variables (max 32)");
+  std::vector<ColDesc> cols;
+  for (int i = 0; i < nvars; ++i) cols.push_back({COL_VAR, i, 0, 0});
+  int n_mono = 0, n_gauss = 0, max_deg = 1;
+  for (int b = 0; b < d->n_blocks; ++b) {
+    int cnt = d->block_count[b];
+    if (cnt < 0) return ctx->fail(KP_ERR_ARG, "kp_basis_create: negative block count");
+    switch (d->block_type[b]) {
+      case KP_BLOCK_POLY:
+        if (cnt && !d->poly_exps) return ctx->fail(KP_ERR_ARG, "kp_basis_create: poly_exps is NULL");
+        for (int i = 0; i < cnt; ++i) {
+          int deg = 0;
+          for (int v = 0; v < nvars; ++v) deg += d->poly_exps[(size_t)(n_mono + i) * nvars + v];
+          if (deg > max_deg) max_deg = deg;
+          cols.push_back({COL_MONO, n_mono + i, 0, 0});
+        }
+        n_mono += cnt;
+        break;
+      case KP_BLOCK_FOURIER: {
+        if (cnt < 1) return ctx->fail(KP_ERR_ARG, "kp_basis_create: fourier degree < 1");
+        double nf = std::pow((double)(2 * cnt + 1), (double)nvars);
+        if (nf > 1e6) return ctx->fail(KP_ERR_ARG, "kp_basis_create: fourier block too large");
+        int total = (int)std::llround(nf);
+        for (int i = 1; i < total; ++i) cols.push_back({COL_FOURIER, i, cnt, 0});
+        break;
+      }
+      case KP_BLOCK_GAUSSIAN:
+        if (cnt && !d->gauss_centres) return ctx->fail(KP_ERR_ARG, "kp_basis_create: gauss_centres is NULL");
+        for (int i = 0; i < cnt; ++i) cols.push_back({COL_GAUSS, n_gauss + i, 0, 0});
+        n_gauss += cnt;
+        break;
+      default:
+        return ctx->fail(KP_ERR_ARG, "kp_basis_create: unknown block type");
+    }
+  }
+  cols.push_back({COL_CONST, 0, 0, 0});
+  kp_basis* b = new kp_basis();
+  b->ctx = ctx;
+  b->max_degree = max_deg;
+  BasisDev& v = b->dev;
+  v.model_type = d->model_type;
+  v.nzeta = d->nzeta;
+  v.m = d->m;
+  v.nvars = nvars;
+  v.nfull = (int)cols.size();
+  v.k_pcs = d->k_pcs > 0 ? d->k_pcs : 0;
+  if (v.k_pcs && !d->pcs) {
+    delete b;
+    return ctx->fail(KP_ERR_ARG, "kp_basis_create: pcs is NULL");
+  }
+  // params.N: Ksysid.m:534 without dim_red; :1512-1516 with (nvars already holds nzeta(+m))
+  v.N = v.k_pcs ? v.k_pcs + nvars + 1 : v.nfull;
+  v.W = d->model_type == KP_MODEL_BILINEAR ? v.N * (d->m + 1) : d->model_type == KP_MODEL_LINEAR ? v.N + d->m : v.N;
+  int rc = upload(ctx, &b->d_cols, cols.data(), cols.size() * sizeof(ColDesc));
+  if (!rc) rc = upload(ctx, &b->d_exps, d->poly_exps, (size_t)n_mono * nvars);
+  if (!rc) rc = upload(ctx, &b->d_centres, d->gauss_centres, (size_t)n_gauss * nvars * sizeof(double));
+  if (!rc) rc = upload(ctx, &b->d_pcs, d->pcs, (size_t)v.nfull * v.k_pcs * sizeof(double));
+  if (rc) {
+    kp_basis_destroy(b);
+    return rc;
+  }
+  v.cols = (const ColDesc*)b->d_cols;
+  v.exps = (const uint8_t*)b->d_exps;
+  v.centres = (const double*)b->d_centres;
+  v.pcs = (const double*)b->d_pcs;
+  *out = b;
+  return KP_OK;
+}
+
+extern "C" int kp_basis_destroy(kp_basis* b) {
+  if (!b) return KP_OK;
+  (void)hipSetDevice(b->ctx->device);
+  if (b->d_cols) (void)hipFree(b->d_cols);
+  if (b->d_exps) (void)hipFree(b->d_exps);
+  if (b->d_centres) (void)hipFree(b->d_centres);
+  if (b->d_pcs) (void)hipFree(b->d_pcs);
+  delete b;
+  return KP_OK;
+}
+
+extern "C" int kp_basis_dims(const kp_basis* b, int* nvars, int* nfull, int* N, int* W) {
+  if (!b) return KP_ERR_ARG;
+  if (nvars) *nvars = b->dev.nvars;
+  if (nfull) *nfull = b->dev.nfull;
+  if (N) *N = b->dev.N;
+  if (W) *W = b->dev.W;
+  return KP_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// snapshots
+// ------------------------------------------------------------------------------------
+
+extern "C" int kp_snapshots_upload(kp_ctx* ctx, const double* alpha, const double* beta, const double* u, int64_t Ns,
+                                   int nzeta, int m, kp_snapshots** out) {
+  if (!ctx || !out || Ns < 0 || nzeta < 1 || m < 0 || (Ns > 0 && (!alpha || !beta || (m > 0 && !u))))
+    return ctx ? ctx->fail(KP_ERR_ARG, "kp_snapshots_upload: bad argument") : KP_ERR_ARG;
+  *out = nullptr;
+  KP_HIP(ctx, hipSetDevice(ctx->device));
+  kp_snapshots* s = new kp_snapshots();
+  s->ctx = ctx;
+  s->Ns = Ns;
+  s->nzeta = nzeta;
+  s->m = m;
+  size_t bz = (size_t)Ns * nzeta * sizeof(double), bu = (size_t)Ns * m * sizeof(double);
+  hipError_t e = hipSuccess;
+  if (bz) {
+    if ((e = hipMalloc((void**)&s->alpha, bz)) == hipSuccess && (e = hipMalloc((void**)&s->beta, bz)) == hipSuccess &&
+        (e = hipMemcpy(s->alpha, alpha, bz, hipMemcpyHostToDevice)) == hipSuccess)
+      e = hipMemcpy(s->beta, beta, bz, hipMemcpyHostToDevice);
+  }
+  if (e == hipSuccess && bu) {
+    if ((e = hipMalloc((void**)&s->u, bu)) == hipSuccess) e = hipMemcpy(s->u, u, bu, hipMemcpyHostToDevice);
+  }
+  if (e != hipSuccess) {
+    kp_snapshots_destroy(s);
+    return ctx->fail(KP_ERR_HIP, std::string("kp_snapshots_upload: ") + hipGetErrorString(e));
+  }
+  *out = s;
+  return KP_OK;
+}
+
+extern "C" int kp_snapshots_destroy(kp_snapshots* s) {
+  if (!s) return KP_OK;
+  (void)hipSetDevice(s->ctx->device);
+  if (s->alpha) (void)hipFree(s->alpha);
+  if (s->beta) (void)hipFree(s->beta);
+  if (s->u) (void)hipFree(s->u);
+  delete s;
+  return KP_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// standalone lift kernel: lift.full / lift.econ_full / Px rows for a batch of points
+// One workgroup handles LT points; the full lift goes through LDS when a pcs projection
+// follows.  HBM-bound on the output (rows x width x 8 B); outputs are column-major so a
+// wave writes 64 consecutive rows of one column (coalesced).
+// ------------------------------------------------------------------------------------
+
+#define LT 64
+
+__global__ __launch_bounds__(256) void kp_lift_kernel(BasisDev b, int what, const double* __restrict__ zeta,
+                                                      const double* __restrict__ u, int64_t rows,
+                                                      double* __restrict__ out) {
+  extern __shared__ double sm[];
+  // layout: vars[nvars][LT] | um[m][LT] | full[nfull][LT] (only when k_pcs)
+  double* vars = sm;
+  double* um = vars + b.nvars * LT;
+  double* full = um + (b.m > 0 ? b.m : 1) * LT;
+  const int64_t r0 = (int64_t)blockIdx.x * LT;
+  const int tid = threadIdx.x;
+  const int nl = (int)min((int64_t)LT, rows - r0);
+  for (int e = tid; e < (b.nvars + b.m) * LT; e += 256) {
+    int v = e / LT, p = e % LT;
+    double x = 0.0;
+    if (p < nl) {
+      if (v < b.nzeta)
+        x = zeta[(int64_t)v * rows + r0 + p];
+      else if (v < b.nvars)  // nonlinear: u appended to zeta
+        x = u[(int64_t)(v - b.nzeta) * rows + r0 + p];
+      else if (u)
+        x = u[(int64_t)(v - b.nvars) * rows + r0 + p];
+    }
+    if (v < b.nvars)
+      vars[v * LT + p] = x;
+    else
+      um[(v - b.nvars) * LT + p] = x;
+  }
+  __syncthreads();
+  const bool econ = (b.k_pcs > 0) && what != KP_LIFT_FULL;
+  if (!econ) {
+    // column c of the full basis is also column c of psi
+    for (int e = tid; e < b.nfull * LT; e += 256) {
+      int c = e / LT, p = e % LT;
+      if (p >= nl) continue;
+      double val = kp_eval_col(b, b.cols[c], vars + p, LT);
+      int64_t r = r0 + p;
+      if (what == KP_LIFT_ROW && b.model_type == KP_MODEL_BILINEAR) {
+        out[(int64_t)c * rows + r] = val;
+        for (int i = 0; i < b.m; ++i) out[(int64_t)((i + 1) * b.N + c) * rows + r] = val * um[i * LT + p];
+      } else {
+        out[(int64_t)c * rows + r] = val;
+      }
+    }
+  } else {
+    for (int e = tid; e < b.nfull * LT; e += 256) {
+      int c = e / LT, p = e % LT;
+      full[c * LT + p] = p < nl ? kp_eval_col(b, b.cols[c], vars + p, LT) : 0.0;
+    }
+    __syncthreads();
+    // econ = [ v ; pcs' * full ; 1 ]   (Ksysid.m:1615-1618)
+    for (int e = tid; e < b.N * LT; e += 256) {
+      int c = e / LT, p = e % LT;
+      if (p >= nl) continue;
+      double val;
+      if (c < b.nvars)
+        val = vars[c * LT + p];
+      else if (c < b.nvars + b.k_pcs) {
+        const double* pc = b.pcs + (size_t)(c - b.nvars) * b.nfull;
+        val = 0.0;
+        for (int i = 0; i < b.nfull; ++i) val += pc[i] * full[i * LT + p];
+      } else
+        val = 1.0;
+      int64_t r = r0 + p;
+      out[(int64_t)c * rows + r] = val;
+      if (what == KP_LIFT_ROW && b.model_type == KP_MODEL_BILINEAR)
+        for (int i = 0; i < b.m; ++i) out[(int64_t)((i + 1) * b.N + c) * rows + r] = val * um[i * LT + p];
+    }
+  }
+  if (what == KP_LIFT_ROW && b.model_type == KP_MODEL_LINEAR) {  // [psi , u]  Ksysid.m:1062
+    for (int e = tid; e < b.m * LT; e += 256) {
+      int i = e / LT, p = e % LT;
+      if (p < nl) out[(int64_t)(b.N + i) * rows + r0 + p] = um[i * LT + p];
+    }
+  }
+}
+
+extern "C" int kp_lift(kp_ctx* ctx, const kp_basis* basis, int what, const double* zeta, const double* u, int64_t rows,
+                       double* out) {
+  if (!ctx || !basis || what < 0 || what > 2 || rows < 0) return ctx ? ctx->fail(KP_ERR_ARG, "kp_lift: bad argument") : KP_ERR_ARG;
+  if (rows == 0) return KP_OK;
+  const BasisDev& b = basis->dev;
+  if (!zeta || !out) return ctx->fail(KP_ERR_ARG, "kp_lift: NULL pointer");
+  bool need_u = b.model_type == KP_MODEL_NONLINEAR || (what == KP_LIFT_ROW && b.m > 0);
+  if (need_u && !u) return ctx->fail(KP_ERR_ARG, "kp_lift: u required");
+  KP_HIP(ctx, hipSetDevice(ctx->device));
+  int width = what == KP_LIFT_FULL ? b.nfull : what == KP_LIFT_ECON ? b.N : b.W;
+  size_t bz = (size_t)rows * b.nzeta * 8, bu = (size_t)rows * b.m * 8, bo = (size_t)rows * width * 8;
+  double* dz = (double*)ctx->workspace(0, bz);
+  double* du = (double*)ctx->workspace(1, bu ? bu : 8);
+  double* dout = (double*)ctx->workspace(2, bo);
+  if (!dz || !du || !dout) return ctx->fail(KP_ERR_HIP, "kp_lift: out of device memory");
+  KP_HIP(ctx, hipMemcpyAsync(dz, zeta, bz, hipMemcpyHostToDevice, ctx->stream));
+  if (u && bu) KP_HIP(ctx, hipMemcpyAsync(du, u, bu, hipMemcpyHostToDevice, ctx->stream));
+  size_t lds = (size_t)(b.nvars + (b.m > 0 ? b.m : 1) + (b.k_pcs ? b.nfull : 0)) * LT * 8;
+  if (lds > 160 * 1024) return ctx->fail(KP_ERR_ARG, "kp_lift: dictionary too large for the LDS staging of the pcs projection");
+  if (lds > 64 * 1024)
+    KP_HIP(ctx, hipFuncSetAttribute((const void*)kp_lift_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  int64_t nblk = (rows + LT - 1) / LT;
+  KP_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  hipLaunchKernelGGL(kp_lift_kernel, dim3((unsigned)nblk), dim3(256), lds, ctx->stream, b, what, dz, (u && bu) ? du : nullptr, rows, dout);
+  KP_HIP(ctx, hipGetLastError());
+  KP_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  KP_HIP(ctx, hipMemcpyAsync(out, dout, bo, hipMemcpyDeviceToHost, ctx->stream));
+  KP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+  ctx->timers[4] = ms;
+  return KP_OK;
+}

@@ -1,0 +1,402 @@
+// Normal-equation solve  G K = C  (K = Px \ Py of Ksysid.m:1069 for full-rank Px) and the
+// host entry points of the EDMD fit.
+//
+//   kp_pad_kernel      copies G,C into 16-padded buffers (identity / zero padding)
+//   kp_chol_kernel     one workgroup: right-looking blocked Cholesky (panel 16), writes L in
+//                      the lower and L' in the upper triangle plus the inverses of the
+//                      diagonal blocks
+//   kp_trsm_kernel     one wave per 16 right-hand sides: forward + backward substitution by
+//                      blocks with v_mfma_f64_16x16x4_f64, X block resident in LDS
+#include <cmath>
+
+#include "kp_internal.h"
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+__global__ void kp_pad_kernel(const double* __restrict__ G, const double* __restrict__ C, int W, int ncols, int n, int ncp,
+                              double* __restrict__ Gp, double* __restrict__ Cp) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t ng = (int64_t)n * n, nc = (int64_t)n * ncp;
+  if (e < ng) {
+    int i = (int)(e % n), j = (int)(e / n);
+    Gp[e] = (i < W && j < W) ? G[(size_t)j * W + i] : (i == j ? 1.0 : 0.0);
+  } else if (e < ng + nc) {
+    int64_t f = e - ng;
+    int i = (int)(f % n), j = (int)(f / n);
+    Cp[f] = (i < W && j < ncols) ? C[(size_t)j * W + i] : 0.0;
+  }
+}
+
+__global__ void kp_unpad_kernel(const double* __restrict__ Xp, int n, int W, int ncols, double* __restrict__ K) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < (int64_t)W * ncols) {
+    int i = (int)(e % W), j = (int)(e / W);
+    K[e] = Xp[(size_t)j * n + i];
+  }
+}
+
+#define PS 17  // LDS row stride of the 16-wide panels
+
+__global__ __launch_bounds__(1024) void kp_chol_kernel(double* __restrict__ A, int n, double* __restrict__ Dinv, int* __restrict__ info) {
+  extern __shared__ double sm[];
+  __shared__ double D[16][PS];
+  __shared__ double Di[16][PS];
+  __shared__ int bad;
+  double* Pin = sm;                    // [R][PS]
+  double* Pout = sm + (size_t)n * PS;  // [R][PS]
+  const int tid = threadIdx.x;
+  if (tid == 0) bad = 0;
+  const int nt = n / 16;
+  for (int kb = 0; kb < nt; ++kb) {
+    const int k0 = kb * 16;
+    const int R = n - k0 - 16;
+    if (tid < 256) {
+      int r = tid & 15, c = tid >> 4;
+      D[r][c] = A[(size_t)(k0 + c) * n + k0 + r];
+    }
+    __syncthreads();
+    for (int c = 0; c < 16; ++c) {
+      if (tid == 0) {
+        double d = D[c][c];
+        if (!(d > 0.0)) {
+          bad = 1;
+          d = 1.0;
+        }
+        D[c][c] = sqrt(d);
+      }
+      __syncthreads();
+      if (tid < 16 && tid > c) D[tid][c] /= D[c][c];
+      __syncthreads();
+      if (tid < 256) {
+        int r = tid & 15, cc = tid >> 4;
+        if (cc > c && r >= cc) D[r][cc] -= D[r][c] * D[cc][c];
+      }
+      __syncthreads();
+    }
+    // inverse of the lower-triangular diagonal block, one column per thread
+    if (tid < 16) {
+      int j = tid;
+      double x[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) x[i] = 0.0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        if (i == j)
+          x[i] = 1.0 / D[i][i];
+        else if (i > j) {
+          double s = 0.0;
+#pragma unroll
+          for (int q = 0; q < 16; ++q)
+            if (q >= j && q < i) s += D[i][q] * x[q];
+          x[i] = -s / D[i][i];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) Di[i][j] = x[i];
+    }
+    __syncthreads();
+    if (tid < 256) {
+      int r = tid & 15, c = tid >> 4;
+      A[(size_t)(k0 + c) * n + k0 + r] = (r >= c) ? D[r][c] : D[c][r];
+      Dinv[(size_t)kb * 256 + c * 16 + r] = Di[r][c];
+    }
+    if (R > 0) {
+      // A21 -> LDS
+      for (int e = tid; e < R * 16; e += 1024) {
+        int r = e % R, q = e / R;
+        Pin[r * PS + q] = A[(size_t)(k0 + q) * n + k0 + 16 + r];
+      }
+      __syncthreads();
+      // L21 = A21 * D^-T
+      for (int e = tid; e < R * 16; e += 1024) {
+        int r = e % R, c = e / R;
+        double s = 0.0;
+        for (int q = 0; q <= c; ++q) s += Pin[r * PS + q] * Di[c][q];
+        Pout[r * PS + c] = s;
+        A[(size_t)(k0 + c) * n + k0 + 16 + r] = s;   // L (lower)
+        A[(size_t)(k0 + 16 + r) * n + k0 + c] = s;   // L' (upper)
+      }
+      __syncthreads();
+      // trailing update of the lower triangle in 4x4 micro tiles; the triangle of ntb x ntb
+      // micro tiles is folded into an (ntb+1) x (ntb/2) rectangle
+      const int ntb = R / 4;
+      const int total = (ntb + 1) * (ntb / 2);
+      double* A22 = A + (size_t)(k0 + 16) * n + k0 + 16;
+      for (int e = tid; e < total; e += 1024) {
+        int i = e % (ntb + 1), j = e / (ntb + 1);
+        int ti, tj;
+        if (i > j) {
+          ti = i - 1;
+          tj = j;
+        } else {
+          ti = ntb - 1 - i;
+          tj = ntb - 1 - j;
+        }
+        const double* pr = Pout + (size_t)(4 * ti) * PS;
+        const double* pc = Pout + (size_t)(4 * tj) * PS;
+        double acc[4][4] = {};
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          double rv[4], cv[4];
+#pragma unroll
+          for (int x = 0; x < 4; ++x) {
+            rv[x] = pr[x * PS + q];
+            cv[x] = pc[x * PS + q];
+          }
+#pragma unroll
+          for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int y = 0; y < 4; ++y) acc[x][y] += rv[x] * cv[y];
+        }
+#pragma unroll
+        for (int y = 0; y < 4; ++y)
+#pragma unroll
+          for (int x = 0; x < 4; ++x) A22[(size_t)(4 * tj + y) * n + 4 * ti + x] -= acc[x][y];
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) *info = bad;
+}
+
+__global__ __launch_bounds__(64) void kp_trsm_kernel(const double* __restrict__ LU, const double* __restrict__ Dinv, int n,
+                                                     double* __restrict__ X) {
+  extern __shared__ double xs[];  // [n][16]  (row of the block = 16 consecutive doubles) + tmp[256]
+  double* tmp = xs + (size_t)n * 16;
+  const int lane = threadIdx.x;
+  const int cb = blockIdx.x;
+  const int nt = n / 16;
+  const int lr = lane >> 4, lc = lane & 15;
+  double* Xb = X + (size_t)cb * 16 * n;
+  // forward substitution  L Y = C
+  for (int i = 0; i < nt; ++i) {
+    double4_t acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = Xb[(size_t)lc * n + i * 16 + lr + 4 * r];
+    for (int j = 0; j < i; ++j) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        int k = j * 16 + kk * 4 + lr;
+        double av = -LU[(size_t)k * n + i * 16 + lc];
+        double bv = xs[k * 16 + lc];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tmp[(lr + 4 * r) * 16 + lc] = acc[r];
+    __syncthreads();
+    double4_t y = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      int k = kk * 4 + lr;
+      double av = Dinv[(size_t)i * 256 + k * 16 + lc];  // Dinv_i[lc][k]
+      double bv = tmp[k * 16 + lc];
+      y = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, y, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xs[(i * 16 + lr + 4 * r) * 16 + lc] = y[r];
+    __syncthreads();
+  }
+  // backward substitution  L' K = Y   (upper triangle of LU holds L')
+  for (int i = nt - 1; i >= 0; --i) {
+    double4_t acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = xs[(i * 16 + lr + 4 * r) * 16 + lc];
+    for (int j = i + 1; j < nt; ++j) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        int k = j * 16 + kk * 4 + lr;
+        double av = -LU[(size_t)k * n + i * 16 + lc];
+        double bv = xs[k * 16 + lc];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tmp[(lr + 4 * r) * 16 + lc] = acc[r];
+    __syncthreads();
+    double4_t y = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      int k = kk * 4 + lr;
+      double av = Dinv[(size_t)i * 256 + lc * 16 + k];  // (Dinv_i')[lc][k] = Dinv_i[k][lc]
+      double bv = tmp[k * 16 + lc];
+      y = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, y, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xs[(i * 16 + lr + 4 * r) * 16 + lc] = y[r];
+    __syncthreads();
+  }
+  for (int e = lane; e < n * 16; e += 64) {
+    int row = e % n, col = e / n;
+    Xb[(size_t)col * n + row] = xs[row * 16 + col];
+  }
+}
+
+// G_dev, C_dev: W x W / W x ncols column-major on the device (not modified); K_dev: W x ncols.
+int kp_chol_solve_dev(kp_ctx* ctx, double* G_dev, double* C_dev, int W, int ncols, double* K_dev) {
+  const int n = (W + 15) / 16 * 16, ncp = (ncols + 15) / 16 * 16;
+  size_t bG = (size_t)n * n * 8, bC = (size_t)n * ncp * 8, bD = (size_t)(n / 16) * 256 * 8;
+  char* ws = (char*)ctx->workspace(5, bG + bC + bD + 64);
+  if (!ws) return ctx->fail(KP_ERR_HIP, "kp_fit_solve: out of device memory");
+  double* Gp = (double*)ws;
+  double* Cp = (double*)(ws + bG);
+  double* Dinv = (double*)(ws + bG + bC);
+  int* info = (int*)(ws + bG + bC + bD);
+  size_t lds_chol = (size_t)2 * n * PS * 8;
+  size_t lds_trsm = ((size_t)n * 16 + 256) * 8;
+  if (lds_chol > 160 * 1024 - 4096 || lds_trsm > 160 * 1024) return ctx->fail(KP_ERR_ARG, "kp_fit_solve: W too large (max ~580)");
+  int64_t tot = (int64_t)n * n + (int64_t)n * ncp;
+  hipLaunchKernelGGL(kp_pad_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, G_dev, C_dev, W, ncols, n, ncp, Gp, Cp);
+  KP_HIP(ctx, hipGetLastError());
+  KP_HIP(ctx, hipFuncSetAttribute((const void*)kp_chol_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_chol));
+  hipLaunchKernelGGL(kp_chol_kernel, dim3(1), dim3(1024), lds_chol, ctx->stream, Gp, n, Dinv, info);
+  KP_HIP(ctx, hipGetLastError());
+  KP_HIP(ctx, hipFuncSetAttribute((const void*)kp_trsm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_trsm));
+  hipLaunchKernelGGL(kp_trsm_kernel, dim3(ncp / 16), dim3(64), lds_trsm, ctx->stream, Gp, Dinv, n, Cp);
+  KP_HIP(ctx, hipGetLastError());
+  hipLaunchKernelGGL(kp_unpad_kernel, dim3((unsigned)(((int64_t)W * ncols + 255) / 256)), dim3(256), 0, ctx->stream, Cp, n, W, ncols, K_dev);
+  KP_HIP(ctx, hipGetLastError());
+  return KP_OK;
+}
+
+static int check_info(kp_ctx* ctx) {
+  // info word sits behind the padded buffers of workspace 5; read it back (stream is synced by callers)
+  return KP_OK;
+}
+
+static int read_chol_info(kp_ctx* ctx, int W, int ncols, int* bad) {
+  const int n = (W + 15) / 16 * 16, ncp = (ncols + 15) / 16 * 16;
+  size_t off = (size_t)n * n * 8 + (size_t)n * ncp * 8 + (size_t)(n / 16) * 256 * 8;
+  KP_HIP(ctx, hipMemcpyAsync(bad, (char*)ctx->ws[5] + off, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  KP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  (void)check_info;
+  return KP_OK;
+}
+
+static int ensure_gc(kp_ctx* ctx, int W) {
+  size_t need = (size_t)2 * W * W * 8;
+  if (ctx->GC_bytes < need) {
+    if (ctx->GC) (void)hipFree(ctx->GC);
+    ctx->GC = nullptr;
+    ctx->GC_bytes = 0;
+    KP_HIP(ctx, hipMalloc((void**)&ctx->GC, need));
+    ctx->GC_bytes = need;
+  }
+  ctx->GC_W = W;
+  return KP_OK;
+}
+
+static int ensure_kres(kp_ctx* ctx, int W, int n) {
+  size_t need = (size_t)n * W * W * 8;
+  if (ctx->Kres_bytes < need) {
+    if (ctx->Kres) (void)hipFree(ctx->Kres);
+    ctx->Kres = nullptr;
+    ctx->Kres_bytes = 0;
+    KP_HIP(ctx, hipMalloc((void**)&ctx->Kres, need));
+    ctx->Kres_bytes = need;
+  }
+  ctx->Kres_W = W;
+  ctx->Kres_n = n;
+  return KP_OK;
+}
+
+extern "C" int kp_fit_gram(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* snaps, double* G, double* C) {
+  if (!ctx || !basis || !snaps) return ctx ? ctx->fail(KP_ERR_ARG, "kp_fit_gram: NULL handle") : KP_ERR_ARG;
+  KP_HIP(ctx, hipSetDevice(ctx->device));
+  const int W = basis->dev.W;
+  int rc = ensure_gc(ctx, W);
+  if (rc) return rc;
+  rc = kp_gram_launch(ctx, basis, snaps, ctx->GC);
+  if (rc) return rc;
+  size_t bW = (size_t)W * W * 8;
+  if (G) KP_HIP(ctx, hipMemcpyAsync(G, ctx->GC, bW, hipMemcpyDeviceToHost, ctx->stream));
+  if (C) KP_HIP(ctx, hipMemcpyAsync(C, ctx->GC + (size_t)W * W, bW, hipMemcpyDeviceToHost, ctx->stream));
+  KP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+  ctx->timers[0] = ms;
+  return KP_OK;
+}
+
+extern "C" int kp_fit_solve(kp_ctx* ctx, const double* G, const double* C, int W, int ncols, double* K) {
+  if (!ctx || !G || !C || !K || W < 1 || ncols < 1) return ctx ? ctx->fail(KP_ERR_ARG, "kp_fit_solve: bad argument") : KP_ERR_ARG;
+  KP_HIP(ctx, hipSetDevice(ctx->device));
+  size_t bG = (size_t)W * W * 8, bC = (size_t)W * ncols * 8;
+  char* ws = (char*)ctx->workspace(6, bG + 2 * bC);
+  if (!ws) return ctx->fail(KP_ERR_HIP, "kp_fit_solve: out of device memory");
+  double* Gd = (double*)ws;
+  double* Cd = (double*)(ws + bG);
+  double* Kd = (double*)(ws + bG + bC);
+  KP_HIP(ctx, hipMemcpyAsync(Gd, G, bG, hipMemcpyHostToDevice, ctx->stream));
+  KP_HIP(ctx, hipMemcpyAsync(Cd, C, bC, hipMemcpyHostToDevice, ctx->stream));
+  KP_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  int rc = kp_chol_solve_dev(ctx, Gd, Cd, W, ncols, Kd);
+  if (rc) return rc;
+  KP_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  KP_HIP(ctx, hipMemcpyAsync(K, Kd, bC, hipMemcpyDeviceToHost, ctx->stream));
+  int bad = 0;
+  rc = read_chol_info(ctx, W, ncols, &bad);
+  if (rc) return rc;
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+  ctx->timers[1] = ms;
+  if (bad) return ctx->fail(KP_ERR_NOT_SPD, "kp_fit_solve: Gram matrix is not numerically positive definite (rank-deficient dictionary)");
+  return KP_OK;
+}
+
+extern "C" int kp_fit(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* snaps, const double* lasso, int n_lasso,
+                      double* K_out) {
+  if (!ctx || !basis || !snaps || n_lasso < 1) return ctx ? ctx->fail(KP_ERR_ARG, "kp_fit: bad argument") : KP_ERR_ARG;
+  KP_HIP(ctx, hipSetDevice(ctx->device));
+  const int W = basis->dev.W, N = basis->dev.N;
+  int rc = ensure_gc(ctx, W);
+  if (!rc) rc = ensure_kres(ctx, W, n_lasso);
+  if (rc) return rc;
+  rc = kp_gram_launch(ctx, basis, snaps, ctx->GC);  // records ev0/ev1 around gram+reduce
+  if (rc) return rc;
+  double* Gd = ctx->GC;
+  double* Cd = ctx->GC + (size_t)W * W;
+  bool need_ls = false;
+  for (int i = 0; i < n_lasso; ++i) need_ls |= (!lasso || !(lasso[i] < 1e6));
+  int ls_index = -1;
+  // the least-squares solution is also the warm start / inactive-constraint answer of the lasso path
+  for (int i = 0; i < n_lasso; ++i) {
+    double* Ki = ctx->Kres + (size_t)i * W * W;
+    bool is_ls = (!lasso || !(lasso[i] < 1e6));  // Ksysid.m:1068 (Inf was mapped to 1e6 at :155-157)
+    if (is_ls) {
+      if (ls_index >= 0) {
+        KP_HIP(ctx, hipMemcpyAsync(Ki, ctx->Kres + (size_t)ls_index * W * W, (size_t)W * W * 8, hipMemcpyDeviceToDevice, ctx->stream));
+      } else {
+        rc = kp_chol_solve_dev(ctx, Gd, Cd, W, W, Ki);
+        if (rc) return rc;
+        ls_index = i;
+      }
+    } else {
+      int iters = 0;
+      rc = kp_lasso_dev(ctx, Gd, Cd, W, W, lasso[i] * N /* t = lasso*N, Ksysid.m:996 */, 20000, 1e-10, Ki, &iters);
+      if (rc) return rc;
+    }
+  }
+  (void)need_ls;
+  if (K_out) KP_HIP(ctx, hipMemcpyAsync(K_out, ctx->Kres, (size_t)n_lasso * W * W * 8, hipMemcpyDeviceToHost, ctx->stream));
+  int bad = 0;
+  if (ls_index >= 0) {
+    rc = read_chol_info(ctx, W, W, &bad);
+    if (rc) return rc;
+  } else {
+    KP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+  ctx->timers[0] = ms;
+  if (bad) return ctx->fail(KP_ERR_NOT_SPD, "kp_fit: Gram matrix is not numerically positive definite (rank-deficient dictionary)");
+  return KP_OK;
+}
+
+extern "C" int kp_fit_get_K(kp_ctx* ctx, int index, int W, double* K) {
+  if (!ctx || !K || index < 0 || index >= ctx->Kres_n || W != ctx->Kres_W) return ctx ? ctx->fail(KP_ERR_ARG, "kp_fit_get_K: bad argument") : KP_ERR_ARG;
+  KP_HIP(ctx, hipSetDevice(ctx->device));
+  KP_HIP(ctx, hipMemcpy(K, ctx->Kres + (size_t)index * W * W, (size_t)W * W * 8, hipMemcpyDeviceToHost));
+  return KP_OK;
+}

@@ -1,0 +1,142 @@
+// Internal declarations shared by the translation units of libkoopman_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "koopman_hip.h"
+
+#define KP_MAX_VARS 32
+
+void kp_set_global_error(const std::string& s);
+
+struct kp_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int num_cu = 0;
+  int64_t hbm_bytes = 0;
+  std::string name;
+  mutable std::string err;
+  double timers[8] = {0};
+  // growable device workspaces
+  void* ws[8] = {nullptr};
+  size_t ws_bytes[8] = {0};
+  // results of the last kp_fit
+  double* Kres = nullptr;   // n_lasso x W x W
+  size_t Kres_bytes = 0;
+  int Kres_W = 0, Kres_n = 0;
+  // last gram (device): G then C, W x W each, column-major
+  double* GC = nullptr;
+  size_t GC_bytes = 0;
+  int GC_W = 0;
+
+  int fail(int code, const std::string& s) const {
+    err = s;
+    kp_set_global_error(s);
+    return code;
+  }
+  void* workspace(int slot, size_t bytes);  // returns nullptr on failure
+};
+
+#define KP_HIP(ctx, expr)                                                                  \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess)                                                                  \
+      return (ctx)->fail(KP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));   \
+  } while (0)
+
+// Column kinds of the full basis (device table, one entry per full-basis column)
+enum : int { COL_VAR = 0, COL_MONO = 1, COL_FOURIER = 2, COL_GAUSS = 3, COL_CONST = 4 };
+
+struct ColDesc {
+  int32_t kind;
+  int32_t arg;  // VAR: variable index; MONO: row in exps; FOURIER: mixed-radix index (>=1); GAUSS: centre
+  int32_t aux;  // FOURIER: degree
+  int32_t pad;
+};
+
+// Device view of a dictionary, passed by value to kernels.
+struct BasisDev {
+  int model_type, nzeta, m, nvars;
+  int nfull, N, W, k_pcs;
+  const ColDesc* cols;    // nfull
+  const uint8_t* exps;    // n_mono x nvars
+  const double* centres;  // n_gauss x nvars (centre-major)
+  const double* pcs;      // nfull x k_pcs column-major
+};
+
+struct kp_basis {
+  kp_ctx* ctx = nullptr;
+  BasisDev dev{};
+  void* d_cols = nullptr;
+  void* d_exps = nullptr;
+  void* d_centres = nullptr;
+  void* d_pcs = nullptr;
+  int max_degree = 0;
+};
+
+struct kp_snapshots {
+  kp_ctx* ctx = nullptr;
+  int64_t Ns = 0;
+  int nzeta = 0, m = 0;
+  double* alpha = nullptr;  // Ns x nzeta col-major
+  double* beta = nullptr;
+  double* u = nullptr;      // Ns x m
+};
+
+// --- device helpers shared by the lift and gram kernels -----------------------------
+
+// Value of full-basis column `c` at the point whose variables are v[0..nvars) (stride vs).
+__device__ __forceinline__ double kp_eval_col(const BasisDev& b, const ColDesc c, const double* v, int vs) {
+  switch (c.kind) {
+    case COL_VAR:
+      return v[c.arg * vs];
+    case COL_MONO: {
+      const uint8_t* e = b.exps + (size_t)c.arg * b.nvars;
+      double p = 1.0;
+      for (int i = 0; i < b.nvars; ++i) {
+        int ei = e[i];
+        if (ei) {
+          double x = v[i * vs];
+          for (int k = 0; k < ei; ++k) p *= x;
+        }
+      }
+      return p;
+    }
+    case COL_FOURIER: {
+      // index = sum_i digit_i * radix^(nvars-1-i); digit 0 -> 1, 2j-1 -> cos(2 pi j x), 2j -> sin(2 pi j x)
+      int radix = 2 * c.aux + 1;
+      int idx = c.arg;
+      double p = 1.0;
+      for (int i = b.nvars - 1; i >= 0; --i) {
+        int d = idx % radix;
+        idx /= radix;
+        if (d) {
+          int j = (d + 1) >> 1;
+          double a = 2.0 * 3.14159265358979323846 * (double)j * v[i * vs];
+          p *= (d & 1) ? cos(a) : sin(a);
+        }
+      }
+      return p;
+    }
+    case COL_GAUSS: {
+      const double* ctr = b.centres + (size_t)c.arg * b.nvars;
+      double r2 = 0.0;
+      for (int i = 0; i < b.nvars; ++i) {
+        double d = v[i * vs] - ctr[i];
+        r2 += d * d;
+      }
+      return exp(-r2);
+    }
+    default:
+      return 1.0;
+  }
+}
+
+// host-side launchers implemented in the .hip files
+int kp_gram_launch(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* s, double* GC_dev);
+int kp_chol_solve_dev(kp_ctx* ctx, double* G_dev, double* C_dev, int W, int ncols, double* K_dev);
+int kp_lasso_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, int W, int ncols, double t,
+                 int max_iter, double tol, double* K_dev, int* iters);

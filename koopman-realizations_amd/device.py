@@ -1,0 +1,218 @@
+"""Thin object wrappers over the C ABI handles (kp_ctx, kp_basis, kp_snapshots, kp_mpc).
+
+Host-side plumbing only: argument marshalling (column-major f64) and handle lifetime.
+All arithmetic of the hot path happens inside libkoopman_hip.so on the GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi as F
+
+
+class Context:
+    """kp_ctx: one per process/GPU (one process per GPU in multi-GPU runs)."""
+
+    def __init__(self, device_id: int = 0):
+        self._h = F.vp()
+        F.check(F.lib().kp_create(int(device_id), C.byref(self._h)))
+        self.device_id = device_id
+
+    @property
+    def handle(self):
+        return self._h
+
+    def info(self):
+        name = C.create_string_buffer(256)
+        ncu = C.c_int()
+        hbm = C.c_int64()
+        F.check(F.lib().kp_device_info(self._h, name, 256, C.byref(ncu), C.byref(hbm)), self._h)
+        return {"name": name.value.decode(), "num_cu": ncu.value, "hbm_bytes": hbm.value}
+
+    def timer(self, which: int) -> float:
+        ms = C.c_double()
+        F.check(F.lib().kp_timer_get(self._h, which, C.byref(ms)), self._h)
+        return ms.value
+
+    def stream(self):
+        return F.lib().kp_stream(self._h)
+
+    def close(self):
+        if self._h:
+            F.lib().kp_destroy(self._h)
+            self._h = F.vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- stateless entry points ----------------------------------------------------
+    def fit_solve(self, G, Cm):
+        """K = G \\ C by Cholesky on the device (normal equations of Ksysid.m:1069)."""
+        G = F.fcol(G); Cm = F.fcol(Cm)
+        W, nc = G.shape[0], Cm.shape[1]
+        K = np.zeros((W, nc), order="F")
+        F.check(F.lib().kp_fit_solve(self._h, F.dptr(G), F.dptr(Cm), W, nc, F.dptr(K)), self._h)
+        return K
+
+    def fit_lasso(self, G, Cm, t, max_iter=20000, tol=1e-10):
+        G = F.fcol(G); Cm = F.fcol(Cm)
+        W, nc = G.shape[0], Cm.shape[1]
+        K = np.zeros((W, nc), order="F")
+        it = C.c_int()
+        F.check(F.lib().kp_fit_lasso(self._h, F.dptr(G), F.dptr(Cm), W, nc, float(t), int(max_iter), float(tol),
+                                     F.dptr(K), C.byref(it)), self._h)
+        return K, it.value
+
+    def model_project(self, K, G, Cm, N, m):
+        K = F.fcol(K); G = F.fcol(G); Cm = F.fcol(Cm)
+        A = np.zeros((N, N), order="F"); B = np.zeros((N, m), order="F"); M = np.zeros((N, N), order="F")
+        F.check(F.lib().kp_model_project(self._h, F.dptr(K), F.dptr(G), F.dptr(Cm), N, m, F.dptr(A), F.dptr(B), F.dptr(M)),
+                self._h)
+        return A, B, M
+
+    def rollout(self, model_type, A, B, z0, U, n_out):
+        """Batched rollouts: A (batch,N,N), B (batch,N,mb), z0 (batch,N), U (batch,T,m) -> Y (batch,T,n_out)."""
+        A = np.asarray(A, dtype=np.float64); B = np.asarray(B, dtype=np.float64)
+        z0 = np.asarray(z0, dtype=np.float64); U = np.asarray(U, dtype=np.float64)
+        single = A.ndim == 2
+        if single:
+            A, B, z0, U = A[None], B[None], z0[None], U[None]
+        batch, N = A.shape[0], A.shape[1]
+        T, m = U.shape[1], U.shape[2]
+        Ac = np.ascontiguousarray(np.transpose(A, (0, 2, 1)))  # each matrix column-major
+        Bc = np.ascontiguousarray(np.transpose(B, (0, 2, 1)))
+        Uc = np.ascontiguousarray(np.transpose(U, (0, 2, 1)))
+        Y = np.zeros((batch, n_out, T))
+        F.check(F.lib().kp_rollout(self._h, F.MODEL[model_type], batch, F.dptr(Ac), F.dptr(Bc), N, m,
+                                   F.dptr(np.ascontiguousarray(z0)), F.dptr(Uc), T, n_out, F.dptr(Y)), self._h)
+        Y = np.transpose(Y, (0, 2, 1))
+        return Y[0] if single else Y
+
+    def qp_solve(self, H, f, A, b):
+        """quadprog_gurobi(H,f,A,b) shim: NaN vector on failure (quadprog_gurobi.m:22-23)."""
+        H = F.fcol(H); A = F.fcol(A)
+        f = np.ascontiguousarray(f, dtype=np.float64); b = np.ascontiguousarray(b, dtype=np.float64)
+        n, mr = H.shape[0], A.shape[0]
+        x = np.zeros(n)
+        st = C.c_int()
+        F.check(F.lib().kp_qp_solve(self._h, F.dptr(H), F.dptr(f), F.dptr(A), F.dptr(b), n, mr, F.dptr(x), C.byref(st)),
+                self._h)
+        return x, st.value
+
+
+class Basis:
+    """kp_basis built from a host-side dictionary description (see basis.py)."""
+
+    def __init__(self, ctx: Context, model_type, nzeta, m, blocks, pcs=None):
+        """blocks: list of ('poly', exps[rows,nvars] uint8) | ('fourier', deg) | ('gaussian', centres[nvars,k])."""
+        self.ctx = ctx
+        nvars = nzeta + (m if model_type == "nonlinear" else 0)
+        btype, bcount, exps, centres = [], [], [], []
+        for kind, arg in blocks:
+            btype.append(F.BLOCK[kind])
+            if kind == "poly":
+                e = np.ascontiguousarray(arg, dtype=np.uint8).reshape(-1, nvars)
+                bcount.append(e.shape[0]); exps.append(e)
+            elif kind == "fourier":
+                bcount.append(int(arg))
+            else:
+                c = np.asarray(arg, dtype=np.float64).reshape(nvars, -1)
+                bcount.append(c.shape[1]); centres.append(np.ascontiguousarray(c.T))  # centre-major
+        self._bt = np.array(btype, dtype=np.int32); self._bc = np.array(bcount, dtype=np.int32)
+        self._ex = np.ascontiguousarray(np.vstack(exps)) if exps else np.zeros((0, nvars), np.uint8)
+        self._ce = np.ascontiguousarray(np.vstack(centres)) if centres else np.zeros((0, nvars))
+        self._pcs = None if pcs is None else F.fcol(pcs)
+        d = F.KpBasisDesc()
+        d.model_type, d.nzeta, d.m, d.n_blocks = F.MODEL[model_type], nzeta, m, len(blocks)
+        d.block_type = self._bt.ctypes.data_as(C.POINTER(C.c_int32))
+        d.block_count = self._bc.ctypes.data_as(C.POINTER(C.c_int32))
+        d.poly_exps = self._ex.ctypes.data_as(C.POINTER(C.c_uint8))
+        d.gauss_centres = F.dptr(self._ce)
+        d.k_pcs = 0 if pcs is None else self._pcs.shape[1]
+        d.pcs = F.dptr(self._pcs)
+        self._h = F.vp()
+        F.check(F.lib().kp_basis_create(ctx.handle, C.byref(d), C.byref(self._h)), ctx.handle)
+        nv, nf, N, W = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        F.check(F.lib().kp_basis_dims(self._h, C.byref(nv), C.byref(nf), C.byref(N), C.byref(W)))
+        self.nvars, self.nfull, self.N, self.W = nv.value, nf.value, N.value, W.value
+        self.model_type, self.nzeta, self.m = model_type, nzeta, m
+
+    @property
+    def handle(self):
+        return self._h
+
+    def lift(self, what, zeta, u=None):
+        zeta = F.fcol(np.atleast_2d(zeta))
+        rows = zeta.shape[0]
+        uu = None if u is None else F.fcol(np.atleast_2d(u))
+        width = {F.LIFT_FULL: self.nfull, F.LIFT_ECON: self.N, F.LIFT_ROW: self.W}[what]
+        out = np.zeros((rows, width), order="F")
+        F.check(F.lib().kp_lift(self.ctx.handle, self._h, what, F.dptr(zeta), F.dptr(uu), rows, F.dptr(out)),
+                self.ctx.handle)
+        return out
+
+    def close(self):
+        if self._h:
+            F.lib().kp_basis_destroy(self._h)
+            self._h = F.vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Snapshots:
+    """kp_snapshots: snapshot pairs resident in HBM."""
+
+    def __init__(self, ctx: Context, alpha, beta, u):
+        self.ctx = ctx
+        a = F.fcol(alpha); b = F.fcol(beta); uu = F.fcol(u)
+        self.Ns, self.nzeta, self.m = a.shape[0], a.shape[1], uu.shape[1]
+        self._h = F.vp()
+        F.check(F.lib().kp_snapshots_upload(ctx.handle, F.dptr(a), F.dptr(b), F.dptr(uu), self.Ns, self.nzeta, self.m,
+                                            C.byref(self._h)), ctx.handle)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def close(self):
+        if self._h:
+            F.lib().kp_snapshots_destroy(self._h)
+            self._h = F.vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def fit_gram(ctx: Context, basis: Basis, snaps: Snapshots, fetch=True):
+    W = basis.W
+    if not fetch:
+        F.check(F.lib().kp_fit_gram(ctx.handle, basis.handle, snaps.handle, None, None), ctx.handle)
+        return None, None
+    G = np.zeros((W, W), order="F"); Cm = np.zeros((W, W), order="F")
+    F.check(F.lib().kp_fit_gram(ctx.handle, basis.handle, snaps.handle, F.dptr(G), F.dptr(Cm)), ctx.handle)
+    return G, Cm
+
+
+def fit(ctx: Context, basis: Basis, snaps: Snapshots, lasso=None, fetch=True):
+    """get_Koopman on resident snapshots for each lasso value (None/inf/>=1e6 => least squares)."""
+    if lasso is None:
+        lasso = [np.inf]
+    las = np.ascontiguousarray(np.atleast_1d(np.asarray(lasso, dtype=np.float64)))
+    W = basis.W
+    K = np.zeros((len(las), W, W)) if fetch else None  # each W x W block column-major
+    F.check(F.lib().kp_fit(ctx.handle, basis.handle, snaps.handle, F.dptr(las), len(las), F.dptr(K)), ctx.handle)
+    if not fetch:
+        return None
+    return [np.asfortranarray(K[i].T) for i in range(len(las))]

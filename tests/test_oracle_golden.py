@@ -1,0 +1,117 @@
+"""CPU tests: the oracle against the reference's own stored artefacts (golden vectors) and
+its mathematical pins.  No GPU needed."""
+import numpy as np
+import pytest
+
+from oracle import koopman_oracle as ko
+
+
+def test_partitions_order_matches_reference_documentation():
+    # partitions.m:206-219 order; SURVEY appendix A: n=3, d=2
+    e = ko.partitions_ones(2, 3)
+    assert e.tolist() == [[2, 0, 0], [1, 1, 0], [0, 2, 0], [1, 0, 1], [0, 1, 1], [0, 0, 2]]
+    e = ko.poly_exponents(6, 3)
+    assert e.shape == (83, 6)                      # N = C(9,3) = 84 with the constant (Ksysid.m:641)
+    assert (e[:6] == np.eye(6, dtype=int)).all()   # first nzeta monomials are zeta (Ksysid.m:488)
+    assert e[6].tolist() == [2, 0, 0, 0, 0, 0] and e[7].tolist() == [1, 1, 0, 0, 0, 0]
+    for nv, d in [(1, 13), (2, 4), (9, 3)]:
+        assert ko.poly_exponents(nv, d).shape[0] == np.prod(np.arange(nv + 1, nv + d + 1)) // np.prod(np.arange(1, d + 1)) - 1
+
+
+def test_scale_and_pairs_match_arm_file(arm):
+    # factors and the 11 999 pairs of the shipped arm data file
+    np.testing.assert_allclose(arm["scale"]["u_factor"], [2.8108652, 2.80934499, 2.802723], rtol=1e-8)
+    np.testing.assert_allclose(arm["scale"]["y_factor"][:2], [0.33333333, 0.3193511], rtol=1e-7)
+    assert arm["pairs"]["alpha"].shape == (11999, 6)
+    assert np.abs(arm["scaled"]["y"]).max() <= 1 + 1e-12
+
+
+@pytest.mark.parametrize("which", ["bilin", "lin"])
+def test_econ_lift_reproduces_stored_Z(arm, golden, which):
+    """Golden vector: res_bilin.Z / res_lin.Z (300x34) = lift.econ_full(scaledown.y(Y(k,:)))
+    stored by Ksim.run_trial_mpc (Ksim.m:256).  Pins scaling, pair selection, monomial
+    order, pca (incl. sign convention and the 99 % cut) and the econ lift."""
+    r = golden["arm_blockM"]
+    dic = ko.build_dictionary("bilinear" if which == "bilin" else "linear", 6, 3, ["poly"], [3], arm["pairs"], dim_red=True)
+    assert dic.pcs.shape == (84, 27) and dic.N == 34
+    Z = ko.econ_full(dic, ko.scaledown(arm["scale"], "y", r[which + "_Y"][:300]))
+    assert np.abs(Z - r[which + "_Z"]).max() < 5e-14
+
+
+def test_nonlinear_dictionary_width_matches_stored_Z(arm, golden):
+    dn = ko.build_dictionary("nonlinear", 6, 3, ["poly"], [3], arm["pairs"], dim_red=True)
+    assert dn.basis.nfull == 220 and dn.N == int(golden["arm_blockM"]["nonlin_Zwidth"]) == 88
+
+
+def test_px_layouts():
+    rng = np.random.default_rng(1)
+    z = rng.uniform(-1, 1, (5, 2)); u = rng.uniform(-1, 1, (5, 2))
+    for mt in ("linear", "bilinear", "nonlinear"):
+        dic = ko.build_dictionary(mt, 2, 2, ["poly"], [2])
+        P = ko.lift_rows(dic, z, u)
+        assert P.shape == (5, dic.W)
+        if mt == "bilinear":   # [psi, u1 psi, u2 psi]  Ksysid.m:510-511
+            N = dic.N
+            np.testing.assert_allclose(P[:, N:2 * N], P[:, :N] * u[:, [0]])
+            np.testing.assert_allclose(P[:, 2 * N:], P[:, :N] * u[:, [1]])
+            assert np.all(P[:, N - 1] == 1)
+        if mt == "linear":
+            np.testing.assert_allclose(P[:, -2:], u)
+        if mt == "nonlinear":  # psi over [zeta;u]
+            np.testing.assert_allclose(P[:, :4], np.hstack([z, u]))
+
+
+def test_fourier_and_gaussian_blocks():
+    rng = np.random.default_rng(2)
+    V = rng.uniform(-1, 1, (4, 2))
+    c = rng.uniform(-1, 1, (2, 3))
+    b = ko.make_basis(2, ["fourier", "gaussian"], [1, 3], [c])
+    Pf = ko.lift_full(b, V)
+    assert Pf.shape == (4, 2 + 8 + 3 + 1)
+    # kron(poop(:,1), poop(:,2)) with poop = [1; cos; sin], minus the leading 1 (Ksysid.m:718-724)
+    c1, s1 = np.cos(2 * np.pi * V[:, 0]), np.sin(2 * np.pi * V[:, 0])
+    c2, s2 = np.cos(2 * np.pi * V[:, 1]), np.sin(2 * np.pi * V[:, 1])
+    exp = np.stack([c2, s2, c1, c1 * c2, c1 * s2, s1, s1 * c2, s1 * s2], axis=1)
+    np.testing.assert_allclose(Pf[:, 2:10], exp, atol=1e-15)
+    np.testing.assert_allclose(Pf[:, 10], np.exp(-((V - c[:, 0]) ** 2).sum(axis=1)))
+
+
+def test_ls_fit_recovers_exact_linear_system():
+    rng = np.random.default_rng(3)
+    A = rng.standard_normal((3, 3)) * 0.3; B = rng.standard_normal((3, 2))
+    x = rng.uniform(-1, 1, (400, 3)); u = rng.uniform(-1, 1, (400, 2))
+    y = x @ A.T + u @ B.T
+    dic = ko.build_dictionary("linear", 3, 2, ["poly"], [1])
+    koop = ko.get_koopman(dic, {"alpha": x, "beta": y, "u": u})
+    mdl = ko.get_model(dic, koop, 3)
+    np.testing.assert_allclose(mdl["A_raw"][:3, :3], A, atol=1e-10)
+    np.testing.assert_allclose(mdl["B_raw"][:3], B, atol=1e-10)
+    np.testing.assert_allclose(mdl["M"] @ mdl["A_raw"], mdl["A"])
+
+
+def test_lasso_inactive_equals_ls_and_active_is_kkt():
+    rng = np.random.default_rng(4)
+    P = rng.standard_normal((200, 6)); Y = P @ rng.standard_normal((6, 6)) * 0.5 + 0.01 * rng.standard_normal((200, 6))
+    G, C = ko.gram(P, Y)
+    Kls = np.linalg.solve(G, C)
+    K = ko.koopman_lasso(G, C, np.abs(Kls).sum() * 2)
+    np.testing.assert_allclose(K, Kls, atol=1e-9)
+    t = np.abs(Kls).sum() * 0.5
+    K = ko.koopman_lasso(G, C, t)
+    assert abs(np.abs(K).sum() - t) < 1e-9
+    assert ko.lasso_kkt_residual(G, C, K, t) < 1e-8
+
+
+def test_qp_oracle_kkt_on_random_problems():
+    rng = np.random.default_rng(0)
+    for _ in range(100):
+        n = rng.integers(2, 31); mr = rng.integers(1, 100)
+        M = rng.standard_normal((n, n)); H = M @ M.T + 0.1 * np.eye(n); f = rng.standard_normal(n) * 3
+        A = rng.standard_normal((mr, n)); x0 = rng.standard_normal(n); b = A @ x0 + rng.random(mr) * 0.5
+        b[0] = A[0] @ x0
+        A = np.vstack([A, A[:2], -A[:1], np.zeros((1, n))]); b = np.concatenate([b, b[:2], -b[:1], [0.0]])
+        x, lam, ok = ko.qp_solve(H, f, A, b)
+        assert ok and ko.qp_kkt_residual(H, f, A, b, x, lam) < 1e-8
+    # infeasible -> NaN (quadprog_gurobi.m:22-23)
+    x, lam, ok = ko.qp_solve(np.eye(2), np.zeros(2), np.array([[1.0, 0], [-1.0, 0]]), np.array([-1.0, -1.0]))
+    assert not ok and np.isnan(x).all()
