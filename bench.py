@@ -1,0 +1,152 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the Koopman hot path on MI355X.
+
+Metric (BASELINE.json): EDMD snapshot-pairs/s (+ MPC steps/s reported beside it) for the
+3-link-arm bilinear model.  Workload at N=1 = BASELINE configs[1]: bilinear Koopman fit,
+poly degree 3 (N=84, W=336), 1e5 synthetic snapshot pairs, one MI355X.  A "step" is one
+complete fit (fused lift+Gram kernel, partial reduction, Cholesky solve -> K) of the
+resident snapshot matrix.  Inputs are uploaded to HBM before the timed region.
+
+Multi-GPU (N>1): one process per GPU; every rank fits its own snapshot matrix of the same
+shape (the units of the reference's sweeps are independent fits: lasso grid
+Ksysid.m:1372-1387, evaluate_rand_models.m:45-144) => weak scaling, no data-path
+collective; one RCCL all_gather of the resulting K matrices closes the timed region.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F64_MFMA_TFLOPS = 78.6   # MI355X FP64 matrix (vendor datasheet; the guide lists no f64 row)
+PEAK_HBM_GBS = 8000.0
+
+
+def synth_pairs(Ns, nz=6, m=3, seed=0):
+    rng = np.random.default_rng(seed)
+    alpha = rng.uniform(-1, 1, (Ns, nz)); u = rng.uniform(-1, 1, (Ns, m))
+    Mx = rng.standard_normal((nz + m, nz)) * 0.3
+    beta = np.clip(alpha + 0.05 * np.tanh(np.hstack([alpha, u]) @ Mx), -1, 1)
+    return alpha, beta, u
+
+
+def cpu_baseline(Ns_sample, degree):
+    """The oracle's restatement of get_Koopman (lift of every row + `\\`) on the host cores,
+    on a bounded sample of the same workload."""
+    from oracle import koopman_oracle as ko
+    alpha, beta, u = synth_pairs(Ns_sample, seed=123)
+    pairs = {"alpha": alpha, "beta": beta, "u": u}
+    dic = ko.build_dictionary("bilinear", 6, 3, ["poly"], [degree])
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        ko.get_koopman(dic, pairs)
+        reps += 1
+        if time.perf_counter() - t0 > 10.0 or reps >= 5:
+            break
+    dt = (time.perf_counter() - t0) / reps
+    try:
+        import threadpoolctl
+        cores = max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()] + [1])
+    except Exception:
+        cores = os.cpu_count()
+    return {"value": Ns_sample / dt, "unit": "snapshot-pairs/s", "cores": int(cores), "kind": "port",
+            "sample": f"{reps} x get_Koopman (numpy lift + LAPACK lstsq) on {Ns_sample} pairs, W=336, {dt*1e3:.0f} ms each"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--snapshots", type=int, default=100000)
+    ap.add_argument("--degree", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import koopman_realizations_amd as kra
+    from koopman_realizations_amd import _ffi as F
+
+    ctx = kra.Context(local_rank)
+    Ns = args.snapshots
+    alpha, beta, u = synth_pairs(Ns, seed=rank)
+    basis = kra.Basis(ctx, "bilinear", 6, 3, [("poly", kra.poly_exponent_table(6, args.degree)[6:])])
+    snaps = kra.Snapshots(ctx, alpha, beta, u)      # resident in HBM before timing
+    W = basis.W
+
+    def barrier():
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        kra.fit(ctx, basis, snaps, fetch=False)
+    t_gram, t_red, t_solve = [], [], []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        kra.fit(ctx, basis, snaps, fetch=False)     # synchronises the library stream
+        t_gram.append(ctx.timer(0)); t_red.append(ctx.timer(6)); t_solve.append(ctx.timer(1))
+    if dist is not None:
+        import torch
+        K = np.zeros((W, W), order="F")
+        F.check(F.lib().kp_fit_get_K(ctx.handle, 0, W, F.dptr(K)), ctx.handle)
+        Kt = torch.from_numpy(K).cuda()
+        out = [torch.empty_like(Kt) for _ in range(world)]
+        dist.all_gather(out, Kt)                    # the sweep's only collective: final gather
+        torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        flops_pair = W * (W + 1) + 2.0 * W * W                 # F(336) = 339 024
+        g_ms = float(np.mean(t_gram))
+        achieved = flops_pair * Ns / (g_ms * 1e-3) / 1e12
+        res = {
+            "metric": "EDMD snapshot-pairs/sec (bilinear fit, 3-link arm, poly-3)",
+            "value": world * Ns * args.steps / dt,
+            "unit": "snapshot-pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"bilinear Koopman fit, poly degree {args.degree}, {Ns} synthetic snapshot pairs per GPU, "
+                                   f"N={basis.N}, W={W} (BASELINE configs[1])",
+                       "snapshots_per_gpu": Ns, "W": W, "parallelism": f"{world} independent fits + final all_gather"},
+            "kernel_ms": {"gram": g_ms, "gram_reduce": float(np.mean(t_red)), "solve": float(np.mean(t_solve))},
+            "roofline": {"bound": "mfma", "kernel": "kp_gram_kernel", "achieved": achieved, "peak": PEAK_F64_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_F64_MFMA_TFLOPS, "traffic": None,
+                         "hbm_algorithmic_GBs": 120.0 * Ns / (g_ms * 1e-3) / 1e9},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline(min(Ns, 20000), args.degree)
+        print(json.dumps(res))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

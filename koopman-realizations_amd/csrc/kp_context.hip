@@ -1,4 +1,5 @@
 // Context, dictionary upload, snapshot upload and the standalone lift kernel.
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <mutex>
@@ -45,6 +46,7 @@ extern "C" int kp_create(int device_id, kp_ctx** out) {
     delete c;
     return KP_ERR_HIP;
   }
+  for (int i = 0; i < 6; ++i) (void)hipEventCreate(&c->evp[i]);
   hipDeviceProp_t p;
   if (hipGetDeviceProperties(&p, device_id) == hipSuccess) {
     c->num_cu = p.multiProcessorCount;
@@ -63,6 +65,8 @@ extern "C" int kp_destroy(kp_ctx* c) {
     if (c->ws[i]) (void)hipFree(c->ws[i]);
   if (c->Kres) (void)hipFree(c->Kres);
   if (c->GC) (void)hipFree(c->GC);
+  for (int i = 0; i < 6; ++i)
+    if (c->evp[i]) (void)hipEventDestroy(c->evp[i]);
   (void)hipEventDestroy(c->ev0);
   (void)hipEventDestroy(c->ev1);
   (void)hipStreamDestroy(c->stream);
@@ -155,6 +159,38 @@ extern "C" int kp_basis_create(kp_ctx* ctx, const kp_basis_desc* d, kp_basis** o
   kp_basis* b = new kp_basis();
   b->ctx = ctx;
   b->max_degree = max_deg;
+  // recipes of the fused Gram kernel's fast lift: column = product of <= 4 entries x_v^e of a
+  // power table, id = v*D + (e-1), 255 = the constant 1
+  {
+    int D = 1;
+    for (size_t i = 0; i < (size_t)n_mono * nvars; ++i) D = std::max(D, (int)d->poly_exps[i]);
+    bool fast = (nvars * D <= 254);
+    std::vector<uint32_t> rec(cols.size(), 0xffffffffu);
+    for (size_t c = 0; c < cols.size() && fast; ++c) {
+      uint32_t r = 0xffffffffu;
+      int nf = 0;
+      if (cols[c].kind == COL_VAR) {
+        r = (r & ~0xffu) | (uint32_t)(cols[c].arg * D);
+      } else if (cols[c].kind == COL_MONO) {
+        const uint8_t* e = d->poly_exps + (size_t)cols[c].arg * nvars;
+        for (int v = 0; v < nvars; ++v)
+          if (e[v]) {
+            if (nf == 4) { fast = false; break; }
+            r = (r & ~(0xffu << (8 * nf))) | ((uint32_t)(v * D + e[v] - 1) << (8 * nf));
+            ++nf;
+          }
+      } else if (cols[c].kind != COL_CONST) {
+        fast = false;
+      }
+      rec[c] = r;
+    }
+    b->fast = fast;
+    b->pow_depth = D;
+    if (fast) {
+      int rc0 = upload(ctx, &b->d_recipes, rec.data(), rec.size() * 4);
+      if (rc0) { delete b; return rc0; }
+    }
+  }
   BasisDev& v = b->dev;
   v.model_type = d->model_type;
   v.nzeta = d->nzeta;
@@ -192,6 +228,8 @@ extern "C" int kp_basis_destroy(kp_basis* b) {
   if (b->d_exps) (void)hipFree(b->d_exps);
   if (b->d_centres) (void)hipFree(b->d_centres);
   if (b->d_pcs) (void)hipFree(b->d_pcs);
+  if (b->d_recipes) (void)hipFree(b->d_recipes);
+  kp_gram_plan_free(b->plan);
   delete b;
   return KP_OK;
 }

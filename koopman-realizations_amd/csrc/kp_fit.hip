@@ -274,6 +274,14 @@ static int read_chol_info(kp_ctx* ctx, int W, int ncols, int* bad) {
   return KP_OK;
 }
 
+// timers: 0 = fused lift+Gram kernel, 6 = partial-tile reduction, 1 = solve (when run)
+static void collect_gram_timers(kp_ctx* ctx, bool solved) {
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, ctx->evp[0], ctx->evp[1]) == hipSuccess) ctx->timers[0] = ms;
+  if (hipEventElapsedTime(&ms, ctx->evp[1], ctx->evp[2]) == hipSuccess) ctx->timers[6] = ms;
+  if (solved && hipEventElapsedTime(&ms, ctx->evp[2], ctx->evp[3]) == hipSuccess) ctx->timers[1] = ms;
+}
+
 static int ensure_gc(kp_ctx* ctx, int W) {
   size_t need = (size_t)2 * W * W * 8;
   if (ctx->GC_bytes < need) {
@@ -313,9 +321,7 @@ extern "C" int kp_fit_gram(kp_ctx* ctx, const kp_basis* basis, const kp_snapshot
   if (G) KP_HIP(ctx, hipMemcpyAsync(G, ctx->GC, bW, hipMemcpyDeviceToHost, ctx->stream));
   if (C) KP_HIP(ctx, hipMemcpyAsync(C, ctx->GC + (size_t)W * W, bW, hipMemcpyDeviceToHost, ctx->stream));
   KP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  float ms = 0;
-  (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
-  ctx->timers[0] = ms;
+  collect_gram_timers(ctx, false);
   return KP_OK;
 }
 
@@ -379,6 +385,7 @@ extern "C" int kp_fit(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* sn
     }
   }
   (void)need_ls;
+  KP_HIP(ctx, hipEventRecord(ctx->evp[3], ctx->stream));
   if (K_out) KP_HIP(ctx, hipMemcpyAsync(K_out, ctx->Kres, (size_t)n_lasso * W * W * 8, hipMemcpyDeviceToHost, ctx->stream));
   int bad = 0;
   if (ls_index >= 0) {
@@ -387,9 +394,7 @@ extern "C" int kp_fit(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* sn
   } else {
     KP_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
-  float ms = 0;
-  (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
-  ctx->timers[0] = ms;
+  collect_gram_timers(ctx, true);
   if (bad) return ctx->fail(KP_ERR_NOT_SPD, "kp_fit: Gram matrix is not numerically positive definite (rank-deficient dictionary)");
   return KP_OK;
 }

@@ -13,6 +13,9 @@
 
 #include "kp_internal.h"
 
+#ifndef KP_ABLATE
+#define KP_ABLATE 0
+#endif
 #define KT 8  // snapshots per LDS tile (two k-steps of the 16x16x4 MFMA)
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
@@ -26,46 +29,47 @@ struct GramArgs {
   int Wp;               // padded row length of the Psi tiles (doubles), == 16 (mod 32)
   int nsuper;           // workgroups per snapshot split
   int ktiles_per_split; // KT-snapshot tiles per split
+  int D;                // depth of the power table (max exponent), >= 1
+  int pcs_in_lds;       // copy the pcs matrix into LDS
+  const uint32_t* recipes;  // [nfull] 4 x 8-bit factor ids (fast path)
   const uint32_t* desc; // [nsuper*4][NACC]  a_off | b_off << 16  (doubles, rel. to buffer)
   const int* tile_out;  // [nsuper*4][NACC]  output tile id or -1
   double* part;         // [nsplit][ntile_out][4][64]
   int ntile_out;
 };
 
-// LDS carve-up (doubles)
+// LDS carve-up (in doubles)
 struct GramLds {
-  int raw;      // [2][nrawrows][KT]
+  int pow;      // [2][nrawrows][D][KT] power table x^e (e = 1..D) of the raw variables
+  int ones;     // [KT] ones
+  int rec;      // [nfull] recipes (uint32, two per double)
+  int pcs;      // [k_pcs][nfull] (optional)
   int full;     // [2 sides][nfull][KT]   (only with pcs)
   int psi;      // [2][2 sides][KT][Wp]
   int total;
 };
 
-static __host__ __device__ inline GramLds gram_lds(const BasisDev& b, int Wp) {
+static __host__ __device__ inline GramLds gram_lds(const BasisDev& b, int Wp, int D, int pcs_in_lds) {
   GramLds l;
   int nraw = 2 * (b.nzeta + b.m);
-  l.raw = 0;
-  l.full = l.raw + 2 * nraw * KT;
+  l.pow = 0;
+  l.ones = l.pow + 2 * nraw * D * KT;
+  l.rec = l.ones + KT;
+  l.pcs = l.rec + (b.nfull + 1) / 2;
+  l.full = l.pcs + (pcs_in_lds ? b.k_pcs * b.nfull : 0);
   l.psi = l.full + (b.k_pcs ? 2 * b.nfull * KT : 0);
+  l.psi = (l.psi + 1) & ~1;
   l.total = l.psi + 2 * 2 * KT * Wp;
   return l;
 }
 
-// Writes psi_econ column c (value val, snapshot s of side `side`) with the model-type
-// expansion of Ksysid.m:1034-1064 into the Psi tile.
-__device__ __forceinline__ void put_psi(const BasisDev& b, double* psi_side, int Wp, int s, int c, double val,
-                                        const double* uvals /* [m][KT] */) {
-  double* row = psi_side + s * Wp;
-  row[c] = val;
-  if (b.model_type == KP_MODEL_BILINEAR) {
-    for (int i = 0; i < b.m; ++i) row[(i + 1) * b.N + c] = val * uvals[i * KT + s];
-  }
-}
-
-template <int NACC>
+// FAST: every full-basis column is a product of <= 4 powers of single variables (monomial
+// dictionaries): value = prod_f pow[id_f], ids packed in a 32-bit recipe (255 = 1.0).
+template <int NACC, bool FAST>
 __global__ __launch_bounds__(256, 1) void kp_gram_kernel(GramArgs a) {
   extern __shared__ double sm[];
   const BasisDev& b = a.b;
-  const GramLds L = gram_lds(b, a.Wp);
+  const GramLds L = gram_lds(b, a.Wp, a.D, a.pcs_in_lds);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -74,6 +78,7 @@ __global__ __launch_bounds__(256, 1) void kp_gram_kernel(GramArgs a) {
   const int job = super * 4 + wave;
   const int nrawrows = 2 * (b.nzeta + b.m);
   const int nzm = b.nzeta + b.m;
+  const int D = a.D;
 
   // per-tile operand offsets (doubles, relative to the Psi buffer), lane part pre-added
   const int lane_off = (lane >> 4) * a.Wp + (lane & 15);
@@ -89,63 +94,113 @@ __global__ __launch_bounds__(256, 1) void kp_gram_kernel(GramArgs a) {
 #pragma unroll
   for (int t = 0; t < NACC; ++t) acc[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
 
-  // zero both Psi buffers once: padding columns [W, Wp) are never written again
+  // one-time LDS setup: zero both Psi buffers (padding columns [W, Wp) are never written
+  // again), ones row, recipes, pcs
   for (int e = tid; e < 2 * 2 * KT * a.Wp; e += 256) sm[L.psi + e] = 0.0;
+  if (tid < KT) sm[L.ones + tid] = 1.0;
+  uint32_t* rec = (uint32_t*)(sm + L.rec);
+  if (FAST)
+    for (int e = tid; e < b.nfull; e += 256) rec[e] = a.recipes[e];
+  if (a.pcs_in_lds)
+    for (int e = tid; e < b.k_pcs * b.nfull; e += 256) sm[L.pcs + e] = b.pcs[e];
+  const double* pcs = a.pcs_in_lds ? (const double*)(sm + L.pcs) : b.pcs;
 
   const int64_t kt0 = (int64_t)split * a.ktiles_per_split;
   const int64_t ktiles_total = (a.Ns + KT - 1) / KT;
   int nkt = (int)max((int64_t)0, min((int64_t)a.ktiles_per_split, ktiles_total - kt0));
 
-  // raw tile loader: thread e < nrawrows*KT handles (row r, snapshot s)
+  // raw tile loader: thread e < nrawrows*KT handles (row r, snapshot s);
+  // rows: [alpha(nzeta) u(m) | beta(nzeta) u(m)]
+  const bool is_loader = tid < nrawrows * KT;
+  const int lr_ = tid / KT, lsn = tid % KT;
+  const double* lsrc = nullptr;
+  if (is_loader) {
+    int rr = lr_ % nzm;
+    lsrc = rr < b.nzeta ? ((lr_ < nzm ? a.alpha : a.beta) + (int64_t)rr * a.Ns) : (a.u + (int64_t)(rr - b.nzeta) * a.Ns);
+  }
   auto load_raw = [&](int64_t kt) -> double {
-    if (tid >= nrawrows * KT) return 0.0;
-    int r = tid / KT, s = tid % KT;
-    int64_t i = kt * KT + s;
-    if (i >= a.Ns) return 0.0;
-    int rr = r % nzm;          // rows: [alpha(nzeta) u(m) | beta(nzeta) u(m)]
-    const double* src = rr < b.nzeta ? ((r < nzm ? a.alpha : a.beta) + (int64_t)rr * a.Ns) : (a.u + (int64_t)(rr - b.nzeta) * a.Ns);
-    return src[i];
+    int64_t i = kt * KT + lsn;
+    return (is_loader && i < a.Ns) ? lsrc[i] : 0.0;
   };
-  auto store_raw = [&](int buf, double v) {
-    if (tid < nrawrows * KT) sm[L.raw + buf * nrawrows * KT + tid] = v;
+  auto store_raw = [&](int buf, double x) {   // powers x^1..x^D
+    if (is_loader) {
+      double* dst = sm + L.pow + ((buf * nrawrows + lr_) * D) * KT + lsn;
+      double p = x;
+      for (int e = 0; e < D; ++e) {
+        dst[e * KT] = p;
+        p *= x;
+      }
+    }
   };
 
-  // lift of one KT tile from raw buffer rb into Psi buffer pb
+  // lift of one KT tile from power-table buffer rb into Psi buffer pb
   const int jl = tid & 15, combo = tid >> 4, ls = combo & (KT - 1), lside = combo >> 3;
   auto lift_tile = [&](int rb, int pb, int64_t kt) {
-    const double* raw = sm + L.raw + rb * nrawrows * KT;
-    const double* vars = raw + lside * nzm * KT;   // this side's variables, stride KT
-    const double* uvals = raw + b.nzeta * KT;
-    double* psi_side = sm + L.psi + (pb * 2 + lside) * KT * a.Wp;
+    const double* tab = sm + L.pow + rb * nrawrows * D * KT;
+    const double* side_tab = tab + lside * nzm * D * KT + ls;     // + id*KT -> x_v^e of this side / snapshot
+    const double* ones = sm + L.ones;
+    double* psi_row = sm + L.psi + (pb * 2 + lside) * KT * a.Wp + ls * a.Wp;
     const bool valid = (kt * KT + ls) < a.Ns;
-    if (b.k_pcs == 0) {
-      for (int c = jl; c < b.nfull; c += 16) {
-        double val = valid ? kp_eval_col(b, b.cols[c], vars + ls, KT) : 0.0;
-        put_psi(b, psi_side, a.Wp, ls, c, val, uvals);
+    double uv[4] = {0.0, 0.0, 0.0, 0.0};
+    const bool bil = b.model_type == KP_MODEL_BILINEAR;
+    if (bil && b.m <= 4) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (i < b.m) uv[i] = tab[(b.nzeta + i) * D * KT + ls];
+    }
+    auto eval_full = [&](int c) -> double {
+      if (FAST) {
+        uint32_t r = rec[c];
+        double v = 1.0;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          uint32_t id = (r >> (8 * f)) & 255u;
+          const double* src = id == 255u ? ones : side_tab + id * KT;
+          v *= *src;
+        }
+        return v;
+      } else {
+        // generic columns (fourier, gaussian, high-factor monomials): variables are the e = 1 entries
+        return kp_eval_col(b, b.cols[c], side_tab, D * KT);
       }
+    };
+    auto put = [&](int c, double val) {
+      psi_row[c] = val;
+      if (bil) {
+        if (b.m <= 4) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (i < b.m) psi_row[(i + 1) * b.N + c] = val * uv[i];
+        } else {
+          for (int i = 0; i < b.m; ++i) psi_row[(i + 1) * b.N + c] = val * tab[(b.nzeta + i) * D * KT + ls];
+        }
+      }
+    };
+    if (b.k_pcs == 0) {
+      for (int c = jl; c < b.nfull; c += 16) put(c, valid ? eval_full(c) : 0.0);
     } else {
       double* full = sm + L.full + lside * b.nfull * KT;
-      for (int c = jl; c < b.nfull; c += 16) full[c * KT + ls] = valid ? kp_eval_col(b, b.cols[c], vars + ls, KT) : 0.0;
+      for (int c = jl; c < b.nfull; c += 16) full[c * KT + ls] = valid ? eval_full(c) : 0.0;
       __syncthreads();
       for (int c = jl; c < b.N; c += 16) {
         double val;
         if (c < b.nvars)
-          val = vars[c * KT + ls];
+          val = side_tab[c * D * KT];
         else if (c < b.nvars + b.k_pcs) {
-          const double* pc = b.pcs + (size_t)(c - b.nvars) * b.nfull;
+          const double* pc = pcs + (size_t)(c - b.nvars) * b.nfull;
           val = 0.0;
           for (int i = 0; i < b.nfull; ++i) val += pc[i] * full[i * KT + ls];
         } else
           val = 1.0;
-        put_psi(b, psi_side, a.Wp, ls, c, valid ? val : 0.0, uvals);
+        put(c, valid ? val : 0.0);
       }
     }
     if (b.model_type == KP_MODEL_LINEAR) {  // [psi , u]
-      for (int i = jl; i < b.m; i += 16) psi_side[ls * a.Wp + b.N + i] = valid ? uvals[i * KT + ls] : 0.0;
+      for (int i = jl; i < b.m; i += 16) psi_row[b.N + i] = valid ? tab[(b.nzeta + i) * D * KT + ls] : 0.0;
     }
   };
 
-  // prologue: raw tile 0 -> LDS, lift it, raw tile 1 -> LDS
+  // prologue: raw tile 0 -> power table, lift it, raw tile 1 -> power table
   store_raw(0, load_raw(kt0));
   __syncthreads();
   if (nkt > 0) lift_tile(0, 0, kt0);
@@ -156,9 +211,12 @@ __global__ __launch_bounds__(256, 1) void kp_gram_kernel(GramArgs a) {
     // (1) prefetch raw tile t+2 into a register
     double rawreg = load_raw(kt0 + t + 2);
     // (2) lift tile t+1 into the other Psi buffer
+#if KP_ABLATE != 1
     if (t + 1 < nkt) lift_tile((t + 1) & 1, (t + 1) & 1, kt0 + t + 1);
+#endif
     // (3) MFMA over tile t
     const double* P = sm + L.psi + (t & 1) * 2 * KT * a.Wp;
+#if KP_ABLATE != 2
     {
       // software-pipelined operand fetch: LDS reads run PF MFMAs ahead of their use
       constexpr int NM = (KT / 4) * NACC;
@@ -180,7 +238,8 @@ __global__ __launch_bounds__(256, 1) void kp_gram_kernel(GramArgs a) {
         acc[i % NACC] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bv[i], acc[i % NACC], 0, 0, 0);
       }
     }
-    // (4) raw tile t+2 -> raw buffer t&1 (last read while lifting tile t)
+#endif
+    // (4) raw tile t+2 -> power-table buffer t&1 (last read while lifting tile t)
     store_raw(t & 1, rawreg);
     __syncthreads();
   }
@@ -222,19 +281,28 @@ __global__ __launch_bounds__(256) void kp_gram_reduce_kernel(const double* __res
   }
 }
 
-struct GramPlan {
-  int nt, Wp, nacc, njobs, nsuper, ntile_out;
-  std::vector<uint32_t> desc;
-  std::vector<int> tile_out, tile_info;
+// Host plan: tile -> wave assignment and device tables, built once per dictionary.
+struct kp_gram_plan {
+  int nt = 0, Wp = 0, nacc = 0, njobs = 0, nsuper = 0, ntile_out = 0;
+  char* tab = nullptr;   // device: desc | tile_out | tile_info
+  size_t off_to = 0, off_ti = 0;
+  bool attr_set = false;
 };
 
-static void make_plan(int W, GramPlan& p) {
-  p.nt = (W + 15) / 16;
-  int wp = p.nt * 16;
+void kp_gram_plan_free(kp_gram_plan* p) {
+  if (!p) return;
+  if (p->tab) (void)hipFree(p->tab);
+  delete p;
+}
+
+static int make_plan(kp_ctx* ctx, int W, kp_gram_plan** out) {
+  kp_gram_plan* p = new kp_gram_plan();
+  p->nt = (W + 15) / 16;
+  int wp = p->nt * 16;
   while (wp % 32 != 16) wp += 16;  // conflict-free ds_read_b64 of rows k, k+1
-  p.Wp = wp;
-  int ntile = p.nt * (p.nt + 1) / 2 + p.nt * p.nt;
-  p.ntile_out = ntile;
+  p->Wp = wp;
+  int ntile = p->nt * (p->nt + 1) / 2 + p->nt * p->nt;
+  p->ntile_out = ntile;
   static const int cand[] = {8, 16, 24, 28, 32};
   int best = 8;
   long best_cost = -1;
@@ -245,47 +313,81 @@ static void make_plan(int W, GramPlan& p) {
       best = c;
     }
   }
-  p.nacc = best;
-  p.nsuper = (ntile + 4 * best - 1) / (4 * best);
-  p.njobs = p.nsuper * 4;
-  p.desc.assign((size_t)p.njobs * best, 0u);
-  p.tile_out.assign((size_t)p.njobs * best, -1);
-  p.tile_info.clear();
+  p->nacc = best;
+  p->nsuper = (ntile + 4 * best - 1) / (4 * best);
+  p->njobs = p->nsuper * 4;
+  std::vector<uint32_t> desc((size_t)p->njobs * best, 0u);
+  std::vector<int> tile_out((size_t)p->njobs * best, -1), tile_info;
   int id = 0;
   auto push = [&](int kind, int tr, int tc) {
     uint32_t a_off = (uint32_t)(tr * 16);
-    uint32_t b_off = (uint32_t)((kind ? KT * p.Wp : 0) + tc * 16);
+    uint32_t b_off = (uint32_t)((kind ? KT * p->Wp : 0) + tc * 16);
     // deal tiles round-robin over jobs so every wave carries the same load
-    int job = id % p.njobs, slot = id / p.njobs;
-    p.desc[(size_t)job * best + slot] = a_off | (b_off << 16);
-    p.tile_out[(size_t)job * best + slot] = id;
-    p.tile_info.push_back(kind);
-    p.tile_info.push_back(tr);
-    p.tile_info.push_back(tc);
+    int job = id % p->njobs, slot = id / p->njobs;
+    desc[(size_t)job * best + slot] = a_off | (b_off << 16);
+    tile_out[(size_t)job * best + slot] = id;
+    tile_info.push_back(kind);
+    tile_info.push_back(tr);
+    tile_info.push_back(tc);
     ++id;
   };
-  for (int tr = 0; tr < p.nt; ++tr)
-    for (int tc = tr; tc < p.nt; ++tc) push(0, tr, tc);
-  for (int tr = 0; tr < p.nt; ++tr)
-    for (int tc = 0; tc < p.nt; ++tc) push(1, tr, tc);
+  for (int tr = 0; tr < p->nt; ++tr)
+    for (int tc = tr; tc < p->nt; ++tc) push(0, tr, tc);
+  for (int tr = 0; tr < p->nt; ++tr)
+    for (int tc = 0; tc < p->nt; ++tc) push(1, tr, tc);
+  size_t b_desc = desc.size() * 4, b_to = tile_out.size() * 4, b_ti = tile_info.size() * 4;
+  p->off_to = b_desc;
+  p->off_ti = b_desc + b_to;
+  hipError_t e = hipMalloc((void**)&p->tab, b_desc + b_to + b_ti);
+  if (e == hipSuccess) e = hipMemcpy(p->tab, desc.data(), b_desc, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(p->tab + p->off_to, tile_out.data(), b_to, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(p->tab + p->off_ti, tile_info.data(), b_ti, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    kp_gram_plan_free(p);
+    return ctx->fail(KP_ERR_HIP, std::string("kp_fit_gram: plan upload: ") + hipGetErrorString(e));
+  }
+  *out = p;
+  return KP_OK;
 }
 
-template <int NACC>
-static hipError_t launch_gram(const GramArgs& a, int grid, size_t lds, hipStream_t st) {
-  hipError_t e = hipFuncSetAttribute((const void*)kp_gram_kernel<NACC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kp_gram_kernel<NACC>, dim3(grid), dim3(256), lds, st, a);
+template <int NACC, bool FAST>
+static hipError_t launch_gram(const GramArgs& a, int grid, size_t lds, hipStream_t st, bool) {
+  static size_t lds_set = 0;   // per instantiation: largest dynamic-LDS size granted so far
+  if (lds > lds_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kp_gram_kernel<NACC, FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    lds_set = lds;
+  }
+  hipLaunchKernelGGL((kp_gram_kernel<NACC, FAST>), dim3(grid), dim3(256), lds, st, a);
   return hipGetLastError();
 }
 
-int kp_gram_launch(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* s, double* GC_dev) {
+template <bool FAST>
+static hipError_t launch_gram_n(int nacc, const GramArgs& a, int grid, size_t lds, hipStream_t st, bool set_attr) {
+  switch (nacc) {
+    case 8: return launch_gram<8, FAST>(a, grid, lds, st, set_attr);
+    case 16: return launch_gram<16, FAST>(a, grid, lds, st, set_attr);
+    case 24: return launch_gram<24, FAST>(a, grid, lds, st, set_attr);
+    case 28: return launch_gram<28, FAST>(a, grid, lds, st, set_attr);
+    default: return launch_gram<32, FAST>(a, grid, lds, st, set_attr);
+  }
+}
+
+int kp_gram_launch(kp_ctx* ctx, const kp_basis* basis_c, const kp_snapshots* s, double* GC_dev) {
+  kp_basis* basis = const_cast<kp_basis*>(basis_c);
   const BasisDev& b = basis->dev;
   if (s->nzeta != b.nzeta || s->m != b.m) return ctx->fail(KP_ERR_ARG, "kp_fit_gram: snapshot/basis dimension mismatch");
   const int W = b.W;
-  GramPlan plan;
-  make_plan(W, plan);
+  if (!basis->plan) {
+    int rc = make_plan(ctx, W, &basis->plan);
+    if (rc) return rc;
+  }
+  kp_gram_plan& plan = *basis->plan;
   if ((uint32_t)(2 * KT * plan.Wp) > 65535u) return ctx->fail(KP_ERR_ARG, "kp_fit_gram: dictionary too wide");
-  GramLds L = gram_lds(b, plan.Wp);
+  const bool fast = basis->fast;
+  const int D = fast ? basis->pow_depth : 1;
+  const int pcs_in_lds = (b.k_pcs > 0 && (size_t)b.k_pcs * b.nfull * 8 <= 40 * 1024) ? 1 : 0;
+  GramLds L = gram_lds(b, plan.Wp, D, pcs_in_lds);
   size_t lds = (size_t)L.total * sizeof(double);
   if (lds > 160 * 1024) return ctx->fail(KP_ERR_ARG, "kp_fit_gram: dictionary too wide for the LDS-staged tile (W > ~580)");
   if (2 * (b.nzeta + b.m) * KT > 256) return ctx->fail(KP_ERR_ARG, "kp_fit_gram: too many raw columns");
@@ -296,16 +398,9 @@ int kp_gram_launch(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* s, do
   if (kps < 1) kps = 1;
   nsplit = (int)std::max<int64_t>(1, (ktiles + kps - 1) / kps);
 
-  size_t b_desc = plan.desc.size() * 4, b_to = plan.tile_out.size() * 4, b_ti = plan.tile_info.size() * 4;
   size_t b_part = (size_t)nsplit * plan.ntile_out * 256 * 8;
-  char* tab = (char*)ctx->workspace(3, b_desc + b_to + b_ti);
   double* part = (double*)ctx->workspace(4, b_part);
-  if (!tab || !part) return ctx->fail(KP_ERR_HIP, "kp_fit_gram: out of device memory");
-  KP_HIP(ctx, hipMemcpyAsync(tab, plan.desc.data(), b_desc, hipMemcpyHostToDevice, ctx->stream));
-  KP_HIP(ctx, hipMemcpyAsync(tab + b_desc, plan.tile_out.data(), b_to, hipMemcpyHostToDevice, ctx->stream));
-  KP_HIP(ctx, hipMemcpyAsync(tab + b_desc + b_to, plan.tile_info.data(), b_ti, hipMemcpyHostToDevice, ctx->stream));
-  // the host vectors die at return; make sure the copies are done (small, once per call)
-  KP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (!part) return ctx->fail(KP_ERR_HIP, "kp_fit_gram: out of device memory");
 
   GramArgs a;
   a.b = b;
@@ -316,24 +411,26 @@ int kp_gram_launch(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* s, do
   a.Wp = plan.Wp;
   a.nsuper = plan.nsuper;
   a.ktiles_per_split = kps;
-  a.desc = (const uint32_t*)tab;
-  a.tile_out = (const int*)(tab + b_desc);
+  a.D = D;
+  a.pcs_in_lds = pcs_in_lds;
+  a.recipes = (const uint32_t*)basis->d_recipes;
+  a.desc = (const uint32_t*)plan.tab;
+  a.tile_out = (const int*)(plan.tab + plan.off_to);
   a.part = part;
   a.ntile_out = plan.ntile_out;
   int grid = plan.nsuper * nsplit;
   KP_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-  hipError_t e;
-  switch (plan.nacc) {
-    case 8: e = launch_gram<8>(a, grid, lds, ctx->stream); break;
-    case 16: e = launch_gram<16>(a, grid, lds, ctx->stream); break;
-    case 24: e = launch_gram<24>(a, grid, lds, ctx->stream); break;
-    case 28: e = launch_gram<28>(a, grid, lds, ctx->stream); break;
-    default: e = launch_gram<32>(a, grid, lds, ctx->stream); break;
-  }
+  KP_HIP(ctx, hipEventRecord(ctx->evp[0], ctx->stream));
+  hipError_t e = fast ? launch_gram_n<true>(plan.nacc, a, grid, lds, ctx->stream, !plan.attr_set)
+                      : launch_gram_n<false>(plan.nacc, a, grid, lds, ctx->stream, !plan.attr_set);
   KP_HIP(ctx, e);
+  plan.attr_set = true;
+  KP_HIP(ctx, hipEventRecord(ctx->evp[1], ctx->stream));
   hipLaunchKernelGGL(kp_gram_reduce_kernel, dim3(plan.ntile_out), dim3(256), 0, ctx->stream, part, nsplit, plan.ntile_out,
-                     (const int*)(tab + b_desc + b_to), W, GC_dev, GC_dev + (size_t)W * W);
+                     (const int*)(plan.tab + plan.off_ti), W, GC_dev, GC_dev + (size_t)W * W);
   KP_HIP(ctx, hipGetLastError());
   KP_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  KP_HIP(ctx, hipEventRecord(ctx->evp[2], ctx->stream));
+  ctx->gram_flops_per_pair = (double)W * (W + 1) + 2.0 * W * W;
   return KP_OK;
 }

@@ -15,11 +15,13 @@ struct kp_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t evp[6] = {nullptr};   // gram start, gram end, reduce end, solve end, spare x2
   int num_cu = 0;
   int64_t hbm_bytes = 0;
   std::string name;
   mutable std::string err;
   double timers[8] = {0};
+  double gram_flops_per_pair = 0;
   // growable device workspaces
   void* ws[8] = {nullptr};
   size_t ws_bytes[8] = {0};
@@ -67,6 +69,9 @@ struct BasisDev {
   const double* pcs;      // nfull x k_pcs column-major
 };
 
+struct kp_gram_plan;
+void kp_gram_plan_free(kp_gram_plan* p);
+
 struct kp_basis {
   kp_ctx* ctx = nullptr;
   BasisDev dev{};
@@ -74,7 +79,11 @@ struct kp_basis {
   void* d_exps = nullptr;
   void* d_centres = nullptr;
   void* d_pcs = nullptr;
+  void* d_recipes = nullptr;   // [nfull] uint32: 4 x 8-bit power-table ids (255 = 1.0)
   int max_degree = 0;
+  int pow_depth = 1;           // largest single-variable exponent
+  bool fast = false;           // every column is a product of <= 4 single-variable powers
+  kp_gram_plan* plan = nullptr;  // tile->wave plan of the fused Gram kernel (built on first use)
 };
 
 struct kp_snapshots {
