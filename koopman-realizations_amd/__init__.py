@@ -9,7 +9,9 @@ name carries a hyphen to match the reference's repository name).
 from . import _ffi
 from ._ffi import KoopmanHipError
 from .device import Basis, Context, Snapshots, fit, fit_gram
+from .device import Mpc
+from .kmpc import Kmpc, Ksim, ModelPlant
 from .ksysid import Ksysid, default_context, poly_exponent_table
 
-__all__ = ["Basis", "Context", "Snapshots", "fit", "fit_gram", "Ksysid", "KoopmanHipError", "default_context",
+__all__ = ["Basis", "Context", "Snapshots", "fit", "fit_gram", "Ksysid", "Kmpc", "Ksim", "ModelPlant", "Mpc", "KoopmanHipError", "default_context",
            "poly_exponent_table", "_ffi"]

@@ -1,0 +1,414 @@
+// Remaining rows of the fit path: L1-ball constrained least squares (solve_KoopmanQP),
+// the M-projection of get_model computed from the Grams, and batched validation rollouts.
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "kp_internal.h"
+
+// ---- small dense helpers -------------------------------------------------------------------
+// C(M x N) = alpha * op(A) * op(B) + beta * C, column-major; one thread per output element.
+// Lanes run along the rows of C, so op(A) = A reads are coalesced and B reads broadcast.
+__global__ __launch_bounds__(256) void kp_gemm_kernel(int tA, int tB, int M, int N, int K, double alpha,
+                                                      const double* __restrict__ A, int lda, const double* __restrict__ B,
+                                                      int ldb, double beta, double* __restrict__ C, int ldc) {
+  int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (int64_t)M * N) return;
+  int i = (int)(e % M), j = (int)(e / M);
+  double s = 0.0;
+  for (int k = 0; k < K; ++k) {
+    double av = tA ? A[k + (size_t)i * lda] : A[i + (size_t)k * lda];
+    double bv = tB ? B[j + (size_t)k * ldb] : B[k + (size_t)j * ldb];
+    s += av * bv;
+  }
+  double c0 = beta != 0.0 ? beta * C[i + (size_t)j * ldc] : 0.0;
+  C[i + (size_t)j * ldc] = alpha * s + c0;
+}
+
+static hipError_t gemm(hipStream_t st, int tA, int tB, int M, int N, int K, double alpha, const double* A, int lda,
+                       const double* B, int ldb, double beta, double* C, int ldc) {
+  int64_t tot = (int64_t)M * N;
+  hipLaunchKernelGGL(kp_gemm_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, tA, tB, M, N, K, alpha, A, lda, B, ldb,
+                     beta, C, ldc);
+  return hipGetLastError();
+}
+
+// ---- lasso: min 1/2 tr(K'GK) - tr(K'C)  s.t. ||vec K||_1 <= t ----------------------------------
+// Accelerated projected gradient (FISTA with gradient restart).  Projection onto the L1 ball by
+// Michelot's finite fixed-point iteration for the soft threshold (no sort).
+
+// largest eigenvalue of the symmetric PSD matrix G by power iteration (one workgroup)
+__global__ __launch_bounds__(1024) void kp_power_kernel(const double* __restrict__ G, int W, int iters, double* __restrict__ out) {
+  extern __shared__ double sm[];
+  double* v = sm;
+  double* w = sm + W;
+  __shared__ double red[1024];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < W; i += 1024) v[i] = 1.0 + 0.01 * (i % 7);
+  __syncthreads();
+  double lam = 0.0;
+  for (int it = 0; it < iters; ++it) {
+    for (int i = tid; i < W; i += 1024) {
+      double s = 0.0;
+      for (int k = 0; k < W; ++k) s += G[i + (size_t)k * W] * v[k];
+      w[i] = s;
+    }
+    __syncthreads();
+    double p = 0.0;
+    for (int i = tid; i < W; i += 1024) p += w[i] * w[i];
+    red[tid] = p;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+      if (tid < o) red[tid] += red[tid + o];
+      __syncthreads();
+    }
+    lam = sqrt(red[0]);
+    __syncthreads();
+    for (int i = tid; i < W; i += 1024) v[i] = w[i] / lam;
+    __syncthreads();
+  }
+  if (tid == 0) out[0] = lam * 1.0001;   // slight over-estimate keeps the step safe
+}
+
+struct LassoState {
+  double tk;        // FISTA momentum scalar
+  double change;    // max |K_new - K_old|
+  double kmax;      // max |K_new|
+  int restarts;
+};
+
+// One workgroup: Kn = P_ball(Y - grad / L);  restart test;  Y <- Kn + ((tk-1)/tn)(Kn - K);  K <- Kn
+__global__ __launch_bounds__(1024) void kp_lasso_step_kernel(double* __restrict__ K, double* __restrict__ Y,
+                                                             const double* __restrict__ grad, int64_t n, double invL, double t,
+                                                             LassoState* __restrict__ st) {
+  __shared__ double r1[1024];
+  __shared__ double r2[1024];
+  __shared__ double theta_sh;
+  const int tid = threadIdx.x;
+  auto reduce2 = [&](double a, double b, double& oa, double& ob) {
+    r1[tid] = a;
+    r2[tid] = b;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+      if (tid < o) {
+        r1[tid] += r1[tid + o];
+        r2[tid] += r2[tid + o];
+      }
+      __syncthreads();
+    }
+    oa = r1[0];
+    ob = r2[0];
+    __syncthreads();
+  };
+  // v = Y - grad/L  (kept in `Y` storage as a temporary is unsafe: recompute on the fly)
+  double s1 = 0.0, cnt = 0.0;
+  for (int64_t i = tid; i < n; i += 1024) s1 += fabs(Y[i] - grad[i] * invL);
+  double tot, dummy;
+  reduce2(s1, 0.0, tot, dummy);
+  double theta = 0.0;
+  if (tot > t) {
+    theta = (tot - t) / (double)n;   // Michelot: theta_{k+1} = (sum_{|v|>theta_k} |v| - t) / #{|v|>theta_k}
+    for (int it = 0; it < 200; ++it) {
+      s1 = 0.0;
+      cnt = 0.0;
+      for (int64_t i = tid; i < n; i += 1024) {
+        double a = fabs(Y[i] - grad[i] * invL);
+        if (a > theta) {
+          s1 += a;
+          cnt += 1.0;
+        }
+      }
+      double ss, cc;
+      reduce2(s1, cnt, ss, cc);
+      double nt = cc > 0.0 ? (ss - t) / cc : theta;
+      bool done = !(nt > theta);   // non-decreasing sequence; stops at the fixed point
+      theta = nt > theta ? nt : theta;
+      if (done) break;
+    }
+  }
+  if (tid == 0) theta_sh = theta;
+  __syncthreads();
+  theta = theta_sh;
+  // restart test  <Y - Kn, Kn - K> > 0, change, max
+  double dot = 0.0, chg = 0.0, kmx = 0.0;
+  for (int64_t i = tid; i < n; i += 1024) {
+    double v = Y[i] - grad[i] * invL;
+    double a = fabs(v) - theta;
+    double kn = a > 0.0 ? copysign(a, v) : 0.0;
+    dot += (Y[i] - kn) * (kn - K[i]);
+    chg = fmax(chg, fabs(kn - K[i]));
+    kmx = fmax(kmx, fabs(kn));
+  }
+  double dsum, d2;
+  reduce2(dot, 0.0, dsum, d2);
+  r1[tid] = chg;
+  r2[tid] = kmx;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if (tid < o) {
+      r1[tid] = fmax(r1[tid], r1[tid + o]);
+      r2[tid] = fmax(r2[tid], r2[tid + o]);
+    }
+    __syncthreads();
+  }
+  const double change = r1[0], kmax = r2[0];
+  const double tk = st->tk;
+  double tn = 0.5 * (1.0 + sqrt(1.0 + 4.0 * tk * tk));
+  const bool restart = dsum > 0.0;
+  if (restart) tn = 1.0;
+  const double mom = restart ? 0.0 : (tk - 1.0) / tn;
+  __syncthreads();
+  for (int64_t i = tid; i < n; i += 1024) {
+    double v = Y[i] - grad[i] * invL;
+    double a = fabs(v) - theta;
+    double kn = a > 0.0 ? copysign(a, v) : 0.0;
+    double ko = K[i];
+    Y[i] = kn + mom * (kn - ko);
+    K[i] = kn;
+  }
+  if (tid == 0) {
+    st->tk = tn;
+    st->change = change;
+    st->kmax = kmax;
+    st->restarts += restart ? 1 : 0;
+  }
+}
+
+__global__ void kp_l1norm_kernel(const double* __restrict__ K, int64_t n, double* out) {
+  __shared__ double r[256];
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 256) s += fabs(K[i]);
+  r[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) r[threadIdx.x] += r[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = r[0];
+}
+
+__global__ void kp_add_diag_kernel(double* G, int W, double v) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < W) G[i + (size_t)i * W] += v;
+}
+
+int kp_lasso_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, int W, int ncols, double t, int max_iter, double tol,
+                 double* K_dev, int* iters) {
+  const int64_t n = (int64_t)W * ncols;
+  size_t bK = (size_t)n * 8;
+  char* ws = (char*)ctx->workspace(7, 2 * bK + (size_t)W * W * 8 + 256);
+  if (!ws) return ctx->fail(KP_ERR_HIP, "kp_fit_lasso: out of device memory");
+  double* Y = (double*)ws;
+  double* grad = (double*)(ws + bK);
+  double* Gw = (double*)(ws + 2 * bK);
+  double* scal = (double*)(ws + 2 * bK + (size_t)W * W * 8);   // [0] L or l1 norm
+  LassoState* st = (LassoState*)(scal + 2);
+  hipStream_t s = ctx->stream;
+  if (iters) *iters = 0;
+  // 1. least-squares solution; if it satisfies the constraint it is the answer (the QP of
+  //    Ksysid.m:1126-1137 then has an inactive L1 row)
+  KP_HIP(ctx, hipMemcpyAsync(Gw, G_dev, (size_t)W * W * 8, hipMemcpyDeviceToDevice, s));
+  int rc = kp_chol_solve_dev(ctx, Gw, const_cast<double*>(C_dev), W, ncols, K_dev);
+  if (rc) return rc;
+  hipLaunchKernelGGL(kp_l1norm_kernel, dim3(1), dim3(256), 0, s, K_dev, n, scal);
+  double l1 = 0.0;
+  int bad = 0;
+  {
+    const int np = (W + 15) / 16 * 16, ncp = (ncols + 15) / 16 * 16;
+    size_t off = (size_t)np * np * 8 + (size_t)np * ncp * 8 + (size_t)(np / 16) * 256 * 8;
+    KP_HIP(ctx, hipMemcpyAsync(&bad, (char*)ctx->ws[5] + off, sizeof(int), hipMemcpyDeviceToHost, s));
+  }
+  KP_HIP(ctx, hipMemcpyAsync(&l1, scal, 8, hipMemcpyDeviceToHost, s));
+  KP_HIP(ctx, hipStreamSynchronize(s));
+  if (!bad && l1 <= t) return KP_OK;
+  // PSD guard of Ksysid.m:1117-1120: a non-PD Gram gets 1e-6 on the diagonal
+  if (bad) hipLaunchKernelGGL(kp_add_diag_kernel, dim3((W + 255) / 256), dim3(256), 0, s, Gw, W, 1e-6);
+  // 2. FISTA from K = 0
+  KP_HIP(ctx, hipFuncSetAttribute((const void*)kp_power_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W * 8));
+  hipLaunchKernelGGL(kp_power_kernel, dim3(1), dim3(1024), 2 * W * 8, s, Gw, W, 60, scal);
+  double L = 0.0;
+  KP_HIP(ctx, hipMemcpyAsync(&L, scal, 8, hipMemcpyDeviceToHost, s));
+  KP_HIP(ctx, hipMemsetAsync(K_dev, 0, bK, s));
+  KP_HIP(ctx, hipMemsetAsync(Y, 0, bK, s));
+  LassoState h{1.0, 1e300, 0.0, 0};
+  KP_HIP(ctx, hipMemcpyAsync(st, &h, sizeof(h), hipMemcpyHostToDevice, s));
+  KP_HIP(ctx, hipStreamSynchronize(s));
+  if (!(L > 0.0)) return ctx->fail(KP_ERR_ARG, "kp_fit_lasso: Gram matrix is zero");
+  int it = 0;
+  const int check_every = 20;
+  while (it < max_iter) {
+    for (int c = 0; c < check_every && it < max_iter; ++c, ++it) {
+      KP_HIP(ctx, hipMemcpyAsync(grad, C_dev, bK, hipMemcpyDeviceToDevice, s));
+      KP_HIP(ctx, gemm(s, 0, 0, W, ncols, W, 1.0, Gw, W, Y, W, -1.0, grad, W));   // grad = G Y - C
+      hipLaunchKernelGGL(kp_lasso_step_kernel, dim3(1), dim3(1024), 0, s, K_dev, Y, grad, n, 1.0 / L, t, st);
+    }
+    KP_HIP(ctx, hipMemcpyAsync(&h, st, sizeof(h), hipMemcpyDeviceToHost, s));
+    KP_HIP(ctx, hipStreamSynchronize(s));
+    if (h.change <= tol * std::max(1.0, h.kmax)) break;
+  }
+  if (iters) *iters = it;
+  if (it >= max_iter && !(h.change <= tol * std::max(1.0, h.kmax)))
+    return ctx->fail(KP_ERR_NOT_CONVERGED, "kp_fit_lasso: iteration cap reached");
+  return KP_OK;
+}
+
+extern "C" int kp_fit_lasso(kp_ctx* ctx, const double* G, const double* C, int W, int ncols, double t, int max_iter, double tol,
+                            double* K, int* iters) {
+  if (!ctx || !G || !C || !K || W < 1 || ncols < 1 || !(t >= 0.0)) return ctx ? ctx->fail(KP_ERR_ARG, "kp_fit_lasso: bad argument") : KP_ERR_ARG;
+  KP_HIP(ctx, hipSetDevice(ctx->device));
+  size_t bG = (size_t)W * W * 8, bC = (size_t)W * ncols * 8;
+  char* ws = (char*)ctx->workspace(6, bG + 2 * bC);
+  if (!ws) return ctx->fail(KP_ERR_HIP, "kp_fit_lasso: out of device memory");
+  double* Gd = (double*)ws;
+  double* Cd = (double*)(ws + bG);
+  double* Kd = (double*)(ws + bG + bC);
+  KP_HIP(ctx, hipMemcpyAsync(Gd, G, bG, hipMemcpyHostToDevice, ctx->stream));
+  KP_HIP(ctx, hipMemcpyAsync(Cd, C, bC, hipMemcpyHostToDevice, ctx->stream));
+  KP_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  int rc = kp_lasso_dev(ctx, Gd, Cd, W, ncols, t, max_iter > 0 ? max_iter : 20000, tol > 0 ? tol : 1e-10, Kd, iters);
+  if (rc) return rc;
+  KP_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  KP_HIP(ctx, hipMemcpyAsync(K, Kd, bC, hipMemcpyDeviceToHost, ctx->stream));
+  KP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+  ctx->timers[3] = ms;
+  return KP_OK;
+}
+
+// ---- get_model M-projection from the Grams (Ksysid.m:1206-1225) ---------------------------------
+// L = [Px U] K1 with K1 = K(:,1:N)  =>  L'L = K1' G K1,  L'R = K1' C(:,1:N);  M' = (L'L) \ (L'R);
+// A = K(1:N,1:N)', B = K(N+1:end,1:N)';  out.A = M A, out.B = M B.
+__global__ void kp_transpose_kernel(const double* __restrict__ in, int rows, int cols, int ld, double* __restrict__ out) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < (int64_t)rows * cols) {
+    int i = (int)(e % rows), j = (int)(e / rows);
+    out[j + (size_t)i * cols] = in[i + (size_t)j * ld];
+  }
+}
+
+extern "C" int kp_model_project(kp_ctx* ctx, const double* K, const double* G, const double* C, int N, int m, double* A_out,
+                                double* B_out, double* M_out) {
+  if (!ctx || !K || !G || !C || !A_out || !B_out || !M_out || N < 1 || m < 0)
+    return ctx ? ctx->fail(KP_ERR_ARG, "kp_model_project: bad argument") : KP_ERR_ARG;
+  KP_HIP(ctx, hipSetDevice(ctx->device));
+  const int W = N + m;
+  hipStream_t s = ctx->stream;
+  size_t bW = (size_t)W * W * 8, bN = (size_t)N * N * 8;
+  char* ws = (char*)ctx->workspace(6, 3 * bW + (size_t)W * N * 8 + 6 * bN + (size_t)N * m * 8 * 2 + 64);
+  if (!ws) return ctx->fail(KP_ERR_HIP, "kp_model_project: out of device memory");
+  double* Kd = (double*)ws;
+  double* Gd = Kd + (size_t)W * W;
+  double* Cd = Gd + (size_t)W * W;
+  double* T = Cd + (size_t)W * W;       // W x N : G K1
+  double* LtL = T + (size_t)W * N;      // N x N
+  double* LtR = LtL + (size_t)N * N;    // N x N
+  double* Mt = LtR + (size_t)N * N;     // N x N : M'
+  double* At = Mt + (size_t)N * N;      // N x N : A = K(1:N,1:N)'
+  double* MA = At + (size_t)N * N;
+  double* Md = MA + (size_t)N * N;
+  double* Bt = Md + (size_t)N * N;      // N x m
+  double* MB = Bt + (size_t)N * m;
+  KP_HIP(ctx, hipMemcpyAsync(Kd, K, bW, hipMemcpyHostToDevice, s));
+  KP_HIP(ctx, hipMemcpyAsync(Gd, G, bW, hipMemcpyHostToDevice, s));
+  KP_HIP(ctx, hipMemcpyAsync(Cd, C, bW, hipMemcpyHostToDevice, s));
+  KP_HIP(ctx, gemm(s, 0, 0, W, N, W, 1.0, Gd, W, Kd, W, 0.0, T, W));       // T = G K1
+  KP_HIP(ctx, gemm(s, 1, 0, N, N, W, 1.0, Kd, W, T, W, 0.0, LtL, N));      // K1' G K1
+  KP_HIP(ctx, gemm(s, 1, 0, N, N, W, 1.0, Kd, W, Cd, W, 0.0, LtR, N));     // K1' C(:,1:N)
+  int rc = kp_chol_solve_dev(ctx, LtL, LtR, N, N, Mt);                       // M' = (L'L) \ (L'R)
+  if (rc) return rc;
+  int64_t nn = (int64_t)N * N;
+  hipLaunchKernelGGL(kp_transpose_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, s, Kd, N, N, W, At);   // A = K(1:N,1:N)'
+  if (m > 0) {
+    int64_t nm = (int64_t)m * N;
+    hipLaunchKernelGGL(kp_transpose_kernel, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, s, Kd + N, m, N, W, Bt);  // B = K(N+1:end,1:N)'
+  }
+  KP_HIP(ctx, gemm(s, 1, 0, N, N, N, 1.0, Mt, N, At, N, 0.0, MA, N));      // M A = (M')' A
+  if (m > 0) KP_HIP(ctx, gemm(s, 1, 0, N, m, N, 1.0, Mt, N, Bt, N, 0.0, MB, N));
+  hipLaunchKernelGGL(kp_transpose_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, s, Mt, N, N, N, Md);
+  KP_HIP(ctx, hipGetLastError());
+  KP_HIP(ctx, hipMemcpyAsync(A_out, MA, bN, hipMemcpyDeviceToHost, s));
+  if (m > 0) KP_HIP(ctx, hipMemcpyAsync(B_out, MB, (size_t)N * m * 8, hipMemcpyDeviceToHost, s));
+  KP_HIP(ctx, hipMemcpyAsync(M_out, Md, bN, hipMemcpyDeviceToHost, s));
+  int bad = 0;
+  {
+    const int np = (N + 15) / 16 * 16;
+    size_t off = (size_t)np * np * 8 + (size_t)np * np * 8 + (size_t)(np / 16) * 256 * 8;
+    KP_HIP(ctx, hipMemcpyAsync(&bad, (char*)ctx->ws[5] + off, sizeof(int), hipMemcpyDeviceToHost, s));
+  }
+  KP_HIP(ctx, hipStreamSynchronize(s));
+  if (bad) return ctx->fail(KP_ERR_NOT_SPD, "kp_model_project: L'L is not positive definite");
+  return KP_OK;
+}
+
+// ---- batched rollouts (val_model / val_BLmodel, Ksysid.m:1678-1689, 1772-1787) -------------------
+// One workgroup per model; z lives in LDS, thread r owns row r of z+.
+__global__ __launch_bounds__(256) void kp_rollout_kernel(int bilinear, const double* __restrict__ A, const double* __restrict__ B,
+                                                         int N, int m, const double* __restrict__ z0, const double* __restrict__ U,
+                                                         int T, int n_out, double* __restrict__ Y) {
+  extern __shared__ double sm[];
+  double* z = sm;
+  double* zn = sm + N;
+  const int tid = threadIdx.x;
+  const int bidx = blockIdx.x;
+  const int mb = bilinear ? N * m : m;
+  const double* Ab = A + (size_t)bidx * N * N;
+  const double* Bb = B + (size_t)bidx * N * mb;
+  const double* Ub = U + (size_t)bidx * T * m;
+  double* Yb = Y + (size_t)bidx * T * n_out;
+  for (int r = tid; r < N; r += 256) z[r] = z0[(size_t)bidx * N + r];
+  __syncthreads();
+  for (int t = 0; t < T; ++t) {
+    for (int r = tid; r < n_out; r += 256) Yb[(size_t)r * T + t] = z[r];     // y = C z, C = [I 0] (Ksysid.m:1203)
+    if (t == T - 1) break;
+    for (int r = tid; r < N; r += 256) {
+      double s = 0.0;
+      for (int c = 0; c < N; ++c) s += Ab[r + (size_t)c * N] * z[c];
+      if (bilinear) {
+        for (int i = 0; i < m; ++i) {
+          const double* Bi = Bb + (size_t)i * N * N;
+          double q = 0.0;
+          for (int c = 0; c < N; ++c) q += Bi[r + (size_t)c * N] * z[c];
+          s += q * Ub[(size_t)i * T + t];
+        }
+      } else {
+        for (int i = 0; i < m; ++i) s += Bb[r + (size_t)i * N] * Ub[(size_t)i * T + t];
+      }
+      zn[r] = s;
+    }
+    __syncthreads();
+    for (int r = tid; r < N; r += 256) z[r] = zn[r];
+    __syncthreads();
+  }
+}
+
+extern "C" int kp_rollout(kp_ctx* ctx, int model_type, int batch, const double* A, const double* B, int N, int m, const double* z0,
+                          const double* U, int T, int n_out, double* Y) {
+  if (!ctx || !A || !B || !z0 || !U || !Y || batch < 1 || N < 1 || m < 0 || T < 1 || n_out < 1 || n_out > N)
+    return ctx ? ctx->fail(KP_ERR_ARG, "kp_rollout: bad argument") : KP_ERR_ARG;
+  if (model_type != KP_MODEL_LINEAR && model_type != KP_MODEL_BILINEAR)
+    return ctx->fail(KP_ERR_ARG, "kp_rollout: linear or bilinear models only");
+  KP_HIP(ctx, hipSetDevice(ctx->device));
+  const int bil = model_type == KP_MODEL_BILINEAR;
+  const size_t mb = bil ? (size_t)N * m : (size_t)m;
+  size_t nA = (size_t)batch * N * N, nB = (size_t)batch * N * mb, nz = (size_t)batch * N, nU = (size_t)batch * T * m,
+         nY = (size_t)batch * T * n_out;
+  double* ws = (double*)ctx->workspace(6, (nA + nB + nz + nU + nY) * 8);
+  if (!ws) return ctx->fail(KP_ERR_HIP, "kp_rollout: out of device memory");
+  double *dA = ws, *dB = dA + nA, *dz = dB + nB, *dU = dz + nz, *dY = dU + nU;
+  hipStream_t s = ctx->stream;
+  KP_HIP(ctx, hipMemcpyAsync(dA, A, nA * 8, hipMemcpyHostToDevice, s));
+  KP_HIP(ctx, hipMemcpyAsync(dB, B, nB * 8, hipMemcpyHostToDevice, s));
+  KP_HIP(ctx, hipMemcpyAsync(dz, z0, nz * 8, hipMemcpyHostToDevice, s));
+  if (nU) KP_HIP(ctx, hipMemcpyAsync(dU, U, nU * 8, hipMemcpyHostToDevice, s));
+  KP_HIP(ctx, hipEventRecord(ctx->ev0, s));
+  hipLaunchKernelGGL(kp_rollout_kernel, dim3(batch), dim3(256), (size_t)2 * N * 8, s, bil, dA, dB, N, m, dz, dU, T, n_out, dY);
+  KP_HIP(ctx, hipGetLastError());
+  KP_HIP(ctx, hipEventRecord(ctx->ev1, s));
+  KP_HIP(ctx, hipMemcpyAsync(Y, dY, nY * 8, hipMemcpyDeviceToHost, s));
+  KP_HIP(ctx, hipStreamSynchronize(s));
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+  ctx->timers[5] = ms;
+  return KP_OK;
+}

@@ -1,0 +1,805 @@
+// Per-step MPC: condensed QP assembly for the linear / bilinear Koopman model and a dense
+// strictly convex QP solve, one workgroup per problem.
+//
+// Replaces Kmpc.get_mpcInput (Kmpc.m:329-387), get_mpcInput_bilinear(_iter) (:750-904) with
+// get_costB/H/G/D_bilinear (:569-622), and the quadprog call (:383,810,883).
+//
+// Algebra: P_k = proj*A^k, Beta(z) = B*kron(I_m,z), S_k = P_k*Beta(z_k);
+// (Chat*Bhat)[i,j] = S_{i-j-1} for i > j;  H = (CB)'Q(CB) + R;  f = 2 (CB)'Q(Chat*Ahat*z - Yr).
+// The reference rebuilds the (N(Np+1)) x (m Np) matrix Bhat four times per step with dense
+// matrix powers; here P_k is precomputed once and only the nproj x m blocks S_k are formed.
+//
+// QP: Goldfarb-Idnani dual active set run by one wavefront, with the inverse of the active
+// constraints' Schur complement (N'H^-1 N)^-1 updated by bordering / deletion formulas, so an
+// iteration is O(n^2) lane-parallel work without triangular solves.
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "kp_internal.h"
+
+#define QP_MAXN 64       // variables (one wave handles <= 64)
+#define QP_MAXIT 2000
+
+struct kp_mpc {
+  kp_ctx* ctx = nullptr;
+  int model_type = 0, N = 0, m = 0, Np = 0, nproj = 0, nvar = 0, nrows = 0, mb = 0;
+  double q_run = 0, q_term = 0;
+  // device
+  double* A = nullptr;     // N x N
+  double* B = nullptr;     // N x mb
+  double* P = nullptr;     // (Np+1) x [nproj x N]  (P_k column-major nproj x N)
+  double* S0 = nullptr;    // linear model: Np x [nproj x m]
+  double* r = nullptr;     // m
+  double* Aq = nullptr;    // nrows x nvar column-major (constant: L = F, tack rows)
+  double* bq0 = nullptr;   // nrows (c and zeros for the tack rows)
+  double* Anorm = nullptr; // nrows
+  double* work = nullptr;  // per-problem QP export: Hq (nvar^2) | f (nvar)
+  size_t work_problems = 0;
+  double *d_in = nullptr, *d_out = nullptr;
+  int* d_status = nullptr;
+  size_t io_problems = 0;
+};
+
+// ---- wave-level helpers (64 lanes) -------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ void wave_argmax(double& v, int& idx) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    double ov = __shfl_xor(v, o, 64);
+    int oi = __shfl_xor(idx, o, 64);
+    if (ov > v || (ov == v && oi < idx)) {
+      v = ov;
+      idx = oi;
+    }
+  }
+}
+__device__ __forceinline__ void wave_argmin(double& v, int& idx) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    double ov = __shfl_xor(v, o, 64);
+    int oi = __shfl_xor(idx, o, 64);
+    if (ov < v || (ov == v && oi < idx)) {
+      v = ov;
+      idx = oi;
+    }
+  }
+}
+
+// LDS scratch of the QP solver (doubles): Hinv n*n | HN n*n | Sinv n*n | x,hp,r,lam,d,zd,ap,f: 8n | act: n ints
+__host__ __device__ inline int qp_lds_doubles(int n) { return 3 * n * n + 8 * n + (n + 1) / 2 + 2; }
+
+// min 1/2 x'Hq x + f'x  s.t.  A x <= b.   Hq (n x n, column-major, in LDS or global), A: mr x n
+// column-major (global), Anorm: row norms.  Executed by ONE wave (all 64 lanes must call).
+// Returns 0 on success, 1 infeasible / iteration cap / non-SPD.  x_out: n values (LDS or global).
+// Wave-local synchronisation: LDS operations of one wave complete in issue order, so lanes only
+// need the compiler not to reorder across this point (usable inside multi-wave workgroups).
+#define WSYNC()                                              \
+  do {                                                       \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   \
+    __builtin_amdgcn_wave_barrier();                         \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   \
+  } while (0)
+
+__device__ int qp_goldfarb_idnani(const double* Hq, const double* f, const double* __restrict__ A, const double* bvec,
+                                  const double* __restrict__ Anorm, int n, int mr, double* ws, double* x_out, double tol) {
+  const int lane = threadIdx.x & 63;
+  double* Hinv = ws;
+  double* HN = Hinv + n * n;
+  double* Sinv = HN + n * n;
+  double* x = Sinv + n * n;
+  double* hp = x + n;
+  double* r = hp + n;
+  double* lam = r + n;
+  double* d = lam + n;
+  double* zd = d + n;
+  double* ap = zd + n;
+  double* fl = ap + n;
+  int* act = (int*)(fl + n);
+
+  // ---- Hinv by Gauss-Jordan on [Hq] (SPD: no pivoting) ----
+  for (int e = lane; e < n * n; e += 64) Hinv[e] = Hq[e];
+  for (int e = lane; e < n; e += 64) fl[e] = f[e];
+  WSYNC();
+  int bad = 0;
+  for (int k = 0; k < n; ++k) {
+    double piv = Hinv[k + k * n];
+    if (!(piv > 0.0)) bad = 1;
+    double ip = 1.0 / piv;
+    WSYNC();
+    // in-place Gauss-Jordan step k
+    for (int e = lane; e < n * n; e += 64) {
+      int i = e % n, j = e / n;
+      if (i != k && j != k) Hinv[e] -= Hinv[i + k * n] * Hinv[k + j * n] * ip;
+    }
+    WSYNC();
+    for (int e = lane; e < n; e += 64) {
+      if (e != k) {
+        Hinv[e + k * n] *= -ip;         // column k
+        Hinv[k + e * n] *= ip;          // row k
+      }
+    }
+    if (lane == 0) Hinv[k + k * n] = ip;
+    WSYNC();
+  }
+  for (int i = lane; i < n; i += 64) {
+    double s = 0.0;
+    for (int j = 0; j < n; ++j) s += Hinv[i + j * n] * fl[j];
+    x[i] = -s;
+  }
+  WSYNC();
+
+  int q = 0;
+  int status = 1;
+  int it = bad ? QP_MAXIT : 0;   // non-SPD Hessian: report failure
+  while (it < QP_MAXIT) {
+    ++it;
+    // most violated inactive constraint (scaled by the row norm)
+    double best = -1e300;
+    int bestp = 0x7fffffff;
+    int infeas = 0;
+    for (int row = lane; row < mr; row += 64) {
+      double v = -bvec[row];
+      for (int j = 0; j < n; ++j) v += A[row + (size_t)j * mr] * x[j];
+      double nr = Anorm[row];
+      bool isact = false;
+      for (int c = 0; c < q; ++c) isact |= (act[c] == row);
+      if (nr == 0.0) {
+        if (v > tol) infeas = 1;
+        continue;
+      }
+      double vs = v / nr;
+      if (!isact && vs > best) {
+        best = vs;
+        bestp = row;
+      }
+    }
+    wave_argmax(best, bestp);
+    infeas = __any(infeas);
+    if (infeas) break;
+    if (best <= tol) {
+      status = 0;
+      break;
+    }
+    const int p = bestp;
+    const double bp = bvec[p];
+    for (int j = lane; j < n; j += 64) ap[j] = A[p + (size_t)j * mr];
+    WSYNC();
+    double app_l = 0.0;
+    for (int i = lane; i < n; i += 64) {
+      double s = 0.0;
+      for (int j = 0; j < n; ++j) s += Hinv[i + j * n] * ap[j];
+      hp[i] = s;
+      app_l += s * ap[i];
+    }
+    const double app = wave_sum(app_l);
+    WSYNC();
+    double lam_p = 0.0;
+    bool fail = false;
+    while (it < QP_MAXIT) {
+      ++it;
+      // d = N' Hinv a_p ; r = Sinv d ; zd = hp - HN r
+      for (int c = lane; c < q; c += 64) {
+        double s = 0.0;
+        for (int i = 0; i < n; ++i) s += HN[i + c * n] * ap[i];
+        d[c] = s;
+      }
+      WSYNC();
+      for (int c = lane; c < q; c += 64) {
+        double s = 0.0;
+        for (int k = 0; k < q; ++k) s += Sinv[c + k * n] * d[k];
+        r[c] = s;
+      }
+      WSYNC();
+      double apz_l = 0.0, apx_l = 0.0;
+      for (int i = lane; i < n; i += 64) {
+        double s = hp[i];
+        for (int c = 0; c < q; ++c) s -= HN[i + c * n] * r[c];
+        zd[i] = s;
+        apz_l += ap[i] * s;
+        apx_l += ap[i] * x[i];
+      }
+      const double apz = wave_sum(apz_l);
+      const double apx = wave_sum(apx_l);
+      double t1 = 1e300;
+      int l = 0x7fffffff;
+      for (int c = lane; c < q; c += 64) {
+        if (r[c] > 1e-13) {
+          double ratio = lam[c] / r[c];
+          if (ratio < t1) {
+            t1 = ratio;
+            l = c;
+          }
+        }
+      }
+      wave_argmin(t1, l);
+      const bool t2fin = apz > 1e-13 * app;
+      const double t2 = t2fin ? (apx - bp) / apz : 1e300;
+      const double t = fmin(t1, t2);
+      if (!(t < 1e299)) {
+        fail = true;
+        break;
+      }
+      WSYNC();
+      for (int c = lane; c < q; c += 64) lam[c] -= t * r[c];
+      lam_p += t;
+      if (t2fin)
+        for (int i = lane; i < n; i += 64) x[i] -= t * zd[i];
+      WSYNC();
+      if (t2 <= t1) {
+        // add p: Sinv <- bordered inverse with w = r, beta = apz (Schur complement)
+        if (q >= n) {
+          fail = true;
+          break;
+        }
+        const double ib = 1.0 / apz;
+        for (int e = lane; e < q * q; e += 64) {
+          int i = e % q, j = e / q;
+          Sinv[i + j * n] += r[i] * r[j] * ib;
+        }
+        for (int c = lane; c < q; c += 64) {
+          Sinv[c + q * n] = -r[c] * ib;
+          Sinv[q + c * n] = -r[c] * ib;
+        }
+        for (int i = lane; i < n; i += 64) HN[i + q * n] = hp[i];
+        if (lane == 0) {
+          Sinv[q + q * n] = ib;
+          act[q] = p;
+          lam[q] = lam_p;
+        }
+        ++q;
+        WSYNC();
+        break;
+      }
+      // partial step: drop active constraint l
+      {
+        const double isl = 1.0 / Sinv[l + l * n];
+        // Schur deletion on the (q x q) inverse, then compact row/col l away
+        // r reused as the scaled column l
+        for (int c = lane; c < q; c += 64) r[c] = Sinv[c + l * n];
+        WSYNC();
+        for (int e = lane; e < q * q; e += 64) {
+          int i = e % q, j = e / q;
+          if (i != l && j != l) Sinv[i + j * n] -= r[i] * r[j] * isl;
+        }
+        WSYNC();
+        // compact: move rows/cols > l up/left (serialised over columns to avoid overlap hazards)
+        for (int j = 0; j < q; ++j) {
+          if (j == l) continue;
+          int jn = j > l ? j - 1 : j;
+          double vals0 = 0.0;
+          int i = lane;  // q <= 64
+          int in_ = i > l ? i - 1 : i;
+          bool ok = i < q && i != l;
+          if (ok) vals0 = Sinv[i + j * n];
+          WSYNC();
+          if (ok) Sinv[in_ + jn * n] = vals0;
+          WSYNC();
+        }
+        for (int j = l; j + 1 < q; ++j) {
+          for (int i = lane; i < n; i += 64) HN[i + j * n] = HN[i + (j + 1) * n];
+          WSYNC();
+        }
+        if (lane == 0) {
+          for (int c = l; c + 1 < q; ++c) {
+            act[c] = act[c + 1];
+            lam[c] = lam[c + 1];
+          }
+        }
+        --q;
+        WSYNC();
+      }
+    }
+    if (fail) break;
+  }
+  WSYNC();
+  for (int i = lane; i < n; i += 64) x_out[i] = status == 0 ? x[i] : __builtin_nan("");
+  return status;
+}
+
+// ---- generic QP shim kernel -----------------------------------------------------------------
+__global__ __launch_bounds__(64) void kp_qp_kernel(const double* H, const double* f, const double* A, const double* b,
+                                                   const double* Anorm, int n, int mr, double* x, int* status) {
+  extern __shared__ double sm[];
+  int st = qp_goldfarb_idnani(H, f, A, b, Anorm, n, mr, sm, x, 1e-10);
+  if (threadIdx.x == 0) *status = st ? KP_ERR_QP_FAIL : KP_OK;
+}
+
+__global__ void kp_rownorm_kernel(const double* A, int mr, int n, double* out) {
+  int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row < mr) {
+    double s = 0.0;
+    for (int j = 0; j < n; ++j) {
+      double v = A[row + (size_t)j * mr];
+      s += v * v;
+    }
+    out[row] = sqrt(s);
+  }
+}
+
+extern "C" int kp_qp_solve(kp_ctx* ctx, const double* H, const double* f, const double* A, const double* b, int n, int mr,
+                           double* x, int* status) {
+  if (!ctx || !H || !f || !x || n < 1 || n > QP_MAXN || mr < 0 || (mr > 0 && (!A || !b)))
+    return ctx ? ctx->fail(KP_ERR_ARG, "kp_qp_solve: bad argument (n <= 64)") : KP_ERR_ARG;
+  KP_HIP(ctx, hipSetDevice(ctx->device));
+  size_t bH = (size_t)n * n * 8, bA = (size_t)mr * n * 8;
+  char* ws = (char*)ctx->workspace(7, bH + bA + (size_t)(2 * n + 2 * mr) * 8 + 64);
+  if (!ws) return ctx->fail(KP_ERR_HIP, "kp_qp_solve: out of device memory");
+  double* dH = (double*)ws;
+  double* dA = (double*)(ws + bH);
+  double* df = (double*)(ws + bH + bA);
+  double* dx = df + n;
+  double* db = dx + n;
+  double* dn = db + mr;
+  int* dst = (int*)(dn + mr);
+  KP_HIP(ctx, hipMemcpyAsync(dH, H, bH, hipMemcpyHostToDevice, ctx->stream));
+  KP_HIP(ctx, hipMemcpyAsync(df, f, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+  if (mr) {
+    KP_HIP(ctx, hipMemcpyAsync(dA, A, bA, hipMemcpyHostToDevice, ctx->stream));
+    KP_HIP(ctx, hipMemcpyAsync(db, b, (size_t)mr * 8, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(kp_rownorm_kernel, dim3((mr + 63) / 64), dim3(64), 0, ctx->stream, dA, mr, n, dn);
+  }
+  size_t lds = (size_t)qp_lds_doubles(n) * 8;
+  hipLaunchKernelGGL(kp_qp_kernel, dim3(1), dim3(64), lds, ctx->stream, dH, df, dA, db, dn, n, mr, dx, dst);
+  KP_HIP(ctx, hipGetLastError());
+  int st = 0;
+  KP_HIP(ctx, hipMemcpyAsync(x, dx, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  KP_HIP(ctx, hipMemcpyAsync(&st, dst, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  KP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (status) *status = st;
+  return KP_OK;
+}
+
+// ---- MPC setup ---------------------------------------------------------------------------------
+// P_0 = proj, P_{k+1} = P_k A   (Ahat rows of Kmpc.m:168-172 / 528-532 projected by Chat :193,540);
+// linear model: S_k = P_k B.
+__global__ __launch_bounds__(256) void kp_mpc_setup_kernel(const double* __restrict__ A, const double* __restrict__ B,
+                                                           const double* __restrict__ proj, int N, int m, int Np, int nproj,
+                                                           int linear, double* __restrict__ P, double* __restrict__ S0) {
+  const int tid = threadIdx.x;
+  for (int e = tid; e < nproj * N; e += 256) P[e] = proj[e];
+  __syncthreads();
+  for (int k = 0; k < Np; ++k) {
+    const double* Pk = P + (size_t)k * nproj * N;
+    double* Pn = P + (size_t)(k + 1) * nproj * N;
+    for (int e = tid; e < nproj * N; e += 256) {
+      int p = e % nproj, c = e / nproj;
+      double s = 0.0;
+      for (int j = 0; j < N; ++j) s += Pk[p + j * nproj] * A[j + (size_t)c * N];
+      Pn[e] = s;
+    }
+    __syncthreads();
+  }
+  if (linear) {
+    for (int e = tid; e < Np * nproj * m; e += 256) {
+      int k = e / (nproj * m), rem = e % (nproj * m), p = rem % nproj, a = rem / nproj;
+      const double* Pk = P + (size_t)k * nproj * N;
+      double s = 0.0;
+      for (int j = 0; j < N; ++j) s += Pk[p + j * nproj] * B[j + (size_t)a * N];
+      S0[e] = s;
+    }
+  }
+}
+
+struct MpcArgs {
+  BasisDev basis;   // used when zeta != nullptr (fused lift)
+  int model_type, N, m, Np, nproj, nvar, nrows, iters, has_basis;
+  double q_run, q_term;
+  const double *A, *B, *P, *S0, *r, *Aq, *bq0, *Anorm;
+  const double* z;      // [nb][N]      (or nullptr with zeta)
+  const double* zeta;   // [nb][nzeta]  (fused lift)
+  const double* u_prev; // [nb][m]
+  const double* Yr;     // [nb][nproj*(Np+1)]
+  double* U;            // [nb][nvar]   x = vec(U') : u_0 (m), u_1 (m), ...
+  double* z_out;        // [nb][N] or nullptr
+  double* qp_export;    // [nb][nvar*nvar + nvar + nrows] or nullptr
+  int* status;          // [nb]
+};
+
+// LDS (doubles): z N | beta N*m | S Np*nproj*m | e (Np+1)*nproj | Hq nvar^2 | f nvar | b nrows | zh (Np+1)*N (iters>1)
+//                | full nfull (fused lift) | qp scratch
+__host__ __device__ inline int mpc_lds_doubles(int N, int m, int Np, int nproj, int nvar, int nrows, int iters, int nfull) {
+  return N + N * m + Np * nproj * m + (Np + 1) * nproj + nvar * nvar + nvar + nrows + (iters > 1 ? (Np + 1) * N : 0) + nfull + 4 +
+         qp_lds_doubles(nvar);
+}
+
+__global__ __launch_bounds__(256) void kp_mpc_step_kernel(MpcArgs a) {
+  extern __shared__ double sm[];
+  const int tid = threadIdx.x;
+  const int pb = blockIdx.x;
+  const int N = a.N, m = a.m, Np = a.Np, nproj = a.nproj, nv = a.nvar, nr = a.nrows;
+  double* z = sm;
+  double* beta = z + N;                  // N x m  (Beta(z) = B kron(I,z), Ksysid.m:1288-1289)
+  double* S = beta + N * m;              // [Np][nproj x m]
+  double* ev = S + Np * nproj * m;       // [(Np+1)][nproj]   P_i z - Yr_i
+  double* Hq = ev + (Np + 1) * nproj;    // nv x nv  (= 2H)
+  double* f = Hq + nv * nv;
+  double* bq = f + nv;
+  double* zh = bq + nr;                  // (Np+1) x N   lifted horizon (iters > 1)
+  double* full = zh + (a.iters > 1 ? (Np + 1) * N : 0);
+  int* st_sh = (int*)(full + (a.has_basis ? a.basis.nfull : 0));   // one slot for the QP status
+  double* qpws = (double*)st_sh + 1;
+  qpws = (double*)(((uintptr_t)qpws + 15) & ~(uintptr_t)15);
+  const double* Yr = a.Yr + (size_t)pb * nproj * (Np + 1);
+  const double* up = a.u_prev + (size_t)pb * m;
+
+  // ---- lifted state (Kmpc.m:842) ----
+  if (a.has_basis) {
+    const BasisDev& b = a.basis;
+    const double* zeta = a.zeta + (size_t)pb * b.nzeta;
+    for (int c = tid; c < b.nfull; c += 256) full[c] = kp_eval_col(b, b.cols[c], zeta, 1);
+    __syncthreads();
+    for (int c = tid; c < N; c += 256) {
+      double v;
+      if (b.k_pcs == 0)
+        v = full[c];
+      else if (c < b.nvars)
+        v = zeta[c];
+      else if (c < b.nvars + b.k_pcs) {
+        const double* pc = b.pcs + (size_t)(c - b.nvars) * b.nfull;
+        v = 0.0;
+        for (int i = 0; i < b.nfull; ++i) v += pc[i] * full[i];
+      } else
+        v = 1.0;
+      z[c] = v;
+    }
+  } else {
+    for (int c = tid; c < N; c += 256) z[c] = a.z[(size_t)pb * N + c];
+  }
+  __syncthreads();
+  if (a.z_out)
+    for (int c = tid; c < N; c += 256) a.z_out[(size_t)pb * N + c] = z[c];
+
+  // constraint right-hand side: b = c (E = 0 without state bounds, Kmpc.m:862) and the
+  // "memory" rows +-u_0 <= +-u_prev (Kmpc.m:865-870)
+  for (int e = tid; e < nr; e += 256) {
+    double v = a.bq0[e];
+    int k = e - (nr - 2 * m);
+    if (k >= 0) v = k < m ? up[k] : -up[k - m];
+    bq[e] = v;
+  }
+  // e_i = P_i z - Yr_i
+  for (int e = tid; e < (Np + 1) * nproj; e += 256) {
+    int i = e / nproj, p = e % nproj;
+    const double* Pi = a.P + (size_t)i * nproj * N;
+    double s = 0.0;
+    for (int j = 0; j < N; ++j) s += Pi[p + j * nproj] * z[j];
+    ev[e] = s - Yr[e];
+  }
+  int status = 0;
+  for (int iter = 0; iter < a.iters; ++iter) {
+    // ---- S_k = P_k * Beta(z_k)  (get_costB_bilinear, Kmpc.m:578-585: block i uses z(i,:) when a
+    // horizon of lifted states is given, else z) ----
+    if (a.model_type == KP_MODEL_BILINEAR) {
+      for (int k = 0; k < Np; ++k) {
+        const double* zk = iter == 0 ? z : zh + (size_t)k * N;
+        if (iter == 0 && k > 0) break;   // same z for every block: compute Beta once
+        __syncthreads();
+        for (int e = tid; e < N * m; e += 256) {
+          int rr = e % N, i = e / N;
+          const double* Bi = a.B + (size_t)i * N * N;
+          double s = 0.0;
+          for (int c = 0; c < N; ++c) s += Bi[rr + (size_t)c * N] * zk[c];
+          beta[e] = s;
+        }
+        __syncthreads();
+        int k0 = k, k1 = iter == 0 ? Np : k + 1;
+        for (int e = tid; e < (k1 - k0) * nproj * m; e += 256) {
+          int kk = k0 + e / (nproj * m), rem = e % (nproj * m), p = rem % nproj, i = rem / nproj;
+          const double* Pk = a.P + (size_t)kk * nproj * N;
+          double s = 0.0;
+          for (int j = 0; j < N; ++j) s += Pk[p + j * nproj] * beta[j + i * N];
+          S[kk * nproj * m + rem] = s;
+        }
+      }
+    } else {
+      for (int e = tid; e < Np * nproj * m; e += 256) S[e] = a.S0[e];
+    }
+    __syncthreads();
+    // ---- Hq = 2 (CB'Q CB + R),  f = 2 CB'Q e   (Kmpc.m:604,879,883) ----
+    for (int e = tid; e < nv * nv; e += 256) {
+      int r1 = e % nv, r2 = e / nv;
+      int j1 = r1 / m, a1 = r1 % m, j2 = r2 / m, a2 = r2 % m;
+      double s = 0.0;
+      for (int i = max(j1, j2) + 1; i <= Np; ++i) {
+        double qi = i == Np ? a.q_term : a.q_run;
+        const double* S1 = S + (i - j1 - 1) * nproj * m + a1 * nproj;
+        const double* S2 = S + (i - j2 - 1) * nproj * m + a2 * nproj;
+        double t = 0.0;
+        for (int p = 0; p < nproj; ++p) t += S1[p] * S2[p];
+        s += qi * t;
+      }
+      if (r1 == r2) s += a.r[a1];
+      Hq[e] = 2.0 * s;
+    }
+    for (int e = tid; e < nv; e += 256) {
+      int j = e / m, a1 = e % m;
+      double s = 0.0;
+      for (int i = j + 1; i <= Np; ++i) {
+        double qi = i == Np ? a.q_term : a.q_run;
+        const double* S1 = S + (i - j - 1) * nproj * m + a1 * nproj;
+        double t = 0.0;
+        for (int p = 0; p < nproj; ++p) t += S1[p] * ev[i * nproj + p];
+        s += qi * t;
+      }
+      f[e] = 2.0 * s;
+    }
+    __syncthreads();
+    if (a.qp_export) {
+      double* ex = a.qp_export + (size_t)pb * (nv * nv + nv + nr);
+      for (int e = tid; e < nv * nv; e += 256) ex[e] = Hq[e];
+      for (int e = tid; e < nv; e += 256) ex[nv * nv + e] = f[e];
+      for (int e = tid; e < nr; e += 256) ex[nv * nv + nv + e] = bq[e];
+    }
+    // ---- QP by wave 0 ----
+    double* xout = a.U + (size_t)pb * nv;
+    if (tid < 64) {
+      int st = qp_goldfarb_idnani(Hq, f, a.Aq, bq, a.Anorm, nv, nr, qpws, xout, 1e-10);
+      if (tid == 0) *st_sh = st;
+    }
+    // the other waves wait here (the solver itself only uses wave-local synchronisation)
+    __syncthreads();
+    status = *st_sh;
+    if (status || iter == a.iters - 1) break;
+    // ---- lifted horizon for the next linearisation (Kmpc.m:891-895) ----
+    if (tid < 64) {
+      for (int c = tid; c < N; c += 64) zh[c] = z[c];
+    }
+    __syncthreads();
+    for (int j = 0; j < Np; ++j) {
+      const double* zj = zh + (size_t)j * N;
+      for (int e = tid; e < N; e += 256) {
+        double s = 0.0;
+        for (int c = 0; c < N; ++c) s += a.A[e + (size_t)c * N] * zj[c];
+        for (int i = 0; i < m; ++i) {
+          const double* Bi = a.B + (size_t)i * N * N;
+          double t = 0.0;
+          for (int c = 0; c < N; ++c) t += Bi[e + (size_t)c * N] * zj[c];
+          s += t * xout[j * m + i];
+        }
+        zh[(size_t)(j + 1) * N + e] = s;
+      }
+      __syncthreads();
+    }
+  }
+  if (tid == 0) a.status[pb] = status ? KP_ERR_QP_FAIL : KP_OK;
+}
+
+// ---- host API ------------------------------------------------------------------------------------
+
+static int dev_alloc_copy(kp_ctx* ctx, double** dst, const double* src, size_t n) {
+  *dst = nullptr;
+  if (!n) return KP_OK;
+  KP_HIP(ctx, hipMalloc((void**)dst, n * 8));
+  if (src) KP_HIP(ctx, hipMemcpy(*dst, src, n * 8, hipMemcpyHostToDevice));
+  return KP_OK;
+}
+
+extern "C" int kp_mpc_destroy(kp_mpc* M) {
+  if (!M) return KP_OK;
+  (void)hipSetDevice(M->ctx->device);
+  double* ptrs[] = {M->A, M->B, M->P, M->S0, M->r, M->Aq, M->bq0, M->Anorm, M->work, M->d_in, M->d_out};
+  for (double* p : ptrs)
+    if (p) (void)hipFree(p);
+  if (M->d_status) (void)hipFree(M->d_status);
+  delete M;
+  return KP_OK;
+}
+
+extern "C" int kp_mpc_create(kp_ctx* ctx, int model_type, const double* A, const double* B, int N, int m, int Np,
+                             const double* proj, int nproj, double q_run, double q_term, const double* r, const double* lo,
+                             const double* hi, double slope_lim, double smooth_lim, kp_mpc** out) {
+  if (!ctx || !out) return KP_ERR_ARG;
+  *out = nullptr;
+  if (!A || !B || !proj || !r || N < 1 || m < 1 || Np < 1 || nproj < 1)
+    return ctx->fail(KP_ERR_ARG, "kp_mpc_create: bad argument");
+  if (model_type != KP_MODEL_LINEAR && model_type != KP_MODEL_BILINEAR)
+    return ctx->fail(KP_ERR_ARG, "kp_mpc_create: model_type must be linear or bilinear (NMPC is out of scope)");
+  if ((lo == nullptr) != (hi == nullptr)) return ctx->fail(KP_ERR_ARG, "kp_mpc_create: lo and hi must both be given or both NULL");
+  const int nvar = m * Np;
+  if (nvar > QP_MAXN) return ctx->fail(KP_ERR_ARG, "kp_mpc_create: m*horizon must be <= 64");
+  KP_HIP(ctx, hipSetDevice(ctx->device));
+  const bool has_slope = !std::isnan(slope_lim) && Np >= 2, has_smooth = !std::isnan(smooth_lim) && Np >= 3;
+  // constraint rows in the order the reference stacks them (Kmpc.m:641-730, then :865-870)
+  int nb = lo ? 2 * m * (Np + 1) : 0, ns = has_slope ? 2 * m * (Np - 1) : 0, nsm = has_smooth ? 2 * m * (Np - 2) : 0;
+  const int nrows = nb + ns + nsm + 2 * m;
+  std::vector<double> Aq((size_t)nrows * nvar, 0.0), bq(nrows, 0.0);
+  auto at = [&](int row, int col) -> double& { return Aq[(size_t)col * nrows + row]; };
+  int row0 = 0;
+  if (lo) {  // Fbounds: kron(I_Np, [-I; I]) in the first 2m*Np rows, last 2m rows zero (Kmpc.m:646-663)
+    for (int j = 0; j < Np; ++j)
+      for (int i = 0; i < m; ++i) {
+        at(row0 + j * 2 * m + i, j * m + i) = -1.0;
+        bq[row0 + j * 2 * m + i] = -lo[i];
+        at(row0 + j * 2 * m + m + i, j * m + i) = 1.0;
+        bq[row0 + j * 2 * m + m + i] = hi[i];
+      }
+    row0 += nb;
+  }
+  if (has_slope) {  // [u_{j+1} - u_j ; -(u_{j+1} - u_j)] <= slope_lim   (Kmpc.m:670-688)
+    int h = m * (Np - 1);
+    for (int j = 0; j < Np - 1; ++j)
+      for (int i = 0; i < m; ++i) {
+        int rr = j * m + i;
+        at(row0 + rr, j * m + i) = -1.0;
+        at(row0 + rr, (j + 1) * m + i) = 1.0;
+        at(row0 + h + rr, j * m + i) = 1.0;
+        at(row0 + h + rr, (j + 1) * m + i) = -1.0;
+        bq[row0 + rr] = slope_lim;
+        bq[row0 + h + rr] = slope_lim;
+      }
+    row0 += ns;
+  }
+  if (has_smooth) {  // u_j - 2u_{j+1} + u_{j+2}   (Kmpc.m:694-708)
+    int h = m * (Np - 2);
+    for (int j = 0; j < Np - 2; ++j)
+      for (int i = 0; i < m; ++i) {
+        int rr = j * m + i;
+        at(row0 + rr, j * m + i) = 1.0;
+        at(row0 + rr, (j + 1) * m + i) = -2.0;
+        at(row0 + rr, (j + 2) * m + i) = 1.0;
+        at(row0 + h + rr, j * m + i) = -1.0;
+        at(row0 + h + rr, (j + 1) * m + i) = 2.0;
+        at(row0 + h + rr, (j + 2) * m + i) = -1.0;
+        bq[row0 + rr] = smooth_lim;
+        bq[row0 + h + rr] = smooth_lim;
+      }
+    row0 += nsm;
+  }
+  for (int i = 0; i < m; ++i) {  // memory rows (Kmpc.m:865): [I; -I] on u_0
+    at(row0 + i, i) = 1.0;
+    at(row0 + m + i, i) = -1.0;
+  }
+  kp_mpc* M = new kp_mpc();
+  M->ctx = ctx;
+  M->model_type = model_type;
+  M->N = N; M->m = m; M->Np = Np; M->nproj = nproj; M->nvar = nvar; M->nrows = nrows;
+  M->mb = model_type == KP_MODEL_BILINEAR ? N * m : m;
+  M->q_run = q_run; M->q_term = q_term;
+  int rc = dev_alloc_copy(ctx, &M->A, A, (size_t)N * N);
+  if (!rc) rc = dev_alloc_copy(ctx, &M->B, B, (size_t)N * M->mb);
+  if (!rc) rc = dev_alloc_copy(ctx, &M->P, nullptr, (size_t)(Np + 1) * nproj * N);
+  if (!rc) rc = dev_alloc_copy(ctx, &M->S0, nullptr, (size_t)Np * nproj * m);
+  if (!rc) rc = dev_alloc_copy(ctx, &M->r, r, m);
+  if (!rc) rc = dev_alloc_copy(ctx, &M->Aq, Aq.data(), Aq.size());
+  if (!rc) rc = dev_alloc_copy(ctx, &M->bq0, bq.data(), nrows);
+  if (!rc) rc = dev_alloc_copy(ctx, &M->Anorm, nullptr, nrows);
+  double* dproj = nullptr;
+  if (!rc) rc = dev_alloc_copy(ctx, &dproj, proj, (size_t)nproj * N);
+  if (rc) {
+    if (dproj) (void)hipFree(dproj);
+    kp_mpc_destroy(M);
+    return rc;
+  }
+  hipLaunchKernelGGL(kp_mpc_setup_kernel, dim3(1), dim3(256), 0, ctx->stream, M->A, M->B, dproj, N, m, Np, nproj,
+                     model_type == KP_MODEL_LINEAR ? 1 : 0, M->P, M->S0);
+  hipLaunchKernelGGL(kp_rownorm_kernel, dim3((nrows + 63) / 64), dim3(64), 0, ctx->stream, M->Aq, nrows, nvar, M->Anorm);
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(dproj);
+  if (e != hipSuccess) {
+    kp_mpc_destroy(M);
+    return ctx->fail(KP_ERR_HIP, std::string("kp_mpc_create: ") + hipGetErrorString(e));
+  }
+  *out = M;
+  return KP_OK;
+}
+
+extern "C" int kp_mpc_dims(const kp_mpc* M, int* nvar, int* nrows) {
+  if (!M) return KP_ERR_ARG;
+  if (nvar) *nvar = M->nvar;
+  if (nrows) *nrows = M->nrows;
+  return KP_OK;
+}
+
+static int mpc_run(kp_mpc* M, const kp_basis* basis, int nb, const double* z, const double* zeta, const double* u_prev,
+                   const double* Yr, int iters, double* U_out, double* z_out, int* status) {
+  kp_ctx* ctx = M->ctx;
+  if (nb < 1 || !u_prev || !Yr || !U_out || iters < 1 || (!z && !zeta)) return ctx->fail(KP_ERR_ARG, "kp_mpc_step: bad argument");
+  if (iters > 1 && M->model_type != KP_MODEL_BILINEAR) iters = 1;
+  KP_HIP(ctx, hipSetDevice(ctx->device));
+  const int N = M->N, m = M->m, Np = M->Np, nproj = M->nproj, nv = M->nvar, nr = M->nrows;
+  int nzeta = 0;
+  if (zeta) {
+    if (!basis) return ctx->fail(KP_ERR_ARG, "kp_mpc_step_zeta: basis required");
+    if (basis->dev.N != N || basis->dev.model_type == KP_MODEL_NONLINEAR)
+      return ctx->fail(KP_ERR_ARG, "kp_mpc_step_zeta: basis does not match the controller's model");
+    nzeta = basis->dev.nzeta;
+  }
+  const size_t n_out = (size_t)nv + N;
+  const size_t n_ex = (size_t)nv * nv + nv + nr;
+  if (M->io_problems < (size_t)nb) {
+    if (M->d_in) (void)hipFree(M->d_in);
+    if (M->d_out) (void)hipFree(M->d_out);
+    if (M->d_status) (void)hipFree(M->d_status);
+    if (M->work) (void)hipFree(M->work);
+    M->d_in = M->d_out = M->work = nullptr;
+    M->d_status = nullptr;
+    M->io_problems = 0;
+    size_t cap = (size_t)nb;
+    KP_HIP(ctx, hipMalloc((void**)&M->d_in, cap * ((size_t)std::max(N, 64) + m + (size_t)nproj * (Np + 1)) * 8));
+    KP_HIP(ctx, hipMalloc((void**)&M->d_out, cap * n_out * 8));
+    KP_HIP(ctx, hipMalloc((void**)&M->d_status, cap * sizeof(int)));
+    KP_HIP(ctx, hipMalloc((void**)&M->work, n_ex * 8));
+    M->io_problems = cap;
+  }
+  const size_t nz = zeta ? nzeta : N;
+  double* d_z = M->d_in;
+  double* d_up = d_z + (size_t)nb * nz;
+  double* d_yr = d_up + (size_t)nb * m;
+  KP_HIP(ctx, hipMemcpyAsync(d_z, zeta ? zeta : z, (size_t)nb * nz * 8, hipMemcpyHostToDevice, ctx->stream));
+  KP_HIP(ctx, hipMemcpyAsync(d_up, u_prev, (size_t)nb * m * 8, hipMemcpyHostToDevice, ctx->stream));
+  KP_HIP(ctx, hipMemcpyAsync(d_yr, Yr, (size_t)nb * nproj * (Np + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+  MpcArgs a{};
+  if (zeta) a.basis = basis->dev;
+  a.has_basis = zeta ? 1 : 0;
+  a.model_type = M->model_type; a.N = N; a.m = m; a.Np = Np; a.nproj = nproj; a.nvar = nv; a.nrows = nr; a.iters = iters;
+  a.q_run = M->q_run; a.q_term = M->q_term;
+  a.A = M->A; a.B = M->B; a.P = M->P; a.S0 = M->S0; a.r = M->r; a.Aq = M->Aq; a.bq0 = M->bq0; a.Anorm = M->Anorm;
+  a.z = zeta ? nullptr : d_z;
+  a.zeta = zeta ? d_z : nullptr;
+  a.u_prev = d_up; a.Yr = d_yr;
+  a.U = M->d_out;
+  a.z_out = M->d_out + (size_t)nb * nv;
+  a.qp_export = nb == 1 ? M->work : nullptr;
+  a.status = M->d_status;
+  size_t lds = (size_t)mpc_lds_doubles(N, m, Np, nproj, nv, nr, iters, zeta ? basis->dev.nfull : 0) * 8 + 32;
+  if (lds > 160 * 1024) return ctx->fail(KP_ERR_ARG, "kp_mpc_step: problem too large for LDS");
+  static size_t lds_set = 0;
+  if (lds > lds_set) {
+    KP_HIP(ctx, hipFuncSetAttribute((const void*)kp_mpc_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    lds_set = lds;
+  }
+  KP_HIP(ctx, hipEventRecord(ctx->evp[4], ctx->stream));
+  hipLaunchKernelGGL(kp_mpc_step_kernel, dim3(nb), dim3(256), lds, ctx->stream, a);
+  KP_HIP(ctx, hipGetLastError());
+  KP_HIP(ctx, hipEventRecord(ctx->evp[5], ctx->stream));
+  // x = [u_0; u_1; ...] (m each)  ->  U (Np x m column-major) = reshape(x,[m,Np])'  (Kmpc.m:884)
+  std::vector<double> x((size_t)nb * nv);
+  std::vector<int> st(nb);
+  KP_HIP(ctx, hipMemcpyAsync(x.data(), M->d_out, x.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+  KP_HIP(ctx, hipMemcpyAsync(st.data(), M->d_status, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  if (z_out) KP_HIP(ctx, hipMemcpyAsync(z_out, M->d_out + (size_t)nb * nv, (size_t)nb * N * 8, hipMemcpyDeviceToHost, ctx->stream));
+  KP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int p = 0; p < nb; ++p) {
+    for (int j = 0; j < Np; ++j)
+      for (int i = 0; i < m; ++i) U_out[(size_t)p * nv + (size_t)i * Np + j] = x[(size_t)p * nv + j * m + i];
+    if (status) status[p] = st[p];
+  }
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, ctx->evp[4], ctx->evp[5]) == hipSuccess) ctx->timers[2] = ms;
+  return KP_OK;
+}
+
+extern "C" int kp_mpc_step(kp_mpc* M, const double* z, const double* u_prev, const double* Yr, int iters, double* U_out,
+                           int* status) {
+  if (!M) return KP_ERR_ARG;
+  return mpc_run(M, nullptr, 1, z, nullptr, u_prev, Yr, iters, U_out, nullptr, status);
+}
+
+extern "C" int kp_mpc_step_zeta(kp_mpc* M, const kp_basis* basis, const double* zeta, const double* u_prev, const double* Yr,
+                                int iters, double* U_out, double* z_out, int* status) {
+  if (!M) return KP_ERR_ARG;
+  return mpc_run(M, basis, 1, nullptr, zeta, u_prev, Yr, iters, U_out, z_out, status);
+}
+
+extern "C" int kp_mpc_step_batch(kp_mpc* M, int nb, const double* z, const double* u_prev, const double* Yr, double* U_out,
+                                 int* status) {
+  if (!M) return KP_ERR_ARG;
+  return mpc_run(M, nullptr, nb, z, nullptr, u_prev, Yr, 1, U_out, nullptr, status);
+}
+
+extern "C" int kp_mpc_last_qp(kp_mpc* M, double* Hq, double* f, double* Aq, double* bq) {
+  if (!M || !M->work) return M ? M->ctx->fail(KP_ERR_ARG, "kp_mpc_last_qp: no single-problem step has run") : KP_ERR_ARG;
+  kp_ctx* ctx = M->ctx;
+  KP_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t nv = M->nvar, nr = M->nrows;
+  if (Hq) KP_HIP(ctx, hipMemcpy(Hq, M->work, nv * nv * 8, hipMemcpyDeviceToHost));
+  if (f) KP_HIP(ctx, hipMemcpy(f, M->work + nv * nv, nv * 8, hipMemcpyDeviceToHost));
+  if (bq) KP_HIP(ctx, hipMemcpy(bq, M->work + nv * nv + nv, nr * 8, hipMemcpyDeviceToHost));
+  if (Aq) KP_HIP(ctx, hipMemcpy(Aq, M->Aq, nr * nv * 8, hipMemcpyDeviceToHost));
+  return KP_OK;
+}

@@ -216,3 +216,77 @@ def fit(ctx: Context, basis: Basis, snaps: Snapshots, lasso=None, fetch=True):
     if not fetch:
         return None
     return [np.asfortranarray(K[i].T) for i in range(len(las))]
+
+
+class Mpc:
+    """kp_mpc: condensed MPC problem of a linear / bilinear Koopman model on the device."""
+
+    def __init__(self, ctx: Context, model_type, A, B, Np, proj, q_run, q_term, r, lo=None, hi=None,
+                 slope_lim=None, smooth_lim=None):
+        self.ctx = ctx
+        A = F.fcol(A); B = F.fcol(B); proj = F.fcol(np.atleast_2d(proj))
+        self.N, self.m, self.Np, self.nproj = A.shape[0], len(np.atleast_1d(r)), int(Np), proj.shape[0]
+        r = np.ascontiguousarray(np.atleast_1d(r), dtype=np.float64)
+        lo_ = None if lo is None else np.ascontiguousarray(lo, dtype=np.float64)
+        hi_ = None if hi is None else np.ascontiguousarray(hi, dtype=np.float64)
+        nan = float("nan")
+        self._h = F.vp()
+        F.check(F.lib().kp_mpc_create(ctx.handle, F.MODEL[model_type], F.dptr(A), F.dptr(B), self.N, self.m, self.Np,
+                                      F.dptr(proj), self.nproj, float(q_run), float(q_term), F.dptr(r), F.dptr(lo_),
+                                      F.dptr(hi_), nan if slope_lim is None else float(slope_lim),
+                                      nan if smooth_lim is None else float(smooth_lim), C.byref(self._h)), ctx.handle)
+        nv, nr = C.c_int(), C.c_int()
+        F.check(F.lib().kp_mpc_dims(self._h, C.byref(nv), C.byref(nr)))
+        self.nvar, self.nrows = nv.value, nr.value
+
+    @property
+    def handle(self):
+        return self._h
+
+    def step(self, z, u_prev, Yr, iters=1):
+        """Returns (U [Np x m], status).  U is NaN when the QP failed (quadprog_gurobi.m:22-23)."""
+        z = np.ascontiguousarray(z, dtype=np.float64); up = np.ascontiguousarray(u_prev, dtype=np.float64)
+        yr = np.ascontiguousarray(Yr, dtype=np.float64)
+        U = np.zeros((self.Np, self.m), order="F")
+        st = C.c_int()
+        F.check(F.lib().kp_mpc_step(self._h, F.dptr(z), F.dptr(up), F.dptr(yr), int(iters), F.dptr(U), C.byref(st)),
+                self.ctx.handle)
+        return U, st.value
+
+    def step_zeta(self, basis: Basis, zeta, u_prev, Yr, iters=1):
+        zeta = np.ascontiguousarray(zeta, dtype=np.float64); up = np.ascontiguousarray(u_prev, dtype=np.float64)
+        yr = np.ascontiguousarray(Yr, dtype=np.float64)
+        U = np.zeros((self.Np, self.m), order="F"); z = np.zeros(self.N)
+        st = C.c_int()
+        F.check(F.lib().kp_mpc_step_zeta(self._h, basis.handle, F.dptr(zeta), F.dptr(up), F.dptr(yr), int(iters),
+                                         F.dptr(U), F.dptr(z), C.byref(st)), self.ctx.handle)
+        return U, z, st.value
+
+    def step_batch(self, Z, U_prev, YR):
+        """Z (nb,N), U_prev (nb,m), YR (nb, nproj*(Np+1)) -> U (nb, Np, m), status (nb,)."""
+        Z = np.ascontiguousarray(Z, dtype=np.float64); UP = np.ascontiguousarray(U_prev, dtype=np.float64)
+        YR = np.ascontiguousarray(YR, dtype=np.float64)
+        nb = Z.shape[0]
+        U = np.zeros((nb, self.m, self.Np))          # each problem: Np x m column-major
+        st = np.zeros(nb, dtype=np.int32)
+        F.check(F.lib().kp_mpc_step_batch(self._h, nb, F.dptr(Z), F.dptr(UP), F.dptr(YR), F.dptr(U),
+                                          st.ctypes.data_as(F.c_ip)), self.ctx.handle)
+        return np.transpose(U, (0, 2, 1)), st
+
+    def last_qp(self):
+        """(Hq, f, Aq, bq) of the most recent single-problem step: quadprog(Hq, f, Aq, bq)."""
+        Hq = np.zeros((self.nvar, self.nvar), order="F"); f = np.zeros(self.nvar)
+        Aq = np.zeros((self.nrows, self.nvar), order="F"); bq = np.zeros(self.nrows)
+        F.check(F.lib().kp_mpc_last_qp(self._h, F.dptr(Hq), F.dptr(f), F.dptr(Aq), F.dptr(bq)), self.ctx.handle)
+        return Hq, f, Aq, bq
+
+    def close(self):
+        if self._h:
+            F.lib().kp_mpc_destroy(self._h)
+            self._h = F.vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

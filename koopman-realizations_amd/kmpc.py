@@ -1,0 +1,223 @@
+"""Host-side mirrors of the reference's `Kmpc` (Kmpc.m) and `Ksim` (Ksim.m) classes.
+
+Kmpc keeps the reference's constructor options and method signatures for the QP-based
+controllers (model_type 'linear' and 'bilinear' with mpc_type 'linear'); the per-step work —
+lift, QP assembly and QP solve — is one kernel launch in libkoopman_hip.so.
+Out of scope: mpc_type 'nonlinear' (fmincon SQP), loaded models,
+state_bounds (KP_ERR_ARG in the library).
+"""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+
+from .device import Mpc
+
+
+class Kmpc:
+    """Model predictive controller (mirror of classdef Kmpc, Kmpc.m:1)."""
+
+    def __init__(self, sysid_class, **kwargs):
+        s = sysid_class
+        self.sysid = s
+        self.ctx = s.ctx
+        self.params = s.params                      # Kmpc.m:44
+        self.model = s.model
+        self.lift = s.lift
+        self.basis = s.basis
+        self.model_type = s.model_type              # :51
+        self.loaded = s.loaded
+        # defaults (:55-72)
+        self.horizon = int(np.floor(1.0 / self.params["Ts"]))
+        self.input_bounds = None
+        self.input_slopeConst = None
+        self.input_smoothConst = None
+        self.state_bounds = None
+        self.cost_running = 0.1
+        self.cost_terminal = 100.0
+        self.cost_input = 0.0
+        self.projmtx = self.model["C"]
+        self.mpc_type = "nonlinear" if self.model_type == "nonlinear" else "linear"
+        for k, v in kwargs.items():                 # parse_args :107-113
+            if not hasattr(self, k):
+                raise AttributeError(f"unknown Kmpc property {k}")
+            setattr(self, k, v)
+        if isinstance(self.input_bounds, (list, tuple, np.ndarray)) and np.size(self.input_bounds) == 0:
+            self.input_bounds = None
+        if isinstance(self.state_bounds, (list, tuple, np.ndarray)) and np.size(self.state_bounds) == 0:
+            self.state_bounds = None
+        if self.mpc_type != "linear" or self.model_type == "nonlinear":
+            raise NotImplementedError("nonlinear MPC (fmincon SQP) is out of scope (SURVEY section 8)")
+        if self.state_bounds is not None:
+            raise NotImplementedError("state_bounds are not supported")
+        self.projmtx = np.atleast_2d(np.asarray(self.projmtx, dtype=np.float64))
+        self.expand_props()                         # :82
+        m = self.params["m"]
+        sc = self.params["scale"]
+        ci = np.asarray(self.cost_input, dtype=np.float64)
+        r = np.full(m, float(ci)) if ci.ndim == 0 else ci.reshape(-1)   # eye(m).*cost_input  :201,548
+        lo = hi = None
+        if self.input_bounds is not None:           # :247,659  scaled-down bounds
+            lo = (self.input_bounds[:, 0] - sc["u_offset"]) / sc["u_factor"]
+            hi = (self.input_bounds[:, 1] - sc["u_offset"]) / sc["u_factor"]
+        slope = None if self.input_slopeConst is None else float(self.input_slopeConst) * float(np.mean(sc["u_factor"]))  # :272,684
+        smooth = None if self.input_smoothConst is None else \
+            self.params["Ts"] ** 2 * float(self.input_smoothConst) * float(np.mean(sc["u_factor"]))                       # :294,706
+        self.dev = Mpc(self.ctx, self.model_type, self.model["A"], self.model["B"], self.horizon, self.projmtx,
+                       self.cost_running, self.cost_terminal, r, lo, hi, slope, smooth)
+
+    # ---- Kmpc.m:116-130 -------------------------------------------------------------------
+    def expand_props(self):
+        m = self.params["m"]
+        if self.input_bounds is not None:
+            b = np.atleast_2d(np.asarray(self.input_bounds, dtype=np.float64))
+            if b.shape[0] != m:
+                b = np.kron(np.ones((m, 1)), b)
+            self.input_bounds = b
+
+    # ---- Kmpc.m:135-152 --------------------------------------------------------------------
+    def _ref_index(self):
+        n = self.params["n"]
+        return np.nonzero(self.projmtx[:, :n].sum(axis=0))[0]
+
+    def scaledown_ref(self, ref):
+        idx = self._ref_index(); sc = self.params["scale"]
+        return (np.atleast_2d(ref) - sc["y_offset"][idx]) / sc["y_factor"][idx]
+
+    def scaleup_ref(self, ref_sc):
+        idx = self._ref_index(); sc = self.params["scale"]
+        return np.atleast_2d(ref_sc) * sc["y_factor"][idx] + sc["y_offset"][idx]
+
+    # ---- per-step entry points ----------------------------------------------------------------
+    def _zeta(self, traj):
+        _, zeta = self.sysid.get_zeta(traj)
+        return zeta[-1]                                               # Kmpc.m:343-344
+
+    def _pad_ref(self, ref):
+        """Kmpc.m:354-365."""
+        Np = self.horizon
+        ref = np.atleast_2d(np.asarray(ref, dtype=np.float64))
+        if ref.shape[1] != self.projmtx.shape[0]:
+            raise ValueError("Reference trajectory is not the correct dimension")
+        if ref.shape[0] > Np + 1:
+            ref = ref[:Np + 1]
+        elif ref.shape[0] < Np + 1:
+            ref = np.vstack([ref, np.tile(ref[-1], (Np + 1 - ref.shape[0], 1))])
+        return ref.reshape(-1)
+
+    def _step(self, traj, ref, iters):
+        zeta = self._zeta(traj)
+        u_prev = np.atleast_2d(traj["u"])[-1]
+        U, z, st = self.dev.step_zeta(self.sysid.basis_dev, zeta, u_prev, self._pad_ref(ref), iters)
+        return U, z                                                    # U is NaN when the QP failed
+
+    def get_mpcInput(self, traj, ref):
+        """Kmpc.m:329-387 (linear model)."""
+        return self._step(traj, ref, 1)
+
+    def get_mpcInput_bilinear(self, traj, ref):
+        """Kmpc.m:750-814."""
+        return self._step(traj, ref, 1)
+
+    def get_mpcInput_bilinear_iter(self, traj, ref, iter=1):
+        """Kmpc.m:817-904."""
+        return self._step(traj, ref, int(iter))
+
+    # ---- Kmpc.m:403-512 ---------------------------------------------------------------------------
+    def run_simulation(self, ref_y, y0=None, u0=None):
+        """Closed loop with the identified model as the plant (delays = 0)."""
+        p = self.params
+        n, m = p["n"], p["m"]
+        s = self.sysid
+        y0 = np.zeros(n) if y0 is None else np.asarray(y0, dtype=np.float64)
+        u0 = np.zeros(m) if u0 is None else np.asarray(u0, dtype=np.float64)
+        ref_sc = self.scaledown_ref(ref_y)
+        res = {"T": [0.0], "U": [u0], "Y": [y0], "K": [0], "R": [np.atleast_2d(ref_y)[0]], "Z": [], "comp_time": []}
+        k = 1
+        while k < ref_sc.shape[0]:
+            cur = {"y": s.scaledown_y(res["Y"][-1])[None, :], "u": s.scaledown_u(res["U"][-1])[None, :]}
+            refhor = ref_sc[k - 1:k + self.horizon]
+            t0 = time.perf_counter()
+            if self.model_type == "linear":
+                U, z = self.get_mpcInput(cur, refhor)
+            else:
+                U, z = self.get_mpcInput_bilinear_iter(cur, refhor, 1)
+            res["comp_time"].append(time.perf_counter() - t0)
+            if np.isnan(U).any():
+                break
+            u_k_sc = s.scaledown_u(res["U"][-1])                    # Kmpc.m:495 one-step input delay
+            if self.model_type == "linear":
+                z1 = self.model["A"] @ z + self.model["B"] @ u_k_sc
+            else:
+                z1 = self.model["A"] @ z + self.model["Beta"](z) @ u_k_sc
+            res["T"].append(k * p["Ts"]); res["U"].append(s.scaleup_u(U[1])); res["Y"].append(s.scaleup_y(self.model["C"] @ z1))
+            res["K"].append(k); res["R"].append(self.scaleup_ref(ref_sc[k - 1])[0]); res["Z"].append(z)
+            k += 1
+        return {k_: np.array(v) for k_, v in res.items()}
+
+
+class Ksim:
+    """Closed-loop simulator (mirror of classdef Ksim, Ksim.m:1).  `system_class` must offer
+    simulate_Ts(x, u, w) -> x+ and get_y(x) -> y, like the reference's Arm class, plus
+    params['nx'], params['nu']."""
+
+    def __init__(self, system_class, mpc_class):
+        self.sys = system_class
+        self.mpc = mpc_class
+
+    def run_trial_mpc(self, ref, x0=None, u0=None):
+        """Ksim.m:47-262 (delays = 0, unloaded).  Result fields as in the reference."""
+        mpc, s = self.mpc, self.mpc.sysid
+        Np = mpc.horizon
+        nx, nu = self.sys.params["nx"], self.sys.params["nu"]
+        x0 = np.zeros(nx) if x0 is None else np.asarray(x0, dtype=np.float64)
+        u0 = np.zeros(nu) if u0 is None else np.asarray(u0, dtype=np.float64)
+        y0 = np.asarray(self.sys.get_y(x0), dtype=np.float64)
+        ref = np.atleast_2d(np.asarray(ref, dtype=np.float64))
+        ref_sc = mpc.scaledown_ref(ref)                                       # Ksim.m:113
+        res = {"T": [0.0], "U": [u0], "Y": [y0], "K": [0], "R": [ref[0]], "X": [x0], "Z": [], "comp_time": [], "err": []}
+        proj = mpc.projmtx[:, :mpc.params["n"]]
+        k = 1
+        while k < ref_sc.shape[0]:                                            # :147
+            cur = {"y": s.scaledown_y(res["Y"][-1])[None, :], "u": s.scaledown_u(res["U"][-1])[None, :]}   # :153-166
+            refhor = ref_sc[k - 1:k + Np]                                     # :198-202 (1-based k : k+Np)
+            t0 = time.perf_counter()                                          # :205
+            if mpc.model_type == "linear":
+                U, z = mpc.get_mpcInput(cur, refhor)
+            else:
+                U, z = mpc.get_mpcInput_bilinear_iter(cur, refhor, 1)         # :210
+            comp = time.perf_counter() - t0
+            if np.isnan(U).any():                                             # :220-222
+                break
+            u_kp1 = s.scaleup_u(U[1])                                         # :225-228
+            x_kp1 = np.asarray(self.sys.simulate_Ts(res["X"][-1], res["U"][-1], None), dtype=np.float64)   # :239-245
+            y_kp1 = np.asarray(self.sys.get_y(x_kp1), dtype=np.float64)
+            res["T"].append(k * mpc.params["Ts"]); res["U"].append(u_kp1); res["Y"].append(y_kp1); res["K"].append(k)
+            res["R"].append(mpc.scaleup_ref(ref_sc[k - 1])[0]); res["X"].append(x_kp1); res["Z"].append(z)
+            res["comp_time"].append(comp)
+            res["err"].append(float(np.sqrt(((res["R"][-1] - proj @ y_kp1) ** 2).sum())))   # :258
+            k += 1
+        return {k_: np.array(v) for k_, v in res.items()}
+
+
+class ModelPlant:
+    """Plant adapter that steps the identified Koopman model itself (the role Arm plays in
+    example_control.m; the true arm dynamics are out of scope)."""
+
+    def __init__(self, sysid_class):
+        self.s = sysid_class
+        self.params = {"nx": sysid_class.params["n"], "nu": sysid_class.params["m"]}
+
+    def get_y(self, x):
+        return np.asarray(x, dtype=np.float64)
+
+    def simulate_Ts(self, x, u, w=None):
+        s = self.s
+        z = s.lift.econ_full(s.scaledown_y(x))
+        us = s.scaledown_u(u)
+        if s.model_type == "linear":
+            z1 = s.model["A"] @ z + s.model["B"] @ us
+        else:
+            z1 = s.model["A"] @ z + s.model["Beta"](z) @ us
+        return s.scaleup_y(s.model["C"] @ z1)

@@ -1,0 +1,122 @@
+"""GPU parity tests (through the C ABI): lasso (solve_KoopmanQP), get_model's M-projection,
+validation rollouts, and the Ksysid host mirror end to end (example_sysid.m flow).
+Tolerances: M-projection / models 1e-8 relative (two nested normal-equation solves);
+rollouts 1e-9 absolute over 400 steps of a stable model; lasso 1e-6 relative (iterative,
+both sides stop at a fixed-point tolerance; the reference's quadprog has 1e-8 tolerances)."""
+import numpy as np
+import pytest
+
+import koopman_realizations_amd as kra
+from koopman_realizations_amd import _ffi as F
+from oracle import koopman_oracle as ko
+from test_gpu_fit import make_basis
+from conftest import synth_pairs
+
+pytestmark = pytest.mark.gpu
+
+
+def test_lasso_inactive_constraint_returns_least_squares(ctx):
+    rng = np.random.default_rng(4)
+    P = rng.standard_normal((300, 20)); Y = P @ (rng.standard_normal((20, 20)) * 0.3) + 0.01 * rng.standard_normal((300, 20))
+    G, C = P.T @ P, P.T @ Y
+    Kls = np.linalg.solve(G, C)
+    K, it = ctx.fit_lasso(G, C, 2 * np.abs(Kls).sum())
+    assert it == 0 and np.abs(K - Kls).max() < 1e-10
+
+
+@pytest.mark.parametrize("frac", [0.7, 0.3])
+def test_lasso_active_constraint_matches_oracle(ctx, frac):
+    rng = np.random.default_rng(5)
+    P = rng.standard_normal((400, 24)); Y = P @ (rng.standard_normal((24, 24)) * 0.3) + 0.01 * rng.standard_normal((400, 24))
+    G, C = P.T @ P, P.T @ Y
+    t = frac * np.abs(np.linalg.solve(G, C)).sum()
+    K, it = ctx.fit_lasso(G, C, t, max_iter=50000, tol=1e-12)
+    Ko = ko.koopman_lasso(G, C, t)
+    assert abs(np.abs(K).sum() - t) < 1e-8 * t
+    assert ko.lasso_kkt_residual(G, C, K, t) < 1e-6 * np.abs(C).max()
+    assert np.abs(K - Ko).max() < 1e-6 * np.abs(Ko).max()
+
+
+def test_fit_with_lasso_values(ctx):
+    """train_models with a vector of lasso values (Ksysid.m:1372-1387): t = lasso*N."""
+    p = synth_pairs(3000, 2, 1, seed=9)
+    dic = ko.build_dictionary("bilinear", 2, 1, ["poly"], [2])
+    b = make_basis(ctx, dic)
+    snaps = kra.Snapshots(ctx, p["alpha"], p["beta"], p["u"])
+    Px, Py = ko.px_py(dic, p)
+    G, C = ko.gram(Px, Py)
+    Kls = np.linalg.solve(G, C)
+    l_act = 0.5 * np.abs(Kls).sum() / dic.N
+    Ks = kra.fit(ctx, b, snaps, [np.inf, 1e4, l_act])
+    assert np.abs(Ks[0] - Kls).max() < 1e-9 and np.abs(Ks[1] - Kls).max() < 1e-9
+    Ko = ko.koopman_lasso(G, C, l_act * dic.N)
+    assert np.abs(Ks[2] - Ko).max() < 1e-6 * np.abs(Ko).max()
+
+
+def test_model_projection_matches_literal_get_model(ctx, arm):
+    pairs = arm["pairs"]
+    dic = ko.build_dictionary("linear", 6, 3, ["poly"], [3], pairs, dim_red=True)
+    koop = ko.get_koopman(dic, pairs)
+    ref = ko.get_model(dic, koop, 6)             # literal: L = (A Px' + B U')', M' = L \ Py
+    Px, Py = ko.px_py(dic, pairs)
+    G, C = ko.gram(Px, Py)
+    A, B, M = ctx.model_project(koop["K"], G, C, dic.N, 3)
+    for got, want in ((A, ref["A"]), (B, ref["B"]), (M, ref["M"])):
+        assert np.abs(got - want).max() <= 1e-8 * max(1.0, np.abs(want).max())
+
+
+@pytest.mark.parametrize("mt", ["linear", "bilinear"])
+def test_rollout_matches_oracle(ctx, arm, mt):
+    pairs = arm["pairs"]
+    dic = ko.build_dictionary(mt, 6, 3, ["poly"], [3], pairs, dim_red=True)
+    koop = ko.get_koopman(dic, pairs)
+    mdl = ko.get_model(dic, koop, 6) if mt == "linear" else ko.get_blmodel(dic, koop, 6)
+    val = {"t": arm["val"]["t"], "y": ko.scaledown(arm["scale"], "y", arm["val"]["y"]),
+           "u": ko.scaledown(arm["scale"], "u", arm["val"]["u"])}
+    res = ko.val_model(dic, mdl, val, 0)
+    z0 = ko.econ_full(dic, val["y"][:1])[0]
+    Y = ctx.rollout(mt, mdl["A"], mdl["B"], z0, val["u"], 6)
+    Y[0] = val["y"][0]
+    assert np.abs(Y - res["sim_y"]).max() < 1e-9
+    # batch of 3 identical models == single
+    Yb = ctx.rollout(mt, np.stack([mdl["A"]] * 3), np.stack([mdl["B"]] * 3), np.stack([z0] * 3), np.stack([val["u"]] * 3), 6)
+    Yb[:, 0] = val["y"][0]
+    assert (Yb[1] == Y).all() and (Yb[2] == Y).all()
+
+
+@pytest.mark.parametrize("mt", ["linear", "bilinear", "nonlinear"])
+def test_ksysid_mirror_example_sysid_flow(ctx, golden, arm, mt):
+    """example_sysid.m:22-65 through the host mirror: constructor, train_models, val_*."""
+    g = golden["arm_data"]
+    lens = g["train_len"]; off = np.concatenate([[0], np.cumsum(lens)])
+    train = [{"t": g["train_t"][a:b], "y": g["train_y"][a:b], "u": g["train_u"][a:b]} for a, b in zip(off[:-1], off[1:])]
+    val = [{"t": g["val_t"], "y": g["val_y"], "u": g["val_u"]}]
+    ks = kra.Ksysid({"train": train, "val": val}, ctx=ctx, model_type=mt, obs_type=["poly"], obs_degree=[3], snapshots=np.inf,
+                    lasso=[np.inf], delays=0, dim_red=True)
+    np.testing.assert_allclose(ks.params["scale"]["u_factor"], arm["scale"]["u_factor"])
+    assert ks.snapshotPairs["alpha"].shape == (11999, 6)
+    assert ks.params["N"] == (88 if mt == "nonlinear" else 34)          # stored Z widths
+    # the host mirror's PCA basis spans the oracle's (same columns up to rounding)
+    dic = ko.build_dictionary(mt, 6, 3, ["poly"], [3], arm["pairs"], dim_red=True)
+    assert np.abs(ks.basis["pcs"] - dic.pcs).max() < 1e-9
+    ks.train_models()
+    Px, Py = ko.px_py(dic, arm["pairs"])
+    Kref = ko.koopman_ls(Px, Py)      # least squares is invariant to the row permutation of the snapshot draw
+    assert np.abs(ks.model["K"] - Kref).max() <= 2e-8 * np.abs(Kref).max()
+    vd = ks.valdata[0]
+    if mt == "linear":
+        res = ks.val_model(ks.model, vd)
+        ref = ko.val_model(dic, ko.get_model(dic, {"K": Kref, "Px": Px[:, :34], "Py": Py[:, :34], "u": arm["pairs"]["u"]}, 6), vd, 0)
+    elif mt == "bilinear":
+        res = ks.val_BLmodel(ks.model, vd)
+        ref = ko.val_model(dic, ko.get_blmodel(dic, {"K": Kref}, 6), vd, 0)
+    else:
+        res = ks.val_NLmodel(ks.model, vd)
+        ref = ko.val_model(dic, ko.get_nlmodel(dic, {"K": Kref}, 6), vd, 0)
+    assert np.abs(res["sim"]["y"] - ref["sim_y"]).max() < 1e-5      # 400-step rollouts amplify the 1e-8 model difference
+    e_ref = ko.get_error(ref["sim_y"], ref["real_y"], arm["scale"])
+    assert abs(res["error"]["euclid_mean"] - e_ref["euclid_mean"]) < 1e-5
+    # lift handles mirror the reference's lift.* (Ksysid.m:1615-1618)
+    zeta = vd["y"][5]
+    v = np.concatenate([zeta, vd["u"][5]]) if mt == "nonlinear" else zeta
+    np.testing.assert_allclose(ks.lift.econ_full(v), ko.econ_full(dic, v[None, :])[0], atol=1e-9)

@@ -1,0 +1,219 @@
+"""GPU parity tests (through the C ABI) of the MPC step: QP assembly and QP solve.
+Oracle: oracle/koopman_oracle.py — the LITERAL assembly of Kmpc.m (Bhat rebuilt from dense
+matrix powers, H = B'C'QCB + R, ...) and an exact dual active-set QP solve (the reference's
+quadprog is a MathWorks built-in; its stored U sequences are not reproducible, so parity is
+pinned by the uniqueness of the optimum of a strictly convex QP: KKT residual checks).
+Tolerances (f64): QP data 1e-11 relative; U 1e-8 absolute (inputs are O(1))."""
+import numpy as np
+import pytest
+
+import koopman_realizations_amd as kra
+from koopman_realizations_amd import _ffi as F
+from koopman_realizations_amd.device import Mpc
+from oracle import koopman_oracle as ko
+from test_gpu_fit import make_basis
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def arm_models(arm):
+    """Bilinear and linear arm models (example_sysid.m settings) fitted by the oracle."""
+    out = {}
+    for mt in ("bilinear", "linear"):
+        dic = ko.build_dictionary(mt, 6, 3, ["poly"], [3], arm["pairs"], dim_red=True)
+        koop = ko.get_koopman(dic, arm["pairs"])
+        mdl = ko.get_blmodel(dic, koop, 6) if mt == "bilinear" else ko.get_model(dic, koop, 6)
+        out[mt] = (dic, mdl)
+    return out
+
+
+def example_control_setup(arm, mt, dic, mdl, Np=10, with_bounds=True, smooth=False):
+    """example_control.m:19-28 settings, scaled as the Kmpc constructor does."""
+    sc = arm["scale"]
+    bounds = np.tile([-7 * np.pi / 8, 7 * np.pi / 8], (3, 1))
+    lohi = np.stack([ko.scaledown(sc, "u", bounds[:, 0]), ko.scaledown(sc, "u", bounds[:, 1])], axis=1)  # Kmpc.m:659
+    return ko.MpcSetup(model_type=mt, A=mdl["A"], B=mdl["B"], m=3, Np=Np, projmtx=mdl["C"][-2:, :],
+                       cost_running=10.0, cost_terminal=100.0, cost_input=0.1 * np.array([3e-2, 2e-2, 1e-2]),
+                       input_bounds=lohi if with_bounds else None,
+                       slope_lim=1e-1 * sc["u_factor"].mean(),               # Kmpc.m:684
+                       smooth_lim=(0.05 ** 2 * 0.5 * sc["u_factor"].mean()) if smooth else None, n=6)
+
+
+def make_mpc(ctx, s: ko.MpcSetup):
+    ci = np.asarray(s.cost_input, dtype=float)
+    r = np.full(s.m, float(ci)) if ci.ndim == 0 else ci
+    lo = hi = None
+    if s.input_bounds is not None:
+        lo, hi = s.input_bounds[:, 0], s.input_bounds[:, 1]
+    return Mpc(ctx, s.model_type, s.A, s.B, s.Np, s.projmtx, s.cost_running, s.cost_terminal, r, lo, hi, s.slope_lim, s.smooth_lim)
+
+
+def sample_states(arm, golden, dic, k):
+    """(z, u_prev, ref horizon) taken from the stored closed-loop run (state Y(k), input U(k), ref R)."""
+    r = golden["arm_blockM"]
+    y = ko.scaledown(arm["scale"], "y", r["bilin_Y"][k])
+    z = ko.econ_full(dic, y[None, :])[0]
+    u_prev = np.clip(ko.scaledown(arm["scale"], "u", r["bilin_U"][k]), -0.9, 0.9)
+    ref = golden["blockM_ref"]["y"]
+    ysc = (ref - arm["scale"]["y_offset"][-2:]) / arm["scale"]["y_factor"][-2:]      # scaledown_ref, Kmpc.m:135-142
+    return y, z, u_prev, ysc[k:k + 11]
+
+
+@pytest.mark.parametrize("mt", ["bilinear", "linear"])
+@pytest.mark.parametrize("smooth", [False, True])
+def test_qp_assembly_matches_literal_kmpc(ctx, arm, golden, arm_models, mt, smooth):
+    dic, mdl = arm_models[mt]
+    s = example_control_setup(arm, mt, dic, mdl, smooth=smooth)
+    mpc = make_mpc(ctx, s)
+    assert mpc.nvar == 30 and mpc.nrows == (126 if not smooth else 126 + 48)   # 66 + 54 + 6
+    for k in (0, 17, 150, 295):
+        y, z, u_prev, ref = sample_states(arm, golden, dic, k)
+        U, st = mpc.step(z, u_prev, ko.pad_ref(ref, s.Np))
+        Hq, f, Aq, bq = mpc.last_qp()
+        Hr, fr, Ar, br = ko.mpc_qp(s, z, u_prev, ref)
+        assert np.abs(Hq - Hr).max() <= 1e-11 * np.abs(Hr).max()
+        assert np.abs(f - fr).max() <= 1e-11 * max(1.0, np.abs(fr).max())
+        assert (Aq == Ar).all() and np.abs(bq - br).max() <= 1e-15
+        x, lam, ok = ko.qp_solve(Hr, fr, Ar, br)
+        assert ok and st == 0
+        assert ko.qp_kkt_residual(Hr, fr, Ar, br, x, lam) < 1e-8
+        assert np.abs(U - x.reshape(s.Np, s.m)).max() < 1e-8
+        assert np.abs(U[0] - u_prev).max() < 1e-9          # pinned first input (Kmpc.m:865-870)
+
+
+def test_fused_lift_step_and_iterated_linearisation(ctx, arm, golden, arm_models):
+    dic, mdl = arm_models["bilinear"]
+    s = example_control_setup(arm, "bilinear", dic, mdl)
+    mpc = make_mpc(ctx, s)
+    b = make_basis(ctx, dic)
+    for k in (3, 120):
+        y, z, u_prev, ref = sample_states(arm, golden, dic, k)
+        Yr = ko.pad_ref(ref, s.Np)
+        U1, st1 = mpc.step(z, u_prev, Yr)
+        U2, z2, st2 = mpc.step_zeta(b, y, u_prev, Yr)
+        assert st1 == 0 and st2 == 0
+        assert np.abs(z2 - z).max() < 1e-13 and np.abs(U1 - U2).max() < 1e-9
+        for iters in (2, 3):                                   # get_mpcInput_bilinear_iter, Kmpc.m:874-899
+            Ui, sti = mpc.step(z, u_prev, Yr, iters=iters)
+            Uo, kkt = ko.mpc_step(s, z, u_prev, ref, iters=iters)
+            assert sti == 0 and np.abs(Ui - Uo).max() < 1e-7
+
+
+def test_short_reference_is_padded_like_the_reference(ctx, arm, golden, arm_models):
+    dic, mdl = arm_models["bilinear"]
+    s = example_control_setup(arm, "bilinear", dic, mdl)
+    mpc = make_mpc(ctx, s)
+    y, z, u_prev, ref = sample_states(arm, golden, dic, 297)      # tail of the 301-point trajectory: 4 rows
+    assert ref.shape[0] == 4
+    U, st = mpc.step(z, u_prev, ko.pad_ref(ref, s.Np))
+    Uo, _ = ko.mpc_step(s, z, u_prev, ref)
+    assert st == 0 and np.abs(U - Uo).max() < 1e-8
+
+
+def test_batch_matches_single(ctx, arm, golden, arm_models):
+    dic, mdl = arm_models["bilinear"]
+    s = example_control_setup(arm, "bilinear", dic, mdl)
+    mpc = make_mpc(ctx, s)
+    ks = list(range(0, 290, 7))
+    Z, UP, YR, Us = [], [], [], []
+    for k in ks:
+        y, z, u_prev, ref = sample_states(arm, golden, dic, k)
+        Z.append(z); UP.append(u_prev); YR.append(ko.pad_ref(ref, s.Np))
+        Us.append(mpc.step(z, u_prev, YR[-1])[0])
+    Ub, st = mpc.step_batch(np.array(Z), np.array(UP), np.array(YR))
+    assert (st == 0).all()
+    assert np.abs(Ub - np.array(Us)).max() == 0.0             # same kernel, same arithmetic
+
+
+def test_infeasible_qp_returns_nan_like_the_gurobi_shim(ctx, arm, golden, arm_models):
+    dic, mdl = arm_models["bilinear"]
+    s = example_control_setup(arm, "bilinear", dic, mdl)
+    mpc = make_mpc(ctx, s)
+    y, z, u_prev, ref = sample_states(arm, golden, dic, 10)
+    u_bad = np.array([5.0, 0.0, 0.0])                           # pinned input outside the box: infeasible
+    U, st = mpc.step(z, u_bad, ko.pad_ref(ref, s.Np))
+    assert st == F.KP_ERR_QP_FAIL and np.isnan(U).all()         # quadprog_gurobi.m:22-23, Ksim.m:220
+
+
+def test_generic_qp_shim_on_random_problems(ctx):
+    rng = np.random.default_rng(0)
+    for trial in range(40):
+        n = int(rng.integers(2, 41)); mr = int(rng.integers(1, 120))
+        M = rng.standard_normal((n, n)); H = M @ M.T + 0.1 * np.eye(n); f = rng.standard_normal(n) * 3
+        A = rng.standard_normal((mr, n)); x0 = rng.standard_normal(n); b = A @ x0 + rng.random(mr) * 0.5
+        b[0] = A[0] @ x0
+        A = np.vstack([A, A[:2], -A[:1], np.zeros((1, n))]); b = np.concatenate([b, b[:2], -b[:1], [0.0]])
+        x, st = ctx.qp_solve(H, f, A, b)
+        xo, lam, ok = ko.qp_solve(H, f, A, b)
+        assert ok and st == 0, trial
+        assert np.abs(x - xo).max() < 1e-7 * max(1.0, np.abs(xo).max()), trial
+    x, st = ctx.qp_solve(np.eye(2), np.zeros(2), np.array([[1.0, 0], [-1.0, 0]]), np.array([-1.0, -1.0]))
+    assert st == F.KP_ERR_QP_FAIL and np.isnan(x).all()
+    x, st = ctx.qp_solve(np.eye(3), np.array([1.0, -2, 3]), np.zeros((0, 3)), np.zeros(0))   # unconstrained
+    assert st == 0 and np.abs(x - np.array([-1.0, 2, -3])).max() < 1e-14
+
+
+def test_closed_loop_model_as_plant_tracks_blockM(ctx, arm, golden, arm_models):
+    """300-step closed loop on the blockM reference (BASELINE config 3) with the identified model
+    as the plant (Kmpc.run_simulation, Kmpc.m:403-512): GPU controller vs oracle controller."""
+    dic, mdl = arm_models["bilinear"]
+    s = example_control_setup(arm, "bilinear", dic, mdl)
+    mpc = make_mpc(ctx, s)
+    ref = golden["blockM_ref"]["y"]
+    ysc = (ref - arm["scale"]["y_offset"][-2:]) / arm["scale"]["y_factor"][-2:]
+    y = ko.scaledown(arm["scale"], "y", golden["arm_blockM"]["bilin_Y"][0])
+    z = ko.econ_full(dic, y[None, :])[0]
+    u_prev = np.zeros(3); u_prev = ko.scaledown(arm["scale"], "u", np.zeros(3))
+    worst = 0.0
+    err = []
+    for k in range(120):
+        refhor = ysc[k:k + s.Np + 1]
+        U, st = mpc.step(z, u_prev, ko.pad_ref(refhor, s.Np))
+        assert st == 0
+        if k % 10 == 0:
+            Uo, kkt = ko.mpc_step(s, z, u_prev, refhor)
+            worst = max(worst, np.abs(U - Uo).max())
+        z = mdl["A"] @ z + ko.beta_bilinear(mdl["B"], z, 3) @ u_prev        # plant = model (one-step delay, Ksim.m:240)
+        u_prev = U[1]
+        err.append(np.linalg.norm(mdl["C"][-2:] @ z - ysc[min(k + 1, len(ysc) - 1)]))
+    assert worst < 1e-8
+    assert np.mean(err[20:]) < 0.15          # the controller tracks the reference in scaled units
+
+
+def test_kmpc_ksim_mirror_example_control_flow(ctx, golden):
+    """example_control.m:31-40,59,68 through the host mirrors (Ksysid -> Kmpc -> Ksim), with the
+    identified model as the plant.  Result struct has the reference's fields (Ksim.m:129-138)."""
+    g = golden["arm_data"]
+    lens = g["train_len"]; off = np.concatenate([[0], np.cumsum(lens)])
+    train = [{"t": g["train_t"][a:b], "y": g["train_y"][a:b], "u": g["train_u"][a:b]} for a, b in zip(off[:-1], off[1:])]
+    val = [{"t": g["val_t"], "y": g["val_y"], "u": g["val_u"]}]
+    ks = kra.Ksysid({"train": train, "val": val}, ctx=ctx, model_type="bilinear", obs_type=["poly"], obs_degree=[3],
+                    snapshots=np.inf, lasso=[np.inf], delays=0, dim_red=True).train_models()
+    mpc = kra.Kmpc(ks, horizon=10, input_bounds=[-7 * np.pi / 8, 7 * np.pi / 8], input_slopeConst=1e-1, input_smoothConst=None,
+                   state_bounds=None, cost_running=10, cost_terminal=100, cost_input=0.1 * np.array([3e-2, 2e-2, 1e-2]),
+                   projmtx=ks.model["C"][-2:, :])
+    assert mpc.dev.nvar == 30 and mpc.dev.nrows == 126
+    sim = kra.Ksim(kra.ModelPlant(ks), mpc)
+    ref = golden["blockM_ref"]["y"]
+    y0 = golden["arm_blockM"]["bilin_Y"][0]
+    res = sim.run_trial_mpc(ref[:80], x0=y0, u0=np.zeros(3))
+    assert set(res) == {"T", "U", "Y", "K", "R", "X", "Z", "comp_time", "err"}
+    assert res["U"].shape == (80, 3) and res["Z"].shape == (79, 34) and res["comp_time"].shape == (79,)
+    assert np.abs(res["U"]).max() <= 7 * np.pi / 8 + 1e-9                     # input box respected
+    du = np.abs(np.diff(res["U"], axis=0))
+    lim = 1e-1 * ks.params["scale"]["u_factor"].mean() * ks.params["scale"]["u_factor"]
+    assert (du <= lim + 1e-8).all()                                            # slope constraint (Kmpc.m:684)
+    assert res["err"][40:].mean() < 0.12                                       # tracks the block-M in output units
+    # first controller call reproduces the oracle's optimum for the same state
+    dic = ko.Dictionary("bilinear", 6, 3, ko.make_basis(6, ["poly"], [3]), ks.basis["pcs"])
+    sc = ks.params["scale"]
+    s = ko.MpcSetup("bilinear", ks.model["A"], ks.model["B"], 3, 10, ks.model["C"][-2:, :], 10.0, 100.0,
+                    0.1 * np.array([3e-2, 2e-2, 1e-2]),
+                    np.stack([(np.full(3, -7 * np.pi / 8) - sc["u_offset"]) / sc["u_factor"],
+                              (np.full(3, 7 * np.pi / 8) - sc["u_offset"]) / sc["u_factor"]], axis=1),
+                    1e-1 * sc["u_factor"].mean(), None, None, 6)
+    ysc = mpc.scaledown_ref(ref)
+    z0 = ko.econ_full(dic, ks.scaledown_y(y0)[None, :])[0]
+    Uo, kkt = ko.mpc_step(s, z0, ks.scaledown_u(np.zeros(3)), ysc[0:11])
+    assert np.abs(ks.scaleup_u(Uo[1]) - res["U"][1]).max() < 1e-7
