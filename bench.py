@@ -61,6 +61,77 @@ def cpu_baseline(Ns_sample, degree):
             "sample": f"{reps} x get_Koopman (numpy lift + LAPACK lstsq) on {Ns_sample} pairs, W=336, {dt*1e3:.0f} ms each"}
 
 
+def mpc_problem(kra, ctx, basis, snaps, horizon=10):
+    """Bilinear Kmpc on the model of the synthetic fit (N=84), example_control.m:20-28 settings."""
+    from koopman_realizations_amd.device import Mpc
+    N, m = basis.N, 3
+    K = kra.fit(ctx, basis, snaps)[0]
+    A = np.asfortranarray(K[:N, :N].T); B = np.asfortranarray(K[N:, :N].T)      # Ksysid.m:1258-1259
+    proj = np.zeros((2, N)); proj[0, 4] = proj[1, 5] = 1.0                      # C(end-1:end,:)
+    u_fac = 2.8
+    setup = dict(A=A, B=B, N=N, m=m, Np=horizon, proj=proj, q_run=10.0, q_term=100.0,
+                 r=0.1 * np.array([3e-2, 2e-2, 1e-2]), lo=np.full(3, -7 * np.pi / 8 / u_fac), hi=np.full(3, 7 * np.pi / 8 / u_fac),
+                 slope=1e-1 * u_fac)
+    mpc = Mpc(ctx, "bilinear", A, B, horizon, proj, setup["q_run"], setup["q_term"], setup["r"], setup["lo"], setup["hi"], setup["slope"])
+    return mpc, setup
+
+
+def mpc_inputs(nb, seed=7):
+    rng = np.random.default_rng(seed)
+    zeta = rng.uniform(-0.6, 0.6, (nb, 6))
+    u_prev = rng.uniform(-0.3, 0.3, (nb, 3))
+    th = rng.uniform(0, 2 * np.pi, (nb, 1)) + 0.15 * np.arange(11)[None, :]
+    ref = np.stack([zeta[:, [4]] + 0.2 * (np.cos(th) - np.cos(th[:, :1])), zeta[:, [5]] + 0.2 * (np.sin(th) - np.sin(th[:, :1]))], axis=2)
+    return zeta, u_prev, ref.reshape(nb, -1)      # Yr = vec(ref') per problem
+
+
+def bench_mpc(ctx, kra, basis, snaps, args):
+    """MPC steps/s: (a) latency-bound stream of single steps (lift + assembly + QP in one launch,
+    host round trip per step, as Ksim.run_trial_mpc calls it), (b) batched independent problems."""
+    from koopman_realizations_amd import _ffi as F
+    mpc, setup = mpc_problem(kra, ctx, basis, snaps)
+    zeta, u_prev, Yr = mpc_inputs(max(args.mpc_steps, args.mpc_batch))
+    for i in range(5):
+        mpc.step_zeta(basis, zeta[i], u_prev[i], Yr[i])
+    t0 = time.perf_counter(); ok = 0; kern = []
+    for i in range(args.mpc_steps):
+        U, z, st = mpc.step_zeta(basis, zeta[i], u_prev[i], Yr[i])
+        ok += st == 0; kern.append(ctx.timer(2))
+    dt1 = time.perf_counter() - t0
+    Z = basis.lift(F.LIFT_ECON, zeta[:args.mpc_batch])
+    mpc.step_batch(Z, u_prev[:args.mpc_batch], Yr[:args.mpc_batch])
+    t0 = time.perf_counter()
+    Ub, stb = mpc.step_batch(Z, u_prev[:args.mpc_batch], Yr[:args.mpc_batch])
+    dtb = time.perf_counter() - t0
+    return {"single_steps_per_s": args.mpc_steps / dt1, "single_us_per_step": dt1 / args.mpc_steps * 1e6,
+            "single_kernel_us": float(np.mean(kern)) * 1e3, "single_solved": int(ok), "single_steps": args.mpc_steps,
+            "batch_problems_per_s": args.mpc_batch / dtb, "batch": args.mpc_batch, "batch_kernel_ms": ctx.timer(2),
+            "batch_solved": int((stb == 0).sum()),
+            "workload": "bilinear Kmpc, N=84 model of the synthetic fit, horizon 10, 30 variables x 126 rows (BASELINE configs[2] shape)",
+            "reference_recorded": "MATLAB R2019a stored comp_time: median 8.7 ms/step (~104 steps/s), N=34, unknown PC",
+            "_setup": (setup, basis.N, zeta[:20], u_prev[:20], Yr[:20])}
+
+
+def cpu_baseline_mpc(pack):
+    """The oracle's literal Kmpc step (Bhat from dense matrix powers, 4 rebuilds folded into one,
+    exact active-set QP) on the host, on a bounded sample of the same problems."""
+    from oracle import koopman_oracle as ko
+    setup, N, zeta, u_prev, Yr = pack
+    dic = ko.build_dictionary("bilinear", 6, 3, ["poly"], [3])
+    s = ko.MpcSetup("bilinear", setup["A"], setup["B"], 3, setup["Np"], setup["proj"], setup["q_run"], setup["q_term"], setup["r"],
+                    np.stack([setup["lo"], setup["hi"]], axis=1), setup["slope"], None, None, 6)
+    t0 = time.perf_counter(); n = 0
+    for i in range(len(zeta)):
+        z = ko.econ_full(dic, zeta[i][None, :])[0]
+        ko.mpc_step(s, z, u_prev[i], Yr[i].reshape(-1, 2))
+        n += 1
+        if time.perf_counter() - t0 > 10.0:
+            break
+    dt = (time.perf_counter() - t0) / n
+    return {"value": 1.0 / dt, "unit": "MPC steps/s", "cores": 1, "kind": "port",
+            "sample": f"{n} literal Kmpc steps (numpy), N={N}, {dt*1e3:.1f} ms each"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -69,6 +140,9 @@ def main():
     ap.add_argument("--snapshots", type=int, default=100000)
     ap.add_argument("--degree", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-mpc", action="store_true")
+    ap.add_argument("--mpc-steps", type=int, default=300)
+    ap.add_argument("--mpc-batch", type=int, default=4096)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -121,6 +195,10 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    mpc_res = None
+    if rank == 0 and not args.no_mpc:
+        mpc_res = bench_mpc(ctx, kra, basis, snaps, args)
+
     if rank == 0:
         flops_pair = W * (W + 1) + 2.0 * W * W                 # F(336) = 339 024
         g_ms = float(np.mean(t_gram))
@@ -141,8 +219,14 @@ def main():
                          "unit": "TFLOP/s", "frac": achieved / PEAK_F64_MFMA_TFLOPS, "traffic": None,
                          "hbm_algorithmic_GBs": 120.0 * Ns / (g_ms * 1e-3) / 1e9},
         }
+        if mpc_res is not None:
+            res["mpc"] = mpc_res
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(min(Ns, 20000), args.degree)
+            if mpc_res is not None:
+                res["cpu_baseline"]["mpc"] = cpu_baseline_mpc(mpc_res.pop("_setup"))
+        if mpc_res is not None:
+            mpc_res.pop("_setup", None)
         print(json.dumps(res))
     if dist is not None:
         dist.destroy_process_group()

@@ -186,6 +186,11 @@ int kp_mpc_step_batch(kp_mpc* mpc, int nb, const double* z, const double* u_prev
 /* The QP data (2H, f, A_ineq, b) of the most recent kp_mpc_step, for parity checks against
  * the literal assembly of Kmpc.m:861-883.  Hq: nvar x nvar, Aq: nrows x nvar (column-major). */
 int kp_mpc_last_qp(kp_mpc* mpc, double* Hq, double* f, double* Aq, double* bq);
+/* Diagnostics (the reference only has tic/toc around the call, Ksim.m:205-217): device-side phase
+ * times in microseconds of the most recent kp_mpc_step: us[0] lift + reference error, [1] Beta/S_k,
+ * [2] H and f, [3] H^-1, [4] active-set iterations, [5] whole kernel; counts[0] solver
+ * iterations, counts[1] active constraints at the optimum. */
+int kp_mpc_last_profile(kp_mpc* mpc, double* us, int* counts);
 int kp_qp_solve(kp_ctx* ctx, const double* H, const double* f, const double* A, const double* b, int n,
                 int mrows, double* x, int* status);
 

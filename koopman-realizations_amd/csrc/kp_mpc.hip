@@ -34,6 +34,9 @@ struct kp_mpc {
   double* Aq = nullptr;    // nrows x nvar column-major (constant: L = F, tack rows)
   double* bq0 = nullptr;   // nrows (c and zeros for the tack rows)
   double* Anorm = nullptr; // nrows
+  double* ellv = nullptr;  // K x nrows
+  int* ellc = nullptr;     // K x nrows
+  int ellK = 1;
   double* work = nullptr;  // per-problem QP export: Hq (nvar^2) | f (nvar)
   size_t work_problems = 0;
   double *d_in = nullptr, *d_out = nullptr;
@@ -70,12 +73,20 @@ __device__ __forceinline__ void wave_argmin(double& v, int& idx) {
   }
 }
 
-// LDS scratch of the QP solver (doubles): Hinv n*n | HN n*n | Sinv n*n | x,hp,r,lam,d,zd,ap,f: 8n | act: n ints
-__host__ __device__ inline int qp_lds_doubles(int n) { return 3 * n * n + 8 * n + (n + 1) / 2 + 2; }
+// Constraint matrix in ELL form: row r has K slots (val[k*mr + r], col[k*mr + r]); unused slots
+// carry val = 0, col = 0.  The MPC rows have <= 3 non-zeros, so A x, H^-1 a_p and N'H^-1 a_p cost
+// K operations instead of n.
+struct EllMat {
+  const double* val;
+  const int* col;
+  const double* norm;  // row 2-norms
+  int K;
+};
 
-// min 1/2 x'Hq x + f'x  s.t.  A x <= b.   Hq (n x n, column-major, in LDS or global), A: mr x n
-// column-major (global), Anorm: row norms.  Executed by ONE wave (all 64 lanes must call).
-// Returns 0 on success, 1 infeasible / iteration cap / non-SPD.  x_out: n values (LDS or global).
+// LDS scratch of the QP solver (doubles): Hinv n*n | HN n*n | Sinv n*n | x,hp,r,lam,d,zd,ap,f: 8n |
+// act: n ints | isact: mr bytes
+__host__ __device__ inline int qp_lds_doubles(int n, int mr) { return 3 * n * n + 8 * n + (n + 1) / 2 + (mr + 7) / 8 + 4; }
+
 // Wave-local synchronisation: LDS operations of one wave complete in issue order, so lanes only
 // need the compiler not to reorder across this point (usable inside multi-wave workgroups).
 #define WSYNC()                                              \
@@ -85,8 +96,12 @@ __host__ __device__ inline int qp_lds_doubles(int n) { return 3 * n * n + 8 * n 
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   \
   } while (0)
 
-__device__ int qp_goldfarb_idnani(const double* Hq, const double* f, const double* __restrict__ A, const double* bvec,
-                                  const double* __restrict__ Anorm, int n, int mr, double* ws, double* x_out, double tol) {
+// min 1/2 x'Hq x + f'x  s.t.  A x <= b.   Hq: n x n column-major (LDS or global).
+// Executed by ONE wave (all 64 lanes must call).  Returns 0 on success, 1 on infeasible /
+// iteration cap / non-SPD Hessian (x_out = NaN then).
+__device__ int qp_goldfarb_idnani(const double* Hq, const double* f, const EllMat A, const double* bvec, int n, int mr,
+                                  double* ws, double* x_out, double tol, long long* stamps = nullptr, bool have_hinv = false,
+                                  int hinv_bad = 0) {
   const int lane = threadIdx.x & 63;
   double* Hinv = ws;
   double* HN = Hinv + n * n;
@@ -100,39 +115,49 @@ __device__ int qp_goldfarb_idnani(const double* Hq, const double* f, const doubl
   double* ap = zd + n;
   double* fl = ap + n;
   int* act = (int*)(fl + n);
+  unsigned char* isact = (unsigned char*)(act + n + (n & 1));
 
-  // ---- Hinv by Gauss-Jordan on [Hq] (SPD: no pivoting) ----
-  for (int e = lane; e < n * n; e += 64) Hinv[e] = Hq[e];
-  for (int e = lane; e < n; e += 64) fl[e] = f[e];
+  // ---- Hinv by in-place Gauss-Jordan (SPD: no pivoting) ----
+  if (!have_hinv)
+    for (int e = lane; e < n * n; e += 64) Hinv[e] = Hq[e];
+  for (int e = lane; e < n; e += 64) {
+    fl[e] = f[e];
+    ap[e] = 0.0;
+  }
+  for (int e = lane; e < mr; e += 64) isact[e] = 0;
   WSYNC();
-  int bad = 0;
-  for (int k = 0; k < n; ++k) {
-    double piv = Hinv[k + k * n];
+  int bad = hinv_bad;
+  for (int k = 0; k < (have_hinv ? 0 : n); ++k) {
+    const double piv = Hinv[k + k * n];
     if (!(piv > 0.0)) bad = 1;
-    double ip = 1.0 / piv;
+    const double ip = 1.0 / piv;
+    // each lane owns rows i = lane (n <= 64): read its column-k entry once, then update the row
+    const int i = lane;
+    double cik = 0.0;
+    if (i < n) cik = Hinv[i + k * n];
     WSYNC();
-    // in-place Gauss-Jordan step k
-    for (int e = lane; e < n * n; e += 64) {
-      int i = e % n, j = e / n;
-      if (i != k && j != k) Hinv[e] -= Hinv[i + k * n] * Hinv[k + j * n] * ip;
-    }
-    WSYNC();
-    for (int e = lane; e < n; e += 64) {
-      if (e != k) {
-        Hinv[e + k * n] *= -ip;         // column k
-        Hinv[k + e * n] *= ip;          // row k
+    if (i < n && i != k) {
+      const double fct = cik * ip;
+#pragma unroll 4
+      for (int j = 0; j < n; ++j) {
+        if (j != k) Hinv[i + j * n] -= fct * Hinv[k + j * n];
       }
+      Hinv[i + k * n] = -fct;
     }
+    WSYNC();
+    if (i < n && i != k) Hinv[k + i * n] *= ip;   // row k (read by everyone above, scaled after)
     if (lane == 0) Hinv[k + k * n] = ip;
     WSYNC();
   }
   for (int i = lane; i < n; i += 64) {
     double s = 0.0;
+#pragma unroll 4
     for (int j = 0; j < n; ++j) s += Hinv[i + j * n] * fl[j];
     x[i] = -s;
   }
   WSYNC();
 
+  if (stamps && lane == 0) stamps[4] = wall_clock64();
   int q = 0;
   int status = 1;
   int it = bad ? QP_MAXIT : 0;   // non-SPD Hessian: report failure
@@ -144,16 +169,14 @@ __device__ int qp_goldfarb_idnani(const double* Hq, const double* f, const doubl
     int infeas = 0;
     for (int row = lane; row < mr; row += 64) {
       double v = -bvec[row];
-      for (int j = 0; j < n; ++j) v += A[row + (size_t)j * mr] * x[j];
-      double nr = Anorm[row];
-      bool isact = false;
-      for (int c = 0; c < q; ++c) isact |= (act[c] == row);
+      for (int k = 0; k < A.K; ++k) v += A.val[k * mr + row] * x[A.col[k * mr + row]];
+      const double nr = A.norm[row];
       if (nr == 0.0) {
         if (v > tol) infeas = 1;
         continue;
       }
-      double vs = v / nr;
-      if (!isact && vs > best) {
+      const double vs = v / nr;
+      if (!isact[row] && vs > best) {
         best = vs;
         bestp = row;
       }
@@ -167,12 +190,16 @@ __device__ int qp_goldfarb_idnani(const double* Hq, const double* f, const doubl
     }
     const int p = bestp;
     const double bp = bvec[p];
-    for (int j = lane; j < n; j += 64) ap[j] = A[p + (size_t)j * mr];
+    // sparse a_p: (col_k, val_k), k < K (wave-uniform broadcast loads); dense copy in ap for dot products
+    if (lane < A.K) {
+      double v = A.val[lane * mr + p];
+      if (v != 0.0) ap[A.col[lane * mr + p]] = v;
+    }
     WSYNC();
     double app_l = 0.0;
     for (int i = lane; i < n; i += 64) {
       double s = 0.0;
-      for (int j = 0; j < n; ++j) s += Hinv[i + j * n] * ap[j];
+      for (int k = 0; k < A.K; ++k) s += A.val[k * mr + p] * Hinv[i + A.col[k * mr + p] * n];
       hp[i] = s;
       app_l += s * ap[i];
     }
@@ -185,12 +212,13 @@ __device__ int qp_goldfarb_idnani(const double* Hq, const double* f, const doubl
       // d = N' Hinv a_p ; r = Sinv d ; zd = hp - HN r
       for (int c = lane; c < q; c += 64) {
         double s = 0.0;
-        for (int i = 0; i < n; ++i) s += HN[i + c * n] * ap[i];
+        for (int k = 0; k < A.K; ++k) s += A.val[k * mr + p] * HN[A.col[k * mr + p] + c * n];
         d[c] = s;
       }
       WSYNC();
       for (int c = lane; c < q; c += 64) {
         double s = 0.0;
+#pragma unroll 4
         for (int k = 0; k < q; ++k) s += Sinv[c + k * n] * d[k];
         r[c] = s;
       }
@@ -198,6 +226,7 @@ __device__ int qp_goldfarb_idnani(const double* Hq, const double* f, const doubl
       double apz_l = 0.0, apx_l = 0.0;
       for (int i = lane; i < n; i += 64) {
         double s = hp[i];
+#pragma unroll 4
         for (int c = 0; c < q; ++c) s -= HN[i + c * n] * r[c];
         zd[i] = s;
         apz_l += ap[i] * s;
@@ -250,16 +279,15 @@ __device__ int qp_goldfarb_idnani(const double* Hq, const double* f, const doubl
           Sinv[q + q * n] = ib;
           act[q] = p;
           lam[q] = lam_p;
+          isact[p] = 1;
         }
         ++q;
         WSYNC();
         break;
       }
-      // partial step: drop active constraint l
+      // partial step: drop active constraint l  (Schur deletion on the inverse, then compaction)
       {
         const double isl = 1.0 / Sinv[l + l * n];
-        // Schur deletion on the (q x q) inverse, then compact row/col l away
-        // r reused as the scaled column l
         for (int c = lane; c < q; c += 64) r[c] = Sinv[c + l * n];
         WSYNC();
         for (int e = lane; e < q * q; e += 64) {
@@ -267,24 +295,26 @@ __device__ int qp_goldfarb_idnani(const double* Hq, const double* f, const doubl
           if (i != l && j != l) Sinv[i + j * n] -= r[i] * r[j] * isl;
         }
         WSYNC();
-        // compact: move rows/cols > l up/left (serialised over columns to avoid overlap hazards)
-        for (int j = 0; j < q; ++j) {
-          if (j == l) continue;
-          int jn = j > l ? j - 1 : j;
-          double vals0 = 0.0;
-          int i = lane;  // q <= 64
-          int in_ = i > l ? i - 1 : i;
-          bool ok = i < q && i != l;
-          if (ok) vals0 = Sinv[i + j * n];
-          WSYNC();
-          if (ok) Sinv[in_ + jn * n] = vals0;
-          WSYNC();
+        // compact: lane i owns row i (q <= 64); columns shift left one at a time
+        {
+          const int i = lane;
+          const bool ok = i < q && i != l;
+          const int in_ = i > l ? i - 1 : i;
+          for (int j = 0; j < q; ++j) {
+            if (j == l) continue;
+            const int jn = j > l ? j - 1 : j;
+            double v = ok ? Sinv[i + j * n] : 0.0;
+            WSYNC();
+            if (ok) Sinv[in_ + jn * n] = v;
+            WSYNC();
+          }
         }
         for (int j = l; j + 1 < q; ++j) {
           for (int i = lane; i < n; i += 64) HN[i + j * n] = HN[i + (j + 1) * n];
           WSYNC();
         }
         if (lane == 0) {
+          isact[act[l]] = 0;
           for (int c = l; c + 1 < q; ++c) {
             act[c] = act[c + 1];
             lam[c] = lam[c + 1];
@@ -294,30 +324,52 @@ __device__ int qp_goldfarb_idnani(const double* Hq, const double* f, const doubl
         WSYNC();
       }
     }
+    // clear the dense copy of a_p
+    if (lane < A.K) ap[A.col[lane * mr + p]] = 0.0;
+    WSYNC();
     if (fail) break;
   }
   WSYNC();
+  if (stamps && lane == 0) {
+    stamps[8] = it;
+    stamps[9] = q;
+  }
   for (int i = lane; i < n; i += 64) x_out[i] = status == 0 ? x[i] : __builtin_nan("");
   return status;
 }
 
 // ---- generic QP shim kernel -----------------------------------------------------------------
-__global__ __launch_bounds__(64) void kp_qp_kernel(const double* H, const double* f, const double* A, const double* b,
-                                                   const double* Anorm, int n, int mr, double* x, int* status) {
+__global__ __launch_bounds__(64) void kp_qp_kernel(const double* H, const double* f, EllMat A, const double* b, int n, int mr,
+                                                   double* x, int* status) {
   extern __shared__ double sm[];
-  int st = qp_goldfarb_idnani(H, f, A, b, Anorm, n, mr, sm, x, 1e-10);
+  int st = qp_goldfarb_idnani(H, f, A, b, n, mr, sm, x, 1e-10);
   if (threadIdx.x == 0) *status = st ? KP_ERR_QP_FAIL : KP_OK;
 }
 
-__global__ void kp_rownorm_kernel(const double* A, int mr, int n, double* out) {
-  int row = blockIdx.x * blockDim.x + threadIdx.x;
-  if (row < mr) {
+// dense (mr x n, column-major) -> ELL on the host
+static void to_ell(const double* A, int mr, int n, std::vector<double>& val, std::vector<int>& col, std::vector<double>& norm, int& K) {
+  K = 1;
+  for (int r = 0; r < mr; ++r) {
+    int c = 0;
+    for (int j = 0; j < n; ++j) c += A[r + (size_t)j * mr] != 0.0;
+    K = std::max(K, c);
+  }
+  val.assign((size_t)K * mr, 0.0);
+  col.assign((size_t)K * mr, 0);
+  norm.assign(mr, 0.0);
+  for (int r = 0; r < mr; ++r) {
+    int k = 0;
     double s = 0.0;
     for (int j = 0; j < n; ++j) {
-      double v = A[row + (size_t)j * mr];
-      s += v * v;
+      double v = A[r + (size_t)j * mr];
+      if (v != 0.0) {
+        val[(size_t)k * mr + r] = v;
+        col[(size_t)k * mr + r] = j;
+        s += v * v;
+        ++k;
+      }
     }
-    out[row] = sqrt(s);
+    norm[r] = std::sqrt(s);
   }
 }
 
@@ -326,30 +378,44 @@ extern "C" int kp_qp_solve(kp_ctx* ctx, const double* H, const double* f, const 
   if (!ctx || !H || !f || !x || n < 1 || n > QP_MAXN || mr < 0 || (mr > 0 && (!A || !b)))
     return ctx ? ctx->fail(KP_ERR_ARG, "kp_qp_solve: bad argument (n <= 64)") : KP_ERR_ARG;
   KP_HIP(ctx, hipSetDevice(ctx->device));
-  size_t bH = (size_t)n * n * 8, bA = (size_t)mr * n * 8;
-  char* ws = (char*)ctx->workspace(7, bH + bA + (size_t)(2 * n + 2 * mr) * 8 + 64);
+  std::vector<double> val, norm;
+  std::vector<int> col;
+  int K = 1;
+  to_ell(A, mr, n, val, col, norm, K);
+  size_t bH = (size_t)n * n * 8, bV = val.size() * 8, bCo = col.size() * 4;
+  char* ws = (char*)ctx->workspace(7, bH + bV + bCo + (size_t)(2 * n + 2 * mr) * 8 + 64);
   if (!ws) return ctx->fail(KP_ERR_HIP, "kp_qp_solve: out of device memory");
   double* dH = (double*)ws;
-  double* dA = (double*)(ws + bH);
-  double* df = (double*)(ws + bH + bA);
+  double* dV = (double*)(ws + bH);
+  double* df = (double*)(ws + bH + bV);
   double* dx = df + n;
   double* db = dx + n;
   double* dn = db + mr;
-  int* dst = (int*)(dn + mr);
-  KP_HIP(ctx, hipMemcpyAsync(dH, H, bH, hipMemcpyHostToDevice, ctx->stream));
-  KP_HIP(ctx, hipMemcpyAsync(df, f, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+  int* dC = (int*)(dn + mr);
+  int* dst = dC + col.size();
+  hipStream_t s = ctx->stream;
+  KP_HIP(ctx, hipMemcpyAsync(dH, H, bH, hipMemcpyHostToDevice, s));
+  KP_HIP(ctx, hipMemcpyAsync(df, f, (size_t)n * 8, hipMemcpyHostToDevice, s));
   if (mr) {
-    KP_HIP(ctx, hipMemcpyAsync(dA, A, bA, hipMemcpyHostToDevice, ctx->stream));
-    KP_HIP(ctx, hipMemcpyAsync(db, b, (size_t)mr * 8, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(kp_rownorm_kernel, dim3((mr + 63) / 64), dim3(64), 0, ctx->stream, dA, mr, n, dn);
+    KP_HIP(ctx, hipMemcpyAsync(dV, val.data(), bV, hipMemcpyHostToDevice, s));
+    KP_HIP(ctx, hipMemcpyAsync(dC, col.data(), bCo, hipMemcpyHostToDevice, s));
+    KP_HIP(ctx, hipMemcpyAsync(db, b, (size_t)mr * 8, hipMemcpyHostToDevice, s));
+    KP_HIP(ctx, hipMemcpyAsync(dn, norm.data(), (size_t)mr * 8, hipMemcpyHostToDevice, s));
   }
-  size_t lds = (size_t)qp_lds_doubles(n) * 8;
-  hipLaunchKernelGGL(kp_qp_kernel, dim3(1), dim3(64), lds, ctx->stream, dH, df, dA, db, dn, n, mr, dx, dst);
+  EllMat E{dV, dC, dn, K};
+  size_t lds = (size_t)qp_lds_doubles(n, mr) * 8;
+  if (lds > 160 * 1024) return ctx->fail(KP_ERR_ARG, "kp_qp_solve: problem too large");
+  static size_t lds_set = 0;
+  if (lds > lds_set) {
+    KP_HIP(ctx, hipFuncSetAttribute((const void*)kp_qp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    lds_set = lds;
+  }
+  hipLaunchKernelGGL(kp_qp_kernel, dim3(1), dim3(64), lds, s, dH, df, E, db, n, mr, dx, dst);
   KP_HIP(ctx, hipGetLastError());
   int st = 0;
-  KP_HIP(ctx, hipMemcpyAsync(x, dx, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
-  KP_HIP(ctx, hipMemcpyAsync(&st, dst, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-  KP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  KP_HIP(ctx, hipMemcpyAsync(x, dx, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+  KP_HIP(ctx, hipMemcpyAsync(&st, dst, sizeof(int), hipMemcpyDeviceToHost, s));
+  KP_HIP(ctx, hipStreamSynchronize(s));   // also keeps the host vectors alive until the copies are done
   if (status) *status = st;
   return KP_OK;
 }
@@ -385,11 +451,40 @@ __global__ __launch_bounds__(256) void kp_mpc_setup_kernel(const double* __restr
   }
 }
 
+// In-place Gauss-Jordan inverse of an SPD n x n matrix in LDS by a whole 256-thread workgroup.
+// Returns non-zero if a pivot is not positive.
+__device__ int wg_spd_inverse(double* Hinv, int n, double* colk /* n scratch */) {
+  const int tid = threadIdx.x;
+  int bad = 0;
+  for (int k = 0; k < n; ++k) {
+    const double piv = Hinv[k + k * n];
+    if (!(piv > 0.0)) bad = 1;
+    const double ip = 1.0 / piv;
+    for (int i = tid; i < n; i += 256) colk[i] = Hinv[i + k * n];
+    __syncthreads();
+    for (int e = tid; e < n * n; e += 256) {
+      int i = e % n, j = e / n;
+      if (i != k && j != k) Hinv[e] -= colk[i] * ip * Hinv[k + j * n];
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+      if (i != k) {
+        Hinv[i + k * n] = -colk[i] * ip;
+        Hinv[k + i * n] *= ip;
+      }
+    }
+    if (tid == 0) Hinv[k + k * n] = ip;
+    __syncthreads();
+  }
+  return bad;
+}
+
 struct MpcArgs {
   BasisDev basis;   // used when zeta != nullptr (fused lift)
   int model_type, N, m, Np, nproj, nvar, nrows, iters, has_basis;
   double q_run, q_term;
   const double *A, *B, *P, *S0, *r, *Aq, *bq0, *Anorm;
+  EllMat ell;
   const double* z;      // [nb][N]      (or nullptr with zeta)
   const double* zeta;   // [nb][nzeta]  (fused lift)
   const double* u_prev; // [nb][m]
@@ -398,13 +493,14 @@ struct MpcArgs {
   double* z_out;        // [nb][N] or nullptr
   double* qp_export;    // [nb][nvar*nvar + nvar + nrows] or nullptr
   int* status;          // [nb]
+  long long* stamps;    // [8] wall_clock64 stamps + [8] counters of problem 0 (diagnostics), or nullptr
 };
 
 // LDS (doubles): z N | beta N*m | S Np*nproj*m | e (Np+1)*nproj | Hq nvar^2 | f nvar | b nrows | zh (Np+1)*N (iters>1)
 //                | full nfull (fused lift) | qp scratch
 __host__ __device__ inline int mpc_lds_doubles(int N, int m, int Np, int nproj, int nvar, int nrows, int iters, int nfull) {
   return N + N * m + Np * nproj * m + (Np + 1) * nproj + nvar * nvar + nvar + nrows + (iters > 1 ? (Np + 1) * N : 0) + nfull + 4 +
-         qp_lds_doubles(nvar);
+         qp_lds_doubles(nvar, nrows);
 }
 
 __global__ __launch_bounds__(256) void kp_mpc_step_kernel(MpcArgs a) {
@@ -426,6 +522,8 @@ __global__ __launch_bounds__(256) void kp_mpc_step_kernel(MpcArgs a) {
   qpws = (double*)(((uintptr_t)qpws + 15) & ~(uintptr_t)15);
   const double* Yr = a.Yr + (size_t)pb * nproj * (Np + 1);
   const double* up = a.u_prev + (size_t)pb * m;
+  long long* stamps = (a.stamps && pb == 0) ? a.stamps : nullptr;
+  if (stamps && tid == 0) stamps[0] = wall_clock64();
 
   // ---- lifted state (Kmpc.m:842) ----
   if (a.has_basis) {
@@ -463,14 +561,19 @@ __global__ __launch_bounds__(256) void kp_mpc_step_kernel(MpcArgs a) {
     bq[e] = v;
   }
   // e_i = P_i z - Yr_i
-  for (int e = tid; e < (Np + 1) * nproj; e += 256) {
+  for (int e4 = tid; e4 < (Np + 1) * nproj * 4; e4 += 256) {   // each dot product split over 4 lanes
+    int e = e4 >> 2, part = e4 & 3;
     int i = e / nproj, p = e % nproj;
     const double* Pi = a.P + (size_t)i * nproj * N;
     double s = 0.0;
-    for (int j = 0; j < N; ++j) s += Pi[p + j * nproj] * z[j];
-    ev[e] = s - Yr[e];
+#pragma unroll 4
+    for (int j = part; j < N; j += 4) s += Pi[p + j * nproj] * z[j];
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    if (part == 0) ev[e] = s - Yr[e];
   }
   int status = 0;
+  if (stamps && tid == 0) stamps[1] = wall_clock64();
   for (int iter = 0; iter < a.iters; ++iter) {
     // ---- S_k = P_k * Beta(z_k)  (get_costB_bilinear, Kmpc.m:578-585: block i uses z(i,:) when a
     // horizon of lifted states is given, else z) ----
@@ -483,23 +586,29 @@ __global__ __launch_bounds__(256) void kp_mpc_step_kernel(MpcArgs a) {
           int rr = e % N, i = e / N;
           const double* Bi = a.B + (size_t)i * N * N;
           double s = 0.0;
+#pragma unroll 8
           for (int c = 0; c < N; ++c) s += Bi[rr + (size_t)c * N] * zk[c];
           beta[e] = s;
         }
         __syncthreads();
         int k0 = k, k1 = iter == 0 ? Np : k + 1;
-        for (int e = tid; e < (k1 - k0) * nproj * m; e += 256) {
+        for (int e4 = tid; e4 < (k1 - k0) * nproj * m * 4; e4 += 256) {
+          int e = e4 >> 2, part = e4 & 3;
           int kk = k0 + e / (nproj * m), rem = e % (nproj * m), p = rem % nproj, i = rem / nproj;
           const double* Pk = a.P + (size_t)kk * nproj * N;
           double s = 0.0;
-          for (int j = 0; j < N; ++j) s += Pk[p + j * nproj] * beta[j + i * N];
-          S[kk * nproj * m + rem] = s;
+#pragma unroll 4
+          for (int j = part; j < N; j += 4) s += Pk[p + j * nproj] * beta[j + i * N];
+          s += __shfl_xor(s, 1, 64);
+          s += __shfl_xor(s, 2, 64);
+          if (part == 0) S[kk * nproj * m + rem] = s;
         }
       }
     } else {
       for (int e = tid; e < Np * nproj * m; e += 256) S[e] = a.S0[e];
     }
     __syncthreads();
+    if (stamps && tid == 0) stamps[2] = wall_clock64();
     // ---- Hq = 2 (CB'Q CB + R),  f = 2 CB'Q e   (Kmpc.m:604,879,883) ----
     for (int e = tid; e < nv * nv; e += 256) {
       int r1 = e % nv, r2 = e / nv;
@@ -536,13 +645,19 @@ __global__ __launch_bounds__(256) void kp_mpc_step_kernel(MpcArgs a) {
       for (int e = tid; e < nr; e += 256) ex[nv * nv + nv + e] = bq[e];
     }
     // ---- QP by wave 0 ----
+    if (stamps && tid == 0) stamps[3] = wall_clock64();
     double* xout = a.U + (size_t)pb * nv;
+    // H^-1 by the whole workgroup into the solver's scratch (first n*n doubles); d-slot as scratch
+    for (int e = tid; e < nv * nv; e += 256) qpws[e] = Hq[e];
+    __syncthreads();
+    const int hbad = wg_spd_inverse(qpws, nv, qpws + 3 * nv * nv + 4 * nv);
     if (tid < 64) {
-      int st = qp_goldfarb_idnani(Hq, f, a.Aq, bq, a.Anorm, nv, nr, qpws, xout, 1e-10);
+      int st = qp_goldfarb_idnani(Hq, f, a.ell, bq, nv, nr, qpws, xout, 1e-10, stamps, true, hbad);
       if (tid == 0) *st_sh = st;
     }
     // the other waves wait here (the solver itself only uses wave-local synchronisation)
     __syncthreads();
+    if (stamps && tid == 0) stamps[5] = wall_clock64();
     status = *st_sh;
     if (status || iter == a.iters - 1) break;
     // ---- lifted horizon for the next linearisation (Kmpc.m:891-895) ----
@@ -586,6 +701,8 @@ extern "C" int kp_mpc_destroy(kp_mpc* M) {
   for (double* p : ptrs)
     if (p) (void)hipFree(p);
   if (M->d_status) (void)hipFree(M->d_status);
+  if (M->ellc) (void)hipFree(M->ellc);
+  if (M->ellv) (void)hipFree(M->ellv);
   delete M;
   return KP_OK;
 }
@@ -667,7 +784,16 @@ extern "C" int kp_mpc_create(kp_ctx* ctx, int model_type, const double* A, const
   if (!rc) rc = dev_alloc_copy(ctx, &M->r, r, m);
   if (!rc) rc = dev_alloc_copy(ctx, &M->Aq, Aq.data(), Aq.size());
   if (!rc) rc = dev_alloc_copy(ctx, &M->bq0, bq.data(), nrows);
-  if (!rc) rc = dev_alloc_copy(ctx, &M->Anorm, nullptr, nrows);
+  std::vector<double> ev, en;
+  std::vector<int> ec;
+  to_ell(Aq.data(), nrows, nvar, ev, ec, en, M->ellK);
+  if (!rc) rc = dev_alloc_copy(ctx, &M->Anorm, en.data(), nrows);
+  if (!rc) rc = dev_alloc_copy(ctx, &M->ellv, ev.data(), ev.size());
+  if (!rc) {
+    hipError_t e2 = hipMalloc((void**)&M->ellc, ec.size() * 4);
+    if (e2 == hipSuccess) e2 = hipMemcpy(M->ellc, ec.data(), ec.size() * 4, hipMemcpyHostToDevice);
+    if (e2 != hipSuccess) rc = ctx->fail(KP_ERR_HIP, std::string("kp_mpc_create: ") + hipGetErrorString(e2));
+  }
   double* dproj = nullptr;
   if (!rc) rc = dev_alloc_copy(ctx, &dproj, proj, (size_t)nproj * N);
   if (rc) {
@@ -677,7 +803,6 @@ extern "C" int kp_mpc_create(kp_ctx* ctx, int model_type, const double* A, const
   }
   hipLaunchKernelGGL(kp_mpc_setup_kernel, dim3(1), dim3(256), 0, ctx->stream, M->A, M->B, dproj, N, m, Np, nproj,
                      model_type == KP_MODEL_LINEAR ? 1 : 0, M->P, M->S0);
-  hipLaunchKernelGGL(kp_rownorm_kernel, dim3((nrows + 63) / 64), dim3(64), 0, ctx->stream, M->Aq, nrows, nvar, M->Anorm);
   hipError_t e = hipStreamSynchronize(ctx->stream);
   (void)hipFree(dproj);
   if (e != hipSuccess) {
@@ -723,7 +848,7 @@ static int mpc_run(kp_mpc* M, const kp_basis* basis, int nb, const double* z, co
     KP_HIP(ctx, hipMalloc((void**)&M->d_in, cap * ((size_t)std::max(N, 64) + m + (size_t)nproj * (Np + 1)) * 8));
     KP_HIP(ctx, hipMalloc((void**)&M->d_out, cap * n_out * 8));
     KP_HIP(ctx, hipMalloc((void**)&M->d_status, cap * sizeof(int)));
-    KP_HIP(ctx, hipMalloc((void**)&M->work, n_ex * 8));
+    KP_HIP(ctx, hipMalloc((void**)&M->work, (n_ex + 16) * 8));
     M->io_problems = cap;
   }
   const size_t nz = zeta ? nzeta : N;
@@ -739,6 +864,7 @@ static int mpc_run(kp_mpc* M, const kp_basis* basis, int nb, const double* z, co
   a.model_type = M->model_type; a.N = N; a.m = m; a.Np = Np; a.nproj = nproj; a.nvar = nv; a.nrows = nr; a.iters = iters;
   a.q_run = M->q_run; a.q_term = M->q_term;
   a.A = M->A; a.B = M->B; a.P = M->P; a.S0 = M->S0; a.r = M->r; a.Aq = M->Aq; a.bq0 = M->bq0; a.Anorm = M->Anorm;
+  a.ell = EllMat{M->ellv, M->ellc, M->Anorm, M->ellK};
   a.z = zeta ? nullptr : d_z;
   a.zeta = zeta ? d_z : nullptr;
   a.u_prev = d_up; a.Yr = d_yr;
@@ -746,6 +872,7 @@ static int mpc_run(kp_mpc* M, const kp_basis* basis, int nb, const double* z, co
   a.z_out = M->d_out + (size_t)nb * nv;
   a.qp_export = nb == 1 ? M->work : nullptr;
   a.status = M->d_status;
+  a.stamps = nb == 1 ? (long long*)(M->work + n_ex) : nullptr;
   size_t lds = (size_t)mpc_lds_doubles(N, m, Np, nproj, nv, nr, iters, zeta ? basis->dev.nfull : 0) * 8 + 32;
   if (lds > 160 * 1024) return ctx->fail(KP_ERR_ARG, "kp_mpc_step: problem too large for LDS");
   static size_t lds_set = 0;
@@ -801,5 +928,29 @@ extern "C" int kp_mpc_last_qp(kp_mpc* M, double* Hq, double* f, double* Aq, doub
   if (f) KP_HIP(ctx, hipMemcpy(f, M->work + nv * nv, nv * 8, hipMemcpyDeviceToHost));
   if (bq) KP_HIP(ctx, hipMemcpy(bq, M->work + nv * nv + nv, nr * 8, hipMemcpyDeviceToHost));
   if (Aq) KP_HIP(ctx, hipMemcpy(Aq, M->Aq, nr * nv * 8, hipMemcpyDeviceToHost));
+  return KP_OK;
+}
+
+// Diagnostics: phase times (microseconds) of the most recent single-problem step:
+// [0] lift + e, [1] Beta/S, [2] H/f, [3] Hinv (Gauss-Jordan), [4] active-set iterations,
+// [5] total kernel; counts[0] = solver iterations, counts[1] = active constraints at the optimum.
+extern "C" int kp_mpc_last_profile(kp_mpc* M, double* us, int* counts) {
+  if (!M || !M->work || !us) return KP_ERR_ARG;
+  kp_ctx* ctx = M->ctx;
+  KP_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t n_ex = (size_t)M->nvar * M->nvar + M->nvar + M->nrows;
+  long long st[16];
+  KP_HIP(ctx, hipMemcpy(st, M->work + n_ex, sizeof(st), hipMemcpyDeviceToHost));
+  const double tick = 0.01;  // wall_clock64: 100 MHz
+  us[0] = (st[1] - st[0]) * tick;
+  us[1] = (st[2] - st[1]) * tick;
+  us[2] = (st[3] - st[2]) * tick;
+  us[3] = (st[4] - st[3]) * tick;
+  us[4] = (st[5] - st[4]) * tick;
+  us[5] = (st[5] - st[0]) * tick;
+  if (counts) {
+    counts[0] = (int)st[8];
+    counts[1] = (int)st[9];
+  }
   return KP_OK;
 }

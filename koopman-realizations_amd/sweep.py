@@ -1,0 +1,115 @@
+"""Embarrassingly parallel sweeps over independent fits, one process per GPU.
+
+The reference runs these loops serially in one MATLAB interpreter:
+  * lasso grid            train_models with a vector of lasso values (Ksysid.m:1372-1387)
+  * random-system sweep   evaluate_rand_models.m:45-144 (per system: linear deg 1..13,
+                          bilinear deg 1..6, nonlinear deg 1..4 with lasso 4)
+Units (lasso values / systems) are dealt round-robin to ranks; there is NO collective on the
+data path.  The only communication is the final gather of the per-unit results
+(`torch.distributed.all_gather_object` / all_gather over RCCL on GPUs, gloo in CPU tests).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def shard_units(n_units: int, rank: int, world: int):
+    """Unit ids owned by `rank`: round-robin, so ragged counts differ by at most one."""
+    return list(range(rank, n_units, world))
+
+
+def gather_results(local: dict, n_units: int, dist=None):
+    """Final gather.  `local` maps unit id -> result (numpy array or picklable object).
+    Returns the list of all results ordered by unit id on every rank."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        merged = dict(local)
+    else:
+        parts = [None] * dist.get_world_size()
+        dist.all_gather_object(parts, local)
+        merged = {}
+        for p in parts:
+            merged.update(p)
+    missing = [i for i in range(n_units) if i not in merged]
+    if missing:
+        raise RuntimeError(f"sweep: units {missing[:5]}... were not computed by any rank")
+    return [merged[i] for i in range(n_units)]
+
+
+def gather_matrices(local: dict, n_units: int, shape, dist=None, device=None):
+    """Final gather of equally shaped f64 matrices with ONE tensor all_gather (RCCL on GPUs).
+    Ranks own round-robin shards, so every rank contributes ceil(n/world) slots (padded)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return [local[i] for i in range(n_units)]
+    import torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    per = (n_units + world - 1) // world
+    buf = torch.zeros((per,) + tuple(shape), dtype=torch.float64)
+    for slot, uid in enumerate(shard_units(n_units, rank, world)):
+        buf[slot] = torch.from_numpy(np.ascontiguousarray(local[uid]))
+    if device is not None:
+        buf = buf.to(device)
+    out = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(out, buf)
+    res = [None] * n_units
+    for r in range(world):
+        o = out[r].cpu().numpy()
+        for slot, uid in enumerate(shard_units(n_units, r, world)):
+            res[uid] = o[slot]
+    return res
+
+
+def lasso_sweep(fit_one, lassos, rank=0, world=1, dist=None, shape=None, device=None):
+    """Config 4: K for every lasso value.  fit_one(lasso) -> K (W x W)."""
+    lassos = list(lassos)
+    local = {i: fit_one(lassos[i]) for i in shard_units(len(lassos), rank, world)}
+    if shape is not None:
+        return gather_matrices(local, len(lassos), shape, dist, device)
+    return gather_results(local, len(lassos), dist)
+
+
+# evaluate_rand_models.m:14-16
+MAX_DEGREE = {"linear": 13, "bilinear": 6, "nonlinear": 4}
+
+
+def eval_system(data4sysid, ctx=None, degrees=None, Ksysid=None):
+    """evaluate_rand_models.m:47-143 for ONE system: normalised mean validation error of every
+    model type / degree.  Returns dict model_type -> (errors[deg], dims[deg])."""
+    if Ksysid is None:
+        from .ksysid import Ksysid
+    degrees = degrees or MAX_DEGREE
+    out = {}
+    for mt in ("linear", "bilinear", "nonlinear"):
+        errs, dims = [], []
+        for j in range(1, degrees[mt] + 1):
+            ks = Ksysid(data4sysid, ctx=ctx, model_type=mt, obs_type=["poly"], obs_degree=[j], snapshots=np.inf,
+                        lasso=[4.0] if mt == "nonlinear" else [np.inf],      # :56,:89,:122
+                        delays=0, loaded=False, dim_red=False)
+            ks.train_models()
+            vd = ks.valdata[0]
+            res = {"linear": ks.val_model, "bilinear": ks.val_BLmodel, "nonlinear": ks.val_NLmodel}[mt](ks.model, vd)
+            mean_error = res["error"]["mean"]                                   # :70
+            mean_error_zeros = np.abs(res["real"]["y"]).sum(axis=0) / res["real"]["y"].shape[0]   # :71
+            errs.append(float(np.ravel(mean_error / mean_error_zeros)[0]))      # :72 (n = 1 systems)
+            dims.append(ks.basis_dev.W if mt == "bilinear" else ks.basis_dev.nfull)   # :76,:109,:142
+        out[mt] = (np.array(errs), np.array(dims))
+    return out
+
+
+def rand_models_sweep(systems, rank=0, world=1, dist=None, ctx=None, degrees=None, eval_fn=None):
+    """Config 5: every rank evaluates its systems; final gather of the error tables.
+    Returns dict model_type -> array (max_degree x n_systems), as err_*_models in
+    evaluate_rand_models.m:38-43."""
+    eval_fn = eval_fn or (lambda d: eval_system(d, ctx=ctx, degrees=degrees))
+    local = {i: eval_fn(systems[i]) for i in shard_units(len(systems), rank, world)}
+    allres = gather_results(local, len(systems), dist)
+    return {mt: np.stack([r[mt][0] for r in allres], axis=1) for mt in ("linear", "bilinear", "nonlinear")}
+
+
+def sweep_statistics(err):
+    """evaluate_rand_models.m:149-171: drop NaN / > 10 outliers, mean and std per degree."""
+    mean, std = [], []
+    for row in err:
+        ok = row[np.isfinite(row) & (row <= 10)]
+        mean.append(ok.mean() if ok.size else np.nan)
+        std.append(ok.std(ddof=1) if ok.size > 1 else np.nan)
+    return np.array(mean), np.array(std)
