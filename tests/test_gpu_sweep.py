@@ -57,4 +57,7 @@ def test_eval_system_matches_oracle(ctx, golden):
 def test_rand_sweep_table_single_rank(ctx, golden):
     systems = [_system(golden, i) for i in range(3)]
     tab = sweep.rand_models_sweep(systems, ctx=ctx, degrees={"linear": 3, "bilinear": 2, "nonlinear": 2})
-    assert tab["linear"].shape == (3, 3) and tab["bilinear"].shape == (2, 3) and np.isfinite(tab["nonlinear"]).all()
+    assert tab["linear"].shape == (3, 3) and tab["bilinear"].shape == (2, 3) and tab["nonlinear"].shape == (2, 3)
+    # unstable models blow up to NaN in the reference too; the statistics drop them (evaluate_rand_models.m:149-171)
+    mean, std = sweep.sweep_statistics(tab["nonlinear"])
+    assert np.isfinite(mean).all() and np.isfinite(tab["linear"]).all()
