@@ -315,7 +315,7 @@ extern "C" int kp_fit_gram(kp_ctx* ctx, const kp_basis* basis, const kp_snapshot
   const int W = basis->dev.W;
   int rc = ensure_gc(ctx, W);
   if (rc) return rc;
-  rc = kp_gram_launch(ctx, basis, snaps, ctx->GC);
+  rc = kp_gram_dispatch(ctx, basis, snaps, ctx->GC);
   if (rc) return rc;
   size_t bW = (size_t)W * W * 8;
   if (G) KP_HIP(ctx, hipMemcpyAsync(G, ctx->GC, bW, hipMemcpyDeviceToHost, ctx->stream));
@@ -359,7 +359,7 @@ extern "C" int kp_fit(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* sn
   int rc = ensure_gc(ctx, W);
   if (!rc) rc = ensure_kres(ctx, W, n_lasso);
   if (rc) return rc;
-  rc = kp_gram_launch(ctx, basis, snaps, ctx->GC);  // records ev0/ev1 around gram+reduce
+  rc = kp_gram_dispatch(ctx, basis, snaps, ctx->GC);  // records ev0/ev1 around gram+reduce
   if (rc) return rc;
   double* Gd = ctx->GC;
   double* Cd = ctx->GC + (size_t)W * W;

@@ -71,6 +71,8 @@ struct BasisDev {
 
 struct kp_gram_plan;
 void kp_gram_plan_free(kp_gram_plan* p);
+struct kp_gram2_plan;
+void kp_gram2_plan_free(kp_gram2_plan* p);
 
 struct kp_basis {
   kp_ctx* ctx = nullptr;
@@ -84,6 +86,7 @@ struct kp_basis {
   int pow_depth = 1;           // largest single-variable exponent
   bool fast = false;           // every column is a product of <= 4 single-variable powers
   kp_gram_plan* plan = nullptr;  // tile->wave plan of the fused Gram kernel (built on first use)
+  kp_gram2_plan* plan2 = nullptr;  // plan of the 4x4x4-MFMA Gram kernel (monomial dictionaries)
 };
 
 struct kp_snapshots {
@@ -146,6 +149,12 @@ __device__ __forceinline__ double kp_eval_col(const BasisDev& b, const ColDesc c
 
 // host-side launchers implemented in the .hip files
 int kp_gram_launch(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* s, double* GC_dev);
+bool kp_gram2_applicable(const kp_basis* basis);
+int kp_gram2_launch(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* s, double* GC_dev);
+// picks the 4x4x4-MFMA kernel when the dictionary allows it, else the general kernel
+inline int kp_gram_dispatch(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* s, double* GC_dev) {
+  return kp_gram2_applicable(basis) ? kp_gram2_launch(ctx, basis, s, GC_dev) : kp_gram_launch(ctx, basis, s, GC_dev);
+}
 int kp_chol_solve_dev(kp_ctx* ctx, double* G_dev, double* C_dev, int W, int ncols, double* K_dev);
 int kp_lasso_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, int W, int ncols, double t,
                  int max_iter, double tol, double* K_dev, int* iters);
