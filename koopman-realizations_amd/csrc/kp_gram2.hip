@@ -11,12 +11,18 @@
 // Replaces the per-row lift loop of Ksysid.get_Koopman (Ksysid.m:1030-1065) and the products
 // Px'Px, Px'Py (Ksysid.m:1114,1125).
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 #include "kp_internal.h"
 
+#ifndef KP_ABL
+#define KP_ABL 0   // timing-only ablations (results wrong): 1 no lift in loop, 2 also no raw store, 3 no MFMA
+#endif
 #define KT 8    // snapshots per LDS tile (two k-steps)
-#define CPT 6   // dictionary columns per lifting thread (16 column lanes => nfull <= 96)
+#define NW 8    // waves per workgroup (two per SIMD: one wave's LDS/VALU issue hides behind the other's MFMAs)
+#define NTHR (64 * NW)
+#define CPT 3   // dictionary columns per lifting thread (32 column slots x 3 => nfull <= 96)
 
 struct Gram2Args {
   BasisDev b;
@@ -45,7 +51,7 @@ __device__ __forceinline__ double row_ror(double v) {
 
 // BM: 0 = no input expansion (linear / nonlinear rows), 1..3 = bilinear with m = BM inputs.
 template <int NACC, int BM>
-__global__ __launch_bounds__(256, 1) void kp_gram2_kernel(Gram2Args a) {
+__global__ __launch_bounds__(NTHR, 2) void kp_gram2_kernel(Gram2Args a) {
   extern __shared__ double sm[];
   const BasisDev& b = a.b;
   const int tid = threadIdx.x;
@@ -53,7 +59,7 @@ __global__ __launch_bounds__(256, 1) void kp_gram2_kernel(Gram2Args a) {
   const int wave = tid >> 6;
   const int super = blockIdx.x % a.nsuper;
   const int split = blockIdx.x / a.nsuper;
-  const int job = super * 4 + wave;
+  const int job = super * NW + wave;
   const int nzm = b.nzeta + b.m;
   const int nrawrows = 2 * nzm;
   const int D = a.D;
@@ -79,17 +85,17 @@ __global__ __launch_bounds__(256, 1) void kp_gram2_kernel(Gram2Args a) {
     for (int s = 0; s < 4; ++s) acc[q][s] = 0.0;
 
   // ---- one-time LDS setup ----
-  for (int e = tid; e < 2 * psi_stride; e += 256) sm[psi_base + e] = 0.0;   // padding columns stay zero
+  for (int e = tid; e < 2 * psi_stride + Wp; e += NTHR) sm[psi_base + e] = 0.0;   // padding columns stay zero
   if (tid < 2 * KT) sm[(tid / KT) * pow_stride + nrawrows * D * KT + (tid % KT)] = 1.0;
 
   // ---- lifting thread constants ----
-  const int jl = tid & 15, combo = tid >> 4, ls = combo & (KT - 1), lside = combo >> 3;
+  const int jl = tid & 15, combo = tid >> 4, ls = combo & (KT - 1), lside = (combo >> 3) & 1, half = combo >> 4;
   int foff[CPT][4];
   int woff[CPT];
   bool wok[CPT];
 #pragma unroll
   for (int i = 0; i < CPT; ++i) {
-    const int c = jl + 16 * i;
+    const int c = jl + 16 * (2 * i + half);
     wok[i] = c < b.nfull;
     const uint32_t r = wok[i] ? a.recipes[c] : 0xffffffffu;
 #pragma unroll
@@ -140,7 +146,7 @@ __global__ __launch_bounds__(256, 1) void kp_gram2_kernel(Gram2Args a) {
     if (BM > 0) uv0 = T[uoff];
     if (BM > 1) uv1 = T[uoff + D * KT];
     if (BM > 2) uv2 = T[uoff + 2 * D * KT];
-    if (BM == 0 && lin && jl < m) {   // [psi , u]  (Ksysid.m:1062)
+    if (BM == 0 && lin && half == 0 && jl < m) {   // [psi , u]  (Ksysid.m:1062)
       double* P = sm + psi_base + pb * psi_stride;
       P[(lside * KT + ls) * Wp + N + jl] = T[uoff + jl * D * KT] * vmask;
     }
@@ -200,13 +206,19 @@ __global__ __launch_bounds__(256, 1) void kp_gram2_kernel(Gram2Args a) {
         const int kk = step / NACC, q = step % NACC;
         if (step + PF < NSTEP) bvs[step + PF] = P[((step + PF) / NACC) * 4 * Wp + bo[(step + PF) % NACC]];
         const double bv = bvs[step];
+#if KP_ABL != 3
         acc[q][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[kk][0], bv, acc[q][0], 0, 0, 0);
         acc[q][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[kk][1], bv, acc[q][1], 0, 0, 0);
         acc[q][2] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[kk][2], bv, acc[q][2], 0, 0, 0);
         acc[q][3] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[kk][3], bv, acc[q][3], 0, 0, 0);
+#else
+        acc[q][0] += bv * af[kk][0];
+#endif
         // lift of the NEXT snapshot tile: chunk i reads at step i*SP, writes LAG steps later
+#if KP_ABL != 1 && KP_ABL != 2
         if (step % SP == 0 && step / SP < CPT) lift_read(step / SP, nxt);
         if (step >= LAG && (step - LAG) % SP == 0 && (step - LAG) / SP < CPT) lift_write((step - LAG) / SP, nxt);
+#endif
       }
 #pragma unroll
       for (int i = 0; i < CPT; ++i) {              // chunks that did not fit inside the MFMA loop (tiny NACC)
@@ -214,7 +226,9 @@ __global__ __launch_bounds__(256, 1) void kp_gram2_kernel(Gram2Args a) {
         if (i * SP + LAG >= NSTEP) lift_write(i, nxt);
       }
     }
+#if KP_ABL != 2
     store_raw(cur, rawreg);                        // raw tile t+2 -> power table `cur` (read while lifting tile t)
+#endif
     __syncthreads();
   }
 
@@ -292,21 +306,37 @@ static int make_plan2(kp_ctx* ctx, int W, kp_gram2_plan** out) {
       if (2 * d == nt && r >= nt / 2) continue;   // antipodal pairs appear twice
       rows[r].push_back({0, r, c});
     }
-  size_t maxrow = 0;
-  for (auto& v : rows) maxrow = std::max(maxrow, v.size());
-  static const int cand[] = {4, 8, 16, 24, 32};
-  int nacc = 32;
-  for (int c : cand)
-    if ((size_t)c >= maxrow) { nacc = c; break; }
+  // tiles per wave-job: the candidate that wastes the fewest accumulator slots over whole workgroups
+  static const int cand[] = {4, 6, 8, 11, 12, 16};
+  int nacc = 16;
+  double best_eff = -1.0;
+  size_t total = 0;
+  for (auto& v : rows) total += v.size();
+  for (int c : cand) {
+    size_t nj = 0;
+    for (auto& v : rows) nj += (v.size() + c - 1) / c;
+    size_t slots = (nj + NW - 1) / NW * NW * (size_t)c;
+    double eff = (double)total / (double)slots;
+    if (eff > best_eff + 1e-9 || (eff > best_eff - 1e-9 && c > nacc)) {
+      best_eff = eff;
+      nacc = c;
+    }
+  }
+  if (const char* ov = getenv("KP_GRAM2_NACC")) {   // tuning override
+    int v = atoi(ov);
+    for (int c : cand)
+      if (c == v) nacc = v;
+  }
   p->nacc = nacc;
   std::vector<uint32_t> desc;
   std::vector<int> tile_out, tile_info;
   int id = 0, njobs = 0;
   for (int r = 0; r < nt; ++r) {
-    for (size_t s0 = 0; s0 < rows[r].size(); s0 += nacc) {
+    const size_t nchunk = (rows[r].size() + nacc - 1) / nacc, per = (rows[r].size() + nchunk - 1) / nchunk;   // even chunks
+    for (size_t s0 = 0; s0 < rows[r].size(); s0 += per) {
       desc.push_back((uint32_t)(r * 16));
       for (int q = 0; q < nacc; ++q) {
-        if (s0 + q < rows[r].size()) {
+        if ((size_t)q < per && s0 + q < rows[r].size()) {
           const Tile& t = rows[r][s0 + q];
           desc.push_back((uint32_t)((t.kind ? KT * p->Wp : 0) + t.tc * 16));
           tile_out.push_back(id++);
@@ -319,13 +349,13 @@ static int make_plan2(kp_ctx* ctx, int W, kp_gram2_plan** out) {
       ++njobs;
     }
   }
-  while (njobs % 4) {   // pad to whole workgroups with idle jobs
+  while (njobs % NW) {   // pad to whole workgroups with idle jobs
     desc.push_back(0u);
     for (int q = 0; q < nacc; ++q) { desc.push_back(0u); tile_out.push_back(-1); }
     ++njobs;
   }
   p->njobs = njobs;
-  p->nsuper = njobs / 4;
+  p->nsuper = njobs / NW;
   p->ntile_out = id;
   size_t b_desc = desc.size() * 4, b_to = tile_out.size() * 4, b_ti = tile_info.size() * 4;
   p->off_to = b_desc;
@@ -350,7 +380,7 @@ static hipError_t launch2b(const Gram2Args& a, int grid, size_t lds, hipStream_t
     if (e != hipSuccess) return e;
     lds_set = lds;
   }
-  hipLaunchKernelGGL((kp_gram2_kernel<NACC, BM>), dim3(grid), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((kp_gram2_kernel<NACC, BM>), dim3(grid), dim3(NTHR), lds, st, a);
   return hipGetLastError();
 }
 
@@ -366,7 +396,7 @@ static hipError_t launch2(const Gram2Args& a, int bm, int grid, size_t lds, hipS
 
 bool kp_gram2_applicable(const kp_basis* basis) {
   const BasisDev& b = basis->dev;
-  return basis->fast && b.k_pcs == 0 && b.nfull <= 16 * CPT && b.m <= 16 && (b.model_type != KP_MODEL_BILINEAR || (b.m >= 1 && b.m <= 3)) &&
+  return basis->fast && b.k_pcs == 0 && b.nfull <= 32 * CPT && b.m <= 16 && (b.model_type != KP_MODEL_BILINEAR || (b.m >= 1 && b.m <= 3)) &&
          2 * (b.nzeta + b.m) * KT <= 256;
 }
 
@@ -417,10 +447,11 @@ int kp_gram2_launch(kp_ctx* ctx, const kp_basis* basis_c, const kp_snapshots* s,
   hipError_t e;
   switch (plan.nacc) {
     case 4: e = launch2<4>(a, bm, grid, lds, ctx->stream); break;
+    case 6: e = launch2<6>(a, bm, grid, lds, ctx->stream); break;
     case 8: e = launch2<8>(a, bm, grid, lds, ctx->stream); break;
-    case 16: e = launch2<16>(a, bm, grid, lds, ctx->stream); break;
-    case 24: e = launch2<24>(a, bm, grid, lds, ctx->stream); break;
-    default: e = launch2<32>(a, bm, grid, lds, ctx->stream); break;
+    case 11: e = launch2<11>(a, bm, grid, lds, ctx->stream); break;
+    case 12: e = launch2<12>(a, bm, grid, lds, ctx->stream); break;
+    default: e = launch2<16>(a, bm, grid, lds, ctx->stream); break;
   }
   KP_HIP(ctx, e);
   KP_HIP(ctx, hipEventRecord(ctx->evp[1], ctx->stream));
