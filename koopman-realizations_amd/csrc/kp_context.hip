@@ -231,6 +231,7 @@ extern "C" int kp_basis_destroy(kp_basis* b) {
   if (b->d_recipes) (void)hipFree(b->d_recipes);
   kp_gram_plan_free(b->plan);
   kp_gram2_plan_free(b->plan2);
+  kp_gram3_plan_free(b->plan3);
   delete b;
   return KP_OK;
 }

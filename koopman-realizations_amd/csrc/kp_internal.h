@@ -73,6 +73,8 @@ struct kp_gram_plan;
 void kp_gram_plan_free(kp_gram_plan* p);
 struct kp_gram2_plan;
 void kp_gram2_plan_free(kp_gram2_plan* p);
+struct kp_gram3_plan;
+void kp_gram3_plan_free(kp_gram3_plan* p);
 
 struct kp_basis {
   kp_ctx* ctx = nullptr;
@@ -87,6 +89,7 @@ struct kp_basis {
   bool fast = false;           // every column is a product of <= 4 single-variable powers
   kp_gram_plan* plan = nullptr;  // tile->wave plan of the fused Gram kernel (built on first use)
   kp_gram2_plan* plan2 = nullptr;  // plan of the 4x4x4-MFMA Gram kernel (monomial dictionaries)
+  kp_gram3_plan* plan3 = nullptr;  // plan of the Kronecker (bilinear) Gram kernel
 };
 
 struct kp_snapshots {
@@ -152,7 +155,10 @@ int kp_gram_launch(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* s, do
 bool kp_gram2_applicable(const kp_basis* basis);
 int kp_gram2_launch(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* s, double* GC_dev);
 // picks the 4x4x4-MFMA kernel when the dictionary allows it, else the general kernel
+bool kp_gram3_applicable(const kp_basis* basis);
+int kp_gram3_launch(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* s, double* GC_dev);
 inline int kp_gram_dispatch(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* s, double* GC_dev) {
+  if (kp_gram3_applicable(basis)) return kp_gram3_launch(ctx, basis, s, GC_dev);
   return kp_gram2_applicable(basis) ? kp_gram2_launch(ctx, basis, s, GC_dev) : kp_gram_launch(ctx, basis, s, GC_dev);
 }
 int kp_chol_solve_dev(kp_ctx* ctx, double* G_dev, double* C_dev, int W, int ncols, double* K_dev);
