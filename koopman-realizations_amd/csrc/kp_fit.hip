@@ -159,75 +159,87 @@ __global__ __launch_bounds__(1024) void kp_chol_kernel(double* __restrict__ A, i
   if (tid == 0) *info = bad;
 }
 
-__global__ __launch_bounds__(64) void kp_trsm_kernel(const double* __restrict__ LU, const double* __restrict__ Dinv, int n,
+// Forward + backward block substitution for 16 right-hand sides by a 4-wave workgroup.
+// Block row i:  X_i = Dinv_i (C_i - sum_{j<i} L_ij X_j).  The sum over j is dealt round-robin to
+// the 4 waves (j = wave, wave+4, ...), partial tiles are combined through LDS by wave 0, which
+// applies the inverse diagonal block.  The L operands of step i+1 do not depend on X, so they are
+// loaded from global memory (L2) during step i (software pipeline across steps).
+#define TR_MAXJ 8   // block products per wave and step: ceil(nt/4) <= 8  =>  n <= 512
+__global__ __launch_bounds__(256) void kp_trsm_kernel(const double* __restrict__ LU, const double* __restrict__ Dinv, int n,
                                                      double* __restrict__ X) {
-  extern __shared__ double xs[];  // [n][16]  (row of the block = 16 consecutive doubles) + tmp[256]
-  double* tmp = xs + (size_t)n * 16;
-  const int lane = threadIdx.x;
+  extern __shared__ double xs[];  // [n][16] X block (row = 16 consecutive doubles) | part[4][256] partial tiles
+  double* part = xs + (size_t)n * 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cb = blockIdx.x;
   const int nt = n / 16;
   const int lr = lane >> 4, lc = lane & 15;
   double* Xb = X + (size_t)cb * 16 * n;
-  // forward substitution  L Y = C
-  for (int i = 0; i < nt; ++i) {
-    double4_t acc;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] = Xb[(size_t)lc * n + i * 16 + lr + 4 * r];
-    for (int j = 0; j < i; ++j) {
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        int k = j * 16 + kk * 4 + lr;
-        double av = -LU[(size_t)k * n + i * 16 + lc];
-        double bv = xs[k * 16 + lc];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) tmp[(lr + 4 * r) * 16 + lc] = acc[r];
-    __syncthreads();
-    double4_t y = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      int k = kk * 4 + lr;
-      double av = Dinv[(size_t)i * 256 + k * 16 + lc];  // Dinv_i[lc][k]
-      double bv = tmp[k * 16 + lc];
-      y = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, y, 0, 0, 0);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) xs[(i * 16 + lr + 4 * r) * 16 + lc] = y[r];
-    __syncthreads();
+  for (int e = tid; e < n * 16; e += 256) {
+    int row = e % n, col = e / n;
+    xs[row * 16 + col] = Xb[(size_t)col * n + row];       // C block -> LDS (overwritten by Y, then K)
   }
-  // backward substitution  L' K = Y   (upper triangle of LU holds L')
-  for (int i = nt - 1; i >= 0; --i) {
-    double4_t acc;
+  __syncthreads();
+  double an[TR_MAXJ][4];                                   // -L operands of the NEXT step
+  for (int dir = 0; dir < 2; ++dir) {                      // 0: L Y = C (forward), 1: L' K = Y (backward)
+    // operands of block row i against block column j: A[r][k] = LU[(16j + k) * n + 16i + r]
+    // (lower triangle holds L, upper triangle L', so the same formula serves both sweeps)
+    auto load_ops = [&](int i) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] = xs[(i * 16 + lr + 4 * r) * 16 + lc];
-    for (int j = i + 1; j < nt; ++j) {
+      for (int s = 0; s < TR_MAXJ; ++s) {
+        const int jj = wave + 4 * s;
+        const int j = dir == 0 ? jj : nt - 1 - jj;
+        const bool on = dir == 0 ? (j < i) : (j > i);
+        if (i >= 0 && i < nt && on) {
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        int k = j * 16 + kk * 4 + lr;
-        double av = -LU[(size_t)k * n + i * 16 + lc];
-        double bv = xs[k * 16 + lc];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+          for (int kk = 0; kk < 4; ++kk) an[s][kk] = -LU[(size_t)(j * 16 + kk * 4 + lr) * n + i * 16 + lc];
+        }
       }
+    };
+    const int i0 = dir == 0 ? 0 : nt - 1, istep = dir == 0 ? 1 : -1;
+    load_ops(i0);
+    for (int it = 0; it < nt; ++it) {
+      const int i = i0 + it * istep;
+      double ac[TR_MAXJ][4];
+#pragma unroll
+      for (int s = 0; s < TR_MAXJ; ++s)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) ac[s][kk] = an[s][kk];
+      load_ops(i + istep);                                  // prefetch the next step's L tiles
+      double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s = 0; s < TR_MAXJ; ++s) {
+        const int jj = wave + 4 * s;
+        const int j = dir == 0 ? jj : nt - 1 - jj;
+        const bool on = dir == 0 ? (j < i) : (j > i);
+        if (on) {
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            const double bv = xs[(j * 16 + kk * 4 + lr) * 16 + lc];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[s][kk], bv, acc, 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part[wave * 256 + (lr + 4 * r) * 16 + lc] = acc[r];
+      __syncthreads();
+      if (wave == 0) {
+        double4_t y = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const int k = kk * 4 + lr;
+          // forward: Dinv_i[lc][k]; backward: (Dinv_i')[lc][k] = Dinv_i[k][lc]
+          const double av = dir == 0 ? Dinv[(size_t)i * 256 + k * 16 + lc] : Dinv[(size_t)i * 256 + lc * 16 + k];
+          const int o = k * 16 + lc;
+          const double bv = xs[(i * 16 + k) * 16 + lc] + part[o] + part[256 + o] + part[512 + o] + part[768 + o];
+          y = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, y, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xs[(i * 16 + lr + 4 * r) * 16 + lc] = y[r];
+      }
+      __syncthreads();
     }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 4; ++r) tmp[(lr + 4 * r) * 16 + lc] = acc[r];
-    __syncthreads();
-    double4_t y = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      int k = kk * 4 + lr;
-      double av = Dinv[(size_t)i * 256 + lc * 16 + k];  // (Dinv_i')[lc][k] = Dinv_i[k][lc]
-      double bv = tmp[k * 16 + lc];
-      y = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, y, 0, 0, 0);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) xs[(i * 16 + lr + 4 * r) * 16 + lc] = y[r];
-    __syncthreads();
   }
-  for (int e = lane; e < n * 16; e += 64) {
+  for (int e = tid; e < n * 16; e += 256) {
     int row = e % n, col = e / n;
     Xb[(size_t)col * n + row] = xs[row * 16 + col];
   }
@@ -244,16 +256,23 @@ int kp_chol_solve_dev(kp_ctx* ctx, double* G_dev, double* C_dev, int W, int ncol
   double* Dinv = (double*)(ws + bG + bC);
   int* info = (int*)(ws + bG + bC + bD);
   size_t lds_chol = (size_t)2 * n * PS * 8;
-  size_t lds_trsm = ((size_t)n * 16 + 256) * 8;
-  if (lds_chol > 160 * 1024 - 4096 || lds_trsm > 160 * 1024) return ctx->fail(KP_ERR_ARG, "kp_fit_solve: W too large (max ~580)");
+  size_t lds_trsm = ((size_t)n * 16 + 1024) * 8;
+  if (lds_chol > 160 * 1024 - 4096 || lds_trsm > 160 * 1024 || n > 16 * 4 * TR_MAXJ) return ctx->fail(KP_ERR_ARG, "kp_fit_solve: W too large (max ~580)");
   int64_t tot = (int64_t)n * n + (int64_t)n * ncp;
   hipLaunchKernelGGL(kp_pad_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, G_dev, C_dev, W, ncols, n, ncp, Gp, Cp);
   KP_HIP(ctx, hipGetLastError());
-  KP_HIP(ctx, hipFuncSetAttribute((const void*)kp_chol_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_chol));
+  static size_t chol_lds_set = 0, trsm_lds_set = 0;
+  if (lds_chol > chol_lds_set) {
+    KP_HIP(ctx, hipFuncSetAttribute((const void*)kp_chol_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_chol));
+    chol_lds_set = lds_chol;
+  }
   hipLaunchKernelGGL(kp_chol_kernel, dim3(1), dim3(1024), lds_chol, ctx->stream, Gp, n, Dinv, info);
   KP_HIP(ctx, hipGetLastError());
-  KP_HIP(ctx, hipFuncSetAttribute((const void*)kp_trsm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_trsm));
-  hipLaunchKernelGGL(kp_trsm_kernel, dim3(ncp / 16), dim3(64), lds_trsm, ctx->stream, Gp, Dinv, n, Cp);
+  if (lds_trsm > trsm_lds_set) {
+    KP_HIP(ctx, hipFuncSetAttribute((const void*)kp_trsm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_trsm));
+    trsm_lds_set = lds_trsm;
+  }
+  hipLaunchKernelGGL(kp_trsm_kernel, dim3(ncp / 16), dim3(256), lds_trsm, ctx->stream, Gp, Dinv, n, Cp);
   KP_HIP(ctx, hipGetLastError());
   hipLaunchKernelGGL(kp_unpad_kernel, dim3((unsigned)(((int64_t)W * ncols + 255) / 256)), dim3(256), 0, ctx->stream, Cp, n, W, ncols, K_dev);
   KP_HIP(ctx, hipGetLastError());

@@ -426,7 +426,6 @@ int kp_gram3_launch(kp_ctx* ctx, const kp_basis* basis_c, const kp_snapshots* s,
   a.part = part;
   a.njobs = plan.njobs;
   const int grid = plan.nsuper * nsplit;
-  KP_HIP(ctx, hipMemsetAsync(GC_dev, 0, (size_t)2 * W * W * 8, ctx->stream));
   KP_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   KP_HIP(ctx, hipEventRecord(ctx->evp[0], ctx->stream));
   hipError_t e;
