@@ -65,7 +65,8 @@ __global__ __launch_bounds__(NTHR, 2) void kp_gram2_kernel(Gram2Args a) {
   const int D = a.D;
   const int Wp = a.Wp;
   // LDS (doubles): pow[2][(nrawrows*D + 1)][KT] (last row: ones) | psi[2][2 sides][KT][Wp]
-  const int pow_stride = (nrawrows * D + 1) * KT;
+  const int NID = nrawrows * D + 1;              // power-table entries per snapshot (last: the constant 1)
+  const int pow_stride = NID * KT;                // layout [snapshot][id]: lanes with different ids hit different banks
   const int psi_base = 2 * pow_stride;
   const int psi_stride = 2 * KT * Wp;
   const int trash = 2 * psi_stride;   // one spare row (offset from psi_base): target of masked-off column writes
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(NTHR, 2) void kp_gram2_kernel(Gram2Args a) {
 
   // ---- one-time LDS setup ----
   for (int e = tid; e < 2 * psi_stride + Wp; e += NTHR) sm[psi_base + e] = 0.0;   // padding columns stay zero
-  if (tid < 2 * KT) sm[(tid / KT) * pow_stride + nrawrows * D * KT + (tid % KT)] = 1.0;
+  if (tid < 2 * KT) sm[(tid / KT) * pow_stride + (tid % KT) * NID + nrawrows * D] = 1.0;
 
   // ---- lifting thread constants ----
   const int jl = tid & 15, combo = tid >> 4, ls = combo & (KT - 1), lside = (combo >> 3) & 1, half = combo >> 4;
@@ -101,11 +102,11 @@ __global__ __launch_bounds__(NTHR, 2) void kp_gram2_kernel(Gram2Args a) {
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
       const int id = (int)((r >> (8 * f)) & 255u);
-      foff[i][f] = (id == 255 ? nrawrows * D : lside * nzm * D + id) * KT + ls;
+      foff[i][f] = ls * NID + (id == 255 ? nrawrows * D : lside * nzm * D + id);
     }
     woff[i] = wok[i] ? (lside * KT + ls) * Wp + c : trash + jl;   // relative to the Psi buffer of the tile
   }
-  const int uoff = b.nzeta * D * KT + ls;        // + j*D*KT : u_j (e = 1) of snapshot ls
+  const int uoff = ls * NID + b.nzeta * D;        // + j*D : u_j (e = 1) of snapshot ls
   const bool lin = b.model_type == KP_MODEL_LINEAR;
   const int N = b.N, m = b.m;
 
@@ -127,10 +128,10 @@ __global__ __launch_bounds__(NTHR, 2) void kp_gram2_kernel(Gram2Args a) {
   };
   auto store_raw = [&](int buf, double x) {   // powers x^1..x^D
     if (is_loader) {
-      double* dst = sm + buf * pow_stride + (lr_ * D) * KT + lsn;
+      double* dst = sm + buf * pow_stride + lsn * NID + lr_ * D;
       double p = x;
       for (int e = 0; e < D; ++e) {
-        dst[e * KT] = p;
+        dst[e] = p;
         p *= x;
       }
     }
@@ -144,11 +145,11 @@ __global__ __launch_bounds__(NTHR, 2) void kp_gram2_kernel(Gram2Args a) {
     const double* T = sm + rb * pow_stride;
     vmask = (kt * KT + ls) < a.Ns ? 1.0 : 0.0;
     if (BM > 0) uv0 = T[uoff];
-    if (BM > 1) uv1 = T[uoff + D * KT];
-    if (BM > 2) uv2 = T[uoff + 2 * D * KT];
+    if (BM > 1) uv1 = T[uoff + D];
+    if (BM > 2) uv2 = T[uoff + 2 * D];
     if (BM == 0 && lin && half == 0 && jl < m) {   // [psi , u]  (Ksysid.m:1062)
       double* P = sm + psi_base + pb * psi_stride;
-      P[(lside * KT + ls) * Wp + N + jl] = T[uoff + jl * D * KT] * vmask;
+      P[(lside * KT + ls) * Wp + N + jl] = T[uoff + jl * D] * vmask;
     }
   };
   auto lift_read = [&](int i, int rb) {

@@ -59,7 +59,8 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
   const int RS = a.RS;
   const int UOFF = 2 * a.Np4 + 4;
   // LDS (doubles): pow[2][(nrawrows*D + 1)][KT3] (last row: ones) | psi[2][KT3][RS] | spare row
-  const int pow_stride = (nrawrows * D + 1) * KT3;
+  const int NID = nrawrows * D + 1;              // power-table entries per snapshot (last: the constant 1)
+  const int pow_stride = NID * KT3;                // layout [snapshot][id]: lanes with different ids hit different banks
   const int psi_base = 2 * pow_stride;
   const int psi_stride = KT3 * RS;
   const int trash = 2 * psi_stride;
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
 
   // ---- one-time LDS setup: Psi buffers zero (padding columns and the zero group stay zero) ----
   for (int e = tid; e < 2 * psi_stride + RS; e += 256) sm[psi_base + e] = 0.0;
-  if (tid < 2 * KT3) sm[(tid / KT3) * pow_stride + nrawrows * D * KT3 + (tid % KT3)] = 1.0;
+  if (tid < 2 * KT3) sm[(tid / KT3) * pow_stride + (tid % KT3) * NID + nrawrows * D] = 1.0;
 
   // ---- lifting thread constants ----
   const int jl = tid & 15, combo = tid >> 4, ls = combo & (KT3 - 1), lside = combo >> 3;
@@ -96,11 +97,11 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
       const int id = (int)((r >> (8 * f)) & 255u);
-      foff[i][f] = (id == 255 ? nrawrows * D : lside * nzm * D + id) * KT3 + ls;
+      foff[i][f] = ls * NID + (id == 255 ? nrawrows * D : lside * nzm * D + id);
     }
     woff[i] = wok[i] ? ls * RS + lside * a.Np4 + c : trash + jl;
   }
-  const int uoff_pow = b.nzeta * D * KT3 + ls;     // + j*D*KT3 : u_j (e = 1) of snapshot ls in the power table
+  const int uoff_pow = ls * NID + b.nzeta * D;     // + j*D : u_j (e = 1) of snapshot ls in the power table
 
   const int64_t kt0 = (int64_t)split * a.ktiles_per_split;
   const int64_t ktiles_total = (a.Ns + KT3 - 1) / KT3;
@@ -120,10 +121,10 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
   };
   auto store_raw = [&](int buf, double x) {
     if (is_loader) {
-      double* dst = sm + buf * pow_stride + (lr_ * D) * KT3 + lsn;
+      double* dst = sm + buf * pow_stride + lsn * NID + lr_ * D;
       double p = x;
       for (int e = 0; e < D; ++e) {
-        dst[e * KT3] = p;
+        dst[e] = p;
         p *= x;
       }
     }
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
     vmask = (kt * KT3 + ls) < a.Ns ? 1.0 : 0.0;
     if (lside == 0 && jl < BM) {                    // u_j of this snapshot next to the Psi row
       double* P = sm + psi_base + pb * psi_stride;
-      P[ls * RS + UOFF + jl] = T[uoff_pow + jl * D * KT3] * vmask;
+      P[ls * RS + UOFF + jl] = T[uoff_pow + jl * D] * vmask;
     }
   };
   auto lift_read = [&](int i, int rb) {
