@@ -44,33 +44,70 @@ struct kp_mpc {
   size_t io_problems = 0;
 };
 
-// ---- wave-level helpers (64 lanes) -------------------------------------------------------
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+// ---- wave-level helpers (64 lanes): DPP inside 16-lane rows, v_readlane across the 4 rows ----
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+  int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
 }
+template <int CTRL>
+__device__ __forceinline__ int dpp_movi(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+}
+__device__ __forceinline__ double lane_get(double v, int lane) {
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+// quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E, row_half_mirror = 0x141, row_mirror = 0x140
+__device__ __forceinline__ double wave_sum(double v) {
+  v += dpp_mov<0xB1>(v);
+  v += dpp_mov<0x4E>(v);
+  v += dpp_mov<0x141>(v);
+  v += dpp_mov<0x140>(v);                 // every lane: sum of its 16-lane row
+  return (lane_get(v, 0) + lane_get(v, 16)) + (lane_get(v, 32) + lane_get(v, 48));
+}
+#define KP_ARGSTEP(CTRL, CMP)                                   \
+  {                                                             \
+    double ov = dpp_mov<CTRL>(v);                               \
+    int oi = dpp_movi<CTRL>(idx);                               \
+    if (ov CMP v || (ov == v && oi < idx)) {                    \
+      v = ov;                                                   \
+      idx = oi;                                                 \
+    }                                                           \
+  }
 __device__ __forceinline__ void wave_argmax(double& v, int& idx) {
+  KP_ARGSTEP(0xB1, >) KP_ARGSTEP(0x4E, >) KP_ARGSTEP(0x141, >) KP_ARGSTEP(0x140, >)
+  double bv = lane_get(v, 0);
+  int bi = __builtin_amdgcn_readlane(idx, 0);
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    double ov = __shfl_xor(v, o, 64);
-    int oi = __shfl_xor(idx, o, 64);
-    if (ov > v || (ov == v && oi < idx)) {
-      v = ov;
-      idx = oi;
+  for (int r = 16; r < 64; r += 16) {
+    double ov = lane_get(v, r);
+    int oi = __builtin_amdgcn_readlane(idx, r);
+    if (ov > bv || (ov == bv && oi < bi)) {
+      bv = ov;
+      bi = oi;
     }
   }
+  v = bv;
+  idx = bi;
 }
 __device__ __forceinline__ void wave_argmin(double& v, int& idx) {
+  KP_ARGSTEP(0xB1, <) KP_ARGSTEP(0x4E, <) KP_ARGSTEP(0x141, <) KP_ARGSTEP(0x140, <)
+  double bv = lane_get(v, 0);
+  int bi = __builtin_amdgcn_readlane(idx, 0);
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    double ov = __shfl_xor(v, o, 64);
-    int oi = __shfl_xor(idx, o, 64);
-    if (ov < v || (ov == v && oi < idx)) {
-      v = ov;
-      idx = oi;
+  for (int r = 16; r < 64; r += 16) {
+    double ov = lane_get(v, r);
+    int oi = __builtin_amdgcn_readlane(idx, r);
+    if (ov < bv || (ov == bv && oi < bi)) {
+      bv = ov;
+      bi = oi;
     }
   }
+  v = bv;
+  idx = bi;
 }
 
 // Constraint matrix in ELL form: row r has K slots (val[k*mr + r], col[k*mr + r]); unused slots
@@ -85,7 +122,7 @@ struct EllMat {
 
 // LDS scratch of the QP solver (doubles): Hinv n*n | HN n*n | Sinv n*n | x,hp,r,lam,d,zd,ap,f: 8n |
 // act: n ints | isact: mr bytes
-__host__ __device__ inline int qp_lds_doubles(int n, int mr) { return 3 * n * n + 8 * n + (n + 1) / 2 + (mr + 7) / 8 + 4; }
+__host__ __device__ inline int qp_lds_doubles(int n, int mr) { return 3 * n * n + 9 * n + 2 * ((n + 1) / 2) + (mr + 7) / 8 + 8; }
 
 // Wave-local synchronisation: LDS operations of one wave complete in issue order, so lanes only
 // need the compiler not to reorder across this point (usable inside multi-wave workgroups).
@@ -114,7 +151,9 @@ __device__ int qp_goldfarb_idnani(const double* Hq, const double* f, const EllMa
   double* zd = d + n;
   double* ap = zd + n;
   double* fl = ap + n;
-  int* act = (int*)(fl + n);
+  double* apv = fl + n;                      // sparse a_p values (K <= n)
+  int* apc = (int*)(apv + n);                // and columns
+  int* act = apc + n + (n & 1);
   unsigned char* isact = (unsigned char*)(act + n + (n & 1));
 
   // ---- Hinv by in-place Gauss-Jordan (SPD: no pivoting) ----
@@ -190,16 +229,19 @@ __device__ int qp_goldfarb_idnani(const double* Hq, const double* f, const EllMa
     }
     const int p = bestp;
     const double bp = bvec[p];
-    // sparse a_p: (col_k, val_k), k < K (wave-uniform broadcast loads); dense copy in ap for dot products
+    // sparse a_p: (col_k, val_k), k < K, staged in LDS (apv/apc) for the loops below; dense copy in ap
     if (lane < A.K) {
       double v = A.val[lane * mr + p];
-      if (v != 0.0) ap[A.col[lane * mr + p]] = v;
+      int cidx = A.col[lane * mr + p];
+      apv[lane] = v;
+      apc[lane] = cidx;
+      if (v != 0.0) ap[cidx] = v;
     }
     WSYNC();
     double app_l = 0.0;
     for (int i = lane; i < n; i += 64) {
       double s = 0.0;
-      for (int k = 0; k < A.K; ++k) s += A.val[k * mr + p] * Hinv[i + A.col[k * mr + p] * n];
+      for (int k = 0; k < A.K; ++k) s += apv[k] * Hinv[i + apc[k] * n];
       hp[i] = s;
       app_l += s * ap[i];
     }
@@ -212,7 +254,7 @@ __device__ int qp_goldfarb_idnani(const double* Hq, const double* f, const EllMa
       // d = N' Hinv a_p ; r = Sinv d ; zd = hp - HN r
       for (int c = lane; c < q; c += 64) {
         double s = 0.0;
-        for (int k = 0; k < A.K; ++k) s += A.val[k * mr + p] * HN[A.col[k * mr + p] + c * n];
+        for (int k = 0; k < A.K; ++k) s += apv[k] * HN[apc[k] + c * n];
         d[c] = s;
       }
       WSYNC();
@@ -325,7 +367,7 @@ __device__ int qp_goldfarb_idnani(const double* Hq, const double* f, const EllMa
       }
     }
     // clear the dense copy of a_p
-    if (lane < A.K) ap[A.col[lane * mr + p]] = 0.0;
+    if (lane < A.K) ap[apc[lane]] = 0.0;
     WSYNC();
     if (fail) break;
   }
