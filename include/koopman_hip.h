@@ -133,6 +133,12 @@ int kp_fit_lasso(kp_ctx* ctx, const double* G, const double* C, int W, int ncols
 int kp_fit(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* snaps, const double* lasso,
            int n_lasso, double* K_out);
 int kp_fit_get_K(kp_ctx* ctx, int index, int W, double* K);
+/* kp_fit with K_out == NULL and one least-squares value is ASYNCHRONOUS: it returns when the work is
+ * enqueued; the solve runs on a second HIP stream so that it overlaps the fused Gram kernel of the
+ * next kp_fit call (sweeps over many fits: lasso grids, random systems).  kp_synchronize waits for
+ * everything in flight and returns KP_ERR_NOT_SPD if a deferred fit failed; kp_fit_get_K,
+ * kp_fit_gram, kp_fit_solve and kp_destroy synchronise implicitly. */
+int kp_synchronize(kp_ctx* ctx);
 
 /* Model extraction with the M-projection of get_model (Ksysid.m:1206-1225): from K and
  * the Grams (no second pass over the data): L'L = [A B] G [A B]', L'R = [A B] C(:,1:N).

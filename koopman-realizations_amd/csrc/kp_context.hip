@@ -47,6 +47,12 @@ extern "C" int kp_create(int device_id, kp_ctx** out) {
     return KP_ERR_HIP;
   }
   for (int i = 0; i < 6; ++i) (void)hipEventCreate(&c->evp[i]);
+  (void)hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
+  (void)hipEventCreateWithFlags(&c->ev_gram_done, hipEventDisableTiming);
+  (void)hipEventCreateWithFlags(&c->ev_pad_done, hipEventDisableTiming);
+  (void)hipEventCreate(&c->ev_solve0);
+  (void)hipEventCreate(&c->ev_solve1);
+  if (hipMalloc((void**)&c->sticky_info, sizeof(int)) == hipSuccess) (void)hipMemset(c->sticky_info, 0, sizeof(int));
   hipDeviceProp_t p;
   if (hipGetDeviceProperties(&p, device_id) == hipSuccess) {
     c->num_cu = p.multiProcessorCount;
@@ -61,8 +67,15 @@ extern "C" int kp_destroy(kp_ctx* c) {
   if (!c) return KP_OK;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
+  if (c->stream2) (void)hipStreamSynchronize(c->stream2);
   for (int i = 0; i < 8; ++i)
     if (c->ws[i]) (void)hipFree(c->ws[i]);
+  if (c->sticky_info) (void)hipFree(c->sticky_info);
+  if (c->ev_gram_done) (void)hipEventDestroy(c->ev_gram_done);
+  if (c->ev_pad_done) (void)hipEventDestroy(c->ev_pad_done);
+  if (c->ev_solve0) (void)hipEventDestroy(c->ev_solve0);
+  if (c->ev_solve1) (void)hipEventDestroy(c->ev_solve1);
+  if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->Kres) (void)hipFree(c->Kres);
   if (c->GC) (void)hipFree(c->GC);
   for (int i = 0; i < 6; ++i)

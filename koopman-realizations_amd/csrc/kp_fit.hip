@@ -8,10 +8,12 @@
 //   kp_trsm_kernel     one wave per 16 right-hand sides: forward + backward substitution by
 //                      blocks with v_mfma_f64_16x16x4_f64, X block resident in LDS
 #include <cmath>
+#include <cstdlib>
 
 #include "kp_internal.h"
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
+extern "C" int kp_synchronize(kp_ctx* ctx);
 
 __global__ void kp_pad_kernel(const double* __restrict__ G, const double* __restrict__ C, int W, int ncols, int n, int ncp,
                               double* __restrict__ Gp, double* __restrict__ Cp) {
@@ -37,7 +39,8 @@ __global__ void kp_unpad_kernel(const double* __restrict__ Xp, int n, int W, int
 
 #define PS 17  // LDS row stride of the 16-wide panels
 
-__global__ __launch_bounds__(1024) void kp_chol_kernel(double* __restrict__ A, int n, double* __restrict__ Dinv, int* __restrict__ info) {
+__global__ __launch_bounds__(1024) void kp_chol_kernel(double* __restrict__ A, int n, double* __restrict__ Dinv, int* __restrict__ info,
+                                                       int* __restrict__ sticky) {
   extern __shared__ double sm[];
   __shared__ double D[16][PS];
   __shared__ double Di[16][PS];
@@ -156,7 +159,10 @@ __global__ __launch_bounds__(1024) void kp_chol_kernel(double* __restrict__ A, i
     }
     __syncthreads();
   }
-  if (tid == 0) *info = bad;
+  if (tid == 0) {
+    *info = bad;
+    if (bad && sticky) *sticky = 1;
+  }
 }
 
 // Forward + backward block substitution for 16 right-hand sides by a 4-wave workgroup.
@@ -246,7 +252,9 @@ __global__ __launch_bounds__(256) void kp_trsm_kernel(const double* __restrict__
 }
 
 // G_dev, C_dev: W x W / W x ncols column-major on the device (not modified); K_dev: W x ncols.
-int kp_chol_solve_dev(kp_ctx* ctx, double* G_dev, double* C_dev, int W, int ncols, double* K_dev) {
+int kp_chol_solve_dev(kp_ctx* ctx, double* G_dev, double* C_dev, int W, int ncols, double* K_dev, hipStream_t st, hipEvent_t pad_done,
+                      int* sticky) {
+  if (!st) st = ctx->stream;
   const int n = (W + 15) / 16 * 16, ncp = (ncols + 15) / 16 * 16;
   size_t bG = (size_t)n * n * 8, bC = (size_t)n * ncp * 8, bD = (size_t)(n / 16) * 256 * 8;
   char* ws = (char*)ctx->workspace(5, bG + bC + bD + 64);
@@ -259,22 +267,23 @@ int kp_chol_solve_dev(kp_ctx* ctx, double* G_dev, double* C_dev, int W, int ncol
   size_t lds_trsm = ((size_t)n * 16 + 1024) * 8;
   if (lds_chol > 160 * 1024 - 4096 || lds_trsm > 160 * 1024 || n > 16 * 4 * TR_MAXJ) return ctx->fail(KP_ERR_ARG, "kp_fit_solve: W too large (max ~580)");
   int64_t tot = (int64_t)n * n + (int64_t)n * ncp;
-  hipLaunchKernelGGL(kp_pad_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, G_dev, C_dev, W, ncols, n, ncp, Gp, Cp);
+  hipLaunchKernelGGL(kp_pad_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, G_dev, C_dev, W, ncols, n, ncp, Gp, Cp);
   KP_HIP(ctx, hipGetLastError());
+  if (pad_done) KP_HIP(ctx, hipEventRecord(pad_done, st));
   static size_t chol_lds_set = 0, trsm_lds_set = 0;
   if (lds_chol > chol_lds_set) {
     KP_HIP(ctx, hipFuncSetAttribute((const void*)kp_chol_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_chol));
     chol_lds_set = lds_chol;
   }
-  hipLaunchKernelGGL(kp_chol_kernel, dim3(1), dim3(1024), lds_chol, ctx->stream, Gp, n, Dinv, info);
+  hipLaunchKernelGGL(kp_chol_kernel, dim3(1), dim3(1024), lds_chol, st, Gp, n, Dinv, info, sticky);
   KP_HIP(ctx, hipGetLastError());
   if (lds_trsm > trsm_lds_set) {
     KP_HIP(ctx, hipFuncSetAttribute((const void*)kp_trsm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_trsm));
     trsm_lds_set = lds_trsm;
   }
-  hipLaunchKernelGGL(kp_trsm_kernel, dim3(ncp / 16), dim3(256), lds_trsm, ctx->stream, Gp, Dinv, n, Cp);
+  hipLaunchKernelGGL(kp_trsm_kernel, dim3(ncp / 16), dim3(256), lds_trsm, st, Gp, Dinv, n, Cp);
   KP_HIP(ctx, hipGetLastError());
-  hipLaunchKernelGGL(kp_unpad_kernel, dim3((unsigned)(((int64_t)W * ncols + 255) / 256)), dim3(256), 0, ctx->stream, Cp, n, W, ncols, K_dev);
+  hipLaunchKernelGGL(kp_unpad_kernel, dim3((unsigned)(((int64_t)W * ncols + 255) / 256)), dim3(256), 0, st, Cp, n, W, ncols, K_dev);
   KP_HIP(ctx, hipGetLastError());
   return KP_OK;
 }
@@ -332,7 +341,10 @@ extern "C" int kp_fit_gram(kp_ctx* ctx, const kp_basis* basis, const kp_snapshot
   if (!ctx || !basis || !snaps) return ctx ? ctx->fail(KP_ERR_ARG, "kp_fit_gram: NULL handle") : KP_ERR_ARG;
   KP_HIP(ctx, hipSetDevice(ctx->device));
   const int W = basis->dev.W;
-  int rc = ensure_gc(ctx, W);
+  int rc = ctx->async_pending ? kp_synchronize(ctx) : KP_OK;
+  if (rc) return rc;
+  ctx->reserve_cus = 0;
+  rc = ensure_gc(ctx, W);
   if (rc) return rc;
   rc = kp_gram_dispatch(ctx, basis, snaps, ctx->GC);
   if (rc) return rc;
@@ -347,6 +359,10 @@ extern "C" int kp_fit_gram(kp_ctx* ctx, const kp_basis* basis, const kp_snapshot
 extern "C" int kp_fit_solve(kp_ctx* ctx, const double* G, const double* C, int W, int ncols, double* K) {
   if (!ctx || !G || !C || !K || W < 1 || ncols < 1) return ctx ? ctx->fail(KP_ERR_ARG, "kp_fit_solve: bad argument") : KP_ERR_ARG;
   KP_HIP(ctx, hipSetDevice(ctx->device));
+  if (ctx->async_pending) {
+    int rc0 = kp_synchronize(ctx);
+    if (rc0) return rc0;
+  }
   size_t bG = (size_t)W * W * 8, bC = (size_t)W * ncols * 8;
   char* ws = (char*)ctx->workspace(6, bG + 2 * bC);
   if (!ws) return ctx->fail(KP_ERR_HIP, "kp_fit_solve: out of device memory");
@@ -378,6 +394,33 @@ extern "C" int kp_fit(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* sn
   int rc = ensure_gc(ctx, W);
   if (!rc) rc = ensure_kres(ctx, W, n_lasso);
   if (rc) return rc;
+  const bool all_ls = [&] {
+    for (int i = 0; i < n_lasso; ++i)
+      if (lasso && lasso[i] < 1e6) return false;
+    return true;
+  }();
+  if (!K_out && n_lasso == 1 && all_ls && ctx->stream2 && ctx->sticky_info && !getenv("KP_NO_ASYNC")) {
+    // ---- asynchronous pipeline: this fit's solve (stream2) overlaps the next fit's Gram (stream) ----
+    // G|C is rewritten by the next Gram's reduction: it must wait until this solve has copied it (pad kernel)
+    if (ctx->pad_pending) KP_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_pad_done, 0));
+    ctx->reserve_cus = 24;
+    rc = kp_gram_dispatch(ctx, basis, snaps, ctx->GC);
+    if (rc) return rc;
+    KP_HIP(ctx, hipEventRecord(ctx->ev_gram_done, ctx->stream));
+    KP_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_gram_done, 0));
+    KP_HIP(ctx, hipEventRecord(ctx->ev_solve0, ctx->stream2));
+    rc = kp_chol_solve_dev(ctx, ctx->GC, ctx->GC + (size_t)W * W, W, W, ctx->Kres, ctx->stream2, ctx->ev_pad_done, ctx->sticky_info);
+    if (rc) return rc;
+    KP_HIP(ctx, hipEventRecord(ctx->ev_solve1, ctx->stream2));
+    ctx->pad_pending = true;
+    ctx->async_pending = true;
+    return KP_OK;
+  }
+  if (ctx->async_pending) {
+    rc = kp_synchronize(ctx);
+    if (rc) return rc;
+  }
+  ctx->reserve_cus = 0;
   rc = kp_gram_dispatch(ctx, basis, snaps, ctx->GC);  // records ev0/ev1 around gram+reduce
   if (rc) return rc;
   double* Gd = ctx->GC;
@@ -418,9 +461,32 @@ extern "C" int kp_fit(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* sn
   return KP_OK;
 }
 
+extern "C" int kp_synchronize(kp_ctx* ctx) {
+  if (!ctx) return KP_ERR_ARG;
+  KP_HIP(ctx, hipSetDevice(ctx->device));
+  KP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->stream2) KP_HIP(ctx, hipStreamSynchronize(ctx->stream2));
+  int bad = 0;
+  if (ctx->async_pending) {
+    collect_gram_timers(ctx, false);
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, ctx->ev_solve0, ctx->ev_solve1) == hipSuccess) ctx->timers[1] = ms;
+    KP_HIP(ctx, hipMemcpy(&bad, ctx->sticky_info, sizeof(int), hipMemcpyDeviceToHost));
+    if (bad) KP_HIP(ctx, hipMemset(ctx->sticky_info, 0, sizeof(int)));
+  }
+  ctx->async_pending = false;
+  ctx->pad_pending = false;
+  if (bad) return ctx->fail(KP_ERR_NOT_SPD, "kp_synchronize: a deferred fit hit a Gram matrix that is not numerically positive definite");
+  return KP_OK;
+}
+
 extern "C" int kp_fit_get_K(kp_ctx* ctx, int index, int W, double* K) {
   if (!ctx || !K || index < 0 || index >= ctx->Kres_n || W != ctx->Kres_W) return ctx ? ctx->fail(KP_ERR_ARG, "kp_fit_get_K: bad argument") : KP_ERR_ARG;
   KP_HIP(ctx, hipSetDevice(ctx->device));
+  {
+    int rc = kp_synchronize(ctx);
+    if (rc) return rc;
+  }
   KP_HIP(ctx, hipMemcpy(K, ctx->Kres + (size_t)index * W * W, (size_t)W * W * 8, hipMemcpyDeviceToHost));
   return KP_OK;
 }

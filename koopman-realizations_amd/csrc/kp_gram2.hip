@@ -418,7 +418,7 @@ int kp_gram2_launch(kp_ctx* ctx, const kp_basis* basis_c, const kp_snapshots* s,
   if (lds > 160 * 1024 || (uint32_t)(2 * KT * plan.Wp) > 65535u)
     return ctx->fail(KP_ERR_ARG, "kp_fit_gram: dictionary too wide for the LDS-staged tile (W > ~580)");
   int64_t ktiles = (s->Ns + KT - 1) / KT;
-  int ncu = ctx->num_cu > 0 ? ctx->num_cu : 256;
+  int ncu = std::max(8, (ctx->num_cu > 0 ? ctx->num_cu : 256) - ctx->reserve_cus);
   int nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(ktiles, ncu / plan.nsuper > 0 ? ncu / plan.nsuper : 1));
   int kps = (int)((ktiles + nsplit - 1) / nsplit);
   if (kps < 1) kps = 1;

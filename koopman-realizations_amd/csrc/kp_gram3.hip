@@ -402,7 +402,7 @@ int kp_gram3_launch(kp_ctx* ctx, const kp_basis* basis_c, const kp_snapshots* s,
   int ncu = ctx->num_cu > 0 ? ctx->num_cu : 256;
   int wg_per_cu = 2;                                  // __launch_bounds__(256, 2): two workgroups share a CU
   if (const char* ov = getenv("KP_GRAM3_WGPCU")) wg_per_cu = std::max(1, atoi(ov));
-  int64_t slots = (int64_t)ncu * wg_per_cu;
+  int64_t slots = (int64_t)std::max(8, ncu - ctx->reserve_cus) * wg_per_cu;
   int nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(ktiles, slots / plan.nsuper > 0 ? slots / plan.nsuper : 1));
   int kps = (int)((ktiles + nsplit - 1) / nsplit);
   if (kps < 1) kps = 1;

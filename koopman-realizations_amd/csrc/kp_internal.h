@@ -16,6 +16,12 @@ struct kp_ctx {
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipEvent_t evp[6] = {nullptr};   // gram start, gram end, reduce end, solve end, spare x2
+  // asynchronous fit pipeline (kp_fit with K_out == NULL): Gram on `stream`, solve on `stream2`
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev_gram_done = nullptr, ev_pad_done = nullptr, ev_solve0 = nullptr, ev_solve1 = nullptr;
+  bool pad_pending = false, async_pending = false;
+  int* sticky_info = nullptr;       // device word: set by any deferred factorisation that hit a non-positive pivot
+  int reserve_cus = 0;              // CUs left free by the Gram grid so the solve of the previous fit can run beside it
   int num_cu = 0;
   int64_t hbm_bytes = 0;
   std::string name;
@@ -161,6 +167,7 @@ inline int kp_gram_dispatch(kp_ctx* ctx, const kp_basis* basis, const kp_snapsho
   if (kp_gram3_applicable(basis)) return kp_gram3_launch(ctx, basis, s, GC_dev);
   return kp_gram2_applicable(basis) ? kp_gram2_launch(ctx, basis, s, GC_dev) : kp_gram_launch(ctx, basis, s, GC_dev);
 }
-int kp_chol_solve_dev(kp_ctx* ctx, double* G_dev, double* C_dev, int W, int ncols, double* K_dev);
+int kp_chol_solve_dev(kp_ctx* ctx, double* G_dev, double* C_dev, int W, int ncols, double* K_dev, hipStream_t st = nullptr,
+                      hipEvent_t pad_done = nullptr, int* sticky = nullptr);
 int kp_lasso_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, int W, int ncols, double t,
                  int max_iter, double tol, double* K_dev, int* iters);

@@ -256,6 +256,10 @@ extern "C" int kp_fit_lasso(kp_ctx* ctx, const double* G, const double* C, int W
                             double* K, int* iters) {
   if (!ctx || !G || !C || !K || W < 1 || ncols < 1 || !(t >= 0.0)) return ctx ? ctx->fail(KP_ERR_ARG, "kp_fit_lasso: bad argument") : KP_ERR_ARG;
   KP_HIP(ctx, hipSetDevice(ctx->device));
+  if (ctx->async_pending) {
+    int rc0 = kp_synchronize(ctx);
+    if (rc0) return rc0;
+  }
   size_t bG = (size_t)W * W * 8, bC = (size_t)W * ncols * 8;
   char* ws = (char*)ctx->workspace(6, bG + 2 * bC);
   if (!ws) return ctx->fail(KP_ERR_HIP, "kp_fit_lasso: out of device memory");
@@ -292,6 +296,10 @@ extern "C" int kp_model_project(kp_ctx* ctx, const double* K, const double* G, c
   if (!ctx || !K || !G || !C || !A_out || !B_out || !M_out || N < 1 || m < 0)
     return ctx ? ctx->fail(KP_ERR_ARG, "kp_model_project: bad argument") : KP_ERR_ARG;
   KP_HIP(ctx, hipSetDevice(ctx->device));
+  if (ctx->async_pending) {
+    int rc0 = kp_synchronize(ctx);
+    if (rc0) return rc0;
+  }
   const int W = N + m;
   hipStream_t s = ctx->stream;
   size_t bW = (size_t)W * W * 8, bN = (size_t)N * N * 8;

@@ -39,6 +39,10 @@ class Context:
     def stream(self):
         return F.lib().kp_stream(self._h)
 
+    def synchronize(self):
+        """Waits for asynchronous fits (fit(..., fetch=False)); raises if one of them failed."""
+        F.check(F.lib().kp_synchronize(self._h), self._h)
+
     def close(self):
         if self._h:
             F.lib().kp_destroy(self._h)

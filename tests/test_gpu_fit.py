@@ -144,3 +144,35 @@ def test_fit_synthetic_config2(ctx):
     Px, Py = ko.px_py(dic, p)
     Kref = ko.koopman_ls(Px, Py)
     assert np.abs(K - Kref).max() <= 1e-9 * np.abs(Kref).max()
+
+
+def test_async_fit_pipeline_matches_synchronous_result(ctx):
+    """kp_fit with K_out = NULL is asynchronous (solve of fit i overlaps the Gram of fit i+1 on a
+    second stream); results and error reporting must equal the synchronous path."""
+    dic = ko.build_dictionary("bilinear", 6, 3, ["poly"], [3])
+    b = make_basis(ctx, dic)
+    sets = [synth_pairs(20000 + 1000 * i, seed=20 + i) for i in range(3)]
+    snaps = [kra.Snapshots(ctx, p["alpha"], p["beta"], p["u"]) for p in sets]
+    Ksync = [kra.fit(ctx, b, s)[0] for s in snaps]
+    W = b.W
+    for s, Kref in zip(snaps, Ksync):           # back-to-back async fits: each K fetched after the next was enqueued
+        kra.fit(ctx, b, s, fetch=False)
+        K = np.zeros((W, W), order="F")
+        F.check(F.lib().kp_fit_get_K(ctx.handle, 0, W, F.dptr(K)), ctx.handle)
+        # the async path leaves CUs free for the overlapped solve => different snapshot split, different
+        # (still fixed) summation order of the partial Grams: equal to rounding, not bitwise
+        assert np.abs(K - Kref).max() <= 1e-11 * np.abs(Kref).max()
+    for s in snaps:
+        kra.fit(ctx, b, s, fetch=False)
+    ctx.synchronize()
+    K = np.zeros((W, W), order="F")
+    F.check(F.lib().kp_fit_get_K(ctx.handle, 0, W, F.dptr(K)), ctx.handle)
+    assert np.abs(K - Ksync[-1]).max() <= 1e-11 * np.abs(Ksync[-1]).max()
+    # deferred failure: a rank-deficient dictionary is reported by kp_synchronize
+    z = np.zeros((64, 6)); u = np.random.default_rng(0).uniform(-1, 1, (64, 3))
+    bad = kra.Snapshots(ctx, z, z, u)           # all-zero states: Gram is singular
+    kra.fit(ctx, b, bad, fetch=False)
+    with pytest.raises(kra.KoopmanHipError) as e:
+        ctx.synchronize()
+    assert e.value.code == F.KP_ERR_NOT_SPD
+    ctx.synchronize()                            # the sticky flag was cleared
