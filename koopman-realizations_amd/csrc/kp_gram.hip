@@ -111,24 +111,42 @@ __global__ __launch_bounds__(256, 1) void kp_gram_kernel(GramArgs a) {
 
   // raw tile loader: thread e < nrawrows*KT handles (row r, snapshot s);
   // rows: [alpha(nzeta) u(m) | beta(nzeta) u(m)]
-  const bool is_loader = tid < nrawrows * KT;
-  const int lr_ = tid / KT, lsn = tid % KT;
-  const double* lsrc = nullptr;
-  if (is_loader) {
-    int rr = lr_ % nzm;
-    lsrc = rr < b.nzeta ? ((lr_ < nzm ? a.alpha : a.beta) + (int64_t)rr * a.Ns) : (a.u + (int64_t)(rr - b.nzeta) * a.Ns);
+  // raw loader: value e = tid + j*256 of the tile -> (row e / KT, snapshot e % KT), up to LR per thread
+  constexpr int LR = 3;
+  struct RawRegs { double v[LR]; };
+  bool ld_on[LR];
+  int ld_r[LR], ld_s[LR];
+  const double* ld_src[LR];
+#pragma unroll
+  for (int j = 0; j < LR; ++j) {
+    const int e = tid + j * 256;
+    ld_on[j] = e < nrawrows * KT;
+    ld_r[j] = e / KT;
+    ld_s[j] = e % KT;
+    ld_src[j] = nullptr;
+    if (ld_on[j]) {
+      int rr = ld_r[j] % nzm;
+      ld_src[j] = rr < b.nzeta ? ((ld_r[j] < nzm ? a.alpha : a.beta) + (int64_t)rr * a.Ns) : (a.u + (int64_t)(rr - b.nzeta) * a.Ns);
+    }
   }
-  auto load_raw = [&](int64_t kt) -> double {
-    int64_t i = kt * KT + lsn;
-    return (is_loader && i < a.Ns) ? lsrc[i] : 0.0;
+  auto load_raw = [&](int64_t kt) -> RawRegs {
+    RawRegs x;
+#pragma unroll
+    for (int j = 0; j < LR; ++j) {
+      int64_t i = kt * KT + ld_s[j];
+      x.v[j] = (ld_on[j] && i < a.Ns) ? ld_src[j][i] : 0.0;
+    }
+    return x;
   };
-  auto store_raw = [&](int buf, double x) {   // powers x^1..x^D
-    if (is_loader) {
-      double* dst = sm + L.pow + ((buf * nrawrows + lr_) * D) * KT + lsn;
-      double p = x;
+  auto store_raw = [&](int buf, const RawRegs& x) {   // powers x^1..x^D
+#pragma unroll
+    for (int j = 0; j < LR; ++j) {
+      if (!ld_on[j]) continue;
+      double* dst = sm + L.pow + ((buf * nrawrows + ld_r[j]) * D) * KT + ld_s[j];
+      double p = x.v[j];
       for (int e = 0; e < D; ++e) {
         dst[e * KT] = p;
-        p *= x;
+        p *= x.v[j];
       }
     }
   };
@@ -209,7 +227,7 @@ __global__ __launch_bounds__(256, 1) void kp_gram_kernel(GramArgs a) {
 
   for (int t = 0; t < nkt; ++t) {
     // (1) prefetch raw tile t+2 into a register
-    double rawreg = load_raw(kt0 + t + 2);
+    const RawRegs rawreg = load_raw(kt0 + t + 2);
     // (2) lift tile t+1 into the other Psi buffer
 #if KP_ABLATE != 1
     if (t + 1 < nkt) lift_tile((t + 1) & 1, (t + 1) & 1, kt0 + t + 1);
@@ -390,7 +408,7 @@ int kp_gram_launch(kp_ctx* ctx, const kp_basis* basis_c, const kp_snapshots* s, 
   GramLds L = gram_lds(b, plan.Wp, D, pcs_in_lds);
   size_t lds = (size_t)L.total * sizeof(double);
   if (lds > 160 * 1024) return ctx->fail(KP_ERR_ARG, "kp_fit_gram: dictionary too wide for the LDS-staged tile (W > ~580)");
-  if (2 * (b.nzeta + b.m) * KT > 256) return ctx->fail(KP_ERR_ARG, "kp_fit_gram: too many raw columns");
+  if (2 * (b.nzeta + b.m) * KT > 3 * 256) return ctx->fail(KP_ERR_ARG, "kp_fit_gram: too many raw columns");
   int64_t ktiles = (s->Ns + KT - 1) / KT;
   int ncu = ctx->num_cu > 0 ? ctx->num_cu : 256;
   int nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(ktiles, ncu / plan.nsuper > 0 ? ncu / plan.nsuper : 1));

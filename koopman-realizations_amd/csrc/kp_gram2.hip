@@ -115,24 +115,42 @@ __global__ __launch_bounds__(NTHR, 2) void kp_gram2_kernel(Gram2Args a) {
   const int nkt = (int)max((int64_t)0, min((int64_t)a.ktiles_per_split, ktiles_total - kt0));
 
   // ---- raw loader (thread -> (row, snapshot)); rows: [alpha(nzeta) u(m) | beta(nzeta) u(m)] ----
-  const bool is_loader = tid < nrawrows * KT;
-  const int lr_ = tid / KT, lsn = tid % KT;
-  const double* lsrc = nullptr;
-  if (is_loader) {
-    int rr = lr_ % nzm;
-    lsrc = rr < b.nzeta ? ((lr_ < nzm ? a.alpha : a.beta) + (int64_t)rr * a.Ns) : (a.u + (int64_t)(rr - b.nzeta) * a.Ns);
+  // raw loader: value e = tid + j*NTHR of the tile -> (row e / KT, snapshot e % KT), up to LR per thread
+  constexpr int LR = 3;
+  struct RawRegs { double v[LR]; };
+  bool ld_on[LR];
+  int ld_r[LR], ld_s[LR];
+  const double* ld_src[LR];
+#pragma unroll
+  for (int j = 0; j < LR; ++j) {
+    const int e = tid + j * NTHR;
+    ld_on[j] = e < nrawrows * KT;
+    ld_r[j] = e / KT;
+    ld_s[j] = e % KT;
+    ld_src[j] = nullptr;
+    if (ld_on[j]) {
+      int rr = ld_r[j] % nzm;
+      ld_src[j] = rr < b.nzeta ? ((ld_r[j] < nzm ? a.alpha : a.beta) + (int64_t)rr * a.Ns) : (a.u + (int64_t)(rr - b.nzeta) * a.Ns);
+    }
   }
-  auto load_raw = [&](int64_t kt) -> double {
-    int64_t i = kt * KT + lsn;
-    return (is_loader && i < a.Ns) ? lsrc[i] : 0.0;
+  auto load_raw = [&](int64_t kt) -> RawRegs {
+    RawRegs x;
+#pragma unroll
+    for (int j = 0; j < LR; ++j) {
+      int64_t i = kt * KT + ld_s[j];
+      x.v[j] = (ld_on[j] && i < a.Ns) ? ld_src[j][i] : 0.0;
+    }
+    return x;
   };
-  auto store_raw = [&](int buf, double x) {   // powers x^1..x^D
-    if (is_loader) {
-      double* dst = sm + buf * pow_stride + lsn * NID + lr_ * D;
-      double p = x;
+  auto store_raw = [&](int buf, const RawRegs& x) {   // powers x^1..x^D
+#pragma unroll
+    for (int j = 0; j < LR; ++j) {
+      if (!ld_on[j]) continue;
+      double* dst = sm + buf * pow_stride + ld_s[j] * NID + ld_r[j] * D;
+      double p = x.v[j];
       for (int e = 0; e < D; ++e) {
         dst[e] = p;
-        p *= x;
+        p *= x.v[j];
       }
     }
   };
@@ -183,7 +201,7 @@ __global__ __launch_bounds__(NTHR, 2) void kp_gram2_kernel(Gram2Args a) {
   constexpr int SP = NSTEP / CPT > 0 ? NSTEP / CPT : 1;   // tile steps between lift chunks
   constexpr int LAG = SP / 2 > 0 ? SP / 2 : 1;            // tile steps between a chunk's reads and its writes
   for (int t = 0; t < nkt; ++t) {
-    const double rawreg = load_raw(kt0 + t + 2);
+    const RawRegs rawreg = load_raw(kt0 + t + 2);
     const int cur = t & 1, nxt = cur ^ 1;
     const double* P = sm + psi_base + cur * psi_stride;
     lift_begin(nxt, nxt, kt0 + t + 1);
@@ -398,7 +416,7 @@ static hipError_t launch2(const Gram2Args& a, int bm, int grid, size_t lds, hipS
 bool kp_gram2_applicable(const kp_basis* basis) {
   const BasisDev& b = basis->dev;
   return basis->fast && b.k_pcs == 0 && b.nfull <= 32 * CPT && b.m <= 16 && (b.model_type != KP_MODEL_BILINEAR || (b.m >= 1 && b.m <= 3)) &&
-         2 * (b.nzeta + b.m) * KT <= 256;
+         2 * (b.nzeta + b.m) * KT <= 3 * 256;
 }
 
 int kp_gram2_launch(kp_ctx* ctx, const kp_basis* basis_c, const kp_snapshots* s, double* GC_dev) {

@@ -108,24 +108,42 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
   const int nkt = (int)max((int64_t)0, min((int64_t)a.ktiles_per_split, ktiles_total - kt0));
 
   // ---- raw loader; rows: [alpha(nzeta) u(m) | beta(nzeta) u(m)] ----
-  const bool is_loader = tid < nrawrows * KT3;
-  const int lr_ = tid / KT3, lsn = tid % KT3;
-  const double* lsrc = nullptr;
-  if (is_loader) {
-    int rr = lr_ % nzm;
-    lsrc = rr < b.nzeta ? ((lr_ < nzm ? a.alpha : a.beta) + (int64_t)rr * a.Ns) : (a.u + (int64_t)(rr - b.nzeta) * a.Ns);
+  // raw loader: value e = tid + j*256 of the tile -> (row e / KT3, snapshot e % KT3), up to LR per thread
+  constexpr int LR = 3;
+  struct RawRegs { double v[LR]; };
+  bool ld_on[LR];
+  int ld_r[LR], ld_s[LR];
+  const double* ld_src[LR];
+#pragma unroll
+  for (int j = 0; j < LR; ++j) {
+    const int e = tid + j * 256;
+    ld_on[j] = e < nrawrows * KT3;
+    ld_r[j] = e / KT3;
+    ld_s[j] = e % KT3;
+    ld_src[j] = nullptr;
+    if (ld_on[j]) {
+      int rr = ld_r[j] % nzm;
+      ld_src[j] = rr < b.nzeta ? ((ld_r[j] < nzm ? a.alpha : a.beta) + (int64_t)rr * a.Ns) : (a.u + (int64_t)(rr - b.nzeta) * a.Ns);
+    }
   }
-  auto load_raw = [&](int64_t kt) -> double {
-    int64_t i = kt * KT3 + lsn;
-    return (is_loader && i < a.Ns) ? lsrc[i] : 0.0;
+  auto load_raw = [&](int64_t kt) -> RawRegs {
+    RawRegs x;
+#pragma unroll
+    for (int j = 0; j < LR; ++j) {
+      int64_t i = kt * KT3 + ld_s[j];
+      x.v[j] = (ld_on[j] && i < a.Ns) ? ld_src[j][i] : 0.0;
+    }
+    return x;
   };
-  auto store_raw = [&](int buf, double x) {
-    if (is_loader) {
-      double* dst = sm + buf * pow_stride + lsn * NID + lr_ * D;
-      double p = x;
+  auto store_raw = [&](int buf, const RawRegs& x) {   // powers x^1..x^D
+#pragma unroll
+    for (int j = 0; j < LR; ++j) {
+      if (!ld_on[j]) continue;
+      double* dst = sm + buf * pow_stride + ld_s[j] * NID + ld_r[j] * D;
+      double p = x.v[j];
       for (int e = 0; e < D; ++e) {
         dst[e] = p;
-        p *= x;
+        p *= x.v[j];
       }
     }
   };
@@ -167,7 +185,7 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
   constexpr int LAG = SP / 2 > 0 ? SP / 2 : 1;
   constexpr int PF = NSTEP < 3 ? NSTEP : 3;
   for (int t = 0; t < nkt; ++t) {
-    const double rawreg = load_raw(kt0 + t + 2);
+    const RawRegs rawreg = load_raw(kt0 + t + 2);
     const int cur = t & 1, nxt = cur ^ 1;
     const double* P = sm + psi_base + cur * psi_stride;
     lift_begin(nxt, nxt, kt0 + t + 1);
@@ -380,7 +398,7 @@ bool kp_gram3_applicable(const kp_basis* basis) {
   const BasisDev& b = basis->dev;
   if (getenv("KP_NO_GRAM3")) return false;
   return b.model_type == KP_MODEL_BILINEAR && basis->fast && b.k_pcs == 0 && b.nfull <= 16 * CPT3 && b.m >= 1 && b.m <= 3 &&
-         2 * (b.nzeta + b.m) * KT3 <= 256 && 2 * ((b.nfull + 3) / 4) < 255;
+         2 * (b.nzeta + b.m) * KT3 <= 3 * 256 && 2 * ((b.nfull + 3) / 4) < 255;
 }
 
 int kp_gram3_launch(kp_ctx* ctx, const kp_basis* basis_c, const kp_snapshots* s, double* GC_dev) {
