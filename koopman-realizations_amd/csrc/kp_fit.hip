@@ -39,6 +39,12 @@ __global__ void kp_unpad_kernel(const double* __restrict__ Xp, int n, int W, int
 
 #define PS 17  // LDS row stride of the 16-wide panels
 
+__device__ __forceinline__ double lane_bcast(double v, int lane) {
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
 __global__ __launch_bounds__(1024) void kp_chol_kernel(double* __restrict__ A, int n, double* __restrict__ Dinv, int* __restrict__ info,
                                                        int* __restrict__ sticky) {
   extern __shared__ double sm[];
@@ -53,49 +59,51 @@ __global__ __launch_bounds__(1024) void kp_chol_kernel(double* __restrict__ A, i
   for (int kb = 0; kb < nt; ++kb) {
     const int k0 = kb * 16;
     const int R = n - k0 - 16;
-    if (tid < 256) {
-      int r = tid & 15, c = tid >> 4;
-      D[r][c] = A[(size_t)(k0 + c) * n + k0 + r];
-    }
-    __syncthreads();
-    for (int c = 0; c < 16; ++c) {
-      if (tid == 0) {
-        double d = D[c][c];
+    // ---- 16 x 16 diagonal block by wave 0, entirely in registers: lane r (< 16) owns row r; pivots and
+    // pivot-column entries travel by v_readlane, so the 16 serial pivot steps need no LDS round trip and
+    // no workgroup barrier (a barrier-per-step version spent most of its time in s_barrier) ----
+    if (tid < 64) {
+      const int r = tid & 15;
+      double row[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) row[c] = A[(size_t)(k0 + c) * n + k0 + r];
+      double idg[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        double d = lane_bcast(row[c], c);
         if (!(d > 0.0)) {
-          bad = 1;
+          if (tid == 0) bad = 1;
           d = 1.0;
         }
-        D[c][c] = sqrt(d);
+        // 1/sqrt(d): hardware estimate + two Newton steps (full f64 accuracy, no division)
+        double id = __builtin_amdgcn_rsq(d);
+        id = id * (1.5 - 0.5 * d * id * id);
+        id = id * (1.5 - 0.5 * d * id * id);
+        idg[c] = id;
+        const double l = row[c] * id;          // lane c: sqrt(d); lanes r > c: L_rc
+        row[c] = l;
+#pragma unroll
+        for (int cc = c + 1; cc < 16; ++cc) row[cc] -= l * lane_bcast(l, cc);   // entries with cc <= r are used
       }
-      __syncthreads();
-      if (tid < 16 && tid > c) D[tid][c] /= D[c][c];
-      __syncthreads();
-      if (tid < 256) {
-        int r = tid & 15, cc = tid >> 4;
-        if (cc > c && r >= cc) D[r][cc] -= D[r][c] * D[cc][c];
-      }
-      __syncthreads();
-    }
-    // inverse of the lower-triangular diagonal block, one column per thread
-    if (tid < 16) {
-      int j = tid;
+      // inverse of the lower-triangular block: lane j builds column j, x_i = -(sum_{q=j}^{i-1} L_iq x_q) / L_ii
       double x[16];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) x[i] = 0.0;
-#pragma unroll
       for (int i = 0; i < 16; ++i) {
-        if (i == j)
-          x[i] = 1.0 / D[i][i];
-        else if (i > j) {
-          double s = 0.0;
+        double sacc = 0.0;
 #pragma unroll
-          for (int q = 0; q < 16; ++q)
-            if (q >= j && q < i) s += D[i][q] * x[q];
-          x[i] = -s / D[i][i];
+        for (int q = 0; q < i; ++q) {
+          const double liq = lane_bcast(row[q], i);            // L_iq lives in lane i, register q
+          sacc += (q >= r) ? liq * x[q] : 0.0;
+        }
+        x[i] = i == r ? idg[i] : (i > r ? -sacc * idg[i] : 0.0);
+      }
+      if (tid < 16) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          D[r][c] = c <= r ? row[c] : 0.0;
+          Di[c][r] = x[c];                                      // column r of the inverse
         }
       }
-#pragma unroll
-      for (int i = 0; i < 16; ++i) Di[i][j] = x[i];
     }
     __syncthreads();
     if (tid < 256) {
