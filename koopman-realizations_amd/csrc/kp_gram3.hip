@@ -222,20 +222,24 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
             for (int j = 0; j < BM; ++j) utn[j] = Pn[uo + j];
           }
         }
+#if KP_ABL3 != 4 && KP_ABL3 != 6
         if (step + PF < NSTEP) bvs[step + PF] = P[((step + PF) / NQ) * 4 * RS + bo[(step + PF) % NQ]];
         const double bv = bvs[step];
+#else
+        const double bv = bvs[step % PF];
+#endif
 #if KP_ABL3 != 3
 #pragma unroll
         for (int w = 0; w < NWT; ++w) acc[q][w] = __builtin_amdgcn_mfma_f64_4x4x4f64(aw[w], bv, acc[q][w], 0, 0, 0);
 #else
         acc[q][0] += bv * aw[0];
 #endif
-#if KP_ABL3 != 1
+#if KP_ABL3 != 1 && KP_ABL3 != 6
         if (step % SP == 0 && step / SP < CPT3) lift_read(step / SP, nxt);
         if (step >= LAG && (step - LAG) % SP == 0 && (step - LAG) / SP < CPT3) lift_write((step - LAG) / SP, nxt);
 #endif
       }
-#if KP_ABL3 != 1
+#if KP_ABL3 != 1 && KP_ABL3 != 6
 #pragma unroll
       for (int i = 0; i < CPT3; ++i) {
         if (i * SP >= NSTEP) lift_read(i, nxt);
@@ -244,7 +248,9 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
 #endif
     }
     store_raw(cur, rawreg);
+#if KP_ABL3 != 5 && KP_ABL3 != 6
     __syncthreads();
+#endif
   }
 
   // epilogue: [split][job][q][w][lane]

@@ -3,7 +3,7 @@
 cd $GRAFT_REPO_ROOT
 L=koopman-realizations_amd/libkoopman_hip.so
 cp $L /tmp/orig.so
-for A in 0 1 3; do if [ $A != 0 ]; then cp tools/libkp_abl$A.so $L; fi; python - <<PY
+for A in 0 1 4 5 6; do if [ $A != 0 ]; then cp tools/libkp_abl$A.so $L; fi; python - <<PY
 import sys, numpy as np
 sys.path.insert(0,'.')
 import koopman_realizations_amd as kra, bench
