@@ -154,6 +154,12 @@ int kp_model_project(kp_ctx* ctx, const double* K, const double* G, const double
 int kp_rollout(kp_ctx* ctx, int model_type, int batch, const double* A, const double* B, int N, int m,
                const double* z0, const double* U, int T, int n_out, double* Y);
 
+/* val_NLmodel (Ksysid.m:1848-1863): zeta+ = F(zeta,u) = Kf * lift.econ_full([zeta;u]) with
+ * Kf = K(:,1:nzeta)' (nzeta x N, Ksysid.m:1329).  basis must be a 'nonlinear' dictionary.
+ * zeta0: batch x nzeta, U: T x m per rollout, Z out: T x nzeta per rollout (column-major). */
+int kp_rollout_nl(kp_ctx* ctx, const kp_basis* basis, int batch, const double* Kf, const double* zeta0,
+                  const double* U, int T, double* Z);
+
 /* ---- MPC --------------------------------------------------------------------------
  * kp_mpc_create: Kmpc constructor for the linear-MPC types: get_costMatrices
  *   (Kmpc.m:157-211) / get_costMatrices_bilinear (:517-559) and

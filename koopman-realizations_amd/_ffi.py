@@ -53,6 +53,7 @@ SIGNATURES = {
     "kp_fit_get_K": (C.c_int, [vp, C.c_int, C.c_int, c_dp]),
     "kp_model_project": (C.c_int, [vp, c_dp, c_dp, c_dp, C.c_int, C.c_int, c_dp, c_dp, c_dp]),
     "kp_rollout": (C.c_int, [vp, C.c_int, C.c_int, c_dp, c_dp, C.c_int, C.c_int, c_dp, c_dp, C.c_int, C.c_int, c_dp]),
+    "kp_rollout_nl": (C.c_int, [vp, vp, C.c_int, c_dp, c_dp, c_dp, C.c_int, c_dp]),
     "kp_mpc_create": (C.c_int, [vp, C.c_int, c_dp, c_dp, C.c_int, C.c_int, C.c_int, c_dp, C.c_int, C.c_double,
                                 C.c_double, c_dp, c_dp, c_dp, C.c_double, C.c_double, C.POINTER(vp)]),
     "kp_mpc_destroy": (C.c_int, [vp]),

@@ -420,3 +420,84 @@ extern "C" int kp_rollout(kp_ctx* ctx, int model_type, int batch, const double* 
   ctx->timers[5] = ms;
   return KP_OK;
 }
+
+// ---- nonlinear rollouts (val_NLmodel, Ksysid.m:1848-1863):  zeta+ = Kf * lift.econ_full([zeta; u]) -------
+// One workgroup per rollout; the lift of the current point and the nzeta x N matrix-vector product run
+// inside the kernel, so a T-step validation is one launch instead of T lift calls.
+__global__ __launch_bounds__(256) void kp_rollout_nl_kernel(BasisDev b, const double* __restrict__ Kf /* batch x [nzeta x N] col-major */,
+                                                            const double* __restrict__ zeta0, const double* __restrict__ U, int T,
+                                                            double* __restrict__ Z /* batch x [T x nzeta] col-major */) {
+  extern __shared__ double sm[];
+  double* v = sm;                 // nvars = nzeta + m : [zeta; u]
+  double* full = v + b.nvars;     // nfull
+  double* z = full + b.nfull;     // N
+  const int tid = threadIdx.x, bi = blockIdx.x;
+  const int nz = b.nzeta, m = b.m, N = b.N;
+  const double* Kb = Kf + (size_t)bi * nz * N;
+  const double* Ub = U + (size_t)bi * T * m;
+  double* Zb = Z + (size_t)bi * T * nz;
+  for (int i = tid; i < nz; i += 256) v[i] = zeta0[(size_t)bi * nz + i];
+  __syncthreads();
+  for (int t = 0; t < T; ++t) {
+    for (int i = tid; i < nz; i += 256) Zb[(size_t)i * T + t] = v[i];
+    if (t == T - 1) break;
+    for (int i = tid; i < m; i += 256) v[nz + i] = Ub[(size_t)i * T + t];
+    __syncthreads();
+    for (int c = tid; c < b.nfull; c += 256) full[c] = kp_eval_col(b, b.cols[c], v, 1);
+    __syncthreads();
+    for (int c = tid; c < N; c += 256) {
+      double val;
+      if (b.k_pcs == 0)
+        val = full[c];
+      else if (c < b.nvars)
+        val = v[c];
+      else if (c < b.nvars + b.k_pcs) {
+        const double* pc = b.pcs + (size_t)(c - b.nvars) * b.nfull;
+        val = 0.0;
+        for (int i = 0; i < b.nfull; ++i) val += pc[i] * full[i];
+      } else
+        val = 1.0;
+      z[c] = val;
+    }
+    __syncthreads();
+    for (int r = tid; r < nz; r += 256) {
+      double s = 0.0;
+      for (int c = 0; c < N; ++c) s += Kb[r + (size_t)c * nz] * z[c];
+      v[r] = s;
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int kp_rollout_nl(kp_ctx* ctx, const kp_basis* basis, int batch, const double* Kf, const double* zeta0, const double* U, int T,
+                             double* Z) {
+  if (!ctx || !basis || !Kf || !zeta0 || !U || !Z || batch < 1 || T < 1) return ctx ? ctx->fail(KP_ERR_ARG, "kp_rollout_nl: bad argument") : KP_ERR_ARG;
+  const BasisDev& b = basis->dev;
+  if (b.model_type != KP_MODEL_NONLINEAR) return ctx->fail(KP_ERR_ARG, "kp_rollout_nl: the dictionary must be of the nonlinear model type");
+  KP_HIP(ctx, hipSetDevice(ctx->device));
+  if (ctx->async_pending) {
+    int rc0 = kp_synchronize(ctx);
+    if (rc0) return rc0;
+  }
+  const int nz = b.nzeta, m = b.m, N = b.N;
+  size_t nK = (size_t)batch * nz * N, nz0 = (size_t)batch * nz, nU = (size_t)batch * T * m, nZ = (size_t)batch * T * nz;
+  double* ws = (double*)ctx->workspace(6, (nK + nz0 + nU + nZ) * 8);
+  if (!ws) return ctx->fail(KP_ERR_HIP, "kp_rollout_nl: out of device memory");
+  double *dK = ws, *dz = dK + nK, *dU = dz + nz0, *dZ = dU + nU;
+  hipStream_t s = ctx->stream;
+  KP_HIP(ctx, hipMemcpyAsync(dK, Kf, nK * 8, hipMemcpyHostToDevice, s));
+  KP_HIP(ctx, hipMemcpyAsync(dz, zeta0, nz0 * 8, hipMemcpyHostToDevice, s));
+  if (nU) KP_HIP(ctx, hipMemcpyAsync(dU, U, nU * 8, hipMemcpyHostToDevice, s));
+  size_t lds = (size_t)(b.nvars + b.nfull + N) * 8;
+  if (lds > 64 * 1024) return ctx->fail(KP_ERR_ARG, "kp_rollout_nl: dictionary too large");
+  KP_HIP(ctx, hipEventRecord(ctx->ev0, s));
+  hipLaunchKernelGGL(kp_rollout_nl_kernel, dim3(batch), dim3(256), lds, s, b, dK, dz, dU, T, dZ);
+  KP_HIP(ctx, hipGetLastError());
+  KP_HIP(ctx, hipEventRecord(ctx->ev1, s));
+  KP_HIP(ctx, hipMemcpyAsync(Z, dZ, nZ * 8, hipMemcpyDeviceToHost, s));
+  KP_HIP(ctx, hipStreamSynchronize(s));
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+  ctx->timers[5] = ms;
+  return KP_OK;
+}

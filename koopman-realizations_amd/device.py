@@ -97,6 +97,15 @@ class Context:
         Y = np.transpose(Y, (0, 2, 1))
         return Y[0] if single else Y
 
+    def rollout_nl(self, basis, Kf, zeta0, U):
+        """Nonlinear rollout zeta+ = Kf * econ_full([zeta;u]) on the device: Kf (nzeta,N), zeta0 (nzeta,), U (T,m)
+        -> Z (T,nzeta)."""
+        Kf = F.fcol(Kf); z0 = np.ascontiguousarray(zeta0, dtype=np.float64); U = F.fcol(np.atleast_2d(U))
+        T = U.shape[0]
+        Z = np.zeros((T, Kf.shape[0]), order="F")
+        F.check(F.lib().kp_rollout_nl(self._h, basis.handle, 1, F.dptr(Kf), F.dptr(z0), F.dptr(U), T, F.dptr(Z)), self._h)
+        return Z
+
     def qp_solve(self, H, f, A, b):
         """quadprog_gurobi(H,f,A,b) shim: NaN vector on failure (quadprog_gurobi.m:22-23)."""
         H = F.fcol(H); A = F.fcol(A)

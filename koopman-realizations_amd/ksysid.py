@@ -390,9 +390,7 @@ class Ksysid:
     def val_NLmodel(self, model, valdata):
         """Ksysid.m:1815-1879: zeta+ = F(zeta,u) (serial; lift per step on the device)."""
         t, yreal, ureal, zetareal = self._val_common(valdata)
-        zs = np.zeros_like(zetareal); zs[0] = zetareal[0]
-        for j in range(len(t) - 1):
-            zs[j + 1] = model["F_func"](zs[j], ureal[j])
+        zs = self.ctx.rollout_nl(self.basis_dev, model["Kf"], zetareal[0], ureal)   # one launch for the whole trial
         return self._results(t, ureal, zs[:, :self.params["n"]], yreal)
 
     def get_error(self, simdata, realdata):

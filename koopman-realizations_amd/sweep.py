@@ -67,6 +67,30 @@ def lasso_sweep(fit_one, lassos, rank=0, world=1, dist=None, shape=None, device=
     return gather_results(local, len(lassos), dist)
 
 
+def shard_rows(n_rows: int, rank: int, world: int):
+    """Contiguous snapshot range [lo, hi) of `rank` (sizes differ by at most one)."""
+    base, rem = divmod(n_rows, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def fit_sharded(gram_fn, solve_fn, dist=None, device=None):
+    """ONE large fit sharded over snapshots (pattern 2): every rank accumulates the Grams
+    G = Px'Px, C = Px'Py of its snapshot shard (gram_fn() -> (G, C)), a single all-reduce(sum) of the
+    stacked [G; C] (2 W^2 doubles, 1.8 MB at W = 336) is the only exchange step, and every rank solves
+    G K = C (solve_fn(G, C) -> K), so all ranks hold the same K."""
+    G, C = gram_fn()
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(np.stack([np.asarray(G), np.asarray(C)])))
+        if device is not None:
+            t = t.to(device)
+        dist.all_reduce(t)          # sum over ranks (RCCL on GPUs)
+        t = t.cpu().numpy()
+        G, C = np.asfortranarray(t[0]), np.asfortranarray(t[1])
+    return solve_fn(G, C)
+
+
 # evaluate_rand_models.m:14-16
 MAX_DEGREE = {"linear": 13, "bilinear": 6, "nonlinear": 4}
 

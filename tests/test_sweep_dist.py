@@ -36,6 +36,12 @@ def _worker(rank, world, port, q):
         def eval_fn(sysid):
             return {mt: (np.arange(1, d + 1) * (sysid + 1.0), np.arange(d)) for mt, d in sweep.MAX_DEGREE.items()}
         tab = sweep.rand_models_sweep(systems, rank, world, dist, eval_fn=eval_fn)
+        # snapshot-sharded single fit: Grams of the local rows, one all-reduce, local solve
+        rng = np.random.default_rng(5)
+        P = rng.standard_normal((101, 6)); Y = rng.standard_normal((101, 6))
+        lo, hi = sweep.shard_rows(101, rank, world)
+        Ksh = sweep.fit_sharded(lambda: (P[lo:hi].T @ P[lo:hi], P[lo:hi].T @ Y[lo:hi]), np.linalg.solve, dist)
+        assert np.abs(Ksh - np.linalg.lstsq(P, Y, rcond=None)[0]).max() < 1e-12
         q.put((rank, len(calls) // 2, [k.tolist() for k in Ks], [k.tolist() for k in Ko], {k: v.tolist() for k, v in tab.items()}))
     finally:
         dist.destroy_process_group()
@@ -43,6 +49,9 @@ def _worker(rank, world, port, q):
 
 def test_sharding_is_a_partition():
     from koopman_realizations_amd import sweep
+    for n, w in [(101, 2), (100000, 8), (3, 8)]:
+        edges = [sweep.shard_rows(n, r, w) for r in range(w)]
+        assert edges[0][0] == 0 and edges[-1][1] == n and all(a[1] == b[0] for a, b in zip(edges[:-1], edges[1:]))
     for n, w in [(0, 2), (1, 8), (7, 2), (64, 8), (1024, 8), (5, 8)]:
         ids = sorted(i for r in range(w) for i in sweep.shard_units(n, r, w))
         assert ids == list(range(n))
