@@ -10,8 +10,9 @@ from . import _ffi
 from ._ffi import KoopmanHipError
 from .device import Basis, Context, Snapshots, fit, fit_gram
 from .device import Mpc
+from .arm import Arm
 from .kmpc import Kmpc, Ksim, ModelPlant
 from .ksysid import Ksysid, default_context, poly_exponent_table
 
-__all__ = ["Basis", "Context", "Snapshots", "fit", "fit_gram", "Ksysid", "Kmpc", "Ksim", "ModelPlant", "Mpc", "KoopmanHipError", "default_context",
+__all__ = ["Arm", "Basis", "Context", "Snapshots", "fit", "fit_gram", "Ksysid", "Kmpc", "Ksim", "ModelPlant", "Mpc", "KoopmanHipError", "default_context",
            "poly_exponent_table", "_ffi"]

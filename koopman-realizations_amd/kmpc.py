@@ -170,7 +170,7 @@ class Ksim:
         """Ksim.m:47-262 (delays = 0, unloaded).  Result fields as in the reference."""
         mpc, s = self.mpc, self.mpc.sysid
         Np = mpc.horizon
-        nx, nu = self.sys.params["nx"], self.sys.params["nu"]
+        nx, nu = int(self.sys.params["nx"]), int(self.sys.params["nu"])
         x0 = np.zeros(nx) if x0 is None else np.asarray(x0, dtype=np.float64)
         u0 = np.zeros(nu) if u0 is None else np.asarray(u0, dtype=np.float64)
         y0 = np.asarray(self.sys.get_y(x0), dtype=np.float64)

@@ -129,11 +129,30 @@ def rand_models_sweep(systems, rank=0, world=1, dist=None, ctx=None, degrees=Non
     return {mt: np.stack([r[mt][0] for r in allres], axis=1) for mt in ("linear", "bilinear", "nonlinear")}
 
 
+def _keep_systems(err):
+    """evaluate_rand_models.m:155-157: a system (column) is kept only if ALL its degrees have an
+    error below 10 (NaN fails the comparison, so NaN systems drop out as well)."""
+    err = np.asarray(err, dtype=np.float64)
+    with np.errstate(invalid="ignore"):
+        return err[:, np.all(err < 10, axis=0)]
+
+
 def sweep_statistics(err):
-    """evaluate_rand_models.m:149-171: drop NaN / > 10 outliers, mean and std per degree."""
-    mean, std = [], []
-    for row in err:
-        ok = row[np.isfinite(row) & (row <= 10)]
-        mean.append(ok.mean() if ok.size else np.nan)
-        std.append(ok.std(ddof=1) if ok.size > 1 else np.nan)
-    return np.array(mean), np.array(std)
+    """evaluate_rand_models.m:149-171: drop systems with NaN / >= 10 errors, then mean and sample
+    standard deviation over the remaining systems for each degree."""
+    kept = _keep_systems(err)
+    if kept.shape[1] == 0:
+        return np.full(kept.shape[0], np.nan), np.full(kept.shape[0], np.nan)
+    mean = kept.mean(axis=1)
+    std = kept.std(axis=1, ddof=1) if kept.shape[1] > 1 else np.full(kept.shape[0], np.nan)
+    return mean, std
+
+
+def sweep_percentiles(err, q=(0, 25, 50, 75, 100)):
+    """evaluate_rand_models.m:209-211: prctile(err, [0 25 50 75 100], 2) of the kept systems.
+    MATLAB's prctile places sample i of n at 100 (i - 0.5)/n and interpolates linearly (numpy's
+    'hazen' rule)."""
+    kept = _keep_systems(err)
+    if kept.shape[1] == 0:
+        return np.full((kept.shape[0], len(q)), np.nan)
+    return np.percentile(kept, q, axis=1, method="hazen").T

@@ -13,6 +13,9 @@ MAT v5 files); no reference source text is read or stored.
                       res_nonlin: Z width (88)  -> pins scale+pairs+monomial order+pca+econ lift
   blockM_ref.npz      trajectories/files/blockM_c0p45-0p35_0p5x0p5_15sec.mat  ref.y (301x2), Ts
   rand_systems.npz    datafiles/rand-systems_2021-01-10_16-59 (1)/rsys-all_*.mat, first 3 systems
+  arm_plant.npz       the plant behind the stored closed loops: train{1}.params (numeric fields),
+                      res_bilin.{X,U,Y,err} (X(k+1) = Arm.simulate_Ts(X(k), U(k)), Ksim.m:239-245),
+                      train{1}.{x,u,y} rows 1..200
 """
 import glob
 import os
@@ -64,6 +67,11 @@ def main():
         out[f's{i}_train_u'] = np.vstack([t.u for t in trs])
         out[f's{i}_val_t'], out[f's{i}_val_y'], out[f's{i}_val_u'] = v.t, v.y, v.u
     np.savez_compressed(os.path.join(OUT, 'rand_systems.npz'), **out)
+    p = tr[0].params[0, 0]
+    par = {'p_' + f: np.asarray(getattr(p, f), dtype=np.float64).squeeze() for f in p._fieldnames if f != 'sysName'}
+    np.savez_compressed(os.path.join(OUT, 'arm_plant.npz'), bilin_X=rb.X, bilin_U=rb.U, bilin_Y=rb.Y, bilin_err=rb.err,
+                        lin_err=rl.err, nonlin_err=rn.err,
+                        train_x=tr[0].x[:200], train_u=tr[0].u[:200], train_y=tr[0].y[:200], **par)
     for fn in sorted(glob.glob(os.path.join(OUT, '*.npz'))):
         print(fn, os.path.getsize(fn))
 

@@ -217,3 +217,43 @@ def test_kmpc_ksim_mirror_example_control_flow(ctx, golden):
     z0 = ko.econ_full(dic, ks.scaledown_y(y0)[None, :])[0]
     Uo, kkt = ko.mpc_step(s, z0, ks.scaledown_u(np.zeros(3)), ysc[0:11])
     assert np.abs(ks.scaleup_u(Uo[1]) - res["U"][1]).max() < 1e-7
+
+
+def _example_control(ctx, golden, mt):
+    g = golden["arm_data"]; gp = golden["arm_plant"]
+    lens = g["train_len"]; off = np.concatenate([[0], np.cumsum(lens)])
+    train = [{"t": g["train_t"][a:b], "y": g["train_y"][a:b], "u": g["train_u"][a:b]} for a, b in zip(off[:-1], off[1:])]
+    val = [{"t": g["val_t"], "y": g["val_y"], "u": g["val_u"]}]
+    ks = kra.Ksysid({"train": train, "val": val}, ctx=ctx, model_type=mt, obs_type=["poly"], obs_degree=[3],
+                    snapshots=np.inf, lasso=[np.inf], delays=0, dim_red=True).train_models()
+    mpc = kra.Kmpc(ks, horizon=10, input_bounds=[-7 * np.pi / 8, 7 * np.pi / 8], input_slopeConst=1e-1, input_smoothConst=None,
+                   state_bounds=None, cost_running=10, cost_terminal=100, cost_input=0.1 * np.array([3e-2, 2e-2, 1e-2]),
+                   projmtx=ks.model["C"][-2:, :])
+    params = {k[2:]: (float(gp[k]) if gp[k].ndim == 0 else gp[k]) for k in gp.files if k.startswith("p_")}
+    return ks, mpc, kra.Ksim(kra.Arm(params, output_type="markers"), mpc)
+
+
+def test_example_control_true_arm_closed_loop_bilinear(ctx, golden):
+    """example_control.m:15-69 end to end: fit on the arm data, build the bilinear controller, close
+    the loop around the TRUE arm plant for the 15 s block-M.  The stored run of the reference
+    (res_bilin) tracked with mean error 0.0203; the loop here must do as well, inside the same
+    constraints."""
+    ks, mpc, sim = _example_control(ctx, golden, "bilinear")
+    res = sim.run_trial_mpc(golden["blockM_ref"]["y"], None, None)
+    assert res["Y"].shape == (301, 6) and res["X"].shape == (301, 6) and res["Z"].shape == (300, 34)
+    stored = float(golden["arm_plant"]["bilin_err"].mean())
+    assert 0.7 * stored < res["err"].mean() < 1.1 * stored
+    assert np.abs(res["U"]).max() <= 7 * np.pi / 8 + 1e-9
+    du = np.abs(np.diff(res["U"], axis=0))
+    assert (du <= 1e-1 * ks.params["scale"]["u_factor"].mean() * ks.params["scale"]["u_factor"] + 1e-8).all()
+    # the end effector ends within 1 cm of the stored run's end point
+    assert np.abs(res["Y"][-1, -2:] - golden["arm_blockM"]["bilin_Y"][-1, -2:]).max() < 1e-2
+
+
+def test_example_control_linear_first_input_matches_stored_run(ctx, golden):
+    """Same flow with the linear realization: the first controller output equals the stored U(2,:)
+    of res_lin (same data, same least-squares model, same QP) to solver precision."""
+    ks, mpc, sim = _example_control(ctx, golden, "linear")
+    res = sim.run_trial_mpc(golden["blockM_ref"]["y"][:12], None, None)       # first call sees rows 1..11, unpadded
+    assert np.abs(res["U"][1] - golden["arm_blockM"]["lin_U"][1]).max() < 1e-6
+    assert np.abs(res["Y"][1] - golden["arm_blockM"]["lin_Y"][1]).max() < 1e-12

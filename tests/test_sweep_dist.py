@@ -82,3 +82,6 @@ def test_two_rank_sweeps_gather_identically():
     assert lin.shape == (13, 5) and np.allclose(lin[:, 3], np.arange(1, 14) * 4.0)
     mean, std = sweep.sweep_statistics(np.array([[1.0, 2.0, np.nan, 50.0], [1.0, 1.0, 1.0, 1.0]]))
     assert np.allclose(mean, [1.5, 1.0])
+    # prctile's rule: [1 2 3 4] -> 0/25/50/75/100 % = 1, 1.5, 2.5, 3.5, 4 (a 99 system is dropped first)
+    bars = sweep.sweep_percentiles(np.array([[1.0, 2.0, 3.0, 4.0, 99.0]]))
+    assert np.allclose(bars, [[1.0, 1.5, 2.5, 3.5, 4.0]])
