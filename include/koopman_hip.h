@@ -65,10 +65,16 @@ void* kp_stream(const kp_ctx* ctx);
  *                      AFTER the first nvars (Ksysid.m:488); data: exponents in poly_exps
  *   KP_BLOCK_FOURIER   count = degree; (1+2deg)^nvars - 1 functions, last variable fastest
  *   KP_BLOCK_GAUSSIAN  count = number of centres; data: nvars doubles per centre
+ *   KP_BLOCK_HERMITE   count = rows of orders (nvars bytes each, in poly_exps): products of
+ *                      hermiteH(order_i, v_i), ALL rows of degree 1..deg (Ksysid.m:820-851)
+ *   KP_BLOCK_FOURIER_SPARSER  count = rows of multipliers (2*nvars bytes each, in poly_exps):
+ *                      prod sin(2 pi a_i v_i) * prod cos(2 pi b_i v_i), zero multipliers skipped
+ *                      (def_fourierLift_sparser / get_sinusoid, Ksysid.m:734-786)
+ * poly_exps carries the byte rows of the POLY, HERMITE and FOURIER_SPARSER blocks in block order.
  * pcs (Nfull x k, column-major) may be NULL (dim_red = false).
  */
 enum { KP_MODEL_LINEAR = 0, KP_MODEL_BILINEAR = 1, KP_MODEL_NONLINEAR = 2 };
-enum { KP_BLOCK_POLY = 0, KP_BLOCK_FOURIER = 1, KP_BLOCK_GAUSSIAN = 2 };
+enum { KP_BLOCK_POLY = 0, KP_BLOCK_FOURIER = 1, KP_BLOCK_GAUSSIAN = 2, KP_BLOCK_HERMITE = 3, KP_BLOCK_FOURIER_SPARSER = 4 };
 
 typedef struct {
   int32_t model_type;          /* KP_MODEL_*                                         */
@@ -77,7 +83,7 @@ typedef struct {
   int32_t n_blocks;
   const int32_t* block_type;   /* n_blocks                                           */
   const int32_t* block_count;  /* n_blocks                                           */
-  const uint8_t* poly_exps;    /* all POLY blocks' exponent rows, concatenated       */
+  const uint8_t* poly_exps;    /* byte rows of POLY/HERMITE/FOURIER_SPARSER blocks    */
   const double* gauss_centres; /* all GAUSSIAN blocks' centres, concatenated         */
   int32_t k_pcs;               /* 0 => no dimension reduction                        */
   const double* pcs;           /* Nfull x k_pcs column-major, or NULL                */

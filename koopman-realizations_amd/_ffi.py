@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libkoopman_hip.so")
 
 KP_OK, KP_ERR_ARG, KP_ERR_HIP, KP_ERR_NOT_SPD, KP_ERR_QP_FAIL, KP_ERR_NOT_CONVERGED = 0, -1, -2, -3, -4, -5
 MODEL = {"linear": 0, "bilinear": 1, "nonlinear": 2}
-BLOCK = {"poly": 0, "fourier": 1, "gaussian": 2}
+BLOCK = {"poly": 0, "fourier": 1, "gaussian": 2, "hermite": 3, "fourier_sparser": 4}
 LIFT_FULL, LIFT_ECON, LIFT_ROW = 0, 1, 2
 
 c_dp = C.POINTER(C.c_double)

@@ -159,6 +159,16 @@ extern "C" int kp_basis_create(kp_ctx* ctx, const kp_basis_desc* d, kp_basis** o
         for (int i = 1; i < total; ++i) cols.push_back({COL_FOURIER, i, cnt, 0});
         break;
       }
+      case KP_BLOCK_HERMITE:
+        if (cnt && !d->poly_exps) return ctx->fail(KP_ERR_ARG, "kp_basis_create: poly_exps is NULL");
+        for (int i = 0; i < cnt; ++i) cols.push_back({COL_HERMITE, n_mono + i, 0, 0});
+        n_mono += cnt;
+        break;
+      case KP_BLOCK_FOURIER_SPARSER:
+        if (cnt && !d->poly_exps) return ctx->fail(KP_ERR_ARG, "kp_basis_create: poly_exps is NULL");
+        for (int i = 0; i < cnt; ++i) cols.push_back({COL_FSPARSE, n_mono + 2 * i, 0, 0});
+        n_mono += 2 * cnt;   // two table rows (sine, cosine multipliers) per function
+        break;
       case KP_BLOCK_GAUSSIAN:
         if (cnt && !d->gauss_centres) return ctx->fail(KP_ERR_ARG, "kp_basis_create: gauss_centres is NULL");
         for (int i = 0; i < cnt; ++i) cols.push_back({COL_GAUSS, n_gauss + i, 0, 0});

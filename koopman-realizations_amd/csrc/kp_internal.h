@@ -56,11 +56,12 @@ struct kp_ctx {
   } while (0)
 
 // Column kinds of the full basis (device table, one entry per full-basis column)
-enum : int { COL_VAR = 0, COL_MONO = 1, COL_FOURIER = 2, COL_GAUSS = 3, COL_CONST = 4 };
+enum : int { COL_VAR = 0, COL_MONO = 1, COL_FOURIER = 2, COL_GAUSS = 3, COL_CONST = 4, COL_HERMITE = 5, COL_FSPARSE = 6 };
 
 struct ColDesc {
   int32_t kind;
-  int32_t arg;  // VAR: variable index; MONO: row in exps; FOURIER: mixed-radix index (>=1); GAUSS: centre
+  int32_t arg;  // VAR: variable index; MONO/HERMITE: row in exps; FSPARSE: first of two rows in exps (sin, cos
+                // multipliers); FOURIER: mixed-radix index (>=1); GAUSS: centre
   int32_t aux;  // FOURIER: degree
   int32_t pad;
 };
@@ -150,6 +151,34 @@ __device__ __forceinline__ double kp_eval_col(const BasisDev& b, const ColDesc c
         r2 += d * d;
       }
       return exp(-r2);
+    }
+    case COL_HERMITE: {
+      // product of physicists' Hermite polynomials: H0 = 1, H1 = 2x, H_{k+1} = 2x H_k - 2k H_{k-1}
+      const uint8_t* e = b.exps + (size_t)c.arg * b.nvars;
+      double p = 1.0;
+      for (int i = 0; i < b.nvars; ++i) {
+        int n = e[i];
+        if (n) {
+          double x = v[i * vs], h0 = 1.0, h1 = 2.0 * x;
+          for (int k = 1; k < n; ++k) {
+            double h2 = 2.0 * x * h1 - 2.0 * (double)k * h0;
+            h0 = h1;
+            h1 = h2;
+          }
+          p *= h1;
+        }
+      }
+      return p;
+    }
+    case COL_FSPARSE: {
+      const uint8_t* sm = b.exps + (size_t)c.arg * b.nvars;  // sine multipliers, then cosine multipliers
+      const uint8_t* cm = sm + b.nvars;
+      double p = 1.0;
+      for (int i = 0; i < b.nvars; ++i)
+        if (sm[i]) p *= sin(2.0 * 3.14159265358979323846 * (double)sm[i] * v[i * vs]);
+      for (int i = 0; i < b.nvars; ++i)
+        if (cm[i]) p *= cos(2.0 * 3.14159265358979323846 * (double)cm[i] * v[i * vs]);
+      return p;
     }
     default:
       return 1.0;

@@ -122,15 +122,19 @@ class Basis:
     """kp_basis built from a host-side dictionary description (see basis.py)."""
 
     def __init__(self, ctx: Context, model_type, nzeta, m, blocks, pcs=None):
-        """blocks: list of ('poly', exps[rows,nvars] uint8) | ('fourier', deg) | ('gaussian', centres[nvars,k])."""
+        """blocks: list of ('poly', exps[rows,nvars] uint8) | ('fourier', deg) | ('gaussian', centres[nvars,k])
+        | ('hermite', orders[rows,nvars] uint8) | ('fourier_sparser', multipliers[rows,2*nvars] uint8)."""
         self.ctx = ctx
         nvars = nzeta + (m if model_type == "nonlinear" else 0)
         btype, bcount, exps, centres = [], [], [], []
         for kind, arg in blocks:
             btype.append(F.BLOCK[kind])
-            if kind == "poly":
+            if kind in ("poly", "hermite"):
                 e = np.ascontiguousarray(arg, dtype=np.uint8).reshape(-1, nvars)
                 bcount.append(e.shape[0]); exps.append(e)
+            elif kind == "fourier_sparser":
+                e = np.ascontiguousarray(arg, dtype=np.uint8).reshape(-1, 2 * nvars)
+                bcount.append(e.shape[0]); exps.append(e.reshape(-1, nvars))      # two table rows per function
             elif kind == "fourier":
                 bcount.append(int(arg))
             else:

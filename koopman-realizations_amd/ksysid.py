@@ -7,8 +7,7 @@ arrays with MATLAB's shapes (rows = time steps / snapshots).  All heavy arithmet
 this file only does what the MATLAB host does around those calls: option parsing,
 scaling bookkeeping, snapshot selection, dictionary description.
 
-Not supported (KP scope): loaded=True, time_type='continuous',
-obs_type 'hermite'/'fourier_sparser'.
+Not supported (KP scope): loaded=True, time_type='continuous'.
 """
 from __future__ import annotations
 
@@ -164,8 +163,12 @@ class Ksysid:
                 else:
                     c = np.asarray(self._gauss_centres[gi], dtype=np.float64); gi += 1
                 blocks.append(("gaussian", c))
+            elif kind == "hermite":
+                blocks.append(("hermite", poly_exponent_table(nv, deg)))   # :836-844, every row of degree 1..deg
+            elif kind == "fourier_sparser":
+                blocks.append(("fourier_sparser", poly_exponent_table(2 * nv, deg)))   # :746-750
             else:
-                raise NotImplementedError(f"obs_type {kind!r} is out of scope (SURVEY section 8)")
+                raise ValueError(f"unknown obs_type {kind!r}")
         self._blocks = blocks
         self._nvars = nv
         self.basis_dev = Basis(self.ctx, self.model_type, p["nzeta"], p["m"], blocks, None)

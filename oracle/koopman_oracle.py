@@ -66,7 +66,8 @@ class Basis:
     """fullBasis of Ksysid.m:484-505 over `nvars` variables (zeta, or [zeta;u] for
     the 'nonlinear' model type, Ksysid.m:475-477)."""
     nvars: int
-    blocks: list = field(default_factory=list)   # ('poly', exps) | ('fourier', deg) | ('gaussian', centres)
+    blocks: list = field(default_factory=list)   # ('poly', exps) | ('fourier', deg) | ('gaussian', centres) |
+                                                 # ('hermite', orders) | ('fourier_sparser', multipliers)
 
     @property
     def nfull(self) -> int:
@@ -78,6 +79,8 @@ class Basis:
                 n += (1 + 2 * arg) ** self.nvars - 1  # Ksysid.m:718-724
             elif kind == 'gaussian':
                 n += arg.shape[1]
+            elif kind in ('hermite', 'fourier_sparser'):
+                n += arg.shape[0]                   # Ksysid.m:497,503: whole block appended
         return n + 1                                 # Ksysid.m:505 constant at the end
 
 
@@ -96,9 +99,24 @@ def make_basis(nvars, obs_type, obs_degree, gaussian_centres=None) -> Basis:
             gi += 1
             assert c.shape == (nvars, int(deg))      # Ksysid.m:803 columns are centres
             b.blocks.append(('gaussian', c))
+        elif kind == 'hermite':                       # Ksysid.m:836-844: ALL rows of degree 1..deg
+            b.blocks.append(('hermite', poly_exponents(nvars, int(deg))))
+        elif kind == 'fourier_sparser':               # Ksysid.m:746-750 over 2*nvars multipliers
+            b.blocks.append(('fourier_sparser', poly_exponents(2 * nvars, int(deg))))
         else:
             raise ValueError(kind)
     return b
+
+
+def hermite_h(n, x):
+    """MATLAB hermiteH(n, x): physicists' Hermite polynomial, H0 = 1, H1 = 2x,
+    H_{k+1} = 2x H_k - 2k H_{k-1}."""
+    h0, h1 = np.ones_like(x), 2.0 * x
+    if n == 0:
+        return h0
+    for k in range(1, n):
+        h0, h1 = h1, 2.0 * x * h1 - 2.0 * k * h0
+    return h1
 
 
 def lift_full(basis: Basis, V: np.ndarray) -> np.ndarray:
@@ -133,6 +151,21 @@ def lift_full(basis: Basis, V: np.ndarray) -> np.ndarray:
             c = arg
             r2 = ((V[:, :, None] - c[None, :, :]) ** 2).sum(axis=1)
             cols.append(np.exp(-r2))
+        elif kind == 'hermite':                       # get_hermite, Ksysid.m:806-817
+            out = np.ones((V.shape[0], arg.shape[0]))
+            for r, orders in enumerate(arg):
+                for j in range(nv):
+                    out[:, r] *= hermite_h(int(orders[j]), V[:, j])
+            cols.append(out)
+        elif kind == 'fourier_sparser':               # get_sinusoid, Ksysid.m:768-786
+            out = np.ones((V.shape[0], arg.shape[0]))
+            for r, mult in enumerate(arg):
+                for j in range(nv):
+                    if mult[j]:
+                        out[:, r] *= np.sin(2 * np.pi * mult[j] * V[:, j])
+                    if mult[nv + j]:
+                        out[:, r] *= np.cos(2 * np.pi * mult[nv + j] * V[:, j])
+            cols.append(out)
     cols.append(np.ones((V.shape[0], 1)))             # Ksysid.m:505
     return np.hstack(cols)
 

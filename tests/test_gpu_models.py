@@ -120,3 +120,22 @@ def test_ksysid_mirror_example_sysid_flow(ctx, golden, arm, mt):
     zeta = vd["y"][5]
     v = np.concatenate([zeta, vd["u"][5]]) if mt == "nonlinear" else zeta
     np.testing.assert_allclose(ks.lift.econ_full(v), ko.econ_full(dic, v[None, :])[0], atol=1e-9)
+
+
+@pytest.mark.parametrize("kind,deg,nfull,dim_red", [("hermite", 3, 1 + 3 + 1, True), ("fourier_sparser", 1, 1 + 2 + 1, False)])
+def test_ksysid_mirror_other_dictionaries(ctx, golden, kind, deg, nfull, dim_red):
+    """README.txt:99-109 lists hermite and fourier_sparser among obs_type; constructor + fit + validation
+    through the host mirror on a shipped random system (1-D state), against the oracle."""
+    g = golden["rand_systems"]
+    n = 1001
+    train = [{"t": g["s0_train_t"][i * n:(i + 1) * n], "y": g["s0_train_y"][i * n:(i + 1) * n], "u": g["s0_train_u"][i * n:(i + 1) * n]}
+             for i in range(9)]
+    val = [{"t": g["s0_val_t"], "y": g["s0_val_y"], "u": g["s0_val_u"]}]
+    ks = kra.Ksysid({"train": train, "val": val}, ctx=ctx, model_type="linear", obs_type=[kind], obs_degree=[deg],
+                    snapshots=np.inf, lasso=[np.inf], delays=0, dim_red=dim_red)   # hermite repeats zeta (H1 = 2x): needs dim_red
+    assert ks.basis_dev.nfull == nfull
+    ks.train_models()
+    dic = ko.Dictionary("linear", 1, 1, ko.make_basis(1, [kind], [deg]), ks.basis["pcs"] if dim_red else None)
+    np.testing.assert_allclose(ks.lift.econ_full(np.array([0.3])), ko.econ_full(dic, np.array([[0.3]]))[0], atol=1e-12)
+    res = ks.val_model(ks.model, ks.valdata[0])
+    assert np.isfinite(res["error"]["mean"]).all()

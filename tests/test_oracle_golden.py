@@ -76,6 +76,32 @@ def test_fourier_and_gaussian_blocks():
     np.testing.assert_allclose(Pf[:, 10], np.exp(-((V - c[:, 0]) ** 2).sum(axis=1)))
 
 
+def test_hermite_and_fourier_sparser_blocks():
+    """Literal forms of get_hermite (Ksysid.m:806-817) and get_sinusoid (:768-786) on 2 variables."""
+    rng = np.random.default_rng(4)
+    V = rng.uniform(-1, 1, (5, 2)); x, y = V[:, 0], V[:, 1]
+    b = ko.make_basis(2, ["hermite"], [2])
+    Pf = ko.lift_full(b, V)
+    assert Pf.shape == (5, 2 + 5 + 1) and b.nfull == 8
+    # hermiteH: H1 = 2x, H2 = 4x^2 - 2; rows of partitions: [1 0],[0 1],[2 0],[1 1],[0 2]
+    want = np.stack([2 * x, 2 * y, 4 * x ** 2 - 2, 4 * x * y, 4 * y ** 2 - 2], axis=1)
+    np.testing.assert_allclose(Pf[:, 2:7], want, atol=1e-14)
+    assert abs(ko.hermite_h(3, np.array([0.5]))[0] - (8 * 0.125 - 12 * 0.5)) < 1e-15
+    b = ko.make_basis(2, ["fourier_sparser"], [1])
+    Pf = ko.lift_full(b, V)
+    # multipliers over [sin x, sin y, cos x, cos y]: rows [1 0 0 0],[0 1 0 0],[0 0 1 0],[0 0 0 1]
+    want = np.stack([np.sin(2 * np.pi * x), np.sin(2 * np.pi * y), np.cos(2 * np.pi * x), np.cos(2 * np.pi * y)], axis=1)
+    np.testing.assert_allclose(Pf[:, 2:6], want, atol=1e-15)
+    b = ko.make_basis(2, ["fourier_sparser"], [2])
+    Pf = ko.lift_full(b, V)
+    assert Pf.shape == (5, 2 + 4 + 10 + 1)
+    ex = b.blocks[0][1]
+    r = [i for i, e in enumerate(ex) if list(e) == [1, 0, 0, 1]][0]      # sin(2 pi x) cos(2 pi y)
+    np.testing.assert_allclose(Pf[:, 2 + r], np.sin(2 * np.pi * x) * np.cos(2 * np.pi * y), atol=1e-15)
+    r = [i for i, e in enumerate(ex) if list(e) == [2, 0, 0, 0]][0]      # sin(4 pi x)
+    np.testing.assert_allclose(Pf[:, 2 + r], np.sin(4 * np.pi * x), atol=1e-15)
+
+
 def test_ls_fit_recovers_exact_linear_system():
     rng = np.random.default_rng(3)
     A = rng.standard_normal((3, 3)) * 0.3; B = rng.standard_normal((3, 2))
