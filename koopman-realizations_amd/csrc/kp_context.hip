@@ -188,6 +188,7 @@ extern "C" int kp_basis_create(kp_ctx* ctx, const kp_basis_desc* d, kp_basis** o
     int D = 1;
     for (size_t i = 0; i < (size_t)n_mono * nvars; ++i) D = std::max(D, (int)d->poly_exps[i]);
     bool fast = (nvars * D <= 254);
+    int max_nf = 1;
     std::vector<uint32_t> rec(cols.size(), 0xffffffffu);
     for (size_t c = 0; c < cols.size() && fast; ++c) {
       uint32_t r = 0xffffffffu;
@@ -199,6 +200,7 @@ extern "C" int kp_basis_create(kp_ctx* ctx, const kp_basis_desc* d, kp_basis** o
         for (int v = 0; v < nvars; ++v)
           if (e[v]) {
             if (nf == 4) { fast = false; break; }
+            if (nf + 1 > max_nf) max_nf = nf + 1;
             r = (r & ~(0xffu << (8 * nf))) | ((uint32_t)(v * D + e[v] - 1) << (8 * nf));
             ++nf;
           }
@@ -208,6 +210,7 @@ extern "C" int kp_basis_create(kp_ctx* ctx, const kp_basis_desc* d, kp_basis** o
       rec[c] = r;
     }
     b->fast = fast;
+    b->max_factors = max_nf;
     b->pow_depth = D;
     if (fast) {
       int rc0 = upload(ctx, &b->d_recipes, rec.data(), rec.size() * 4);
@@ -283,16 +286,19 @@ extern "C" int kp_snapshots_upload(kp_ctx* ctx, const double* alpha, const doubl
   s->Ns = Ns;
   s->nzeta = nzeta;
   s->m = m;
+  // every array carries 64 doubles of zero padding: the Gram kernels prefetch up to two snapshot tiles past the
+  // end of a row without bounds checks (the values are masked, the addresses must be mapped)
+  const size_t pad = 64 * sizeof(double);
   size_t bz = (size_t)Ns * nzeta * sizeof(double), bu = (size_t)Ns * m * sizeof(double);
   hipError_t e = hipSuccess;
-  if (bz) {
-    if ((e = hipMalloc((void**)&s->alpha, bz)) == hipSuccess && (e = hipMalloc((void**)&s->beta, bz)) == hipSuccess &&
-        (e = hipMemcpy(s->alpha, alpha, bz, hipMemcpyHostToDevice)) == hipSuccess)
+  if ((e = hipMalloc((void**)&s->alpha, bz + pad)) == hipSuccess && (e = hipMalloc((void**)&s->beta, bz + pad)) == hipSuccess &&
+      (e = hipMemset((char*)s->alpha + bz, 0, pad)) == hipSuccess && (e = hipMemset((char*)s->beta + bz, 0, pad)) == hipSuccess && bz) {
+    if ((e = hipMemcpy(s->alpha, alpha, bz, hipMemcpyHostToDevice)) == hipSuccess)
       e = hipMemcpy(s->beta, beta, bz, hipMemcpyHostToDevice);
   }
-  if (e == hipSuccess && bu) {
-    if ((e = hipMalloc((void**)&s->u, bu)) == hipSuccess) e = hipMemcpy(s->u, u, bu, hipMemcpyHostToDevice);
-  }
+  if (e == hipSuccess && (e = hipMalloc((void**)&s->u, bu + pad)) == hipSuccess &&
+      (e = hipMemset((char*)s->u + bu, 0, pad)) == hipSuccess && bu)
+    e = hipMemcpy(s->u, u, bu, hipMemcpyHostToDevice);
   if (e != hipSuccess) {
     kp_snapshots_destroy(s);
     return ctx->fail(KP_ERR_HIP, std::string("kp_snapshots_upload: ") + hipGetErrorString(e));

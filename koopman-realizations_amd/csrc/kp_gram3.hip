@@ -11,10 +11,19 @@
 // (one LDS read feeds all weights).  Executed flops are 62.5 % of the dense W x W products the
 // reference forms (W = N(m+1)); the result is the same matrices G = Px'Px, C = Px'Py.
 //
+// Design rule this kernel is built around (tools/mfma_coissue_bench.hip, profiles/r01_coissue.txt):
+// on gfx950 NO VALU instruction (integer or floating point) overlaps with the FP64 MFMA stream of
+// its SIMD -- each costs ~5.5 cycles of MFMA time even with two waves per SIMD -- while LDS reads
+// are free up to about one per MFMA.  So the LDS layout is a compile-time constant (every operand
+// read is `ds_read_b64 v, vaddr offset:imm`, the tile loop is unrolled by two so that the buffer
+// index is an immediate too), the weights ut_a ut_b come from LDS (written once per snapshot by the
+// lift) and the tail mask lives in the power table's constant entry.
+//
 // Replaces the per-row lift loop of Ksysid.get_Koopman (Ksysid.m:1030-1065) and the products
 // PxTPx, PxTPy (Ksysid.m:1114,1125) for model_type 'bilinear'.
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include "kp_internal.h"
@@ -23,21 +32,32 @@
 #define KP_ABL3 0
 #endif
 #define KT3 8     // snapshots per LDS tile (two k-steps)
-#define CPT3 6    // dictionary columns per lifting thread (16 column lanes => N <= 96)
+#define NF3 3     // single-variable powers per column (recipes with 4 factors use the general monomial kernel)
+// LDS row (doubles): psi_x [0,96) | psi_y [96,192) | zero group [192,196) | weights [196,208) | scratch [208,240)
+#define RS3 240   // = 16 mod 32: the four k-rows of an MFMA operand read hit disjoint banks
+#define YOFF3 96
+#define ZOFF3 192
+#define WOFF3 196
+#define SOFF3 208
+#define NIDMAX3 128                 // power-table entries per snapshot (last used one: the constant / tail mask)
+#define POWBUF3 (KT3 * NIDMAX3)     // doubles per power-table buffer
+#define PSIBUF3 (KT3 * RS3)         // doubles per Psi buffer
+#define PSI03 (2 * POWBUF3)         // LDS: pow[2] | psi[2]
+#define LDS3_DOUBLES (PSI03 + 2 * PSIBUF3)
 
 struct Gram3Args {
   BasisDev b;
-  const double* alpha;
+  const double* alpha;   // allocated with >= 64 doubles of zero padding (kp_snapshots_upload): prefetch never leaves the buffer
   const double* beta;
   const double* u;
   int64_t Ns;
-  int RS;               // LDS row stride (doubles): [psi_x (Np4) | psi_y (Np4) | zero group (4) | u (4)] padded to 16 mod 32
-  int Np4;              // N rounded up to a multiple of 4
+  int G4;               // 4-column groups per side
   int nsuper;           // workgroups per snapshot split
   int ktiles_per_split;
   int D;
   const uint32_t* recipes;   // [nfull]
-  const uint32_t* desc;      // [njobs][1 + NQ]: A group, then per quad 4 packed B group ids (8 bit each)
+  const uint32_t* desc;      // [njobs][1 + NQ]: a0 | a1 << 8 | qs << 16 (quads < qs use A group a0, the rest a1),
+                             // then per quad 4 packed B group ids (8 bit each)
   double* part;              // [nsplit][njobs][NQ][NWT][64]
   int njobs;
 };
@@ -56,23 +76,22 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
   const int nzm = b.nzeta + b.m;
   const int nrawrows = 2 * nzm;
   const int D = a.D;
-  const int RS = a.RS;
-  const int UOFF = 2 * a.Np4 + 4;
-  // LDS (doubles): pow[2][(nrawrows*D + 1)][KT3] (last row: ones) | psi[2][KT3][RS] | spare row
-  const int NID = nrawrows * D + 1;              // power-table entries per snapshot (last: the constant 1)
-  const int pow_stride = NID * KT3;                // layout [snapshot][id]: lanes with different ids hit different banks
-  const int psi_base = 2 * pow_stride;
-  const int psi_stride = KT3 * RS;
-  const int trash = 2 * psi_stride;
+  const int CID = nrawrows * D;                    // power-table id of the constant 1 (0 for snapshots past Ns)
 
-  // ---- MFMA operand offsets (doubles, relative to the Psi buffer): row (lane>>4) of the k-step ----
+  // ---- MFMA operand offsets (doubles, Psi buffer 0): row (lane>>4) of k-step 0 ----
   const uint32_t* jd = a.desc + (size_t)job * (1 + NQ);
-  const int lrow = (lane >> 4) * RS, blk = (lane >> 2) & 3, lc = lane & 3;
-  const int ao = lrow + 4 * (int)jd[0] + lc;             // A group replicated over the 4 blocks
+  const uint32_t jh = jd[0];
+  const int lrow = (lane >> 4) * RS3, blk = (lane >> 2) & 3, lc = lane & 3;
+  const int ao0 = PSI03 + lrow + 4 * (int)(jh & 255u) + lc;      // A group replicated over the 4 blocks
+  const int ao1 = PSI03 + lrow + 4 * (int)((jh >> 8) & 255u) + lc;
+  const int qs = __builtin_amdgcn_readfirstlane((int)((jh >> 16) & 255u));   // wave-uniform
   int bo[NQ];
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) bo[q] = lrow + 4 * (int)((jd[1 + q] >> (8 * blk)) & 255u) + lc;
-  const int uo = lrow + UOFF;
+  for (int q = 0; q < NQ; ++q) {
+    const int g = (int)((jd[1 + q] >> (8 * blk)) & 255u);
+    bo[q] = PSI03 + lrow + (g < a.G4 ? 4 * g : g < 2 * a.G4 ? YOFF3 + 4 * (g - a.G4) : ZOFF3) + lc;
+  }
+  const int wo = PSI03 + lrow + WOFF3;
 
   double acc[NQ][NWT];
 #pragma unroll
@@ -80,177 +99,227 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
 #pragma unroll
     for (int w = 0; w < NWT; ++w) acc[q][w] = 0.0;
 
-  // ---- one-time LDS setup: Psi buffers zero (padding columns and the zero group stay zero) ----
-  for (int e = tid; e < 2 * psi_stride + RS; e += 256) sm[psi_base + e] = 0.0;
-  if (tid < 2 * KT3) sm[(tid / KT3) * pow_stride + (tid % KT3) * NID + nrawrows * D] = 1.0;
+  // ---- one-time LDS setup: everything zero (padding columns and the zero group stay zero) ----
+  for (int e = tid; e < LDS3_DOUBLES; e += 256) sm[e] = 0.0;
 
-  // ---- lifting thread constants ----
-  const int jl = tid & 15, combo = tid >> 4, ls = combo & (KT3 - 1), lside = combo >> 3;
-  int foff[CPT3][4];
-  int woff[CPT3];
-  bool wok[CPT3];
+  // ---- lifting thread constants: thread = one (side, column), all KT3 snapshots of the tile ----
+  // power table layout [id][snapshot]: the KT3 values of one entry are contiguous (16-byte reads of snapshot pairs)
+  const bool lvalid = tid < 2 * b.nfull;
+  const int lside = (lvalid && tid >= b.nfull) ? 1 : 0;
+  const int lcol = lvalid ? tid - lside * b.nfull : 0;
+  int fa[NF3];
+  {
+    const uint32_t r = lvalid ? a.recipes[lcol] : 0xffffffffu;
 #pragma unroll
-  for (int i = 0; i < CPT3; ++i) {
-    const int c = jl + 16 * i;
-    wok[i] = c < b.nfull;
-    const uint32_t r = wok[i] ? a.recipes[c] : 0xffffffffu;
-#pragma unroll
-    for (int f = 0; f < 4; ++f) {
+    for (int f = 0; f < NF3; ++f) {
       const int id = (int)((r >> (8 * f)) & 255u);
-      foff[i][f] = ls * NID + (id == 255 ? nrawrows * D : lside * nzm * D + id);
+      fa[f] = (id == 255 ? CID : lside * nzm * D + id) * KT3;
     }
-    woff[i] = wok[i] ? ls * RS + lside * a.Np4 + c : trash + jl;
   }
-  const int uoff_pow = ls * NID + b.nzeta * D;     // + j*D : u_j (e = 1) of snapshot ls in the power table
+  const int woff = PSI03 + (lvalid ? lside * YOFF3 + lcol : SOFF3 + (tid & 31));
+  // weight writer: thread tid < KT3 (NWT-1) forms w = ut_x ut_y of snapshot tid % KT3, pair index tid / KT3 + 1 in (x <= y) order
+  const bool is_wt = tid < KT3 * (NWT - 1);
+  const int wts = tid & (KT3 - 1), wtw = tid / KT3;
+  int wsa = CID * KT3 + wts, wsb = wsa;
+  {
+    int cnt = 0;
+    for (int x = 0; x <= BM; ++x)
+      for (int y = x; y <= BM; ++y) {
+        if (cnt == wtw + 1) {
+          if (x > 0) wsa = (b.nzeta + x - 1) * D * KT3 + wts;
+          if (y > 0) wsb = (b.nzeta + y - 1) * D * KT3 + wts;
+        }
+        ++cnt;
+      }
+  }
+  const int wdst = PSI03 + wts * RS3 + WOFF3 + (is_wt ? wtw : 0);
 
   const int64_t kt0 = (int64_t)split * a.ktiles_per_split;
   const int64_t ktiles_total = (a.Ns + KT3 - 1) / KT3;
   const int nkt = (int)max((int64_t)0, min((int64_t)a.ktiles_per_split, ktiles_total - kt0));
 
   // ---- raw loader; rows: [alpha(nzeta) u(m) | beta(nzeta) u(m)] ----
-  // raw loader: value e = tid + j*256 of the tile -> (row e / KT3, snapshot e % KT3), up to LR per thread
-  constexpr int LR = 3;
-  struct RawRegs { double v[LR]; };
+  // value e = tid + j*256 of a tile -> (row e / KT3, snapshot e % KT3); tiles are loaded in order, so every
+  // thread keeps a running pointer and a running count of the snapshots left in its row
+  constexpr int LR = 2;
+  const int nld = (nrawrows * KT3 + 255) / 256;     // wave-uniform number of active j
+  struct RawRegs { double v[LR]; bool ok; };
   bool ld_on[LR];
-  int ld_r[LR], ld_s[LR];
-  const double* ld_src[LR];
+  const double* ld_ptr[LR];
+  const int ld_s = tid & (KT3 - 1);                 // the same snapshot for every j (256 is a multiple of KT3)
+  const int ld_dst0 = (tid / KT3) * D * KT3 + ld_s;
+  int ld_rem = (int)max((int64_t)-1000000, min((int64_t)1 << 30, a.Ns - (kt0 * KT3 + ld_s)));
 #pragma unroll
   for (int j = 0; j < LR; ++j) {
     const int e = tid + j * 256;
     ld_on[j] = e < nrawrows * KT3;
-    ld_r[j] = e / KT3;
-    ld_s[j] = e % KT3;
-    ld_src[j] = nullptr;
-    if (ld_on[j]) {
-      int rr = ld_r[j] % nzm;
-      ld_src[j] = rr < b.nzeta ? ((ld_r[j] < nzm ? a.alpha : a.beta) + (int64_t)rr * a.Ns) : (a.u + (int64_t)(rr - b.nzeta) * a.Ns);
-    }
+    const int r = ld_on[j] ? e / KT3 : 0;
+    const int rr = r % nzm;
+    const double* src = rr < b.nzeta ? ((r < nzm ? a.alpha : a.beta) + (int64_t)rr * a.Ns) : (a.u + (int64_t)(rr - b.nzeta) * a.Ns);
+    ld_ptr[j] = src + kt0 * KT3 + ld_s;
   }
-  auto load_raw = [&](int64_t kt) -> RawRegs {
+  auto load_raw = [&]() __attribute__((always_inline)) -> RawRegs {                // next tile of this workgroup's range
     RawRegs x;
+    x.ok = ld_rem > 0;
 #pragma unroll
     for (int j = 0; j < LR; ++j) {
-      int64_t i = kt * KT3 + ld_s[j];
-      x.v[j] = (ld_on[j] && i < a.Ns) ? ld_src[j][i] : 0.0;
-    }
-    return x;
-  };
-  auto store_raw = [&](int buf, const RawRegs& x) {   // powers x^1..x^D
-#pragma unroll
-    for (int j = 0; j < LR; ++j) {
-      if (!ld_on[j]) continue;
-      double* dst = sm + buf * pow_stride + ld_s[j] * NID + ld_r[j] * D;
-      double p = x.v[j];
-      for (int e = 0; e < D; ++e) {
-        dst[e] = p;
-        p *= x.v[j];
+      x.v[j] = 0.0;
+      if (j < nld) {
+        const double v = *ld_ptr[j];
+        x.v[j] = x.ok ? v : 0.0;
+        ld_ptr[j] += KT3;
       }
     }
+    ld_rem -= KT3;
+    return x;
   };
-
-  // ---- lift of snapshot tile kt: power-table buffer rb -> Psi buffer pb, in pipelined chunks ----
-  double vmask = 0.0;
-  double lf[CPT3][4];
-  auto lift_begin = [&](int rb, int pb, int64_t kt) {
-    const double* T = sm + rb * pow_stride;
-    vmask = (kt * KT3 + ls) < a.Ns ? 1.0 : 0.0;
-    if (lside == 0 && jl < BM) {                    // u_j of this snapshot next to the Psi row
-      double* P = sm + psi_base + pb * psi_stride;
-      P[ls * RS + UOFF + jl] = T[uoff_pow + jl * D] * vmask;
+  auto store_raw = [&](auto buf_c, const RawRegs& x) __attribute__((always_inline)) {   // powers x^1..x^D, and the constant / tail-mask entry
+    constexpr int BUF = decltype(buf_c)::value;
+#pragma unroll
+    for (int j = 0; j < LR; ++j) {
+      if (j < nld && ld_on[j]) {
+        double* dst = sm + BUF * POWBUF3 + ld_dst0 + j * 32 * D * KT3;
+        double p = x.v[j];
+        for (int e = 0; e < D; ++e) {
+          dst[e * KT3] = p;
+          p *= x.v[j];
+        }
+      }
     }
-  };
-  auto lift_read = [&](int i, int rb) {
-    const double* T = sm + rb * pow_stride;
-#pragma unroll
-    for (int f = 0; f < 4; ++f) lf[i][f] = T[foff[i][f]];
-  };
-  auto lift_write = [&](int i, int pb) {
-    double* P = sm + psi_base + (wok[i] ? pb * psi_stride : 0) + woff[i];
-    P[0] = (lf[i][0] * lf[i][1]) * (lf[i][2] * lf[i][3]) * vmask;
+    if (tid < KT3) sm[BUF * POWBUF3 + CID * KT3 + tid] = x.ok ? 1.0 : 0.0;
   };
 
-  store_raw(0, load_raw(kt0));
-  __syncthreads();
-  lift_begin(0, 0, kt0);
+  // ---- lift of a snapshot tile: power-table buffer B -> Psi buffer B, in pipelined chunks ----
+  constexpr int NCH = KT3 / 2;                       // chunks: snapshot pairs
+  double2 lf[NF3];
+  auto lift_begin = [&](auto buf_c) __attribute__((always_inline)) {               // the weights of this snapshot
+    constexpr int BUF = decltype(buf_c)::value;
+    if (is_wt) sm[BUF * PSIBUF3 + wdst] = sm[BUF * POWBUF3 + wsa] * sm[BUF * POWBUF3 + wsb];
+  };
+  auto lift_read = [&](int ch, auto buf_c) __attribute__((always_inline)) {
+    constexpr int BUF = decltype(buf_c)::value;
 #pragma unroll
-  for (int i = 0; i < CPT3; ++i) {
-    lift_read(i, 0);
-    lift_write(i, 0);
+    for (int f = 0; f < NF3; ++f) lf[f] = *reinterpret_cast<const double2*>(&sm[BUF * POWBUF3 + fa[f] + 2 * ch]);
+  };
+  auto lift_write = [&](int ch, auto buf_c) __attribute__((always_inline)) {
+    constexpr int BUF = decltype(buf_c)::value;
+    sm[BUF * PSIBUF3 + woff + (2 * ch) * RS3] = (lf[0].x * lf[1].x) * lf[2].x;
+    sm[BUF * PSIBUF3 + woff + (2 * ch + 1) * RS3] = (lf[0].y * lf[1].y) * lf[2].y;
+  };
+  using B0 = std::integral_constant<int, 0>;
+  using B1 = std::integral_constant<int, 1>;
+
+  __syncthreads();
+  store_raw(B0{}, load_raw());
+  __syncthreads();
+  lift_begin(B0{});
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    lift_read(i, B0{});
+    lift_write(i, B0{});
   }
-  store_raw(1, load_raw(kt0 + 1));
+  store_raw(B1{}, load_raw());
   __syncthreads();
 
   constexpr int NSTEP = (KT3 / 4) * NQ;                 // quad steps (NWT MFMAs each) per snapshot tile
-  constexpr int SP = NSTEP / CPT3 > 0 ? NSTEP / CPT3 : 1;
+  constexpr int SP = NSTEP / NCH > 0 ? NSTEP / NCH : 1;
   constexpr int LAG = SP / 2 > 0 ? SP / 2 : 1;
   constexpr int PF = NSTEP < 3 ? NSTEP : 3;
-  for (int t = 0; t < nkt; ++t) {
-    const RawRegs rawreg = load_raw(kt0 + t + 2);
-    const int cur = t & 1, nxt = cur ^ 1;
-    const double* P = sm + psi_base + cur * psi_stride;
-    lift_begin(nxt, nxt, kt0 + t + 1);
-    {
-      double bvs[NSTEP];
-      double aw[NWT];
-      double avn, utn[3] = {0.0, 0.0, 0.0};              // raw A fragment and u of the NEXT k-step (prefetched)
+
+  // one snapshot tile: MFMAs on Psi buffer CUR, lift of the next tile into buffer 1-CUR, raw prefetch two ahead.
+  // QS = number of leading quads that use A group a0 (wave-uniform, selected once outside the loop).
+  auto tile = [&](auto cur_c, auto qs_c) __attribute__((always_inline)) {
+    constexpr int CUR = decltype(cur_c)::value;
+    constexpr int QS = decltype(qs_c)::value;
+    using NXT = std::integral_constant<int, 1 - CUR>;
+    constexpr int PB = CUR * PSIBUF3;
+    const RawRegs rawreg = load_raw();
+    lift_begin(NXT{});
+    double bvs[NSTEP];
+    double aw[NWT];
+    double wt[NWT];
+    double av1 = 0.0;
+    double avn0, avn1 = 0.0;                           // raw A fragments of the NEXT k-step (prefetched)
+    auto weigh = [&](double av) __attribute__((always_inline)) {
 #pragma unroll
-      for (int i = 0; i < PF; ++i) bvs[i] = P[(i / NQ) * 4 * RS + bo[i % NQ]];
-      avn = P[ao];
+      for (int w = 0; w < NWT; ++w) {
+#if KP_ABL3 == 7
+        aw[w] = av;
+#else
+        aw[w] = w == 0 ? av : av * wt[w];
+#endif
+      }
+    };
 #pragma unroll
-      for (int j = 0; j < BM; ++j) utn[j] = P[uo + j];
+    for (int i = 0; i < PF; ++i) bvs[i] = sm[PB + (i / NQ) * 4 * RS3 + bo[i % NQ]];
+    avn0 = sm[PB + ao0];
+    if (QS < NQ) avn1 = sm[PB + ao1];
+    // the NWT-1 weights of k-step kk, as 16-byte LDS reads (a pair each; immediate offsets, no address arithmetic)
+    auto load_wt = [&](int kk) __attribute__((always_inline)) {
 #pragma unroll
-      for (int step = 0; step < NSTEP; ++step) {
-        const int kk = step / NQ, q = step % NQ;
-        if (q == 0) {
-          // weighted A fragments of this k-step: w_ab = ut_a ut_b, ut = [1; u]
-          double ut[4];
-          ut[0] = 1.0;
+      for (int w = 0; w < NWT - 1; w += 2) {
+        const double2 v = *reinterpret_cast<const double2*>(&sm[PB + kk * 4 * RS3 + wo + w]);
+        wt[w + 1] = v.x;
+        if (w + 2 < NWT) wt[w + 2] = v.y;
+      }
+    };
+    load_wt(0);
 #pragma unroll
-          for (int j = 0; j < BM; ++j) ut[1 + j] = utn[j];
-          int w = 0;
-#pragma unroll
-          for (int x = 0; x <= BM; ++x)
-#pragma unroll
-            for (int y = x; y <= BM; ++y) {
-              aw[w] = x == 0 ? (y == 0 ? avn : avn * ut[y]) : avn * (ut[x] * ut[y]);
-              ++w;
-            }
-          if (kk + 1 < KT3 / 4) {
-            const double* Pn = P + (kk + 1) * 4 * RS;
-            avn = Pn[ao];
-#pragma unroll
-            for (int j = 0; j < BM; ++j) utn[j] = Pn[uo + j];
-          }
+    for (int step = 0; step < NSTEP; ++step) {
+      const int kk = step / NQ, q = step % NQ;
+      if (q == 0) {
+        weigh(avn0);
+        if (QS < NQ) av1 = avn1;
+        if (kk + 1 < KT3 / 4) {
+          avn0 = sm[PB + (kk + 1) * 4 * RS3 + ao0];
+          if (QS < NQ) avn1 = sm[PB + (kk + 1) * 4 * RS3 + ao1];
         }
-#if KP_ABL3 != 4 && KP_ABL3 != 6
-        if (step + PF < NSTEP) bvs[step + PF] = P[((step + PF) / NQ) * 4 * RS + bo[(step + PF) % NQ]];
-        const double bv = bvs[step];
-#else
-        const double bv = bvs[step % PF];
-#endif
-#if KP_ABL3 != 3
-#pragma unroll
-        for (int w = 0; w < NWT; ++w) acc[q][w] = __builtin_amdgcn_mfma_f64_4x4x4f64(aw[w], bv, acc[q][w], 0, 0, 0);
-#else
-        acc[q][0] += bv * aw[0];
-#endif
-#if KP_ABL3 != 1 && KP_ABL3 != 6
-        if (step % SP == 0 && step / SP < CPT3) lift_read(step / SP, nxt);
-        if (step >= LAG && (step - LAG) % SP == 0 && (step - LAG) / SP < CPT3) lift_write((step - LAG) / SP, nxt);
-#endif
       }
-#if KP_ABL3 != 1 && KP_ABL3 != 6
-#pragma unroll
-      for (int i = 0; i < CPT3; ++i) {
-        if (i * SP >= NSTEP) lift_read(i, nxt);
-        if (i * SP + LAG >= NSTEP) lift_write(i, nxt);
-      }
+      if (QS < NQ && q == QS) weigh(av1);
+      // fetch the weights one step before they are multiplied in (LDS reads are free, registers are not)
+      if (QS < NQ && QS > 1 && q == QS - 1) load_wt(kk);
+      if (q == NQ - 1 && kk + 1 < KT3 / 4) load_wt(kk + 1);
+#if KP_ABL3 != 6
+      if (step + PF < NSTEP) bvs[step + PF] = sm[PB + ((step + PF) / NQ) * 4 * RS3 + bo[(step + PF) % NQ]];
+      const double bv = bvs[step];
+#else
+      const double bv = bvs[step % PF];
 #endif
+#pragma unroll
+      for (int w = 0; w < NWT; ++w) acc[q][w] = __builtin_amdgcn_mfma_f64_4x4x4f64(aw[w], bv, acc[q][w], 0, 0, 0);
+#if KP_ABL3 != 1 && KP_ABL3 != 6
+      if (step % SP == 0 && step / SP < NCH) lift_read(step / SP, NXT{});
+      if (step >= LAG && (step - LAG) % SP == 0 && (step - LAG) / SP < NCH) lift_write((step - LAG) / SP, NXT{});
+#endif
+      __builtin_amdgcn_sched_barrier(0);   // keep the hand-made software pipeline: no hoisting of later steps' LDS reads
     }
-    store_raw(cur, rawreg);
-#if KP_ABL3 != 5 && KP_ABL3 != 6
-    __syncthreads();
+#if KP_ABL3 != 1 && KP_ABL3 != 6
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      if (i * SP >= NSTEP) lift_read(i, NXT{});
+      if (i * SP + LAG >= NSTEP) lift_write(i, NXT{});
+    }
 #endif
+    store_raw(cur_c, rawreg);
+    __syncthreads();
+  };
+  auto run_tiles = [&](auto qs_c) __attribute__((always_inline)) {
+    int t = 0;
+    for (; t + 1 < nkt; t += 2) {
+      tile(B0{}, qs_c);
+      tile(B1{}, qs_c);
+    }
+    if (t < nkt) tile(B0{}, qs_c);
+  };
+  switch (qs) {
+    case 1: run_tiles(std::integral_constant<int, 1>{}); break;
+    case 2: run_tiles(std::integral_constant<int, (NQ >= 2 ? 2 : NQ)>{}); break;
+    case 3: run_tiles(std::integral_constant<int, (NQ >= 3 ? 3 : NQ)>{}); break;
+    case 4: run_tiles(std::integral_constant<int, (NQ >= 4 ? 4 : NQ)>{}); break;
+    case 5: run_tiles(std::integral_constant<int, (NQ >= 5 ? 5 : NQ)>{}); break;
+    case 6: run_tiles(std::integral_constant<int, (NQ >= 6 ? 6 : NQ)>{}); break;
+    case 7: run_tiles(std::integral_constant<int, (NQ >= 7 ? 7 : NQ)>{}); break;
+    default: run_tiles(std::integral_constant<int, NQ>{}); break;
   }
 
   // epilogue: [split][job][q][w][lane]
@@ -273,7 +342,7 @@ __global__ __launch_bounds__(64) void kp_gram3_reduce_kernel(const double* __res
   double s = 0.0;
   for (int p = 0; p < nsplit; ++p) s += part[(size_t)p * per_split + (size_t)idx * 64 + l];
   const uint32_t* jd = desc + (size_t)job * (1 + NQ);
-  const int ga = (int)jd[0];
+  const int ga = q < (int)((jd[0] >> 16) & 255u) ? (int)(jd[0] & 255u) : (int)((jd[0] >> 8) & 255u);
   const int gb = (int)((jd[1 + q] >> (8 * ((l >> 2) & 3))) & 255u);
   if (gb >= 2 * G4) return;                   // zero group: padding of the last quad / idle job
   // weight index -> (x, y), x <= y
@@ -302,7 +371,7 @@ __global__ __launch_bounds__(64) void kp_gram3_reduce_kernel(const double* __res
 }
 
 struct kp_gram3_plan {
-  int G4 = 0, Np4 = 0, RS = 0, nq = 0, njobs = 0, nsuper = 0;
+  int G4 = 0, nq = 0, njobs = 0, nsuper = 0;
   uint32_t* desc = nullptr;  // device
 };
 
@@ -314,14 +383,12 @@ void kp_gram3_plan_free(kp_gram3_plan* p) {
 
 // Row g of psi_x (one 4-column group) is paired with: its circulant half of the psi_x groups
 // (g, g+1, ..., g+floor(G4/2) mod G4; antipodal pairs once) and all G4 groups of psi_y.
-static int make_plan3(kp_ctx* ctx, int N, kp_gram3_plan** out) {
+// All quads (A group, 4 B groups) of all rows form one list; a job (one wave) is nq CONSECUTIVE quads,
+// so it spans at most two A groups when nq <= quads per row, and whole workgroups (4 jobs) fill evenly.
+static int make_plan3(kp_ctx* ctx, int N, int nwt, kp_gram3_plan** out) {
   kp_gram3_plan* p = new kp_gram3_plan();
   const int G4 = (N + 3) / 4;
   p->G4 = G4;
-  p->Np4 = 4 * G4;
-  int rs = 2 * p->Np4 + 8;
-  while (rs % 32 != 16) rs += 4;
-  p->RS = rs;
   const int ZG = 2 * G4;
   std::vector<std::vector<int>> rows(G4);
   for (int g = 0; g < G4; ++g) {
@@ -333,38 +400,42 @@ static int make_plan3(kp_ctx* ctx, int N, kp_gram3_plan** out) {
   }
   size_t maxq = 0;
   for (auto& r : rows) maxq = std::max(maxq, (r.size() + 3) / 4);
-  static const int cand[] = {1, 2, 3, 4, 6, 8};
-  int nq = 8;
-  for (int c : cand)
-    if ((size_t)c >= maxq) { nq = c; break; }
-  if (const char* ov = getenv("KP_GRAM3_NQ")) {   // tuning override: rows are cut into jobs of <= nq quads
+  std::vector<std::pair<int, uint32_t>> quads;
+  for (int g = 0; g < G4; ++g) {
+    const size_t nquads = (rows[g].size() + 3) / 4;
+    for (size_t q = 0; q < nquads; ++q) {
+      uint32_t packed = 0;
+      for (int k = 0; k < 4; ++k) {
+        size_t idx = q * 4 + k;
+        int gb = idx < rows[g].size() ? rows[g][idx] : ZG;
+        packed |= (uint32_t)gb << (8 * k);
+      }
+      quads.push_back({g, packed});
+    }
+  }
+  const int TQ = (int)quads.size();
+  // cost ~ waves x (MFMA cycles of nq quads over the two k-steps of a tile + the per-tile VALU share)
+  int nq = 1;
+  double best = 1e300;
+  for (int c = 1; c <= 8 && (size_t)c <= maxq; ++c) {
+    int waves = ((TQ + c - 1) / c + 3) / 4 * 4;
+    double cost = (double)waves * (c * nwt * 33.0 + 400.0);
+    if (cost < best) { best = cost; nq = c; }
+  }
+  if (const char* ov = getenv("KP_GRAM3_NQ")) {   // tuning override
     int v = atoi(ov);
-    for (int c : cand)
-      if (c == v) nq = v;
+    if (v >= 1 && v <= 8 && (size_t)v <= maxq) nq = v;
   }
   p->nq = nq;
   std::vector<uint32_t> desc;
   int njobs = 0;
-  for (int g = 0; g < G4; ++g) {
-    const size_t nquads = (rows[g].size() + 3) / 4;
-    for (size_t q0 = 0; q0 < nquads; q0 += nq) {          // rows longer than nq quads become several jobs
-      desc.push_back((uint32_t)g);
-      for (int q = 0; q < nq; ++q) {
-        uint32_t packed = 0;
-        for (int k = 0; k < 4; ++k) {
-          size_t idx = (q0 + q) * 4 + k;
-          int gb = ((size_t)(q0 + q) < nquads && idx < rows[g].size()) ? rows[g][idx] : ZG;
-          packed |= (uint32_t)gb << (8 * k);
-        }
-        desc.push_back(packed);
-      }
-      ++njobs;
-    }
-  }
-  while (njobs % 4) {
-    desc.push_back(0u);
-    uint32_t z = (uint32_t)ZG * 0x01010101u;
-    for (int q = 0; q < nq; ++q) desc.push_back(z);
+  const uint32_t zq = (uint32_t)ZG * 0x01010101u;
+  for (int q0 = 0; q0 < TQ || njobs % 4; q0 += nq) {
+    int a0 = q0 < TQ ? quads[q0].first : 0, a1 = a0, qs = nq;
+    for (int q = 0; q < nq; ++q)
+      if (q0 + q < TQ && quads[q0 + q].first != a0) { a1 = quads[q0 + q].first; qs = q; break; }
+    desc.push_back((uint32_t)a0 | ((uint32_t)a1 << 8) | ((uint32_t)qs << 16));
+    for (int q = 0; q < nq; ++q) desc.push_back(q0 + q < TQ ? quads[q0 + q].second : zq);
     ++njobs;
   }
   p->njobs = njobs;
@@ -381,11 +452,11 @@ static int make_plan3(kp_ctx* ctx, int N, kp_gram3_plan** out) {
 
 template <int NQ, int BM>
 static hipError_t launch3b(const Gram3Args& a, int grid, size_t lds, hipStream_t st) {
-  static size_t lds_set = 0;
-  if (lds > lds_set) {
+  static bool attr_set = false;
+  if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kp_gram3_kernel<NQ, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    lds_set = lds;
+    attr_set = true;
   }
   hipLaunchKernelGGL((kp_gram3_kernel<NQ, BM>), dim3(grid), dim3(256), lds, st, a);
   return hipGetLastError();
@@ -403,8 +474,8 @@ static hipError_t launch3(const Gram3Args& a, int bm, int grid, size_t lds, hipS
 bool kp_gram3_applicable(const kp_basis* basis) {
   const BasisDev& b = basis->dev;
   if (getenv("KP_NO_GRAM3")) return false;
-  return b.model_type == KP_MODEL_BILINEAR && basis->fast && b.k_pcs == 0 && b.nfull <= 16 * CPT3 && b.m >= 1 && b.m <= 3 &&
-         2 * (b.nzeta + b.m) * KT3 <= 3 * 256 && 2 * ((b.nfull + 3) / 4) < 255;
+  return b.model_type == KP_MODEL_BILINEAR && basis->fast && basis->max_factors <= NF3 && b.k_pcs == 0 && b.nfull <= YOFF3 &&
+         b.m >= 1 && b.m <= 3 && 2 * (b.nzeta + b.m) * KT3 <= 2 * 256 && 2 * (b.nzeta + b.m) * basis->pow_depth + 1 <= NIDMAX3;
 }
 
 int kp_gram3_launch(kp_ctx* ctx, const kp_basis* basis_c, const kp_snapshots* s, double* GC_dev) {
@@ -412,16 +483,13 @@ int kp_gram3_launch(kp_ctx* ctx, const kp_basis* basis_c, const kp_snapshots* s,
   const BasisDev& b = basis->dev;
   if (s->nzeta != b.nzeta || s->m != b.m) return ctx->fail(KP_ERR_ARG, "kp_fit_gram: snapshot/basis dimension mismatch");
   const int W = b.W, N = b.N;
+  const int BM = b.m, NWT = (BM + 1) * (BM + 2) / 2;
   if (!basis->plan3) {
-    int rc = make_plan3(ctx, N, &basis->plan3);
+    int rc = make_plan3(ctx, N, NWT, &basis->plan3);
     if (rc) return rc;
   }
   kp_gram3_plan& plan = *basis->plan3;
-  const int D = basis->pow_depth;
-  const int nraw = 2 * (b.nzeta + b.m);
-  const int BM = b.m, NWT = (BM + 1) * (BM + 2) / 2;
-  size_t lds = ((size_t)2 * (nraw * D + 1) * KT3 + (size_t)2 * KT3 * plan.RS + plan.RS) * sizeof(double);
-  if (lds > 160 * 1024) return ctx->fail(KP_ERR_ARG, "kp_fit_gram: dictionary too wide");
+  const size_t lds = (size_t)LDS3_DOUBLES * sizeof(double);
   int64_t ktiles = (s->Ns + KT3 - 1) / KT3;
   int ncu = ctx->num_cu > 0 ? ctx->num_cu : 256;
   int wg_per_cu = 2;                                  // __launch_bounds__(256, 2): two workgroups share a CU
@@ -441,11 +509,10 @@ int kp_gram3_launch(kp_ctx* ctx, const kp_basis* basis_c, const kp_snapshots* s,
   a.beta = s->beta;
   a.u = s->u;
   a.Ns = s->Ns;
-  a.RS = plan.RS;
-  a.Np4 = plan.Np4;
+  a.G4 = plan.G4;
   a.nsuper = plan.nsuper;
   a.ktiles_per_split = kps;
-  a.D = D;
+  a.D = basis->pow_depth;
   a.recipes = (const uint32_t*)basis->d_recipes;
   a.desc = plan.desc;
   a.part = part;
@@ -459,7 +526,9 @@ int kp_gram3_launch(kp_ctx* ctx, const kp_basis* basis_c, const kp_snapshots* s,
     case 2: e = launch3<2>(a, BM, grid, lds, ctx->stream); break;
     case 3: e = launch3<3>(a, BM, grid, lds, ctx->stream); break;
     case 4: e = launch3<4>(a, BM, grid, lds, ctx->stream); break;
+    case 5: e = launch3<5>(a, BM, grid, lds, ctx->stream); break;
     case 6: e = launch3<6>(a, BM, grid, lds, ctx->stream); break;
+    case 7: e = launch3<7>(a, BM, grid, lds, ctx->stream); break;
     default: e = launch3<8>(a, BM, grid, lds, ctx->stream); break;
   }
   KP_HIP(ctx, e);

@@ -94,6 +94,7 @@ struct kp_basis {
   int max_degree = 0;
   int pow_depth = 1;           // largest single-variable exponent
   bool fast = false;           // every column is a product of <= 4 single-variable powers
+  int max_factors = 1;         // largest number of single-variable powers in one column (valid if fast)
   kp_gram_plan* plan = nullptr;  // tile->wave plan of the fused Gram kernel (built on first use)
   kp_gram2_plan* plan2 = nullptr;  // plan of the 4x4x4-MFMA Gram kernel (monomial dictionaries)
   kp_gram3_plan* plan3 = nullptr;  // plan of the Kronecker (bilinear) Gram kernel
