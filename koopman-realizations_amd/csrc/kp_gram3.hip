@@ -40,7 +40,9 @@
 #define WOFF3 196
 #define SOFF3 208
 #define NIDMAX3 128                 // power-table entries per snapshot (last used one: the constant / tail mask)
-#define POWBUF3 (KT3 * NIDMAX3)     // doubles per power-table buffer
+#define PST3 10                     // doubles per power-table entry: KT3 snapshots + 2 of padding, so that the 16-byte reads of
+                                    // 64 lanes with arbitrary ids spread over all banks (a stride of 8 puts them on 4 groups)
+#define POWBUF3 (PST3 * NIDMAX3)    // doubles per power-table buffer
 #define PSIBUF3 (KT3 * RS3)         // doubles per Psi buffer
 #define PSI03 (2 * POWBUF3)         // LDS: pow[2] | psi[2]
 #define LDS3_DOUBLES (PSI03 + 2 * PSIBUF3)
@@ -65,7 +67,7 @@ struct Gram3Args {
 template <int NQ, int BM>
 __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
   constexpr int NWT = (BM + 1) * (BM + 2) / 2;
-  extern __shared__ double sm[];
+  extern __shared__ __align__(16) double sm[];
   const BasisDev& b = a.b;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -113,21 +115,21 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
 #pragma unroll
     for (int f = 0; f < NF3; ++f) {
       const int id = (int)((r >> (8 * f)) & 255u);
-      fa[f] = (id == 255 ? CID : lside * nzm * D + id) * KT3;
+      fa[f] = (id == 255 ? CID : lside * nzm * D + id) * PST3;
     }
   }
   const int woff = PSI03 + (lvalid ? lside * YOFF3 + lcol : SOFF3 + (tid & 31));
   // weight writer: thread tid < KT3 (NWT-1) forms w = ut_x ut_y of snapshot tid % KT3, pair index tid / KT3 + 1 in (x <= y) order
   const bool is_wt = tid < KT3 * (NWT - 1);
   const int wts = tid & (KT3 - 1), wtw = tid / KT3;
-  int wsa = CID * KT3 + wts, wsb = wsa;
+  int wsa = CID * PST3 + wts, wsb = wsa;
   {
     int cnt = 0;
     for (int x = 0; x <= BM; ++x)
       for (int y = x; y <= BM; ++y) {
         if (cnt == wtw + 1) {
-          if (x > 0) wsa = (b.nzeta + x - 1) * D * KT3 + wts;
-          if (y > 0) wsb = (b.nzeta + y - 1) * D * KT3 + wts;
+          if (x > 0) wsa = (b.nzeta + x - 1) * D * PST3 + wts;
+          if (y > 0) wsb = (b.nzeta + y - 1) * D * PST3 + wts;
         }
         ++cnt;
       }
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
   bool ld_on[LR];
   const double* ld_ptr[LR];
   const int ld_s = tid & (KT3 - 1);                 // the same snapshot for every j (256 is a multiple of KT3)
-  const int ld_dst0 = (tid / KT3) * D * KT3 + ld_s;
+  const int ld_dst0 = (tid / KT3) * D * PST3 + ld_s;
   int ld_rem = (int)max((int64_t)-1000000, min((int64_t)1 << 30, a.Ns - (kt0 * KT3 + ld_s)));
 #pragma unroll
   for (int j = 0; j < LR; ++j) {
@@ -178,15 +180,15 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
 #pragma unroll
     for (int j = 0; j < LR; ++j) {
       if (j < nld && ld_on[j]) {
-        double* dst = sm + BUF * POWBUF3 + ld_dst0 + j * 32 * D * KT3;
+        double* dst = sm + BUF * POWBUF3 + ld_dst0 + j * 32 * D * PST3;
         double p = x.v[j];
         for (int e = 0; e < D; ++e) {
-          dst[e * KT3] = p;
+          dst[e * PST3] = p;
           p *= x.v[j];
         }
       }
     }
-    if (tid < KT3) sm[BUF * POWBUF3 + CID * KT3 + tid] = x.ok ? 1.0 : 0.0;
+    if (tid < KT3) sm[BUF * POWBUF3 + CID * PST3 + tid] = x.ok ? 1.0 : 0.0;
   };
 
   // ---- lift of a snapshot tile: power-table buffer B -> Psi buffer B, in pipelined chunks ----
@@ -288,8 +290,9 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
 #pragma unroll
       for (int w = 0; w < NWT; ++w) acc[q][w] = __builtin_amdgcn_mfma_f64_4x4x4f64(aw[w], bv, acc[q][w], 0, 0, 0);
 #if KP_ABL3 != 1 && KP_ABL3 != 6
-      if (step % SP == 0 && step / SP < NCH) lift_read(step / SP, NXT{});
+      // one register set for the chunk in flight: the write of chunk i precedes the read of chunk i+1
       if (step >= LAG && (step - LAG) % SP == 0 && (step - LAG) / SP < NCH) lift_write((step - LAG) / SP, NXT{});
+      if (step % SP == 0 && step / SP < NCH) lift_read(step / SP, NXT{});
 #endif
       __builtin_amdgcn_sched_barrier(0);   // keep the hand-made software pipeline: no hoisting of later steps' LDS reads
     }

@@ -85,6 +85,21 @@ def test_gram_edge_sizes(ctx, Ns):
     assert np.abs(C - Cr).max() <= 1e-12 * max(1.0, np.abs(Gr).max())
 
 
+@pytest.mark.parametrize("nz,m,deg,Ns", [(1, 1, 6, 9000), (2, 1, 2, 9008), (2, 1, 6, 20000), (6, 3, 2, 20000), (6, 3, 3, 20001)])
+def test_gram_small_dictionaries_many_splits(ctx, nz, m, deg, Ns):
+    """Small dictionaries put few quads on a wave and several tiles on every snapshot split: exercises the
+    lift pipeline of the Kronecker kernel with 1..3 quad steps per tile and odd/even tile counts."""
+    pairs = synth_pairs(Ns, nz, m, seed=9)
+    dic = ko.build_dictionary("bilinear", nz, m, ["poly"], [deg])
+    b = make_basis(ctx, dic)
+    snaps = kra.Snapshots(ctx, pairs["alpha"], pairs["beta"], pairs["u"])
+    G, C = kra.fit_gram(ctx, b, snaps)
+    Px, Py = ko.px_py(dic, pairs)
+    Gr, Cr = ko.gram(Px, Py)
+    assert np.abs(G - Gr).max() <= 1e-12 * np.abs(Gr).max()
+    assert np.abs(C - Cr).max() <= 1e-12 * np.abs(Gr).max()
+
+
 def test_gram_linearity_in_snapshots(ctx):
     """Size-independent property: Gram over a concatenation = sum of the Grams."""
     dic = ko.build_dictionary("bilinear", 6, 3, ["poly"], [3])
