@@ -240,7 +240,7 @@ def main():
                        "snapshots_per_gpu": Ns, "W": W, "parallelism": f"{world} independent fits + final all_gather"},
             "fit_latency_ms": fit_latency_ms,
             "kernel_ms": {"gram": g_ms, "gram_reduce": float(np.mean(t_red)), "solve": float(np.mean(t_solve))},
-            "roofline": {"bound": "mfma", "kernel": "kp_gram3_kernel<8,3>", "achieved": achieved, "peak": PEAK_F64_MFMA_TFLOPS,
+            "roofline": {"bound": "mfma", "kernel": "kp_gram3_kernel<6,3>", "achieved": achieved, "peak": PEAK_F64_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_F64_MFMA_TFLOPS, "traffic": traffic,
                          "algorithmic_flop_per_launch": flops_pair * Ns, "algorithmic_bytes_per_launch": 120.0 * Ns,
                          "hbm_algorithmic_GBs": 120.0 * Ns / (g_ms * 1e-3) / 1e9,

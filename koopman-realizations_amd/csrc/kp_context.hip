@@ -50,6 +50,7 @@ extern "C" int kp_create(int device_id, kp_ctx** out) {
   (void)hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
   (void)hipEventCreateWithFlags(&c->ev_gram_done, hipEventDisableTiming);
   (void)hipEventCreateWithFlags(&c->ev_pad_done, hipEventDisableTiming);
+  (void)hipEventCreateWithFlags(&c->ev_pad_done2, hipEventDisableTiming);
   (void)hipEventCreate(&c->ev_solve0);
   (void)hipEventCreate(&c->ev_solve1);
   if (hipMalloc((void**)&c->sticky_info, sizeof(int)) == hipSuccess) (void)hipMemset(c->sticky_info, 0, sizeof(int));
@@ -73,6 +74,7 @@ extern "C" int kp_destroy(kp_ctx* c) {
   if (c->sticky_info) (void)hipFree(c->sticky_info);
   if (c->ev_gram_done) (void)hipEventDestroy(c->ev_gram_done);
   if (c->ev_pad_done) (void)hipEventDestroy(c->ev_pad_done);
+  if (c->ev_pad_done2) (void)hipEventDestroy(c->ev_pad_done2);
   if (c->ev_solve0) (void)hipEventDestroy(c->ev_solve0);
   if (c->ev_solve1) (void)hipEventDestroy(c->ev_solve1);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);

@@ -319,7 +319,7 @@ static void collect_gram_timers(kp_ctx* ctx, bool solved) {
 }
 
 static int ensure_gc(kp_ctx* ctx, int W) {
-  size_t need = (size_t)2 * W * W * 8;
+  size_t need = (size_t)4 * W * W * 8;      // two [G | C] buffers: asynchronous fits alternate between them
   if (ctx->GC_bytes < need) {
     if (ctx->GC) (void)hipFree(ctx->GC);
     ctx->GC = nullptr;
@@ -409,18 +409,26 @@ extern "C" int kp_fit(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* sn
   }();
   if (!K_out && n_lasso == 1 && all_ls && ctx->stream2 && ctx->sticky_info && !getenv("KP_NO_ASYNC")) {
     // ---- asynchronous pipeline: this fit's solve (stream2) overlaps the next fit's Gram (stream) ----
-    // G|C is rewritten by the next Gram's reduction: it must wait until this solve has copied it (pad kernel)
-    if (ctx->pad_pending) KP_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_pad_done, 0));
-    ctx->reserve_cus = 24;
-    rc = kp_gram_dispatch(ctx, basis, snaps, ctx->GC);
+    // two [G | C] buffers alternate, so this Gram's reduction only has to wait for the pad kernel (the solve's
+    // copy of G | C) of the fit before the previous one -- never for the solve that is running right now
+    const int flip = ctx->gc_flip;
+    ctx->gc_flip ^= 1;
+    double* GCb = ctx->GC + (size_t)flip * 2 * W * W;
+    hipEvent_t evp = flip ? ctx->ev_pad_done2 : ctx->ev_pad_done;
+    bool& pend = flip ? ctx->pad_pending2 : ctx->pad_pending;
+    if (pend) KP_HIP(ctx, hipStreamWaitEvent(ctx->stream, evp, 0));
+    // CUs left free for the solve stream (Cholesky: one workgroup; TRSM: W/16 workgroups)
+    static const int reserve = [] { const char* e = getenv("KP_RESERVE_CUS"); return e ? atoi(e) : 24; }();
+    ctx->reserve_cus = reserve;
+    rc = kp_gram_dispatch(ctx, basis, snaps, GCb);
     if (rc) return rc;
     KP_HIP(ctx, hipEventRecord(ctx->ev_gram_done, ctx->stream));
     KP_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_gram_done, 0));
     KP_HIP(ctx, hipEventRecord(ctx->ev_solve0, ctx->stream2));
-    rc = kp_chol_solve_dev(ctx, ctx->GC, ctx->GC + (size_t)W * W, W, W, ctx->Kres, ctx->stream2, ctx->ev_pad_done, ctx->sticky_info);
+    rc = kp_chol_solve_dev(ctx, GCb, GCb + (size_t)W * W, W, W, ctx->Kres, ctx->stream2, evp, ctx->sticky_info);
     if (rc) return rc;
     KP_HIP(ctx, hipEventRecord(ctx->ev_solve1, ctx->stream2));
-    ctx->pad_pending = true;
+    pend = true;
     ctx->async_pending = true;
     return KP_OK;
   }
@@ -484,6 +492,7 @@ extern "C" int kp_synchronize(kp_ctx* ctx) {
   }
   ctx->async_pending = false;
   ctx->pad_pending = false;
+  ctx->pad_pending2 = false;
   if (bad) return ctx->fail(KP_ERR_NOT_SPD, "kp_synchronize: a deferred fit hit a Gram matrix that is not numerically positive definite");
   return KP_OK;
 }

@@ -320,8 +320,6 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
     case 3: run_tiles(std::integral_constant<int, (NQ >= 3 ? 3 : NQ)>{}); break;
     case 4: run_tiles(std::integral_constant<int, (NQ >= 4 ? 4 : NQ)>{}); break;
     case 5: run_tiles(std::integral_constant<int, (NQ >= 5 ? 5 : NQ)>{}); break;
-    case 6: run_tiles(std::integral_constant<int, (NQ >= 6 ? 6 : NQ)>{}); break;
-    case 7: run_tiles(std::integral_constant<int, (NQ >= 7 ? 7 : NQ)>{}); break;
     default: run_tiles(std::integral_constant<int, NQ>{}); break;
   }
 
@@ -420,14 +418,15 @@ static int make_plan3(kp_ctx* ctx, int N, int nwt, kp_gram3_plan** out) {
   // cost ~ waves x (MFMA cycles of nq quads over the two k-steps of a tile + the per-tile VALU share)
   int nq = 1;
   double best = 1e300;
-  for (int c = 1; c <= 8 && (size_t)c <= maxq; ++c) {
+  constexpr int NQMAX = 6;   // 7 or 8 quads (140/160 accumulator registers) spill with the 256-register budget of 2 waves per SIMD
+  for (int c = 1; c <= NQMAX && (size_t)c <= maxq; ++c) {
     int waves = ((TQ + c - 1) / c + 3) / 4 * 4;
     double cost = (double)waves * (c * nwt * 33.0 + 400.0);
     if (cost < best) { best = cost; nq = c; }
   }
   if (const char* ov = getenv("KP_GRAM3_NQ")) {   // tuning override
     int v = atoi(ov);
-    if (v >= 1 && v <= 8 && (size_t)v <= maxq) nq = v;
+    if (v >= 1 && v <= NQMAX && (size_t)v <= maxq) nq = v;
   }
   p->nq = nq;
   std::vector<uint32_t> desc;
@@ -530,9 +529,7 @@ int kp_gram3_launch(kp_ctx* ctx, const kp_basis* basis_c, const kp_snapshots* s,
     case 3: e = launch3<3>(a, BM, grid, lds, ctx->stream); break;
     case 4: e = launch3<4>(a, BM, grid, lds, ctx->stream); break;
     case 5: e = launch3<5>(a, BM, grid, lds, ctx->stream); break;
-    case 6: e = launch3<6>(a, BM, grid, lds, ctx->stream); break;
-    case 7: e = launch3<7>(a, BM, grid, lds, ctx->stream); break;
-    default: e = launch3<8>(a, BM, grid, lds, ctx->stream); break;
+    default: e = launch3<6>(a, BM, grid, lds, ctx->stream); break;
   }
   KP_HIP(ctx, e);
   KP_HIP(ctx, hipEventRecord(ctx->evp[1], ctx->stream));

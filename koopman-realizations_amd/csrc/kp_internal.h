@@ -18,8 +18,9 @@ struct kp_ctx {
   hipEvent_t evp[6] = {nullptr};   // gram start, gram end, reduce end, solve end, spare x2
   // asynchronous fit pipeline (kp_fit with K_out == NULL): Gram on `stream`, solve on `stream2`
   hipStream_t stream2 = nullptr;
-  hipEvent_t ev_gram_done = nullptr, ev_pad_done = nullptr, ev_solve0 = nullptr, ev_solve1 = nullptr;
-  bool pad_pending = false, async_pending = false;
+  hipEvent_t ev_gram_done = nullptr, ev_pad_done = nullptr, ev_pad_done2 = nullptr, ev_solve0 = nullptr, ev_solve1 = nullptr;
+  bool pad_pending = false, pad_pending2 = false, async_pending = false;
+  int gc_flip = 0;             // asynchronous fits alternate between the two halves of GC
   int* sticky_info = nullptr;       // device word: set by any deferred factorisation that hit a non-positive pivot
   int reserve_cus = 0;              // CUs left free by the Gram grid so the solve of the previous fit can run beside it
   int num_cu = 0;
