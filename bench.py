@@ -245,7 +245,7 @@ def main():
                          "algorithmic_flop_per_launch": flops_pair * Ns, "algorithmic_bytes_per_launch": 120.0 * Ns,
                          "hbm_algorithmic_GBs": 120.0 * Ns / (g_ms * 1e-3) / 1e9,
                          "note": "achieved = dense algorithmic flop W(W+1)+2W^2 per pair / measured kernel time; the Kronecker-structured "
-                                 "kernel executes ~72% of them (exact same G, C), so frac can exceed the executed-MFMA utilisation",
+                                 "kernel executes ~63% of them (exact same G, C), so frac can exceed the executed-MFMA utilisation",
                          "pmc": prof_note},
         }
         if mpc_res is not None:
