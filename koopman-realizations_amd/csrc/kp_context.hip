@@ -51,6 +51,7 @@ extern "C" int kp_create(int device_id, kp_ctx** out) {
   (void)hipEventCreateWithFlags(&c->ev_gram_done, hipEventDisableTiming);
   (void)hipEventCreateWithFlags(&c->ev_pad_done, hipEventDisableTiming);
   (void)hipEventCreateWithFlags(&c->ev_pad_done2, hipEventDisableTiming);
+  (void)hipEventCreateWithFlags(&c->ev_main_done, hipEventDisableTiming);
   (void)hipEventCreate(&c->ev_solve0);
   (void)hipEventCreate(&c->ev_solve1);
   if (hipMalloc((void**)&c->sticky_info, sizeof(int)) == hipSuccess) (void)hipMemset(c->sticky_info, 0, sizeof(int));
@@ -75,6 +76,7 @@ extern "C" int kp_destroy(kp_ctx* c) {
   if (c->ev_gram_done) (void)hipEventDestroy(c->ev_gram_done);
   if (c->ev_pad_done) (void)hipEventDestroy(c->ev_pad_done);
   if (c->ev_pad_done2) (void)hipEventDestroy(c->ev_pad_done2);
+  if (c->ev_main_done) (void)hipEventDestroy(c->ev_main_done);
   if (c->ev_solve0) (void)hipEventDestroy(c->ev_solve0);
   if (c->ev_solve1) (void)hipEventDestroy(c->ev_solve1);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);

@@ -420,7 +420,13 @@ extern "C" int kp_fit(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* sn
     // CUs left free for the solve stream (Cholesky: one workgroup; TRSM: W/16 workgroups)
     static const int reserve = [] { const char* e = getenv("KP_RESERVE_CUS"); return e ? atoi(e) : 24; }();
     ctx->reserve_cus = reserve;
+    // optional: run the Kronecker kernel's partial reduction on the solve stream.  Off by default: measured 0.572 vs
+    // 0.534 ms per fit, because reduce + Cholesky + TRSM (0.53 ms, serial) then outlasts the Gram kernel (0.50 ms)
+    static const bool reduce_on_solve = getenv("KP_REDUCE_ON_SOLVE_STREAM") != nullptr;
+    ctx->reduce_stream = reduce_on_solve ? ctx->stream2 : nullptr;
+    ctx->part_flip = flip;
     rc = kp_gram_dispatch(ctx, basis, snaps, GCb);
+    ctx->reduce_stream = nullptr;
     if (rc) return rc;
     KP_HIP(ctx, hipEventRecord(ctx->ev_gram_done, ctx->stream));
     KP_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_gram_done, 0));

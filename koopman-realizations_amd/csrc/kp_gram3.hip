@@ -502,8 +502,11 @@ int kp_gram3_launch(kp_ctx* ctx, const kp_basis* basis_c, const kp_snapshots* s,
   if (kps < 1) kps = 1;
   nsplit = (int)std::max<int64_t>(1, (ktiles + kps - 1) / kps);
   size_t per_split = (size_t)plan.njobs * plan.nq * NWT * 64;
-  double* part = (double*)ctx->workspace(4, (size_t)nsplit * per_split * 8);
-  if (!part) return ctx->fail(KP_ERR_HIP, "kp_fit_gram: out of device memory");
+  // asynchronous fits: two partial buffers, so that the next Gram kernel may run while the solve stream reduces this one
+  const size_t part_bytes = ((size_t)nsplit * per_split * 8 + 255) & ~(size_t)255;
+  char* part_base = (char*)ctx->workspace(4, part_bytes * (ctx->reduce_stream ? 2 : 1));
+  if (!part_base) return ctx->fail(KP_ERR_HIP, "kp_fit_gram: out of device memory");
+  double* part = (double*)(part_base + (ctx->reduce_stream ? (size_t)ctx->part_flip * part_bytes : 0));
 
   Gram3Args a;
   a.b = b;
@@ -533,11 +536,17 @@ int kp_gram3_launch(kp_ctx* ctx, const kp_basis* basis_c, const kp_snapshots* s,
   }
   KP_HIP(ctx, e);
   KP_HIP(ctx, hipEventRecord(ctx->evp[1], ctx->stream));
-  hipLaunchKernelGGL(kp_gram3_reduce_kernel, dim3(plan.njobs * plan.nq * NWT), dim3(64), 0, ctx->stream, part, nsplit, plan.njobs,
+  hipStream_t rs = ctx->stream;
+  if (ctx->reduce_stream) {                       // reduction (and everything after it) belongs to the solve stream
+    rs = ctx->reduce_stream;
+    KP_HIP(ctx, hipEventRecord(ctx->ev_main_done, ctx->stream));
+    KP_HIP(ctx, hipStreamWaitEvent(rs, ctx->ev_main_done, 0));
+  }
+  hipLaunchKernelGGL(kp_gram3_reduce_kernel, dim3(plan.njobs * plan.nq * NWT), dim3(64), 0, rs, part, nsplit, plan.njobs,
                      plan.nq, NWT, BM, plan.desc, plan.G4, N, W, GC_dev, GC_dev + (size_t)W * W);
   KP_HIP(ctx, hipGetLastError());
-  KP_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-  KP_HIP(ctx, hipEventRecord(ctx->evp[2], ctx->stream));
+  KP_HIP(ctx, hipEventRecord(ctx->ev1, rs));
+  KP_HIP(ctx, hipEventRecord(ctx->evp[2], rs));
   ctx->gram_flops_per_pair = (double)W * (W + 1) + 2.0 * W * W;
   return KP_OK;
 }

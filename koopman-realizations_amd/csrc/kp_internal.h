@@ -21,6 +21,11 @@ struct kp_ctx {
   hipEvent_t ev_gram_done = nullptr, ev_pad_done = nullptr, ev_pad_done2 = nullptr, ev_solve0 = nullptr, ev_solve1 = nullptr;
   bool pad_pending = false, pad_pending2 = false, async_pending = false;
   int gc_flip = 0;             // asynchronous fits alternate between the two halves of GC
+  // set by the asynchronous kp_fit around kp_gram_dispatch: the split-partial reduction runs on this stream
+  // (after an event recorded behind the main Gram kernel) and the partial buffer `part_flip` is used
+  hipStream_t reduce_stream = nullptr;
+  hipEvent_t ev_main_done = nullptr;
+  int part_flip = 0;
   int* sticky_info = nullptr;       // device word: set by any deferred factorisation that hit a non-positive pivot
   int reserve_cus = 0;              // CUs left free by the Gram grid so the solve of the previous fit can run beside it
   int num_cu = 0;
