@@ -450,6 +450,7 @@ extern "C" int kp_fit(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* sn
   bool need_ls = false;
   for (int i = 0; i < n_lasso; ++i) need_ls |= (!lasso || !(lasso[i] < 1e6));
   int ls_index = -1;
+  kp_lasso_prep lprep;   // least-squares solution + Lipschitz constant, computed once for all lasso values
   // the least-squares solution is also the warm start / inactive-constraint answer of the lasso path
   for (int i = 0; i < n_lasso; ++i) {
     double* Ki = ctx->Kres + (size_t)i * W * W;
@@ -464,7 +465,7 @@ extern "C" int kp_fit(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* sn
       }
     } else {
       int iters = 0;
-      rc = kp_lasso_dev(ctx, Gd, Cd, W, W, lasso[i] * N /* t = lasso*N, Ksysid.m:996 */, 20000, 1e-10, Ki, &iters);
+      rc = kp_lasso_dev(ctx, Gd, Cd, W, W, lasso[i] * N /* t = lasso*N, Ksysid.m:996 */, 20000, 1e-10, Ki, &iters, &lprep);
       if (rc) return rc;
     }
   }

@@ -205,5 +205,13 @@ inline int kp_gram_dispatch(kp_ctx* ctx, const kp_basis* basis, const kp_snapsho
 }
 int kp_chol_solve_dev(kp_ctx* ctx, double* G_dev, double* C_dev, int W, int ncols, double* K_dev, hipStream_t st = nullptr,
                       hipEvent_t pad_done = nullptr, int* sticky = nullptr);
-int kp_lasso_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, int W, int ncols, double t,
-                 int max_iter, double tol, double* K_dev, int* iters);
+// least-squares solution, PSD guard and Lipschitz constant shared by all lasso values of one fit (kp_lasso.hip)
+struct kp_lasso_prep {
+  bool ready = false;
+  double L = 0.0, l1_ls = 0.0;
+  int bad = 0;
+  double* Kls = nullptr;   // device, W x ncols
+  double* Gw = nullptr;    // device copy of G (with the PSD guard applied when needed)
+};
+int kp_lasso_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, int W, int ncols, double t, int max_iter, double tol,
+                 double* K_dev, int* iters, kp_lasso_prep* prep = nullptr);

@@ -1,0 +1,412 @@
+// L1-ball constrained least squares of Ksysid.solve_KoopmanQP (Ksysid.m:1095-1176):
+//     min_K 1/2 tr(K'GK) - tr(K'C)   s.t.  ||vec K||_1 <= t,      t = lasso * N (Ksysid.m:996)
+// The reference hands the equivalent QP (split K = K+ - K-, one L1 row, Ksysid.m:1126-1137) to quadprog;
+// here: accelerated projected gradient (FISTA with gradient restart), projection onto the L1 ball by
+// Newton's method on the piecewise-linear threshold equation (Michelot's fixed point, warm-started with
+// the previous iteration's threshold).  Everything runs as multi-workgroup kernels:
+//   * G K by an MFMA kernel (v_mfma_f64_4x4x4_4b_f64; G symmetric, so G K = G'K is a Gram-type product)
+//   * the momentum is applied algebraically: Y = K + mom (K - Kold) and G Y = GK + mom (GK - GKold), so one
+//     product per iteration suffices and the restart decision of iteration i is a scalar read by iteration i+1
+//   * every global reduction finishes in the last workgroup to arrive (ticket counter), which also updates
+//     the scalar state - no host round trips except the convergence check every 20 iterations
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "kp_internal.h"
+
+// ------------------------------------------------------------------------------------------------
+// C (W x nc) = G (W x W, symmetric) * X (W x nc), column-major.  Workgroup: 16 output rows x 32 output
+// columns; the whole contraction range of both operands is staged in LDS once ([r][16 G cols | 32 X cols]),
+// then 8 waves x (one 4-row group, half of the k-steps) x 2 quads run without barriers.
+// ------------------------------------------------------------------------------------------------
+#define SG_RS 49   // odd: the staging writes (lanes = consecutive rows) and the operand reads both spread over the banks
+__global__ __launch_bounds__(512) void kp_symm_gemm_kernel(const double* __restrict__ G, const double* __restrict__ X, int W, int nc,
+                                                           double* __restrict__ C) {
+  extern __shared__ double sm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r0c = blockIdx.x * 16;       // output rows = columns of G'
+  const int c0 = blockIdx.y * 32;        // output columns
+  const int Wp = (W + 3) & ~3;
+  // consecutive threads: consecutive rows of one column (coalesced); all 48 columns (loads) of a row in flight
+  for (int r = tid; r < Wp; r += 512) {
+    double v[48];
+#pragma unroll
+    for (int col = 0; col < 48; ++col) {
+      const int gc = col < 16 ? r0c + col : c0 + col - 16;
+      const bool ok = r < W && (col < 16 ? gc < W : gc < nc);
+      const double* src = col < 16 ? G : X;
+      v[col] = ok ? src[r + (size_t)gc * W] : 0.0;
+    }
+#pragma unroll
+    for (int col = 0; col < 48; ++col) sm[r * SG_RS + col] = v[col];
+  }
+  __syncthreads();
+  // 8 waves: A group = wave & 3 (4 output rows), half of the contraction range = wave >> 2
+  const int lrow = (lane >> 4) * SG_RS, blk = (lane >> 2) & 3, lc = lane & 3;
+  const int ao = lrow + 4 * (wave & 3) + lc;
+  const int bo0 = lrow + 16 + 4 * blk + lc, bo1 = bo0 + 16;
+  double acc0 = 0.0, acc1 = 0.0;
+  const int nk = Wp / 4, kh = (nk + 1) / 2;
+  const int k0 = (wave >> 2) * kh, k1 = min(nk, k0 + kh);
+#pragma unroll 6
+  for (int k = k0; k < k1; ++k) {
+    const double a = sm[k * 4 * SG_RS + ao];
+    const double b0 = sm[k * 4 * SG_RS + bo0], b1 = sm[k * 4 * SG_RS + bo1];
+    acc0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b0, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b1, acc1, 0, 0, 0);
+  }
+  __syncthreads();                       // operands are consumed: reuse the LDS for the split-k partials
+  if (wave >= 4) { sm[(wave - 4) * 128 + lane] = acc0; sm[(wave - 4) * 128 + 64 + lane] = acc1; }
+  __syncthreads();
+  if (wave < 4) {
+    acc0 += sm[wave * 128 + lane];
+    acc1 += sm[wave * 128 + 64 + lane];
+    // D lane: column j = lane & 3 of block (lane >> 2) & 3, row i = lane >> 4
+    const int io = r0c + 4 * wave + (lane >> 4);
+    const int j0 = c0 + 4 * blk + lc, j1 = j0 + 16;
+    if (io < W) {
+      if (j0 < nc) C[io + (size_t)j0 * W] = acc0;
+      if (j1 < nc) C[io + (size_t)j1 * W] = acc1;
+    }
+  }
+}
+
+// fallback for W too large for the LDS staging above: one thread per output element
+__global__ __launch_bounds__(256) void kp_symm_gemm_naive_kernel(const double* __restrict__ G, const double* __restrict__ X, int W, int nc,
+                                                                 double* __restrict__ C) {
+  int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (int64_t)W * nc) return;
+  const int i = (int)(e % W), j = (int)(e / W);
+  double s = 0.0;
+  for (int k = 0; k < W; ++k) s += G[i + (size_t)k * W] * X[k + (size_t)j * W];
+  C[i + (size_t)j * W] = s;
+}
+
+static hipError_t symm_gemm(hipStream_t st, const double* G, const double* X, int W, int nc, double* C) {
+  const size_t lds = (size_t)((W + 3) & ~3) * SG_RS * 8;
+  if (lds <= 156 * 1024) {
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
+      hipError_t e = hipFuncSetAttribute((const void*)kp_symm_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      lds_set = lds;
+    }
+    hipLaunchKernelGGL(kp_symm_gemm_kernel, dim3((W + 15) / 16, (nc + 31) / 32), dim3(512), lds, st, G, X, W, nc, C);
+  } else {
+    hipLaunchKernelGGL(kp_symm_gemm_naive_kernel, dim3((unsigned)(((int64_t)W * nc + 255) / 256)), dim3(256), 0, st, G, X, W, nc, C);
+  }
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// largest eigenvalue of G (Lipschitz constant of the gradient) by power iteration: y = G v with one wave per
+// row (G symmetric: row i is the contiguous column i), then one workgroup normalises.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__global__ __launch_bounds__(256) void kp_symv_kernel(const double* __restrict__ G, const double* __restrict__ v, int W, double* __restrict__ y) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= W) return;
+  double s = 0.0;
+  for (int k = lane; k < W; k += 64) s += G[k + (size_t)row * W] * v[k];
+  s = wave_sum(s);
+  if (lane == 0) y[row] = s;
+}
+
+__global__ __launch_bounds__(256) void kp_pw_norm_kernel(const double* __restrict__ y, int W, double* __restrict__ v, double* __restrict__ lam, int init) {
+  __shared__ double red[4];
+  const int tid = threadIdx.x;
+  if (init) {
+    for (int i = tid; i < W; i += 256) v[i] = 1.0 + 0.01 * (i % 7);
+    return;
+  }
+  double p = 0.0;
+  for (int i = tid; i < W; i += 256) p += y[i] * y[i];
+  p = wave_sum(p);
+  if ((tid & 63) == 0) red[tid >> 6] = p;
+  __syncthreads();
+  const double nrm = sqrt(red[0] + red[1] + red[2] + red[3]);
+  for (int i = tid; i < W; i += 256) v[i] = y[i] / nrm;
+  if (tid == 0) lam[0] = nrm * 1.0001;   // slight over-estimate keeps the step safe
+}
+
+// ------------------------------------------------------------------------------------------------
+// FISTA iteration kernels
+// ------------------------------------------------------------------------------------------------
+#define LS_NBLK 256
+struct LassoState {
+  double tk, mom, theta, t, invL;
+  double change, kmax, tot;
+  int done, notconv, passes, maxpasses, restarts;
+  unsigned counter;
+  double part[LS_NBLK][3];
+};
+
+// block reduction of up to three sums; result valid in thread 0
+__device__ __forceinline__ void block_sum3(double& a, double& b, double& c, double (*red)[3]) {
+  a = wave_sum(a); b = wave_sum(b); c = wave_sum(c);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[w][0] = a; red[w][1] = b; red[w][2] = c; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    a = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+    b = red[0][1] + red[1][1] + red[2][1] + red[3][1];
+    c = red[0][2] + red[1][2] + red[2][2] + red[3][2];
+  }
+}
+
+// true in exactly one workgroup: the last one to have published its partial
+__device__ __forceinline__ bool last_block(LassoState* st) {
+  __shared__ int is_last;
+  if (threadIdx.x == 0) {
+    __threadfence();
+    is_last = atomicAdd(&st->counter, 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  return is_last != 0;
+}
+
+// V = Y - (GY - C)/L with Y = K + mom (K - Kold), GY = GK + mom (GK - GKold); first Newton step from the previous threshold
+__global__ __launch_bounds__(256) void kp_lasso_v_kernel(const double* __restrict__ Kc, const double* __restrict__ Ko,
+                                                         const double* __restrict__ GKc, const double* __restrict__ GKo,
+                                                         const double* __restrict__ C, int64_t n, double* __restrict__ V,
+                                                         LassoState* __restrict__ st) {
+  __shared__ double red[4][3];
+  const double mom = st->mom, invL = st->invL, th0 = st->theta;
+  double tot = 0.0, ss = 0.0, cc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const double k = Kc[i], g = GKc[i];
+    const double y = k + mom * (k - Ko[i]);
+    const double gy = g + mom * (g - GKo[i]);
+    const double v = y - (gy - C[i]) * invL;
+    V[i] = v;
+    const double a = fabs(v);
+    tot += a;
+    if (a > th0) { ss += a; cc += 1.0; }
+  }
+  block_sum3(tot, ss, cc, red);
+  if (threadIdx.x == 0) { st->part[blockIdx.x][0] = tot; st->part[blockIdx.x][1] = ss; st->part[blockIdx.x][2] = cc; }
+  if (last_block(st)) {
+    const volatile double(*pp)[3] = st->part;
+    const bool on = threadIdx.x < gridDim.x;          // LS_NBLK <= 256: one partial per thread, fixed reduction tree
+    tot = on ? pp[threadIdx.x][0] : 0.0; ss = on ? pp[threadIdx.x][1] : 0.0; cc = on ? pp[threadIdx.x][2] : 0.0;
+    __syncthreads();
+    block_sum3(tot, ss, cc, red);
+  if (threadIdx.x == 0) {
+    st->tot = tot;
+    st->passes = 1;
+    if (tot <= st->t) { st->theta = 0.0; st->done = 1; }
+    else { st->theta = cc > 0.0 ? fmax((ss - st->t) / cc, 0.0) : (tot - st->t) / (double)n; st->done = 0; }
+    st->counter = 0u;
+  }
+  }
+}
+
+// one Newton step on f(theta) = sum max(|v| - theta, 0) - t  (Michelot: theta <- (sum_{|v|>theta} |v| - t) / #{|v|>theta});
+// after the first step the sequence increases monotonically and stops exactly at the fixed point
+__global__ __launch_bounds__(256) void kp_lasso_newton_kernel(const double* __restrict__ V, int64_t n, LassoState* __restrict__ st) {
+  __shared__ double red[4][3];
+  if (st->done) return;
+  const double th = st->theta;
+  double ss = 0.0, cc = 0.0, z = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const double a = fabs(V[i]);
+    if (a > th) { ss += a; cc += 1.0; }
+  }
+  block_sum3(ss, cc, z, red);
+  if (threadIdx.x == 0) { st->part[blockIdx.x][0] = ss; st->part[blockIdx.x][1] = cc; }
+  if (last_block(st)) {
+    const volatile double(*pp)[3] = st->part;
+    const bool on = threadIdx.x < gridDim.x;
+    ss = on ? pp[threadIdx.x][0] : 0.0; cc = on ? pp[threadIdx.x][1] : 0.0; z = 0.0;
+    __syncthreads();
+    block_sum3(ss, cc, z, red);
+  if (threadIdx.x == 0) {
+    const double nt = cc > 0.0 ? (ss - st->t) / cc : th;
+    if (nt > th) st->theta = nt; else st->done = 1;
+    st->passes += 1;
+    st->counter = 0u;
+  }
+  }
+}
+
+// Kn = soft(V, theta); restart test <Y - Kn, Kn - K> > 0; momentum scalars for the next iteration
+__global__ __launch_bounds__(256) void kp_lasso_final_kernel(const double* __restrict__ V, const double* __restrict__ Kc,
+                                                             const double* __restrict__ Ko, int64_t n, double* __restrict__ Kn,
+                                                             LassoState* __restrict__ st) {
+  __shared__ double red[4][3];
+  const double th = st->theta, mom = st->mom;
+  double dot = 0.0, chg = 0.0, kmx = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const double v = V[i], k = Kc[i];
+    const double a = fabs(v) - th;
+    const double kn = a > 0.0 ? copysign(a, v) : 0.0;
+    const double y = k + mom * (k - Ko[i]);
+    Kn[i] = kn;
+    dot += (y - kn) * (kn - k);
+    chg = fmax(chg, fabs(kn - k));
+    kmx = fmax(kmx, fabs(kn));
+  }
+  dot = wave_sum(dot); chg = wave_max(chg); kmx = wave_max(kmx);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[w][0] = dot; red[w][1] = chg; red[w][2] = kmx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    st->part[blockIdx.x][0] = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+    st->part[blockIdx.x][1] = fmax(fmax(red[0][1], red[1][1]), fmax(red[2][1], red[3][1]));
+    st->part[blockIdx.x][2] = fmax(fmax(red[0][2], red[1][2]), fmax(red[2][2], red[3][2]));
+  }
+  if (last_block(st)) {
+    const volatile double(*pp)[3] = st->part;
+    const bool on = threadIdx.x < gridDim.x;
+    dot = on ? pp[threadIdx.x][0] : 0.0; chg = on ? pp[threadIdx.x][1] : 0.0; kmx = on ? pp[threadIdx.x][2] : 0.0;
+    __syncthreads();
+    dot = wave_sum(dot); chg = wave_max(chg); kmx = wave_max(kmx);
+    if ((threadIdx.x & 63) == 0) { red[w][0] = dot; red[w][1] = chg; red[w][2] = kmx; }
+    __syncthreads();
+  if (threadIdx.x == 0) {
+    dot = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+    chg = fmax(fmax(red[0][1], red[1][1]), fmax(red[2][1], red[3][1]));
+    kmx = fmax(fmax(red[0][2], red[1][2]), fmax(red[2][2], red[3][2]));
+    const double tk = st->tk;
+    const bool restart = dot > 0.0;
+    const double tn = restart ? 1.0 : 0.5 * (1.0 + sqrt(1.0 + 4.0 * tk * tk));
+    st->mom = restart ? 0.0 : (tk - 1.0) / tn;
+    st->tk = tn;
+    st->change = chg;
+    st->kmax = kmx;
+    st->restarts += restart ? 1 : 0;
+    if (!st->done) st->notconv += 1;          // the Newton passes of this iteration did not reach the fixed point
+    st->maxpasses = max(st->maxpasses, st->passes);
+    st->done = 0;
+    st->counter = 0u;
+  }
+  }
+}
+
+__global__ __launch_bounds__(256) void kp_l1norm_kernel(const double* __restrict__ K, int64_t n, double* out) {
+  __shared__ double r[4];
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 256) s += fabs(K[i]);
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) r[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = r[0] + r[1] + r[2] + r[3];
+}
+
+__global__ void kp_add_diag_kernel(double* G, int W, double v) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < W) G[i + (size_t)i * W] += v;
+}
+
+// Least-squares solution + its L1 norm, PSD guard and Lipschitz constant: shared by all lasso values of one fit.
+int kp_lasso_prepare(kp_ctx* ctx, const double* G_dev, const double* C_dev, int W, int ncols, kp_lasso_prep* p) {
+  const int64_t n = (int64_t)W * ncols;
+  const size_t bK = (size_t)n * 8, bG = (size_t)W * W * 8;
+  char* ws = (char*)ctx->workspace(3, bK + bG + (size_t)2 * W * 8 + 256);
+  if (!ws) return ctx->fail(KP_ERR_HIP, "kp_fit_lasso: out of device memory");
+  p->Kls = (double*)ws;
+  p->Gw = (double*)(ws + bK);
+  double* vec = (double*)(ws + bK + bG);
+  double* yv = vec + W;
+  double* scal = yv + W;
+  hipStream_t s = ctx->stream;
+  // least-squares solution; if it satisfies the constraint it is the answer (the QP of Ksysid.m:1126-1137
+  // then has an inactive L1 row)
+  KP_HIP(ctx, hipMemcpyAsync(p->Gw, G_dev, bG, hipMemcpyDeviceToDevice, s));
+  int rc = kp_chol_solve_dev(ctx, p->Gw, const_cast<double*>(C_dev), W, ncols, p->Kls);
+  if (rc) return rc;
+  hipLaunchKernelGGL(kp_l1norm_kernel, dim3(1), dim3(256), 0, s, p->Kls, n, scal);
+  {
+    const int np = (W + 15) / 16 * 16, ncp = (ncols + 15) / 16 * 16;
+    size_t off = (size_t)np * np * 8 + (size_t)np * ncp * 8 + (size_t)(np / 16) * 256 * 8;
+    KP_HIP(ctx, hipMemcpyAsync(&p->bad, (char*)ctx->ws[5] + off, sizeof(int), hipMemcpyDeviceToHost, s));
+  }
+  KP_HIP(ctx, hipMemcpyAsync(&p->l1_ls, scal, 8, hipMemcpyDeviceToHost, s));
+  KP_HIP(ctx, hipStreamSynchronize(s));
+  // PSD guard of Ksysid.m:1117-1120: a non-PD Gram gets 1e-6 on the diagonal
+  if (p->bad) hipLaunchKernelGGL(kp_add_diag_kernel, dim3((W + 255) / 256), dim3(256), 0, s, p->Gw, W, 1e-6);
+  hipLaunchKernelGGL(kp_pw_norm_kernel, dim3(1), dim3(256), 0, s, yv, W, vec, scal, 1);
+  for (int it = 0; it < 60; ++it) {
+    hipLaunchKernelGGL(kp_symv_kernel, dim3((W + 3) / 4), dim3(256), 0, s, p->Gw, vec, W, yv);
+    hipLaunchKernelGGL(kp_pw_norm_kernel, dim3(1), dim3(256), 0, s, yv, W, vec, scal, 0);
+  }
+  KP_HIP(ctx, hipGetLastError());
+  KP_HIP(ctx, hipMemcpyAsync(&p->L, scal, 8, hipMemcpyDeviceToHost, s));
+  KP_HIP(ctx, hipStreamSynchronize(s));
+  if (!(p->L > 0.0)) return ctx->fail(KP_ERR_ARG, "kp_fit_lasso: Gram matrix is zero");
+  p->ready = true;
+  return KP_OK;
+}
+
+int kp_lasso_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, int W, int ncols, double t, int max_iter, double tol,
+                 double* K_dev, int* iters, kp_lasso_prep* prep) {
+  kp_lasso_prep local;
+  if (!prep) prep = &local;
+  if (!prep->ready) {
+    int rc = kp_lasso_prepare(ctx, G_dev, C_dev, W, ncols, prep);
+    if (rc) return rc;
+  }
+  const int64_t n = (int64_t)W * ncols;
+  const size_t bK = (size_t)n * 8;
+  hipStream_t s = ctx->stream;
+  if (iters) *iters = 0;
+  if (!prep->bad && prep->l1_ls <= t) {
+    KP_HIP(ctx, hipMemcpyAsync(K_dev, prep->Kls, bK, hipMemcpyDeviceToDevice, s));
+    return KP_OK;
+  }
+  // buffers: K x3 (old, current, new), GK x2, V, state
+  char* ws = (char*)ctx->workspace(7, 6 * bK + sizeof(LassoState) + 256);
+  if (!ws) return ctx->fail(KP_ERR_HIP, "kp_fit_lasso: out of device memory");
+  double* Kb[3] = {(double*)ws, (double*)(ws + bK), (double*)(ws + 2 * bK)};
+  double* GKb[2] = {(double*)(ws + 3 * bK), (double*)(ws + 4 * bK)};
+  double* V = (double*)(ws + 5 * bK);
+  LassoState* st = (LassoState*)(ws + 6 * bK);
+  KP_HIP(ctx, hipMemsetAsync(ws, 0, 5 * bK, s));                  // FISTA from K = 0
+  std::vector<char> hbuf(sizeof(LassoState), 0);
+  LassoState& h = *reinterpret_cast<LassoState*>(hbuf.data());
+  h.tk = 1.0; h.mom = 0.0; h.theta = 0.0; h.t = t; h.invL = 1.0 / prep->L; h.change = 1e300;
+  KP_HIP(ctx, hipMemcpyAsync(st, &h, sizeof(LassoState), hipMemcpyHostToDevice, s));
+  const int nblk = (int)std::min<int64_t>(LS_NBLK, (n + 255) / 256);
+  int ko = 0, kc = 1, kn = 2, go = 0, gc = 1;     // roles of the buffers
+  int P = 24;                                      // Newton passes launched per iteration (adapted every block)
+  int it = 0;
+  const int check_every = 20;
+  bool converged = false;
+  struct Scal { double change, kmax; int notconv, maxpasses; };
+  while (it < max_iter) {
+    for (int c = 0; c < check_every && it < max_iter; ++c, ++it) {
+      hipLaunchKernelGGL(kp_lasso_v_kernel, dim3(nblk), dim3(256), 0, s, Kb[kc], Kb[ko], GKb[gc], GKb[go], C_dev, n, V, st);
+      for (int p = 0; p < P; ++p) hipLaunchKernelGGL(kp_lasso_newton_kernel, dim3(nblk), dim3(256), 0, s, V, n, st);
+      hipLaunchKernelGGL(kp_lasso_final_kernel, dim3(nblk), dim3(256), 0, s, V, Kb[kc], Kb[ko], n, Kb[kn], st);
+      // rotate: old <- current, current <- new; then the product of the new current
+      const int tmp = ko; ko = kc; kc = kn; kn = tmp;
+      std::swap(go, gc);
+      KP_HIP(ctx, symm_gemm(s, prep->Gw, Kb[kc], W, ncols, GKb[gc]));
+    }
+    KP_HIP(ctx, hipMemcpyAsync(&h, st, offsetof(LassoState, part), hipMemcpyDeviceToHost, s));
+    KP_HIP(ctx, hipStreamSynchronize(s));
+    const bool exact = h.notconv == 0;
+    if (exact && h.change <= tol * std::max(1.0, h.kmax)) { converged = true; break; }
+    // adapt the number of Newton passes to what the last block needed
+    P = exact ? std::max(2, h.maxpasses + 1) : std::min(48, P + 6);
+    int zero2[2] = {0, 0};
+    KP_HIP(ctx, hipMemcpyAsync(&st->notconv, &zero2[0], sizeof(int), hipMemcpyHostToDevice, s));
+    KP_HIP(ctx, hipMemcpyAsync(&st->maxpasses, &zero2[1], sizeof(int), hipMemcpyHostToDevice, s));
+    KP_HIP(ctx, hipStreamSynchronize(s));
+  }
+  KP_HIP(ctx, hipMemcpyAsync(K_dev, Kb[kc], bK, hipMemcpyDeviceToDevice, s));
+  if (iters) *iters = it;
+  if (!converged) return ctx->fail(KP_ERR_NOT_CONVERGED, "kp_fit_lasso: iteration cap reached");
+  return KP_OK;
+}

@@ -33,225 +33,6 @@ static hipError_t gemm(hipStream_t st, int tA, int tB, int M, int N, int K, doub
   return hipGetLastError();
 }
 
-// ---- lasso: min 1/2 tr(K'GK) - tr(K'C)  s.t. ||vec K||_1 <= t ----------------------------------
-// Accelerated projected gradient (FISTA with gradient restart).  Projection onto the L1 ball by
-// Michelot's finite fixed-point iteration for the soft threshold (no sort).
-
-// largest eigenvalue of the symmetric PSD matrix G by power iteration (one workgroup)
-__global__ __launch_bounds__(1024) void kp_power_kernel(const double* __restrict__ G, int W, int iters, double* __restrict__ out) {
-  extern __shared__ double sm[];
-  double* v = sm;
-  double* w = sm + W;
-  __shared__ double red[1024];
-  const int tid = threadIdx.x;
-  for (int i = tid; i < W; i += 1024) v[i] = 1.0 + 0.01 * (i % 7);
-  __syncthreads();
-  double lam = 0.0;
-  for (int it = 0; it < iters; ++it) {
-    for (int i = tid; i < W; i += 1024) {
-      double s = 0.0;
-      for (int k = 0; k < W; ++k) s += G[i + (size_t)k * W] * v[k];
-      w[i] = s;
-    }
-    __syncthreads();
-    double p = 0.0;
-    for (int i = tid; i < W; i += 1024) p += w[i] * w[i];
-    red[tid] = p;
-    __syncthreads();
-    for (int o = 512; o > 0; o >>= 1) {
-      if (tid < o) red[tid] += red[tid + o];
-      __syncthreads();
-    }
-    lam = sqrt(red[0]);
-    __syncthreads();
-    for (int i = tid; i < W; i += 1024) v[i] = w[i] / lam;
-    __syncthreads();
-  }
-  if (tid == 0) out[0] = lam * 1.0001;   // slight over-estimate keeps the step safe
-}
-
-struct LassoState {
-  double tk;        // FISTA momentum scalar
-  double change;    // max |K_new - K_old|
-  double kmax;      // max |K_new|
-  int restarts;
-};
-
-// One workgroup: Kn = P_ball(Y - grad / L);  restart test;  Y <- Kn + ((tk-1)/tn)(Kn - K);  K <- Kn
-__global__ __launch_bounds__(1024) void kp_lasso_step_kernel(double* __restrict__ K, double* __restrict__ Y,
-                                                             const double* __restrict__ grad, int64_t n, double invL, double t,
-                                                             LassoState* __restrict__ st) {
-  __shared__ double r1[1024];
-  __shared__ double r2[1024];
-  __shared__ double theta_sh;
-  const int tid = threadIdx.x;
-  auto reduce2 = [&](double a, double b, double& oa, double& ob) {
-    r1[tid] = a;
-    r2[tid] = b;
-    __syncthreads();
-    for (int o = 512; o > 0; o >>= 1) {
-      if (tid < o) {
-        r1[tid] += r1[tid + o];
-        r2[tid] += r2[tid + o];
-      }
-      __syncthreads();
-    }
-    oa = r1[0];
-    ob = r2[0];
-    __syncthreads();
-  };
-  // v = Y - grad/L  (kept in `Y` storage as a temporary is unsafe: recompute on the fly)
-  double s1 = 0.0, cnt = 0.0;
-  for (int64_t i = tid; i < n; i += 1024) s1 += fabs(Y[i] - grad[i] * invL);
-  double tot, dummy;
-  reduce2(s1, 0.0, tot, dummy);
-  double theta = 0.0;
-  if (tot > t) {
-    theta = (tot - t) / (double)n;   // Michelot: theta_{k+1} = (sum_{|v|>theta_k} |v| - t) / #{|v|>theta_k}
-    for (int it = 0; it < 200; ++it) {
-      s1 = 0.0;
-      cnt = 0.0;
-      for (int64_t i = tid; i < n; i += 1024) {
-        double a = fabs(Y[i] - grad[i] * invL);
-        if (a > theta) {
-          s1 += a;
-          cnt += 1.0;
-        }
-      }
-      double ss, cc;
-      reduce2(s1, cnt, ss, cc);
-      double nt = cc > 0.0 ? (ss - t) / cc : theta;
-      bool done = !(nt > theta);   // non-decreasing sequence; stops at the fixed point
-      theta = nt > theta ? nt : theta;
-      if (done) break;
-    }
-  }
-  if (tid == 0) theta_sh = theta;
-  __syncthreads();
-  theta = theta_sh;
-  // restart test  <Y - Kn, Kn - K> > 0, change, max
-  double dot = 0.0, chg = 0.0, kmx = 0.0;
-  for (int64_t i = tid; i < n; i += 1024) {
-    double v = Y[i] - grad[i] * invL;
-    double a = fabs(v) - theta;
-    double kn = a > 0.0 ? copysign(a, v) : 0.0;
-    dot += (Y[i] - kn) * (kn - K[i]);
-    chg = fmax(chg, fabs(kn - K[i]));
-    kmx = fmax(kmx, fabs(kn));
-  }
-  double dsum, d2;
-  reduce2(dot, 0.0, dsum, d2);
-  r1[tid] = chg;
-  r2[tid] = kmx;
-  __syncthreads();
-  for (int o = 512; o > 0; o >>= 1) {
-    if (tid < o) {
-      r1[tid] = fmax(r1[tid], r1[tid + o]);
-      r2[tid] = fmax(r2[tid], r2[tid + o]);
-    }
-    __syncthreads();
-  }
-  const double change = r1[0], kmax = r2[0];
-  const double tk = st->tk;
-  double tn = 0.5 * (1.0 + sqrt(1.0 + 4.0 * tk * tk));
-  const bool restart = dsum > 0.0;
-  if (restart) tn = 1.0;
-  const double mom = restart ? 0.0 : (tk - 1.0) / tn;
-  __syncthreads();
-  for (int64_t i = tid; i < n; i += 1024) {
-    double v = Y[i] - grad[i] * invL;
-    double a = fabs(v) - theta;
-    double kn = a > 0.0 ? copysign(a, v) : 0.0;
-    double ko = K[i];
-    Y[i] = kn + mom * (kn - ko);
-    K[i] = kn;
-  }
-  if (tid == 0) {
-    st->tk = tn;
-    st->change = change;
-    st->kmax = kmax;
-    st->restarts += restart ? 1 : 0;
-  }
-}
-
-__global__ void kp_l1norm_kernel(const double* __restrict__ K, int64_t n, double* out) {
-  __shared__ double r[256];
-  double s = 0.0;
-  for (int64_t i = threadIdx.x; i < n; i += 256) s += fabs(K[i]);
-  r[threadIdx.x] = s;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (threadIdx.x < o) r[threadIdx.x] += r[threadIdx.x + o];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) out[0] = r[0];
-}
-
-__global__ void kp_add_diag_kernel(double* G, int W, double v) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < W) G[i + (size_t)i * W] += v;
-}
-
-int kp_lasso_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, int W, int ncols, double t, int max_iter, double tol,
-                 double* K_dev, int* iters) {
-  const int64_t n = (int64_t)W * ncols;
-  size_t bK = (size_t)n * 8;
-  char* ws = (char*)ctx->workspace(7, 2 * bK + (size_t)W * W * 8 + 256);
-  if (!ws) return ctx->fail(KP_ERR_HIP, "kp_fit_lasso: out of device memory");
-  double* Y = (double*)ws;
-  double* grad = (double*)(ws + bK);
-  double* Gw = (double*)(ws + 2 * bK);
-  double* scal = (double*)(ws + 2 * bK + (size_t)W * W * 8);   // [0] L or l1 norm
-  LassoState* st = (LassoState*)(scal + 2);
-  hipStream_t s = ctx->stream;
-  if (iters) *iters = 0;
-  // 1. least-squares solution; if it satisfies the constraint it is the answer (the QP of
-  //    Ksysid.m:1126-1137 then has an inactive L1 row)
-  KP_HIP(ctx, hipMemcpyAsync(Gw, G_dev, (size_t)W * W * 8, hipMemcpyDeviceToDevice, s));
-  int rc = kp_chol_solve_dev(ctx, Gw, const_cast<double*>(C_dev), W, ncols, K_dev);
-  if (rc) return rc;
-  hipLaunchKernelGGL(kp_l1norm_kernel, dim3(1), dim3(256), 0, s, K_dev, n, scal);
-  double l1 = 0.0;
-  int bad = 0;
-  {
-    const int np = (W + 15) / 16 * 16, ncp = (ncols + 15) / 16 * 16;
-    size_t off = (size_t)np * np * 8 + (size_t)np * ncp * 8 + (size_t)(np / 16) * 256 * 8;
-    KP_HIP(ctx, hipMemcpyAsync(&bad, (char*)ctx->ws[5] + off, sizeof(int), hipMemcpyDeviceToHost, s));
-  }
-  KP_HIP(ctx, hipMemcpyAsync(&l1, scal, 8, hipMemcpyDeviceToHost, s));
-  KP_HIP(ctx, hipStreamSynchronize(s));
-  if (!bad && l1 <= t) return KP_OK;
-  // PSD guard of Ksysid.m:1117-1120: a non-PD Gram gets 1e-6 on the diagonal
-  if (bad) hipLaunchKernelGGL(kp_add_diag_kernel, dim3((W + 255) / 256), dim3(256), 0, s, Gw, W, 1e-6);
-  // 2. FISTA from K = 0
-  KP_HIP(ctx, hipFuncSetAttribute((const void*)kp_power_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * W * 8));
-  hipLaunchKernelGGL(kp_power_kernel, dim3(1), dim3(1024), 2 * W * 8, s, Gw, W, 60, scal);
-  double L = 0.0;
-  KP_HIP(ctx, hipMemcpyAsync(&L, scal, 8, hipMemcpyDeviceToHost, s));
-  KP_HIP(ctx, hipMemsetAsync(K_dev, 0, bK, s));
-  KP_HIP(ctx, hipMemsetAsync(Y, 0, bK, s));
-  LassoState h{1.0, 1e300, 0.0, 0};
-  KP_HIP(ctx, hipMemcpyAsync(st, &h, sizeof(h), hipMemcpyHostToDevice, s));
-  KP_HIP(ctx, hipStreamSynchronize(s));
-  if (!(L > 0.0)) return ctx->fail(KP_ERR_ARG, "kp_fit_lasso: Gram matrix is zero");
-  int it = 0;
-  const int check_every = 20;
-  while (it < max_iter) {
-    for (int c = 0; c < check_every && it < max_iter; ++c, ++it) {
-      KP_HIP(ctx, hipMemcpyAsync(grad, C_dev, bK, hipMemcpyDeviceToDevice, s));
-      KP_HIP(ctx, gemm(s, 0, 0, W, ncols, W, 1.0, Gw, W, Y, W, -1.0, grad, W));   // grad = G Y - C
-      hipLaunchKernelGGL(kp_lasso_step_kernel, dim3(1), dim3(1024), 0, s, K_dev, Y, grad, n, 1.0 / L, t, st);
-    }
-    KP_HIP(ctx, hipMemcpyAsync(&h, st, sizeof(h), hipMemcpyDeviceToHost, s));
-    KP_HIP(ctx, hipStreamSynchronize(s));
-    if (h.change <= tol * std::max(1.0, h.kmax)) break;
-  }
-  if (iters) *iters = it;
-  if (it >= max_iter && !(h.change <= tol * std::max(1.0, h.kmax)))
-    return ctx->fail(KP_ERR_NOT_CONVERGED, "kp_fit_lasso: iteration cap reached");
-  return KP_OK;
-}
-
 extern "C" int kp_fit_lasso(kp_ctx* ctx, const double* G, const double* C, int W, int ncols, double t, int max_iter, double tol,
                             double* K, int* iters) {
   if (!ctx || !G || !C || !K || W < 1 || ncols < 1 || !(t >= 0.0)) return ctx ? ctx->fail(KP_ERR_ARG, "kp_fit_lasso: bad argument") : KP_ERR_ARG;

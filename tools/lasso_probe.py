@@ -1,5 +1,5 @@
 import sys, time, numpy as np
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import koopman_realizations_amd as kra, bench
 from oracle import koopman_oracle as ko
 ctx = kra.Context(0); a, b, u = bench.synth_pairs(100000)
