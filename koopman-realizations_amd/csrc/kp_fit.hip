@@ -45,96 +45,207 @@ __device__ __forceinline__ double lane_bcast(double v, int lane) {
   return __hiloint2double(hi, lo);
 }
 
-__global__ __launch_bounds__(1024) void kp_chol_kernel(double* __restrict__ A, int n, double* __restrict__ Dinv, int* __restrict__ info,
-                                                       int* __restrict__ sticky) {
-  extern __shared__ double sm[];
-  __shared__ double D[16][PS];
-  __shared__ double Di[16][PS];
+#ifndef KP_CHOL_ABL
+#define KP_CHOL_ABL 0
+#endif
+#define CH_NT 512   // 8 waves: two per SIMD, 256 VGPRs each (the 8 x 8 micro tiles of the trailing update hold 64 accumulators)
+
+// 16 x 16 diagonal block at (k0, k0) by ONE wave, entirely in registers: lane r (< 16) owns row r; pivots and
+// pivot-column entries travel by v_readlane, so the 16 serial pivot steps need no LDS round trip and no
+// workgroup barrier.  Writes L (lower) / L' (upper) into A, the block D (LDS, lower part) and the reciprocals
+// Dd of its diagonal.  The inverses of the diagonal blocks, which only the TRSM kernel needs, are formed after the
+// factorisation by kp_chol_finish_kernel, off the critical path.
+__device__ __forceinline__ void chol_diag_block(double* __restrict__ A, int n, int k0, double (*D)[16], double* Dd, int* bad) {
+  const int lane = threadIdx.x & 63;
+  const int r = lane & 15;
+  double row[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) row[c] = A[(size_t)(k0 + c) * n + k0 + r];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    double d = lane_bcast(row[c], c);
+    if (!(d > 0.0)) {
+      if (lane == 0) *bad = 1;
+      d = 1.0;
+    }
+    // 1/sqrt(d): hardware estimate + two Newton steps (full f64 accuracy, no division)
+    double id = __builtin_amdgcn_rsq(d);
+    id = id * (1.5 - 0.5 * d * id * id);
+    id = id * (1.5 - 0.5 * d * id * id);
+    if (lane == c) Dd[c] = id;
+    const double l = row[c] * id;          // lane c: sqrt(d); lanes r > c: L_rc
+    row[c] = l;
+#pragma unroll
+    for (int cc = c + 1; cc < 16; ++cc) row[cc] -= l * lane_bcast(l, cc);   // entries with cc <= r are used
+  }
+  if (lane < 16) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const double lrc = c <= r ? row[c] : 0.0;
+      D[r][c] = lrc;
+      if (c <= r) {
+        A[(size_t)(k0 + c) * n + k0 + r] = lrc;             // L (lower)
+        A[(size_t)(k0 + r) * n + k0 + c] = lrc;             // L' (upper)
+      }
+    }
+  }
+}
+
+// 8 x 8 micro tile (ti >= tj) of the trailing update A22 -= L21 L21': L21 is in LDS as Lt[q][row] (the 8 values
+// of a tile row are contiguous: 16-byte LDS reads, no bank conflicts between lanes with neighbouring tiles)
+__device__ __forceinline__ void chol_tile_update(double* __restrict__ A22, int n, const double* __restrict__ Lt, int ld, int ti, int tj,
+                                                 double* __restrict__ Pnext) {
+  // the tile is loaded first (32 independent 16-byte loads in flight), updated in registers and stored once
+  double acc[8][8];
+#pragma unroll
+  for (int y = 0; y < 8; ++y) {
+    const double2* src = reinterpret_cast<const double2*>(A22 + (size_t)(8 * tj + y) * n + 8 * ti);
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const double2 v = src[h];
+      acc[2 * h][y] = v.x;
+      acc[2 * h + 1][y] = v.y;
+    }
+  }
+#pragma unroll 4
+  for (int q = 0; q < 16; ++q) {
+    double rv[8], cv[8];
+    const double2* pr = reinterpret_cast<const double2*>(Lt + (size_t)q * ld + 8 * ti);
+    const double2* pc = reinterpret_cast<const double2*>(Lt + (size_t)q * ld + 8 * tj);
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const double2 a = pr[h], c = pc[h];
+      rv[2 * h] = a.x; rv[2 * h + 1] = a.y;
+      cv[2 * h] = c.x; cv[2 * h + 1] = c.y;
+    }
+#pragma unroll
+    for (int x = 0; x < 8; ++x)
+#pragma unroll
+      for (int y = 0; y < 8; ++y) acc[x][y] -= rv[x] * cv[y];
+  }
+#pragma unroll
+  for (int y = 0; y < 8; ++y) {
+    double2* dst = reinterpret_cast<double2*>(A22 + (size_t)(8 * tj + y) * n + 8 * ti);
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      double2 v;
+      v.x = acc[2 * h][y];
+      v.y = acc[2 * h + 1][y];
+      dst[h] = v;
+      // the first 16 columns of A22 are the next panel's A21: keep them in LDS ([q][row - 16]) for the next step
+      if (tj <= 1) *reinterpret_cast<double2*>(Pnext + (size_t)(8 * tj + y) * ld + 8 * ti - 16 + 2 * h) = v;
+    }
+  }
+}
+
+// After the factorisation: L' into the upper triangle (the TRSM kernel reads both orientations coalesced), one 16 x 16
+// block pair per workgroup, and the inverses of the diagonal blocks (one wave each), Dinv[kb][col][row].
+__global__ __launch_bounds__(256) void kp_chol_finish_kernel(double* __restrict__ A, int n, int npair, double* __restrict__ Dinv) {
+  __shared__ double T[16][17];
+  const int p = blockIdx.x, t = threadIdx.x;
+  if (p >= npair) {                                  // inverse of diagonal block kb: lane j builds column j
+    if (t >= 64) return;
+    const int kb = p - npair, k0 = 16 * kb, r = t & 15;
+    double row[16], x[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) row[c] = A[(size_t)(k0 + c) * n + k0 + r];     // L_rc for c <= r
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {                   // x_i = -(sum_{q=j}^{i-1} L_iq x_q) / L_ii, x_j = 1 / L_jj
+      double sacc = 0.0;
+#pragma unroll
+      for (int q = 0; q < i; ++q) {
+        const double liq = lane_bcast(row[q], i);    // L_iq lives in lane i, register q
+        sacc += (q >= r) ? liq * x[q] : 0.0;
+      }
+      const double idg = 1.0 / lane_bcast(row[i], i);
+      x[i] = i == r ? idg : (i > r ? -sacc * idg : 0.0);
+    }
+    if (t < 16) {
+#pragma unroll
+      for (int c = 0; c < 16; ++c) Dinv[(size_t)kb * 256 + r * 16 + c] = x[c];   // inverse(c, r)
+    }
+    return;
+  }
+  int bi = (int)((1.0 + sqrt(1.0 + 8.0 * (double)p)) * 0.5);      // pair index -> block (bi > bj)
+  while (bi * (bi - 1) / 2 > p) --bi;
+  while ((bi + 1) * bi / 2 <= p) ++bi;
+  const int bj = p - bi * (bi - 1) / 2;
+  T[t >> 4][t & 15] = A[(size_t)(16 * bj + (t >> 4)) * n + 16 * bi + (t & 15)];     // L block: column t>>4, row t&15
+  __syncthreads();
+  A[(size_t)(16 * bi + (t >> 4)) * n + 16 * bj + (t & 15)] = T[t & 15][t >> 4];
+}
+
+__global__ __launch_bounds__(CH_NT) void kp_chol_kernel(double* __restrict__ A, int n, double* __restrict__ Dinv, int* __restrict__ info,
+                                                        int* __restrict__ sticky, int prof) {
+  long long tph[5] = {0, 0, 0, 0, 0}, tlast = 0;   // KP_CHOL_PROF=1: cycles per phase, printed by thread 0
+#define CH_TICK(i) do { if (prof) { long long tnow = clock64(); tph[i] += tnow - tlast; tlast = tnow; } } while (0)
+  extern __shared__ __align__(16) double sm[];
+  __shared__ __align__(16) double D[16][16];
+  __shared__ double Dd[16];
   __shared__ int bad;
-  double* Pin = sm;                    // [R][PS]
-  double* Pout = sm + (size_t)n * PS;  // [R][PS]
-  const int tid = threadIdx.x;
+  double* Pin = sm;                     // A21 as [q][row], leading dimension n
+  double* Lt = sm + (size_t)16 * n;     // L21 as [q][row]
+  const int tid = threadIdx.x, wave = tid >> 6;
   if (tid == 0) bad = 0;
+  __syncthreads();
   const int nt = n / 16;
+  if (wave == 0) chol_diag_block(A, n, 0, D, Dd, &bad);
+  __syncthreads();
+  if (prof) tlast = clock64();
   for (int kb = 0; kb < nt; ++kb) {
     const int k0 = kb * 16;
     const int R = n - k0 - 16;
-    // ---- 16 x 16 diagonal block by wave 0, entirely in registers: lane r (< 16) owns row r; pivots and
-    // pivot-column entries travel by v_readlane, so the 16 serial pivot steps need no LDS round trip and
-    // no workgroup barrier (a barrier-per-step version spent most of its time in s_barrier) ----
-    if (tid < 64) {
-      const int r = tid & 15;
-      double row[16];
-#pragma unroll
-      for (int c = 0; c < 16; ++c) row[c] = A[(size_t)(k0 + c) * n + k0 + r];
-      double idg[16];
+    if (R <= 0) break;
+    // A21 -> LDS as [q][row] (consecutive threads = consecutive rows: coalesced, conflict free).  Only for the first
+    // panel: afterwards the trailing update of the previous step has left the panel in LDS already.
+    if (kb == 0) {
+      for (int e = tid; e < R * 16; e += CH_NT) {
+        const int r = e % R, q = e / R;
+        Pin[q * n + r] = A[(size_t)(k0 + q) * n + k0 + 16 + r];
+      }
+      __syncthreads();
+    }
+    CH_TICK(0);
+    // L21 = A21 * L^-T by forward substitution, one thread per row (the block L and 1/diag are broadcast LDS reads)
+#if KP_CHOL_ABL != 3
+    for (int r = tid; r < R; r += CH_NT) {
+      double l[16];
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
-        double d = lane_bcast(row[c], c);
-        if (!(d > 0.0)) {
-          if (tid == 0) bad = 1;
-          d = 1.0;
-        }
-        // 1/sqrt(d): hardware estimate + two Newton steps (full f64 accuracy, no division)
-        double id = __builtin_amdgcn_rsq(d);
-        id = id * (1.5 - 0.5 * d * id * id);
-        id = id * (1.5 - 0.5 * d * id * id);
-        idg[c] = id;
-        const double l = row[c] * id;          // lane c: sqrt(d); lanes r > c: L_rc
-        row[c] = l;
+        double sacc = Pin[c * n + r];
 #pragma unroll
-        for (int cc = c + 1; cc < 16; ++cc) row[cc] -= l * lane_bcast(l, cc);   // entries with cc <= r are used
+        for (int q = 0; q < c; ++q) sacc -= l[q] * D[c][q];
+        l[c] = sacc * Dd[c];
+        Lt[c * n + r] = l[c];
+        A[(size_t)(k0 + c) * n + k0 + 16 + r] = l[c];   // L (lower); L' (upper) is filled in once at the end
       }
-      // inverse of the lower-triangular block: lane j builds column j, x_i = -(sum_{q=j}^{i-1} L_iq x_q) / L_ii
-      double x[16];
+    }
+#endif
+    __syncthreads();
+    CH_TICK(1);
+    // trailing update of the lower triangle in 8 x 8 micro tiles.  Look-ahead: the next diagonal block is updated first; then wave 0 factors that block while the other waves update the rest.
+    const int ntb = R / 8;                          // even (R is a multiple of 16)
+    double* A22 = A + (size_t)(k0 + 16) * n + k0 + 16;
+    if (tid < 256) {                                // next diagonal block = micro tiles (0,0), (1,0), (1,1)
+      const int r = tid & 15, c = tid >> 4;
+      if (r >= c) {
+        double s = 0.0;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        double sacc = 0.0;
-#pragma unroll
-        for (int q = 0; q < i; ++q) {
-          const double liq = lane_bcast(row[q], i);            // L_iq lives in lane i, register q
-          sacc += (q >= r) ? liq * x[q] : 0.0;
-        }
-        x[i] = i == r ? idg[i] : (i > r ? -sacc * idg[i] : 0.0);
-      }
-      if (tid < 16) {
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-          D[r][c] = c <= r ? row[c] : 0.0;
-          Di[c][r] = x[c];                                      // column r of the inverse
-        }
+        for (int q = 0; q < 16; ++q) s += Lt[q * n + r] * Lt[q * n + c];
+        A22[(size_t)c * n + r] -= s;
       }
     }
     __syncthreads();
-    if (tid < 256) {
-      int r = tid & 15, c = tid >> 4;
-      A[(size_t)(k0 + c) * n + k0 + r] = (r >= c) ? D[r][c] : D[c][r];
-      Dinv[(size_t)kb * 256 + c * 16 + r] = Di[r][c];
-    }
-    if (R > 0) {
-      // A21 -> LDS
-      for (int e = tid; e < R * 16; e += 1024) {
-        int r = e % R, q = e / R;
-        Pin[r * PS + q] = A[(size_t)(k0 + q) * n + k0 + 16 + r];
-      }
-      __syncthreads();
-      // L21 = A21 * D^-T
-      for (int e = tid; e < R * 16; e += 1024) {
-        int r = e % R, c = e / R;
-        double s = 0.0;
-        for (int q = 0; q <= c; ++q) s += Pin[r * PS + q] * Di[c][q];
-        Pout[r * PS + c] = s;
-        A[(size_t)(k0 + c) * n + k0 + 16 + r] = s;   // L (lower)
-        A[(size_t)(k0 + 16 + r) * n + k0 + c] = s;   // L' (upper)
-      }
-      __syncthreads();
-      // trailing update of the lower triangle in 4x4 micro tiles; the triangle of ntb x ntb
-      // micro tiles is folded into an (ntb+1) x (ntb/2) rectangle
-      const int ntb = R / 4;
+    CH_TICK(2);
+    if (wave == 0) {
+#if KP_CHOL_ABL != 2
+      chol_diag_block(A, n, k0 + 16, D, Dd, &bad);
+#endif
+    } else {
+      // the triangle of ntb x ntb micro tiles is folded into an (ntb+1) x (ntb/2) rectangle; tiles (0,0),(1,0),(1,1) are done
       const int total = (ntb + 1) * (ntb / 2);
-      double* A22 = A + (size_t)(k0 + 16) * n + k0 + 16;
-      for (int e = tid; e < total; e += 1024) {
-        int i = e % (ntb + 1), j = e / (ntb + 1);
+      for (int e = tid - 64; e < total; e += CH_NT - 64) {
+        const int i = e % (ntb + 1), j = e / (ntb + 1);
         int ti, tj;
         if (i > j) {
           ti = i - 1;
@@ -143,30 +254,19 @@ __global__ __launch_bounds__(1024) void kp_chol_kernel(double* __restrict__ A, i
           ti = ntb - 1 - i;
           tj = ntb - 1 - j;
         }
-        const double* pr = Pout + (size_t)(4 * ti) * PS;
-        const double* pc = Pout + (size_t)(4 * tj) * PS;
-        double acc[4][4] = {};
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          double rv[4], cv[4];
-#pragma unroll
-          for (int x = 0; x < 4; ++x) {
-            rv[x] = pr[x * PS + q];
-            cv[x] = pc[x * PS + q];
-          }
-#pragma unroll
-          for (int x = 0; x < 4; ++x)
-#pragma unroll
-            for (int y = 0; y < 4; ++y) acc[x][y] += rv[x] * cv[y];
-        }
-#pragma unroll
-        for (int y = 0; y < 4; ++y)
-#pragma unroll
-          for (int x = 0; x < 4; ++x) A22[(size_t)(4 * tj + y) * n + 4 * ti + x] -= acc[x][y];
+        if (ti <= 1) continue;                      // (0,0), (1,0), (1,1)
+#if KP_CHOL_ABL != 1
+        chol_tile_update(A22, n, Lt, n, ti, tj, Pin);
+#endif
       }
     }
+    if (prof && wave == 0) CH_TICK(3);       // wave 0: the diagonal block alone
     __syncthreads();
+    if (prof && wave == 0) CH_TICK(4); else CH_TICK(3);
   }
+  if (prof && (tid == 0 || tid == 64))
+    printf("chol prof tid %d: A21 load %lld  L21 %lld  next-diag update %lld  [wave0: diag | others: tiles] %lld  wait %lld\n", tid, tph[0], tph[1], tph[2],
+           tph[3], tph[4]);
   if (tid == 0) {
     *info = bad;
     if (bad && sticky) *sticky = 1;
@@ -271,7 +371,7 @@ int kp_chol_solve_dev(kp_ctx* ctx, double* G_dev, double* C_dev, int W, int ncol
   double* Cp = (double*)(ws + bG);
   double* Dinv = (double*)(ws + bG + bC);
   int* info = (int*)(ws + bG + bC + bD);
-  size_t lds_chol = (size_t)2 * n * PS * 8;
+  size_t lds_chol = (size_t)2 * 16 * n * 8;
   size_t lds_trsm = ((size_t)n * 16 + 1024) * 8;
   if (lds_chol > 160 * 1024 - 4096 || lds_trsm > 160 * 1024 || n > 16 * 4 * TR_MAXJ) return ctx->fail(KP_ERR_ARG, "kp_fit_solve: W too large (max ~580)");
   int64_t tot = (int64_t)n * n + (int64_t)n * ncp;
@@ -283,7 +383,13 @@ int kp_chol_solve_dev(kp_ctx* ctx, double* G_dev, double* C_dev, int W, int ncol
     KP_HIP(ctx, hipFuncSetAttribute((const void*)kp_chol_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_chol));
     chol_lds_set = lds_chol;
   }
-  hipLaunchKernelGGL(kp_chol_kernel, dim3(1), dim3(1024), lds_chol, st, Gp, n, Dinv, info, sticky);
+  static const int chol_prof = getenv("KP_CHOL_PROF") ? 1 : 0;
+  hipLaunchKernelGGL(kp_chol_kernel, dim3(1), dim3(CH_NT), lds_chol, st, Gp, n, Dinv, info, sticky, chol_prof);
+  KP_HIP(ctx, hipGetLastError());
+  {
+    const int nb = n / 16, npair = nb * (nb - 1) / 2;
+    hipLaunchKernelGGL(kp_chol_finish_kernel, dim3(npair + nb), dim3(256), 0, st, Gp, n, npair, Dinv);
+  }
   KP_HIP(ctx, hipGetLastError());
   if (lds_trsm > trsm_lds_set) {
     KP_HIP(ctx, hipFuncSetAttribute((const void*)kp_trsm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_trsm));
