@@ -373,7 +373,7 @@ int kp_chol_solve_dev(kp_ctx* ctx, double* G_dev, double* C_dev, int W, int ncol
   int* info = (int*)(ws + bG + bC + bD);
   size_t lds_chol = (size_t)2 * 16 * n * 8;
   size_t lds_trsm = ((size_t)n * 16 + 1024) * 8;
-  if (lds_chol > 160 * 1024 - 4096 || lds_trsm > 160 * 1024 || n > 16 * 4 * TR_MAXJ) return ctx->fail(KP_ERR_ARG, "kp_fit_solve: W too large (max ~580)");
+  if (lds_chol > 160 * 1024 - 4096 || lds_trsm > 160 * 1024 || n > 16 * 4 * TR_MAXJ) return ctx->fail(KP_ERR_ARG, "kp_fit_solve: W too large (max 512)");
   int64_t tot = (int64_t)n * n + (int64_t)n * ncp;
   hipLaunchKernelGGL(kp_pad_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, G_dev, C_dev, W, ncols, n, ncp, Gp, Cp);
   KP_HIP(ctx, hipGetLastError());

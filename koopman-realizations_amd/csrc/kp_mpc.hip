@@ -308,9 +308,9 @@ __device__ int qp_goldfarb_idnani(const double* Hq, const double* f, const EllMa
           break;
         }
         const double ib = 1.0 / apz;
-        for (int e = lane; e < q * q; e += 64) {
-          int i = e % q, j = e / q;
-          Sinv[i + j * n] += r[i] * r[j] * ib;
+        if (lane < q) {                         // lane i owns row i (q <= n <= 64): no index arithmetic
+          const double ri = r[lane] * ib;
+          for (int j = 0; j < q; ++j) Sinv[lane + j * n] += ri * r[j];
         }
         for (int c = lane; c < q; c += 64) {
           Sinv[c + q * n] = -r[c] * ib;
@@ -332,9 +332,10 @@ __device__ int qp_goldfarb_idnani(const double* Hq, const double* f, const EllMa
         const double isl = 1.0 / Sinv[l + l * n];
         for (int c = lane; c < q; c += 64) r[c] = Sinv[c + l * n];
         WSYNC();
-        for (int e = lane; e < q * q; e += 64) {
-          int i = e % q, j = e / q;
-          if (i != l && j != l) Sinv[i + j * n] -= r[i] * r[j] * isl;
+        if (lane < q && lane != l) {
+          const double ri = r[lane] * isl;
+          for (int j = 0; j < q; ++j)
+            if (j != l) Sinv[lane + j * n] -= ri * r[j];
         }
         WSYNC();
         // compact: lane i owns row i (q <= 64); columns shift left one at a time

@@ -118,7 +118,7 @@ def test_gram_linearity_in_snapshots(ctx):
     assert G[dic.N - 1, dic.N - 1] == 100000.0
 
 
-@pytest.mark.parametrize("W,nc", [(5, 5), (16, 16), (17, 3), (136, 136), (336, 336)])
+@pytest.mark.parametrize("W,nc", [(5, 5), (16, 16), (17, 3), (32, 1), (33, 7), (48, 48), (136, 136), (336, 336), (500, 16)])
 def test_solve_parity(ctx, W, nc):
     rng = np.random.default_rng(W)
     P = rng.standard_normal((4 * W + 10, W)); Y = rng.standard_normal((4 * W + 10, nc))
