@@ -297,7 +297,10 @@ class Ksysid:
                 K = fit(self.ctx, self.basis_dev, snaps, [np.inf])[0]
             else:                                                          # :994-999: t = lasso * N
                 lval = 1e4 if lasso is None else float(lasso)
-                K = fit(self.ctx, self.basis_dev, snaps, [lval])[0]
+                if self.model_type == "linear" and self.params["nd"] >= 1:
+                    K = self._lasso_with_delay_rows(snaps, lval * N)           # :1139-1164
+                else:
+                    K = fit(self.ctx, self.basis_dev, snaps, [lval])[0]
         finally:
             snaps.close()
         koop = {"K": K, "u": snapshotPairs["u"], "alpha": snapshotPairs["alpha"]}
@@ -305,6 +308,29 @@ class Ksysid:
             koop["Px"] = self.basis_dev.lift(F.LIFT_ROW, snapshotPairs["alpha"], snapshotPairs["u"])[:, :N]
             koop["Py"] = self.basis_dev.lift(F.LIFT_ROW, snapshotPairs["beta"], snapshotPairs["u"])[:, :N]
         return koop
+
+    def _lasso_with_delay_rows(self, snaps, t):
+        """solve_KoopmanQP of a LINEAR model with delays (Ksysid.m:1139-1164): the columns of K that produce the
+        delayed part of zeta are pinned to 0/1 by equality rows.  The objective separates by column, so the pinned
+        columns are constants and each pinned 1 uses one unit of the L1 budget: the free columns are the lasso
+        with t - #ones, solved on the device from the same Grams."""
+        p = self.params; n, m, nd, N = p["n"], p["m"], p["nd"], p["N"]
+        Nm, nnd, mnd = N + m, n * nd, m * nd
+        ones = []
+        for i in range(nnd):                               # :1146-1149 (index - 1 = Nm * column offset + row)
+            idx = (Nm + 1) * i; ones.append((idx % Nm, n + idx // Nm))
+        for i in range(m):                                 # :1150-1153
+            idx = Nm * nnd + N + (Nm + 1) * i; ones.append((idx % Nm, n + idx // Nm))
+        for i in range(m * (nd - 1)):                      # :1154-1157
+            idx = Nm * (nnd + m) + nnd + (Nm + 1) * i; ones.append((idx % Nm, n + idx // Nm))
+        c0, c1 = n, n * (nd + 1) + mnd
+        G, C = fit_gram(self.ctx, self.basis_dev, snaps)
+        free = [j for j in range(Nm) if not (c0 <= j < c1)]
+        K = np.zeros((Nm, Nm), order="F")
+        for r, c in ones:
+            K[r, c] = 1.0
+        K[:, free] = self.ctx.fit_lasso(G, np.asfortranarray(C[:, free]), t - len(ones))[0]
+        return K
 
     def get_model(self, koopData):
         """Ksysid.m:1179-1235 (discrete): A, B, C and the projection M."""

@@ -377,13 +377,45 @@ def koopman_lasso(G, C, t, iters=200000, tol=1e-13):
     return K
 
 
+def delay_pins(n, m, nd, N):
+    """Equality rows of solve_KoopmanQP for LINEAR models with delays (Ksysid.m:1139-1164): the columns of K that
+    produce the delayed part of zeta (columns n .. n(nd+1)+m nd - 1, i.e. vec rows n*Nm+1 : Nm*(n(nd+1)+mnd))
+    are pinned to 0/1.  Returns (first fixed column, one past the last, list of (row, col) entries equal to 1),
+    0-based, decoded from the literal index formulas of :1146-1157 (index - 1 = Nm * col_offset + row)."""
+    Nm, nnd, mnd = N + m, n * nd, m * nd
+    ones = []
+    for i in range(nnd):                               # :1146-1149  state delays
+        idx = (Nm + 1) * i
+        ones.append((idx % Nm, n + idx // Nm))
+    for i in range(m):                                 # :1150-1153  first input delay
+        idx = Nm * nnd + N + (Nm + 1) * i
+        ones.append((idx % Nm, n + idx // Nm))
+    for i in range(m * (nd - 1)):                      # :1154-1157  subsequent input delays
+        idx = Nm * (nnd + m) + nnd + (Nm + 1) * i
+        ones.append((idx % Nm, n + idx // Nm))
+    return n, n * (nd + 1) + mnd, ones
+
+
+def koopman_lasso_delays(G, C, t, n, m, nd, N):
+    """solve_KoopmanQP for a linear model with nd >= 1: the pinned columns are constants of the (column-separable)
+    objective and use |1| of the L1 budget each, so the free columns solve the same problem with t - #ones."""
+    c0, c1, ones = delay_pins(n, m, nd, N)
+    W = G.shape[0]
+    free = [j for j in range(C.shape[1]) if not (c0 <= j < c1)]
+    K = np.zeros((W, C.shape[1]))
+    for r, c in ones:
+        K[r, c] = 1.0
+    K[:, free] = koopman_lasso(G, C[:, free], t - len(ones))
+    return K
+
+
 def lasso_kkt_residual(G, C, K, t):
     """Optimality measure for the L1-ball problem: || K - P_ball(K - grad) ||_inf."""
     g = G @ K - C
     return np.abs(K - project_l1_ball((K - g).ravel(), t).reshape(K.shape)).max()
 
 
-def get_koopman(dic, pairs, lasso=None, obj_lasso=1e6):
+def get_koopman(dic, pairs, lasso=None, obj_lasso=1e6, n=None, nd=0):
     """Ksysid.m:987-1092.  `lasso` is the per-call argument (t = lasso*N, :996;
     default 1e4*N, :994,999); `obj_lasso` the class property tested at :1068."""
     Px, Py = px_py(dic, pairs)
@@ -392,7 +424,10 @@ def get_koopman(dic, pairs, lasso=None, obj_lasso=1e6):
     else:
         t = (1e4 if lasso is None else lasso) * dic.N
         G, C = gram(Px, Py)
-        K = koopman_lasso(G, C, t)
+        if dic.model_type == 'linear' and nd >= 1:    # :1139 liftinput == 0 && nd >= 1
+            K = koopman_lasso_delays(G, C, t, n, dic.m, nd, dic.N)
+        else:
+            K = koopman_lasso(G, C, t)
     N = dic.N
     return {'K': K, 'Px': Px[:, :N], 'Py': Py[:, :N], 'u': pairs['u'], 'alpha': pairs['alpha']}
 

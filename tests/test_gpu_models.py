@@ -139,3 +139,30 @@ def test_ksysid_mirror_other_dictionaries(ctx, golden, kind, deg, nfull, dim_red
     np.testing.assert_allclose(ks.lift.econ_full(np.array([0.3])), ko.econ_full(dic, np.array([[0.3]]))[0], atol=1e-12)
     res = ks.val_model(ks.model, ks.valdata[0])
     assert np.isfinite(res["error"]["mean"]).all()
+
+
+def test_linear_lasso_with_delays_pins_the_shift_columns(ctx, golden):
+    """Ksysid.m:1139-1164 through the host mirror: linear model, delays = 1, active L1 constraint."""
+    g = golden["rand_systems"]
+    n = 1001
+    train = [{"t": g["s0_train_t"][i * n:(i + 1) * n], "y": g["s0_train_y"][i * n:(i + 1) * n], "u": g["s0_train_u"][i * n:(i + 1) * n]}
+             for i in range(9)]
+    val = [{"t": g["s0_val_t"], "y": g["s0_val_y"], "u": g["s0_val_u"]}]
+    ks = kra.Ksysid({"train": train, "val": val}, ctx=ctx, model_type="linear", obs_type=["poly"], obs_degree=[2],
+                    snapshots=np.inf, lasso=[0.5], delays=1, dim_red=False)
+    p = ks.params
+    assert p["nd"] == 1 and p["nzeta"] == 3
+    koop = ks.get_Koopman(ks.snapshotPairs, 0.5, want_PxPy=False)
+    K = koop["K"]
+    N, m = p["N"], p["m"]
+    c0, c1, ones = ko.delay_pins(p["n"], m, 1, N)
+    pinned = np.zeros((N + m, c1 - c0))
+    for r, c in ones:
+        pinned[r, c - c0] = 1.0
+    assert np.array_equal(K[:, c0:c1], pinned)
+    dic = ko.build_dictionary("linear", p["nzeta"], m, ["poly"], [2])
+    Px, Py = ko.px_py(dic, ks.snapshotPairs)
+    G, C = ko.gram(Px, Py)
+    Kref = ko.koopman_lasso_delays(G, C, 0.5 * N, p["n"], m, 1, N)
+    assert np.abs(np.abs(K).sum() - 0.5 * N) < 1e-8            # the constraint is active
+    assert np.abs(K - Kref).max() <= 1e-5 * max(1.0, np.abs(Kref).max())

@@ -102,6 +102,43 @@ def test_hermite_and_fourier_sparser_blocks():
     np.testing.assert_allclose(Pf[:, 2 + r], np.sin(4 * np.pi * x), atol=1e-15)
 
 
+def test_delay_rows_of_the_lasso_qp():
+    """Ksysid.m:1139-1164 literally: bd_pos over vec rows n*Nm+1 : Nm*(n(nd+1)+m nd) with ones at the three index
+    families; the restatement pins the same entries of K, and the free columns satisfy the reduced problem's KKT."""
+    n, m, nd = 2, 1, 2
+    nzeta = n * (nd + 1) + m * nd
+    N = nzeta + 1                                     # poly degree 1 + constant
+    Nm, nnd, mnd = N + m, n * nd, m * nd
+    bd = np.zeros(Nm * (nnd + mnd))                   # 1-based MATLAB indices below
+    for i in range(1, nnd + 1):
+        bd[(Nm + 1) * (i - 1) + 1 - 1] = 1
+    for i in range(1, m + 1):
+        bd[Nm * nnd + N + (Nm + 1) * (i - 1) + 1 - 1] = 1
+    for i in range(1, m * (nd - 1) + 1):
+        bd[Nm * (nnd + m) + nnd + (Nm + 1) * (i - 1) + 1 - 1] = 1
+    vecK = np.full(Nm * Nm, np.nan)
+    vecK[n * Nm: Nm * (n * (nd + 1) + mnd)] = bd      # Ad_pos rows n*Nm+1 : Nm*(n(nd+1)+mnd)
+    Kpin = vecK.reshape(Nm, Nm, order="F")
+    c0, c1, ones = ko.delay_pins(n, m, nd, N)
+    assert (c0, c1) == (n, nzeta)
+    want = np.full((Nm, Nm), np.nan); want[:, c0:c1] = 0.0
+    for r, c in ones:
+        want[r, c] = 1.0
+    assert np.array_equal(np.isnan(want), np.isnan(Kpin)) and np.nanmax(np.abs(want - Kpin)) == 0
+    assert len(ones) == nnd + m + m * (nd - 1)
+    # state delays shift [x; xd] down by one block: K[i, n+i] = 1
+    assert all((i, n + i) in ones for i in range(nnd))
+    rng = np.random.default_rng(5)
+    P = rng.standard_normal((60, Nm)); Y = rng.standard_normal((60, Nm))
+    G, C = P.T @ P, P.T @ Y
+    free = [j for j in range(Nm) if not (c0 <= j < c1)]
+    t = 0.5 * np.abs(np.linalg.solve(G, C[:, free])).sum() + len(ones)
+    K = ko.koopman_lasso_delays(G, C, t, n, m, nd, N)
+    assert np.nanmax(np.abs(K[:, c0:c1] - want[:, c0:c1])) == 0
+    assert abs(np.abs(K).sum() - t) < 1e-9           # budget used exactly: pinned ones + active free part
+    assert ko.lasso_kkt_residual(G, C[:, free], K[:, free], t - len(ones)) < 1e-8
+
+
 def test_ls_fit_recovers_exact_linear_system():
     rng = np.random.default_rng(3)
     A = rng.standard_normal((3, 3)) * 0.3; B = rng.standard_normal((3, 2))
