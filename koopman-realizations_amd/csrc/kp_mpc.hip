@@ -121,8 +121,11 @@ struct EllMat {
 };
 
 // LDS scratch of the QP solver (doubles): Hinv n*n | HN n*n | Sinv n*n | x,hp,r,lam,d,zd,ap,f: 8n |
-// act: n ints | isact: mr bytes
-__host__ __device__ inline int qp_lds_doubles(int n, int mr) { return 3 * n * n + 9 * n + 2 * ((n + 1) / 2) + (mr + 7) / 8 + 8; }
+// act: n ints | isact: mr bytes | LDS copy of the constraint rows when K <= QP_KLDS: val mr*K, col mr*K ints, norm mr, b mr
+#define QP_KLDS 4
+__host__ __device__ inline int qp_lds_doubles(int n, int mr) {
+  return 3 * n * n + 9 * n + 2 * ((n + 1) / 2) + (mr + 7) / 8 + 8 + mr * QP_KLDS + (mr * QP_KLDS + 1) / 2 + 2 * mr + 2;
+}
 
 // Wave-local synchronisation: LDS operations of one wave complete in issue order, so lanes only
 // need the compiler not to reorder across this point (usable inside multi-wave workgroups).
@@ -155,6 +158,22 @@ __device__ int qp_goldfarb_idnani(const double* Hq, const double* f, const EllMa
   int* apc = (int*)(apv + n);                // and columns
   int* act = apc + n + (n & 1);
   unsigned char* isact = (unsigned char*)(act + n + (n & 1));
+  // constraint rows in LDS (the violation scan of every iteration reads all of them; from global memory a scan costs
+  // ~3000 cycles of L2 latency)
+  double* lval = (double*)(((uintptr_t)(isact + mr) + 7) & ~(uintptr_t)7);
+  double* lnorm = lval + mr * QP_KLDS;
+  double* lb = lnorm + mr;
+  int* lcol = (int*)(lb + mr);
+  const bool ell_lds = A.K <= QP_KLDS;
+  const double* Aval = A.val;
+  const int* Acol = A.col;
+  const double* Anorm = A.norm;
+  const double* bv_ = bvec;
+  if (ell_lds) {
+    for (int e = lane; e < mr * A.K; e += 64) { lval[e] = A.val[e]; lcol[e] = A.col[e]; }
+    for (int e = lane; e < mr; e += 64) { lnorm[e] = A.norm[e]; lb[e] = bvec[e]; }
+    Aval = lval; Acol = lcol; Anorm = lnorm; bv_ = lb;
+  }
 
   // ---- Hinv by in-place Gauss-Jordan (SPD: no pivoting) ----
   if (!have_hinv)
@@ -197,6 +216,12 @@ __device__ int qp_goldfarb_idnani(const double* Hq, const double* f, const EllMa
   WSYNC();
 
   if (stamps && lane == 0) stamps[4] = wall_clock64();
+#ifdef KP_QP_PROF
+  long long qpt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, qlast = clock64();
+#define QP_TICK(i) do { long long tn_ = clock64(); qpt[i] += tn_ - qlast; qlast = tn_; } while (0)
+#else
+#define QP_TICK(i) do { } while (0)
+#endif
   int q = 0;
   int status = 1;
   int it = bad ? QP_MAXIT : 0;   // non-SPD Hessian: report failure
@@ -207,9 +232,9 @@ __device__ int qp_goldfarb_idnani(const double* Hq, const double* f, const EllMa
     int bestp = 0x7fffffff;
     int infeas = 0;
     for (int row = lane; row < mr; row += 64) {
-      double v = -bvec[row];
-      for (int k = 0; k < A.K; ++k) v += A.val[k * mr + row] * x[A.col[k * mr + row]];
-      const double nr = A.norm[row];
+      double v = -bv_[row];
+      for (int k = 0; k < A.K; ++k) v += Aval[k * mr + row] * x[Acol[k * mr + row]];
+      const double nr = Anorm[row];
       if (nr == 0.0) {
         if (v > tol) infeas = 1;
         continue;
@@ -221,6 +246,7 @@ __device__ int qp_goldfarb_idnani(const double* Hq, const double* f, const EllMa
       }
     }
     wave_argmax(best, bestp);
+    QP_TICK(0);
     infeas = __any(infeas);
     if (infeas) break;
     if (best <= tol) {
@@ -228,11 +254,11 @@ __device__ int qp_goldfarb_idnani(const double* Hq, const double* f, const EllMa
       break;
     }
     const int p = bestp;
-    const double bp = bvec[p];
+    const double bp = bv_[p];
     // sparse a_p: (col_k, val_k), k < K, staged in LDS (apv/apc) for the loops below; dense copy in ap
     if (lane < A.K) {
-      double v = A.val[lane * mr + p];
-      int cidx = A.col[lane * mr + p];
+      double v = Aval[lane * mr + p];
+      int cidx = Acol[lane * mr + p];
       apv[lane] = v;
       apc[lane] = cidx;
       if (v != 0.0) ap[cidx] = v;
@@ -247,6 +273,7 @@ __device__ int qp_goldfarb_idnani(const double* Hq, const double* f, const EllMa
     }
     const double app = wave_sum(app_l);
     WSYNC();
+    QP_TICK(1);
     double lam_p = 0.0;
     bool fail = false;
     while (it < QP_MAXIT) {
@@ -258,6 +285,7 @@ __device__ int qp_goldfarb_idnani(const double* Hq, const double* f, const EllMa
         d[c] = s;
       }
       WSYNC();
+      QP_TICK(6);
       for (int c = lane; c < q; c += 64) {
         double s = 0.0;
 #pragma unroll 4
@@ -265,6 +293,7 @@ __device__ int qp_goldfarb_idnani(const double* Hq, const double* f, const EllMa
         r[c] = s;
       }
       WSYNC();
+      QP_TICK(7);
       double apz_l = 0.0, apx_l = 0.0;
       for (int i = lane; i < n; i += 64) {
         double s = hp[i];
@@ -274,8 +303,10 @@ __device__ int qp_goldfarb_idnani(const double* Hq, const double* f, const EllMa
         apz_l += ap[i] * s;
         apx_l += ap[i] * x[i];
       }
+      QP_TICK(8);
       const double apz = wave_sum(apz_l);
       const double apx = wave_sum(apx_l);
+      QP_TICK(9);
       double t1 = 1e300;
       int l = 0x7fffffff;
       for (int c = lane; c < q; c += 64) {
@@ -288,6 +319,7 @@ __device__ int qp_goldfarb_idnani(const double* Hq, const double* f, const EllMa
         }
       }
       wave_argmin(t1, l);
+      QP_TICK(2);
       const bool t2fin = apz > 1e-13 * app;
       const double t2 = t2fin ? (apx - bp) / apz : 1e300;
       const double t = fmin(t1, t2);
@@ -301,6 +333,7 @@ __device__ int qp_goldfarb_idnani(const double* Hq, const double* f, const EllMa
       if (t2fin)
         for (int i = lane; i < n; i += 64) x[i] -= t * zd[i];
       WSYNC();
+      QP_TICK(3);
       if (t2 <= t1) {
         // add p: Sinv <- bordered inverse with w = r, beta = apz (Schur complement)
         if (q >= n) {
@@ -325,46 +358,46 @@ __device__ int qp_goldfarb_idnani(const double* Hq, const double* f, const EllMa
         }
         ++q;
         WSYNC();
+        QP_TICK(4);
         break;
       }
-      // partial step: drop active constraint l  (Schur deletion on the inverse, then compaction)
+      // partial step: drop active constraint l.  The active set is unordered, so l is first swapped with the last
+      // entry (symmetric permutation of Sinv, column swap of HN); deleting the LAST index of the inverse Schur
+      // complement is then one rank-1 downdate of the leading block - no compaction sweeps.
       {
-        const double isl = 1.0 / Sinv[l + l * n];
-        for (int c = lane; c < q; c += 64) r[c] = Sinv[c + l * n];
-        WSYNC();
-        if (lane < q && lane != l) {
-          const double ri = r[lane] * isl;
-          for (int j = 0; j < q; ++j)
-            if (j != l) Sinv[lane + j * n] -= ri * r[j];
-        }
-        WSYNC();
-        // compact: lane i owns row i (q <= 64); columns shift left one at a time
-        {
-          const int i = lane;
-          const bool ok = i < q && i != l;
-          const int in_ = i > l ? i - 1 : i;
-          for (int j = 0; j < q; ++j) {
-            if (j == l) continue;
-            const int jn = j > l ? j - 1 : j;
-            double v = ok ? Sinv[i + j * n] : 0.0;
-            WSYNC();
-            if (ok) Sinv[in_ + jn * n] = v;
-            WSYNC();
+        const int last = q - 1;
+        if (l != last) {
+          if (lane < q) {                       // columns l <-> last (lane = row)
+            const double a = Sinv[lane + l * n], b = Sinv[lane + last * n];
+            Sinv[lane + l * n] = b;
+            Sinv[lane + last * n] = a;
           }
-        }
-        for (int j = l; j + 1 < q; ++j) {
-          for (int i = lane; i < n; i += 64) HN[i + j * n] = HN[i + (j + 1) * n];
+          WSYNC();
+          if (lane < q) {                       // rows l <-> last (lane = column)
+            const double a = Sinv[l + lane * n], b = Sinv[last + lane * n];
+            Sinv[l + lane * n] = b;
+            Sinv[last + lane * n] = a;
+          }
+          for (int i = lane; i < n; i += 64) {
+            const double a = HN[i + l * n];
+            HN[i + l * n] = HN[i + last * n];
+            HN[i + last * n] = a;
+          }
+          if (lane == 0) {
+            const int ta = act[l]; act[l] = act[last]; act[last] = ta;
+            const double tl = lam[l]; lam[l] = lam[last]; lam[last] = tl;
+          }
           WSYNC();
         }
-        if (lane == 0) {
-          isact[act[l]] = 0;
-          for (int c = l; c + 1 < q; ++c) {
-            act[c] = act[c + 1];
-            lam[c] = lam[c + 1];
-          }
+        const double isl = 1.0 / Sinv[last + last * n];
+        if (lane < last) {
+          const double ri = Sinv[lane + last * n] * isl;
+          for (int j = 0; j < last; ++j) Sinv[lane + j * n] -= ri * Sinv[last + j * n];
         }
+        if (lane == 0) isact[act[last]] = 0;
         --q;
         WSYNC();
+        QP_TICK(5);
       }
     }
     // clear the dense copy of a_p
@@ -377,6 +410,11 @@ __device__ int qp_goldfarb_idnani(const double* Hq, const double* f, const EllMa
     stamps[8] = it;
     stamps[9] = q;
   }
+#ifdef KP_QP_PROF
+  if (stamps && lane == 0)
+    printf("qp prof (cycles): scan+argmax %lld  a_p/hp %lld  ratios %lld  step %lld  add(border) %lld  drop %lld | d %lld r %lld zd %lld sums %lld  it %d q %d\n",
+           qpt[0], qpt[1], qpt[2], qpt[3], qpt[4], qpt[5], qpt[6], qpt[7], qpt[8], qpt[9], it, q);
+#endif
   for (int i = lane; i < n; i += 64) x_out[i] = status == 0 ? x[i] : __builtin_nan("");
   return status;
 }
