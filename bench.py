@@ -135,8 +135,8 @@ def cpu_baseline_mpc(pack):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--snapshots", type=int, default=100000)
     ap.add_argument("--degree", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -2,7 +2,7 @@
 """Condenses the rocprofv3 output of tools/prof_round.sh (gpurun_out/prof_r01/*) into
 profiles/r01_pmc_summary.json (per-kernel mean of every counter, per launch) and copies the
 kernel-trace statistics to profiles/r01_bench_kernel_stats.csv.  For each pass the newest run
-(largest process id in the file names) is used."""
+(most recently written files) is used."""
 import csv, glob, json, os, re, shutil, sys
 from collections import defaultdict
 
@@ -12,7 +12,7 @@ SRC = os.path.join(ROOT, "gpurun_out", "prof_r01")
 
 def newest(pattern):
     fs = glob.glob(pattern)
-    return max(fs, key=lambda f: int(re.match(r"(\d+)_", os.path.basename(f)).group(1))) if fs else None
+    return max(fs, key=os.path.getmtime) if fs else None          # newest run of this pass
 
 
 def short(name):
