@@ -132,42 +132,87 @@ extern "C" int kp_model_project(kp_ctx* ctx, const double* K, const double* G, c
 
 // ---- batched rollouts (val_model / val_BLmodel, Ksysid.m:1678-1689, 1772-1787) -------------------
 // One workgroup per model; z lives in LDS, thread r owns row r of z+.
+// One workgroup per trajectory.  The recurrence is serial in t, so a step must be short: the model matrices are
+// staged in LDS once (A always when N*N <= RO_STAGE doubles, B when it fits as well), the state is double buffered
+// (one barrier per step; a wave-level fence when the workgroup is a single wave), and the inputs of step t+1 are
+// fetched before the barrier of step t.
+#define RO_STAGE 8192
+#define RO_TC 256
+template <bool ONE_WAVE>
 __global__ __launch_bounds__(256) void kp_rollout_kernel(int bilinear, const double* __restrict__ A, const double* __restrict__ B,
                                                          int N, int m, const double* __restrict__ z0, const double* __restrict__ U,
-                                                         int T, int n_out, double* __restrict__ Y) {
+                                                         int T, int n_out, double* __restrict__ Y, int stageA, int stageB) {
   extern __shared__ double sm[];
-  double* z = sm;
-  double* zn = sm + N;
-  const int tid = threadIdx.x;
+  double* zb = sm;                                   // [2][N]
+  double* Ash = sm + 2 * N;
+  const int tid = threadIdx.x, nth = blockDim.x;
   const int bidx = blockIdx.x;
   const int mb = bilinear ? N * m : m;
+  double* Bsh = Ash + (stageA ? N * N : 0);
   const double* Ab = A + (size_t)bidx * N * N;
   const double* Bb = B + (size_t)bidx * N * mb;
   const double* Ub = U + (size_t)bidx * T * m;
   double* Yb = Y + (size_t)bidx * T * n_out;
-  for (int r = tid; r < N; r += 256) z[r] = z0[(size_t)bidx * N + r];
-  __syncthreads();
-  for (int t = 0; t < T; ++t) {
-    for (int r = tid; r < n_out; r += 256) Yb[(size_t)r * T + t] = z[r];     // y = C z, C = [I 0] (Ksysid.m:1203)
-    if (t == T - 1) break;
-    for (int r = tid; r < N; r += 256) {
-      double s = 0.0;
-      for (int c = 0; c < N; ++c) s += Ab[r + (size_t)c * N] * z[c];
-      if (bilinear) {
-        for (int i = 0; i < m; ++i) {
-          const double* Bi = Bb + (size_t)i * N * N;
-          double q = 0.0;
-          for (int c = 0; c < N; ++c) q += Bi[r + (size_t)c * N] * z[c];
-          s += q * Ub[(size_t)i * T + t];
-        }
-      } else {
-        for (int i = 0; i < m; ++i) s += Bb[r + (size_t)i * N] * Ub[(size_t)i * T + t];
-      }
-      zn[r] = s;
+  if (stageA) {
+    for (int e = tid; e < N * N; e += nth) Ash[e] = Ab[e];
+    Ab = Ash;
+  }
+  if (stageB) {
+    for (int e = tid; e < N * mb; e += nth) Bsh[e] = Bb[e];
+    Bb = Bsh;
+  }
+  for (int r = tid; r < N; r += nth) zb[r] = z0[(size_t)bidx * N + r];
+  auto sync = [&]() {
+    if (ONE_WAVE) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+      __syncthreads();
     }
-    __syncthreads();
-    for (int r = tid; r < N; r += 256) z[r] = zn[r];
-    __syncthreads();
+  };
+  sync();
+  // time runs in chunks of RO_TC steps: the inputs of a chunk are staged in LDS and the outputs collected there, so no
+  // global-memory latency sits inside the serial recurrence
+  double* Uc = Bsh + (stageB ? N * mb : 0);          // [m][RO_TC]
+  double* Yc = Uc + m * RO_TC;                       // [n_out][RO_TC]
+  for (int t0 = 0; t0 < T; t0 += RO_TC) {
+    const int tc = min(RO_TC, T - t0);
+    for (int e = tid; e < m * tc; e += nth) {
+      const int i = e / tc, tt = e - i * tc;
+      Uc[i * RO_TC + tt] = Ub[(size_t)i * T + t0 + tt];
+    }
+    sync();
+    for (int tt = 0; tt < tc; ++tt) {
+      const int t = t0 + tt;
+      const double* z = zb + (t & 1) * N;
+      double* zn = zb + ((t + 1) & 1) * N;
+      for (int r = tid; r < n_out; r += nth) Yc[r * RO_TC + tt] = z[r];     // y = C z, C = [I 0] (Ksysid.m:1203)
+      if (t == T - 1) break;
+      for (int r = tid; r < N; r += nth) {
+        double s = 0.0;
+#pragma unroll 4
+        for (int c = 0; c < N; ++c) s += Ab[r + (size_t)c * N] * z[c];
+        if (bilinear) {
+          for (int i = 0; i < m; ++i) {
+            const double* Bi = Bb + (size_t)i * N * N;
+            double q = 0.0;
+#pragma unroll 4
+            for (int c = 0; c < N; ++c) q += Bi[r + (size_t)c * N] * z[c];
+            s += q * Uc[i * RO_TC + tt];
+          }
+        } else {
+          for (int i = 0; i < m; ++i) s += Bb[r + (size_t)i * N] * Uc[i * RO_TC + tt];
+        }
+        zn[r] = s;
+      }
+      sync();
+    }
+    for (int e = tid; e < n_out * tc; e += nth) {
+      const int r = e / tc, tt = e - r * tc;
+      Yb[(size_t)r * T + t0 + tt] = Yc[r * RO_TC + tt];
+    }
+    sync();
   }
 }
 
@@ -191,7 +236,21 @@ extern "C" int kp_rollout(kp_ctx* ctx, int model_type, int batch, const double* 
   KP_HIP(ctx, hipMemcpyAsync(dz, z0, nz * 8, hipMemcpyHostToDevice, s));
   if (nU) KP_HIP(ctx, hipMemcpyAsync(dU, U, nU * 8, hipMemcpyHostToDevice, s));
   KP_HIP(ctx, hipEventRecord(ctx->ev0, s));
-  hipLaunchKernelGGL(kp_rollout_kernel, dim3(batch), dim3(256), (size_t)2 * N * 8, s, bil, dA, dB, N, m, dz, dU, T, n_out, dY);
+  {
+    const int stageA = (size_t)N * N <= RO_STAGE;
+    const int stageB = stageA && (size_t)N * N + (size_t)N * mb <= RO_STAGE + RO_STAGE / 2;
+    const size_t lds = ((size_t)2 * N + (stageA ? (size_t)N * N : 0) + (stageB ? (size_t)N * mb : 0) + (size_t)(m + n_out) * RO_TC) * 8;
+    static bool attr = false;
+    if (!attr) {
+      KP_HIP(ctx, hipFuncSetAttribute((const void*)kp_rollout_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+      KP_HIP(ctx, hipFuncSetAttribute((const void*)kp_rollout_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+      attr = true;
+    }
+    if (N <= 64)
+      hipLaunchKernelGGL(kp_rollout_kernel<true>, dim3(batch), dim3(64), lds, s, bil, dA, dB, N, m, dz, dU, T, n_out, dY, stageA, stageB);
+    else
+      hipLaunchKernelGGL(kp_rollout_kernel<false>, dim3(batch), dim3(256), lds, s, bil, dA, dB, N, m, dz, dU, T, n_out, dY, stageA, stageB);
+  }
   KP_HIP(ctx, hipGetLastError());
   KP_HIP(ctx, hipEventRecord(ctx->ev1, s));
   KP_HIP(ctx, hipMemcpyAsync(Y, dY, nY * 8, hipMemcpyDeviceToHost, s));
