@@ -217,6 +217,7 @@ extern "C" int kp_basis_create(kp_ctx* ctx, const kp_basis_desc* d, kp_basis** o
     b->max_factors = max_nf;
     b->pow_depth = D;
     if (fast) {
+      b->h_recipes = rec;
       int rc0 = upload(ctx, &b->d_recipes, rec.data(), rec.size() * 4);
       if (rc0) { delete b; return rc0; }
     }
@@ -262,6 +263,7 @@ extern "C" int kp_basis_destroy(kp_basis* b) {
   kp_gram_plan_free(b->plan);
   kp_gram2_plan_free(b->plan2);
   kp_gram3_plan_free(b->plan3);
+  kp_gram5_plan_free(b->plan5);
   delete b;
   return KP_OK;
 }

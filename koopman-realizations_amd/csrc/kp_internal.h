@@ -88,6 +88,8 @@ struct kp_gram2_plan;
 void kp_gram2_plan_free(kp_gram2_plan* p);
 struct kp_gram3_plan;
 void kp_gram3_plan_free(kp_gram3_plan* p);
+struct kp_gram5_plan;
+void kp_gram5_plan_free(kp_gram5_plan* p);
 
 struct kp_basis {
   kp_ctx* ctx = nullptr;
@@ -104,6 +106,8 @@ struct kp_basis {
   kp_gram_plan* plan = nullptr;  // tile->wave plan of the fused Gram kernel (built on first use)
   kp_gram2_plan* plan2 = nullptr;  // plan of the 4x4x4-MFMA Gram kernel (monomial dictionaries)
   kp_gram3_plan* plan3 = nullptr;  // plan of the Kronecker (bilinear) Gram kernel
+  kp_gram5_plan* plan5 = nullptr;  // plan of the dense 4x4x4 Gram kernel (linear / nonlinear monomial dictionaries)
+  std::vector<uint32_t> h_recipes; // host copy of the recipes (valid if fast)
 };
 
 struct kp_snapshots {
@@ -199,8 +203,11 @@ int kp_gram2_launch(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* s, d
 // picks the 4x4x4-MFMA kernel when the dictionary allows it, else the general kernel
 bool kp_gram3_applicable(const kp_basis* basis);
 int kp_gram3_launch(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* s, double* GC_dev);
+bool kp_gram5_applicable(const kp_basis* basis);
+int kp_gram5_launch(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* s, double* GC_dev);
 inline int kp_gram_dispatch(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* s, double* GC_dev) {
   if (kp_gram3_applicable(basis)) return kp_gram3_launch(ctx, basis, s, GC_dev);
+  if (kp_gram5_applicable(basis)) return kp_gram5_launch(ctx, basis, s, GC_dev);
   return kp_gram2_applicable(basis) ? kp_gram2_launch(ctx, basis, s, GC_dev) : kp_gram_launch(ctx, basis, s, GC_dev);
 }
 int kp_chol_solve_dev(kp_ctx* ctx, double* G_dev, double* C_dev, int W, int ncols, double* K_dev, hipStream_t st = nullptr,
