@@ -333,15 +333,20 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
 
 // Sums the partials of one (job, quad, weight) block vector in split order and scatters the
 // 4 blocks (4x4 each) into G and C.  lane l: block = (l>>2)&3, row r = l>>4, col c = l&3.
-__global__ __launch_bounds__(64) void kp_gram3_reduce_kernel(const double* __restrict__ part, int nsplit, int njobs, int NQ, int NWT,
+__global__ __launch_bounds__(256) void kp_gram3_reduce_kernel(const double* __restrict__ part, int nsplit, int njobs, int NQ, int NWT,
                                                              int BM, const uint32_t* __restrict__ desc, int G4, int N, int W,
                                                              double* __restrict__ G, double* __restrict__ C) {
   const int idx = blockIdx.x;                 // (job*NQ + q)*NWT + w
   const int w = idx % NWT, jq = idx / NWT, q = jq % NQ, job = jq / NQ;
-  const int l = threadIdx.x;
+  const int l = threadIdx.x & 63, wv = threadIdx.x >> 6;   // 4 waves share the split sum (fixed order: deterministic)
+  __shared__ double red4[4][64];
   const size_t per_split = (size_t)njobs * NQ * NWT * 64;
   double s = 0.0;
-  for (int p = 0; p < nsplit; ++p) s += part[(size_t)p * per_split + (size_t)idx * 64 + l];
+  for (int p = wv; p < nsplit; p += 4) s += part[(size_t)p * per_split + (size_t)idx * 64 + l];
+  red4[wv][l] = s;
+  __syncthreads();
+  if (wv) return;
+  s = (red4[0][l] + red4[1][l]) + (red4[2][l] + red4[3][l]);
   const uint32_t* jd = desc + (size_t)job * (1 + NQ);
   const int ga = q < (int)((jd[0] >> 16) & 255u) ? (int)(jd[0] & 255u) : (int)((jd[0] >> 8) & 255u);
   const int gb = (int)((jd[1 + q] >> (8 * ((l >> 2) & 3))) & 255u);
@@ -542,7 +547,7 @@ int kp_gram3_launch(kp_ctx* ctx, const kp_basis* basis_c, const kp_snapshots* s,
     KP_HIP(ctx, hipEventRecord(ctx->ev_main_done, ctx->stream));
     KP_HIP(ctx, hipStreamWaitEvent(rs, ctx->ev_main_done, 0));
   }
-  hipLaunchKernelGGL(kp_gram3_reduce_kernel, dim3(plan.njobs * plan.nq * NWT), dim3(64), 0, rs, part, nsplit, plan.njobs,
+  hipLaunchKernelGGL(kp_gram3_reduce_kernel, dim3(plan.njobs * plan.nq * NWT), dim3(256), 0, rs, part, nsplit, plan.njobs,
                      plan.nq, NWT, BM, plan.desc, plan.G4, N, W, GC_dev, GC_dev + (size_t)W * W);
   KP_HIP(ctx, hipGetLastError());
   KP_HIP(ctx, hipEventRecord(ctx->ev1, rs));

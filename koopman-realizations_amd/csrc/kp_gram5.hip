@@ -255,15 +255,20 @@ __global__ __launch_bounds__(256, 2) void kp_gram5_kernel(Gram5Args a) {
 
 // Sums the partials of one (job, B tile, rotation) block vector in split order and scatters its 4 blocks (4x4 each)
 // into G and C.  Rotation r: block blk is (A group (blk - r) & 3)' x (B group blk);  D lane: column l & 3, row l >> 4.
-__global__ __launch_bounds__(64) void kp_gram5_reduce_kernel(const double* __restrict__ part, int nsplit, int njobs, int NT,
+__global__ __launch_bounds__(256) void kp_gram5_reduce_kernel(const double* __restrict__ part, int nsplit, int njobs, int NT,
                                                              const uint32_t* __restrict__ desc, int NTL, int W,
                                                              double* __restrict__ G, double* __restrict__ C) {
   const int idx = blockIdx.x;                 // (job*NT + t)*4 + r
   const int r = idx & 3, jt = idx >> 2, t = jt % NT, job = jt / NT;
-  const int l = threadIdx.x;
+  const int l = threadIdx.x & 63, wv = threadIdx.x >> 6;   // 4 waves share the split sum (fixed order: deterministic)
+  __shared__ double red4[4][64];
   const size_t per_split = (size_t)njobs * NT * 4 * 64;
   double s = 0.0;
-  for (int p = 0; p < nsplit; ++p) s += part[(size_t)p * per_split + (size_t)idx * 64 + l];
+  for (int p = wv; p < nsplit; p += 4) s += part[(size_t)p * per_split + (size_t)idx * 64 + l];
+  red4[wv][l] = s;
+  __syncthreads();
+  if (wv) return;
+  s = (red4[0][l] + red4[1][l]) + (red4[2][l] + red4[3][l]);
   const uint32_t* jd = desc + (size_t)job * (1 + NT);
   const int ta = (int)jd[0], tb = (int)jd[1 + t];
   if (tb >= 2 * NTL) return;                  // padding
@@ -444,7 +449,7 @@ int kp_gram5_launch(kp_ctx* ctx, const kp_basis* basis_c, const kp_snapshots* s,
   }
   KP_HIP(ctx, e);
   KP_HIP(ctx, hipEventRecord(ctx->evp[1], ctx->stream));
-  hipLaunchKernelGGL(kp_gram5_reduce_kernel, dim3(plan.njobs * plan.nt * 4), dim3(64), 0, ctx->stream, part, nsplit, plan.njobs, plan.nt,
+  hipLaunchKernelGGL(kp_gram5_reduce_kernel, dim3(plan.njobs * plan.nt * 4), dim3(256), 0, ctx->stream, part, nsplit, plan.njobs, plan.nt,
                      plan.desc, plan.NTL, W, GC_dev, GC_dev + (size_t)W * W);
   KP_HIP(ctx, hipGetLastError());
   KP_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
