@@ -420,7 +420,7 @@ static int read_chol_info(kp_ctx* ctx, int W, int ncols, int* bad) {
 static void collect_gram_timers(kp_ctx* ctx, bool solved) {
   float ms = 0;
   if (hipEventElapsedTime(&ms, ctx->evp[0], ctx->evp[1]) == hipSuccess) ctx->timers[0] = ms;
-  if (hipEventElapsedTime(&ms, ctx->evp[1], ctx->evp[2]) == hipSuccess) ctx->timers[6] = ms;
+  if (hipEventElapsedTime(&ms, ctx->evp[ctx->reduce_timed_from], ctx->evp[2]) == hipSuccess) ctx->timers[6] = ms;
   if (solved && hipEventElapsedTime(&ms, ctx->evp[2], ctx->evp[3]) == hipSuccess) ctx->timers[1] = ms;
 }
 
@@ -526,9 +526,10 @@ extern "C" int kp_fit(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* sn
     // CUs left free for the solve stream (Cholesky: one workgroup; TRSM: W/16 workgroups)
     static const int reserve = [] { const char* e = getenv("KP_RESERVE_CUS"); return e ? atoi(e) : 24; }();
     ctx->reserve_cus = reserve;
-    // optional: run the Kronecker kernel's partial reduction on the solve stream.  Off by default: measured 0.572 vs
-    // 0.534 ms per fit, because reduce + Cholesky + TRSM (0.53 ms, serial) then outlasts the Gram kernel (0.50 ms)
-    static const bool reduce_on_solve = getenv("KP_REDUCE_ON_SOLVE_STREAM") != nullptr;
+    // The Kronecker kernel's partial reduction runs on the solve stream: reduce + Cholesky + TRSM (0.43 ms, serial)
+    // are shorter than the Gram kernel (0.46 ms), so the Gram stream issues kernels back to back.
+    // KP_REDUCE_ON_GRAM_STREAM=1 keeps it behind the Gram kernel.
+    static const bool reduce_on_solve = getenv("KP_REDUCE_ON_GRAM_STREAM") == nullptr;
     ctx->reduce_stream = reduce_on_solve ? ctx->stream2 : nullptr;
     ctx->part_flip = flip;
     rc = kp_gram_dispatch(ctx, basis, snaps, GCb);

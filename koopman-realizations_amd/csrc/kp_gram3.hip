@@ -546,7 +546,9 @@ int kp_gram3_launch(kp_ctx* ctx, const kp_basis* basis_c, const kp_snapshots* s,
     rs = ctx->reduce_stream;
     KP_HIP(ctx, hipEventRecord(ctx->ev_main_done, ctx->stream));
     KP_HIP(ctx, hipStreamWaitEvent(rs, ctx->ev_main_done, 0));
+    KP_HIP(ctx, hipEventRecord(ctx->evp[4], rs));   // start of the reduction on its own stream (timer 6)
   }
+  ctx->reduce_timed_from = ctx->reduce_stream ? 4 : 1;
   hipLaunchKernelGGL(kp_gram3_reduce_kernel, dim3(plan.njobs * plan.nq * NWT), dim3(256), 0, rs, part, nsplit, plan.njobs,
                      plan.nq, NWT, BM, plan.desc, plan.G4, N, W, GC_dev, GC_dev + (size_t)W * W);
   KP_HIP(ctx, hipGetLastError());

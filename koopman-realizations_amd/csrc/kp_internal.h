@@ -26,6 +26,7 @@ struct kp_ctx {
   hipStream_t reduce_stream = nullptr;
   hipEvent_t ev_main_done = nullptr;
   int part_flip = 0;
+  int reduce_timed_from = 1;   // evp index that marks the start of the last partial reduction
   int* sticky_info = nullptr;       // device word: set by any deferred factorisation that hit a non-positive pivot
   int reserve_cus = 0;              // CUs left free by the Gram grid so the solve of the previous fit can run beside it
   int num_cu = 0;
@@ -206,6 +207,7 @@ int kp_gram3_launch(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* s, d
 bool kp_gram5_applicable(const kp_basis* basis);
 int kp_gram5_launch(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* s, double* GC_dev);
 inline int kp_gram_dispatch(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* s, double* GC_dev) {
+  ctx->reduce_timed_from = 1;
   if (kp_gram3_applicable(basis)) return kp_gram3_launch(ctx, basis, s, GC_dev);
   if (kp_gram5_applicable(basis)) return kp_gram5_launch(ctx, basis, s, GC_dev);
   return kp_gram2_applicable(basis) ? kp_gram2_launch(ctx, basis, s, GC_dev) : kp_gram_launch(ctx, basis, s, GC_dev);
