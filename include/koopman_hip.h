@@ -146,6 +146,15 @@ int kp_fit_get_K(kp_ctx* ctx, int index, int W, double* K);
  * kp_fit_gram, kp_fit_solve and kp_destroy synchronise implicitly. */
 int kp_synchronize(kp_ctx* ctx);
 
+/* Batched small fits (evaluate_rand_models.m:45-144: one Ksysid fit per random system): nb independent systems
+ * with the same dictionary, W <= 16, no dimension reduction, least squares (lasso = Inf, Ksysid.m:1068-1069).
+ * `snaps` holds the merged snapshot pairs of all systems, nb x Ns_each rows, system s in rows
+ * [s*Ns_each, (s+1)*Ns_each).  One workgroup per system lifts its rows, accumulates Px'Px / Px'Py and solves.
+ * K_out, G_out, C_out: nb matrices W x W, column-major, back to back (G_out/C_out may be NULL);
+ * status_out[s] != 0 (may be NULL) marks a Gram matrix that is not numerically positive definite (K = NaN). */
+int kp_fit_batch(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* snaps, int nb, int64_t Ns_each,
+                 double* K_out, double* G_out, double* C_out, int* status_out);
+
 /* Model extraction with the M-projection of get_model (Ksysid.m:1206-1225): from K and
  * the Grams (no second pass over the data): L'L = [A B] G [A B]', L'R = [A B] C(:,1:N).
  * A_out N x N, B_out N x m (= M*A, M*B), M_out N x N.  Linear models only. */

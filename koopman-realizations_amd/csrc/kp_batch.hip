@@ -1,0 +1,184 @@
+// Batched small fits: many independent systems with the SAME dictionary and W <= 16, one workgroup per system.
+// This is the shape of evaluate_rand_models.m (one Ksysid fit per random system, model type and degree;
+// 1-D state, W <= 16): the per-system work (lift of ~1e4 snapshot pairs, Px'Px, Px'Py, the least-squares
+// solve) is far too small for a launch sequence of its own, so one launch does all systems.
+//   lift            generic column evaluation (any dictionary without dimension reduction), 64 snapshots per tile in LDS
+//   Px'Px, Px'Py    thread (i, j) owns G[i][j] and C[i][j]: 2 FMAs per snapshot from LDS
+//   G K = C         Cholesky of the 16 x 16 block in registers (one wave, pivots by v_readlane, as kp_chol_kernel's
+//                   diagonal block), then forward / backward substitution, one thread per right-hand side
+// Replaces, for each system: Ksysid.get_Koopman (Ksysid.m:987-1092) with lasso = Inf.
+#include "kp_internal.h"
+
+#define SB_TS 64      // snapshots per tile
+#define SB_W 16       // maximum Px width
+#define SB_LD 17
+
+__device__ __forceinline__ double sb_bcast(double v, int lane) {
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
+__global__ __launch_bounds__(256) void kp_small_fit_kernel(BasisDev b, const double* __restrict__ alpha, const double* __restrict__ beta,
+                                                           const double* __restrict__ u, int64_t Ns_total, int Ns, double* __restrict__ Kout,
+                                                           double* __restrict__ Gout, double* __restrict__ Cout, int* __restrict__ status) {
+  extern __shared__ double sm[];
+  // LDS: vx[nvars][TS] | vy[nvars][TS] | um[m][TS] | Px[TS][LD] | Py[TS][LD] | Gs[16][LD] | Cs[16][LD] | Ls[16][LD] | Dd[16]
+  const int nv = b.nvars, m = b.m, N = b.N, W = b.W;
+  double* vx = sm;
+  double* vy = vx + nv * SB_TS;
+  double* um = vy + nv * SB_TS;
+  double* Px = um + (m > 0 ? m : 1) * SB_TS;
+  double* Py = Px + SB_TS * SB_LD;
+  double* Gs = Py + SB_TS * SB_LD;
+  double* Cs = Gs + 16 * SB_LD;
+  double* Ls = Cs + 16 * SB_LD;
+  double* Dd = Ls + 16 * SB_LD;
+  __shared__ int bad;
+  const int tid = threadIdx.x;
+  const int sys = blockIdx.x;
+  const int64_t base = (int64_t)sys * Ns;           // first row of this system inside the merged arrays
+  if (tid == 0) bad = 0;
+  for (int e = tid; e < 2 * SB_TS * SB_LD; e += 256) Px[e] = 0.0;      // Px and Py (contiguous): unused columns stay zero
+  const int gi = tid >> 4, gj = tid & 15;
+  double g = 0.0, c = 0.0;
+  __syncthreads();
+  for (int r0 = 0; r0 < Ns; r0 += SB_TS) {
+    const int nl = min(SB_TS, Ns - r0);
+    // raw variables of the tile: x side (alpha [, u]), y side (beta [, u]), inputs
+    for (int e = tid; e < (2 * nv + m) * SB_TS; e += 256) {
+      const int v = e / SB_TS, p = e % SB_TS;
+      double x = 0.0;
+      if (p < nl) {
+        const int64_t row = base + r0 + p;
+        if (v < nv) x = v < b.nzeta ? alpha[(int64_t)v * Ns_total + row] : u[(int64_t)(v - b.nzeta) * Ns_total + row];
+        else if (v < 2 * nv) x = (v - nv) < b.nzeta ? beta[(int64_t)(v - nv) * Ns_total + row] : u[(int64_t)(v - nv - b.nzeta) * Ns_total + row];
+        else x = u[(int64_t)(v - 2 * nv) * Ns_total + row];
+      }
+      sm[e] = x;                                     // vx | vy | um are contiguous in this order
+    }
+    __syncthreads();
+    // rows of Px / Py (Ksysid.m:1034-1064): [psi, u] / psi (x) [1; u] / psi([zeta; u])
+    for (int e = tid; e < 2 * N * SB_TS; e += 256) {
+      const int p = e % SB_TS, sc = e / SB_TS, side = sc / N, col = sc - side * N;
+      const double val = p < nl ? kp_eval_col(b, b.cols[col], (side ? vy : vx) + p, SB_TS) : 0.0;
+      double* P = (side ? Py : Px) + p * SB_LD;
+      P[col] = val;
+      if (b.model_type == KP_MODEL_BILINEAR)
+        for (int i = 0; i < m; ++i) P[(i + 1) * N + col] = val * um[i * SB_TS + p];
+    }
+    if (b.model_type == KP_MODEL_LINEAR)
+      for (int e = tid; e < 2 * m * SB_TS; e += 256) {
+        const int p = e % SB_TS, si = e / SB_TS, side = si / m, i = si - side * m;
+        ((side ? Py : Px) + p * SB_LD)[N + i] = um[i * SB_TS + p];       // zero past the tail (um is)
+      }
+    __syncthreads();
+#pragma unroll 8
+    for (int p = 0; p < SB_TS; ++p) {
+      const double xi = Px[p * SB_LD + gi];
+      g += xi * Px[p * SB_LD + gj];
+      c += xi * Py[p * SB_LD + gj];
+    }
+    __syncthreads();
+  }
+  // G (identity on the padding so that the 16 x 16 factorisation is well defined) and C
+  Gs[gi * SB_LD + gj] = (gi < W && gj < W) ? g : (gi == gj ? 1.0 : 0.0);
+  Cs[gi * SB_LD + gj] = (gi < W && gj < W) ? c : 0.0;
+  if (gi < W && gj < W) {
+    if (Gout) Gout[(size_t)sys * W * W + (size_t)gj * W + gi] = g;
+    if (Cout) Cout[(size_t)sys * W * W + (size_t)gj * W + gi] = c;
+  }
+  __syncthreads();
+  // Cholesky in registers: lane r (< 16) of wave 0 owns row r
+  if (tid < 64) {
+    const int r = tid & 15;
+    double row[16];
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc) row[cc] = Gs[r * SB_LD + cc];
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc) {
+      double d = sb_bcast(row[cc], cc);
+      if (!(d > 0.0)) {
+        if (tid == 0) bad = 1;
+        d = 1.0;
+      }
+      double id = __builtin_amdgcn_rsq(d);
+      id = id * (1.5 - 0.5 * d * id * id);
+      id = id * (1.5 - 0.5 * d * id * id);
+      if (tid == cc) Dd[cc] = id;
+      const double l = row[cc] * id;
+      row[cc] = l;
+#pragma unroll
+      for (int c2 = cc + 1; c2 < 16; ++c2) row[c2] -= l * sb_bcast(l, c2);
+    }
+    if (tid < 16) {
+#pragma unroll
+      for (int cc = 0; cc < 16; ++cc) Ls[r * SB_LD + cc] = cc <= r ? row[cc] : 0.0;
+    }
+  }
+  __syncthreads();
+  // L Y = C, L' K = Y: one thread per right-hand side
+  if (tid < 16) {
+    const int j = tid;
+    double y[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      double s = Cs[i * SB_LD + j];
+#pragma unroll
+      for (int q = 0; q < i; ++q) s -= Ls[i * SB_LD + q] * y[q];
+      y[i] = s * Dd[i];
+    }
+#pragma unroll
+    for (int i = 15; i >= 0; --i) {
+      double s = y[i];
+#pragma unroll
+      for (int q = i + 1; q < 16; ++q) s -= Ls[q * SB_LD + i] * y[q];
+      y[i] = s * Dd[i];
+    }
+    if (j < W) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if (i < W) Kout[(size_t)sys * W * W + (size_t)j * W + i] = bad ? __builtin_nan("") : y[i];
+    }
+  }
+  if (tid == 0 && status) status[sys] = bad;
+}
+
+extern "C" int kp_fit_batch(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* snaps, int nb, int64_t Ns_each, double* K_out,
+                            double* G_out, double* C_out, int* status_out) {
+  if (!ctx || !basis || !snaps || !K_out || nb < 1 || Ns_each < 1) return ctx ? ctx->fail(KP_ERR_ARG, "kp_fit_batch: bad argument") : KP_ERR_ARG;
+  const BasisDev& b = basis->dev;
+  if (snaps->nzeta != b.nzeta || snaps->m != b.m) return ctx->fail(KP_ERR_ARG, "kp_fit_batch: snapshot/basis dimension mismatch");
+  if (snaps->Ns != (int64_t)nb * Ns_each) return ctx->fail(KP_ERR_ARG, "kp_fit_batch: snapshots must hold nb x Ns_each rows");
+  if (b.W > SB_W || b.k_pcs != 0 || b.N != b.nfull) return ctx->fail(KP_ERR_ARG, "kp_fit_batch: needs W <= 16 and no dimension reduction");
+  if (Ns_each > 0x7fffffff) return ctx->fail(KP_ERR_ARG, "kp_fit_batch: too many snapshots per system");
+  KP_HIP(ctx, hipSetDevice(ctx->device));
+  if (ctx->async_pending) {
+    int rc0 = kp_synchronize(ctx);
+    if (rc0) return rc0;
+  }
+  const int W = b.W;
+  const size_t bW = (size_t)nb * W * W * 8;
+  char* ws = (char*)ctx->workspace(6, 3 * bW + (size_t)nb * 4 + 64);
+  if (!ws) return ctx->fail(KP_ERR_HIP, "kp_fit_batch: out of device memory");
+  double* dK = (double*)ws;
+  double* dG = (double*)(ws + bW);
+  double* dC = (double*)(ws + 2 * bW);
+  int* dS = (int*)(ws + 3 * bW);
+  hipStream_t s = ctx->stream;
+  const size_t lds = ((size_t)(2 * b.nvars + (b.m > 0 ? b.m : 1)) * SB_TS + 2 * SB_TS * SB_LD + 3 * 16 * SB_LD + 16) * sizeof(double);
+  KP_HIP(ctx, hipEventRecord(ctx->ev0, s));
+  hipLaunchKernelGGL(kp_small_fit_kernel, dim3(nb), dim3(256), lds, s, b, snaps->alpha, snaps->beta, snaps->u, snaps->Ns, (int)Ns_each, dK, dG, dC,
+                     dS);
+  KP_HIP(ctx, hipGetLastError());
+  KP_HIP(ctx, hipEventRecord(ctx->ev1, s));
+  KP_HIP(ctx, hipMemcpyAsync(K_out, dK, bW, hipMemcpyDeviceToHost, s));
+  if (G_out) KP_HIP(ctx, hipMemcpyAsync(G_out, dG, bW, hipMemcpyDeviceToHost, s));
+  if (C_out) KP_HIP(ctx, hipMemcpyAsync(C_out, dC, bW, hipMemcpyDeviceToHost, s));
+  if (status_out) KP_HIP(ctx, hipMemcpyAsync(status_out, dS, (size_t)nb * 4, hipMemcpyDeviceToHost, s));
+  KP_HIP(ctx, hipStreamSynchronize(s));
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+  ctx->timers[0] = ms;
+  return KP_OK;
+}

@@ -72,6 +72,29 @@ class Context:
                                      F.dptr(K), C.byref(it)), self._h)
         return K, it.value
 
+    def fit_batch(self, basis, snaps, nb):
+        """Least-squares fits of nb systems that share one dictionary (W <= 16): `snaps` holds the merged snapshot
+        pairs, nb x Ns_each rows.  Returns K, G, C as (nb, W, W) arrays and the status vector."""
+        W = basis.W
+        Ns_each = snaps.Ns // nb
+        K = np.zeros((nb, W, W)); G = np.zeros((nb, W, W)); Cm = np.zeros((nb, W, W))
+        st = np.zeros(nb, dtype=np.int32)
+        F.check(F.lib().kp_fit_batch(self._h, basis.handle, snaps.handle, nb, Ns_each, F.dptr(K), F.dptr(G), F.dptr(Cm),
+                                     st.ctypes.data_as(C.POINTER(C.c_int))), self._h)
+        # the library writes column-major W x W blocks: transpose the last two axes of the C-ordered buffers
+        return K.transpose(0, 2, 1), G.transpose(0, 2, 1), Cm.transpose(0, 2, 1), st
+
+    def rollout_nl_batch(self, basis, Kf, zeta0, U):
+        """Batched nonlinear rollouts: Kf (nb, nzeta, N), zeta0 (nb, nzeta), U (nb, T, m) -> Z (nb, T, nzeta)."""
+        nb, nz, N = Kf.shape
+        T = U.shape[1]
+        Kf_ = np.ascontiguousarray(np.transpose(Kf, (0, 2, 1)))          # per system column-major nzeta x N
+        z0 = np.ascontiguousarray(zeta0, dtype=np.float64)
+        U_ = np.ascontiguousarray(np.transpose(U, (0, 2, 1)))            # per system column-major T x m
+        Z = np.zeros((nb, nz, T))
+        F.check(F.lib().kp_rollout_nl(self._h, basis.handle, nb, F.dptr(Kf_), F.dptr(z0), F.dptr(U_), T, F.dptr(Z)), self._h)
+        return np.transpose(Z, (0, 2, 1))
+
     def model_project(self, K, G, Cm, N, m):
         K = F.fcol(K); G = F.fcol(G); Cm = F.fcol(Cm)
         A = np.zeros((N, N), order="F"); B = np.zeros((N, m), order="F"); M = np.zeros((N, N), order="F")

@@ -119,14 +119,97 @@ def eval_system(data4sysid, ctx=None, degrees=None, Ksysid=None):
     return out
 
 
-def rand_models_sweep(systems, rank=0, world=1, dist=None, ctx=None, degrees=None, eval_fn=None):
+def rand_models_sweep(systems, rank=0, world=1, dist=None, ctx=None, degrees=None, eval_fn=None, batched=False):
     """Config 5: every rank evaluates its systems; final gather of the error tables.
     Returns dict model_type -> array (max_degree x n_systems), as err_*_models in
-    evaluate_rand_models.m:38-43."""
+    evaluate_rand_models.m:38-43.  batched=True: the rank's whole shard goes through
+    `rand_models_sweep_batched` (one launch per model type and degree) instead of one Ksysid per fit."""
+    mine = shard_units(len(systems), rank, world)
+    if batched and eval_fn is None:
+        tab = rand_models_sweep_batched([systems[i] for i in mine], ctx, degrees=degrees) if mine else {}
+        local = {i: {mt: (tab[mt][:, k], None) for mt in tab} for k, i in enumerate(mine)}
+        allres = gather_results(local, len(systems), dist)
+        return {mt: np.stack([r[mt][0] for r in allres], axis=1) for mt in ("linear", "bilinear", "nonlinear")}
     eval_fn = eval_fn or (lambda d: eval_system(d, ctx=ctx, degrees=degrees))
-    local = {i: eval_fn(systems[i]) for i in shard_units(len(systems), rank, world)}
+    local = {i: eval_fn(systems[i]) for i in mine}
     allres = gather_results(local, len(systems), dist)
     return {mt: np.stack([r[mt][0] for r in allres], axis=1) for mt in ("linear", "bilinear", "nonlinear")}
+
+
+def rand_models_sweep_batched(systems, ctx, degrees=None):
+    """Config 5 on ONE GPU without a host round trip per fit: for every (model type, degree) all systems of the
+    shard are fitted by one `kp_fit_batch` launch (one workgroup per system) and validated by one batched rollout
+    launch.  Same table as `rand_models_sweep` (evaluate_rand_models.m:38-43); requires systems with equally many
+    snapshot pairs (the shipped and generated rand-systems data sets have 9 x 1000) and no delays."""
+    from .device import Basis, Snapshots
+    from .ksysid import Ksysid, poly_exponent_table
+    from . import _ffi as F
+    degrees = degrees or MAX_DEGREE
+    nb = len(systems)
+    # scaling, snapshot pairs and scaled validation data: once per system (independent of type and degree)
+    prep = [Ksysid(d, ctx=ctx, model_type="linear", obs_type=["poly"], obs_degree=[1], snapshots=np.inf, lasso=[np.inf],
+                   delays=0, loaded=False, dim_red=False) for d in systems]
+    n, m = prep[0].params["n"], prep[0].params["m"]
+    Ns = prep[0].snapshotPairs["alpha"].shape[0]
+    if any(k.snapshotPairs["alpha"].shape[0] != Ns or k.params["n"] != n or k.params["m"] != m for k in prep):
+        raise ValueError("rand_models_sweep_batched: systems must share dimensions and snapshot counts")
+    alpha = np.vstack([k.snapshotPairs["alpha"] for k in prep]); beta = np.vstack([k.snapshotPairs["beta"] for k in prep])
+    uu = np.vstack([k.snapshotPairs["u"] for k in prep])
+    snaps = Snapshots(ctx, alpha, beta, uu)
+    val = [k._val_common(k.valdata[0]) for k in prep]                      # (t, yreal, ureal, zetareal)
+    T = min(v[1].shape[0] for v in val)
+    yreal = np.stack([v[1][:T] for v in val]); ureal = np.stack([v[2][:T] for v in val]); zeta0 = np.stack([v[3][0] for v in val])
+    mean_zero = np.abs(yreal).sum(axis=1) / T                              # evaluate_rand_models.m:71
+    out = {}
+    try:
+        for mt in ("linear", "bilinear", "nonlinear"):
+            rows = []
+            for j in range(1, degrees[mt] + 1):
+                nv = n + (m if mt == "nonlinear" else 0)
+                basis = Basis(ctx, mt, n, m, [("poly", poly_exponent_table(nv, j)[nv:])], None)
+                try:
+                    K, G, Cm, st = ctx.fit_batch(basis, snaps, nb)
+                    N, W = basis.N, basis.W
+                    if mt == "nonlinear":                                   # lasso = 4 (:122): active only if ||K_ls||_1 > 4 N
+                        K = np.array(K)
+                        for s_ in np.nonzero(np.abs(K).sum(axis=(1, 2)) > 4.0 * N)[0]:
+                            K[s_] = ctx.fit_lasso(G[s_], Cm[s_], 4.0 * N)[0]
+                        Kf = np.transpose(K[:, :, :n], (0, 2, 1))           # Ksysid.m:1325
+                        Z = ctx.rollout_nl_batch(basis, Kf, zeta0, ureal)
+                        Y = Z[:, :, :n]
+                    else:
+                        UT = np.transpose(K, (0, 2, 1))
+                        A, B = UT[:, :N, :N], UT[:, :N, N:]                 # Ksysid.m:1199-1200 / 1250-1251
+                        if mt == "linear":                                  # M-projection of get_model (:1206-1225) from the Grams
+                            K1 = K[:, :, :N]
+                            LtL = np.einsum("bwi,bwv,bvj->bij", K1, G, K1)
+                            LtR = np.einsum("bwi,bwj->bij", K1, Cm[:, :, :N])
+                            ok = np.isfinite(LtL).all(axis=(1, 2)) & np.isfinite(LtR).all(axis=(1, 2))
+                            Mt = np.full_like(LtL, np.nan)
+                            if ok.any():
+                                try:
+                                    Mt[ok] = np.linalg.solve(LtL[ok], LtR[ok])
+                                except np.linalg.LinAlgError:
+                                    for s_ in np.nonzero(ok)[0]:
+                                        try:
+                                            Mt[s_] = np.linalg.solve(LtL[s_], LtR[s_])
+                                        except np.linalg.LinAlgError:
+                                            pass
+                            M = np.transpose(Mt, (0, 2, 1))
+                            A, B = M @ A, M @ B
+                        z0 = basis.lift(F.LIFT_ECON, zeta0)
+                        Y = np.array(ctx.rollout(mt, np.nan_to_num(A), np.nan_to_num(B), z0, ureal, n))
+                        Y[~np.isfinite(A).all(axis=(1, 2))] = np.nan
+                    Y[:, 0] = yreal[:, 0]                                   # Ksysid.m:1654
+                    mean_err = np.abs(Y - yreal).mean(axis=1)               # get_error (:1882-1898): mean abs error per output
+                    with np.errstate(divide="ignore", invalid="ignore"):
+                        rows.append((mean_err / mean_zero)[:, 0])
+                finally:
+                    basis.close()
+            out[mt] = np.stack(rows, axis=0)
+    finally:
+        snaps.close()
+    return out
 
 
 def _keep_systems(err):

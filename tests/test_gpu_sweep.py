@@ -76,3 +76,43 @@ def test_generated_systems_flow_through_the_sweep(ctx):
     assert tab["linear"].shape == (3, 3) and np.isfinite(tab["linear"]).all() and np.isfinite(tab["bilinear"]).all()
     mean, _ = sweep.sweep_statistics(tab["linear"])
     assert mean[2] <= mean[0] * 1.05
+
+
+def test_batched_sweep_matches_per_system_sweep(ctx, golden):
+    """kp_fit_batch (one workgroup per system) + batched rollouts give the same error table as the per-system
+    loop of evaluate_rand_models.m through the Ksysid mirror."""
+    systems = [_system(golden, i) for i in range(3)]
+    degrees = {"linear": 13, "bilinear": 6, "nonlinear": 4}
+    want = sweep.rand_models_sweep(systems, ctx=ctx, degrees=degrees)
+    got = sweep.rand_models_sweep_batched(systems, ctx, degrees=degrees)
+    via_shard = sweep.rand_models_sweep(systems, ctx=ctx, degrees=degrees, batched=True)
+    for mt in want:
+        assert np.array_equal(np.nan_to_num(via_shard[mt], nan=-1.0), np.nan_to_num(got[mt], nan=-1.0))
+        assert got[mt].shape == want[mt].shape
+        w, g = want[mt], got[mt]
+        both_nan = np.isnan(w) & np.isnan(g)
+        big = (np.abs(w) > 10) & ((np.abs(g) > 10) | np.isnan(g))          # diverged rollouts: dropped by the statistics anyway
+        ok = both_nan | big | (np.abs(g - w) <= 1e-4 * np.maximum(1.0, np.abs(w)))
+        assert ok.all(), (mt, g, w)
+
+
+def test_fit_batch_matches_single_fits(ctx, golden):
+    """K, G, C of kp_fit_batch against kp_fit_gram / kp_fit_solve system by system; singular systems are flagged."""
+    from conftest import synth_pairs
+    nb, Ns = 5, 777
+    parts = [synth_pairs(Ns, 2, 1, seed=20 + i) for i in range(nb)]
+    parts[3]["alpha"][:] = 0.25                                            # constant state: rank-deficient dictionary
+    alpha = np.vstack([p["alpha"] for p in parts]); beta = np.vstack([p["beta"] for p in parts]); u = np.vstack([p["u"] for p in parts])
+    for mt, deg in (("linear", 3), ("bilinear", 2), ("nonlinear", 2)):
+        nv = 3 if mt == "nonlinear" else 2
+        basis = kra.Basis(ctx, mt, 2, 1, [("poly", kra.poly_exponent_table(nv, deg)[nv:])], None)
+        assert basis.W <= 16
+        snaps = kra.Snapshots(ctx, alpha, beta, u)
+        K, G, C, st = ctx.fit_batch(basis, snaps, nb)
+        assert st[3] != 0 and np.isnan(K[3]).all() and (st[[0, 1, 2, 4]] == 0).all()
+        for s in (0, 1, 2, 4):
+            one = kra.Snapshots(ctx, parts[s]["alpha"], parts[s]["beta"], parts[s]["u"])
+            G1, C1 = kra.fit_gram(ctx, basis, one)
+            assert np.abs(G[s] - G1).max() <= 1e-12 * np.abs(G1).max() and np.abs(C[s] - C1).max() <= 1e-12 * np.abs(G1).max()
+            K1 = ctx.fit_solve(G1, C1)
+            assert np.abs(K[s] - K1).max() <= 1e-9 * max(1.0, np.abs(K1).max())
