@@ -16,6 +16,8 @@
 #include <cmath>
 #include <vector>
 
+#include <cstring>
+
 #include "kp_internal.h"
 
 #define QP_MAXN 64       // variables (one wave handles <= 64)
@@ -39,8 +41,9 @@ struct kp_mpc {
   int ellK = 1;
   double* work = nullptr;  // per-problem QP export: Hq (nvar^2) | f (nvar)
   size_t work_problems = 0;
-  double *d_in = nullptr, *d_out = nullptr;
-  int* d_status = nullptr;
+  double *d_in = nullptr, *d_out = nullptr;     // d_out: x (nvar) and z (N) per problem, then the status words
+  double *h_in = nullptr, *h_out = nullptr;     // pinned staging buffers: one copy in, one copy out per step
+  int* d_status = nullptr;                      // points into d_out
   size_t io_problems = 0;
 };
 
@@ -781,7 +784,8 @@ extern "C" int kp_mpc_destroy(kp_mpc* M) {
   double* ptrs[] = {M->A, M->B, M->P, M->S0, M->r, M->Aq, M->bq0, M->Anorm, M->work, M->d_in, M->d_out};
   for (double* p : ptrs)
     if (p) (void)hipFree(p);
-  if (M->d_status) (void)hipFree(M->d_status);
+  if (M->h_in) (void)hipHostFree(M->h_in);
+  if (M->h_out) (void)hipHostFree(M->h_out);
   if (M->ellc) (void)hipFree(M->ellc);
   if (M->ellv) (void)hipFree(M->ellv);
   delete M;
@@ -917,28 +921,45 @@ static int mpc_run(kp_mpc* M, const kp_basis* basis, int nb, const double* z, co
   }
   const size_t n_out = (size_t)nv + N;
   const size_t n_ex = (size_t)nv * nv + nv + nr;
+  const size_t in_per = (size_t)std::max(N, 64) + m + (size_t)nproj * (Np + 1);
   if (M->io_problems < (size_t)nb) {
     if (M->d_in) (void)hipFree(M->d_in);
     if (M->d_out) (void)hipFree(M->d_out);
-    if (M->d_status) (void)hipFree(M->d_status);
     if (M->work) (void)hipFree(M->work);
-    M->d_in = M->d_out = M->work = nullptr;
+    if (M->h_in) (void)hipHostFree(M->h_in);
+    if (M->h_out) (void)hipHostFree(M->h_out);
+    M->d_in = M->d_out = M->work = M->h_in = M->h_out = nullptr;
     M->d_status = nullptr;
     M->io_problems = 0;
     size_t cap = (size_t)nb;
-    KP_HIP(ctx, hipMalloc((void**)&M->d_in, cap * ((size_t)std::max(N, 64) + m + (size_t)nproj * (Np + 1)) * 8));
-    KP_HIP(ctx, hipMalloc((void**)&M->d_out, cap * n_out * 8));
-    KP_HIP(ctx, hipMalloc((void**)&M->d_status, cap * sizeof(int)));
+    KP_HIP(ctx, hipMalloc((void**)&M->d_in, cap * in_per * 8));
+    KP_HIP(ctx, hipMalloc((void**)&M->d_out, cap * n_out * 8 + cap * sizeof(int) + 8));
     KP_HIP(ctx, hipMalloc((void**)&M->work, (n_ex + 16) * 8));
+    KP_HIP(ctx, hipHostMalloc((void**)&M->h_in, cap * in_per * 8, hipHostMallocDefault));
+    KP_HIP(ctx, hipHostMalloc((void**)&M->h_out, cap * n_out * 8 + cap * sizeof(int) + 8, hipHostMallocDefault));
     M->io_problems = cap;
   }
+  M->d_status = (int*)(M->d_out + M->io_problems * n_out);
   const size_t nz = zeta ? nzeta : N;
   double* d_z = M->d_in;
   double* d_up = d_z + (size_t)nb * nz;
   double* d_yr = d_up + (size_t)nb * m;
-  KP_HIP(ctx, hipMemcpyAsync(d_z, zeta ? zeta : z, (size_t)nb * nz * 8, hipMemcpyHostToDevice, ctx->stream));
-  KP_HIP(ctx, hipMemcpyAsync(d_up, u_prev, (size_t)nb * m * 8, hipMemcpyHostToDevice, ctx->stream));
-  KP_HIP(ctx, hipMemcpyAsync(d_yr, Yr, (size_t)nb * nproj * (Np + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+  // inputs packed in the pinned buffer in device order: one host-to-device copy
+  const size_t n_in = (size_t)nb * (nz + m + (size_t)nproj * (Np + 1));
+  memcpy(M->h_in, zeta ? zeta : z, (size_t)nb * nz * 8);
+  memcpy(M->h_in + (size_t)nb * nz, u_prev, (size_t)nb * m * 8);
+  memcpy(M->h_in + (size_t)nb * (nz + m), Yr, (size_t)nb * nproj * (Np + 1) * 8);
+  // single problem: the kernel reads the (few hundred bytes of) inputs straight from the pinned, device-mapped
+  // staging buffer and writes its outputs there - no copy commands at all on the latency path of a closed loop
+  static const bool no_zc = getenv("KP_MPC_NO_ZEROCOPY") != nullptr;
+  const bool zc = nb == 1 && !no_zc;
+  if (zc) {
+    d_z = M->h_in;
+    d_up = d_z + (size_t)nb * nz;
+    d_yr = d_up + (size_t)nb * m;
+  } else {
+    KP_HIP(ctx, hipMemcpyAsync(d_z, M->h_in, n_in * 8, hipMemcpyHostToDevice, ctx->stream));
+  }
   MpcArgs a{};
   if (zeta) a.basis = basis->dev;
   a.has_basis = zeta ? 1 : 0;
@@ -949,10 +970,10 @@ static int mpc_run(kp_mpc* M, const kp_basis* basis, int nb, const double* z, co
   a.z = zeta ? nullptr : d_z;
   a.zeta = zeta ? d_z : nullptr;
   a.u_prev = d_up; a.Yr = d_yr;
-  a.U = M->d_out;
-  a.z_out = M->d_out + (size_t)nb * nv;
+  a.U = zc ? M->h_out : M->d_out;
+  a.z_out = a.U + (size_t)nb * nv;
   a.qp_export = nb == 1 ? M->work : nullptr;
-  a.status = M->d_status;
+  a.status = zc ? (int*)(M->h_out + M->io_problems * n_out) : M->d_status;
   a.stamps = nb == 1 ? (long long*)(M->work + n_ex) : nullptr;
   size_t lds = (size_t)mpc_lds_doubles(N, m, Np, nproj, nv, nr, iters, zeta ? basis->dev.nfull : 0) * 8 + 32;
   if (lds > 160 * 1024) return ctx->fail(KP_ERR_ARG, "kp_mpc_step: problem too large for LDS");
@@ -965,13 +986,14 @@ static int mpc_run(kp_mpc* M, const kp_basis* basis, int nb, const double* z, co
   hipLaunchKernelGGL(kp_mpc_step_kernel, dim3(nb), dim3(256), lds, ctx->stream, a);
   KP_HIP(ctx, hipGetLastError());
   KP_HIP(ctx, hipEventRecord(ctx->evp[5], ctx->stream));
-  // x = [u_0; u_1; ...] (m each)  ->  U (Np x m column-major) = reshape(x,[m,Np])'  (Kmpc.m:884)
-  std::vector<double> x((size_t)nb * nv);
-  std::vector<int> st(nb);
-  KP_HIP(ctx, hipMemcpyAsync(x.data(), M->d_out, x.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
-  KP_HIP(ctx, hipMemcpyAsync(st.data(), M->d_status, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-  if (z_out) KP_HIP(ctx, hipMemcpyAsync(z_out, M->d_out + (size_t)nb * nv, (size_t)nb * N * 8, hipMemcpyDeviceToHost, ctx->stream));
+  // one device-to-host copy: x and z of every problem, then the status words
+  const size_t out_bytes = M->io_problems * n_out * 8 + (size_t)nb * sizeof(int);
+  if (!zc) KP_HIP(ctx, hipMemcpyAsync(M->h_out, M->d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
   KP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  // x = [u_0; u_1; ...] (m each)  ->  U (Np x m column-major) = reshape(x,[m,Np])'  (Kmpc.m:884)
+  const double* x = M->h_out;
+  const int* st = (const int*)(M->h_out + M->io_problems * n_out);
+  if (z_out) memcpy(z_out, M->h_out + (size_t)nb * nv, (size_t)nb * N * 8);
   for (int p = 0; p < nb; ++p) {
     for (int j = 0; j < Np; ++j)
       for (int i = 0; i < m; ++i) U_out[(size_t)p * nv + (size_t)i * Np + j] = x[(size_t)p * nv + j * m + i];
