@@ -1,5 +1,5 @@
 import sys, ctypes as C, numpy as np
-sys.path.insert(0,'.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import koopman_realizations_amd as kra
 from koopman_realizations_amd import _ffi as F
 import bench
