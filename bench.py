@@ -208,7 +208,7 @@ def main():
     del os.environ["KP_NO_ASYNC"]
     fit_latency_ms = float(np.median(lat)) * 1e3
     mpc_res = None
-    if rank == 0 and not args.no_mpc:
+    if rank == 0 and not args.no_mpc and world == 1:     # secondary sections only in the single-GPU run
         mpc_res = bench_mpc(ctx, kra, basis, snaps, args)
 
     if rank == 0:
@@ -258,6 +258,7 @@ def main():
             mpc_res.pop("_setup", None)
         print(json.dumps(res))
     if dist is not None:
+        barrier()
         dist.destroy_process_group()
 
 
