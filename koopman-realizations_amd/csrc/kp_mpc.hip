@@ -43,6 +43,7 @@ struct kp_mpc {
   size_t work_problems = 0;
   double *d_in = nullptr, *d_out = nullptr;     // d_out: x (nvar) and z (N) per problem, then the status words
   double *h_in = nullptr, *h_out = nullptr;     // pinned staging buffers: one copy in, one copy out per step
+  int* warm = nullptr;                          // device: [count, rows...] optimal active set of the last single step
   int* d_status = nullptr;                      // points into d_out
   size_t io_problems = 0;
 };
@@ -142,9 +143,14 @@ __host__ __device__ inline int qp_lds_doubles(int n, int mr) {
 // min 1/2 x'Hq x + f'x  s.t.  A x <= b.   Hq: n x n column-major (LDS or global).
 // Executed by ONE wave (all 64 lanes must call).  Returns 0 on success, 1 on infeasible /
 // iteration cap / non-SPD Hessian (x_out = NaN then).
-__device__ int qp_goldfarb_idnani(const double* Hq, const double* f, const EllMat A, const double* bvec, int n, int mr,
+// Warm start (warm_q > 0): the caller has put warm_q active rows into act[], the columns H^-1 a_c into HN and the
+// inverse of S = N'H^-1 N into Sinv (layout below).  The multipliers of the equality-constrained minimiser are
+// formed; constraints with negative multipliers are released one by one (rank-1 downdates); what remains is a
+// valid dual-feasible state from which the usual iteration continues.  The optimum is unique, so the result does
+// not depend on the start.  warm_out (global, 1 + n ints): the optimal active set for the next call.
+__device__ __forceinline__ int qp_goldfarb_idnani(const double* Hq, const double* f, const EllMat A, const double* bvec, int n, int mr,
                                   double* ws, double* x_out, double tol, long long* stamps = nullptr, bool have_hinv = false,
-                                  int hinv_bad = 0) {
+                                  int hinv_bad = 0, int warm_q = 0, int* warm_out = nullptr) {
   const int lane = threadIdx.x & 63;
   double* Hinv = ws;
   double* HN = Hinv + n * n;
@@ -187,6 +193,8 @@ __device__ int qp_goldfarb_idnani(const double* Hq, const double* f, const EllMa
   }
   for (int e = lane; e < mr; e += 64) isact[e] = 0;
   WSYNC();
+  for (int c = lane; c < warm_q; c += 64) isact[act[c]] = 1;
+  WSYNC();
   int bad = hinv_bad;
   for (int k = 0; k < (have_hinv ? 0 : n); ++k) {
     const double piv = Hinv[k + k * n];
@@ -228,6 +236,77 @@ __device__ int qp_goldfarb_idnani(const double* Hq, const double* f, const EllMa
   int q = 0;
   int status = 1;
   int it = bad ? QP_MAXIT : 0;   // non-SPD Hessian: report failure
+  // remove active constraint l: swap with the last entry (symmetric permutation of Sinv, column swap of HN), then one
+  // rank-1 downdate of the leading block deletes the LAST index of the inverse Schur complement
+  auto drop_active = [&](int l) {
+    const int last = q - 1;
+    if (l != last) {
+      if (lane < q) {                       // columns l <-> last (lane = row)
+        const double a_ = Sinv[lane + l * n], b_ = Sinv[lane + last * n];
+        Sinv[lane + l * n] = b_;
+        Sinv[lane + last * n] = a_;
+      }
+      WSYNC();
+      if (lane < q) {                       // rows l <-> last (lane = column)
+        const double a_ = Sinv[l + lane * n], b_ = Sinv[last + lane * n];
+        Sinv[l + lane * n] = b_;
+        Sinv[last + lane * n] = a_;
+      }
+      for (int i = lane; i < n; i += 64) {
+        const double a_ = HN[i + l * n];
+        HN[i + l * n] = HN[i + last * n];
+        HN[i + last * n] = a_;
+      }
+      if (lane == 0) {
+        const int ta = act[l]; act[l] = act[last]; act[last] = ta;
+        const double tl = lam[l]; lam[l] = lam[last]; lam[last] = tl;
+      }
+      WSYNC();
+    }
+    const double isl = 1.0 / Sinv[last + last * n];
+    if (lane < last) {
+      const double ri = Sinv[lane + last * n] * isl;
+      for (int j = 0; j < last; ++j) Sinv[lane + j * n] -= ri * Sinv[last + j * n];
+    }
+    if (lane == 0) isact[act[last]] = 0;
+    --q;
+    WSYNC();
+  };
+  if (warm_q > 0 && !bad) {
+    q = warm_q;
+    while (q > 0) {
+      // lam = Sinv (N x0 - b)
+      for (int c = lane; c < q; c += 64) {
+        const int row = act[c];
+        double v = -bv_[row];
+        for (int k = 0; k < A.K; ++k) v += Aval[k * mr + row] * x[Acol[k * mr + row]];
+        d[c] = v;
+      }
+      WSYNC();
+      double lmin = 1e300;
+      int l = 0x7fffffff;
+      for (int c = lane; c < q; c += 64) {
+        double s_ = 0.0;
+#pragma unroll 4
+        for (int k = 0; k < q; ++k) s_ += Sinv[c + k * n] * d[k];
+        lam[c] = s_;
+        lmin = s_;
+        l = c;
+      }
+      wave_argmin(lmin, l);
+      WSYNC();
+      if (!(lmin < 0.0)) break;             // dual feasible
+      drop_active(l);
+    }
+    // x = x0 - H^-1 N lam
+    for (int i = lane; i < n; i += 64) {
+      double s_ = x[i];
+#pragma unroll 4
+      for (int c = 0; c < q; ++c) s_ -= HN[i + c * n] * lam[c];
+      x[i] = s_;
+    }
+    WSYNC();
+  }
   while (it < QP_MAXIT) {
     ++it;
     // most violated inactive constraint (scaled by the row norm)
@@ -364,42 +443,9 @@ __device__ int qp_goldfarb_idnani(const double* Hq, const double* f, const EllMa
         QP_TICK(4);
         break;
       }
-      // partial step: drop active constraint l.  The active set is unordered, so l is first swapped with the last
-      // entry (symmetric permutation of Sinv, column swap of HN); deleting the LAST index of the inverse Schur
-      // complement is then one rank-1 downdate of the leading block - no compaction sweeps.
+      // partial step: drop active constraint l (swap-with-last rank-1 downdate, no compaction sweeps)
       {
-        const int last = q - 1;
-        if (l != last) {
-          if (lane < q) {                       // columns l <-> last (lane = row)
-            const double a = Sinv[lane + l * n], b = Sinv[lane + last * n];
-            Sinv[lane + l * n] = b;
-            Sinv[lane + last * n] = a;
-          }
-          WSYNC();
-          if (lane < q) {                       // rows l <-> last (lane = column)
-            const double a = Sinv[l + lane * n], b = Sinv[last + lane * n];
-            Sinv[l + lane * n] = b;
-            Sinv[last + lane * n] = a;
-          }
-          for (int i = lane; i < n; i += 64) {
-            const double a = HN[i + l * n];
-            HN[i + l * n] = HN[i + last * n];
-            HN[i + last * n] = a;
-          }
-          if (lane == 0) {
-            const int ta = act[l]; act[l] = act[last]; act[last] = ta;
-            const double tl = lam[l]; lam[l] = lam[last]; lam[last] = tl;
-          }
-          WSYNC();
-        }
-        const double isl = 1.0 / Sinv[last + last * n];
-        if (lane < last) {
-          const double ri = Sinv[lane + last * n] * isl;
-          for (int j = 0; j < last; ++j) Sinv[lane + j * n] -= ri * Sinv[last + j * n];
-        }
-        if (lane == 0) isact[act[last]] = 0;
-        --q;
-        WSYNC();
+        drop_active(l);
         QP_TICK(5);
       }
     }
@@ -419,6 +465,10 @@ __device__ int qp_goldfarb_idnani(const double* Hq, const double* f, const EllMa
            qpt[0], qpt[1], qpt[2], qpt[3], qpt[4], qpt[5], qpt[6], qpt[7], qpt[8], qpt[9], it, q);
 #endif
   for (int i = lane; i < n; i += 64) x_out[i] = status == 0 ? x[i] : __builtin_nan("");
+  if (warm_out) {                            // optimal active set: the start of the next call
+    if (lane == 0) warm_out[0] = status == 0 ? q : 0;
+    for (int c = lane; c < q; c += 64) warm_out[1 + c] = act[c];
+  }
   return status;
 }
 
@@ -537,40 +587,49 @@ __global__ __launch_bounds__(256) void kp_mpc_setup_kernel(const double* __restr
 
 // In-place Gauss-Jordan inverse of an SPD n x n matrix in LDS by a whole 256-thread workgroup.
 // Returns non-zero if a pivot is not positive.
-__device__ int wg_spd_inverse(double* Hinv, int n, double* colk /* n scratch */) {
+// Pivot step k rewrites every element from two copies of the pivot column and row,
+//   cc[i] = (i == k) ? -1 : H[i][k],   rr[j] = (j == k) ? 1/p : H[k][j] / p,   H[i][j] <- (i == k || j == k ? 0 : H[i][j]) - cc[i] rr[j],
+// which covers the pivot row, the pivot column and the pivot itself without branches: two barriers per pivot.
+// Thread tid owns elements e = tid + 256 t; their (row, column) pairs advance by (256 % n, 256 / n) with one carry, so
+// the pivot loop has no integer division and no per-thread index table (a fully unrolled 16-entry table cost 248 VGPRs
+// and halved the occupancy of the batched MPC kernel).  Elements go in groups of 4: all LDS reads, then all writes.
+__device__ __forceinline__ int wg_spd_inverse(double* Hinv, int n, double* colk /* 2 n scratch */, int ld = 0) {
+  if (ld == 0) ld = n;
   const int tid = threadIdx.x;
   int bad = 0;
-  // the elements a thread updates do not depend on the pivot: their (row, column) pairs are decoded once
-  // (n <= 64: at most 16 per thread), so the pivot loop has no integer divisions
-  constexpr int EPT = (QP_MAXN * QP_MAXN + 255) / 256;
-  short ei[EPT], ej[EPT];
-#pragma unroll
-  for (int t = 0; t < EPT; ++t) {
-    const int e = tid + 256 * t;
-    ei[t] = (short)(e < n * n ? e % n : -1);
-    ej[t] = (short)(e < n * n ? e / n : 0);
-  }
+  const int di = 256 % n, dj = 256 / n, i0 = tid % n, j0 = tid / n;
+  const int ne = (n * n + 255) >> 8;
   double* rowk = colk + n;                      // second scratch row (the caller provides 2 n doubles)
   for (int k = 0; k < n; ++k) {
-    const double piv = Hinv[k + k * n];
+    const double piv = Hinv[k + k * ld];
     if (!(piv > 0.0)) bad = 1;
     const double ip = 1.0 / piv;
     for (int i = tid; i < n; i += 256) {
-      colk[i] = Hinv[i + k * n];
-      rowk[i] = Hinv[k + i * n];
+      colk[i] = i == k ? -1.0 : Hinv[i + k * ld];
+      rowk[i] = i == k ? ip : Hinv[k + i * ld] * ip;
     }
     __syncthreads();
-    // every element is rewritten from the two copies, so pivot row and column need no separate pass
+    int i = i0, j = j0;
+    for (int t0 = 0; t0 < ne; t0 += 4) {
+      double v[4];
+      int ix[4];
 #pragma unroll
-    for (int t = 0; t < EPT; ++t) {
-      const int i = ei[t], j = ej[t];
-      if (i >= 0) {
-        double v;
-        if (i == k) v = j == k ? ip : rowk[j] * ip;
-        else if (j == k) v = -colk[i] * ip;
-        else v = Hinv[i + j * n] - colk[i] * ip * rowk[j];
-        Hinv[i + j * n] = v;
+      for (int u = 0; u < 4; ++u) {
+        const bool in = j < n;
+        ix[u] = in ? i + j * ld : -1;
+        const double old = (in && i != k && j != k) ? Hinv[i + j * ld] : 0.0;
+        const double rj = in ? rowk[j] : 0.0;
+        v[u] = old - colk[i] * rj;
+        i += di;
+        j += dj;
+        if (i >= n) {
+          i -= n;
+          ++j;
+        }
       }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (ix[u] >= 0) Hinv[ix[u]] = v[u];
     }
     __syncthreads();
   }
@@ -583,6 +642,7 @@ struct MpcArgs {
   double q_run, q_term;
   const double *A, *B, *P, *S0, *r, *Aq, *bq0, *Anorm;
   EllMat ell;
+  int* warm;            // [1 + nvar] active set of the previous single-problem step (nullptr: cold start)
   const double* z;      // [nb][N]      (or nullptr with zeta)
   const double* zeta;   // [nb][nzeta]  (fused lift)
   const double* u_prev; // [nb][m]
@@ -601,6 +661,9 @@ __host__ __device__ inline int mpc_lds_doubles(int N, int m, int Np, int nproj, 
          qp_lds_doubles(nvar, nrows);
 }
 
+// WARM: single-problem instantiation with the active-set warm start; the batched one carries none of that code
+// (its registers and branches cost the batch 1.8x when they were a run-time option).
+template <bool WARM>
 __global__ __launch_bounds__(256) void kp_mpc_step_kernel(MpcArgs a) {
   extern __shared__ double sm[];
   const int tid = threadIdx.x;
@@ -751,8 +814,39 @@ __global__ __launch_bounds__(256) void kp_mpc_step_kernel(MpcArgs a) {
     // (the solver's own single-wave inverse, have_hinv = false, measured 63 us against 38 us for the workgroup version)
     const int hbad = wg_spd_inverse(qpws, nv, qpws + 3 * nv * nv + 4 * nv);
     const bool have_hinv = true;
+    // warm start from the previous step's active set (closed loops change it by a few rows per step): the whole
+    // workgroup forms HN = H^-1 N' and S = N H^-1 N' and inverts S; wave 0 then only has to release rows whose
+    // multiplier is negative and add the newly violated ones
+    int wq = 0;
+    if (WARM && a.warm && !hbad) {
+      wq = min(a.warm[0], nv);
+      double* HNw = qpws + nv * nv;
+      double* Sw = qpws + 2 * nv * nv;
+      int* actw = (int*)(qpws + 3 * nv * nv + 9 * nv) + nv + (nv & 1);     // the solver's act[] (behind apv and apc)
+      if (wq > 0) {
+        for (int c = tid; c < wq; c += 256) actw[c] = a.warm[1 + c];
+        __syncthreads();
+        const int K = a.ell.K;
+        for (int e = tid; e < nv * wq; e += 256) {
+          const int i = e % nv, c = e / nv, row = actw[c];
+          double sacc = 0.0;
+          for (int k = 0; k < K; ++k) sacc += a.ell.val[k * nr + row] * qpws[i + a.ell.col[k * nr + row] * nv];
+          HNw[i + c * nv] = sacc;
+        }
+        __syncthreads();
+        for (int e = tid; e < wq * wq; e += 256) {
+          const int c = e % wq, c2 = e / wq, row = actw[c];
+          double sacc = 0.0;
+          for (int k = 0; k < K; ++k) sacc += a.ell.val[k * nr + row] * HNw[a.ell.col[k * nr + row] + c2 * nv];
+          Sw[c + c2 * nv] = sacc;
+        }
+        __syncthreads();
+        if (wg_spd_inverse(Sw, wq, qpws + 3 * nv * nv + 4 * nv, nv)) wq = 0;   // dependent rows: cold start
+      }
+    }
     if (tid < 64) {
-      int st = qp_goldfarb_idnani(Hq, f, a.ell, bq, nv, nr, qpws, xout, 1e-10, stamps, have_hinv, hbad);
+      int st = WARM ? qp_goldfarb_idnani(Hq, f, a.ell, bq, nv, nr, qpws, xout, 1e-10, stamps, have_hinv, hbad, wq, a.warm)
+                    : qp_goldfarb_idnani(Hq, f, a.ell, bq, nv, nr, qpws, xout, 1e-10, stamps, have_hinv, hbad);
       if (tid == 0) *st_sh = st;
     }
     // the other waves wait here (the solver itself only uses wave-local synchronisation)
@@ -802,6 +896,7 @@ extern "C" int kp_mpc_destroy(kp_mpc* M) {
     if (p) (void)hipFree(p);
   if (M->h_in) (void)hipHostFree(M->h_in);
   if (M->h_out) (void)hipHostFree(M->h_out);
+  if (M->warm) (void)hipFree(M->warm);
   if (M->ellc) (void)hipFree(M->ellc);
   if (M->ellv) (void)hipFree(M->ellv);
   delete M;
@@ -989,17 +1084,26 @@ static int mpc_run(kp_mpc* M, const kp_basis* basis, int nb, const double* z, co
   a.U = zc ? M->h_out : M->d_out;
   a.z_out = a.U + (size_t)nb * nv;
   a.qp_export = nb == 1 ? M->work : nullptr;
+  static const bool no_warm = getenv("KP_MPC_NO_WARM") != nullptr;
+  if (!M->warm) {
+    KP_HIP(ctx, hipMalloc((void**)&M->warm, (size_t)(1 + nv) * sizeof(int)));
+    KP_HIP(ctx, hipMemsetAsync(M->warm, 0, (size_t)(1 + nv) * sizeof(int), ctx->stream));
+  }
+  a.warm = (nb == 1 && !no_warm) ? M->warm : nullptr;
   a.status = zc ? (int*)(M->h_out + M->io_problems * n_out) : M->d_status;
   a.stamps = nb == 1 ? (long long*)(M->work + n_ex) : nullptr;
   size_t lds = (size_t)mpc_lds_doubles(N, m, Np, nproj, nv, nr, iters, zeta ? basis->dev.nfull : 0) * 8 + 32;
   if (lds > 160 * 1024) return ctx->fail(KP_ERR_ARG, "kp_mpc_step: problem too large for LDS");
-  static size_t lds_set = 0;
-  if (lds > lds_set) {
-    KP_HIP(ctx, hipFuncSetAttribute((const void*)kp_mpc_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    lds_set = lds;
+  static size_t lds_set[2] = {0, 0};
+  const int wk = a.warm != nullptr;
+  if (lds > lds_set[wk]) {
+    KP_HIP(ctx, hipFuncSetAttribute(wk ? (const void*)kp_mpc_step_kernel<true> : (const void*)kp_mpc_step_kernel<false>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    lds_set[wk] = lds;
   }
   KP_HIP(ctx, hipEventRecord(ctx->evp[4], ctx->stream));
-  hipLaunchKernelGGL(kp_mpc_step_kernel, dim3(nb), dim3(256), lds, ctx->stream, a);
+  if (wk) hipLaunchKernelGGL(kp_mpc_step_kernel<true>, dim3(nb), dim3(256), lds, ctx->stream, a);
+  else hipLaunchKernelGGL(kp_mpc_step_kernel<false>, dim3(nb), dim3(256), lds, ctx->stream, a);
   KP_HIP(ctx, hipGetLastError());
   KP_HIP(ctx, hipEventRecord(ctx->evp[5], ctx->stream));
   // one device-to-host copy: x and z of every problem, then the status words

@@ -123,7 +123,9 @@ def test_batch_matches_single(ctx, arm, golden, arm_models):
         Us.append(mpc.step(z, u_prev, YR[-1])[0])
     Ub, st = mpc.step_batch(np.array(Z), np.array(UP), np.array(YR))
     assert (st == 0).all()
-    assert np.abs(Ub - np.array(Us)).max() == 0.0             # same kernel, same arithmetic
+    # same kernel and the same (unique) optimum; the single-problem path warm-starts from the previous step's active
+    # set, so its pivoting order - and rounding - differs from the cold-started batch
+    assert np.abs(Ub - np.array(Us)).max() < 1e-11
 
 
 def test_infeasible_qp_returns_nan_like_the_gurobi_shim(ctx, arm, golden, arm_models):
