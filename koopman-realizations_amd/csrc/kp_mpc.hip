@@ -169,7 +169,9 @@ __device__ __forceinline__ int qp_goldfarb_idnani(const double* Hq, const double
   unsigned char* isact = (unsigned char*)(act + n + (n & 1));
   // constraint rows in LDS (the violation scan of every iteration reads all of them; from global memory a scan costs
   // ~3000 cycles of L2 latency)
-  double* lval = (double*)(((uintptr_t)(isact + mr) + 7) & ~(uintptr_t)7);
+  // (isact is 8-byte aligned.  No pointer -> integer -> pointer round trips here: they hide the LDS address space from
+  // the compiler, which then emits FLAT loads and stores for the whole workspace instead of ds_read / ds_write)
+  double* lval = (double*)isact + ((mr + 7) >> 3);
   double* lnorm = lval + mr * QP_KLDS;
   double* lb = lnorm + mr;
   int* lcol = (int*)(lb + mr);
@@ -585,56 +587,7 @@ __global__ __launch_bounds__(256) void kp_mpc_setup_kernel(const double* __restr
   }
 }
 
-// In-place Gauss-Jordan inverse of an SPD n x n matrix in LDS by a whole 256-thread workgroup.
-// Returns non-zero if a pivot is not positive.
-// Pivot step k rewrites every element from two copies of the pivot column and row,
-//   cc[i] = (i == k) ? -1 : H[i][k],   rr[j] = (j == k) ? 1/p : H[k][j] / p,   H[i][j] <- (i == k || j == k ? 0 : H[i][j]) - cc[i] rr[j],
-// which covers the pivot row, the pivot column and the pivot itself without branches: two barriers per pivot.
-// Thread tid owns elements e = tid + 256 t; their (row, column) pairs advance by (256 % n, 256 / n) with one carry, so
-// the pivot loop has no integer division and no per-thread index table (a fully unrolled 16-entry table cost 248 VGPRs
-// and halved the occupancy of the batched MPC kernel).  Elements go in groups of 4: all LDS reads, then all writes.
-__device__ __forceinline__ int wg_spd_inverse(double* Hinv, int n, double* colk /* 2 n scratch */, int ld = 0) {
-  if (ld == 0) ld = n;
-  const int tid = threadIdx.x;
-  int bad = 0;
-  const int di = 256 % n, dj = 256 / n, i0 = tid % n, j0 = tid / n;
-  const int ne = (n * n + 255) >> 8;
-  double* rowk = colk + n;                      // second scratch row (the caller provides 2 n doubles)
-  for (int k = 0; k < n; ++k) {
-    const double piv = Hinv[k + k * ld];
-    if (!(piv > 0.0)) bad = 1;
-    const double ip = 1.0 / piv;
-    for (int i = tid; i < n; i += 256) {
-      colk[i] = i == k ? -1.0 : Hinv[i + k * ld];
-      rowk[i] = i == k ? ip : Hinv[k + i * ld] * ip;
-    }
-    __syncthreads();
-    int i = i0, j = j0;
-    for (int t0 = 0; t0 < ne; t0 += 4) {
-      double v[4];
-      int ix[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const bool in = j < n;
-        ix[u] = in ? i + j * ld : -1;
-        const double old = (in && i != k && j != k) ? Hinv[i + j * ld] : 0.0;
-        const double rj = in ? rowk[j] : 0.0;
-        v[u] = old - colk[i] * rj;
-        i += di;
-        j += dj;
-        if (i >= n) {
-          i -= n;
-          ++j;
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (ix[u] >= 0) Hinv[ix[u]] = v[u];
-    }
-    __syncthreads();
-  }
-  return bad;
-}
+#include "kp_wg_inverse.h"
 
 struct MpcArgs {
   BasisDev basis;   // used when zeta != nullptr (fused lift)
@@ -665,7 +618,7 @@ __host__ __device__ inline int mpc_lds_doubles(int N, int m, int Np, int nproj, 
 // (its registers and branches cost the batch 1.8x when they were a run-time option).
 template <bool WARM>
 __global__ __launch_bounds__(256) void kp_mpc_step_kernel(MpcArgs a) {
-  extern __shared__ double sm[];
+  extern __shared__ __align__(16) double sm[];
   const int tid = threadIdx.x;
   const int pb = blockIdx.x;
   const int N = a.N, m = a.m, Np = a.Np, nproj = a.nproj, nv = a.nvar, nr = a.nrows;
@@ -680,7 +633,7 @@ __global__ __launch_bounds__(256) void kp_mpc_step_kernel(MpcArgs a) {
   double* full = zh + (a.iters > 1 ? (Np + 1) * N : 0);
   int* st_sh = (int*)(full + (a.has_basis ? a.basis.nfull : 0));   // one slot for the QP status
   double* qpws = (double*)st_sh + 1;
-  qpws = (double*)(((uintptr_t)qpws + 15) & ~(uintptr_t)15);
+  qpws += (qpws - sm) & 1;                // 16-byte aligned (sm is), by index arithmetic: the pointer stays an LDS pointer
   const double* Yr = a.Yr + (size_t)pb * nproj * (Np + 1);
   const double* up = a.u_prev + (size_t)pb * m;
   long long* stamps = (a.stamps && pb == 0) ? a.stamps : nullptr;
@@ -808,11 +761,14 @@ __global__ __launch_bounds__(256) void kp_mpc_step_kernel(MpcArgs a) {
     // ---- QP by wave 0 ----
     if (stamps && tid == 0) stamps[3] = wall_clock64();
     double* xout = a.U + (size_t)pb * nv;
-    // H^-1 by the whole workgroup into the solver's scratch (first n*n doubles); d-slot as scratch
+    // H^-1 by the whole workgroup into the solver's scratch (first n*n doubles).  Hq is not needed after this
+    // point (the solver works from H^-1; the next linearisation pass rebuilds it), so it is the second buffer of the
+    // ping-pong inverse.
+    // (the solver's own single-wave inverse, have_hinv = false, measured 63 us against 38 us for the first workgroup
+    //  version, 27 us for the two-barrier in-place one and 10 us for this one, nv = 30)
     for (int e = tid; e < nv * nv; e += 256) qpws[e] = Hq[e];
     __syncthreads();
-    // (the solver's own single-wave inverse, have_hinv = false, measured 63 us against 38 us for the workgroup version)
-    const int hbad = wg_spd_inverse(qpws, nv, qpws + 3 * nv * nv + 4 * nv);
+    const int hbad = wg_spd_inverse_pp(qpws, Hq, nv, nv);
     const bool have_hinv = true;
     // warm start from the previous step's active set (closed loops change it by a few rows per step): the whole
     // workgroup forms HN = H^-1 N' and S = N H^-1 N' and inverts S; wave 0 then only has to release rows whose
@@ -841,7 +797,7 @@ __global__ __launch_bounds__(256) void kp_mpc_step_kernel(MpcArgs a) {
           Sw[c + c2 * nv] = sacc;
         }
         __syncthreads();
-        if (wg_spd_inverse(Sw, wq, qpws + 3 * nv * nv + 4 * nv, nv)) wq = 0;   // dependent rows: cold start
+        if (wg_spd_inverse_pp(Sw, Hq, wq, nv)) wq = 0;   // dependent rows: cold start
       }
     }
     if (tid < 64) {

@@ -82,6 +82,26 @@ def test_qp_assembly_matches_literal_kmpc(ctx, arm, golden, arm_models, mt, smoo
         assert np.abs(U[0] - u_prev).max() < 1e-9          # pinned first input (Kmpc.m:865-870)
 
 
+@pytest.mark.parametrize("Np", [3, 5, 7, 12, 16, 21])
+def test_horizon_lengths_odd_and_even_variable_counts(ctx, arm, golden, arm_models, Np):
+    """nvar = 3 Np: odd counts take the per-element workgroup inverse, even ones the 2 x 2 tile version, nvar > 32 the
+    multi-tile loop; consecutive steps also exercise the warm start with odd / even active-set sizes."""
+    dic, mdl = arm_models["bilinear"]
+    s = example_control_setup(arm, "bilinear", dic, mdl, Np=Np)
+    mpc = make_mpc(ctx, s)
+    assert mpc.nvar == 3 * Np
+    ref_all = golden["blockM_ref"]["y"]
+    ysc = (ref_all - arm["scale"]["y_offset"][-2:]) / arm["scale"]["y_factor"][-2:]
+    for k in (0, 1, 2, 40, 41, 150):
+        y, z, u_prev, _ = sample_states(arm, golden, dic, k)
+        ref = ysc[k:k + Np + 1]
+        U, st = mpc.step(z, u_prev, ko.pad_ref(ref, s.Np))
+        Hr, fr, Ar, br = ko.mpc_qp(s, z, u_prev, ref)
+        x, lam, ok = ko.qp_solve(Hr, fr, Ar, br)
+        assert ok and st == 0
+        assert np.abs(U - x.reshape(s.Np, s.m)).max() < 1e-8
+
+
 def test_fused_lift_step_and_iterated_linearisation(ctx, arm, golden, arm_models):
     dic, mdl = arm_models["bilinear"]
     s = example_control_setup(arm, "bilinear", dic, mdl)
