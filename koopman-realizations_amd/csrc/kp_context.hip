@@ -40,20 +40,24 @@ extern "C" int kp_create(int device_id, kp_ctx** out) {
   }
   kp_ctx* c = new kp_ctx();
   c->device = device_id;
+  // Events order work between this context's two streams and time kernels; neither needs the system-scope release
+  // (L2 write-back towards the host) that a default event performs after every kernel it follows - results reach the
+  // host through explicit copies.  KP_EVENT_SYSTEM_FENCE=1 restores the default.
+  const unsigned evf = getenv("KP_EVENT_SYSTEM_FENCE") ? 0u : (unsigned)hipEventDisableSystemFence;
   if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
-      (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess) {
+      (e = hipEventCreateWithFlags(&c->ev0, evf)) != hipSuccess || (e = hipEventCreateWithFlags(&c->ev1, evf)) != hipSuccess) {
     kp_set_global_error(std::string("kp_create: ") + hipGetErrorString(e));
     delete c;
     return KP_ERR_HIP;
   }
-  for (int i = 0; i < 6; ++i) (void)hipEventCreate(&c->evp[i]);
+  for (int i = 0; i < 6; ++i) (void)hipEventCreateWithFlags(&c->evp[i], evf);
   (void)hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
-  (void)hipEventCreateWithFlags(&c->ev_gram_done, hipEventDisableTiming);
-  (void)hipEventCreateWithFlags(&c->ev_pad_done, hipEventDisableTiming);
-  (void)hipEventCreateWithFlags(&c->ev_pad_done2, hipEventDisableTiming);
-  (void)hipEventCreateWithFlags(&c->ev_main_done, hipEventDisableTiming);
-  (void)hipEventCreate(&c->ev_solve0);
-  (void)hipEventCreate(&c->ev_solve1);
+  (void)hipEventCreateWithFlags(&c->ev_gram_done, hipEventDisableTiming | evf);
+  (void)hipEventCreateWithFlags(&c->ev_pad_done, hipEventDisableTiming | evf);
+  (void)hipEventCreateWithFlags(&c->ev_pad_done2, hipEventDisableTiming | evf);
+  (void)hipEventCreateWithFlags(&c->ev_main_done, hipEventDisableTiming | evf);
+  (void)hipEventCreateWithFlags(&c->ev_solve0, evf);
+  (void)hipEventCreateWithFlags(&c->ev_solve1, evf);
   if (hipMalloc((void**)&c->sticky_info, sizeof(int)) == hipSuccess) (void)hipMemset(c->sticky_info, 0, sizeof(int));
   hipDeviceProp_t p;
   if (hipGetDeviceProperties(&p, device_id) == hipSuccess) {

@@ -532,11 +532,14 @@ extern "C" int kp_fit(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* sn
     static const bool reduce_on_solve = getenv("KP_REDUCE_ON_GRAM_STREAM") == nullptr;
     ctx->reduce_stream = reduce_on_solve ? ctx->stream2 : nullptr;
     ctx->part_flip = flip;
+    ctx->solve_chained = false;
     rc = kp_gram_dispatch(ctx, basis, snaps, GCb);
     ctx->reduce_stream = nullptr;
     if (rc) return rc;
-    KP_HIP(ctx, hipEventRecord(ctx->ev_gram_done, ctx->stream));
-    KP_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_gram_done, 0));
+    if (!ctx->solve_chained) {
+      KP_HIP(ctx, hipEventRecord(ctx->ev_gram_done, ctx->stream));
+      KP_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_gram_done, 0));
+    }
     KP_HIP(ctx, hipEventRecord(ctx->ev_solve0, ctx->stream2));
     rc = kp_chol_solve_dev(ctx, GCb, GCb + (size_t)W * W, W, W, ctx->Kres, ctx->stream2, evp, ctx->sticky_info);
     if (rc) return rc;

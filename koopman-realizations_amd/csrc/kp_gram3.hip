@@ -528,7 +528,9 @@ int kp_gram3_launch(kp_ctx* ctx, const kp_basis* basis_c, const kp_snapshots* s,
   a.part = part;
   a.njobs = plan.njobs;
   const int grid = plan.nsuper * nsplit;
-  KP_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  // every event record is a barrier packet the command processor works through between two Gram kernels: the
+  // pipelined path keeps two (kernel start / end; the end also releases the reduction on the solve stream)
+  if (!ctx->reduce_stream) KP_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   KP_HIP(ctx, hipEventRecord(ctx->evp[0], ctx->stream));
   hipError_t e;
   switch (plan.nq) {
@@ -544,15 +546,15 @@ int kp_gram3_launch(kp_ctx* ctx, const kp_basis* basis_c, const kp_snapshots* s,
   hipStream_t rs = ctx->stream;
   if (ctx->reduce_stream) {                       // reduction (and everything after it) belongs to the solve stream
     rs = ctx->reduce_stream;
-    KP_HIP(ctx, hipEventRecord(ctx->ev_main_done, ctx->stream));
-    KP_HIP(ctx, hipStreamWaitEvent(rs, ctx->ev_main_done, 0));
+    KP_HIP(ctx, hipStreamWaitEvent(rs, ctx->evp[1], 0));
     KP_HIP(ctx, hipEventRecord(ctx->evp[4], rs));   // start of the reduction on its own stream (timer 6)
+    ctx->solve_chained = true;                      // the solve stream already waits for this Gram kernel
   }
   ctx->reduce_timed_from = ctx->reduce_stream ? 4 : 1;
   hipLaunchKernelGGL(kp_gram3_reduce_kernel, dim3(plan.njobs * plan.nq * NWT), dim3(256), 0, rs, part, nsplit, plan.njobs,
                      plan.nq, NWT, BM, plan.desc, plan.G4, N, W, GC_dev, GC_dev + (size_t)W * W);
   KP_HIP(ctx, hipGetLastError());
-  KP_HIP(ctx, hipEventRecord(ctx->ev1, rs));
+  if (!ctx->reduce_stream) KP_HIP(ctx, hipEventRecord(ctx->ev1, rs));
   KP_HIP(ctx, hipEventRecord(ctx->evp[2], rs));
   ctx->gram_flops_per_pair = (double)W * (W + 1) + 2.0 * W * W;
   return KP_OK;

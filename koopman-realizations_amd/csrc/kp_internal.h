@@ -25,6 +25,7 @@ struct kp_ctx {
   // (after an event recorded behind the main Gram kernel) and the partial buffer `part_flip` is used
   hipStream_t reduce_stream = nullptr;
   hipEvent_t ev_main_done = nullptr;
+  bool solve_chained = false;   // set by a Gram launch that already made the solve stream wait for it
   int part_flip = 0;
   int reduce_timed_from = 1;   // evp index that marks the start of the last partial reduction
   int* sticky_info = nullptr;       // device word: set by any deferred factorisation that hit a non-positive pivot
