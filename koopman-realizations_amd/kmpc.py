@@ -3,8 +3,10 @@
 Kmpc keeps the reference's constructor options and method signatures for the QP-based
 controllers (model_type 'linear' and 'bilinear' with mpc_type 'linear'); the per-step work —
 lift, QP assembly and QP solve — is one kernel launch in libkoopman_hip.so.
-Out of scope: mpc_type 'nonlinear' (fmincon SQP), loaded models,
-state_bounds (KP_ERR_ARG in the library).
+Loaded models (sysid_class.loaded): the lifted state is the loaded lift with the current load estimate
+traj['what'] (Kmpc.m:347-348, :771-772, :839-840); estimate_load_linear / estimate_load_bilinear (Kmpc.m:1298-1445)
+assemble the regression on the host and solve the constrained least squares with the library's QP kernel.
+Out of scope: mpc_type 'nonlinear' (fmincon SQP), state_bounds (KP_ERR_ARG in the library).
 """
 from __future__ import annotations
 
@@ -109,8 +111,65 @@ class Kmpc:
     def _step(self, traj, ref, iters):
         zeta = self._zeta(traj)
         u_prev = np.atleast_2d(traj["u"])[-1]
+        if self.loaded:                                                # Kmpc.m:347-348: lift with the load estimate
+            z = self.lift.econ_full_loaded(zeta, np.atleast_2d(traj["what"])[-1])
+            U, st = self.dev.step(z, u_prev, self._pad_ref(ref), iters)
+            return U, z
         U, z, st = self.dev.step_zeta(self.sysid.basis_dev, zeta, u_prev, self._pad_ref(ref), iters)
         return U, z                                                    # U is NaN when the QP failed
+
+    # ---- load estimation (Kmpc.m:1298-1445) ------------------------------------------------------------
+    def _lsqlin_load(self, Cl, dl, whatpast, pin_last_zero):
+        """The lsqlin call (Kmpc.m:1354, :1442): min ||C x - d||^2, x = [1; w], x_1 = 1, -1 <= w <= 1 and, with a
+        previous estimate, |w_i - whatpast_i| <= 0.01.  Strictly convex QP in the free loads, solved by kp_qp_solve."""
+        nw = self.params["nw"]
+        free = list(range(nw - 1)) if (pin_last_zero and nw >= 1) else list(range(nw))
+        what = np.zeros(nw)
+        if free:
+            Cf = Cl[:, 1:][:, free]
+            r = dl - Cl[:, 0]
+            rows, rhs = [], []
+            for k, i in enumerate(free):
+                lo, hi = -1.0, 1.0
+                if whatpast is not None:
+                    wp = np.atleast_2d(whatpast)[-1]
+                    lo, hi = max(lo, wp[i] - 0.01), min(hi, wp[i] + 0.01)
+                e = np.zeros(len(free)); e[k] = 1.0
+                rows += [e, -e]; rhs += [hi, -lo]
+            what[free] = self.ctx.qp_solve(2.0 * Cf.T @ Cf, -2.0 * Cf.T @ r, np.array(rows), np.array(rhs))[0]
+        res = Cl @ np.concatenate([[1.0], what]) - dl
+        return what, float(res @ res)
+
+    def estimate_load_linear(self, ypast, upast, whatpast=None):
+        """Kmpc.m:1298-1356.  The shipped code pins the LAST load to zero through the debugging equality
+        Aeq = blkdiag(1, 0, 1) (:1350), which only has the right size for nw = 2; reproduced for nw = 2."""
+        p = self.params; N, nz, nw, nd = p["N"], p["nzeta"], p["nw"], p["nd"]
+        ypast = np.atleast_2d(ypast); upast = np.atleast_2d(upast)
+        if ypast.shape[0] != upast.shape[0]:
+            raise ValueError("Input arguments must have the same number of rows")
+        _, zp = self.sysid.get_zeta({"y": ypast, "u": upast})
+        G = self.lift.econ_full(zp[:-1])                                # psi of every past state, one device call
+        CA, CB = self.model["A"][:nz, :], self.model["B"][:nz, :]
+        rows = [CA @ np.kron(np.eye(nw + 1), g[:, None]) for g in G]      # :1320-1326
+        rhs = [zp[i + 1, :nz] - CB @ upast[nd + i] for i in range(len(G))]
+        return self._lsqlin_load(np.vstack(rows), np.concatenate(rhs), whatpast, nw == 2)
+
+    def estimate_load_bilinear(self, ypast, upast, whatpast=None):
+        """Kmpc.m:1360-1444."""
+        p = self.params; N, nz, nw, m = p["N"], p["nzeta"], p["nw"], p["m"]
+        NL = N * (nw + 1)
+        ypast = np.atleast_2d(ypast); upast = np.atleast_2d(upast)
+        if ypast.shape[0] != upast.shape[0]:
+            raise ValueError("Input arguments must have the same number of rows")
+        _, zp = self.sysid.get_zeta({"y": ypast, "u": upast})
+        G = self.lift.econ_full(zp[:-1])
+        A, B = self.model["A"], self.model["B"]
+        rows = []
+        for i, g in enumerate(G):
+            Om = np.kron(np.eye(nw + 1), g[:, None])
+            rows.append((A[:nz, :] + sum(upast[i, j] * B[:nz, j * NL:(j + 1) * NL] for j in range(m))) @ Om)   # :1384-1394
+        rhs = [zp[i + 1, :nz] for i in range(len(G))]
+        return self._lsqlin_load(np.vstack(rows), np.concatenate(rhs), whatpast, False)
 
     def get_mpcInput(self, traj, ref):
         """Kmpc.m:329-387 (linear model)."""

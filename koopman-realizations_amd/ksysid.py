@@ -7,7 +7,11 @@ arrays with MATLAB's shapes (rows = time steps / snapshots).  All heavy arithmet
 this file only does what the MATLAB host does around those calls: option parsing,
 scaling bookkeeping, snapshot selection, dictionary description.
 
-Not supported (KP scope): loaded=True, time_type='continuous'.
+loaded=True (Ksysid.m:539-626: lifted state psi (x) [1; w] for a load vector w) is expressed with the same device
+kernels: for monomial dictionaries w_i * psi_k is again a monomial, over the variables [zeta; w], so the loaded
+dictionary is an exponent table and the columns only have to be put back into the reference's block order
+(`_loaded_perm`).  Limits: 'poly' observables, no dim_red.
+Not supported (KP scope): time_type='continuous'.
 """
 from __future__ import annotations
 
@@ -82,6 +86,18 @@ class _Lift:
         """lift.econ_full (Ksysid.m:1615-1618 / 1443-1491)."""
         return self._lift(F.LIFT_ECON, v)
 
+    def econ_full_loaded(self, v, w):
+        """lift.econ_full_loaded (Ksysid.m:1606-1612): [psi, w_1 psi, ...] with psi = econ_full(v)."""
+        return self._o._lift_loaded(F.LIFT_FULL, v, w, None)
+
+    full_loaded = econ_full_loaded        # no dim_red for loaded systems here: the two coincide (:1444)
+
+    def econ_full_loaded_input(self, zeta, w, u):
+        """lift.econ_full_loaded_input (Ksysid.m:1580-1591), bilinear only: kron(eye(m+1), full_loaded) * [1; u]."""
+        return self._o._lift_loaded(F.LIFT_ROW, zeta, w, u)
+
+    full_loaded_input = econ_full_loaded_input
+
     def econ_full_input(self, zeta, u):
         """lift.econ_full_input (Ksysid.m:1594-1604), bilinear only."""
         b = self._o.basis_dev
@@ -114,8 +130,8 @@ class Ksysid:
         las = np.atleast_1d(np.asarray(self.lasso, dtype=np.float64))
         las = np.where(np.isinf(las), 1e6, las)                            # :155-157
         self.lasso = las if las.size > 1 else float(las[0])
-        if self.loaded:
-            raise NotImplementedError("loaded models are out of scope (SURVEY section 8)")
+        if self.loaded and "w" not in data:                                # :106-109
+            raise ValueError("You have specified a loaded system, but your training data does not have the required load field (w)")
         if self.time_type != "discrete":
             raise NotImplementedError("continuous-time models are out of scope (SURVEY section 8)")
         if self.model_type not in ("linear", "bilinear", "nonlinear"):    # :96-104
@@ -129,7 +145,10 @@ class Ksysid:
         p = self.params
         p["nd"] = int(self.delays)
         p["nzeta"] = p["n"] * (p["nd"] + 1) + p["m"] * p["nd"]             # :86
-        p["nw"] = 0
+        p["nw"] = np.atleast_2d(np.asarray(data["w"], dtype=np.float64)).reshape(len(t0), -1).shape[1] if self.loaded else 0   # :89-93
+        if self.loaded and (self.dim_red or any(k != "poly" for k in self.obs_type)):
+            raise NotImplementedError("loaded systems: 'poly' observables without dim_red")
+        self.basis_loaded_dev = None
         self._gauss_centres = gaussian_centres
         self._rng = np.random.default_rng(snapshot_seed)
         self.basis = {}
@@ -174,21 +193,80 @@ class Ksysid:
         self.basis_dev = Basis(self.ctx, self.model_type, p["nzeta"], p["m"], blocks, None)
         p["N"] = self.basis_dev.nfull                                      # :534
         self.basis["blocks"] = blocks
+        if self.loaded:
+            self._def_observables_loaded()
+
+    def _def_observables_loaded(self):
+        """def_observables_loaded (Ksysid.m:539-626).  Reference order of the loaded dictionary: blocks
+        [psi ; w_1 psi ; ... ; w_nw psi] (:596-599) with psi = [zeta ; poly blocks ; 1] over zeta (or [zeta ; u] for
+        'nonlinear').  Device dictionary: the same monomials over the variables [zeta ; w] ([zeta ; w ; u] for
+        'nonlinear'), which the library orders [identity of every variable ; given rows ; 1]; `_loaded_perm[c]` is the
+        device column of reference column c."""
+        p = self.params
+        nz, nw, m = p["nzeta"], p["nw"], p["m"]
+        nonlin = self.model_type == "nonlinear"
+        nv_ref = self._nvars                                      # nzeta (+ m)
+        nv_dev = nz + nw + (m if nonlin else 0)
+        E = np.vstack([np.eye(nv_ref, dtype=np.uint8)] + [np.asarray(b[1], dtype=np.uint8) for b in self._blocks] +
+                      [np.zeros((1, nv_ref), dtype=np.uint8)])    # psi: identity, poly rows of every block, constant
+        col = list(range(nz)) + ([nz + nw + j for j in range(m)] if nonlin else [])      # reference variable -> device variable
+        rows = np.zeros(((nw + 1) * E.shape[0], nv_dev), dtype=np.uint8)
+        for i in range(nw + 1):
+            blk = rows[i * E.shape[0]:(i + 1) * E.shape[0]]
+            blk[:, col] = E
+            if i > 0:
+                blk[:, nz + i - 1] = 1                            # times w_i
+        poly, perm = [], np.zeros(rows.shape[0], dtype=np.int64)
+        for c, r in enumerate(rows):
+            tot = int(r.sum())
+            if tot == 0:
+                perm[c] = -1                                      # constant: last device column
+            elif tot == 1:
+                perm[c] = int(np.argmax(r))                       # a bare variable: identity part
+            else:
+                perm[c] = nv_dev + len(poly); poly.append(r)
+        perm[perm < 0] = nv_dev + len(poly)
+        self.basis_loaded_dev = Basis(self.ctx, self.model_type, nz + nw, m, [("poly", np.array(poly, dtype=np.uint8).reshape(-1, nv_dev))], None)
+        assert self.basis_loaded_dev.nfull == rows.shape[0] and sorted(perm) == list(range(rows.shape[0]))
+        self._loaded_perm = perm
+        NL = rows.shape[0]
+        if self.model_type == "bilinear":                         # [Psi_L ; u_1 Psi_L ; ...]
+            self._loaded_perm_W = np.concatenate([b * NL + perm for b in range(m + 1)])
+        elif self.model_type == "linear":                         # [Psi_L ; u]
+            self._loaded_perm_W = np.concatenate([perm, NL + np.arange(m)])
+        else:
+            self._loaded_perm_W = perm
+
+    def _lift_loaded(self, what, v, w, u):
+        """Rows of the loaded lift in the reference's column order; v = zeta (or [zeta, u] for 'nonlinear')."""
+        p = self.params; nz, m = p["nzeta"], p["m"]
+        V = np.asarray(v, dtype=np.float64); vec = V.ndim == 1 or (V.ndim == 2 and V.shape[1] == 1)
+        V = V.reshape(1, -1) if vec else V
+        Wl = np.asarray(w, dtype=np.float64).reshape(V.shape[0], -1)
+        zw = np.hstack([V[:, :nz], Wl])
+        if self.model_type == "nonlinear":
+            uu = V[:, nz:nz + m]
+        else:
+            uu = None if u is None else np.asarray(u, dtype=np.float64).reshape(V.shape[0], -1)
+        out = self.basis_loaded_dev.lift(what, zw, uu)
+        out = out[:, self._loaded_perm_W if what == F.LIFT_ROW else self._loaded_perm]
+        return out[0] if vec else out
 
     # ---- data handling ---------------------------------------------------------------
     @staticmethod
     def merge_trials(data):
         """Ksysid.m:380-401."""
         if isinstance(data, (list, tuple)):
+            keys = ("t", "y", "u") + (("w",) if all("w" in d for d in data) else ())
             return {k: np.vstack([np.asarray(d[k], dtype=np.float64).reshape(len(np.ravel(d["t"])), -1) for d in data])
-                    for k in ("t", "y", "u")}
+                    for k in keys}
         return data
 
     def get_scale(self, data):
         """Ksysid.m:180-229 (scale factors kept in params.scale)."""
         sc = {}
         out = {"t": np.asarray(data["t"], dtype=np.float64)}
-        for k in ("y", "u"):
+        for k in ("y", "u") + (("w",) if "w" in data else ()):              # w: :246-264 (same affine map)
             v = np.asarray(data[k], dtype=np.float64)
             mn, mx = v.min(axis=0), v.max(axis=0)
             off = (mx + mn) / 2.0
@@ -205,6 +283,12 @@ class Ksysid:
     def scaledown_u(self, u):
         s = self.params["scale"]; return (np.asarray(u, dtype=np.float64) - s["u_offset"]) / s["u_factor"]
 
+    def scaledown_w(self, w):
+        s = self.params["scale"]; return (np.asarray(w, dtype=np.float64) - s["w_offset"]) / s["w_factor"]
+
+    def scaleup_w(self, w):
+        s = self.params["scale"]; return np.asarray(w, dtype=np.float64) * s["w_factor"] + s["w_offset"]
+
     def scaleup_y(self, y):
         s = self.params["scale"]; return np.asarray(y, dtype=np.float64) * s["y_factor"] + s["y_offset"]
 
@@ -214,7 +298,10 @@ class Ksysid:
     def scale_data(self, data, down=True):
         """Ksysid.m:308-343."""
         fy, fu = (self.scaledown_y, self.scaledown_u) if down else (self.scaleup_y, self.scaleup_u)
-        return {"t": np.asarray(data["t"], dtype=np.float64), "y": fy(data["y"]), "u": fu(data["u"])}
+        out = {"t": np.asarray(data["t"], dtype=np.float64), "y": fy(data["y"]), "u": fu(data["u"])}
+        if "w" in data and "w_factor" in self.params.get("scale", {}):          # :327-330
+            out["w"] = (self.scaledown_w if down else self.scaleup_w)(np.asarray(data["w"], dtype=np.float64).reshape(len(out["y"]), -1))
+        return out
 
     def get_zeta(self, data_in):
         """Ksysid.m:868-907.  Returns (data_out, zeta)."""
@@ -229,6 +316,8 @@ class Ksysid:
             cols = [y[nd:]] + [y[nd - j:T - j] for j in range(1, nd + 1)] + [u[nd - j:T - j] for j in range(1, nd + 1)]
             out["zeta"] = np.hstack(cols)
             out["uzeta"] = u[nd:]
+        if "w" in data_in:                                                 # :895-897, :902-904
+            out["wzeta"] = np.asarray(data_in["w"], dtype=np.float64).reshape(y.shape[0], -1)[nd:]
         return out, out["zeta"]
 
     def get_snapshotPairs(self, data, num=math.inf):
@@ -242,7 +331,10 @@ class Ksysid:
             data, _ = self.get_zeta(data)
         if "snapshots" in data:                                            # :932-938
             s = data["snapshots"]
-            return {"alpha": np.asarray(s["alpha"], float), "beta": np.asarray(s["beta"], float), "u": np.asarray(s["u"], float)}
+            sp = {"alpha": np.asarray(s["alpha"], float), "beta": np.asarray(s["beta"], float), "u": np.asarray(s["u"], float)}
+            if "w" in s:
+                sp["w"] = np.asarray(s["w"], float)
+            return sp
         nd = self.params["nd"]
         t = np.asarray(data["t"], dtype=np.float64).ravel()
         good = np.nonzero(t[nd:-1] < t[nd + 1:])[0]                        # :941-948
@@ -251,7 +343,10 @@ class Ksysid:
         if num > num_max - 1:                                              # :963-967
             num = num_max
         index = self._rng.permutation(num_max)[:int(num)]                  # :974-975
-        return {"alpha": before[index], "beta": after[index], "u": u[index]}
+        sp = {"alpha": before[index], "beta": after[index], "u": u[index]}
+        if "wzeta" in data:                                                # :953-957, :980-982
+            sp["w"] = data["wzeta"][:-1][good][index]
+        return sp
 
     # ---- dimension reduction -----------------------------------------------------------
     def lift_snapshots(self, snapshotPairs):
@@ -290,6 +385,8 @@ class Ksysid:
         GPU; Px/Py are only materialised (kp_lift) for the koopData fields the reference
         returns (:1085-1086)."""
         N = self.params["N"]
+        if self.loaded:
+            return self._get_Koopman_loaded(snapshotPairs, lasso, want_PxPy)
         snaps = Snapshots(self.ctx, snapshotPairs["alpha"], snapshotPairs["beta"], snapshotPairs["u"])
         try:
             obj_lasso = np.atleast_1d(self.lasso)
@@ -307,6 +404,29 @@ class Ksysid:
         if want_PxPy:
             koop["Px"] = self.basis_dev.lift(F.LIFT_ROW, snapshotPairs["alpha"], snapshotPairs["u"])[:, :N]
             koop["Py"] = self.basis_dev.lift(F.LIFT_ROW, snapshotPairs["beta"], snapshotPairs["u"])[:, :N]
+        return koop
+
+    def _get_Koopman_loaded(self, sp, lasso, want_PxPy):
+        """get_Koopman with loads (Ksysid.m:1005-1092): the fit runs on the device over the variables [zeta ; w]
+        (w is the same on both sides of a pair); K comes back in the reference's column order."""
+        N = self.params["N"]; NL = N * (self.params["nw"] + 1)
+        w = np.asarray(sp["w"], dtype=np.float64).reshape(len(sp["alpha"]), -1)
+        snaps = Snapshots(self.ctx, np.hstack([sp["alpha"], w]), np.hstack([sp["beta"], w]), sp["u"])
+        try:
+            if np.all(np.atleast_1d(self.lasso) >= 1e6):
+                Kd = fit(self.ctx, self.basis_loaded_dev, snaps, [np.inf])[0]
+            else:                                                          # t = lasso * N (:996); the library scales by ITS N
+                lval = 1e4 if lasso is None else float(lasso)
+                Kd = fit(self.ctx, self.basis_loaded_dev, snaps, [lval * N / self.basis_loaded_dev.N])[0]
+        finally:
+            snaps.close()
+        P = self._loaded_perm_W
+        koop = {"K": np.asfortranarray(Kd[np.ix_(P, P)]), "u": sp["u"], "alpha": sp["alpha"], "w": w}
+        if want_PxPy:                                                      # :1085-1086
+            koop["Px"] = self._lift_loaded(F.LIFT_ROW, sp["alpha"], w, sp["u"])[:, :NL] if self.model_type != "nonlinear" else \
+                self._lift_loaded(F.LIFT_FULL, np.hstack([sp["alpha"], sp["u"]]), w, None)
+            koop["Py"] = self._lift_loaded(F.LIFT_ROW, sp["beta"], w, sp["u"])[:, :NL] if self.model_type != "nonlinear" else \
+                self._lift_loaded(F.LIFT_FULL, np.hstack([sp["beta"], sp["u"]]), w, None)
         return koop
 
     def _lasso_with_delay_rows(self, snaps, t):
@@ -336,19 +456,30 @@ class Ksysid:
         """Ksysid.m:1179-1235 (discrete): A, B, C and the projection M."""
         p = self.params; N, n, m = p["N"], p["n"], p["m"]
         K = koopData["K"]
-        snaps = Snapshots(self.ctx, koopData["alpha"], koopData["beta"], koopData["u"])
-        try:
-            G, Cm = fit_gram(self.ctx, self.basis_dev, snaps)
-        finally:
-            snaps.close()
+        if self.loaded:                                                    # :1192-1200: every size is N (nw + 1)
+            N = N * (p["nw"] + 1)
+            w = koopData["w"]
+            snaps = Snapshots(self.ctx, np.hstack([koopData["alpha"], w]), np.hstack([koopData["beta"], w]), koopData["u"])
+            try:
+                Gd, Cd = fit_gram(self.ctx, self.basis_loaded_dev, snaps)
+            finally:
+                snaps.close()
+            P = self._loaded_perm_W
+            G, Cm = np.asfortranarray(Gd[np.ix_(P, P)]), np.asfortranarray(Cd[np.ix_(P, P)])
+        else:
+            snaps = Snapshots(self.ctx, koopData["alpha"], koopData["beta"], koopData["u"])
+            try:
+                G, Cm = fit_gram(self.ctx, self.basis_dev, snaps)
+            finally:
+                snaps.close()
         A, B, M = self.ctx.model_project(K, G, Cm, N, m)
         out = {"A": A, "B": B, "C": np.hstack([np.eye(n), np.zeros((n, N - n))]), "M": M, "params": dict(p), "K": K}
         self.model = out
         return out
 
     def get_BLmodel(self, koopData):
-        """Ksysid.m:1238-1282."""
-        p = self.params; N, n, m = p["N"], p["n"], p["m"]
+        """Ksysid.m:1238-1282 (with loads every size is N (nw + 1), :1251-1259)."""
+        p = self.params; N, n, m = p["N"] * (p["nw"] + 1), p["n"], p["m"]
         UT = koopData["K"].T
         A = np.asfortranarray(UT[:N, :N]); B = np.asfortranarray(UT[:N, N:])
         out = {"A": A, "B": B, "C": np.hstack([np.eye(n), np.zeros((n, N - n))]), "params": dict(p), "K": koopData["K"],
@@ -360,8 +491,11 @@ class Ksysid:
         """Ksysid.m:1298-1341: F(zeta,u) = K(:,1:nzeta)' * basis([zeta;u])."""
         p = self.params
         Kf = np.ascontiguousarray(koopData["K"][:, :p["nzeta"]].T)
-        out = {"Kf": Kf, "C": np.eye(p["n"]), "params": dict(p), "K": koopData["K"],
-               "F_func": lambda zeta, u: Kf @ self.lift.econ_full(np.concatenate([np.ravel(zeta), np.ravel(u)]))}
+        if self.loaded:                                                    # :1320-1327
+            ff = lambda zeta, u, w: Kf @ self.lift.econ_full_loaded(np.concatenate([np.ravel(zeta), np.ravel(u)]), np.ravel(w))
+        else:
+            ff = lambda zeta, u: Kf @ self.lift.econ_full(np.concatenate([np.ravel(zeta), np.ravel(u)]))
+        out = {"Kf": Kf, "C": np.eye(p["n"]), "params": dict(p), "K": koopData["K"], "F_func": ff}
         self.model = out
         return out
 
@@ -400,8 +534,52 @@ class Ksysid:
         res["error"] = self.get_error(res["sim"], res["real"])
         return res
 
+    def _val_loaded(self, model, valdata, kind):
+        """Loaded rollouts (Ksysid.m:1657-1671, :1751-1765, :1857-1858).  Every step re-lifts the first N entries
+        of the state with the load of that step, znow = kron(eye(nw+1), z(1:N)) [1; w]; only those N entries (and
+        y = C z, the first n of them) feed forward, so for a constant load the recursion is an ordinary N-dimensional
+        linear / bilinear model with A_eff = sum_i wt_i A(1:N, block i) - rolled out on the device, one launch per
+        run of constant load (loads are constant per trial in practice)."""
+        p = self.params; N, n, m, nw, nz = p["N"], p["n"], p["m"], p["nw"], p["nzeta"]
+        t, yreal, ureal, zetareal = self._val_common(valdata)
+        wreal = np.asarray(valdata["w"], dtype=np.float64).reshape(len(np.ravel(valdata["t"])), -1)[p["nd"]:]
+        T = yreal.shape[0]
+        NL = N * (nw + 1)
+        cuts = [0] + [j for j in range(1, T - 1) if np.any(wreal[j] != wreal[j - 1])] + [T - 1]
+        if kind == "nonlinear":
+            Kf = model["Kf"]
+            Kd = np.zeros((nz + nw, NL))
+            Kd[:nz, self._loaded_perm] = Kf                                   # reference column c -> device column perm[c]
+            for i in range(nw):
+                Kd[nz + i, nz + i] = 1.0                                      # the load is carried along unchanged
+            zs = np.zeros((T, nz)); zs[0] = zetareal[0]
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                if b > a:
+                    seg = self.ctx.rollout_nl(self.basis_loaded_dev, Kd, np.concatenate([zs[a], wreal[a]]), ureal[a:b + 1])
+                    zs[a:b + 1] = seg[:, :nz]
+            return self._results(t, ureal, zs[:, :n], yreal)
+        A, B = model["A"], model["B"]
+        Y = np.zeros((T, N)); Y[0] = self.lift.econ_full(zetareal[0])
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            if b <= a:
+                continue
+            wt = np.concatenate([[1.0], wreal[a]])
+            Aeff = sum(wt[i] * A[:N, i * N:(i + 1) * N] for i in range(nw + 1))
+            if kind == "bilinear":
+                Beff = np.hstack([sum(wt[i] * B[:N, j * NL + i * N:j * NL + (i + 1) * N] for i in range(nw + 1)) for j in range(m)])
+            else:
+                Beff = B[:N, :]
+            Y[a:b + 1] = self.ctx.rollout(kind, Aeff, Beff, Y[a], ureal[a:b + 1], N)
+        ys = Y[:, :n].copy()
+        ys[0] = yreal[0]
+        res = self._results(t, ureal, ys, yreal)
+        res["sim"]["w"] = res["real"]["w"] = wreal                             # :1707-1710
+        return res
+
     def val_model(self, model, valdata):
         """Ksysid.m:1623-1714: z+ = A z + B u rolled out on the device."""
+        if self.loaded:
+            return self._val_loaded(model, valdata, "linear")
         t, yreal, ureal, zetareal = self._val_common(valdata)
         z0 = self.lift.econ_full(zetareal[0])
         Y = self.ctx.rollout("linear", model["A"], model["B"], z0, ureal, self.params["n"])
@@ -410,6 +588,8 @@ class Ksysid:
 
     def val_BLmodel(self, model, valdata):
         """Ksysid.m:1717-1812: z+ = A z + B kron(I,z) u."""
+        if self.loaded:
+            return self._val_loaded(model, valdata, "bilinear")
         t, yreal, ureal, zetareal = self._val_common(valdata)
         z0 = self.lift.econ_full(zetareal[0])
         Y = self.ctx.rollout("bilinear", model["A"], model["B"], z0, ureal, self.params["n"])
@@ -418,6 +598,8 @@ class Ksysid:
 
     def val_NLmodel(self, model, valdata):
         """Ksysid.m:1815-1879: zeta+ = F(zeta,u) (serial; lift per step on the device)."""
+        if self.loaded:
+            return self._val_loaded(model, valdata, "nonlinear")
         t, yreal, ureal, zetareal = self._val_common(valdata)
         zs = self.ctx.rollout_nl(self.basis_dev, model["Kf"], zetareal[0], ureal)   # one launch for the whole trial
         return self._results(t, ureal, zs[:, :self.params["n"]], yreal)

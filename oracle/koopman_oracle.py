@@ -515,6 +515,170 @@ def get_error(sim_y, real_y, sc=None):
 
 
 # ----------------------------------------------------------------------------------
+# Loaded systems (Ksysid.m `loaded` = true): the lifted state is psi (x) [1; w] for a load
+# vector w (scaled like y and u, Ksysid.m:246-264)
+# ----------------------------------------------------------------------------------
+
+def loaded_lift(psi, w):
+    """lift.econ_full_loaded (Ksysid.m:1606-1612, :596-599): kron(eye(nw+1), psi) * [1; w], i.e. the blocks
+    [psi, w_1 psi, ..., w_nw psi].  psi: T x N, w: T x nw (or one row each)."""
+    psi = np.atleast_2d(psi); w = np.atleast_2d(w)
+    return np.hstack([psi] + [psi * w[:, [i]] for i in range(w.shape[1])])
+
+
+def lift_rows_loaded(dic: Dictionary, zeta, u, w):
+    """One row block of Px / Py for a loaded system, Ksysid.m:1034-1064 (loaded branches)."""
+    zeta = np.atleast_2d(zeta); u = np.atleast_2d(u); w = np.atleast_2d(w)
+    if dic.model_type == 'nonlinear':                 # :1036
+        return loaded_lift(econ_full(dic, np.hstack([zeta, u])), w)
+    psi = loaded_lift(econ_full(dic, zeta), w)        # :1056
+    if dic.model_type == 'bilinear':                  # :1046, 1587-1590: kron(eye(m+1), full_loaded) * [1; u]
+        return np.hstack([psi] + [psi * u[:, [i]] for i in range(dic.m)])
+    return np.hstack([psi, u])                        # :1060-1061
+
+
+def snapshot_pairs_loaded(data, nd, index=None):
+    """snapshot_pairs plus the load that acts between the two states (Ksysid.m:953-957, :980-982);
+    wzeta is w at the current time step (:896, :903)."""
+    pairs = snapshot_pairs(data, nd, index)
+    t = np.asarray(data['t']).ravel()
+    good = np.nonzero(t[nd:-1] < t[nd + 1:])[0]
+    w = np.atleast_2d(data['w'])[nd:][:-1][good]
+    num_max = w.shape[0] - 1
+    idx = np.arange(num_max) if index is None else np.asarray(index)
+    pairs['w'] = w[idx]
+    return pairs
+
+
+def get_koopman_loaded(dic, pairs, lasso=None, obj_lasso=1e6):
+    """get_Koopman for a loaded system (Ksysid.m:1005-1092): K is square of width N(nw+1) [+ m | x (m+1)];
+    koopData.Px / Py keep the first N(nw+1) columns (:1085-1086)."""
+    Px = lift_rows_loaded(dic, pairs['alpha'], pairs['u'], pairs['w'])
+    Py = lift_rows_loaded(dic, pairs['beta'], pairs['u'], pairs['w'])
+    nw = pairs['w'].shape[1]
+    NL = dic.N * (nw + 1)
+    if obj_lasso >= 1e6:
+        K = koopman_ls(Px, Py)
+    else:
+        G, C = gram(Px, Py)
+        K = koopman_lasso(G, C, (1e4 if lasso is None else lasso) * dic.N)      # t = lasso * N (:996)
+    return {'K': K, 'Px': Px[:, :NL], 'Py': Py[:, :NL], 'u': pairs['u'], 'alpha': pairs['alpha'], 'w': pairs['w']}
+
+
+def get_model_loaded(dic, koop, n):
+    """get_model with loads (Ksysid.m:1192-1231): A is N(nw+1) square, B is N(nw+1) x m, M-projection as unloaded."""
+    NL = koop['Px'].shape[1]
+    UT = koop['K'].T
+    A, B = UT[:NL, :NL], UT[:NL, NL:]                 # :1199-1200
+    L = koop['Px'] @ A.T + koop['u'] @ B.T            # :1208-1210
+    M = np.linalg.lstsq(L, koop['Py'], rcond=None)[0].T
+    C = np.hstack([np.eye(n), np.zeros((n, NL - n))]) # :1203
+    return {'A': M @ A, 'B': M @ B, 'C': C, 'M': M, 'K': koop['K']}
+
+
+def get_blmodel_loaded(dic, koop, n):
+    """get_BLmodel with loads (Ksysid.m:1251-1278)."""
+    NL = koop['Px'].shape[1]
+    UT = koop['K'].T
+    C = np.hstack([np.eye(n), np.zeros((n, NL - n))])
+    return {'A': UT[:NL, :NL], 'B': UT[:NL, NL:], 'C': C, 'K': koop['K']}
+
+
+def get_nlmodel_loaded(dic, koop, n):
+    """get_NLmodel with loads (Ksysid.m:1320-1327): F(zeta,u,w) = K(:,1:nzeta)' * basis_loaded."""
+    return {'Kf': koop['K'][:, :dic.nzeta].T.copy(), 'C': np.eye(n), 'K': koop['K']}
+
+
+def val_model_loaded(dic, model, val, nd, model_type=None):
+    """val_model / val_BLmodel / val_NLmodel for loaded systems (Ksysid.m:1657-1671, :1751-1765, :1857-1858):
+    every step re-lifts the first N entries of the simulated state with the ACTUAL load of that step,
+    znow = kron(eye(nw+1), zsim(j,1:N)') * [1; w_j]."""
+    mt = model_type or dic.model_type
+    yreal = val['y'][nd:]; ureal = val['u'][nd:]; wreal = np.atleast_2d(val['w'])[nd:]
+    zetareal, _ = get_zeta(val['y'], val['u'], nd)
+    T, n, N = yreal.shape[0], yreal.shape[1], dic.N
+    if mt == 'nonlinear':
+        zs = np.zeros_like(zetareal); zs[0] = zetareal[0]
+        for j in range(T - 1):
+            psi = loaded_lift(econ_full(dic, np.concatenate([zs[j], ureal[j]])[None, :]), wreal[j][None, :])[0]
+            zs[j + 1] = model['Kf'] @ psi
+        return {'sim_y': zs[:, :n], 'real_y': yreal, 't': val['t'][nd:]}
+    z = loaded_lift(econ_full(dic, zetareal[0][None, :]), wreal[0][None, :])[0]
+    ysim = np.zeros_like(yreal); ysim[0] = yreal[0]
+    for j in range(T - 1):
+        znow = loaded_lift(z[None, :N], wreal[j][None, :])[0]
+        if mt == 'bilinear':
+            z = model['A'] @ znow + beta_bilinear(model['B'], znow, dic.m) @ ureal[j]
+        else:
+            z = model['A'] @ znow + model['B'] @ ureal[j]
+        ysim[j + 1] = model['C'] @ z
+    return {'sim_y': ysim, 'real_y': yreal, 't': val['t'][nd:]}
+
+
+def _lsqlin_load(Cl, dl, nw, whatpast, pin_last_zero):
+    """The lsqlin call of the load estimators (Kmpc.m:1354, :1442): min ||C x - d||^2 over x = [1; w] with
+    x_1 = 1 (Aeq/beq), -1 <= x <= 1, and, when the previous estimate is given, |w_i - whatpast_i x_1| <= 0.01
+    (the inequality block A, b at :1344-1347).  Solved as a QP in w after substituting x_1 = 1 (the toolbox solver
+    is third-party; the problem is strictly convex whenever C(:,2:end) has full column rank, so its optimum is
+    unique)."""
+    C1, Cw = Cl[:, 0], Cl[:, 1:]
+    free = list(range(nw - 1)) if (pin_last_zero and nw >= 1) else list(range(nw))
+    what = np.zeros(nw)
+    if free:
+        Cf = Cw[:, free]
+        r = dl - C1
+        H = 2.0 * Cf.T @ Cf
+        f = -2.0 * Cf.T @ r
+        rows, rhs = [], []
+        for k, i in enumerate(free):
+            lo, hi = -1.0, 1.0
+            if whatpast is not None:
+                lo, hi = max(lo, whatpast[i] - 0.01), min(hi, whatpast[i] + 0.01)
+            e = np.zeros(len(free)); e[k] = 1.0
+            rows += [e, -e]; rhs += [hi, -lo]
+        x, _, ok = qp_solve(H, f, np.array(rows), np.array(rhs))
+        assert ok
+        what[free] = x
+    res = Cl @ np.concatenate([[1.0], what]) - dl
+    return what, float(res @ res)
+
+
+def estimate_load_linear(dic, model, ypast, upast, nw, nd=0, whatpast=None):
+    """Kmpc.estimate_load_linear (Kmpc.m:1298-1356): over the past horizon, zeta_{k+1} = CA kron(I, psi(zeta_k)) [1; w]
+    + CB u_k is linear in [1; w].  The shipped code pins the LAST load to zero through the debugging equality
+    Aeq = blkdiag(1, 0, 1) (:1350), which only has the right size for nw = 2; that is reproduced for nw = 2."""
+    zetapast, _ = get_zeta(ypast, upast, nd)
+    hor, N, nz = zetapast.shape[0], dic.N, dic.nzeta
+    CA, CB = model['A'][:nz, :], model['B'][:nz, :]
+    rows, rhs = [], []
+    for i in range(hor - 1):
+        g = econ_full(dic, zetapast[i][None, :])[0]
+        Om = np.kron(np.eye(nw + 1), g[:, None])        # :1323
+        rows.append(CA @ Om)
+        rhs.append(zetapast[i + 1, :nz] - CB @ upast[nd + i])      # :1328-1335
+    return _lsqlin_load(np.vstack(rows), np.concatenate(rhs), nw, whatpast, pin_last_zero=(nw == 2))
+
+
+def estimate_load_bilinear(dic, model, ypast, upast, nw, nd=0, whatpast=None):
+    """Kmpc.estimate_load_bilinear (Kmpc.m:1360-1444): rows (CA + sum_j u_j CB_j) kron(I, psi(zeta_k)); Aeq pins
+    only the leading 1 (:1436)."""
+    zetapast, _ = get_zeta(ypast, upast, nd)
+    hor, N, nz, m = zetapast.shape[0], dic.N, dic.nzeta, dic.m
+    NL = N * (nw + 1)
+    CA = model['A'][:nz, :]
+    rows, rhs = [], []
+    for i in range(hor - 1):
+        g = econ_full(dic, zetapast[i][None, :])[0]
+        Om = np.kron(np.eye(nw + 1), g[:, None])
+        R = CA @ Om
+        for j in range(m):                               # :1388-1393
+            R = R + model['B'][:nz, j * NL:(j + 1) * NL] @ Om * upast[i, j]
+        rows.append(R)
+        rhs.append(zetapast[i + 1, :nz])
+    return _lsqlin_load(np.vstack(rows), np.concatenate(rhs), nw, whatpast, pin_last_zero=False)
+
+
+# ----------------------------------------------------------------------------------
 # Kmpc: cost / constraint matrices and the per-step QP (Kmpc.m)
 # ----------------------------------------------------------------------------------
 
