@@ -134,6 +134,43 @@ def bench_mpc(ctx, kra, basis, snaps, args):
             "_setup": (setup, basis.N, zeta[:20], u_prev[:20], Yr[:20])}
 
 
+def bench_lasso(ctx, kra, basis, snaps, n_values=8):
+    """BASELINE configs[3] on one GPU: a lasso grid on the bilinear fit through ONE kp_fit call (snapshots lifted once,
+    least-squares solution and Lipschitz constant shared, Ksysid.train_models with a vector of lasso values).  The
+    grid is chosen so that the L1 constraint is active for every value (t between 0.9 and 0.1 of ||K_LS||_1)."""
+    G, C = kra.fit_gram(ctx, basis, snaps)
+    l1 = float(np.abs(ctx.fit_solve(G, C)).sum())
+    vals = list(np.geomspace(0.9, 0.1, n_values) * l1 / basis.N)          # t = lasso * N (Ksysid.m:996)
+    kra.fit(ctx, basis, snaps, vals[:1])
+    t0 = time.perf_counter()
+    Ks = kra.fit(ctx, basis, snaps, vals)
+    dt = time.perf_counter() - t0
+    return {"values": n_values, "seconds": dt, "values_per_s": n_values / dt, "W": basis.W,
+            "l1_fraction_reached": [float(np.abs(K).sum() / l1) for K in (Ks[0], Ks[-1])],
+            "workload": "lasso grid on the bilinear poly-3 fit, 1e5 pairs, constraint active (BASELINE configs[3] shape, one GPU's share)"}
+
+
+def bench_rand_sweep(ctx, kra, n_systems=256):
+    """BASELINE configs[4] on one GPU: evaluate_rand_models.m (linear / bilinear / nonlinear fits of every degree +
+    validation rollouts per random system) through the batched path; the three systems committed under tests/golden
+    (taken from the reference's data set) are repeated to n_systems."""
+    from koopman_realizations_amd import sweep
+    g = np.load(os.path.join(ROOT, "tests", "golden", "rand_systems.npz"))
+    def system(i):
+        t, y, u = g[f"s{i}_train_t"], g[f"s{i}_train_y"], g[f"s{i}_train_u"]
+        n = t.shape[0] // 1001
+        train = [{"t": t[k * 1001:(k + 1) * 1001], "y": y[k * 1001:(k + 1) * 1001], "u": u[k * 1001:(k + 1) * 1001]} for k in range(n)]
+        return {"train": train, "val": [{"t": g[f"s{i}_val_t"], "y": g[f"s{i}_val_y"], "u": g[f"s{i}_val_u"]}]}
+    base = [system(i) for i in range(3)]
+    systems = [base[i % 3] for i in range(n_systems)]
+    sweep.rand_models_sweep_batched(systems[:3], ctx)
+    t0 = time.perf_counter()
+    tab = sweep.rand_models_sweep_batched(systems, ctx)
+    dt = time.perf_counter() - t0
+    return {"systems": n_systems, "seconds": dt, "systems_per_s": n_systems / dt, "fits_per_system": int(sum(len(v) for v in tab.values())),
+            "workload": "evaluate_rand_models.m: 23 fits + validation rollouts per 1-D random system (BASELINE configs[4] shape, one GPU's share)"}
+
+
 def cpu_baseline_mpc(pack):
     """The oracle's literal Kmpc step (Bhat from dense matrix powers, 4 rebuilds folded into one,
     exact active-set QP) on the host, on a bounded sample of the same problems."""
@@ -163,6 +200,7 @@ def main():
     ap.add_argument("--degree", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mpc", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the lasso-grid and random-sweep sections")
     ap.add_argument("--mpc-steps", type=int, default=300)
     ap.add_argument("--mpc-batch", type=int, default=4096)
     args = ap.parse_args()
@@ -205,7 +243,8 @@ def main():
     for _ in range(args.steps):
         kra.fit(ctx, basis, snaps, fetch=False)     # enqueue: Gram on stream 1, solve on stream 2
     ctx.synchronize()                               # all K fits complete (HIP events of the last step are read after this)
-    t_gram.append(ctx.timer(0)); t_red.append(ctx.timer(6)); t_solve.append(ctx.timer(1))
+    # timer 0 = mean HIP-event duration of the last min(steps, 64) Gram launches of this timed region (timer 7 = count)
+    t_gram.append(ctx.timer(0)); t_red.append(ctx.timer(6)); t_solve.append(ctx.timer(1)); n_timed = int(ctx.timer(7))
     if dist is not None:
         import torch
         K = np.zeros((W, W), order="F")
@@ -232,6 +271,9 @@ def main():
     mpc_res = None
     if rank == 0 and not args.no_mpc and world == 1:     # secondary sections only in the single-GPU run
         mpc_res = bench_mpc(ctx, kra, basis, snaps, args)
+    extras = None
+    if rank == 0 and not args.no_extras and world == 1 and args.degree == 3:
+        extras = {"lasso_grid": bench_lasso(ctx, kra, basis, snaps), "rand_sweep": bench_rand_sweep(ctx, kra)}
 
     if rank == 0:
         flops_pair = W * (W + 1) + 2.0 * W * W                 # F(336) = 339 024
@@ -261,7 +303,7 @@ def main():
                                    f"N={basis.N}, W={W} (BASELINE configs[1])",
                        "snapshots_per_gpu": Ns, "W": W, "parallelism": f"{world} independent fits + final all_gather"},
             "fit_latency_ms": fit_latency_ms,
-            "kernel_ms": {"gram": g_ms, "gram_reduce": float(np.mean(t_red)), "solve": float(np.mean(t_solve))},
+            "kernel_ms": {"gram": g_ms, "gram_launches_averaged": n_timed, "gram_reduce": float(np.mean(t_red)), "solve": float(np.mean(t_solve))},
             "roofline": {"bound": "mfma", "kernel": "kp_gram3_kernel<6,3>", "achieved": achieved, "peak": PEAK_F64_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_F64_MFMA_TFLOPS, "traffic": traffic,
                          "algorithmic_flop_per_launch": flops_pair * Ns, "algorithmic_bytes_per_launch": 120.0 * Ns,
@@ -272,6 +314,8 @@ def main():
         }
         if mpc_res is not None:
             res["mpc"] = mpc_res
+        if extras is not None:
+            res.update(extras)
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(min(Ns, 20000), args.degree)
             if mpc_res is not None:

@@ -45,7 +45,9 @@ const char* kp_last_error(const kp_ctx* ctx);   /* ctx may be NULL: last global 
 /* name (<=255 chars), number of CUs, total HBM bytes of the bound device */
 int kp_device_info(const kp_ctx* ctx, char* name, int name_len, int* num_cu, int64_t* hbm_bytes);
 /* milliseconds spent in the device part of the most recent call of each kind
- * (HIP events on the library stream): which = 0 fused lift+Gram kernel, 1 solve, 2 mpc step, 3 lasso, 4 lift, 5 rollout, 6 Gram partial reduction */
+ * (HIP events on the library stream): which = 0 fused lift+Gram kernel, 1 solve, 2 mpc step, 3 lasso, 4 lift, 5 rollout, 6 Gram partial reduction.
+ * After a run of pipelined fits (kp_fit with K_out == NULL) timer 0 is the MEAN duration of the last (up to 64) Gram
+ * launches and which = 7 the number of launches in that mean. */
 int kp_timer_get(const kp_ctx* ctx, int which, double* ms);
 /* Device pointer + byte size of the library stream's raw handle, for profilers/benchmarks
  * that want to bracket work with their own HIP events: returns hipStream_t as void*. */

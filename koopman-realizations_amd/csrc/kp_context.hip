@@ -51,6 +51,7 @@ extern "C" int kp_create(int device_id, kp_ctx** out) {
     return KP_ERR_HIP;
   }
   for (int i = 0; i < 6; ++i) (void)hipEventCreateWithFlags(&c->evp[i], evf);
+  for (int i = 0; i < 2 * 64; ++i) (void)hipEventCreateWithFlags(&c->ring[i], evf);
   (void)hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
   (void)hipEventCreateWithFlags(&c->ev_gram_done, hipEventDisableTiming | evf);
   (void)hipEventCreateWithFlags(&c->ev_pad_done, hipEventDisableTiming | evf);
@@ -88,6 +89,8 @@ extern "C" int kp_destroy(kp_ctx* c) {
   if (c->GC) (void)hipFree(c->GC);
   for (int i = 0; i < 6; ++i)
     if (c->evp[i]) (void)hipEventDestroy(c->evp[i]);
+  for (int i = 0; i < 2 * 64; ++i)
+    if (c->ring[i]) (void)hipEventDestroy(c->ring[i]);
   (void)hipEventDestroy(c->ev0);
   (void)hipEventDestroy(c->ev1);
   (void)hipStreamDestroy(c->stream);

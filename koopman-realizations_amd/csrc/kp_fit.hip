@@ -419,7 +419,23 @@ static int read_chol_info(kp_ctx* ctx, int W, int ncols, int* bad) {
 // timers: 0 = fused lift+Gram kernel, 6 = partial-tile reduction, 1 = solve (when run)
 static void collect_gram_timers(kp_ctx* ctx, bool solved) {
   float ms = 0;
-  if (hipEventElapsedTime(&ms, ctx->evp[0], ctx->evp[1]) == hipSuccess) ctx->timers[0] = ms;
+  if (ctx->ring_n > 0) {                          // pipelined fits: mean over the last ring_n Gram launches
+    double sum = 0.0;
+    int cnt = 0;
+    for (int i = 0; i < ctx->ring_n; ++i) {
+      const int p = (ctx->ring_pos - 1 - i + 2 * 64) % 64;
+      if (hipEventElapsedTime(&ms, ctx->ring[2 * p], ctx->ring[2 * p + 1]) == hipSuccess) {
+        sum += ms;
+        ++cnt;
+      }
+    }
+    if (cnt) ctx->timers[0] = (float)(sum / cnt);
+    ctx->timers[7] = (float)cnt;
+    ctx->ring_n = 0;
+  } else if (hipEventElapsedTime(&ms, ctx->evp[0], ctx->evp[1]) == hipSuccess) {
+    ctx->timers[0] = ms;
+    ctx->timers[7] = 1.0f;
+  }
   if (hipEventElapsedTime(&ms, ctx->evp[ctx->reduce_timed_from], ctx->evp[2]) == hipSuccess) ctx->timers[6] = ms;
   if (solved && hipEventElapsedTime(&ms, ctx->evp[2], ctx->evp[3]) == hipSuccess) ctx->timers[1] = ms;
 }

@@ -531,7 +531,14 @@ int kp_gram3_launch(kp_ctx* ctx, const kp_basis* basis_c, const kp_snapshots* s,
   // every event record is a barrier packet the command processor works through between two Gram kernels: the
   // pipelined path keeps two (kernel start / end; the end also releases the reduction on the solve stream)
   if (!ctx->reduce_stream) KP_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-  KP_HIP(ctx, hipEventRecord(ctx->evp[0], ctx->stream));
+  hipEvent_t ev_start = ctx->evp[0], ev_end = ctx->evp[1];
+  if (ctx->reduce_stream) {                       // pipelined fits: a ring of event pairs, averaged at kp_synchronize
+    ev_start = ctx->ring[2 * ctx->ring_pos];
+    ev_end = ctx->ring[2 * ctx->ring_pos + 1];
+    ctx->ring_pos = (ctx->ring_pos + 1) % 64;
+    if (ctx->ring_n < 64) ++ctx->ring_n;
+  }
+  KP_HIP(ctx, hipEventRecord(ev_start, ctx->stream));
   hipError_t e;
   switch (plan.nq) {
     case 1: e = launch3<1>(a, BM, grid, lds, ctx->stream); break;
@@ -542,11 +549,11 @@ int kp_gram3_launch(kp_ctx* ctx, const kp_basis* basis_c, const kp_snapshots* s,
     default: e = launch3<6>(a, BM, grid, lds, ctx->stream); break;
   }
   KP_HIP(ctx, e);
-  KP_HIP(ctx, hipEventRecord(ctx->evp[1], ctx->stream));
+  KP_HIP(ctx, hipEventRecord(ev_end, ctx->stream));
   hipStream_t rs = ctx->stream;
   if (ctx->reduce_stream) {                       // reduction (and everything after it) belongs to the solve stream
     rs = ctx->reduce_stream;
-    KP_HIP(ctx, hipStreamWaitEvent(rs, ctx->evp[1], 0));
+    KP_HIP(ctx, hipStreamWaitEvent(rs, ev_end, 0));
     KP_HIP(ctx, hipEventRecord(ctx->evp[4], rs));   // start of the reduction on its own stream (timer 6)
     ctx->solve_chained = true;                      // the solve stream already waits for this Gram kernel
   }

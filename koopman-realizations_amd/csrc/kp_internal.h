@@ -25,6 +25,10 @@ struct kp_ctx {
   // (after an event recorded behind the main Gram kernel) and the partial buffer `part_flip` is used
   hipStream_t reduce_stream = nullptr;
   hipEvent_t ev_main_done = nullptr;
+  // start / end events of the most recent pipelined Gram launches (ring of KP_RING pairs): kp_synchronize reports the
+  // MEAN kernel duration over them (timer 0), not just the last launch
+  hipEvent_t ring[2 * 64] = {};
+  int ring_pos = 0, ring_n = 0;
   bool solve_chained = false;   // set by a Gram launch that already made the solve stream wait for it
   int part_flip = 0;
   int reduce_timed_from = 1;   // evp index that marks the start of the last partial reduction
