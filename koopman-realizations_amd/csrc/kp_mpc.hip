@@ -72,46 +72,30 @@ __device__ __forceinline__ double wave_sum(double v) {
   v += dpp_mov<0x140>(v);                 // every lane: sum of its 16-lane row
   return (lane_get(v, 0) + lane_get(v, 16)) + (lane_get(v, 32) + lane_get(v, 48));
 }
-#define KP_ARGSTEP(CTRL, CMP)                                   \
-  {                                                             \
-    double ov = dpp_mov<CTRL>(v);                               \
-    int oi = dpp_movi<CTRL>(idx);                               \
-    if (ov CMP v || (ov == v && oi < idx)) {                    \
-      v = ov;                                                   \
-      idx = oi;                                                 \
-    }                                                           \
-  }
+// arg max / arg min over the wave: the extreme VALUE by a DPP reduction (2 moves + 1 v_max per step), then the first lane
+// that holds it (ballot + s_ff1) hands over its index.  (Carrying (value, index) pairs through the reduction took ~12
+// dependent VALU instructions per step, ~600 cycles per call; this is ~220.)  Ties go to the lowest lane.
 __device__ __forceinline__ void wave_argmax(double& v, int& idx) {
-  KP_ARGSTEP(0xB1, >) KP_ARGSTEP(0x4E, >) KP_ARGSTEP(0x141, >) KP_ARGSTEP(0x140, >)
-  double bv = lane_get(v, 0);
-  int bi = __builtin_amdgcn_readlane(idx, 0);
-#pragma unroll
-  for (int r = 16; r < 64; r += 16) {
-    double ov = lane_get(v, r);
-    int oi = __builtin_amdgcn_readlane(idx, r);
-    if (ov > bv || (ov == bv && oi < bi)) {
-      bv = ov;
-      bi = oi;
-    }
-  }
-  v = bv;
-  idx = bi;
+  double m = v;
+  m = fmax(m, dpp_mov<0xB1>(m));
+  m = fmax(m, dpp_mov<0x4E>(m));
+  m = fmax(m, dpp_mov<0x141>(m));
+  m = fmax(m, dpp_mov<0x140>(m));
+  const double w = fmax(fmax(lane_get(m, 0), lane_get(m, 16)), fmax(lane_get(m, 32), lane_get(m, 48)));
+  const unsigned long long mask = __ballot(v == w);
+  idx = mask ? __builtin_amdgcn_readlane(idx, __ffsll((long long)mask) - 1) : 0x7fffffff;
+  v = w;
 }
 __device__ __forceinline__ void wave_argmin(double& v, int& idx) {
-  KP_ARGSTEP(0xB1, <) KP_ARGSTEP(0x4E, <) KP_ARGSTEP(0x141, <) KP_ARGSTEP(0x140, <)
-  double bv = lane_get(v, 0);
-  int bi = __builtin_amdgcn_readlane(idx, 0);
-#pragma unroll
-  for (int r = 16; r < 64; r += 16) {
-    double ov = lane_get(v, r);
-    int oi = __builtin_amdgcn_readlane(idx, r);
-    if (ov < bv || (ov == bv && oi < bi)) {
-      bv = ov;
-      bi = oi;
-    }
-  }
-  v = bv;
-  idx = bi;
+  double m = v;
+  m = fmin(m, dpp_mov<0xB1>(m));
+  m = fmin(m, dpp_mov<0x4E>(m));
+  m = fmin(m, dpp_mov<0x141>(m));
+  m = fmin(m, dpp_mov<0x140>(m));
+  const double w = fmin(fmin(lane_get(m, 0), lane_get(m, 16)), fmin(lane_get(m, 32), lane_get(m, 48)));
+  const unsigned long long mask = __ballot(v == w);
+  idx = mask ? __builtin_amdgcn_readlane(idx, __ffsll((long long)mask) - 1) : 0x7fffffff;
+  v = w;
 }
 
 // Constraint matrix in ELL form: row r has K slots (val[k*mr + r], col[k*mr + r]); unused slots
@@ -182,7 +166,11 @@ __device__ __forceinline__ int qp_goldfarb_idnani(const double* Hq, const double
   const double* bv_ = bvec;
   if (ell_lds) {
     for (int e = lane; e < mr * A.K; e += 64) { lval[e] = A.val[e]; lcol[e] = A.col[e]; }
-    for (int e = lane; e < mr; e += 64) { lnorm[e] = A.norm[e]; lb[e] = bvec[e]; }
+    for (int e = lane; e < mr; e += 64) {          // the LDS copy holds 1 / norm (0 for a null row): no division in the scan
+      const double nr_ = A.norm[e];
+      lnorm[e] = nr_ == 0.0 ? 0.0 : 1.0 / nr_;
+      lb[e] = bvec[e];
+    }
     Aval = lval; Acol = lcol; Anorm = lnorm; bv_ = lb;
   }
 
@@ -268,7 +256,18 @@ __device__ __forceinline__ int qp_goldfarb_idnani(const double* Hq, const double
     const double isl = 1.0 / Sinv[last + last * n];
     if (lane < last) {
       const double ri = Sinv[lane + last * n] * isl;
-      for (int j = 0; j < last; ++j) Sinv[lane + j * n] -= ri * Sinv[last + j * n];
+      // four columns at a time, every read before the first write: the compiler cannot tell the read-modify-write of
+      // column j from the reads of column j + 1 (same LDS array) and would otherwise pay one LDS round trip per column
+      int j = 0;
+      for (; j + 4 <= last; j += 4) {
+        const double a0 = Sinv[lane + j * n], a1 = Sinv[lane + (j + 1) * n], a2 = Sinv[lane + (j + 2) * n], a3 = Sinv[lane + (j + 3) * n];
+        const double r0 = Sinv[last + j * n], r1 = Sinv[last + (j + 1) * n], r2 = Sinv[last + (j + 2) * n], r3 = Sinv[last + (j + 3) * n];
+        Sinv[lane + j * n] = a0 - ri * r0;
+        Sinv[lane + (j + 1) * n] = a1 - ri * r1;
+        Sinv[lane + (j + 2) * n] = a2 - ri * r2;
+        Sinv[lane + (j + 3) * n] = a3 - ri * r3;
+      }
+      for (; j < last; ++j) Sinv[lane + j * n] -= ri * Sinv[last + j * n];
     }
     if (lane == 0) isact[act[last]] = 0;
     --q;
@@ -315,19 +314,20 @@ __device__ __forceinline__ int qp_goldfarb_idnani(const double* Hq, const double
     double best = -1e300;
     int bestp = 0x7fffffff;
     int infeas = 0;
+    // branch-free: every LDS read of a row is issued unconditionally (a `continue` or a guarded isact read makes the
+    // compiler wait for each read in turn), the row is then taken or not by selects
     for (int row = lane; row < mr; row += 64) {
       double v = -bv_[row];
-      for (int k = 0; k < A.K; ++k) v += Aval[k * mr + row] * x[Acol[k * mr + row]];
       const double nr = Anorm[row];
-      if (nr == 0.0) {
-        if (v > tol) infeas = 1;
-        continue;
-      }
-      const double vs = v / nr;
-      if (!isact[row] && vs > best) {
-        best = vs;
-        bestp = row;
-      }
+      const int active = isact[row];
+      for (int k = 0; k < A.K; ++k) v += Aval[k * mr + row] * x[Acol[k * mr + row]];
+      const double inr = ell_lds ? nr : (nr == 0.0 ? 0.0 : 1.0 / nr);
+      const bool null_row = inr == 0.0;
+      const double vs = v * inr;
+      infeas |= (null_row && v > tol) ? 1 : 0;
+      const bool take = !null_row && !active && vs > best;
+      best = take ? vs : best;
+      bestp = take ? row : bestp;
     }
     wave_argmax(best, bestp);
     QP_TICK(0);
@@ -427,7 +427,16 @@ __device__ __forceinline__ int qp_goldfarb_idnani(const double* Hq, const double
         const double ib = 1.0 / apz;
         if (lane < q) {                         // lane i owns row i (q <= n <= 64): no index arithmetic
           const double ri = r[lane] * ib;
-          for (int j = 0; j < q; ++j) Sinv[lane + j * n] += ri * r[j];
+          int j = 0;
+          for (; j + 4 <= q; j += 4) {           // reads before writes, as in drop_active
+            const double a0 = Sinv[lane + j * n], a1 = Sinv[lane + (j + 1) * n], a2 = Sinv[lane + (j + 2) * n], a3 = Sinv[lane + (j + 3) * n];
+            const double r0 = r[j], r1 = r[j + 1], r2 = r[j + 2], r3 = r[j + 3];
+            Sinv[lane + j * n] = a0 + ri * r0;
+            Sinv[lane + (j + 1) * n] = a1 + ri * r1;
+            Sinv[lane + (j + 2) * n] = a2 + ri * r2;
+            Sinv[lane + (j + 3) * n] = a3 + ri * r3;
+          }
+          for (; j < q; ++j) Sinv[lane + j * n] += ri * r[j];
         }
         for (int c = lane; c < q; c += 64) {
           Sinv[c + q * n] = -r[c] * ib;
