@@ -314,20 +314,32 @@ __device__ __forceinline__ int qp_goldfarb_idnani(const double* Hq, const double
     double best = -1e300;
     int bestp = 0x7fffffff;
     int infeas = 0;
-    // branch-free: every LDS read of a row is issued unconditionally (a `continue` or a guarded isact read makes the
-    // compiler wait for each read in turn), the row is then taken or not by selects
-    for (int row = lane; row < mr; row += 64) {
-      double v = -bv_[row];
-      const double nr = Anorm[row];
-      const int active = isact[row];
-      for (int k = 0; k < A.K; ++k) v += Aval[k * mr + row] * x[Acol[k * mr + row]];
-      const double inr = ell_lds ? nr : (nr == 0.0 ? 0.0 : 1.0 / nr);
-      const bool null_row = inr == 0.0;
-      const double vs = v * inr;
-      infeas |= (null_row && v > tol) ? 1 : 0;
-      const bool take = !null_row && !active && vs > best;
-      best = take ? vs : best;
-      bestp = take ? row : bestp;
+    // branch-free, two rows per lane at a time: every LDS read of both rows is issued unconditionally and before any
+    // arithmetic (a `continue` or a guarded isact read makes the compiler wait for each read in turn; one row after the
+    // other doubles the col -> x[col] dependent chain), the rows are then taken or not by selects
+    for (int row0 = lane; row0 < mr; row0 += 128) {
+      const int rowA = row0, rowB = row0 + 64;
+      const bool inB = rowB < mr;
+      const int rB = inB ? rowB : rowA;
+      double vA = -bv_[rowA], vB = -bv_[rB];
+      const double nA = Anorm[rowA], nB = Anorm[rB];
+      const int actA = isact[rowA], actB = isact[rB];
+      for (int k = 0; k < A.K; ++k) {
+        const int cA = Acol[k * mr + rowA], cB = Acol[k * mr + rB];
+        const double aA = Aval[k * mr + rowA], aB = Aval[k * mr + rB];
+        vA += aA * x[cA];
+        vB += aB * x[cB];
+      }
+      const double iA = ell_lds ? nA : (nA == 0.0 ? 0.0 : 1.0 / nA);
+      const double iB = ell_lds ? nB : (nB == 0.0 ? 0.0 : 1.0 / nB);
+      const double sA = vA * iA, sB = vB * iB;
+      infeas |= ((iA == 0.0 && vA > tol) || (inB && iB == 0.0 && vB > tol)) ? 1 : 0;
+      const bool takeA = iA != 0.0 && !actA && sA > best;
+      best = takeA ? sA : best;
+      bestp = takeA ? rowA : bestp;
+      const bool takeB = inB && iB != 0.0 && !actB && sB > best;
+      best = takeB ? sB : best;
+      bestp = takeB ? rowB : bestp;
     }
     wave_argmax(best, bestp);
     QP_TICK(0);
