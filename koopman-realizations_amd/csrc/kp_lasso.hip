@@ -173,6 +173,9 @@ __device__ __forceinline__ bool last_block(LassoState* st) {
     is_last = atomicAdd(&st->counter, 1u) == gridDim.x - 1;
   }
   __syncthreads();
+  // the partials of the other workgroups were released (agent scope) before their ticket; acquire before reading them
+  // (the reads below are also volatile = cache-bypassing; per-XCD L2s and per-CU L1s are not coherent on their own)
+  if (is_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   return is_last != 0;
 }
 
