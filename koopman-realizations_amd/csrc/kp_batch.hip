@@ -3,7 +3,10 @@
 // 1-D state, W <= 16): the per-system work (lift of ~1e4 snapshot pairs, Px'Px, Px'Py, the least-squares
 // solve) is far too small for a launch sequence of its own, so one launch does all systems.
 //   lift            generic column evaluation (any dictionary without dimension reduction), 64 snapshots per tile in LDS
-//   Px'Px, Px'Py    thread (i, j) owns G[i][j] and C[i][j]: 2 FMAs per snapshot from LDS
+//   Px'Px, Px'Py    register-blocked: a lane owns one 4 x 4 block of G and of C for 4 of the 64 snapshots of a tile
+//                   (16 blocks x 16 snapshot groups = 256 threads): three 4-wide LDS reads per 32 FMAs.  (One output
+//                   element per thread needed 3 LDS reads per 2 FMAs and was LDS-bound: 0.78 ms per 1024 systems.)
+//                   The 16 groups are summed in a fixed order at the end (deterministic).
 //   G K = C         Cholesky of the 16 x 16 block in registers (one wave, pivots by v_readlane, as kp_chol_kernel's
 //                   diagonal block), then forward / backward substitution, one thread per right-hand side
 // Replaces, for each system: Ksysid.get_Koopman (Ksysid.m:987-1092) with lasso = Inf.
@@ -11,7 +14,7 @@
 
 #define SB_TS 64      // snapshots per tile
 #define SB_W 16       // maximum Px width
-#define SB_LD 17
+#define SB_LD 18      // row stride of the tiles (even: 16-byte aligned rows for the 4-wide operand reads)
 
 __device__ __forceinline__ double sb_bcast(double v, int lane) {
   int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
@@ -22,7 +25,7 @@ __device__ __forceinline__ double sb_bcast(double v, int lane) {
 __global__ __launch_bounds__(256) void kp_small_fit_kernel(BasisDev b, const double* __restrict__ alpha, const double* __restrict__ beta,
                                                            const double* __restrict__ u, int64_t Ns_total, int Ns, double* __restrict__ Kout,
                                                            double* __restrict__ Gout, double* __restrict__ Cout, int* __restrict__ status) {
-  extern __shared__ double sm[];
+  extern __shared__ __align__(16) double sm[];
   // LDS: vx[nvars][TS] | vy[nvars][TS] | um[m][TS] | Px[TS][LD] | Py[TS][LD] | Gs[16][LD] | Cs[16][LD] | Ls[16][LD] | Dd[16]
   const int nv = b.nvars, m = b.m, N = b.N, W = b.W;
   double* vx = sm;
@@ -41,7 +44,13 @@ __global__ __launch_bounds__(256) void kp_small_fit_kernel(BasisDev b, const dou
   if (tid == 0) bad = 0;
   for (int e = tid; e < 2 * SB_TS * SB_LD; e += 256) Px[e] = 0.0;      // Px and Py (contiguous): unused columns stay zero
   const int gi = tid >> 4, gj = tid & 15;
-  double g = 0.0, c = 0.0;
+  const int blk = tid & 15, grp = tid >> 4;          // 4 x 4 output block, snapshot group (4 consecutive snapshots of a tile)
+  const int bi = (blk >> 2) * 4, bj = (blk & 3) * 4;
+  double g[4][4], c[4][4];
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int y = 0; y < 4; ++y) g[x][y] = c[x][y] = 0.0;
   __syncthreads();
   for (int r0 = 0; r0 < Ns; r0 += SB_TS) {
     const int nl = min(SB_TS, Ns - r0);
@@ -73,20 +82,50 @@ __global__ __launch_bounds__(256) void kp_small_fit_kernel(BasisDev b, const dou
         ((side ? Py : Px) + p * SB_LD)[N + i] = um[i * SB_TS + p];       // zero past the tail (um is)
       }
     __syncthreads();
-#pragma unroll 8
-    for (int p = 0; p < SB_TS; ++p) {
-      const double xi = Px[p * SB_LD + gi];
-      g += xi * Px[p * SB_LD + gj];
-      c += xi * Py[p * SB_LD + gj];
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) {
+      const double* xr = Px + (grp * 4 + s_) * SB_LD;
+      const double* yr = Py + (grp * 4 + s_) * SB_LD;
+      const double2 xa = *reinterpret_cast<const double2*>(xr + bi), xb = *reinterpret_cast<const double2*>(xr + bi + 2);
+      const double2 ja = *reinterpret_cast<const double2*>(xr + bj), jb = *reinterpret_cast<const double2*>(xr + bj + 2);
+      const double2 ya = *reinterpret_cast<const double2*>(yr + bj), yb = *reinterpret_cast<const double2*>(yr + bj + 2);
+      const double xi[4] = {xa.x, xa.y, xb.x, xb.y}, xj[4] = {ja.x, ja.y, jb.x, jb.y}, yj[4] = {ya.x, ya.y, yb.x, yb.y};
+#pragma unroll
+      for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+          g[x][y] += xi[x] * xj[y];
+          c[x][y] += xi[x] * yj[y];
+        }
     }
     __syncthreads();
   }
+  // sum of the 16 snapshot groups in a fixed order
+  Gs[gi * SB_LD + gj] = 0.0;
+  Cs[gi * SB_LD + gj] = 0.0;
+  for (int t = 0; t < 16; ++t) {
+    __syncthreads();
+    if (grp == t) {
+#pragma unroll
+      for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+          Gs[(bi + x) * SB_LD + bj + y] += g[x][y];
+          Cs[(bi + x) * SB_LD + bj + y] += c[x][y];
+        }
+    }
+  }
+  __syncthreads();
   // G (identity on the padding so that the 16 x 16 factorisation is well defined) and C
-  Gs[gi * SB_LD + gj] = (gi < W && gj < W) ? g : (gi == gj ? 1.0 : 0.0);
-  Cs[gi * SB_LD + gj] = (gi < W && gj < W) ? c : 0.0;
-  if (gi < W && gj < W) {
-    if (Gout) Gout[(size_t)sys * W * W + (size_t)gj * W + gi] = g;
-    if (Cout) Cout[(size_t)sys * W * W + (size_t)gj * W + gi] = c;
+  {
+    const double gv = Gs[gi * SB_LD + gj], cv = Cs[gi * SB_LD + gj];
+    if (gi < W && gj < W) {
+      if (Gout) Gout[(size_t)sys * W * W + (size_t)gj * W + gi] = gv;
+      if (Cout) Cout[(size_t)sys * W * W + (size_t)gj * W + gi] = cv;
+    } else {
+      Gs[gi * SB_LD + gj] = gi == gj ? 1.0 : 0.0;
+      Cs[gi * SB_LD + gj] = 0.0;
+    }
   }
   __syncthreads();
   // Cholesky in registers: lane r (< 16) of wave 0 owns row r
