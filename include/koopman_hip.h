@@ -163,6 +163,13 @@ int kp_fit_batch(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* snaps, 
 int kp_model_project(kp_ctx* ctx, const double* K, const double* G, const double* C, int N, int m,
                      double* A_out, double* B_out, double* M_out);
 
+/* kp_model_project for nb small linear models at once (W = N + m <= 16; evaluate_rand_models.m fits one per system,
+ * :49-59 -> get_model, Ksysid.m:1206-1225): K, G, C are nb blocks W x W, column-major, back to back (as kp_fit_batch
+ * returns them); A_out nb x (N x N), B_out nb x (N x m), M_out nb x (N x N) or NULL.  One workgroup per model;
+ * status_out[s] != 0 (may be NULL) marks a singular L'L (A, B = NaN). */
+int kp_model_project_batch(kp_ctx* ctx, const double* K, const double* G, const double* C, int nb, int N, int m,
+                           double* A_out, double* B_out, double* M_out, int* status_out);
+
 /* ---- validation rollouts ------------------------------------------------------------
  * val_model (Ksysid.m:1678-1689) z+ = A z + B u ; val_BLmodel (:1772-1787)
  * z+ = A z + B kron(I_m,z) u.  z0: N, U: T x m (rows = steps), Y: T x n_out with

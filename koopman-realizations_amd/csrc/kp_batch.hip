@@ -7,8 +7,8 @@
 //                   (16 blocks x 16 snapshot groups = 256 threads): three 4-wide LDS reads per 32 FMAs.  (One output
 //                   element per thread needed 3 LDS reads per 2 FMAs and was LDS-bound: 0.78 ms per 1024 systems.)
 //                   The 16 groups are summed in a fixed order at the end (deterministic).
-//   G K = C         Cholesky of the 16 x 16 block in registers (one wave, pivots by v_readlane, as kp_chol_kernel's
-//                   diagonal block), then forward / backward substitution, one thread per right-hand side
+//   G K = C         sb_spd_solve16: Cholesky of the 16 x 16 block in registers (one wave, pivots by v_readlane, as
+//                   kp_chol_kernel's diagonal block), then forward / backward substitution, one thread per right-hand side
 // Replaces, for each system: Ksysid.get_Koopman (Ksysid.m:987-1092) with lasso = Inf.
 #include "kp_internal.h"
 
@@ -20,6 +20,63 @@ __device__ __forceinline__ double sb_bcast(double v, int lane) {
   int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
   int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
   return __hiloint2double(hi, lo);
+}
+
+// Solves G X = C for the 16 x 16 SPD matrix Gs (identity on the padding) and 16 right-hand sides Cs, all in LDS with
+// row stride SB_LD; X -> Xs.  Cholesky in registers: lane r (< 16) of wave 0 owns row r, pivots by v_readlane (as
+// kp_chol_kernel's diagonal block), then forward / backward substitution, one thread per right-hand side.
+// All 256 threads call; *bad is set when a pivot is not positive.
+__device__ __forceinline__ void sb_spd_solve16(const double* Gs, const double* Cs, double* Xs, double* Ls, double* Dd, int* bad) {
+  const int tid = threadIdx.x;
+  if (tid < 64) {
+    const int r = tid & 15;
+    double row[16];
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc) row[cc] = Gs[r * SB_LD + cc];
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc) {
+      double d = sb_bcast(row[cc], cc);
+      if (!(d > 0.0)) {
+        if (tid == 0) *bad = 1;
+        d = 1.0;
+      }
+      double id = __builtin_amdgcn_rsq(d);
+      id = id * (1.5 - 0.5 * d * id * id);
+      id = id * (1.5 - 0.5 * d * id * id);
+      if (tid == cc) Dd[cc] = id;
+      const double l = row[cc] * id;
+      row[cc] = l;
+#pragma unroll
+      for (int c2 = cc + 1; c2 < 16; ++c2) row[c2] -= l * sb_bcast(l, c2);
+    }
+    if (tid < 16) {
+#pragma unroll
+      for (int cc = 0; cc < 16; ++cc) Ls[r * SB_LD + cc] = cc <= r ? row[cc] : 0.0;
+    }
+  }
+  __syncthreads();
+  // L Y = C, L' X = Y: one thread per right-hand side
+  if (tid < 16) {
+    const int j = tid;
+    double y[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      double s = Cs[i * SB_LD + j];
+#pragma unroll
+      for (int q = 0; q < i; ++q) s -= Ls[i * SB_LD + q] * y[q];
+      y[i] = s * Dd[i];
+    }
+#pragma unroll
+    for (int i = 15; i >= 0; --i) {
+      double s = y[i];
+#pragma unroll
+      for (int q = i + 1; q < 16; ++q) s -= Ls[q * SB_LD + i] * y[q];
+      y[i] = s * Dd[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Xs[i * SB_LD + j] = y[i];
+  }
+  __syncthreads();
 }
 
 __global__ __launch_bounds__(256) void kp_small_fit_kernel(BasisDev b, const double* __restrict__ alpha, const double* __restrict__ beta,
@@ -128,58 +185,10 @@ __global__ __launch_bounds__(256) void kp_small_fit_kernel(BasisDev b, const dou
     }
   }
   __syncthreads();
-  // Cholesky in registers: lane r (< 16) of wave 0 owns row r
-  if (tid < 64) {
-    const int r = tid & 15;
-    double row[16];
-#pragma unroll
-    for (int cc = 0; cc < 16; ++cc) row[cc] = Gs[r * SB_LD + cc];
-#pragma unroll
-    for (int cc = 0; cc < 16; ++cc) {
-      double d = sb_bcast(row[cc], cc);
-      if (!(d > 0.0)) {
-        if (tid == 0) bad = 1;
-        d = 1.0;
-      }
-      double id = __builtin_amdgcn_rsq(d);
-      id = id * (1.5 - 0.5 * d * id * id);
-      id = id * (1.5 - 0.5 * d * id * id);
-      if (tid == cc) Dd[cc] = id;
-      const double l = row[cc] * id;
-      row[cc] = l;
-#pragma unroll
-      for (int c2 = cc + 1; c2 < 16; ++c2) row[c2] -= l * sb_bcast(l, c2);
-    }
-    if (tid < 16) {
-#pragma unroll
-      for (int cc = 0; cc < 16; ++cc) Ls[r * SB_LD + cc] = cc <= r ? row[cc] : 0.0;
-    }
-  }
-  __syncthreads();
-  // L Y = C, L' K = Y: one thread per right-hand side
-  if (tid < 16) {
-    const int j = tid;
-    double y[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      double s = Cs[i * SB_LD + j];
-#pragma unroll
-      for (int q = 0; q < i; ++q) s -= Ls[i * SB_LD + q] * y[q];
-      y[i] = s * Dd[i];
-    }
-#pragma unroll
-    for (int i = 15; i >= 0; --i) {
-      double s = y[i];
-#pragma unroll
-      for (int q = i + 1; q < 16; ++q) s -= Ls[q * SB_LD + i] * y[q];
-      y[i] = s * Dd[i];
-    }
-    if (j < W) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i)
-        if (i < W) Kout[(size_t)sys * W * W + (size_t)j * W + i] = bad ? __builtin_nan("") : y[i];
-    }
-  }
+  // G K = C (16 x 16 Cholesky in registers + substitution); K into the (no longer needed) Px tile
+  double* Xs = Px;
+  sb_spd_solve16(Gs, Cs, Xs, Ls, Dd, &bad);
+  if (gi < W && gj < W) Kout[(size_t)sys * W * W + (size_t)gj * W + gi] = bad ? __builtin_nan("") : Xs[gi * SB_LD + gj];
   if (tid == 0 && status) status[sys] = bad;
 }
 
@@ -219,5 +228,83 @@ extern "C" int kp_fit_batch(kp_ctx* ctx, const kp_basis* basis, const kp_snapsho
   float ms = 0;
   (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
   ctx->timers[0] = ms;
+  return KP_OK;
+}
+
+// ---- batched M-projection of get_model (Ksysid.m:1206-1225) for the small linear models of the sweep ---------------
+// Per model, with K1 = K(:, 1:N) (W x N), A0 = K1(1:N, :)', B0 = K1(N+1:W, :)':
+//   L'L = K1' G K1,   L'R = K1' C(:, 1:N),   M' = (L'L) \ (L'R),   A = M A0,  B = M B0.
+// Thread (i, j) of the 16 x 16 grid owns one element of every product; matrices live in LDS with row stride SB_LD.
+__global__ __launch_bounds__(256) void kp_small_project_kernel(const double* __restrict__ K, const double* __restrict__ G,
+                                                               const double* __restrict__ C, int N, int m, double* __restrict__ Aout,
+                                                               double* __restrict__ Bout, double* __restrict__ Mout, int* __restrict__ status) {
+  __shared__ double Ks[16 * SB_LD], Gs[16 * SB_LD], Cs[16 * SB_LD], Ts[16 * SB_LD], LL[16 * SB_LD], LR[16 * SB_LD], Ms[16 * SB_LD], Ls[16 * SB_LD], Dd[16];
+  __shared__ int bad;
+  const int tid = threadIdx.x, i = tid >> 4, j = tid & 15, sys = blockIdx.x, W = N + m;
+  const size_t off = (size_t)sys * W * W;
+  const bool in = i < W && j < W;
+  Ks[i * SB_LD + j] = in ? K[off + (size_t)j * W + i] : 0.0;            // [row][col]
+  Gs[i * SB_LD + j] = in ? G[off + (size_t)j * W + i] : 0.0;
+  Cs[i * SB_LD + j] = in ? C[off + (size_t)j * W + i] : 0.0;
+  if (tid == 0) bad = 0;
+  __syncthreads();
+  double t = 0.0;                                                        // T = G K1  (W x N)
+  if (j < N)
+    for (int w = 0; w < W; ++w) t += Gs[i * SB_LD + w] * Ks[w * SB_LD + j];
+  Ts[i * SB_LD + j] = t;
+  __syncthreads();
+  double ll = 0.0, lr = 0.0;                                             // L'L = K1' T, L'R = K1' C(:, 1:N)  (N x N)
+  if (i < N && j < N)
+    for (int w = 0; w < W; ++w) {
+      ll += Ks[w * SB_LD + i] * Ts[w * SB_LD + j];
+      lr += Ks[w * SB_LD + i] * Cs[w * SB_LD + j];
+    }
+  LL[i * SB_LD + j] = (i < N && j < N) ? ll : (i == j ? 1.0 : 0.0);      // identity on the padding
+  LR[i * SB_LD + j] = (i < N && j < N) ? lr : 0.0;
+  __syncthreads();
+  sb_spd_solve16(LL, LR, Ms, Ls, Dd, &bad);                               // Ms = M' (N x N)
+  const double nanv = __builtin_nan("");
+  double a = 0.0, b = 0.0;                                               // A = M A0: A[i][j] = sum_k M[i][k] K[j][k]; B[i][j] = sum_k M[i][k] K[N + j][k]
+  if (i < N)
+    for (int k = 0; k < N; ++k) {
+      const double mik = Ms[k * SB_LD + i];                              // M[i][k] = M'[k][i]
+      if (j < N) a += mik * Ks[j * SB_LD + k];
+      if (j < m) b += mik * Ks[(N + j) * SB_LD + k];
+    }
+  if (i < N && j < N) {
+    Aout[(size_t)sys * N * N + (size_t)j * N + i] = bad ? nanv : a;
+    if (Mout) Mout[(size_t)sys * N * N + (size_t)j * N + i] = bad ? nanv : Ms[j * SB_LD + i];
+  }
+  if (i < N && j < m) Bout[(size_t)sys * N * m + (size_t)j * N + i] = bad ? nanv : b;
+  if (tid == 0 && status) status[sys] = bad;
+}
+
+extern "C" int kp_model_project_batch(kp_ctx* ctx, const double* K, const double* G, const double* C, int nb, int N, int m, double* A_out,
+                                      double* B_out, double* M_out, int* status_out) {
+  if (!ctx || !K || !G || !C || !A_out || !B_out || nb < 1 || N < 1 || m < 0 || N + m > SB_W)
+    return ctx ? ctx->fail(KP_ERR_ARG, "kp_model_project_batch: bad argument (needs N + m <= 16)") : KP_ERR_ARG;
+  KP_HIP(ctx, hipSetDevice(ctx->device));
+  if (ctx->async_pending) {
+    int rc0 = kp_synchronize(ctx);
+    if (rc0) return rc0;
+  }
+  const int W = N + m;
+  const size_t bW = (size_t)nb * W * W * 8, bA = (size_t)nb * N * N * 8, bB = (size_t)nb * N * (m > 0 ? m : 1) * 8;
+  char* ws = (char*)ctx->workspace(6, 3 * bW + 2 * bA + bB + (size_t)nb * 4 + 64);
+  if (!ws) return ctx->fail(KP_ERR_HIP, "kp_model_project_batch: out of device memory");
+  double *dK = (double*)ws, *dG = (double*)(ws + bW), *dC = (double*)(ws + 2 * bW);
+  double *dA = (double*)(ws + 3 * bW), *dM = (double*)(ws + 3 * bW + bA), *dB = (double*)(ws + 3 * bW + 2 * bA);
+  int* dS = (int*)(ws + 3 * bW + 2 * bA + bB);
+  hipStream_t s = ctx->stream;
+  KP_HIP(ctx, hipMemcpyAsync(dK, K, bW, hipMemcpyHostToDevice, s));
+  KP_HIP(ctx, hipMemcpyAsync(dG, G, bW, hipMemcpyHostToDevice, s));
+  KP_HIP(ctx, hipMemcpyAsync(dC, C, bW, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(kp_small_project_kernel, dim3(nb), dim3(256), 0, s, dK, dG, dC, N, m, dA, dB, M_out ? dM : nullptr, dS);
+  KP_HIP(ctx, hipGetLastError());
+  KP_HIP(ctx, hipMemcpyAsync(A_out, dA, bA, hipMemcpyDeviceToHost, s));
+  if (m > 0) KP_HIP(ctx, hipMemcpyAsync(B_out, dB, (size_t)nb * N * m * 8, hipMemcpyDeviceToHost, s));
+  if (M_out) KP_HIP(ctx, hipMemcpyAsync(M_out, dM, bA, hipMemcpyDeviceToHost, s));
+  if (status_out) KP_HIP(ctx, hipMemcpyAsync(status_out, dS, (size_t)nb * 4, hipMemcpyDeviceToHost, s));
+  KP_HIP(ctx, hipStreamSynchronize(s));
   return KP_OK;
 }

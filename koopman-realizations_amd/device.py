@@ -84,6 +84,17 @@ class Context:
         # the library writes column-major W x W blocks: transpose the last two axes of the C-ordered buffers
         return K.transpose(0, 2, 1), G.transpose(0, 2, 1), Cm.transpose(0, 2, 1), st
 
+    def model_project_batch(self, K, G, Cm, N, m):
+        """get_model's M-projection (Ksysid.m:1206-1225) for nb small linear models on the device: K, G, Cm (nb, W, W)
+        as fit_batch returns them -> A (nb, N, N), B (nb, N, m), status (nb,).  Singular systems give NaN."""
+        nb = K.shape[0]
+        to_cm = lambda X: np.ascontiguousarray(np.transpose(np.asarray(X, dtype=np.float64), (0, 2, 1)))     # per system column-major
+        Kc, Gc, Cc = to_cm(K), to_cm(G), to_cm(Cm)
+        A = np.zeros((nb, N, N)); B = np.zeros((nb, max(m, 1), N)); st = np.zeros(nb, dtype=np.int32)
+        F.check(F.lib().kp_model_project_batch(self._h, F.dptr(Kc), F.dptr(Gc), F.dptr(Cc), nb, N, m, F.dptr(A), F.dptr(B), None,
+                                               st.ctypes.data_as(C.POINTER(C.c_int))), self._h)
+        return A.transpose(0, 2, 1), B[:, :m].transpose(0, 2, 1), st
+
     def rollout_nl_batch(self, basis, Kf, zeta0, U):
         """Batched nonlinear rollouts: Kf (nb, nzeta, N), zeta0 (nb, nzeta), U (nb, T, m) -> Z (nb, T, nzeta)."""
         nb, nz, N = Kf.shape

@@ -123,6 +123,7 @@ class Ksysid:
         self.obs_type = ["poly"]; self.obs_degree = [1]
         self.snapshots = math.inf; self.lasso = 1e6; self.delays = 0
         self.model_type = "linear"; self.loaded = False; self.time_type = "discrete"; self.dim_red = False
+        self._host_only = bool(kwargs.pop("_host_only", False))           # sweeps: scaling / pairs only, no device dictionary
         for k, v in kwargs.items():                                        # parse_args :147-158
             if not hasattr(self, k):
                 raise AttributeError(f"unknown Ksysid property {k}")
@@ -190,6 +191,10 @@ class Ksysid:
                 raise ValueError(f"unknown obs_type {kind!r}")
         self._blocks = blocks
         self._nvars = nv
+        if self._host_only:
+            self.basis_dev = None
+            p["N"] = None
+            return
         self.basis_dev = Basis(self.ctx, self.model_type, p["nzeta"], p["m"], blocks, None)
         p["N"] = self.basis_dev.nfull                                      # :534
         self.basis["blocks"] = blocks

@@ -148,7 +148,7 @@ def rand_models_sweep_batched(systems, ctx, degrees=None):
     nb = len(systems)
     # scaling, snapshot pairs and scaled validation data: once per system (independent of type and degree)
     prep = [Ksysid(d, ctx=ctx, model_type="linear", obs_type=["poly"], obs_degree=[1], snapshots=np.inf, lasso=[np.inf],
-                   delays=0, loaded=False, dim_red=False) for d in systems]
+                   delays=0, loaded=False, dim_red=False, _host_only=True) for d in systems]
     n, m = prep[0].params["n"], prep[0].params["m"]
     Ns = prep[0].snapshotPairs["alpha"].shape[0]
     if any(k.snapshotPairs["alpha"].shape[0] != Ns or k.params["n"] != n or k.params["m"] != m for k in prep):
@@ -180,23 +180,11 @@ def rand_models_sweep_batched(systems, ctx, degrees=None):
                     else:
                         UT = np.transpose(K, (0, 2, 1))
                         A, B = UT[:, :N, :N], UT[:, :N, N:]                 # Ksysid.m:1199-1200 / 1250-1251
-                        if mt == "linear":                                  # M-projection of get_model (:1206-1225) from the Grams
-                            K1 = K[:, :, :N]
-                            LtL = np.einsum("bwi,bwv,bvj->bij", K1, G, K1)
-                            LtR = np.einsum("bwi,bwj->bij", K1, Cm[:, :, :N])
-                            ok = np.isfinite(LtL).all(axis=(1, 2)) & np.isfinite(LtR).all(axis=(1, 2))
-                            Mt = np.full_like(LtL, np.nan)
-                            if ok.any():
-                                try:
-                                    Mt[ok] = np.linalg.solve(LtL[ok], LtR[ok])
-                                except np.linalg.LinAlgError:
-                                    for s_ in np.nonzero(ok)[0]:
-                                        try:
-                                            Mt[s_] = np.linalg.solve(LtL[s_], LtR[s_])
-                                        except np.linalg.LinAlgError:
-                                            pass
-                            M = np.transpose(Mt, (0, 2, 1))
-                            A, B = M @ A, M @ B
+                        if mt == "linear":                                  # M-projection of get_model (:1206-1225) from the Grams, on the device
+                            bad = ~(np.isfinite(K).all(axis=(1, 2)))
+                            A, B, _ = ctx.model_project_batch(np.nan_to_num(K), np.nan_to_num(G), np.nan_to_num(Cm), N, m)
+                            A = np.array(A); B = np.array(B)
+                            A[bad] = np.nan; B[bad] = np.nan
                         z0 = basis.lift(F.LIFT_ECON, zeta0)
                         Y = np.array(ctx.rollout(mt, np.nan_to_num(A), np.nan_to_num(B), z0, ureal, n))
                         Y[~np.isfinite(A).all(axis=(1, 2))] = np.nan

@@ -116,3 +116,28 @@ def test_fit_batch_matches_single_fits(ctx, golden):
             assert np.abs(G[s] - G1).max() <= 1e-12 * np.abs(G1).max() and np.abs(C[s] - C1).max() <= 1e-12 * np.abs(G1).max()
             K1 = ctx.fit_solve(G1, C1)
             assert np.abs(K[s] - K1).max() <= 1e-9 * max(1.0, np.abs(K1).max())
+
+
+def test_model_project_batch_matches_single_and_oracle(ctx):
+    """kp_model_project_batch (M-projection of get_model for many small linear models) against kp_model_project and
+    the oracle's literal get_model (Ksysid.m:1206-1225) on the same snapshot pairs."""
+    from conftest import synth_pairs
+    nb, Ns, n, m = 6, 600, 2, 1
+    parts = [synth_pairs(Ns, n, m, seed=40 + i) for i in range(nb)]
+    alpha = np.vstack([p["alpha"] for p in parts]); beta = np.vstack([p["beta"] for p in parts]); u = np.vstack([p["u"] for p in parts])
+    for deg in (1, 2, 3):
+        basis = kra.Basis(ctx, "linear", n, m, [("poly", kra.poly_exponent_table(n, deg)[n:])], None)
+        N = basis.N
+        snaps = kra.Snapshots(ctx, alpha, beta, u)
+        K, G, C, st = ctx.fit_batch(basis, snaps, nb)
+        assert (st == 0).all()
+        A, B, st2 = ctx.model_project_batch(K, G, C, N, m)
+        assert (st2 == 0).all()
+        dic = ko.build_dictionary("linear", n, m, ["poly"], [deg])
+        for s in range(nb):
+            A1, B1, M1 = ctx.model_project(K[s], G[s], C[s], N, m)
+            assert np.abs(A[s] - A1).max() < 1e-9 and np.abs(B[s] - B1).max() < 1e-9
+            koop = ko.get_koopman(dic, parts[s])
+            om = ko.get_model(dic, koop, n)
+            assert np.abs(A[s] - om["A"]).max() < 1e-7 * max(1.0, np.abs(om["A"]).max())
+            assert np.abs(B[s] - om["B"]).max() < 1e-7 * max(1.0, np.abs(om["B"]).max())
