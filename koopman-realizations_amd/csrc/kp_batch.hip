@@ -79,9 +79,14 @@ __device__ __forceinline__ void sb_spd_solve16(const double* Gs, const double* C
   __syncthreads();
 }
 
+// recipes != nullptr (monomial dictionaries): column c is the product of <= nfmax entries of a per-snapshot power table
+// x_v^e (recipe byte = v * D + e - 1, 0xff = unused; the table kp_basis_create builds for the fused Gram kernels), so a
+// lift entry costs <= nfmax LDS reads and multiplies instead of the generic evaluation (exponent rows from global
+// memory, up to 13 multiplies per column for the degree-13 dictionaries of the sweep).
 __global__ __launch_bounds__(256) void kp_small_fit_kernel(BasisDev b, const double* __restrict__ alpha, const double* __restrict__ beta,
                                                            const double* __restrict__ u, int64_t Ns_total, int Ns, double* __restrict__ Kout,
-                                                           double* __restrict__ Gout, double* __restrict__ Cout, int* __restrict__ status) {
+                                                           double* __restrict__ Gout, double* __restrict__ Cout, int* __restrict__ status,
+                                                           const uint32_t* __restrict__ recipes, int D, int nfmax) {
   extern __shared__ __align__(16) double sm[];
   // LDS: vx[nvars][TS] | vy[nvars][TS] | um[m][TS] | Px[TS][LD] | Py[TS][LD] | Gs[16][LD] | Cs[16][LD] | Ls[16][LD] | Dd[16]
   const int nv = b.nvars, m = b.m, N = b.N, W = b.W;
@@ -94,7 +99,10 @@ __global__ __launch_bounds__(256) void kp_small_fit_kernel(BasisDev b, const dou
   double* Cs = Gs + 16 * SB_LD;
   double* Ls = Cs + 16 * SB_LD;
   double* Dd = Ls + 16 * SB_LD;
+  double* pw = Dd + 16;                             // [side][v * D + e - 1][snapshot]  (only with recipes)
   __shared__ int bad;
+  __shared__ uint32_t recs[SB_W];
+  if (recipes && threadIdx.x < N) recs[threadIdx.x] = recipes[threadIdx.x];
   const int tid = threadIdx.x;
   const int sys = blockIdx.x;
   const int64_t base = (int64_t)sys * Ns;           // first row of this system inside the merged arrays
@@ -124,10 +132,33 @@ __global__ __launch_bounds__(256) void kp_small_fit_kernel(BasisDev b, const dou
       sm[e] = x;                                     // vx | vy | um are contiguous in this order
     }
     __syncthreads();
+    if (recipes) {                                   // power table of both sides
+      for (int e = tid; e < 2 * nv * SB_TS; e += 256) {
+        const int p = e % SB_TS, sv = e / SB_TS;     // sv = side * nv + v; vx | vy are contiguous
+        const double x = sm[sv * SB_TS + p];
+        double q = x;
+        for (int k = 0; k < D; ++k) {
+          pw[(sv * D + k) * SB_TS + p] = q;
+          q *= x;
+        }
+      }
+      __syncthreads();
+    }
     // rows of Px / Py (Ksysid.m:1034-1064): [psi, u] / psi (x) [1; u] / psi([zeta; u])
     for (int e = tid; e < 2 * N * SB_TS; e += 256) {
       const int p = e % SB_TS, sc = e / SB_TS, side = sc / N, col = sc - side * N;
-      const double val = p < nl ? kp_eval_col(b, b.cols[col], (side ? vy : vx) + p, SB_TS) : 0.0;
+      double val;
+      if (recipes) {
+        const uint32_t rc = recs[col];
+        val = p < nl ? 1.0 : 0.0;
+        for (int f = 0; f < nfmax; ++f) {
+          const uint32_t id = (rc >> (8 * f)) & 255u;
+          const double t = pw[((side * nv) * D + (id == 255u ? 0u : id)) * SB_TS + p];       // unconditional read, then select
+          val *= id == 255u ? 1.0 : t;
+        }
+      } else {
+        val = p < nl ? kp_eval_col(b, b.cols[col], (side ? vy : vx) + p, SB_TS) : 0.0;
+      }
       double* P = (side ? Py : Px) + p * SB_LD;
       P[col] = val;
       if (b.model_type == KP_MODEL_BILINEAR)
@@ -214,10 +245,14 @@ extern "C" int kp_fit_batch(kp_ctx* ctx, const kp_basis* basis, const kp_snapsho
   double* dC = (double*)(ws + 2 * bW);
   int* dS = (int*)(ws + 3 * bW);
   hipStream_t s = ctx->stream;
-  const size_t lds = ((size_t)(2 * b.nvars + (b.m > 0 ? b.m : 1)) * SB_TS + 2 * SB_TS * SB_LD + 3 * 16 * SB_LD + 16) * sizeof(double);
+  size_t lds = ((size_t)(2 * b.nvars + (b.m > 0 ? b.m : 1)) * SB_TS + 2 * SB_TS * SB_LD + 3 * 16 * SB_LD + 16) * sizeof(double);
+  // power-table lift for monomial dictionaries whose table fits (2 sides x nvars x depth x 64 snapshots)
+  const size_t pw_bytes = (size_t)2 * b.nvars * basis->pow_depth * SB_TS * sizeof(double);
+  const bool use_rec = basis->fast && basis->d_recipes && basis->pow_depth >= 1 && lds + pw_bytes <= 64 * 1024;
+  if (use_rec) lds += pw_bytes;
   KP_HIP(ctx, hipEventRecord(ctx->ev0, s));
   hipLaunchKernelGGL(kp_small_fit_kernel, dim3(nb), dim3(256), lds, s, b, snaps->alpha, snaps->beta, snaps->u, snaps->Ns, (int)Ns_each, dK, dG, dC,
-                     dS);
+                     dS, use_rec ? (const uint32_t*)basis->d_recipes : nullptr, basis->pow_depth, basis->max_factors > 0 ? basis->max_factors : 1);
   KP_HIP(ctx, hipGetLastError());
   KP_HIP(ctx, hipEventRecord(ctx->ev1, s));
   KP_HIP(ctx, hipMemcpyAsync(K_out, dK, bW, hipMemcpyDeviceToHost, s));
