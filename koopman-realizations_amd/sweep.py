@@ -147,18 +147,23 @@ def rand_models_sweep_batched(systems, ctx, degrees=None):
     degrees = degrees or MAX_DEGREE
     nb = len(systems)
     # scaling, snapshot pairs and scaled validation data: once per system (independent of type and degree)
-    prep = [Ksysid(d, ctx=ctx, model_type="linear", obs_type=["poly"], obs_degree=[1], snapshots=np.inf, lasso=[np.inf],
-                   delays=0, loaded=False, dim_red=False, _host_only=True) for d in systems]
-    n, m = prep[0].params["n"], prep[0].params["m"]
-    Ns = prep[0].snapshotPairs["alpha"].shape[0]
-    if any(k.snapshotPairs["alpha"].shape[0] != Ns or k.params["n"] != n or k.params["m"] != m for k in prep):
-        raise ValueError("rand_models_sweep_batched: systems must share dimensions and snapshot counts")
-    alpha = np.vstack([k.snapshotPairs["alpha"] for k in prep]); beta = np.vstack([k.snapshotPairs["beta"] for k in prep])
-    uu = np.vstack([k.snapshotPairs["u"] for k in prep])
+    pre = _prep_stacked(systems)
+    if pre is None:                                                        # differently shaped systems: one Ksysid each
+        prep = [Ksysid(d, ctx=ctx, model_type="linear", obs_type=["poly"], obs_degree=[1], snapshots=np.inf, lasso=[np.inf],
+                       delays=0, loaded=False, dim_red=False, _host_only=True) for d in systems]
+        n, m = prep[0].params["n"], prep[0].params["m"]
+        Ns = prep[0].snapshotPairs["alpha"].shape[0]
+        if any(k.snapshotPairs["alpha"].shape[0] != Ns or k.params["n"] != n or k.params["m"] != m for k in prep):
+            raise ValueError("rand_models_sweep_batched: systems must share dimensions and snapshot counts")
+        alpha = np.vstack([k.snapshotPairs["alpha"] for k in prep]); beta = np.vstack([k.snapshotPairs["beta"] for k in prep])
+        uu = np.vstack([k.snapshotPairs["u"] for k in prep])
+        val = [k._val_common(k.valdata[0]) for k in prep]                  # (t, yreal, ureal, zetareal)
+        T = min(v[1].shape[0] for v in val)
+        yreal = np.stack([v[1][:T] for v in val]); ureal = np.stack([v[2][:T] for v in val]); zeta0 = np.stack([v[3][0] for v in val])
+    else:
+        n, m, alpha, beta, uu, yreal, ureal, zeta0 = pre
+        T = yreal.shape[1]
     snaps = Snapshots(ctx, alpha, beta, uu)
-    val = [k._val_common(k.valdata[0]) for k in prep]                      # (t, yreal, ureal, zetareal)
-    T = min(v[1].shape[0] for v in val)
-    yreal = np.stack([v[1][:T] for v in val]); ureal = np.stack([v[2][:T] for v in val]); zeta0 = np.stack([v[3][0] for v in val])
     mean_zero = np.abs(yreal).sum(axis=1) / T                              # evaluate_rand_models.m:71
     out = {}
     try:
@@ -198,6 +203,45 @@ def rand_models_sweep_batched(systems, ctx, degrees=None):
     finally:
         snaps.close()
     return out
+
+
+def _prep_stacked(systems):
+    """The constructor steps of Ksysid that the sweep needs - merge_trials (Ksysid.m:380-401), get_scale (:180-229),
+    scale_data of the validation trial (:308-343), get_snapshotPairs (:941-978, delays = 0, all pairs) - for all systems
+    at once with stacked numpy arrays (the per-system objects cost 0.2 ms each, a third of the whole sweep).  Returns
+    None unless every system has the same trial layout.  The pairs are taken in time order instead of a random
+    permutation: the least-squares fit does not depend on the order (up to rounding)."""
+    try:
+        tr = [d["train"] for d in systems]
+        k = len(tr[0])
+        if any(len(t) != k for t in tr):
+            return None
+        def stacked(key, src):                                             # nb x (k T) x width in one conversion
+            a = np.asarray([[x[key] for x in t] for t in src], dtype=np.float64)   # ValueError when ragged
+            if a.ndim == 3:                                                # vectors (t, or 1-D y / u): nb x k x T
+                a = a[..., None]
+            return a.reshape(a.shape[0], a.shape[1] * a.shape[2], -1)
+        Y, U = stacked("y", tr), stacked("u", tr)
+        Tm = stacked("t", tr)[:, :, 0]
+        va = [[d["val"][0]] for d in systems]
+        vy, vu = stacked("y", va), stacked("u", va)
+    except ValueError:                                                     # ragged shapes
+        return None
+    good = Tm[:, :-1] < Tm[:, 1:]                                          # :948 seams between trials
+    if not (good == good[0]).all():
+        return None
+    nb, _, n = Y.shape
+    m = U.shape[2]
+    def scale(V):                                                          # :187-210
+        mn, mx = V.min(axis=1, keepdims=True), V.max(axis=1, keepdims=True)
+        off, fac = (mx + mn) / 2.0, (mx - mn) / 2.0
+        return off, np.where(fac == 0, 1.0, fac)
+    oy, fy = scale(Y); ou, fu = scale(U)
+    Ys, Us = (Y - oy) / fy, (U - ou) / fu
+    idx = np.nonzero(good[0])[0][:-1]                                      # num_max = #good - 1 (:960): the last good pair is dropped
+    alpha = Ys[:, idx].reshape(nb * len(idx), n); beta = Ys[:, idx + 1].reshape(nb * len(idx), n); uu = Us[:, idx].reshape(nb * len(idx), m)
+    yreal, ureal = (vy - oy) / fy, (vu - ou) / fu
+    return n, m, alpha, beta, uu, yreal, ureal, yreal[:, 0].copy()
 
 
 def _keep_systems(err):

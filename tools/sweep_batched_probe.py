@@ -18,6 +18,6 @@ for nb in (3, 64, 1024):
     t0 = time.perf_counter(); tab = sweep.rand_models_sweep_batched(systems, ctx); dt = time.perf_counter() - t0
     print("nb %4d batched sweep %.3f s  (%.2f ms per system)  linear deg-13 mean err %.4f" % (nb, dt, dt / nb * 1e3, np.nanmean(tab["linear"][-1])))
 import cProfile, pstats
-systems = [base[i % 3] for i in range(256)]
+systems = [base[i % 3] for i in range(1024)]
 pr = cProfile.Profile(); pr.enable(); sweep.rand_models_sweep_batched(systems, ctx); pr.disable()
-pstats.Stats(pr).sort_stats('cumulative').print_stats(12)
+pstats.Stats(pr).sort_stats('cumulative').print_stats(22)
