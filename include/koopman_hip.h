@@ -119,8 +119,7 @@ int kp_snapshots_destroy(kp_snapshots* snaps);
 /* ---- EDMD fit ---------------------------------------------------------------------
  * kp_fit_gram: the fused per-row lift loop of get_Koopman (Ksysid.m:1030-1065) and the
  *   accumulations PxTPx = Px'*Px (:1114), PxTPy = Px'*Py (:1125).  Px/Py are never
- *   materialised.  G, C: W x W column-major (either may be NULL to leave the result on
- *   the device only, for kp_fit_solve_dev).
+ *   materialised.  G, C: W x W column-major, caller allocated (either may be NULL).
  * kp_fit_solve: K = Px \ Py (Ksysid.m:1069) from the normal equations G K = C by Cholesky.
  *   ncols = columns of C.  KP_ERR_NOT_SPD when Psi is rank deficient (MATLAB warns and
  *   returns a basic solution there, which is not reproducible).
@@ -130,9 +129,6 @@ int kp_snapshots_destroy(kp_snapshots* snaps);
  *   resident snapshots; lasso[i] >= 1e6 (or +Inf) selects the least-squares branch (:1068).
  *   K_out: n_lasso matrices W x W, column-major, back to back (may be NULL: results stay
  *   on the device; fetch with kp_fit_get_K).
- * kp_fit_refine: one step of iterative refinement K += G^-1 Px'(Py - Px K) with the
- *   residual Gram accumulated in a second fused pass (recovers QR-level accuracy for
- *   ill-conditioned dictionaries).
  */
 int kp_fit_gram(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* snaps, double* G, double* C);
 int kp_fit_solve(kp_ctx* ctx, const double* G, const double* C, int W, int ncols, double* K);
