@@ -148,6 +148,9 @@ int kp_synchronize(kp_ctx* ctx);
  * with the same dictionary, W <= 16, no dimension reduction, least squares (lasso = Inf, Ksysid.m:1068-1069).
  * `snaps` holds the merged snapshot pairs of all systems, nb x Ns_each rows, system s in rows
  * [s*Ns_each, (s+1)*Ns_each).  One workgroup per system lifts its rows, accumulates Px'Px / Px'Py and solves.
+ * The normal-equations solution is followed by one step of iterative refinement with the residual taken from the
+ * data, K += G^-1 Px'(Py - Px K) (a second sweep over the system's snapshots): the degree-13 dictionaries of the sweep
+ * have cond(Px) ~ 1e5, and the reference's `\` is a QR solve.  KP_BATCH_REFINE=0..4 overrides the number of steps.
  * K_out, G_out, C_out: nb matrices W x W, column-major, back to back (G_out/C_out may be NULL);
  * status_out[s] != 0 (may be NULL) marks a Gram matrix that is not numerically positive definite (K = NaN). */
 int kp_fit_batch(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* snaps, int nb, int64_t Ns_each,

@@ -11,6 +11,7 @@
 //                   kp_chol_kernel's diagonal block), then forward / backward substitution, one thread per right-hand side
 // Replaces, for each system: Ksysid.get_Koopman (Ksysid.m:987-1092) with lasso = Inf.
 #include "kp_internal.h"
+#include <algorithm>
 
 #define SB_TS 64      // snapshots per tile
 #define SB_W 16       // maximum Px width
@@ -83,12 +84,18 @@ __device__ __forceinline__ void sb_spd_solve16(const double* Gs, const double* C
 // x_v^e (recipe byte = v * D + e - 1, 0xff = unused; the table kp_basis_create builds for the fused Gram kernels), so a
 // lift entry costs <= nfmax LDS reads and multiplies instead of the generic evaluation (exponent rows from global
 // memory, up to 13 multiplies per column for the degree-13 dictionaries of the sweep).
+//
+// refine > 0: iterative refinement of the normal-equations solution with the residual formed FROM THE DATA,
+//   R = Px' (Py - Px K),  G dK = R,  K += dK,
+// in further sweeps over the snapshots (the tile E = Py - Px K replaces Py in the same accumulation).  The reference
+// solves Px \ Py by QR (Ksysid.m:1069); the degree-13 dictionaries of the sweep have cond(Px) ~ 1e5, where the plain
+// normal equations are only good to cond^2 eps ~ 1e-6 - one refinement step brings K to the accuracy of the QR solution.
 __global__ __launch_bounds__(256) void kp_small_fit_kernel(BasisDev b, const double* __restrict__ alpha, const double* __restrict__ beta,
                                                            const double* __restrict__ u, int64_t Ns_total, int Ns, double* __restrict__ Kout,
                                                            double* __restrict__ Gout, double* __restrict__ Cout, int* __restrict__ status,
-                                                           const uint32_t* __restrict__ recipes, int D, int nfmax) {
+                                                           const uint32_t* __restrict__ recipes, int D, int nfmax, int refine) {
   extern __shared__ __align__(16) double sm[];
-  // LDS: vx[nvars][TS] | vy[nvars][TS] | um[m][TS] | Px[TS][LD] | Py[TS][LD] | Gs[16][LD] | Cs[16][LD] | Ls[16][LD] | Dd[16]
+  // LDS: vx[nvars][TS] | vy[nvars][TS] | um[m][TS] | Px[TS][LD] | Py[TS][LD] | Gs[16][LD] | Cs[16][LD] | Ls[16][LD] | Dd[16] | Ks[16][LD] | Xs[16][LD] | pw
   const int nv = b.nvars, m = b.m, N = b.N, W = b.W;
   double* vx = sm;
   double* vy = vx + nv * SB_TS;
@@ -99,7 +106,9 @@ __global__ __launch_bounds__(256) void kp_small_fit_kernel(BasisDev b, const dou
   double* Cs = Gs + 16 * SB_LD;
   double* Ls = Cs + 16 * SB_LD;
   double* Dd = Ls + 16 * SB_LD;
-  double* pw = Dd + 16;                             // [side][v * D + e - 1][snapshot]  (only with recipes)
+  double* Ks = Dd + 16;                             // current K, [row][col]
+  double* Xs = Ks + 16 * SB_LD;                     // solution of the last solve
+  double* pw = Xs + 16 * SB_LD;                     // [side][v * D + e - 1][snapshot]  (only with recipes)
   __shared__ int bad;
   __shared__ uint32_t recs[SB_W];
   if (recipes && threadIdx.x < N) recs[threadIdx.x] = recipes[threadIdx.x];
@@ -111,115 +120,132 @@ __global__ __launch_bounds__(256) void kp_small_fit_kernel(BasisDev b, const dou
   const int gi = tid >> 4, gj = tid & 15;
   const int blk = tid & 15, grp = tid >> 4;          // 4 x 4 output block, snapshot group (4 consecutive snapshots of a tile)
   const int bi = (blk >> 2) * 4, bj = (blk & 3) * 4;
-  double g[4][4], c[4][4];
+  Ks[gi * SB_LD + gj] = 0.0;
+  for (int pass = 0; pass <= refine; ++pass) {
+    double g[4][4], c[4][4];
 #pragma unroll
-  for (int x = 0; x < 4; ++x)
+    for (int x = 0; x < 4; ++x)
 #pragma unroll
-    for (int y = 0; y < 4; ++y) g[x][y] = c[x][y] = 0.0;
-  __syncthreads();
-  for (int r0 = 0; r0 < Ns; r0 += SB_TS) {
-    const int nl = min(SB_TS, Ns - r0);
-    // raw variables of the tile: x side (alpha [, u]), y side (beta [, u]), inputs
-    for (int e = tid; e < (2 * nv + m) * SB_TS; e += 256) {
-      const int v = e / SB_TS, p = e % SB_TS;
-      double x = 0.0;
-      if (p < nl) {
-        const int64_t row = base + r0 + p;
-        if (v < nv) x = v < b.nzeta ? alpha[(int64_t)v * Ns_total + row] : u[(int64_t)(v - b.nzeta) * Ns_total + row];
-        else if (v < 2 * nv) x = (v - nv) < b.nzeta ? beta[(int64_t)(v - nv) * Ns_total + row] : u[(int64_t)(v - nv - b.nzeta) * Ns_total + row];
-        else x = u[(int64_t)(v - 2 * nv) * Ns_total + row];
-      }
-      sm[e] = x;                                     // vx | vy | um are contiguous in this order
-    }
+      for (int y = 0; y < 4; ++y) g[x][y] = c[x][y] = 0.0;
     __syncthreads();
-    if (recipes) {                                   // power table of both sides
-      for (int e = tid; e < 2 * nv * SB_TS; e += 256) {
-        const int p = e % SB_TS, sv = e / SB_TS;     // sv = side * nv + v; vx | vy are contiguous
-        const double x = sm[sv * SB_TS + p];
-        double q = x;
-        for (int k = 0; k < D; ++k) {
-          pw[(sv * D + k) * SB_TS + p] = q;
-          q *= x;
+    for (int r0 = 0; r0 < Ns; r0 += SB_TS) {
+      const int nl = min(SB_TS, Ns - r0);
+      // raw variables of the tile: x side (alpha [, u]), y side (beta [, u]), inputs
+      for (int e = tid; e < (2 * nv + m) * SB_TS; e += 256) {
+        const int v = e / SB_TS, p = e % SB_TS;
+        double x = 0.0;
+        if (p < nl) {
+          const int64_t row = base + r0 + p;
+          if (v < nv) x = v < b.nzeta ? alpha[(int64_t)v * Ns_total + row] : u[(int64_t)(v - b.nzeta) * Ns_total + row];
+          else if (v < 2 * nv) x = (v - nv) < b.nzeta ? beta[(int64_t)(v - nv) * Ns_total + row] : u[(int64_t)(v - nv - b.nzeta) * Ns_total + row];
+          else x = u[(int64_t)(v - 2 * nv) * Ns_total + row];
         }
+        sm[e] = x;                                     // vx | vy | um are contiguous in this order
+      }
+      __syncthreads();
+      if (recipes) {                                   // power table of both sides
+        for (int e = tid; e < 2 * nv * SB_TS; e += 256) {
+          const int p = e % SB_TS, sv = e / SB_TS;     // sv = side * nv + v; vx | vy are contiguous
+          const double x = sm[sv * SB_TS + p];
+          double q = x;
+          for (int k = 0; k < D; ++k) {
+            pw[(sv * D + k) * SB_TS + p] = q;
+            q *= x;
+          }
+        }
+        __syncthreads();
+      }
+      // rows of Px / Py (Ksysid.m:1034-1064): [psi, u] / psi (x) [1; u] / psi([zeta; u])
+      for (int e = tid; e < 2 * N * SB_TS; e += 256) {
+        const int p = e % SB_TS, sc = e / SB_TS, side = sc / N, col = sc - side * N;
+        double val;
+        if (recipes) {
+          const uint32_t rc = recs[col];
+          val = p < nl ? 1.0 : 0.0;
+          for (int f = 0; f < nfmax; ++f) {
+            const uint32_t id = (rc >> (8 * f)) & 255u;
+            const double t = pw[((side * nv) * D + (id == 255u ? 0u : id)) * SB_TS + p];       // unconditional read, then select
+            val *= id == 255u ? 1.0 : t;
+          }
+        } else {
+          val = p < nl ? kp_eval_col(b, b.cols[col], (side ? vy : vx) + p, SB_TS) : 0.0;
+        }
+        double* P = (side ? Py : Px) + p * SB_LD;
+        P[col] = val;
+        if (b.model_type == KP_MODEL_BILINEAR)
+          for (int i = 0; i < m; ++i) P[(i + 1) * N + col] = val * um[i * SB_TS + p];
+      }
+      if (b.model_type == KP_MODEL_LINEAR)
+        for (int e = tid; e < 2 * m * SB_TS; e += 256) {
+          const int p = e % SB_TS, si = e / SB_TS, side = si / m, i = si - side * m;
+          ((side ? Py : Px) + p * SB_LD)[N + i] = um[i * SB_TS + p];       // zero past the tail (um is)
+        }
+      __syncthreads();
+      if (pass > 0) {                                  // E = Py - Px K in place of Py: thread = (snapshot, 4 columns)
+        const int p = tid >> 2, j4 = (tid & 3) * 4;
+        double2 e0 = *reinterpret_cast<const double2*>(Py + p * SB_LD + j4), e1 = *reinterpret_cast<const double2*>(Py + p * SB_LD + j4 + 2);
+        for (int i = 0; i < W; ++i) {
+          const double xi = Px[p * SB_LD + i];
+          const double2 k0 = *reinterpret_cast<const double2*>(Ks + i * SB_LD + j4), k1 = *reinterpret_cast<const double2*>(Ks + i * SB_LD + j4 + 2);
+          e0.x -= xi * k0.x; e0.y -= xi * k0.y; e1.x -= xi * k1.x; e1.y -= xi * k1.y;
+        }
+        *reinterpret_cast<double2*>(Py + p * SB_LD + j4) = e0;
+        *reinterpret_cast<double2*>(Py + p * SB_LD + j4 + 2) = e1;
+        __syncthreads();
+      }
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) {
+        const double* xr = Px + (grp * 4 + s_) * SB_LD;
+        const double* yr = Py + (grp * 4 + s_) * SB_LD;
+        const double2 xa = *reinterpret_cast<const double2*>(xr + bi), xb = *reinterpret_cast<const double2*>(xr + bi + 2);
+        const double2 ja = *reinterpret_cast<const double2*>(xr + bj), jb = *reinterpret_cast<const double2*>(xr + bj + 2);
+        const double2 ya = *reinterpret_cast<const double2*>(yr + bj), yb = *reinterpret_cast<const double2*>(yr + bj + 2);
+        const double xi[4] = {xa.x, xa.y, xb.x, xb.y}, xj[4] = {ja.x, ja.y, jb.x, jb.y}, yj[4] = {ya.x, ya.y, yb.x, yb.y};
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+          for (int y = 0; y < 4; ++y) {
+            if (pass == 0) g[x][y] += xi[x] * xj[y];
+            c[x][y] += xi[x] * yj[y];
+          }
       }
       __syncthreads();
     }
-    // rows of Px / Py (Ksysid.m:1034-1064): [psi, u] / psi (x) [1; u] / psi([zeta; u])
-    for (int e = tid; e < 2 * N * SB_TS; e += 256) {
-      const int p = e % SB_TS, sc = e / SB_TS, side = sc / N, col = sc - side * N;
-      double val;
-      if (recipes) {
-        const uint32_t rc = recs[col];
-        val = p < nl ? 1.0 : 0.0;
-        for (int f = 0; f < nfmax; ++f) {
-          const uint32_t id = (rc >> (8 * f)) & 255u;
-          const double t = pw[((side * nv) * D + (id == 255u ? 0u : id)) * SB_TS + p];       // unconditional read, then select
-          val *= id == 255u ? 1.0 : t;
-        }
+    // sum of the 16 snapshot groups in a fixed order (pass 0: G and C; later passes: the residual R in Cs)
+    if (pass == 0) Gs[gi * SB_LD + gj] = 0.0;
+    Cs[gi * SB_LD + gj] = 0.0;
+    for (int t = 0; t < 16; ++t) {
+      __syncthreads();
+      if (grp == t) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+          for (int y = 0; y < 4; ++y) {
+            if (pass == 0) Gs[(bi + x) * SB_LD + bj + y] += g[x][y];
+            Cs[(bi + x) * SB_LD + bj + y] += c[x][y];
+          }
+      }
+    }
+    __syncthreads();
+    if (pass == 0) {
+      // G (identity on the padding so that the 16 x 16 factorisation is well defined) and C
+      const double gv = Gs[gi * SB_LD + gj], cv = Cs[gi * SB_LD + gj];
+      if (gi < W && gj < W) {
+        if (Gout) Gout[(size_t)sys * W * W + (size_t)gj * W + gi] = gv;
+        if (Cout) Cout[(size_t)sys * W * W + (size_t)gj * W + gi] = cv;
       } else {
-        val = p < nl ? kp_eval_col(b, b.cols[col], (side ? vy : vx) + p, SB_TS) : 0.0;
+        Gs[gi * SB_LD + gj] = gi == gj ? 1.0 : 0.0;
+        Cs[gi * SB_LD + gj] = 0.0;
       }
-      double* P = (side ? Py : Px) + p * SB_LD;
-      P[col] = val;
-      if (b.model_type == KP_MODEL_BILINEAR)
-        for (int i = 0; i < m; ++i) P[(i + 1) * N + col] = val * um[i * SB_TS + p];
+      __syncthreads();
     }
-    if (b.model_type == KP_MODEL_LINEAR)
-      for (int e = tid; e < 2 * m * SB_TS; e += 256) {
-        const int p = e % SB_TS, si = e / SB_TS, side = si / m, i = si - side * m;
-        ((side ? Py : Px) + p * SB_LD)[N + i] = um[i * SB_TS + p];       // zero past the tail (um is)
-      }
-    __syncthreads();
-#pragma unroll
-    for (int s_ = 0; s_ < 4; ++s_) {
-      const double* xr = Px + (grp * 4 + s_) * SB_LD;
-      const double* yr = Py + (grp * 4 + s_) * SB_LD;
-      const double2 xa = *reinterpret_cast<const double2*>(xr + bi), xb = *reinterpret_cast<const double2*>(xr + bi + 2);
-      const double2 ja = *reinterpret_cast<const double2*>(xr + bj), jb = *reinterpret_cast<const double2*>(xr + bj + 2);
-      const double2 ya = *reinterpret_cast<const double2*>(yr + bj), yb = *reinterpret_cast<const double2*>(yr + bj + 2);
-      const double xi[4] = {xa.x, xa.y, xb.x, xb.y}, xj[4] = {ja.x, ja.y, jb.x, jb.y}, yj[4] = {ya.x, ya.y, yb.x, yb.y};
-#pragma unroll
-      for (int x = 0; x < 4; ++x)
-#pragma unroll
-        for (int y = 0; y < 4; ++y) {
-          g[x][y] += xi[x] * xj[y];
-          c[x][y] += xi[x] * yj[y];
-        }
-    }
-    __syncthreads();
-  }
-  // sum of the 16 snapshot groups in a fixed order
-  Gs[gi * SB_LD + gj] = 0.0;
-  Cs[gi * SB_LD + gj] = 0.0;
-  for (int t = 0; t < 16; ++t) {
-    __syncthreads();
-    if (grp == t) {
-#pragma unroll
-      for (int x = 0; x < 4; ++x)
-#pragma unroll
-        for (int y = 0; y < 4; ++y) {
-          Gs[(bi + x) * SB_LD + bj + y] += g[x][y];
-          Cs[(bi + x) * SB_LD + bj + y] += c[x][y];
-        }
-    }
+    // G X = C (pass 0) or G dK = R: 16 x 16 Cholesky in registers + substitution
+    sb_spd_solve16(Gs, Cs, Xs, Ls, Dd, &bad);
+    Ks[gi * SB_LD + gj] += Xs[gi * SB_LD + gj];
+    if (bad) break;                                  // (uniform: `bad` is shared and the solve ends with a barrier)
   }
   __syncthreads();
-  // G (identity on the padding so that the 16 x 16 factorisation is well defined) and C
-  {
-    const double gv = Gs[gi * SB_LD + gj], cv = Cs[gi * SB_LD + gj];
-    if (gi < W && gj < W) {
-      if (Gout) Gout[(size_t)sys * W * W + (size_t)gj * W + gi] = gv;
-      if (Cout) Cout[(size_t)sys * W * W + (size_t)gj * W + gi] = cv;
-    } else {
-      Gs[gi * SB_LD + gj] = gi == gj ? 1.0 : 0.0;
-      Cs[gi * SB_LD + gj] = 0.0;
-    }
-  }
-  __syncthreads();
-  // G K = C (16 x 16 Cholesky in registers + substitution); K into the (no longer needed) Px tile
-  double* Xs = Px;
-  sb_spd_solve16(Gs, Cs, Xs, Ls, Dd, &bad);
-  if (gi < W && gj < W) Kout[(size_t)sys * W * W + (size_t)gj * W + gi] = bad ? __builtin_nan("") : Xs[gi * SB_LD + gj];
+  if (gi < W && gj < W) Kout[(size_t)sys * W * W + (size_t)gj * W + gi] = bad ? __builtin_nan("") : Ks[gi * SB_LD + gj];
   if (tid == 0 && status) status[sys] = bad;
 }
 
@@ -245,14 +271,17 @@ extern "C" int kp_fit_batch(kp_ctx* ctx, const kp_basis* basis, const kp_snapsho
   double* dC = (double*)(ws + 2 * bW);
   int* dS = (int*)(ws + 3 * bW);
   hipStream_t s = ctx->stream;
-  size_t lds = ((size_t)(2 * b.nvars + (b.m > 0 ? b.m : 1)) * SB_TS + 2 * SB_TS * SB_LD + 3 * 16 * SB_LD + 16) * sizeof(double);
+  size_t lds = ((size_t)(2 * b.nvars + (b.m > 0 ? b.m : 1)) * SB_TS + 2 * SB_TS * SB_LD + 5 * 16 * SB_LD + 16) * sizeof(double);
   // power-table lift for monomial dictionaries whose table fits (2 sides x nvars x depth x 64 snapshots)
+  // refinement steps with the residual taken from the data (default 1; KP_BATCH_REFINE=0 gives the plain normal equations)
+  static const int refine = [] { const char* e = getenv("KP_BATCH_REFINE"); return e ? std::max(0, std::min(4, atoi(e))) : 1; }();
   const size_t pw_bytes = (size_t)2 * b.nvars * basis->pow_depth * SB_TS * sizeof(double);
   const bool use_rec = basis->fast && basis->d_recipes && basis->pow_depth >= 1 && lds + pw_bytes <= 64 * 1024;
   if (use_rec) lds += pw_bytes;
   KP_HIP(ctx, hipEventRecord(ctx->ev0, s));
   hipLaunchKernelGGL(kp_small_fit_kernel, dim3(nb), dim3(256), lds, s, b, snaps->alpha, snaps->beta, snaps->u, snaps->Ns, (int)Ns_each, dK, dG, dC,
-                     dS, use_rec ? (const uint32_t*)basis->d_recipes : nullptr, basis->pow_depth, basis->max_factors > 0 ? basis->max_factors : 1);
+                     dS, use_rec ? (const uint32_t*)basis->d_recipes : nullptr, basis->pow_depth, basis->max_factors > 0 ? basis->max_factors : 1,
+                     refine);
   KP_HIP(ctx, hipGetLastError());
   KP_HIP(ctx, hipEventRecord(ctx->ev1, s));
   KP_HIP(ctx, hipMemcpyAsync(K_out, dK, bW, hipMemcpyDeviceToHost, s));

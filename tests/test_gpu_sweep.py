@@ -141,3 +141,24 @@ def test_model_project_batch_matches_single_and_oracle(ctx):
             om = ko.get_model(dic, koop, n)
             assert np.abs(A[s] - om["A"]).max() < 1e-7 * max(1.0, np.abs(om["A"]).max())
             assert np.abs(B[s] - om["B"]).max() < 1e-7 * max(1.0, np.abs(om["B"]).max())
+
+
+def test_fit_batch_refinement_reaches_qr_accuracy_on_ill_conditioned_dictionaries(ctx):
+    """Degree-13 monomials of a 1-D state (the sweep's largest linear dictionary): cond(Px) ~ 4e4, so the plain normal
+    equations are good to ~1e-7 only; kp_fit_batch adds one refinement step with the residual Px'(Py - Px K) taken from
+    the data and matches the QR / SVD least-squares solution (what MATLAB's `\\` returns, Ksysid.m:1069)."""
+    rng = np.random.default_rng(0)
+    nb, Ns = 4, 9000
+    a = rng.uniform(-1, 1, (nb * Ns, 1)); u = rng.uniform(-1, 1, (nb * Ns, 1))
+    b = np.clip(0.9 * a + 0.1 * np.sin(3 * a) + 0.05 * u, -1, 1)
+    basis = kra.Basis(ctx, "linear", 1, 1, [("poly", kra.poly_exponent_table(1, 13)[1:])], None)
+    snaps = kra.Snapshots(ctx, a, b, u)
+    K, G, C, st = ctx.fit_batch(basis, snaps, nb)
+    assert (st == 0).all()
+    dic = ko.build_dictionary("linear", 1, 1, ["poly"], [13])
+    for s in range(nb):
+        pr = {"alpha": a[s * Ns:(s + 1) * Ns], "beta": b[s * Ns:(s + 1) * Ns], "u": u[s * Ns:(s + 1) * Ns]}
+        Px, Py = ko.px_py(dic, pr)
+        assert np.linalg.cond(Px) > 1e4
+        Kq = np.linalg.lstsq(Px, Py, rcond=None)[0]
+        assert np.abs(K[s] - Kq).max() <= 1e-9 * max(1.0, np.abs(Kq).max())
