@@ -137,6 +137,11 @@ int kp_fit_lasso(kp_ctx* ctx, const double* G, const double* C, int W, int ncols
 int kp_fit(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* snaps, const double* lasso,
            int n_lasso, double* K_out);
 int kp_fit_get_K(kp_ctx* ctx, int index, int W, double* K);
+/* Iterative refinement of a least-squares K (W x W, column-major, in/out) with the residual taken from the data:
+ * `steps` times K += G^-1 Px'(Py - Px K).  MATLAB's `\` (Ksysid.m:1069) is a QR solve; the normal equations of
+ * kp_fit lose cond(Px)^2 eps, which one or two of these steps recover (cond 2e5: 4e-6 -> 1e-10).  Materialises Px, Py
+ * (3 Ns W doubles of device memory): the accuracy path, not the throughput path. */
+int kp_fit_refine(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* snaps, int steps, double* K);
 /* kp_fit with K_out == NULL and one least-squares value is ASYNCHRONOUS: it returns when the work is
  * enqueued; the solve runs on a second HIP stream so that it overlaps the fused Gram kernel of the
  * next kp_fit call (sweeps over many fits: lasso grids, random systems).  kp_synchronize waits for

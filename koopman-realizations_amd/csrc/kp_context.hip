@@ -415,6 +415,19 @@ __global__ __launch_bounds__(256) void kp_lift_kernel(BasisDev b, int what, cons
   }
 }
 
+// device-to-device lift (used by kp_lift and kp_fit_refine): zeta, u, out are device pointers
+int kp_lift_dev(kp_ctx* ctx, const kp_basis* basis, int what, const double* dz, const double* du, int64_t rows, double* dout) {
+  const BasisDev& b = basis->dev;
+  size_t lds = (size_t)(b.nvars + (b.m > 0 ? b.m : 1) + (b.k_pcs ? b.nfull : 0)) * LT * 8;
+  if (lds > 160 * 1024) return ctx->fail(KP_ERR_ARG, "kp_lift: dictionary too large for the LDS staging of the pcs projection");
+  if (lds > 64 * 1024)
+    KP_HIP(ctx, hipFuncSetAttribute((const void*)kp_lift_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  int64_t nblk = (rows + LT - 1) / LT;
+  hipLaunchKernelGGL(kp_lift_kernel, dim3((unsigned)nblk), dim3(256), lds, ctx->stream, b, what, dz, du, rows, dout);
+  KP_HIP(ctx, hipGetLastError());
+  return KP_OK;
+}
+
 extern "C" int kp_lift(kp_ctx* ctx, const kp_basis* basis, int what, const double* zeta, const double* u, int64_t rows,
                        double* out) {
   if (!ctx || !basis || what < 0 || what > 2 || rows < 0) return ctx ? ctx->fail(KP_ERR_ARG, "kp_lift: bad argument") : KP_ERR_ARG;

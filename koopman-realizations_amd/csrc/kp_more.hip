@@ -61,6 +61,75 @@ extern "C" int kp_fit_lasso(kp_ctx* ctx, const double* G, const double* C, int W
   return KP_OK;
 }
 
+// ---- iterative refinement of the least-squares fit with the residual taken from the data ------------------------
+// K <- K + G^-1 Px' (Py - Px K).  The reference solves Px \ Py by QR (Ksysid.m:1069); the normal equations lose
+// cond(Px)^2 eps, which shows for the dictionaries WITHOUT dim_red margins (arm data, poly-2 econ: cond 2e5 -> 4e-6).
+// One or two steps with the residual formed from the lifted rows themselves recover the accuracy of the QR solution.
+// Px, Py are materialised here (Ns x W each; this is the accuracy path, not the throughput path) and the products are
+// plain GEMMs.
+__global__ void kp_axpy_kernel(int64_t n, double a, const double* __restrict__ x, double* __restrict__ y) {
+  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n) y[e] += a * x[e];
+}
+
+// R[i][j] = sum_k Px[k][i] E[k][j] for tall Px, E (Ns x W, column-major): one workgroup per output element, the Ns-long
+// dot product split over its 256 threads (coalesced column reads), fixed-order tree reduction
+__global__ __launch_bounds__(256) void kp_tall_dot_kernel(const double* __restrict__ Px, const double* __restrict__ E, int64_t Ns, int W,
+                                                          double* __restrict__ R) {
+  const int i = blockIdx.x % W, j = blockIdx.x / W;
+  const double* a = Px + (size_t)i * Ns;
+  const double* b = E + (size_t)j * Ns;
+  double s = 0.0;
+  for (int64_t k = threadIdx.x; k < Ns; k += 256) s += a[k] * b[k];
+  __shared__ double red[256];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int h = 128; h > 0; h >>= 1) {
+    if ((int)threadIdx.x < h) red[threadIdx.x] += red[threadIdx.x + h];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) R[i + (size_t)j * W] = red[0];
+}
+
+extern "C" int kp_fit_refine(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* snaps, int steps, double* K) {
+  if (!ctx || !basis || !snaps || !K || steps < 1) return ctx ? ctx->fail(KP_ERR_ARG, "kp_fit_refine: bad argument") : KP_ERR_ARG;
+  const BasisDev& b = basis->dev;
+  if (snaps->nzeta != b.nzeta || snaps->m != b.m) return ctx->fail(KP_ERR_ARG, "kp_fit_refine: snapshot/basis dimension mismatch");
+  KP_HIP(ctx, hipSetDevice(ctx->device));
+  if (ctx->async_pending) {
+    int rc0 = kp_synchronize(ctx);
+    if (rc0) return rc0;
+  }
+  const int W = b.W;
+  const int64_t Ns = snaps->Ns;
+  const size_t bW = (size_t)W * W * 8, bP = (size_t)Ns * W * 8;
+  char* ws = (char*)ctx->workspace(7, 3 * bP + 5 * bW);
+  if (!ws) return ctx->fail(KP_ERR_HIP, "kp_fit_refine: out of device memory");
+  double *Px = (double*)ws, *Py = (double*)(ws + bP), *E = (double*)(ws + 2 * bP);
+  double *GC = (double*)(ws + 3 * bP), *Kd = GC + 2 * (size_t)W * W, *R = Kd + (size_t)W * W, *dK = R + (size_t)W * W;
+  hipStream_t s = ctx->stream;
+  ctx->reserve_cus = 0;
+  int rc = kp_gram_dispatch(ctx, basis, snaps, GC);
+  if (rc) return rc;
+  rc = kp_lift_dev(ctx, basis, KP_LIFT_ROW, snaps->alpha, snaps->u, Ns, Px);
+  if (!rc) rc = kp_lift_dev(ctx, basis, KP_LIFT_ROW, snaps->beta, snaps->u, Ns, Py);
+  if (rc) return rc;
+  KP_HIP(ctx, hipMemcpyAsync(Kd, K, bW, hipMemcpyHostToDevice, s));
+  for (int it = 0; it < steps; ++it) {
+    KP_HIP(ctx, hipMemcpyAsync(E, Py, bP, hipMemcpyDeviceToDevice, s));
+    KP_HIP(ctx, gemm(s, 0, 0, (int)Ns, W, W, -1.0, Px, (int)Ns, Kd, W, 1.0, E, (int)Ns));       // E = Py - Px K
+    hipLaunchKernelGGL(kp_tall_dot_kernel, dim3((unsigned)(W * W)), dim3(256), 0, s, Px, E, Ns, W, R);
+    KP_HIP(ctx, hipGetLastError());
+    rc = kp_chol_solve_dev(ctx, GC, R, W, W, dK);                                                 // G dK = Px' E
+    if (rc) return rc;
+    hipLaunchKernelGGL(kp_axpy_kernel, dim3((unsigned)(((int64_t)W * W + 255) / 256)), dim3(256), 0, s, (int64_t)W * W, 1.0, dK, Kd);
+    KP_HIP(ctx, hipGetLastError());
+  }
+  KP_HIP(ctx, hipMemcpyAsync(K, Kd, bW, hipMemcpyDeviceToHost, s));
+  KP_HIP(ctx, hipStreamSynchronize(s));
+  return KP_OK;
+}
+
 // ---- get_model M-projection from the Grams (Ksysid.m:1206-1225) ---------------------------------
 // L = [Px U] K1 with K1 = K(:,1:N)  =>  L'L = K1' G K1,  L'R = K1' C(:,1:N);  M' = (L'L) \ (L'R);
 // A = K(1:N,1:N)', B = K(N+1:end,1:N)';  out.A = M A, out.B = M B.

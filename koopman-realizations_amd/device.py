@@ -269,6 +269,14 @@ def fit(ctx: Context, basis: Basis, snaps: Snapshots, lasso=None, fetch=True):
     return [np.asfortranarray(K[i].T) for i in range(len(las))]
 
 
+def fit_refine(ctx: Context, basis: Basis, snaps: Snapshots, K, steps=1):
+    """kp_fit_refine: `steps` x  K += G^-1 Px'(Py - Px K) with the residual taken from the data (QR-level accuracy for
+    ill-conditioned dictionaries; MATLAB's `\` is a QR solve, Ksysid.m:1069)."""
+    Kc = F.fcol(np.array(K, dtype=np.float64))
+    F.check(F.lib().kp_fit_refine(ctx.handle, basis.handle, snaps.handle, int(steps), F.dptr(Kc)), ctx.handle)
+    return Kc
+
+
 class Mpc:
     """kp_mpc: condensed MPC problem of a linear / bilinear Koopman model on the device."""
 

@@ -20,7 +20,7 @@ import math
 import numpy as np
 
 from . import _ffi as F
-from .device import Basis, Context, Snapshots, fit, fit_gram
+from .device import Basis, Context, Snapshots, fit, fit_gram, fit_refine
 
 _default_ctx = None
 
@@ -123,6 +123,7 @@ class Ksysid:
         self.obs_type = ["poly"]; self.obs_degree = [1]
         self.snapshots = math.inf; self.lasso = 1e6; self.delays = 0
         self.model_type = "linear"; self.loaded = False; self.time_type = "discrete"; self.dim_red = False
+        self.ls_refine = 1     # (not a reference property) refinement steps after the normal-equations solve: `\` is a QR solve
         self._host_only = bool(kwargs.pop("_host_only", False))           # sweeps: scaling / pairs only, no device dictionary
         for k, v in kwargs.items():                                        # parse_args :147-158
             if not hasattr(self, k):
@@ -397,6 +398,8 @@ class Ksysid:
             obj_lasso = np.atleast_1d(self.lasso)
             if np.all(obj_lasso >= 1e6):                                   # :1068 tests the PROPERTY
                 K = fit(self.ctx, self.basis_dev, snaps, [np.inf])[0]
+                if self.ls_refine:                                         # K = Px \ Py (:1069) to QR accuracy
+                    K = fit_refine(self.ctx, self.basis_dev, snaps, K, int(self.ls_refine))
             else:                                                          # :994-999: t = lasso * N
                 lval = 1e4 if lasso is None else float(lasso)
                 if self.model_type == "linear" and self.params["nd"] >= 1:

@@ -198,3 +198,21 @@ def test_async_fit_pipeline_matches_synchronous_result(ctx):
         ctx.synchronize()
     assert e.value.code == F.KP_ERR_NOT_SPD
     ctx.synchronize()                            # the sticky flag was cleared
+
+
+@pytest.mark.parametrize("mt,deg,steps,tol", [("bilinear", 2, 1, 1e-10), ("linear", 2, 1, 1e-10), ("bilinear", 3, 1, 1e-12), ("nonlinear", 2, 2, 1e-10)])
+def test_fit_refine_reaches_qr_accuracy(ctx, arm, mt, deg, steps, tol):
+    """kp_fit_refine: K += G^-1 Px'(Py - Px K) with the residual taken from the lifted rows.  On the arm data with
+    dim_red the poly-2 dictionaries have cond(Px) ~ 1e5: the normal equations alone are good to ~5e-7, one step gives
+    the QR / SVD least-squares solution (MATLAB's `\\`, Ksysid.m:1069) to 1e-10 or better."""
+    p = arm["pairs"]
+    dic = ko.build_dictionary(mt, 6, 3, ["poly"], [deg], p, True)
+    basis = make_basis(ctx, dic)
+    snaps = kra.Snapshots(ctx, p["alpha"], p["beta"], p["u"])
+    K0 = kra.fit(ctx, basis, snaps)[0]
+    K1 = kra.fit_refine(ctx, basis, snaps, K0, steps)
+    Px, Py = ko.px_py(dic, p)
+    Kq = np.linalg.lstsq(Px, Py, rcond=None)[0]
+    scale = max(1.0, np.abs(Kq).max())
+    assert np.abs(K1 - Kq).max() <= tol * scale
+    assert np.abs(K1 - Kq).max() <= np.abs(K0 - Kq).max()          # never worse than the unrefined solution
