@@ -197,7 +197,12 @@ int kp_rollout_nl(kp_ctx* ctx, const kp_basis* basis, int batch, const double* K
  *   r: m input weights = diag of eye(m).*cost_input (:201);
  *   lo, hi: m scaled-down input bounds (:247,659) or NULL; slope_lim =
  *   input_slopeConst*mean(u_factor) (:272,684) or NaN; smooth_lim (:294,706) or NaN.
- *   State bounds (:300-318) are not supported (KP_ERR_ARG).
+ *   State bounds (:300-318, :716-730) are set afterwards with kp_mpc_set_state_bounds.
+ * kp_mpc_set_state_bounds: n scaled-down lower / upper bounds (scaledown.y(state_bounds')', :313); n = 0 removes them.
+ *   The reference writes the kron block of E into the first (Np+1) n columns of the stacked lifted state (:306) - not
+ *   strided by N - and that is reproduced: the bounded entries are s = i n + j of [z_0; ...; z_Np].  The rows are dense
+ *   in U and depend on z for bilinear models; steps with state bounds are single-problem, iters = 1, and go through
+ *   the generic QP kernel (KP_ERR_ARG from kp_mpc_step_batch / iters > 1).
  * kp_mpc_step: one get_mpcInput (Kmpc.m:329-387) / get_mpcInput_bilinear_iter
  *   (:817-904) call: z is the lifted state (N), u_prev = traj.u(end,:) (m), Yr the
  *   padded, vectorised reference (nproj*(Np+1), :354-365); iters as in :874.
@@ -215,6 +220,7 @@ int kp_mpc_create(kp_ctx* ctx, int model_type, const double* A, const double* B,
                   const double* proj, int nproj, double q_run, double q_term, const double* r,
                   const double* lo, const double* hi, double slope_lim, double smooth_lim,
                   kp_mpc** mpc);
+int kp_mpc_set_state_bounds(kp_mpc* mpc, int n, const double* lo, const double* hi);
 int kp_mpc_destroy(kp_mpc* mpc);
 int kp_mpc_dims(const kp_mpc* mpc, int* nvar, int* nrows);
 int kp_mpc_step(kp_mpc* mpc, const double* z, const double* u_prev, const double* Yr, int iters,

@@ -46,6 +46,13 @@ struct kp_mpc {
   int* warm = nullptr;                          // device: [count, rows...] optimal active set of the last single step
   int* d_status = nullptr;                      // points into d_out
   size_t io_problems = 0;
+  // state bounds (Kmpc.m:300-318 / :716-730), single-problem steps only
+  int sb_n = 0, sb_kmax = 0, sb_rows = 0;       // n bounded outputs, highest power of A needed, 2 n (Np + 1) rows
+  double* sb_lohi = nullptr;                    // [lo (n) | hi (n)] scaled down
+  double* sb_Apow = nullptr;                    // (kmax + 1) x [N x N]: A^0 .. A^kmax
+  double* sb_A = nullptr;                       // dense constraint matrix of a step: (nrows + sb_rows) x nvar, column-major
+  double* sb_b = nullptr;                       // | right-hand sides | row norms | solution x
+  int* sb_col = nullptr;                        // ELL column table of a dense matrix: col[k * rows + r] = k
 };
 
 // ---- wave-level helpers (64 lanes): DPP inside 16-lane rows, v_readlane across the 4 rows ----
@@ -876,6 +883,11 @@ extern "C" int kp_mpc_destroy(kp_mpc* M) {
   if (M->warm) (void)hipFree(M->warm);
   if (M->ellc) (void)hipFree(M->ellc);
   if (M->ellv) (void)hipFree(M->ellv);
+  if (M->sb_lohi) (void)hipFree(M->sb_lohi);
+  if (M->sb_Apow) (void)hipFree(M->sb_Apow);
+  if (M->sb_A) (void)hipFree(M->sb_A);
+  if (M->sb_b) (void)hipFree(M->sb_b);
+  if (M->sb_col) (void)hipFree(M->sb_col);
   delete M;
   return KP_OK;
 }
@@ -993,11 +1005,137 @@ extern "C" int kp_mpc_dims(const kp_mpc* M, int* nvar, int* nrows) {
   return KP_OK;
 }
 
+// ---- state bounds (Kmpc.m:300-318, :716-730) -----------------------------------------------------------------------
+// The reference bounds the entries s = i n + j (block i = 0..Np, j < n) of the STACKED lifted state [z_0; z_1; ...]
+// (the kron block of E is written into its first (Np+1) n columns, :306 - not strided by N; restated literally, as the
+// oracle does): entry s belongs to step k = s / N, component c = s % N, so
+//   (Ahat z)_s = (A^k z)_c,   (Bhat U)_s = sum_{j < k} (A^(k-1-j) Bz)_c,: u_j,   Bz = Beta(z) (bilinear) or B (linear),
+// rows  -(Bhat U)_s <= -lo_j + (Ahat z)_s  and  (Bhat U)_s <= hi_j - (Ahat z)_s.  These rows are dense in U and, for a
+// bilinear model, change with z: kp_mpc_sb_kernel writes the whole constraint matrix of the step densely (the constant
+// sparse rows expanded, then the state-bound rows) and the generic QP kernel solves with it.
+__global__ void kp_matmul_nn_kernel(const double* __restrict__ X, const double* __restrict__ Y, int N, double* __restrict__ Z) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= N * N) return;
+  const int i = e % N, j = e / N;
+  double s = 0.0;
+  for (int k = 0; k < N; ++k) s += X[i + (size_t)k * N] * Y[k + (size_t)j * N];
+  Z[e] = s;
+}
+
+__global__ __launch_bounds__(256) void kp_mpc_sb_kernel(int model_type, int N, int m, int Np, int nvar, int nrows, int n_sb, int kmax,
+                                                        const double* __restrict__ Apow, const double* __restrict__ B,
+                                                        const double* __restrict__ Aq, const double* __restrict__ b_in,
+                                                        const double* __restrict__ z, const double* __restrict__ lohi,
+                                                        double* __restrict__ Ad, double* __restrict__ bd, double* __restrict__ nrm) {
+  extern __shared__ double sm[];
+  double* Bz = sm;                         // N x m
+  double* zs = Bz + N * m;                 // N
+  const int tid = threadIdx.x;
+  const int mr = nrows + 2 * n_sb * (Np + 1);
+  for (int c = tid; c < N; c += 256) zs[c] = z[c];
+  __syncthreads();
+  for (int e = tid; e < N * m; e += 256) {
+    const int r = e % N, i = e / N;
+    double s;
+    if (model_type == KP_MODEL_BILINEAR) {
+      s = 0.0;
+      const double* Bi = B + (size_t)i * N * N;
+      for (int c = 0; c < N; ++c) s += Bi[r + (size_t)c * N] * zs[c];
+    } else {
+      s = B[r + (size_t)i * N];
+    }
+    Bz[e] = s;
+  }
+  __syncthreads();
+  // constant rows: expanded copy
+  for (int e = tid; e < nrows * nvar; e += 256) {
+    const int r = e % nrows, v = e / nrows;
+    Ad[r + (size_t)v * mr] = Aq[e];
+  }
+  for (int r = tid; r < nrows; r += 256) bd[r] = b_in[r];
+  // state-bound rows: one (stacked entry, variable) pair per thread and pass
+  const int nst = n_sb * (Np + 1);
+  for (int e = tid; e < nst * nvar; e += 256) {
+    const int st = e % nst, v = e / nst;            // stacked entry, variable v = jj * m + ii
+    const int blk = st / n_sb, j = st % n_sb;
+    const int k = st / N, c = st % N;
+    const int jj = v / m, ii = v % m;
+    double val = 0.0;
+    if (jj < k) {
+      const double* Ap = Apow + (size_t)(k - 1 - jj) * N * N;       // row c of A^(k-1-jj)
+      for (int r = 0; r < N; ++r) val += Ap[c + (size_t)r * N] * Bz[r + ii * N];
+    }
+    const int rneg = nrows + blk * 2 * n_sb + j, rpos = rneg + n_sb;
+    Ad[rneg + (size_t)v * mr] = -val;
+    Ad[rpos + (size_t)v * mr] = val;
+  }
+  for (int st = tid; st < nst; st += 256) {
+    const int blk = st / n_sb, j = st % n_sb;
+    const int k = st / N, c = st % N;
+    const double* Ap = Apow + (size_t)k * N * N;
+    double az = 0.0;
+    for (int r = 0; r < N; ++r) az += Ap[c + (size_t)r * N] * zs[r];
+    const int rneg = nrows + blk * 2 * n_sb + j, rpos = rneg + n_sb;
+    bd[rneg] = -lohi[j] + az;
+    bd[rpos] = lohi[n_sb + j] - az;
+  }
+  __syncthreads();
+  __threadfence_block();
+  for (int r = tid; r < mr; r += 256) {             // row norms (the solver scales violations by them)
+    double s = 0.0;
+    for (int v = 0; v < nvar; ++v) {
+      const double a = Ad[r + (size_t)v * mr];
+      s += a * a;
+    }
+    nrm[r] = sqrt(s);
+  }
+}
+
+extern "C" int kp_mpc_set_state_bounds(kp_mpc* M, int n, const double* lo, const double* hi) {
+  if (!M) return KP_ERR_ARG;
+  kp_ctx* ctx = M->ctx;
+  if (n < 0 || n > M->N || (n > 0 && (!lo || !hi))) return ctx->fail(KP_ERR_ARG, "kp_mpc_set_state_bounds: bad argument");
+  KP_HIP(ctx, hipSetDevice(ctx->device));
+  double** bufs[] = {&M->sb_lohi, &M->sb_Apow, &M->sb_A, &M->sb_b};
+  for (double** p : bufs)
+    if (*p) { (void)hipFree(*p); *p = nullptr; }
+  if (M->sb_col) { (void)hipFree(M->sb_col); M->sb_col = nullptr; }
+  M->sb_n = 0; M->sb_rows = 0;
+  if (n == 0) return KP_OK;
+  const int N = M->N, Np = M->Np, nv = M->nvar;
+  const int kmax = ((Np + 1) * n - 1) / N;
+  const int mr = M->nrows + 2 * n * (Np + 1);
+  std::vector<double> lh(2 * n);
+  for (int i = 0; i < n; ++i) { lh[i] = lo[i]; lh[n + i] = hi[i]; }
+  int rc = dev_alloc_copy(ctx, &M->sb_lohi, lh.data(), lh.size());
+  if (rc) return rc;
+  KP_HIP(ctx, hipMalloc((void**)&M->sb_Apow, (size_t)(kmax + 1) * N * N * 8));
+  KP_HIP(ctx, hipMalloc((void**)&M->sb_A, (size_t)mr * nv * 8));
+  KP_HIP(ctx, hipMalloc((void**)&M->sb_b, (size_t)(2 * mr + nv + 8) * 8));
+  std::vector<double> eye((size_t)N * N, 0.0);
+  for (int i = 0; i < N; ++i) eye[(size_t)i * N + i] = 1.0;
+  KP_HIP(ctx, hipMemcpy(M->sb_Apow, eye.data(), (size_t)N * N * 8, hipMemcpyHostToDevice));
+  for (int p = 1; p <= kmax; ++p) {
+    hipLaunchKernelGGL(kp_matmul_nn_kernel, dim3((N * N + 255) / 256), dim3(256), 0, ctx->stream, M->sb_Apow + (size_t)(p - 1) * N * N, M->A, N,
+                       M->sb_Apow + (size_t)p * N * N);
+    KP_HIP(ctx, hipGetLastError());
+  }
+  std::vector<int> col((size_t)mr * nv);
+  for (int k = 0; k < nv; ++k)
+    for (int r = 0; r < mr; ++r) col[(size_t)k * mr + r] = k;
+  KP_HIP(ctx, hipMalloc((void**)&M->sb_col, col.size() * sizeof(int)));
+  KP_HIP(ctx, hipMemcpy(M->sb_col, col.data(), col.size() * sizeof(int), hipMemcpyHostToDevice));
+  KP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  M->sb_n = n; M->sb_kmax = kmax; M->sb_rows = 2 * n * (Np + 1);
+  return KP_OK;
+}
+
 static int mpc_run(kp_mpc* M, const kp_basis* basis, int nb, const double* z, const double* zeta, const double* u_prev,
                    const double* Yr, int iters, double* U_out, double* z_out, int* status) {
   kp_ctx* ctx = M->ctx;
   if (nb < 1 || !u_prev || !Yr || !U_out || iters < 1 || (!z && !zeta)) return ctx->fail(KP_ERR_ARG, "kp_mpc_step: bad argument");
   if (iters > 1 && M->model_type != KP_MODEL_BILINEAR) iters = 1;
+  if (M->sb_n > 0 && (nb != 1 || iters != 1)) return ctx->fail(KP_ERR_ARG, "kp_mpc_step: state bounds need single-problem steps with iters = 1");
   KP_HIP(ctx, hipSetDevice(ctx->device));
   const int N = M->N, m = M->m, Np = M->Np, nproj = M->nproj, nv = M->nvar, nr = M->nrows;
   int nzeta = 0;
@@ -1082,6 +1220,30 @@ static int mpc_run(kp_mpc* M, const kp_basis* basis, int nb, const double* z, co
   if (wk) hipLaunchKernelGGL(kp_mpc_step_kernel<true>, dim3(nb), dim3(256), lds, ctx->stream, a);
   else hipLaunchKernelGGL(kp_mpc_step_kernel<false>, dim3(nb), dim3(256), lds, ctx->stream, a);
   KP_HIP(ctx, hipGetLastError());
+  if (M->sb_n > 0) {
+    // the step kernel above has assembled H, f and the right-hand sides of the constant rows (its own solution, without
+    // the state bounds, is discarded): dense constraint matrix of this step, then the generic QP kernel
+    const int mr = nr + M->sb_rows;
+    double* bd = M->sb_b;
+    double* nrm = bd + mr;
+    double* dx = nrm + mr;
+    int* dst = (int*)(dx + nv);
+    hipLaunchKernelGGL(kp_mpc_sb_kernel, dim3(1), dim3(256), (size_t)(N * m + N) * 8, ctx->stream, M->model_type, N, m, Np, nv, nr, M->sb_n,
+                       M->sb_kmax, M->sb_Apow, M->B, M->Aq, M->work + (size_t)nv * nv + nv, a.z_out, M->sb_lohi, M->sb_A, bd, nrm);
+    KP_HIP(ctx, hipGetLastError());
+    EllMat E{M->sb_A, M->sb_col, nrm, nv};
+    const size_t lq = (size_t)qp_lds_doubles(nv, mr) * 8 + 64;
+    static size_t lq_set = 0;
+    if (lq > lq_set) {
+      KP_HIP(ctx, hipFuncSetAttribute((const void*)kp_qp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lq));
+      lq_set = lq;
+    }
+    hipLaunchKernelGGL(kp_qp_kernel, dim3(1), dim3(64), lq, ctx->stream, M->work, M->work + (size_t)nv * nv, E, bd, nv, mr, dx, dst);
+    KP_HIP(ctx, hipGetLastError());
+    // x and the status into the output block the host reads below
+    KP_HIP(ctx, hipMemcpyAsync(a.U, dx, (size_t)nv * 8, zc ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, ctx->stream));
+    KP_HIP(ctx, hipMemcpyAsync(a.status, dst, sizeof(int), zc ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, ctx->stream));
+  }
   KP_HIP(ctx, hipEventRecord(ctx->evp[5], ctx->stream));
   // one device-to-host copy: x and z of every problem, then the status words
   const size_t out_bytes = M->io_problems * n_out * 8 + (size_t)nb * sizeof(int);

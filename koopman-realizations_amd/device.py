@@ -271,7 +271,7 @@ def fit(ctx: Context, basis: Basis, snaps: Snapshots, lasso=None, fetch=True):
 
 def fit_refine(ctx: Context, basis: Basis, snaps: Snapshots, K, steps=1):
     """kp_fit_refine: `steps` x  K += G^-1 Px'(Py - Px K) with the residual taken from the data (QR-level accuracy for
-    ill-conditioned dictionaries; MATLAB's `\` is a QR solve, Ksysid.m:1069)."""
+    ill-conditioned dictionaries; MATLAB's mldivide is a QR solve, Ksysid.m:1069)."""
     Kc = F.fcol(np.array(K, dtype=np.float64))
     F.check(F.lib().kp_fit_refine(ctx.handle, basis.handle, snaps.handle, int(steps), F.dptr(Kc)), ctx.handle)
     return Kc
@@ -301,6 +301,14 @@ class Mpc:
     @property
     def handle(self):
         return self._h
+
+    def set_state_bounds(self, lo, hi):
+        """kp_mpc_set_state_bounds: scaled-down bounds on the first n outputs (Kmpc.m:300-318); lo = None removes them."""
+        if lo is None:
+            F.check(F.lib().kp_mpc_set_state_bounds(self._h, 0, None, None), self.ctx.handle)
+            return
+        lo_ = np.ascontiguousarray(lo, dtype=np.float64); hi_ = np.ascontiguousarray(hi, dtype=np.float64)
+        F.check(F.lib().kp_mpc_set_state_bounds(self._h, len(lo_), F.dptr(lo_), F.dptr(hi_)), self.ctx.handle)
 
     def step(self, z, u_prev, Yr, iters=1):
         """Returns (U [Np x m], status).  U is NaN when the QP failed (quadprog_gurobi.m:22-23)."""

@@ -6,7 +6,8 @@ lift, QP assembly and QP solve — is one kernel launch in libkoopman_hip.so.
 Loaded models (sysid_class.loaded): the lifted state is the loaded lift with the current load estimate
 traj['what'] (Kmpc.m:347-348, :771-772, :839-840); estimate_load_linear / estimate_load_bilinear (Kmpc.m:1298-1445)
 assemble the regression on the host and solve the constrained least squares with the library's QP kernel.
-Out of scope: mpc_type 'nonlinear' (fmincon SQP), state_bounds (KP_ERR_ARG in the library).
+state_bounds (Kmpc.m:300-318) are scaled down like the reference does and handed to kp_mpc_set_state_bounds.
+Out of scope: mpc_type 'nonlinear' (fmincon SQP).
 """
 from __future__ import annotations
 
@@ -51,8 +52,6 @@ class Kmpc:
             self.state_bounds = None
         if self.mpc_type != "linear" or self.model_type == "nonlinear":
             raise NotImplementedError("nonlinear MPC (fmincon SQP) is out of scope (SURVEY section 8)")
-        if self.state_bounds is not None:
-            raise NotImplementedError("state_bounds are not supported")
         self.projmtx = np.atleast_2d(np.asarray(self.projmtx, dtype=np.float64))
         self.expand_props()                         # :82
         m = self.params["m"]
@@ -68,6 +67,9 @@ class Kmpc:
             self.params["Ts"] ** 2 * float(self.input_smoothConst) * float(np.mean(sc["u_factor"]))                       # :294,706
         self.dev = Mpc(self.ctx, self.model_type, self.model["A"], self.model["B"], self.horizon, self.projmtx,
                        self.cost_running, self.cost_terminal, r, lo, hi, slope, smooth)
+        if self.state_bounds is not None:                                   # :313 state_bounds_sc = scaledown.y(state_bounds')'
+            self.dev.set_state_bounds((self.state_bounds[:, 0] - sc["y_offset"]) / sc["y_factor"],
+                                      (self.state_bounds[:, 1] - sc["y_offset"]) / sc["y_factor"])
 
     # ---- Kmpc.m:116-130 -------------------------------------------------------------------
     def expand_props(self):
@@ -77,6 +79,12 @@ class Kmpc:
             if b.shape[0] != m:
                 b = np.kron(np.ones((m, 1)), b)
             self.input_bounds = b
+        if self.state_bounds is not None:                                   # :126-129
+            n = self.params["n"]
+            sb = np.atleast_2d(np.asarray(self.state_bounds, dtype=np.float64))
+            if sb.shape[0] != n:
+                sb = np.kron(np.ones((n, 1)), sb)
+            self.state_bounds = sb
 
     # ---- Kmpc.m:135-152 --------------------------------------------------------------------
     def _ref_index(self):

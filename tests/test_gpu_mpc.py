@@ -279,3 +279,47 @@ def test_example_control_linear_first_input_matches_stored_run(ctx, golden):
     res = sim.run_trial_mpc(golden["blockM_ref"]["y"][:12], None, None)       # first call sees rows 1..11, unpadded
     assert np.abs(res["U"][1] - golden["arm_blockM"]["lin_U"][1]).max() < 1e-6
     assert np.abs(res["Y"][1] - golden["arm_blockM"]["lin_Y"][1]).max() < 1e-12
+
+
+@pytest.mark.parametrize("mt", ["linear", "bilinear"])
+@pytest.mark.parametrize("N,n,Np", [(3, 2, 8), (5, 2, 6), (4, 3, 5)])
+def test_state_bounds_match_literal_kmpc(ctx, mt, N, n, Np):
+    """State bounds (Kmpc.m:300-318 / :716-730) with the reference's placement of the kron block (first (Np+1) n columns
+    of the stacked lifted state, :306): dense, z-dependent rows assembled on the device against the oracle's literal
+    E, F, c -> L = F + E Bhat, M = E Ahat and the exact QP optimum."""
+    rng = np.random.default_rng(100 * N + Np)
+    m = 2
+    A = 0.9 * np.linalg.qr(rng.standard_normal((N, N)))[0] + 0.02 * rng.standard_normal((N, N))
+    B = 0.5 * rng.standard_normal((N, m)) if mt == "linear" else 0.5 * rng.standard_normal((N, N * m))
+    proj = np.hstack([np.eye(1), np.zeros((1, N - 1))])
+    lohi = np.stack([np.full(n, -0.55), np.full(n, 0.6)], axis=1)
+    s = ko.MpcSetup(model_type=mt, A=A, B=B, m=m, Np=Np, projmtx=proj, cost_running=1.0, cost_terminal=5.0, cost_input=np.array([0.05, 0.02]),
+                    input_bounds=np.tile([-1.0, 1.0], (m, 1)), slope_lim=0.4, smooth_lim=None, state_bounds=lohi, n=n)
+    mpc = make_mpc(ctx, s)
+    mpc.set_state_bounds(lohi[:, 0], lohi[:, 1])
+    hit = 0
+    for trial in range(10):
+        z = 0.15 * rng.standard_normal(N); z[-1] = 0.5
+        u_prev = 0.2 * rng.standard_normal(m)
+        ref = np.full((Np + 1, 1), 0.8 * (-1) ** trial)
+        U, st = mpc.step(z, u_prev, ko.pad_ref(ref, Np))
+        Hr, fr, Ar, br = ko.mpc_qp(s, z, u_prev, ref)
+        x, lam, ok = ko.qp_solve(Hr, fr, Ar, br)
+        if not ok:
+            assert st != 0 and np.isnan(U).all()                      # infeasible state bounds: NaN like the Gurobi shim
+            continue
+        assert st == 0
+        assert np.abs(U - x.reshape(Np, m)).max() < 1e-8
+        # do the state-bound rows matter for this problem?
+        s0 = ko.MpcSetup(**{**s.__dict__, "state_bounds": None})
+        H0, f0, A0, b0 = ko.mpc_qp(s0, z, u_prev, ref)
+        x0, _, ok0 = ko.qp_solve(H0, f0, A0, b0)
+        hit += ok0 and np.abs(x0 - x).max() > 1e-6
+    if (N, n, Np) == (3, 2, 8):
+        assert hit >= 1                                                 # here the bounded entries reach step 5: the bounds do bind
+    with pytest.raises(kra.KoopmanHipError):
+        mpc.step_batch(np.zeros((2, N)), np.zeros((2, m)), np.zeros((2, Np + 1)))
+    mpc.set_state_bounds(None, None)
+    U, st = mpc.step(z, u_prev, ko.pad_ref(ref, Np))
+    x0, _, ok0 = ko.qp_solve(*ko.mpc_qp(ko.MpcSetup(**{**s.__dict__, "state_bounds": None}), z, u_prev, ref))
+    assert ok0 and np.abs(U - x0.reshape(Np, m)).max() < 1e-8
