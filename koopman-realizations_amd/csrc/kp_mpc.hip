@@ -624,6 +624,7 @@ struct MpcArgs {
   const double *A, *B, *P, *S0, *r, *Aq, *bq0, *Anorm;
   EllMat ell;
   int* warm;            // [1 + nvar] active set of the previous single-problem step (nullptr: cold start)
+  int assemble_only;    // stop after the QP data have been exported (state-bound steps solve with the generic QP kernel)
   const double* z;      // [nb][N]      (or nullptr with zeta)
   const double* zeta;   // [nb][nzeta]  (fused lift)
   const double* u_prev; // [nb][m]
@@ -786,6 +787,7 @@ __global__ __launch_bounds__(256) void kp_mpc_step_kernel(MpcArgs a) {
       for (int e = tid; e < nv; e += 256) ex[nv * nv + e] = f[e];
       for (int e = tid; e < nr; e += 256) ex[nv * nv + nv + e] = bq[e];
     }
+    if (a.assemble_only) return;                 // (uniform) H, f, b are in qp_export, z in z_out
     // ---- QP by wave 0 ----
     if (stamps && tid == 0) stamps[3] = wall_clock64();
     double* xout = a.U + (size_t)pb * nv;
@@ -1199,6 +1201,7 @@ static int mpc_run(kp_mpc* M, const kp_basis* basis, int nb, const double* z, co
   a.U = zc ? M->h_out : M->d_out;
   a.z_out = a.U + (size_t)nb * nv;
   a.qp_export = nb == 1 ? M->work : nullptr;
+  a.assemble_only = M->sb_n > 0 ? 1 : 0;
   static const bool no_warm = getenv("KP_MPC_NO_WARM") != nullptr;
   if (!M->warm) {
     KP_HIP(ctx, hipMalloc((void**)&M->warm, (size_t)(1 + nv) * sizeof(int)));
@@ -1221,8 +1224,8 @@ static int mpc_run(kp_mpc* M, const kp_basis* basis, int nb, const double* z, co
   else hipLaunchKernelGGL(kp_mpc_step_kernel<false>, dim3(nb), dim3(256), lds, ctx->stream, a);
   KP_HIP(ctx, hipGetLastError());
   if (M->sb_n > 0) {
-    // the step kernel above has assembled H, f and the right-hand sides of the constant rows (its own solution, without
-    // the state bounds, is discarded): dense constraint matrix of this step, then the generic QP kernel
+    // the step kernel above has assembled H, f and the right-hand sides of the constant rows and stopped there:
+    // dense constraint matrix of this step, then the generic QP kernel
     const int mr = nr + M->sb_rows;
     double* bd = M->sb_b;
     double* nrm = bd + mr;
