@@ -216,3 +216,35 @@ def test_fit_refine_reaches_qr_accuracy(ctx, arm, mt, deg, steps, tol):
     scale = max(1.0, np.abs(Kq).max())
     assert np.abs(K1 - Kq).max() <= tol * scale
     assert np.abs(K1 - Kq).max() <= np.abs(K0 - Kq).max()          # never worse than the unrefined solution
+
+
+@pytest.mark.parametrize("mt,Ns", [("bilinear", 1_000_000), ("linear", 1_000_000), ("nonlinear", 400_000)])
+def test_large_snapshot_counts_by_size_independent_properties(ctx, mt, Ns):
+    """Scaling sizes of SURVEY 8(d) (1e6 pairs) where the oracle is too slow to run: (1) Gram over a concatenation = sum
+    of the Grams of the parts; (2) exact snapshot count in the constant observable; (3) the fit recovers the generating
+    model: the data are produced by a random K_true in the lifted space restricted to the state rows, so the first nzeta
+    columns of the fitted K reproduce it."""
+    dic = ko.build_dictionary(mt, 6, 3, ["poly"], [3 if mt != "nonlinear" else 2])
+    b = make_basis(ctx, dic)
+    rng = np.random.default_rng(11)
+    alpha = rng.uniform(-1, 1, (Ns, 6)); u = rng.uniform(-1, 1, (Ns, 3))
+    # exact linear-in-the-dictionary dynamics for the state rows: beta = Px @ Kt (no noise), Kt small
+    probe = ko.lift_rows(dic, alpha[:2000], u[:2000])
+    Kt = 0.02 * rng.standard_normal((probe.shape[1], 6)) / np.sqrt(probe.shape[1])
+    chunks = [slice(i, min(i + 200_000, Ns)) for i in range(0, Ns, 200_000)]
+    beta = np.vstack([ko.lift_rows(dic, alpha[c], u[c]) @ Kt for c in chunks])
+    sA = kra.Snapshots(ctx, alpha, beta, u)
+    G, C = kra.fit_gram(ctx, b, sA)
+    Gs = np.zeros_like(G); Cs = np.zeros_like(C)
+    for c in chunks:
+        sc = kra.Snapshots(ctx, alpha[c], beta[c], u[c])
+        g1, c1 = kra.fit_gram(ctx, b, sc)
+        Gs += g1; Cs += c1
+        sc.close()
+    assert np.abs(G - Gs).max() <= 1e-12 * np.abs(G).max()
+    assert np.abs(C - Cs).max() <= 1e-12 * np.abs(G).max()
+    assert G[dic.N - 1, dic.N - 1] == float(Ns)
+    assert np.array_equal(G, G.T)
+    K = kra.fit(ctx, b, sA)[0]
+    assert np.abs(K[:, :6] - Kt).max() < 1e-9
+    sA.close()
