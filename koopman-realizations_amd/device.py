@@ -95,6 +95,15 @@ class Context:
                                                st.ctypes.data_as(C.POINTER(C.c_int))), self._h)
         return A.transpose(0, 2, 1), B[:, :m].transpose(0, 2, 1), st
 
+    def sym_eig(self, S):
+        """kp_sym_eig: eigenvalues (descending) and eigenvectors (columns) of a symmetric matrix, on the device."""
+        S = F.fcol(np.array(S, dtype=np.float64))
+        n = S.shape[0]
+        V = np.zeros((n, n), order="F"); lam = np.zeros(n); sw = C.c_int()
+        F.check(F.lib().kp_sym_eig(self._h, F.dptr(S), n, F.dptr(V), F.dptr(lam), C.byref(sw)), self._h)
+        order = np.argsort(-lam, kind="stable")
+        return lam[order], np.asfortranarray(V[:, order]), sw.value
+
     def rollout_nl_batch(self, basis, Kf, zeta0, U):
         """Batched nonlinear rollouts: Kf (nb, nzeta, N), zeta0 (nb, nzeta), U (nb, T, m) -> Z (nb, T, nzeta)."""
         nb, nz, N = Kf.shape

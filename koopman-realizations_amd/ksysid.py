@@ -125,6 +125,7 @@ class Ksysid:
         self.model_type = "linear"; self.loaded = False; self.time_type = "discrete"; self.dim_red = False
         self.ls_refine = 1     # (not a reference property) refinement steps after the normal-equations solve: `\` is a QR solve
         self._host_only = bool(kwargs.pop("_host_only", False))           # sweeps: scaling / pairs only, no device dictionary
+        self._pca_host = bool(kwargs.pop("_pca_host", False))             # cross-check: pca by host SVD of the lifted matrix
         for k, v in kwargs.items():                                        # parse_args :147-158
             if not hasattr(self, k):
                 raise AttributeError(f"unknown Ksysid property {k}")
@@ -160,7 +161,7 @@ class Ksysid:
         self.traindata = self.get_scale(merged)                            # :122
         self.valdata = [self.scale_data(v) for v in data4sysid["val"]]    # :123-126
         self.snapshotPairs = self.get_snapshotPairs(self.traindata, self.snapshots)   # :134
-        Px = self.lift_snapshots(self.snapshotPairs) if self.dim_red else None       # :137-141
+        Px = self.lift_snapshots(self.snapshotPairs) if (self.dim_red and self._pca_host) else None   # :137-141
         self.get_econ_observables(Px)                                      # :142
         self.lift = _Lift(self)
 
@@ -360,26 +361,43 @@ class Ksysid:
         u = snapshotPairs["u"] if self.model_type == "nonlinear" else None
         return self.basis_dev.lift(F.LIFT_FULL, snapshotPairs["alpha"], u)
 
-    def get_econ_observables(self, Px):
-        """Ksysid.m:1435-1577.  `pca` is a host toolbox call in the reference (:1498) and stays
-        a host call here (LAPACK SVD of the device-lifted matrix): centred economy SVD, sign
-        convention of MATLAB's pca (largest-magnitude entry of each column positive)."""
+    def get_econ_observables(self, Px=None):
+        """Ksysid.m:1435-1577.  `pca` (Statistics toolbox, :1498) = principal axes of the centred lifted snapshots:
+        eigenvectors of their covariance.  The covariance comes from the fused Gram kernel on the full dictionary (its
+        constant column carries the column sums, so the Ns x Nfull lifted matrix is not needed) and is diagonalised on
+        the device (kp_sym_eig, parallel Jacobi); sign convention of MATLAB's pca (largest-magnitude entry of each
+        column positive), `explained` and the 99 % cut (:1501-1504) as in the reference.
+        (`Px` given: the host LAPACK SVD of the lifted matrix instead - kept for cross-checks.)"""
         p = self.params
         if not self.dim_red:
             self.basis["pcs"] = None
             return
-        Xc = Px - Px.mean(axis=0)
-        _, s, vt = np.linalg.svd(Xc, full_matrices=False)
-        coeff = vt.T
+        if Px is not None:
+            Xc = Px - Px.mean(axis=0)
+            _, sv, vt = np.linalg.svd(Xc, full_matrices=False)
+            coeff, latent = vt.T, sv ** 2
+        else:
+            sp = self.snapshotPairs
+            snaps = Snapshots(self.ctx, sp["alpha"], sp["beta"], sp["u"])
+            try:
+                G, _ = fit_gram(self.ctx, self.basis_dev, snaps)          # full dictionary: Psi'Psi is the leading block
+            finally:
+                snaps.close()
+            Nf = self.basis_dev.nfull
+            Gf = G[:Nf, :Nf]
+            cnt = Gf[Nf - 1, Nf - 1]                                     # constant observable: number of snapshots
+            sums = Gf[:, Nf - 1]
+            cov = (Gf - np.outer(sums, sums) / cnt) / (cnt - 1.0)
+            latent, coeff, _ = self.ctx.sym_eig(cov)
+            latent = np.maximum(latent, 0.0)
         sign = np.sign(coeff[np.argmax(np.abs(coeff), axis=0), np.arange(coeff.shape[1])])
         sign[sign == 0] = 1.0
         coeff = coeff * sign
-        latent = s ** 2
         explained = 100.0 * latent / latent.sum()
         num_pcs = 1
         while explained[:num_pcs].sum() < 99:                              # :1501-1504
             num_pcs += 1
-        pcs = coeff[:, :num_pcs]
+        pcs = np.ascontiguousarray(coeff[:, :num_pcs])
         self.basis["pcs"] = pcs
         self.basis_dev.close()
         self.basis_dev = Basis(self.ctx, self.model_type, p["nzeta"], p["m"], self._blocks, pcs)
