@@ -14,9 +14,16 @@ Parity pinning (see DESIGN.md "Oracle"):
     definition is restated: unique least-squares solution of a full-rank system,
     unique optimum of a strictly convex QP, centred economy SVD with MATLAB's sign
     convention.  The fitted-model files are missing from the checkout
-    (.MISSING_LARGE_BLOBS:14-16) and the stored U sequences are not reproducible,
-    so for A/B/Bi and the MPC input sequence this oracle is "parity unpinned by
-    artifacts": it is pinned by mathematics (uniqueness + KKT residual checks).
+    (.MISSING_LARGE_BLOBS:14-16), but the stored closed-loop INPUT sequences
+    (res_bilin.U, res_lin.U, 301x3) PIN the chain fit -> get_model/get_BLmodel ->
+    cost/constraint assembly -> quadprog end to end: replayed teacher-forced (state
+    Y(k), previous input U(k), reference rows k..k+Np; example_control.m settings with
+    input_bounds = [] - the stored inputs leave the +-7pi/8 box) this oracle returns
+    the stored U(k+1) with median deviation 3.1e-7 (bilinear) / 3.2e-8 (linear) over
+    all 299 steps, and on every step MATLAB's input is an optimum of the restated QP
+    to 3e-8 relative cost (tests/test_oracle_golden.py::test_stored_matlab_*).
+    The lasso `quadprog` (Ksysid.m:1169) has no stored artefact: "parity unpinned by
+    artefacts" for that row only (pinned by KKT residuals of the convex problem).
 
 Every function cites the reference file:line it follows.  Layout conventions are
 MATLAB's: rows = snapshots / time steps, matrices are what the .m file builds.

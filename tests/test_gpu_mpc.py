@@ -1,8 +1,9 @@
 """GPU parity tests (through the C ABI) of the MPC step: QP assembly and QP solve.
 Oracle: oracle/koopman_oracle.py — the LITERAL assembly of Kmpc.m (Bhat rebuilt from dense
 matrix powers, H = B'C'QCB + R, ...) and an exact dual active-set QP solve (the reference's
-quadprog is a MathWorks built-in; its stored U sequences are not reproducible, so parity is
-pinned by the uniqueness of the optimum of a strictly convex QP: KKT residual checks).
+quadprog is a MathWorks built-in).  Pinned to MATLAB's own outputs by the teacher-forced replay of the
+stored res_bilin.U / res_lin.U sequences (last test of this file and tests/test_oracle_golden.py), and by
+the uniqueness of the optimum of a strictly convex QP (KKT residual checks) everywhere else.
 Tolerances (f64): QP data 1e-11 relative; U 1e-8 absolute (inputs are O(1))."""
 import numpy as np
 import pytest
@@ -323,3 +324,46 @@ def test_state_bounds_match_literal_kmpc(ctx, mt, N, n, Np):
     U, st = mpc.step(z, u_prev, ko.pad_ref(ref, Np))
     x0, _, ok0 = ko.qp_solve(*ko.mpc_qp(ko.MpcSetup(**{**s.__dict__, "state_bounds": None}), z, u_prev, ref))
     assert ok0 and np.abs(U - x0.reshape(Np, m)).max() < 1e-8
+
+
+@pytest.mark.parametrize("mt,key,max_tol", [("bilinear", "bilin", 1e-3), ("linear", "lin", 5e-3)])
+def test_stored_matlab_input_sequences_replayed_teacher_forced_on_device(ctx, golden, mt, key, max_tol):
+    """The reference's stored closed loops (res_bilin.U / res_lin.U, produced by MATLAB's `\\` and quadprog) replayed
+    through the product path: device fit (Ksysid mirror: fused Gram + Cholesky + refinement) -> get_model / get_BLmodel
+    -> kp_mpc_create -> one kp_mpc_step_zeta per stored state.  At step k the controller sees Y(k), U(k) and the
+    reference rows k..k+Np (Ksim.m:153-166, :198-202) and must return the stored U(k+1) (:225-228).  The stored inputs
+    leave example_control.m's +-7 pi/8 box, so those runs had input_bounds = []; everything else is example_control.m.
+    Same tolerances as the oracle's replay (tests/test_oracle_golden.py): median < 1e-6, max set by the steps on which
+    the QP is flat along the deviation; and the device must agree with the oracle's exact optimum to 1e-7 throughout."""
+    g = golden["arm_data"]
+    lens = g["train_len"]; off = np.concatenate([[0], np.cumsum(lens)])
+    train = [{"t": g["train_t"][a:b], "y": g["train_y"][a:b], "u": g["train_u"][a:b]} for a, b in zip(off[:-1], off[1:])]
+    val = [{"t": g["val_t"], "y": g["val_y"], "u": g["val_u"]}]
+    ks = kra.Ksysid({"train": train, "val": val}, ctx=ctx, model_type=mt, obs_type=["poly"], obs_degree=[3],
+                    snapshots=np.inf, lasso=[np.inf], delays=0, dim_red=True).train_models()
+    mpc = kra.Kmpc(ks, horizon=10, input_bounds=[], input_slopeConst=1e-1, input_smoothConst=None, state_bounds=[],
+                   cost_running=10, cost_terminal=100, cost_input=0.1 * np.array([3e-2, 2e-2, 1e-2]),
+                   projmtx=ks.model["C"][-2:, :])
+    r = golden["arm_blockM"]
+    Y, U = r[key + "_Y"], r[key + "_U"]
+    ref_sc = mpc.scaledown_ref(golden["blockM_ref"]["y"])
+    sc = ks.params["scale"]
+    s = ko.MpcSetup(model_type=mt, A=ks.model["A"], B=ks.model["B"], m=3, Np=10, projmtx=ks.model["C"][-2:, :], cost_running=10.0,
+                    cost_terminal=100.0, cost_input=0.1 * np.array([3e-2, 2e-2, 1e-2]), input_bounds=None,
+                    slope_lim=1e-1 * sc["u_factor"].mean(), smooth_lim=None, n=6)
+    d = np.empty(299); dz = 0.0; dor = 0.0
+    step = mpc.get_mpcInput if mt == "linear" else (lambda c, rh: mpc.get_mpcInput_bilinear_iter(c, rh, 1))
+    for k in range(299):
+        cur = {"y": ks.scaledown_y(Y[k])[None, :], "u": ks.scaledown_u(U[k])[None, :]}
+        Uk, z = step(cur, ref_sc[k:k + 11])
+        assert not np.isnan(Uk).any()
+        d[k] = np.abs(ks.scaleup_u(Uk[1]) - U[k + 1]).max()
+        dz = max(dz, np.abs(z - r[key + "_Z"][k]).max())                       # stored lifted state (Ksim.m:256)
+        if k % 10 == 0:
+            Uo, _ = ko.mpc_step(s, z, cur["u"][0], ref_sc[k:k + 11])
+            dor = max(dor, np.abs(Uo - Uk).max())
+    assert dz < 1e-11, dz
+    assert dor < 1e-7, dor
+    assert np.median(d) < 1e-6, np.median(d)
+    assert d.max() < max_tol, (d.max(), int(d.argmax()))
+    assert (d < 1e-5).sum() >= 245
