@@ -151,10 +151,16 @@ int kp_fit_get_K(kp_ctx* ctx, int index, int W, double* K);
 int kp_fit_refine(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* snaps, int steps, double* K);
 /* kp_fit with K_out == NULL and one least-squares value is ASYNCHRONOUS: it returns when the work is
  * enqueued; the solve runs on a second HIP stream so that it overlaps the fused Gram kernel of the
- * next kp_fit call (sweeps over many fits: lasso grids, random systems).  kp_synchronize waits for
- * everything in flight and returns KP_ERR_NOT_SPD if a deferred fit failed; kp_fit_get_K,
- * kp_fit_gram, kp_fit_solve and kp_destroy synchronise implicitly. */
+ * next kp_fit call (sweeps over many fits, train_models loop Ksysid.m:1372-1387 / evaluate_rand_models.m:45-144).
+ * kp_synchronize waits for everything in flight and returns KP_ERR_NOT_SPD if a deferred fit failed; kp_fit_get_K,
+ * kp_fit_gram, kp_fit_solve and kp_destroy synchronise implicitly.
+ * The fits issued since the previous kp_synchronize form a BATCH; fit number q of the batch keeps its K in slot
+ * q mod n_slots of a device ring, and kp_fit_get_K(ctx, q, W, K) fetches it after the batch (the last n_slots fits are
+ * retrievable; n_slots defaults to 64, kp_fit_async_slots changes it - 8 W^2 bytes of HBM per slot).  A fit with
+ * another dictionary, width or snapshot count than the fits in flight drains the pipeline first (its buffers are
+ * shared), which also closes the batch. */
 int kp_synchronize(kp_ctx* ctx);
+int kp_fit_async_slots(kp_ctx* ctx, int n_slots);
 
 /* Batched small fits (evaluate_rand_models.m:45-144: one Ksysid fit per random system): nb independent systems
  * with the same dictionary, W <= 16, no dimension reduction, least squares (lasso = Inf, Ksysid.m:1068-1069).

@@ -50,6 +50,7 @@ SIGNATURES = {
     "kp_fit_lasso": (C.c_int, [vp, c_dp, c_dp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double, c_dp, c_ip]),
     "kp_fit": (C.c_int, [vp, vp, vp, c_dp, C.c_int, c_dp]),
     "kp_synchronize": (C.c_int, [vp]),
+    "kp_fit_async_slots": (C.c_int, [vp, C.c_int]),
     "kp_fit_get_K": (C.c_int, [vp, C.c_int, C.c_int, c_dp]),
     "kp_fit_batch": (C.c_int, [vp, vp, vp, C.c_int, C.c_int64, c_dp, c_dp, c_dp, C.POINTER(C.c_int)]),
     "kp_fit_refine": (C.c_int, [vp, vp, vp, C.c_int, c_dp]),

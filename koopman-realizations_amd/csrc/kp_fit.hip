@@ -522,7 +522,6 @@ extern "C" int kp_fit(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* sn
   KP_HIP(ctx, hipSetDevice(ctx->device));
   const int W = basis->dev.W, N = basis->dev.N;
   int rc = ensure_gc(ctx, W);
-  if (!rc) rc = ensure_kres(ctx, W, n_lasso);
   if (rc) return rc;
   const bool all_ls = [&] {
     for (int i = 0; i < n_lasso; ++i)
@@ -533,6 +532,23 @@ extern "C" int kp_fit(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* sn
     // ---- asynchronous pipeline: this fit's solve (stream2) overlaps the next fit's Gram (stream) ----
     // two [G | C] buffers alternate, so this Gram's reduction only has to wait for the pad kernel (the solve's
     // copy of G | C) of the fit before the previous one -- never for the solve that is running right now
+    // the two G | C halves and the split-partial buffers are addressed with THIS call's W and partial size: fits in
+    // flight with another dictionary or snapshot count would overlap them, so such a change drains the pipeline first
+    if (ctx->async_pending && (ctx->pend_basis != (const void*)basis || ctx->pend_Ns != snaps->Ns || ctx->pend_W != W)) {
+      rc = kp_synchronize(ctx);
+      if (rc) return rc;
+    }
+    if (ctx->batch_closed) {
+      ctx->async_count = 0;
+      ctx->batch_closed = false;
+    }
+    rc = ensure_kres(ctx, W, ctx->kring_cap);
+    if (rc) return rc;
+    ctx->kres_is_ring = true;
+    ctx->pend_basis = (const void*)basis;
+    ctx->pend_Ns = snaps->Ns;
+    ctx->pend_W = W;
+    double* Kslot = ctx->Kres + (size_t)(ctx->async_count % ctx->kring_cap) * W * W;
     const int flip = ctx->gc_flip;
     ctx->gc_flip ^= 1;
     double* GCb = ctx->GC + (size_t)flip * 2 * W * W;
@@ -557,9 +573,10 @@ extern "C" int kp_fit(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* sn
       KP_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_gram_done, 0));
     }
     KP_HIP(ctx, hipEventRecord(ctx->ev_solve0, ctx->stream2));
-    rc = kp_chol_solve_dev(ctx, GCb, GCb + (size_t)W * W, W, W, ctx->Kres, ctx->stream2, evp, ctx->sticky_info);
+    rc = kp_chol_solve_dev(ctx, GCb, GCb + (size_t)W * W, W, W, Kslot, ctx->stream2, evp, ctx->sticky_info);
     if (rc) return rc;
     KP_HIP(ctx, hipEventRecord(ctx->ev_solve1, ctx->stream2));
+    ++ctx->async_count;
     pend = true;
     ctx->async_pending = true;
     return KP_OK;
@@ -568,7 +585,11 @@ extern "C" int kp_fit(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* sn
     rc = kp_synchronize(ctx);
     if (rc) return rc;
   }
+  rc = ensure_kres(ctx, W, n_lasso);
+  if (rc) return rc;
   ctx->reserve_cus = 0;
+  ctx->kres_is_ring = false;
+  ctx->batch_closed = true;
   rc = kp_gram_dispatch(ctx, basis, snaps, ctx->GC);  // records ev0/ev1 around gram+reduce
   if (rc) return rc;
   double* Gd = ctx->GC;
@@ -626,17 +647,39 @@ extern "C" int kp_synchronize(kp_ctx* ctx) {
   ctx->async_pending = false;
   ctx->pad_pending = false;
   ctx->pad_pending2 = false;
+  ctx->batch_closed = true;
   if (bad) return ctx->fail(KP_ERR_NOT_SPD, "kp_synchronize: a deferred fit hit a Gram matrix that is not numerically positive definite");
   return KP_OK;
 }
 
 extern "C" int kp_fit_get_K(kp_ctx* ctx, int index, int W, double* K) {
-  if (!ctx || !K || index < 0 || index >= ctx->Kres_n || W != ctx->Kres_W) return ctx ? ctx->fail(KP_ERR_ARG, "kp_fit_get_K: bad argument") : KP_ERR_ARG;
+  if (!ctx || !K || index < 0 || W != ctx->Kres_W) return ctx ? ctx->fail(KP_ERR_ARG, "kp_fit_get_K: bad argument") : KP_ERR_ARG;
   KP_HIP(ctx, hipSetDevice(ctx->device));
   {
     int rc = kp_synchronize(ctx);
     if (rc) return rc;
   }
-  KP_HIP(ctx, hipMemcpy(K, ctx->Kres + (size_t)index * W * W, (size_t)W * W * 8, hipMemcpyDeviceToHost));
+  size_t slot = (size_t)index;
+  if (ctx->kres_is_ring) {
+    // asynchronous batch: fit number `index` since the previous kp_synchronize; the ring keeps the last kring_cap of them
+    if (index >= ctx->async_count || index < ctx->async_count - ctx->kring_cap)
+      return ctx->fail(KP_ERR_ARG, "kp_fit_get_K: that fit of the asynchronous batch is not (or no longer) in the result ring "
+                                   "(kp_fit_async_slots sets its size)");
+    slot = (size_t)(index % ctx->kring_cap);
+  } else if (index >= ctx->Kres_n) {
+    return ctx->fail(KP_ERR_ARG, "kp_fit_get_K: index out of range");
+  }
+  KP_HIP(ctx, hipMemcpy(K, ctx->Kres + slot * W * W, (size_t)W * W * 8, hipMemcpyDeviceToHost));
+  return KP_OK;
+}
+
+extern "C" int kp_fit_async_slots(kp_ctx* ctx, int n_slots) {
+  if (!ctx || n_slots < 1 || n_slots > (1 << 20)) return ctx ? ctx->fail(KP_ERR_ARG, "kp_fit_async_slots: bad argument") : KP_ERR_ARG;
+  int rc = kp_synchronize(ctx);
+  if (rc) return rc;
+  ctx->kring_cap = n_slots;
+  ctx->kres_is_ring = false;   // whatever the ring held is addressed with the old size: start over
+  ctx->Kres_n = 0;
+  ctx->async_count = 0;
   return KP_OK;
 }

@@ -21,6 +21,15 @@ struct kp_ctx {
   hipEvent_t ev_gram_done = nullptr, ev_pad_done = nullptr, ev_pad_done2 = nullptr, ev_solve0 = nullptr, ev_solve1 = nullptr;
   bool pad_pending = false, pad_pending2 = false, async_pending = false;
   int gc_flip = 0;             // asynchronous fits alternate between the two halves of GC
+  // results of asynchronous fits: ring of kring_cap slots in Kres; fit number q of the current batch (the fits since
+  // the last kp_synchronize) lives in slot q % kring_cap
+  int kring_cap = 64;
+  int async_count = 0;         // asynchronous fits issued in the current batch
+  bool batch_closed = true;    // kp_synchronize closed the batch: the next asynchronous fit starts a new one
+  bool kres_is_ring = false;   // Kres currently holds an asynchronous batch (kp_fit_get_K indexes the ring)
+  const void* pend_basis = nullptr;   // dictionary / snapshot count / width of the fits in flight: a change drains the pipeline
+  int64_t pend_Ns = 0;
+  int pend_W = 0;
   // set by the asynchronous kp_fit around kp_gram_dispatch: the split-partial reduction runs on this stream
   // (after an event recorded behind the main Gram kernel) and the partial buffer `part_flip` is used
   hipStream_t reduce_stream = nullptr;

@@ -277,6 +277,7 @@ __global__ __launch_bounds__(256) void kp_rollout_kernel(int bilinear, const dou
       }
       sync();
     }
+    sync();   // the last step leaves the loop before its barrier: its Yc entries are read by other waves below
     for (int e = tid; e < n_out * tc; e += nth) {
       const int r = e / tc, tt = e - r * tc;
       Yb[(size_t)r * T + t0 + tt] = Yc[r * RO_TC + tt];

@@ -43,6 +43,17 @@ class Context:
         """Waits for asynchronous fits (fit(..., fetch=False)); raises if one of them failed."""
         F.check(F.lib().kp_synchronize(self._h), self._h)
 
+    def fit_async_slots(self, n_slots: int):
+        """Size of the result ring of asynchronous fits (fit(..., fetch=False)): the last n_slots fits of a batch stay
+        retrievable with fit_result(q)."""
+        F.check(F.lib().kp_fit_async_slots(self._h, int(n_slots)), self._h)
+
+    def fit_result(self, index: int, W: int):
+        """K of fit number `index` of the last batch of asynchronous fits (kp_fit_get_K); synchronises."""
+        K = np.zeros((W, W), order="F")
+        F.check(F.lib().kp_fit_get_K(self._h, int(index), int(W), F.dptr(K)), self._h)
+        return K
+
     def close(self):
         if self._h:
             F.lib().kp_destroy(self._h)

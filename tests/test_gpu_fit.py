@@ -173,23 +173,41 @@ def test_async_fit_pipeline_matches_synchronous_result(ctx):
     second stream); results and error reporting must equal the synchronous path."""
     dic = ko.build_dictionary("bilinear", 6, 3, ["poly"], [3])
     b = make_basis(ctx, dic)
-    sets = [synth_pairs(20000 + 1000 * i, seed=20 + i) for i in range(3)]
+    sets = [synth_pairs(20000, seed=20 + i) for i in range(3)] + [synth_pairs(23000, seed=30)]
     snaps = [kra.Snapshots(ctx, p["alpha"], p["beta"], p["u"]) for p in sets]
     Ksync = [kra.fit(ctx, b, s)[0] for s in snaps]
     W = b.W
-    for s, Kref in zip(snaps, Ksync):           # back-to-back async fits: each K fetched after the next was enqueued
+    tol = lambda Kref: 1e-11 * np.abs(Kref).max()
+    for s, Kref in zip(snaps, Ksync):           # one fit per batch: kp_fit_get_K synchronises, which closes the batch
         kra.fit(ctx, b, s, fetch=False)
-        K = np.zeros((W, W), order="F")
-        F.check(F.lib().kp_fit_get_K(ctx.handle, 0, W, F.dptr(K)), ctx.handle)
         # the async path leaves CUs free for the overlapped solve => different snapshot split, different
         # (still fixed) summation order of the partial Grams: equal to rounding, not bitwise
-        assert np.abs(K - Kref).max() <= 1e-11 * np.abs(Kref).max()
-    for s in snaps:
+        assert np.abs(ctx.fit_result(0, W) - Kref).max() <= tol(Kref)
+    # a batch of pipelined fits: EVERY K stays retrievable (ring of result slots), in issue order
+    for s in snaps[:3]:
         kra.fit(ctx, b, s, fetch=False)
     ctx.synchronize()
-    K = np.zeros((W, W), order="F")
-    F.check(F.lib().kp_fit_get_K(ctx.handle, 0, W, F.dptr(K)), ctx.handle)
-    assert np.abs(K - Ksync[-1]).max() <= 1e-11 * np.abs(Ksync[-1]).max()
+    for i in range(3):
+        assert np.abs(ctx.fit_result(i, W) - Ksync[i]).max() <= tol(Ksync[i])
+    with pytest.raises(kra.KoopmanHipError):
+        ctx.fit_result(3, W)                     # not part of the batch
+    # ring shorter than the batch: the oldest results are gone and say so
+    ctx.fit_async_slots(2)
+    for s in snaps[:3]:
+        kra.fit(ctx, b, s, fetch=False)
+    with pytest.raises(kra.KoopmanHipError) as e:
+        ctx.fit_result(0, W)
+    assert e.value.code == F.KP_ERR_ARG
+    for i in (1, 2):
+        assert np.abs(ctx.fit_result(i, W) - Ksync[i]).max() <= tol(Ksync[i])
+    ctx.fit_async_slots(64)
+    # another snapshot count while fits are in flight: the pipeline drains first (shared partial / G|C buffers are
+    # sized per call), which closes the batch; the new fit is number 0 of the next one
+    kra.fit(ctx, b, snaps[0], fetch=False)
+    kra.fit(ctx, b, snaps[3], fetch=False)
+    kra.fit(ctx, b, snaps[3], fetch=False)
+    assert np.abs(ctx.fit_result(0, W) - Ksync[3]).max() <= tol(Ksync[3])
+    assert np.abs(ctx.fit_result(1, W) - Ksync[3]).max() <= tol(Ksync[3])
     # deferred failure: a rank-deficient dictionary is reported by kp_synchronize
     z = np.zeros((64, 6)); u = np.random.default_rng(0).uniform(-1, 1, (64, 3))
     bad = kra.Snapshots(ctx, z, z, u)           # all-zero states: Gram is singular

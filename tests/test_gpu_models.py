@@ -84,6 +84,28 @@ def test_rollout_matches_oracle(ctx, arm, mt):
     assert (Yb[1] == Y).all() and (Yb[2] == Y).all()
 
 
+@pytest.mark.parametrize("mt", ["linear", "bilinear"])
+def test_rollout_wide_models_last_row_many_repetitions(ctx, mt):
+    """The 256-thread rollout variant (N > 64) with n_out > 64: the last time step leaves the step loop before its
+    barrier, so the collected outputs of that step need their own barrier before other waves copy them out (a data race
+    in round 1).  Y[T-1] is checked over many repetitions and chunk-boundary lengths, T = 1 included."""
+    rng = np.random.default_rng(11)
+    N, m, n_out = 96, 2, 80
+    A = 0.95 * np.linalg.qr(rng.standard_normal((N, N)))[0]
+    B = 0.1 * rng.standard_normal((N, m)) if mt == "linear" else 0.02 * rng.standard_normal((N, N * m))
+    z0 = rng.uniform(-1, 1, N)
+    for T in (1, 2, 7, 256, 257, 300):
+        U = rng.uniform(-1, 1, (T, m))
+        z = z0.copy(); want = np.empty((T, n_out))
+        for t in range(T):
+            want[t] = z[:n_out]
+            Bz = B if mt == "linear" else B @ np.kron(np.eye(m), z[:, None])     # Ksysid.m:1285-1295
+            z = A @ z + Bz @ U[t]
+        for rep in range(40 if T in (1, 7, 257) else 3):
+            Y = ctx.rollout(mt, A, B, z0, U, n_out)
+            assert np.abs(Y - want).max() < 1e-10, (T, rep, np.abs(Y - want).max(axis=1).argmax())
+
+
 @pytest.mark.parametrize("mt", ["linear", "bilinear", "nonlinear"])
 def test_ksysid_mirror_example_sysid_flow(ctx, golden, arm, mt):
     """example_sysid.m:22-65 through the host mirror: constructor, train_models, val_*."""
