@@ -210,7 +210,7 @@ extern "C" int kp_model_project(kp_ctx* ctx, const double* K, const double* G, c
 template <bool ONE_WAVE>
 __global__ __launch_bounds__(256) void kp_rollout_kernel(int bilinear, const double* __restrict__ A, const double* __restrict__ B,
                                                          int N, int m, const double* __restrict__ z0, const double* __restrict__ U,
-                                                         int T, int n_out, double* __restrict__ Y, int stageA, int stageB) {
+                                                         int T, int n_out, double* __restrict__ Y, int stageA, int stageB, int tcmax) {
   extern __shared__ double sm[];
   double* zb = sm;                                   // [2][N]
   double* Ash = sm + 2 * N;
@@ -241,22 +241,22 @@ __global__ __launch_bounds__(256) void kp_rollout_kernel(int bilinear, const dou
     }
   };
   sync();
-  // time runs in chunks of RO_TC steps: the inputs of a chunk are staged in LDS and the outputs collected there, so no
+  // time runs in chunks of tcmax <= RO_TC steps (as many as the LDS left by the model holds): the inputs of a chunk are staged in LDS and the outputs collected there, so no
   // global-memory latency sits inside the serial recurrence
-  double* Uc = Bsh + (stageB ? N * mb : 0);          // [m][RO_TC]
-  double* Yc = Uc + m * RO_TC;                       // [n_out][RO_TC]
-  for (int t0 = 0; t0 < T; t0 += RO_TC) {
-    const int tc = min(RO_TC, T - t0);
+  double* Uc = Bsh + (stageB ? N * mb : 0);          // [m][tcmax]
+  double* Yc = Uc + m * tcmax;                       // [n_out][tcmax]
+  for (int t0 = 0; t0 < T; t0 += tcmax) {
+    const int tc = min(tcmax, T - t0);
     for (int e = tid; e < m * tc; e += nth) {
       const int i = e / tc, tt = e - i * tc;
-      Uc[i * RO_TC + tt] = Ub[(size_t)i * T + t0 + tt];
+      Uc[i * tcmax + tt] = Ub[(size_t)i * T + t0 + tt];
     }
     sync();
     for (int tt = 0; tt < tc; ++tt) {
       const int t = t0 + tt;
       const double* z = zb + (t & 1) * N;
       double* zn = zb + ((t + 1) & 1) * N;
-      for (int r = tid; r < n_out; r += nth) Yc[r * RO_TC + tt] = z[r];     // y = C z, C = [I 0] (Ksysid.m:1203)
+      for (int r = tid; r < n_out; r += nth) Yc[r * tcmax + tt] = z[r];     // y = C z, C = [I 0] (Ksysid.m:1203)
       if (t == T - 1) break;
       for (int r = tid; r < N; r += nth) {
         double s = 0.0;
@@ -268,10 +268,10 @@ __global__ __launch_bounds__(256) void kp_rollout_kernel(int bilinear, const dou
             double q = 0.0;
 #pragma unroll 4
             for (int c = 0; c < N; ++c) q += Bi[r + (size_t)c * N] * z[c];
-            s += q * Uc[i * RO_TC + tt];
+            s += q * Uc[i * tcmax + tt];
           }
         } else {
-          for (int i = 0; i < m; ++i) s += Bb[r + (size_t)i * N] * Uc[i * RO_TC + tt];
+          for (int i = 0; i < m; ++i) s += Bb[r + (size_t)i * N] * Uc[i * tcmax + tt];
         }
         zn[r] = s;
       }
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256) void kp_rollout_kernel(int bilinear, const dou
     sync();   // the last step leaves the loop before its barrier: its Yc entries are read by other waves below
     for (int e = tid; e < n_out * tc; e += nth) {
       const int r = e / tc, tt = e - r * tc;
-      Yb[(size_t)r * T + t0 + tt] = Yc[r * RO_TC + tt];
+      Yb[(size_t)r * T + t0 + tt] = Yc[r * tcmax + tt];
     }
     sync();
   }
@@ -309,7 +309,11 @@ extern "C" int kp_rollout(kp_ctx* ctx, int model_type, int batch, const double* 
   {
     const int stageA = (size_t)N * N <= RO_STAGE;
     const int stageB = stageA && (size_t)N * N + (size_t)N * mb <= RO_STAGE + RO_STAGE / 2;
-    const size_t lds = ((size_t)2 * N + (stageA ? (size_t)N * N : 0) + (stageB ? (size_t)N * mb : 0) + (size_t)(m + n_out) * RO_TC) * 8;
+    const size_t lds_model = ((size_t)2 * N + (stageA ? (size_t)N * N : 0) + (stageB ? (size_t)N * mb : 0)) * 8;
+    // input / output chunk: as many steps as fit beside the model in 128 KB (wide outputs get shorter chunks)
+    const int tcmax = (int)std::min<size_t>(RO_TC, (128 * 1024 - lds_model) / ((size_t)(m + n_out) * 8));
+    if (tcmax < 1) return ctx->fail(KP_ERR_ARG, "kp_rollout: model too large for the LDS staging");
+    const size_t lds = lds_model + (size_t)(m + n_out) * tcmax * 8;
     static bool attr = false;
     if (!attr) {
       KP_HIP(ctx, hipFuncSetAttribute((const void*)kp_rollout_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
@@ -317,9 +321,9 @@ extern "C" int kp_rollout(kp_ctx* ctx, int model_type, int batch, const double* 
       attr = true;
     }
     if (N <= 64)
-      hipLaunchKernelGGL(kp_rollout_kernel<true>, dim3(batch), dim3(64), lds, s, bil, dA, dB, N, m, dz, dU, T, n_out, dY, stageA, stageB);
+      hipLaunchKernelGGL(kp_rollout_kernel<true>, dim3(batch), dim3(64), lds, s, bil, dA, dB, N, m, dz, dU, T, n_out, dY, stageA, stageB, tcmax);
     else
-      hipLaunchKernelGGL(kp_rollout_kernel<false>, dim3(batch), dim3(256), lds, s, bil, dA, dB, N, m, dz, dU, T, n_out, dY, stageA, stageB);
+      hipLaunchKernelGGL(kp_rollout_kernel<false>, dim3(batch), dim3(256), lds, s, bil, dA, dB, N, m, dz, dU, T, n_out, dY, stageA, stageB, tcmax);
   }
   KP_HIP(ctx, hipGetLastError());
   KP_HIP(ctx, hipEventRecord(ctx->ev1, s));

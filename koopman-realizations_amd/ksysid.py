@@ -631,18 +631,18 @@ class Ksysid:
         return self._results(t, ureal, zs[:, :self.params["n"]], yreal)
 
     def get_error(self, simdata, realdata):
-        """Ksysid.m:1882-1898."""
+        """Ksysid.m:1882-1898.  Diverged rollouts give Inf / NaN errors silently, as MATLAB does."""
         ys, yr = simdata["y"], realdata["y"]
         T = len(realdata["t"])
-        d = ys - yr
-        err = {"abs": np.abs(d)}
-        err["mean"] = err["abs"].mean(axis=0)
-        err["rmse"] = np.sqrt((d ** 2).sum(axis=0) / T)
-        with np.errstate(divide="ignore", invalid="ignore"):
+        with np.errstate(over="ignore", divide="ignore", invalid="ignore"):
+            d = ys - yr
+            err = {"abs": np.abs(d)}
+            err["mean"] = err["abs"].mean(axis=0)
+            err["rmse"] = np.sqrt((d ** 2).sum(axis=0) / T)
             err["nrmse"] = err["rmse"] / np.abs(yr.max(axis=0) - yr.min(axis=0))
-        err["euclid"] = np.sqrt((d ** 2).sum(axis=1))
-        err["euclid_mean"] = err["euclid"].sum() / T
-        du = self.scaleup_y(ys) - self.scaleup_y(yr)
-        err["unscaled"] = {"euclid": np.sqrt((du ** 2).sum(axis=1))}
-        err["unscaled"]["euclid_mean"] = err["unscaled"]["euclid"].sum() / T
+            err["euclid"] = np.sqrt((d ** 2).sum(axis=1))
+            err["euclid_mean"] = err["euclid"].sum() / T
+            du = self.scaleup_y(ys) - self.scaleup_y(yr)
+            err["unscaled"] = {"euclid": np.sqrt((du ** 2).sum(axis=1))}
+            err["unscaled"]["euclid_mean"] = err["unscaled"]["euclid"].sum() / T
         return err

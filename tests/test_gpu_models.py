@@ -94,14 +94,14 @@ def test_rollout_wide_models_last_row_many_repetitions(ctx, mt):
     A = 0.95 * np.linalg.qr(rng.standard_normal((N, N)))[0]
     B = 0.1 * rng.standard_normal((N, m)) if mt == "linear" else 0.02 * rng.standard_normal((N, N * m))
     z0 = rng.uniform(-1, 1, N)
-    for T in (1, 2, 7, 256, 257, 300):
+    for T in (1, 2, 7, 197, 198, 256, 257, 400):     # chunk length here: 197 steps
         U = rng.uniform(-1, 1, (T, m))
         z = z0.copy(); want = np.empty((T, n_out))
         for t in range(T):
             want[t] = z[:n_out]
             Bz = B if mt == "linear" else B @ np.kron(np.eye(m), z[:, None])     # Ksysid.m:1285-1295
             z = A @ z + Bz @ U[t]
-        for rep in range(40 if T in (1, 7, 257) else 3):
+        for rep in range(40 if T in (1, 7, 198, 257) else 3):
             Y = ctx.rollout(mt, A, B, z0, U, n_out)
             assert np.abs(Y - want).max() < 1e-10, (T, rep, np.abs(Y - want).max(axis=1).argmax())
 
