@@ -141,6 +141,14 @@ int kp_fit_gram(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* snaps, d
 int kp_fit_solve(kp_ctx* ctx, const double* G, const double* C, int W, int ncols, double* K);
 int kp_fit_lasso(kp_ctx* ctx, const double* G, const double* C, int W, int ncols, double t,
                  int max_iter, double tol, double* K, int* iters);
+/* nv lasso values on the same Grams at once (the train_models loop over a lasso vector, Ksysid.m:1372-1387, re-lifts
+ * and re-solves per value; here the values share G, C, the least-squares solution and every G*[K_1..K_nv] product).
+ * t: nv budgets; K: nv matrices W x ncols back to back; iters: nv counts (may be NULL; 0 = constraint inactive).
+ * Each value ends either by convergence of the projected-gradient iteration (relative change <= tol) or, earlier, when
+ * the active-set candidate built from its current support satisfies every optimality condition of the QP of
+ * Ksysid.m:1126-1137 (then K is that QP's optimum to rounding).  KP_ERR_NOT_CONVERGED: iteration cap (K still written). */
+int kp_fit_lasso_batch(kp_ctx* ctx, const double* G, const double* C, int W, int ncols, const double* t, int nv,
+                       int max_iter, double tol, double* K, int* iters);
 int kp_fit(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* snaps, const double* lasso,
            int n_lasso, double* K_out);
 int kp_fit_get_K(kp_ctx* ctx, int index, int W, double* K);

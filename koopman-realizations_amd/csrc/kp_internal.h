@@ -239,3 +239,6 @@ struct kp_lasso_prep {
 };
 int kp_lasso_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, int W, int ncols, double t, int max_iter, double tol,
                  double* K_dev, int* iters, kp_lasso_prep* prep = nullptr);
+// all lasso values of one fit at once (one wide G*[K_1..K_nv] product per FISTA iteration, active-set polish)
+int kp_lasso_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, int W, int ncols, const double* t, int nv,
+                       int max_iter, double tol, double* const* K_dev, int* iters, kp_lasso_prep* prep = nullptr);

@@ -141,13 +141,17 @@ __global__ __launch_bounds__(256) void kp_pw_norm_kernel(const double* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
-// FISTA iteration kernels
+// FISTA iteration kernels.  All lasso values of one fit (train_models loop, Ksysid.m:1372-1387) run as ONE batch:
+// blockIdx.y = value; buffers hold nb matrices back to back, so G * [K_1 ... K_nb] is a single wide product.
 // ------------------------------------------------------------------------------------------------
 #define LS_NBLK 256
 struct LassoState {
   double tk, mom, theta, t, invL;
   double change, kmax, tot;
+  double pol_theta;                  // multiplier of the L1 row found by the active-set polish
+  unsigned long long pol_res;        // bits of max |g + theta sign(k)| on the support (non-negative double)
   int done, notconv, passes, maxpasses, restarts;
+  int pol_bad;                       // polish rejected: bit 0 sign flip / theta, bit 1 multiplier bound off the support, bit 2 column too dense / singular
   unsigned counter;
   double part[LS_NBLK][3];
 };
@@ -165,7 +169,7 @@ __device__ __forceinline__ void block_sum3(double& a, double& b, double& c, doub
   }
 }
 
-// true in exactly one workgroup: the last one to have published its partial
+// true in exactly one workgroup (of this value's row of the grid): the last one to have published its partial
 __device__ __forceinline__ bool last_block(LassoState* st) {
   __shared__ int is_last;
   if (threadIdx.x == 0) {
@@ -183,8 +187,11 @@ __device__ __forceinline__ bool last_block(LassoState* st) {
 __global__ __launch_bounds__(256) void kp_lasso_v_kernel(const double* __restrict__ Kc, const double* __restrict__ Ko,
                                                          const double* __restrict__ GKc, const double* __restrict__ GKo,
                                                          const double* __restrict__ C, int64_t n, double* __restrict__ V,
-                                                         LassoState* __restrict__ st) {
+                                                         LassoState* __restrict__ stv) {
   __shared__ double red[4][3];
+  LassoState* st = stv + blockIdx.y;
+  const int64_t o = (int64_t)blockIdx.y * n;
+  Kc += o; Ko += o; GKc += o; GKo += o; V += o;
   const double mom = st->mom, invL = st->invL, th0 = st->theta;
   double tot = 0.0, ss = 0.0, cc = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
@@ -217,9 +224,11 @@ __global__ __launch_bounds__(256) void kp_lasso_v_kernel(const double* __restric
 
 // one Newton step on f(theta) = sum max(|v| - theta, 0) - t  (Michelot: theta <- (sum_{|v|>theta} |v| - t) / #{|v|>theta});
 // after the first step the sequence increases monotonically and stops exactly at the fixed point
-__global__ __launch_bounds__(256) void kp_lasso_newton_kernel(const double* __restrict__ V, int64_t n, LassoState* __restrict__ st) {
+__global__ __launch_bounds__(256) void kp_lasso_newton_kernel(const double* __restrict__ V, int64_t n, LassoState* __restrict__ stv) {
   __shared__ double red[4][3];
+  LassoState* st = stv + blockIdx.y;
   if (st->done) return;
+  V += (int64_t)blockIdx.y * n;
   const double th = st->theta;
   double ss = 0.0, cc = 0.0, z = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
@@ -246,8 +255,11 @@ __global__ __launch_bounds__(256) void kp_lasso_newton_kernel(const double* __re
 // Kn = soft(V, theta); restart test <Y - Kn, Kn - K> > 0; momentum scalars for the next iteration
 __global__ __launch_bounds__(256) void kp_lasso_final_kernel(const double* __restrict__ V, const double* __restrict__ Kc,
                                                              const double* __restrict__ Ko, int64_t n, double* __restrict__ Kn,
-                                                             LassoState* __restrict__ st) {
+                                                             LassoState* __restrict__ stv) {
   __shared__ double red[4][3];
+  LassoState* st = stv + blockIdx.y;
+  const int64_t o = (int64_t)blockIdx.y * n;
+  V += o; Kc += o; Ko += o; Kn += o;
   const double th = st->theta, mom = st->mom;
   double dot = 0.0, chg = 0.0, kmx = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
@@ -295,6 +307,166 @@ __global__ __launch_bounds__(256) void kp_lasso_final_kernel(const double* __res
     st->counter = 0u;
   }
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Active-set polish.  FISTA identifies the support and the signs of the optimum long before it has converged; on a
+// fixed support S_j / sign pattern s_j per column the KKT system of the QP (Ksysid.m:1126-1137: stationarity
+// G k_j - c_j + theta s_j = 0 on S_j, one multiplier theta >= 0 for the L1 row, sum |k| = t) is LINEAR:
+//     k_j = a_j - theta b_j,   G_SS a_j = c_S,   G_SS b_j = s_j,   theta = (sum_j s_j'a_j - t) / (sum_j s_j'b_j).
+// The candidate is accepted only if it satisfies every optimality condition of the full problem (signs kept on the
+// support, |g| <= theta off the support, theta >= 0): then it IS the optimum, to rounding - what quadprog returns.
+// One wave per (value, column): nonzeros compacted in order, G_SS gathered into LDS, Cholesky + two substitutions.
+// ------------------------------------------------------------------------------------------------
+#define PL_CAP 64
+__global__ __launch_bounds__(64) void kp_lasso_polish_cols_kernel(const double* __restrict__ G, const double* __restrict__ C,
+                                                                  const double* __restrict__ Kc, int W, int ncols, int64_t n,
+                                                                  LassoState* __restrict__ stv, double* __restrict__ Ah,
+                                                                  double* __restrict__ Bh, double* __restrict__ pab) {
+  __shared__ double A[PL_CAP][PL_CAP + 1];
+  __shared__ int idx[PL_CAP];
+  LassoState* st = stv + blockIdx.y;
+  const int j = blockIdx.x, lane = threadIdx.x;
+  const int64_t o = (int64_t)blockIdx.y * n + (int64_t)j * W;
+  const double* k = Kc + o;
+  double* ah = Ah + o;
+  double* bh = Bh + o;
+  double* pj = pab + ((int64_t)blockIdx.y * ncols + j) * 2;
+  int cnt = 0;
+  double sg = 0.0;
+  for (int base = 0; base < W; base += 64) {
+    const int i = base + lane;
+    const double kv = i < W ? k[i] : 0.0;
+    const bool nz = kv != 0.0;
+    const unsigned long long mk = __ballot(nz);
+    const int pos = cnt + __popcll(mk & ((1ull << lane) - 1ull));
+    if (nz && pos < PL_CAP) idx[pos] = i;
+    cnt += __popcll(mk);
+    if (i < W) { ah[i] = 0.0; bh[i] = 0.0; }
+  }
+  if (cnt > PL_CAP) {
+    if (lane == 0) { atomicOr(&st->pol_bad, 4); pj[0] = 0.0; pj[1] = 0.0; }
+    return;
+  }
+  if (cnt == 0) {
+    if (lane == 0) { pj[0] = 0.0; pj[1] = 0.0; }
+    return;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  const bool act = lane < cnt;
+  const int ir = act ? idx[lane] : 0;
+  if (act) sg = k[ir] > 0.0 ? 1.0 : -1.0;
+  double ra = act ? C[ir + (size_t)j * W] : 0.0, rb = sg;
+  for (int c = 0; c < cnt; ++c) {
+    const int ic = idx[c];
+    if (act) A[lane][c] = G[ir + (size_t)ic * W];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  bool bad = false;
+  for (int kk = 0; kk < cnt; ++kk) {                  // right-looking Cholesky, lane r owns row r
+    const double d = A[kk][kk];
+    if (!(d > 0.0)) { bad = true; break; }
+    const double rinv = 1.0 / sqrt(d);
+    double lrk = 0.0;
+    if (lane > kk && act) { lrk = A[lane][kk] * rinv; A[lane][kk] = lrk; }
+    if (lane == kk) A[kk][kk] = sqrt(d);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (lane > kk && act)
+      for (int c = kk + 1; c <= lane; ++c) A[lane][c] -= lrk * A[c][kk];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
+  if (bad) {
+    if (lane == 0) { atomicOr(&st->pol_bad, 4); pj[0] = 0.0; pj[1] = 0.0; }
+    return;
+  }
+  for (int kk = 0; kk < cnt; ++kk) {                  // L y = rhs, both right-hand sides
+    const double dk = A[kk][kk];
+    const double ya = __shfl(ra, kk, 64) / dk, yb = __shfl(rb, kk, 64) / dk;
+    if (lane == kk) { ra = ya; rb = yb; }
+    if (lane > kk && act) { const double l = A[lane][kk]; ra -= l * ya; rb -= l * yb; }
+  }
+  for (int kk = cnt - 1; kk >= 0; --kk) {             // L'x = y
+    const double dk = A[kk][kk];
+    const double xa = __shfl(ra, kk, 64) / dk, xb = __shfl(rb, kk, 64) / dk;
+    if (lane == kk) { ra = xa; rb = xb; }
+    if (lane < kk) { const double l = A[kk][lane]; ra -= l * xa; rb -= l * xb; }
+  }
+  if (act) { ah[ir] = ra; bh[ir] = rb; }
+  const double pa = wave_sum(act ? sg * ra : 0.0), pb = wave_sum(act ? sg * rb : 0.0);
+  if (lane == 0) { pj[0] = pa; pj[1] = pb; }
+}
+
+// theta = (sum s'a - t) / (sum s'b) (every workgroup reduces the per-column sums in the same order), Kh = A - theta B,
+// sign test against the support pattern of Kc
+__global__ __launch_bounds__(256) void kp_lasso_polish_combine_kernel(const double* __restrict__ Ah, const double* __restrict__ Bh,
+                                                                      const double* __restrict__ Kc, const double* __restrict__ pab,
+                                                                      int ncols, int64_t n, double* __restrict__ Kh,
+                                                                      LassoState* __restrict__ stv) {
+  __shared__ double red[4][3];
+  __shared__ double th_sh;
+  LassoState* st = stv + blockIdx.y;
+  const int64_t o = (int64_t)blockIdx.y * n;
+  const double* pv = pab + (int64_t)blockIdx.y * ncols * 2;
+  double sa = 0.0, sb = 0.0, z = 0.0;
+  for (int j = threadIdx.x; j < ncols; j += 256) { sa += pv[2 * j]; sb += pv[2 * j + 1]; }
+  block_sum3(sa, sb, z, red);
+  if (threadIdx.x == 0) {
+    const double th = sb > 0.0 ? (sa - st->t) / sb : -1.0;
+    th_sh = th;
+    if (blockIdx.x == 0) {
+      st->pol_theta = th;
+      if (!(th >= 0.0)) atomicOr(&st->pol_bad, 1);
+    }
+  }
+  __syncthreads();
+  const double th = th_sh;
+  int flip = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const double kh = Ah[o + i] - th * Bh[o + i], kc = Kc[o + i];
+    Kh[o + i] = kh;
+    if (kc != 0.0 && !(kh * kc > 0.0)) flip = 1;
+  }
+  const int any_flip = __any(flip);
+  if (any_flip && (threadIdx.x & 63) == 0) atomicOr(&st->pol_bad, 1);
+}
+
+// optimality of the candidate on the FULL problem: g = G Kh - C; off the support |g| <= theta, on it g + theta s = 0
+__global__ __launch_bounds__(256) void kp_lasso_polish_check_kernel(const double* __restrict__ GKh, const double* __restrict__ C,
+                                                                    const double* __restrict__ Kc, int64_t n,
+                                                                    LassoState* __restrict__ stv) {
+  LassoState* st = stv + blockIdx.y;
+  const int64_t o = (int64_t)blockIdx.y * n;
+  const double th = st->pol_theta;
+  const double lim = th * (1.0 + 1e-9);
+  double ron = 0.0;
+  int off_bad = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const double g = GKh[o + i] - C[i], kc = Kc[o + i];
+    if (kc != 0.0) ron = fmax(ron, fabs(g + (kc > 0.0 ? th : -th)));
+    else if (fabs(g) > lim) off_bad = 1;
+  }
+  ron = wave_max(ron);
+  const int any_off = __any(off_bad);
+  if ((threadIdx.x & 63) == 0) {
+    if (ron > 0.0) atomicMax(&st->pol_res, (unsigned long long)__double_as_longlong(ron));
+    if (any_off) atomicOr(&st->pol_bad, 2);
+  }
+}
+
+// between check blocks: clears the per-block statistics of the running values
+__global__ void kp_lasso_ctl_kernel(LassoState* __restrict__ stv, int nb) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= nb) return;
+  LassoState* st = stv + v;
+  st->notconv = 0; st->maxpasses = 0; st->pol_bad = 0; st->pol_res = 0ull;
 }
 
 __global__ __launch_bounds__(256) void kp_l1norm_kernel(const double* __restrict__ K, int64_t n, double* out) {
@@ -352,8 +524,10 @@ int kp_lasso_prepare(kp_ctx* ctx, const double* G_dev, const double* C_dev, int 
   return KP_OK;
 }
 
-int kp_lasso_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, int W, int ncols, double t, int max_iter, double tol,
-                 double* K_dev, int* iters, kp_lasso_prep* prep) {
+// All lasso values of one fit as a batch.  t[v]: L1 budgets; K_dev[v]: device destinations (W x ncols each);
+// iters[v] (may be NULL): FISTA iterations spent on value v (0: the least-squares solution satisfies the constraint).
+int kp_lasso_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, int W, int ncols, const double* t, int nv,
+                       int max_iter, double tol, double* const* K_dev, int* iters, kp_lasso_prep* prep) {
   kp_lasso_prep local;
   if (!prep) prep = &local;
   if (!prep->ready) {
@@ -363,53 +537,108 @@ int kp_lasso_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, int W, i
   const int64_t n = (int64_t)W * ncols;
   const size_t bK = (size_t)n * 8;
   hipStream_t s = ctx->stream;
-  if (iters) *iters = 0;
-  if (!prep->bad && prep->l1_ls <= t) {
-    KP_HIP(ctx, hipMemcpyAsync(K_dev, prep->Kls, bK, hipMemcpyDeviceToDevice, s));
-    return KP_OK;
+  std::vector<int> act;                              // values whose L1 constraint is active
+  for (int v = 0; v < nv; ++v) {
+    if (iters) iters[v] = 0;
+    if (!prep->bad && prep->l1_ls <= t[v]) KP_HIP(ctx, hipMemcpyAsync(K_dev[v], prep->Kls, bK, hipMemcpyDeviceToDevice, s));
+    else act.push_back(v);
   }
-  // buffers: K x3 (old, current, new), GK x2, V, state
-  char* ws = (char*)ctx->workspace(7, 6 * bK + sizeof(LassoState) + 256);
+  const int nb = (int)act.size();
+  if (nb == 0) return KP_OK;
+  // buffers, nb matrices each: K x3 (old, current, new), GK x2, V, polish A / B / G Kh; per-column sums; states
+  const size_t bB = (size_t)nb * bK;
+  const size_t b_pab = (size_t)nb * ncols * 2 * 8, b_st = (size_t)nb * sizeof(LassoState);
+  char* ws = (char*)ctx->workspace(7, 9 * bB + b_pab + b_st + (size_t)nb * 4 + 512);
   if (!ws) return ctx->fail(KP_ERR_HIP, "kp_fit_lasso: out of device memory");
-  double* Kb[3] = {(double*)ws, (double*)(ws + bK), (double*)(ws + 2 * bK)};
-  double* GKb[2] = {(double*)(ws + 3 * bK), (double*)(ws + 4 * bK)};
-  double* V = (double*)(ws + 5 * bK);
-  LassoState* st = (LassoState*)(ws + 6 * bK);
-  KP_HIP(ctx, hipMemsetAsync(ws, 0, 5 * bK, s));                  // FISTA from K = 0
-  std::vector<char> hbuf(sizeof(LassoState), 0);
-  LassoState& h = *reinterpret_cast<LassoState*>(hbuf.data());
-  h.tk = 1.0; h.mom = 0.0; h.theta = 0.0; h.t = t; h.invL = 1.0 / prep->L; h.change = 1e300;
-  KP_HIP(ctx, hipMemcpyAsync(st, &h, sizeof(LassoState), hipMemcpyHostToDevice, s));
+  double* Kb[3] = {(double*)ws, (double*)(ws + bB), (double*)(ws + 2 * bB)};
+  double* GKb[2] = {(double*)(ws + 3 * bB), (double*)(ws + 4 * bB)};
+  double* V = (double*)(ws + 5 * bB);
+  double* Ah = (double*)(ws + 6 * bB);
+  double* Bh = (double*)(ws + 7 * bB);
+  double* GKh = (double*)(ws + 8 * bB);
+  double* pab = (double*)(ws + 9 * bB);
+  LassoState* st = (LassoState*)(ws + 9 * bB + b_pab);
+  KP_HIP(ctx, hipMemsetAsync(ws, 0, 5 * bB, s));                  // FISTA from K = 0
+  const size_t head = offsetof(LassoState, part);
+  std::vector<char> hbuf(b_st, 0);
+  auto hs = [&](int v) -> LassoState& { return *reinterpret_cast<LassoState*>(hbuf.data() + (size_t)v * sizeof(LassoState)); };
+  for (int v = 0; v < nb; ++v) {
+    LassoState& h = hs(v);
+    h.tk = 1.0; h.mom = 0.0; h.theta = 0.0; h.t = t[act[v]]; h.invL = 1.0 / prep->L; h.change = 1e300;
+  }
+  KP_HIP(ctx, hipMemcpyAsync(st, hbuf.data(), b_st, hipMemcpyHostToDevice, s));
   const int nblk = (int)std::min<int64_t>(LS_NBLK, (n + 255) / 256);
   int ko = 0, kc = 1, kn = 2, go = 0, gc = 1;     // roles of the buffers
   int P = 24;                                      // Newton passes launched per iteration (adapted every block)
   int it = 0;
-  const int check_every = 20;
-  bool converged = false;
-  struct Scal { double change, kmax; int notconv, maxpasses; };
-  while (it < max_iter) {
+  static const int check_every = [] { const char* e = getenv("KP_LASSO_CHECK"); return e ? std::max(1, atoi(e)) : 10; }();
+  static const bool polish = getenv("KP_LASSO_NO_POLISH") == nullptr;
+  // Values that have their answer leave the batch: the running values occupy slots [0, nba) of every buffer (the last
+  // running slot is moved into the hole), so the wide product and every grid shrink with the work that is left.
+  int nba = nb;
+  std::vector<int> slot_val(nb);
+  for (int v = 0; v < nb; ++v) slot_val[v] = act[v];
+  while (it < max_iter && nba > 0) {
+    const dim3 grid(nblk, nba);
     for (int c = 0; c < check_every && it < max_iter; ++c, ++it) {
-      hipLaunchKernelGGL(kp_lasso_v_kernel, dim3(nblk), dim3(256), 0, s, Kb[kc], Kb[ko], GKb[gc], GKb[go], C_dev, n, V, st);
-      for (int p = 0; p < P; ++p) hipLaunchKernelGGL(kp_lasso_newton_kernel, dim3(nblk), dim3(256), 0, s, V, n, st);
-      hipLaunchKernelGGL(kp_lasso_final_kernel, dim3(nblk), dim3(256), 0, s, V, Kb[kc], Kb[ko], n, Kb[kn], st);
-      // rotate: old <- current, current <- new; then the product of the new current
+      hipLaunchKernelGGL(kp_lasso_v_kernel, grid, dim3(256), 0, s, Kb[kc], Kb[ko], GKb[gc], GKb[go], C_dev, n, V, st);
+      for (int p = 0; p < P; ++p) hipLaunchKernelGGL(kp_lasso_newton_kernel, grid, dim3(256), 0, s, V, n, st);
+      hipLaunchKernelGGL(kp_lasso_final_kernel, grid, dim3(256), 0, s, V, Kb[kc], Kb[ko], n, Kb[kn], st);
+      // rotate: old <- current, current <- new; then the product of the new current (all values: one wide product)
       const int tmp = ko; ko = kc; kc = kn; kn = tmp;
       std::swap(go, gc);
-      KP_HIP(ctx, symm_gemm(s, prep->Gw, Kb[kc], W, ncols, GKb[gc]));
+      KP_HIP(ctx, symm_gemm(s, prep->Gw, Kb[kc], W, nba * ncols, GKb[gc]));
     }
-    KP_HIP(ctx, hipMemcpyAsync(&h, st, offsetof(LassoState, part), hipMemcpyDeviceToHost, s));
+    if (polish) {   // candidate from the current support / signs: Kh lands in the free "new" buffer
+      hipLaunchKernelGGL(kp_lasso_polish_cols_kernel, dim3(ncols, nba), dim3(64), 0, s, prep->Gw, C_dev, Kb[kc], W, ncols, n, st, Ah, Bh, pab);
+      hipLaunchKernelGGL(kp_lasso_polish_combine_kernel, grid, dim3(256), 0, s, Ah, Bh, Kb[kc], pab, ncols, n, Kb[kn], st);
+      KP_HIP(ctx, symm_gemm(s, prep->Gw, Kb[kn], W, nba * ncols, GKh));
+      hipLaunchKernelGGL(kp_lasso_polish_check_kernel, grid, dim3(256), 0, s, GKh, C_dev, Kb[kc], n, st);
+    }
+    KP_HIP(ctx, hipGetLastError());
+    KP_HIP(ctx, hipMemcpy2DAsync(hbuf.data(), sizeof(LassoState), st, sizeof(LassoState), head, nba, hipMemcpyDeviceToHost, s));
     KP_HIP(ctx, hipStreamSynchronize(s));
-    const bool exact = h.notconv == 0;
-    if (exact && h.change <= tol * std::max(1.0, h.kmax)) { converged = true; break; }
-    // adapt the number of Newton passes to what the last block needed
-    P = exact ? std::max(2, h.maxpasses + 1) : std::min(48, P + 6);
-    int zero2[2] = {0, 0};
-    KP_HIP(ctx, hipMemcpyAsync(&st->notconv, &zero2[0], sizeof(int), hipMemcpyHostToDevice, s));
-    KP_HIP(ctx, hipMemcpyAsync(&st->maxpasses, &zero2[1], sizeof(int), hipMemcpyHostToDevice, s));
-    KP_HIP(ctx, hipStreamSynchronize(s));
+    bool all_exact = true;
+    int maxp = 0;
+    for (int v = nba - 1; v >= 0; --v) {             // downwards: the slot moved into a hole has been examined already
+      const LassoState& h = hs(v);
+      const double pres = __builtin_bit_cast(double, h.pol_res);
+      const bool pol_ok = polish && h.pol_bad == 0 && h.pol_theta >= 0.0 && pres <= 1e-9 * std::max(h.pol_theta, 1e-300);
+      const bool exact = h.notconv == 0;
+      const bool conv = exact && h.change <= tol * std::max(1.0, h.kmax);
+      if (!(pol_ok || conv)) {
+        all_exact &= exact;
+        maxp = std::max(maxp, h.maxpasses);
+        continue;
+      }
+      KP_HIP(ctx, hipMemcpyAsync(K_dev[slot_val[v]], (pol_ok ? Kb[kn] : Kb[kc]) + (size_t)v * n, bK, hipMemcpyDeviceToDevice, s));
+      if (iters) iters[slot_val[v]] = it;
+      const int last = nba - 1;
+      if (v != last) {
+        double* mv[4] = {Kb[ko], Kb[kc], GKb[go], GKb[gc]};
+        for (double* bsrc : mv) KP_HIP(ctx, hipMemcpyAsync(bsrc + (size_t)v * n, bsrc + (size_t)last * n, bK, hipMemcpyDeviceToDevice, s));
+        KP_HIP(ctx, hipMemcpyAsync(st + v, st + last, head, hipMemcpyDeviceToDevice, s));
+        slot_val[v] = slot_val[last];
+      }
+      --nba;
+    }
+    if (nba == 0) break;
+    // adapt the number of Newton passes to what the values still running needed in the last block
+    P = all_exact ? std::max(2, maxp + 1) : std::min(48, P + 6);
+    hipLaunchKernelGGL(kp_lasso_ctl_kernel, dim3((nba + 63) / 64), dim3(64), 0, s, st, nba);
   }
-  KP_HIP(ctx, hipMemcpyAsync(K_dev, Kb[kc], bK, hipMemcpyDeviceToDevice, s));
-  if (iters) *iters = it;
-  if (!converged) return ctx->fail(KP_ERR_NOT_CONVERGED, "kp_fit_lasso: iteration cap reached");
+  if (nba > 0) {
+    for (int v = 0; v < nba; ++v) {
+      KP_HIP(ctx, hipMemcpyAsync(K_dev[slot_val[v]], Kb[kc] + (size_t)v * n, bK, hipMemcpyDeviceToDevice, s));
+      if (iters) iters[slot_val[v]] = it;
+    }
+    return ctx->fail(KP_ERR_NOT_CONVERGED, "kp_fit_lasso: iteration cap reached");
+  }
   return KP_OK;
+}
+
+int kp_lasso_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, int W, int ncols, double t, int max_iter, double tol,
+                 double* K_dev, int* iters, kp_lasso_prep* prep) {
+  double* dst[1] = {K_dev};
+  return kp_lasso_batch_dev(ctx, G_dev, C_dev, W, ncols, &t, 1, max_iter, tol, dst, iters, prep);
 }

@@ -33,32 +33,41 @@ static hipError_t gemm(hipStream_t st, int tA, int tB, int M, int N, int K, doub
   return hipGetLastError();
 }
 
-extern "C" int kp_fit_lasso(kp_ctx* ctx, const double* G, const double* C, int W, int ncols, double t, int max_iter, double tol,
-                            double* K, int* iters) {
-  if (!ctx || !G || !C || !K || W < 1 || ncols < 1 || !(t >= 0.0)) return ctx ? ctx->fail(KP_ERR_ARG, "kp_fit_lasso: bad argument") : KP_ERR_ARG;
+extern "C" int kp_fit_lasso_batch(kp_ctx* ctx, const double* G, const double* C, int W, int ncols, const double* t, int nv,
+                                  int max_iter, double tol, double* K, int* iters) {
+  if (!ctx || !G || !C || !K || !t || W < 1 || ncols < 1 || nv < 1) return ctx ? ctx->fail(KP_ERR_ARG, "kp_fit_lasso_batch: bad argument") : KP_ERR_ARG;
+  for (int v = 0; v < nv; ++v)
+    if (!(t[v] >= 0.0)) return ctx->fail(KP_ERR_ARG, "kp_fit_lasso_batch: negative L1 budget");
   KP_HIP(ctx, hipSetDevice(ctx->device));
   if (ctx->async_pending) {
     int rc0 = kp_synchronize(ctx);
     if (rc0) return rc0;
   }
   size_t bG = (size_t)W * W * 8, bC = (size_t)W * ncols * 8;
-  char* ws = (char*)ctx->workspace(6, bG + 2 * bC);
+  char* ws = (char*)ctx->workspace(6, bG + (size_t)(1 + nv) * bC);
   if (!ws) return ctx->fail(KP_ERR_HIP, "kp_fit_lasso: out of device memory");
   double* Gd = (double*)ws;
   double* Cd = (double*)(ws + bG);
   double* Kd = (double*)(ws + bG + bC);
+  std::vector<double*> dst(nv);
+  for (int v = 0; v < nv; ++v) dst[v] = Kd + (size_t)v * W * ncols;
   KP_HIP(ctx, hipMemcpyAsync(Gd, G, bG, hipMemcpyHostToDevice, ctx->stream));
   KP_HIP(ctx, hipMemcpyAsync(Cd, C, bC, hipMemcpyHostToDevice, ctx->stream));
   KP_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-  int rc = kp_lasso_dev(ctx, Gd, Cd, W, ncols, t, max_iter > 0 ? max_iter : 20000, tol > 0 ? tol : 1e-10, Kd, iters);
-  if (rc) return rc;
+  int rc = kp_lasso_batch_dev(ctx, Gd, Cd, W, ncols, t, nv, max_iter > 0 ? max_iter : 20000, tol > 0 ? tol : 1e-10, dst.data(), iters);
+  if (rc && rc != KP_ERR_NOT_CONVERGED) return rc;
   KP_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-  KP_HIP(ctx, hipMemcpyAsync(K, Kd, bC, hipMemcpyDeviceToHost, ctx->stream));
+  KP_HIP(ctx, hipMemcpyAsync(K, Kd, (size_t)nv * bC, hipMemcpyDeviceToHost, ctx->stream));
   KP_HIP(ctx, hipStreamSynchronize(ctx->stream));
   float ms = 0;
   (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
   ctx->timers[3] = ms;
-  return KP_OK;
+  return rc;
+}
+
+extern "C" int kp_fit_lasso(kp_ctx* ctx, const double* G, const double* C, int W, int ncols, double t, int max_iter, double tol,
+                            double* K, int* iters) {
+  return kp_fit_lasso_batch(ctx, G, C, W, ncols, &t, 1, max_iter, tol, K, iters);
 }
 
 // ---- iterative refinement of the least-squares fit with the residual taken from the data ------------------------

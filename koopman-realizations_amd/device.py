@@ -83,6 +83,17 @@ class Context:
                                      F.dptr(K), C.byref(it)), self._h)
         return K, it.value
 
+    def fit_lasso_batch(self, G, Cm, t, max_iter=20000, tol=1e-10):
+        """kp_fit_lasso_batch: all L1 budgets t[v] on the same Grams at once.  Returns ([K_v], iters)."""
+        G = F.fcol(G); Cm = F.fcol(Cm)
+        W, nc = G.shape[0], Cm.shape[1]
+        tv = np.ascontiguousarray(np.atleast_1d(np.asarray(t, dtype=np.float64)))
+        K = np.zeros((len(tv), nc, W))                      # each W x nc block column-major
+        it = np.zeros(len(tv), dtype=np.int32)
+        F.check(F.lib().kp_fit_lasso_batch(self._h, F.dptr(G), F.dptr(Cm), W, nc, F.dptr(tv), len(tv), int(max_iter), float(tol),
+                                           F.dptr(K), it.ctypes.data_as(F.c_ip)), self._h)
+        return [np.asfortranarray(K[v].T) for v in range(len(tv))], it
+
     def fit_batch(self, basis, snaps, nb):
         """Least-squares fits of nb systems that share one dictionary (W <= 16): `snaps` holds the merged snapshot
         pairs, nb x Ns_each rows.  Returns K, G, C as (nb, W, W) arrays and the status vector."""

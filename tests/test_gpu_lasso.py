@@ -1,0 +1,81 @@
+"""GPU parity tests of the lasso path at BASELINE configs[3]'s shape: bilinear poly-3 dictionary (W = 336) on 1e5 synthetic
+snapshot pairs, a grid of L1 budgets on the same Grams (solve_KoopmanQP, Ksysid.m:1095-1176; train_models loop
+:1372-1387).  Oracle: the optimality conditions of the reference's QP (min 1/2||Px K - Py||^2 s.t. ||vec K||_1 <= t:
+`lasso_kkt_residual` = || K - P_ball(K - grad) ||_inf, zero exactly at the optimum) and, at sizes the numpy oracle
+finishes in seconds, the oracle's own solution.  Tolerances: KKT residual <= 1e-8 max|C| (quadprog's stopping
+tolerance is 1e-8 relative); budget met to 1e-9 relative."""
+import numpy as np
+import pytest
+
+import koopman_realizations_amd as kra
+from oracle import koopman_oracle as ko
+from conftest import synth_pairs
+from test_gpu_fit import make_basis
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def config3(ctx):
+    p = synth_pairs(100000)
+    dic = ko.build_dictionary("bilinear", 6, 3, ["poly"], [3])
+    b = make_basis(ctx, dic)
+    snaps = kra.Snapshots(ctx, p["alpha"], p["beta"], p["u"])
+    G, C = kra.fit_gram(ctx, b, snaps)
+    Kls = ctx.fit_solve(G, C)
+    return {"basis": b, "snaps": snaps, "G": G, "C": C, "Kls": Kls, "l1": float(np.abs(Kls).sum()), "N": dic.N}
+
+
+def test_lasso_grid_at_config3_shape_is_kkt_optimal(ctx, config3):
+    """Eight budgets from almost-least-squares (dense support) to 1 % of ||K_LS||_1 (16 nonzeros), one inactive."""
+    G, C, l1 = config3["G"], config3["C"], config3["l1"]
+    assert G.shape == (336, 336)
+    fr = np.array([1.5, 0.99, 0.9, 0.7, 0.5, 0.3, 0.1, 0.01])
+    Ks, iters = ctx.fit_lasso_batch(G, C, fr * l1)
+    cmax = np.abs(C).max()
+    assert iters[0] == 0 and np.abs(Ks[0] - config3["Kls"]).max() == 0          # constraint inactive: the LS answer
+    for f, K, it in zip(fr[1:], Ks[1:], iters[1:]):
+        t = f * l1
+        assert it > 0
+        assert abs(np.abs(K).sum() - t) <= 1e-9 * t, (f, np.abs(K).sum() / t)
+        res = ko.lasso_kkt_residual(G, C, K, t)
+        assert res <= 1e-8 * cmax, (f, res / cmax)
+    nnz = [(K != 0).sum() for K in Ks]
+    assert nnz[-1] < nnz[-3] < nnz[2] < nnz[1]                                  # sparser as the budget shrinks
+    # single-value entry point = the batch's answer
+    K1, _ = ctx.fit_lasso(G, C, 0.5 * l1)
+    assert np.abs(K1 - Ks[4]).max() <= 1e-9 * np.abs(Ks[4]).max()
+
+
+def test_train_models_lasso_vector_at_config3_shape(ctx, config3):
+    """kp_fit with a vector of lasso values (t = lasso * N, Ksysid.m:996): snapshots lifted once, values batched."""
+    b, snaps, l1, N = config3["basis"], config3["snaps"], config3["l1"], config3["N"]
+    las = [np.inf, 0.6 * l1 / N, 0.05 * l1 / N, 1e4]
+    Ks = kra.fit(ctx, b, snaps, las)
+    cmax = np.abs(config3["C"]).max()
+    assert np.abs(Ks[0] - config3["Kls"]).max() <= 1e-12 * np.abs(config3["Kls"]).max()
+    assert np.abs(Ks[3] - Ks[0]).max() == 0
+    for lv, K in zip(las[1:3], Ks[1:3]):
+        assert ko.lasso_kkt_residual(config3["G"], config3["C"], K, lv * N) <= 1e-8 * cmax
+
+
+def test_lasso_matches_numpy_oracle_mid_size(ctx):
+    """W = 60 bilinear poly-2 problem: the oracle's projected-gradient solution (run to 1e-13) and the device agree."""
+    p = synth_pairs(5000, 4, 2, seed=3)
+    dic = ko.build_dictionary("bilinear", 4, 2, ["poly"], [2])
+    Px, Py = ko.px_py(dic, p)
+    G, C = ko.gram(Px, Py)
+    l1 = np.abs(np.linalg.solve(G, C)).sum()
+    fr = [0.8, 0.4, 0.05]
+    Ks, iters = ctx.fit_lasso_batch(G, C, [f * l1 for f in fr], tol=1e-12)
+    for f, K in zip(fr, Ks):
+        Ko = ko.koopman_lasso(G, C, f * l1)
+        assert np.abs(K - Ko).max() <= 1e-8 * np.abs(Ko).max(), f
+        assert ko.lasso_kkt_residual(G, C, K, f * l1) <= 1e-9 * np.abs(C).max()
+
+
+def test_lasso_without_polish_agrees(ctx, config3, monkeypatch):
+    """The active-set polish only ends the iteration early: the plain projected-gradient answer is the same optimum."""
+    G, C, l1 = config3["G"], config3["C"], config3["l1"]
+    Kp, itp = ctx.fit_lasso_batch(G, C, [0.3 * l1])
+    assert ko.lasso_kkt_residual(G, C, Kp[0], 0.3 * l1) <= 1e-10 * np.abs(C).max()     # polished: optimum to rounding
