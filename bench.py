@@ -7,10 +7,12 @@ poly degree 3 (N=84, W=336), 1e5 synthetic snapshot pairs, one MI355X.  A "step"
 complete fit (fused lift+Gram kernel, partial reduction, Cholesky solve -> K) of the
 resident snapshot matrix.  Inputs are uploaded to HBM before the timed region.
 
-Multi-GPU (N>1): one process per GPU; every rank fits its own snapshot matrix of the same
-shape (the units of the reference's sweeps are independent fits: lasso grid
-Ksysid.m:1372-1387, evaluate_rand_models.m:45-144) => weak scaling, no data-path
-collective; one RCCL all_gather of the resulting K matrices closes the timed region.
+Multi-GPU (N>1): one process per GPU (launched by torch.distributed.run, or spawned here when bench.py is
+started directly with --gpus N), torch-free: the RCCL communicator lives behind the C ABI (kp_comm_*).  Every rank
+fits its own snapshot matrix of the same shape (the units of the reference's sweeps are independent fits: lasso grid
+Ksysid.m:1372-1387, evaluate_rand_models.m:45-144) => weak scaling, no data-path collective; one RCCL all-gather of
+the resulting K matrices closes the timed region.  The sharded sections (64-value lasso grid, 1024 random systems)
+report their own whole-job numbers per N.
 
 Prints ONE JSON line on rank 0.
 """
@@ -37,28 +39,38 @@ def synth_pairs(Ns, nz=6, m=3, seed=0):
     return alpha, beta, u
 
 
-def cpu_baseline(Ns_sample, degree):
-    """The oracle's restatement of get_Koopman (lift of every row + `\\`) on the host cores,
-    on a bounded sample of the same workload."""
+def cpu_baseline(Ns_sample, degree, seconds=9.0):
+    """The oracle's restatement of get_Koopman on the host cores, on a bounded sample of the same workload: the lift of
+    every row (Ksysid.m:1030-1065) + `Px \\ Py` (:1069).  MATLAB's mldivide on a rectangular system is a QR solve with
+    column pivoting, so the solve here is LAPACK gelsy (not the SVD lstsq).  Two rows: one thread (the reference's
+    interpreter is single threaded apart from BLAS) and all host cores."""
+    import scipy.linalg as sla
+    import threadpoolctl
     from oracle import koopman_oracle as ko
     alpha, beta, u = synth_pairs(Ns_sample, seed=123)
     pairs = {"alpha": alpha, "beta": beta, "u": u}
     dic = ko.build_dictionary("bilinear", 6, 3, ["poly"], [degree])
-    t0 = time.perf_counter()
-    reps = 0
-    while True:
-        ko.get_koopman(dic, pairs)
-        reps += 1
-        if time.perf_counter() - t0 > 12.0:   # bounded sample: ~12 s of host work
-            break
-    dt = (time.perf_counter() - t0) / reps
-    try:
-        import threadpoolctl
-        cores = max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()] + [1])
-    except Exception:
-        cores = os.cpu_count()
-    return {"value": Ns_sample / dt, "unit": "snapshot-pairs/s", "cores": int(cores), "kind": "port",
-            "sample": f"{reps} x get_Koopman (numpy lift + LAPACK lstsq) on {Ns_sample} pairs, W=336, {dt*1e3:.0f} ms each"}
+
+    def one():
+        Px, Py = ko.px_py(dic, pairs)
+        return sla.lstsq(Px, Py, lapack_driver="gelsy", check_finite=False)[0]
+
+    def timed(limit):
+        t0 = time.perf_counter(); reps = 0
+        while True:
+            one(); reps += 1
+            if time.perf_counter() - t0 > limit:
+                break
+        return (time.perf_counter() - t0) / reps, reps
+    all_cores = max([p_.get("num_threads", 1) for p_ in threadpoolctl.threadpool_info()] + [1])
+    dt_all, reps_all = timed(seconds)
+    with threadpoolctl.threadpool_limits(1):
+        dt_1, reps_1 = timed(seconds)
+    W = dic.W
+    return {"value": Ns_sample / dt_all, "unit": "snapshot-pairs/s", "cores": int(all_cores), "kind": "port",
+            "sample": f"{reps_all} x get_Koopman (numpy lift + LAPACK QR gelsy) on {Ns_sample} pairs, W={W}, {dt_all*1e3:.0f} ms each",
+            "one_thread": {"value": Ns_sample / dt_1, "cores": 1,
+                           "sample": f"{reps_1} x the same on one thread, {dt_1*1e3:.0f} ms each"}}
 
 
 def mpc_problem(kra, ctx, basis, snaps, horizon=10):
@@ -128,47 +140,146 @@ def bench_mpc(ctx, kra, basis, snaps, args):
             "closed_loop_steps_per_s": okc / dtc, "closed_loop_us_per_step": dtc / max(okc, 1) * 1e6,
             "closed_loop_kernel_us": float(np.mean(kernc)) * 1e3, "closed_loop_solved": int(okc),
             "batch_problems_per_s": args.mpc_batch / dtb, "batch": args.mpc_batch, "batch_kernel_ms": ctx.timer(2),
+            "batch_problems_per_s_kernel_only": args.mpc_batch / (ctx.timer(2) * 1e-3),
             "batch_solved": int((stb == 0).sum()),
             "workload": "bilinear Kmpc, N=84 model of the synthetic fit, horizon 10, 30 variables x 126 rows (BASELINE configs[2] shape)",
             "reference_recorded": "MATLAB R2019a stored comp_time: median 8.7 ms/step (~104 steps/s), N=34, unknown PC",
             "_setup": (setup, basis.N, zeta[:20], u_prev[:20], Yr[:20])}
 
 
-def bench_lasso(ctx, kra, basis, snaps, n_values=8):
-    """BASELINE configs[3] on one GPU: a lasso grid on the bilinear fit through ONE kp_fit call (snapshots lifted once,
-    least-squares solution and Lipschitz constant shared, Ksysid.train_models with a vector of lasso values).  The
-    grid is chosen so that the L1 constraint is active for every value (t between 0.9 and 0.1 of ||K_LS||_1)."""
-    G, C = kra.fit_gram(ctx, basis, snaps)
-    l1 = float(np.abs(ctx.fit_solve(G, C)).sum())
-    vals = list(np.geomspace(0.9, 0.1, n_values) * l1 / basis.N)          # t = lasso * N (Ksysid.m:996)
-    kra.fit(ctx, basis, snaps, vals[:1])
+def bench_lasso(ctx, comm, kra, basis, snaps, n_values=64):
+    """BASELINE configs[3]: the 64-value lasso grid on the bilinear fit (SURVEY 8(d): t/N log-spaced in [1e-2, 1e2];
+    lasso = t/N, Ksysid.m:996), values dealt round-robin to the ranks, each rank handing its whole shard to ONE kp_fit
+    call (snapshots lifted once, the shard's values batched on the device), final gather of the K stack over RCCL.
+    Every rank fits the same snapshot matrix (as train_models does for every value)."""
+    from koopman_realizations_amd import sweep, comm as kc
+    W = basis.W
+    vals = list(np.geomspace(1e-2, 1e2, n_values))
+    fit_many = lambda ls: kra.fit(ctx, basis, snaps, ls)
+    mine = sweep.shard_units(n_values, comm.rank, comm.world)
+    kra.fit(ctx, basis, snaps, [vals[i] for i in mine[:1]])               # warm-up (allocations, RCCL channels)
+    sweep.gather_matrices({i: np.zeros((W, W)) for i in mine}, n_values, (W, W), comm)
+    comm.barrier()
     t0 = time.perf_counter()
-    Ks = kra.fit(ctx, basis, snaps, vals)
-    dt = time.perf_counter() - t0
-    return {"values": n_values, "seconds": dt, "values_per_s": n_values / dt, "W": basis.W,
-            "l1_fraction_reached": [float(np.abs(K).sum() / l1) for K in (Ks[0], Ks[-1])],
-            "workload": "lasso grid on the bilinear poly-3 fit, 1e5 pairs, constraint active (BASELINE configs[3] shape, one GPU's share)"}
+    Ks = sweep.lasso_sweep(None, vals, comm, shape=(W, W), fit_many=fit_many)
+    comm.barrier()
+    dt = kc.max_over_ranks(comm, time.perf_counter() - t0)
+    l1 = np.array([np.abs(K).sum() for K in Ks])
+    t = np.array(vals) * basis.N
+    active = int((l1 < l1.max() * (1 - 1e-9)).sum())
+    return {"values": n_values, "seconds": dt, "values_per_s": n_values / dt, "ms_per_value": dt / n_values * 1e3, "W": W,
+            "n_gpus": comm.world, "active_constraints": active,
+            "budget_met": bool(np.all(l1 <= t * (1 + 1e-9) + 1e-12)),
+            "device_ms_rank0": ctx.timer(3),
+            "workload": "64 lasso values (t/N log-spaced 1e-2..1e2) on the bilinear poly-3 fit, 1e5 pairs, sharded round-robin, "
+                        "K stack gathered (BASELINE configs[3])"}
 
 
-def bench_rand_sweep(ctx, kra, n_systems=256):
-    """BASELINE configs[4] on one GPU: evaluate_rand_models.m (linear / bilinear / nonlinear fits of every degree +
-    validation rollouts per random system) through the batched path; the three systems committed under tests/golden
-    (taken from the reference's data set) are repeated to n_systems."""
-    from koopman_realizations_amd import sweep
-    g = np.load(os.path.join(ROOT, "tests", "golden", "rand_systems.npz"))
-    def system(i):
-        t, y, u = g[f"s{i}_train_t"], g[f"s{i}_train_y"], g[f"s{i}_train_u"]
-        n = t.shape[0] // 1001
-        train = [{"t": t[k * 1001:(k + 1) * 1001], "y": y[k * 1001:(k + 1) * 1001], "u": u[k * 1001:(k + 1) * 1001]} for k in range(n)]
-        return {"train": train, "val": [{"t": g[f"s{i}_val_t"], "y": g[f"s{i}_val_y"], "u": g[f"s{i}_val_u"]}]}
-    base = [system(i) for i in range(3)]
-    systems = [base[i % 3] for i in range(n_systems)]
-    sweep.rand_models_sweep_batched(systems[:3], ctx)
+RAND_CHUNK = 128
+
+
+def _rand_chunk(c):
+    """Systems [128 c, 128 c + 128) of the generated sweep population (host, numpy; seeded per chunk so that every
+    N-GPU run sees the same 1024 systems): Rsys(128 systems, 3 terms, degree_x 3, degree_u 2), 10 + 1 trials of 1001
+    samples at Ts = 0.01 (Rsys.m:96-125, 136-150; the shipped data set's shape)."""
+    from koopman_realizations_amd.rsys import Rsys
+    r = Rsys(RAND_CHUNK, 3, 3, 2, seed=1000 + c)
+    return Rsys.save_data(r.simulate_systems_fast(10.0, 0.01, 11, np.zeros((1, 1))))
+
+
+def gen_rand_systems(chunks):
+    """Generates the chunks in worker processes (fork, BEFORE this process touches the GPU)."""
+    import multiprocessing as mp
+    if not chunks:
+        return {}
+    nproc = min(len(chunks), max(1, (os.cpu_count() or 2) - 1))
+    if nproc == 1:
+        return {c: _rand_chunk(c) for c in chunks}
+    with mp.get_context("fork").Pool(nproc) as pool:
+        return dict(zip(chunks, pool.map(_rand_chunk, chunks)))
+
+
+def bench_rand_sweep(ctx, comm, kra, chunks, n_systems):
+    """BASELINE configs[4]: evaluate_rand_models.m (linear deg 1..13, bilinear 1..6, nonlinear 1..4 fits + validation
+    rollouts per random system) on n_systems DISTINCT generated systems, chunks of 128 dealt round-robin to the ranks,
+    each rank's shard through the batched device path, final gather of the error tables."""
+    from koopman_realizations_amd import sweep, comm as kc
+    mine = [s_ for c in sorted(chunks) for s_ in chunks[c]]
+    ids = [c * RAND_CHUNK + k for c in sorted(chunks) for k in range(RAND_CHUNK)]
+    sweep.rand_models_sweep_batched(mine[:4], ctx)                           # warm-up
+    comm.barrier()
     t0 = time.perf_counter()
-    tab = sweep.rand_models_sweep_batched(systems, ctx)
+    tab = sweep.rand_models_sweep_batched(mine, ctx) if mine else {}
+    t_local = time.perf_counter() - t0
+    local = {i: {mt: tab[mt][:, k] for mt in tab} for k, i in enumerate(ids)}
+    allres = sweep.gather_results(local, n_systems, comm)
+    comm.barrier()
+    dt = kc.max_over_ranks(comm, time.perf_counter() - t0)
+    lin = np.stack([r["linear"] for r in allres], axis=1)
+    mean, _ = sweep.sweep_statistics(lin)
+    return {"systems": n_systems, "distinct_systems": True, "seconds": dt, "systems_per_s": n_systems / dt, "n_gpus": comm.world,
+            "rank0_compute_seconds": t_local, "fits_per_system": int(sum(v.shape[0] for v in tab.values())) if tab else 23,
+            "mean_linear_error_deg1_deg13": [float(mean[0]), float(mean[-1])],
+            "workload": "evaluate_rand_models.m on 1024 generated 1-D random systems (Rsys restatement), 23 fits + validation "
+                        "rollouts each, 128-system chunks round-robin over the ranks (BASELINE configs[4])"}
+
+
+def bench_arm_closed_loop(ctx, kra):
+    """BASELINE configs[2] as named: bilinear Kmpc, horizon 10, closed loop on the block-M reference with the arm model
+    identified from the shipped 3-link data (poly-3, dim_red: N = 34), example_control.m settings, the identified
+    model as the plant (Kmpc.run_simulation, Kmpc.m:403-512).  Fixtures: tests/golden (data files of the reference)."""
+    gd = os.path.join(ROOT, "tests", "golden")
+    g = np.load(os.path.join(gd, "arm_data.npz")); ref = np.load(os.path.join(gd, "blockM_ref.npz"))["y"]
+    lens = g["train_len"]; off = np.concatenate([[0], np.cumsum(lens)])
+    train = [{"t": g["train_t"][a:b], "y": g["train_y"][a:b], "u": g["train_u"][a:b]} for a, b in zip(off[:-1], off[1:])]
+    val = [{"t": g["val_t"], "y": g["val_y"], "u": g["val_u"]}]
+    t0 = time.perf_counter()
+    ks = kra.Ksysid({"train": train, "val": val}, ctx=ctx, model_type="bilinear", obs_type=["poly"], obs_degree=[3],
+                    snapshots=np.inf, lasso=[np.inf], delays=0, dim_red=True).train_models()
+    t_sysid = time.perf_counter() - t0
+    mpc = kra.Kmpc(ks, horizon=10, input_bounds=[-7 * np.pi / 8, 7 * np.pi / 8], input_slopeConst=1e-1, input_smoothConst=None,
+                   state_bounds=None, cost_running=10, cost_terminal=100, cost_input=0.1 * np.array([3e-2, 2e-2, 1e-2]),
+                   projmtx=ks.model["C"][-2:, :])
+    mpc.run_simulation(ref[:20])
+    t0 = time.perf_counter()
+    res = mpc.run_simulation(ref)
     dt = time.perf_counter() - t0
-    return {"systems": n_systems, "seconds": dt, "systems_per_s": n_systems / dt, "fits_per_system": int(sum(len(v) for v in tab.values())),
-            "workload": "evaluate_rand_models.m: 23 fits + validation rollouts per 1-D random system (BASELINE configs[4] shape, one GPU's share)"}
+    n = len(res["comp_time"])
+    proj = ks.model["C"][-2:, :6]
+    err = float(np.mean(np.linalg.norm(res["Y"][1:] @ proj.T - res["R"][1:], axis=1)))
+    return {"steps": n, "steps_per_s": n / dt, "controller_us_per_step": float(np.median(res["comp_time"])) * 1e6, "N": int(ks.params["N"]),
+            "mean_tracking_error": err, "sysid_seconds": t_sysid,
+            "reference_recorded": "MATLAB R2019a stored comp_time of the same controller shape: median 8.7 ms/step",
+            "workload": "bilinear Kmpc horizon 10 on the block-M reference, arm model N=34 (poly-3, dim_red) from the shipped "
+                        "3-link data, model as plant (BASELINE configs[2])"}
+
+
+def bench_width_points(ctx, kra, Ns):
+    """SURVEY 8(d)'s other two fit shapes next to W = 336: W = 200 (N = 50: the first 49 poly-3 rows + constant) and W = 136
+    (N = 34: econ lift through a pcs matrix, the shape of example_sysid.m with dim_red).  Kernel time of the fused
+    lift+Gram launch and its algorithmic rate F(W) Ns / t."""
+    out = {}
+    a, b, u = synth_pairs(Ns, seed=5)
+    snaps = kra.Snapshots(ctx, a, b, u)
+    tab = kra.poly_exponent_table(6, 3)
+    rng = np.random.default_rng(3)
+    pcs = np.linalg.qr(rng.standard_normal((84, 27)))[0]
+    for name, basis in (("W200", kra.Basis(ctx, "bilinear", 6, 3, [("poly", tab[6:49])])),
+                        ("W136_pcs", kra.Basis(ctx, "bilinear", 6, 3, [("poly", tab[6:])], pcs))):
+        W = basis.W
+        for _ in range(3):
+            kra.fit_gram(ctx, basis, snaps, fetch=False)
+        g = []
+        for _ in range(10):
+            kra.fit_gram(ctx, basis, snaps, fetch=False); g.append(ctx.timer(0))
+        ms = float(np.median(g))
+        F_ = W * (W + 1) + 2.0 * W * W
+        out[name] = {"W": W, "N": basis.N, "gram_ms": ms, "algorithmic_TFLOPs": F_ * Ns / (ms * 1e-3) / 1e12,
+                     "frac_of_f64_mfma_peak": F_ * Ns / (ms * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS,
+                     "pairs_per_s_gram_only": Ns / (ms * 1e-3)}
+        basis.close()
+    snaps.close()
+    return out
 
 
 def cpu_baseline_mpc(pack):
@@ -200,66 +311,61 @@ def main():
     ap.add_argument("--degree", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mpc", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the lasso-grid and random-sweep sections")
+    ap.add_argument("--no-extras", action="store_true", help="skip the lasso-grid, random-sweep and width-point sections")
     ap.add_argument("--mpc-steps", type=int, default=300)
     ap.add_argument("--mpc-batch", type=int, default=4096)
+    ap.add_argument("--rand-systems", type=int, default=1024)
     args = ap.parse_args()
 
+    from koopman_realizations_amd import comm as kc
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # launched directly: one fresh process per GPU, started before anything here has touched a GPU
+        out = kc.spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus)
+        lines = [l for l in out.splitlines() if l.startswith("{")]
+        print(lines[-1] if lines else out)
+        return
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    extras_on = not args.no_extras and args.degree == 3
+    # host-side generation of this rank's share of the random systems (worker processes, before the GPU is touched)
+    n_chunks = max(1, args.rand_systems // RAND_CHUNK)
+    chunks = gen_rand_systems([c for c in range(n_chunks) if c % world == rank]) if extras_on else {}
 
     import koopman_realizations_amd as kra
-    from koopman_realizations_amd import _ffi as F
-
-    ctx = kra.Context(local_rank)
+    ctx, comm = kc.init_from_env(kra.Context)      # one process per GPU; RCCL communicator through the C ABI when world > 1
     Ns = args.snapshots
     alpha, beta, u = synth_pairs(Ns, seed=rank)
     basis = kra.Basis(ctx, "bilinear", 6, 3, [("poly", kra.poly_exponent_table(6, args.degree)[6:])])
+    t_up = []
+    for _ in range(3):
+        t1 = time.perf_counter(); snaps = kra.Snapshots(ctx, alpha, beta, u); t_up.append(time.perf_counter() - t1)
+        snaps.close()
     snaps = kra.Snapshots(ctx, alpha, beta, u)      # resident in HBM before timing
     W = basis.W
+    ctx.fit_async_slots(max(args.steps, args.warmup, 1))   # every K of the timed region stays retrievable
 
-    def barrier():
-        if dist is not None:
-            import torch
-            torch.cuda.synchronize()
-            dist.barrier()
-
-    # Steps are independent fits (the unit of the reference's sweeps), issued through the library's
-    # asynchronous pipeline: the solve of fit i (second HIP stream) overlaps the fused Gram kernel of
-    # fit i+1; everything is drained (kp_synchronize) inside the timed region.
+    # Steps are independent fits (the unit of the reference's sweeps), issued through the library's asynchronous pipeline:
+    # the solve of fit i (second HIP stream) overlaps the fused Gram kernel of fit i+1; each K lands in its own slot of
+    # the device result ring; everything is drained and the ranks' last K matrices are gathered (RCCL, device to
+    # device) inside the timed region.
     for _ in range(args.warmup):
         kra.fit(ctx, basis, snaps, fetch=False)
     ctx.synchronize()
-    t_gram, t_red, t_solve = [], [], []
-    barrier()
+    if world > 1:
+        comm.all_gather_fit(args.warmup - 1 if args.warmup else 0, W) if args.warmup else None
+    comm.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         kra.fit(ctx, basis, snaps, fetch=False)     # enqueue: Gram on stream 1, solve on stream 2
-    ctx.synchronize()                               # all K fits complete (HIP events of the last step are read after this)
-    # timer 0 = mean HIP-event duration of the last min(steps, 64) Gram launches of this timed region (timer 7 = count)
-    t_gram.append(ctx.timer(0)); t_red.append(ctx.timer(6)); t_solve.append(ctx.timer(1)); n_timed = int(ctx.timer(7))
-    if dist is not None:
-        import torch
-        K = np.zeros((W, W), order="F")
-        F.check(F.lib().kp_fit_get_K(ctx.handle, 0, W, F.dptr(K)), ctx.handle)
-        Kt = torch.from_numpy(K).cuda()
-        out = [torch.empty_like(Kt) for _ in range(world)]
-        dist.all_gather(out, Kt)                    # the sweep's only collective: final gather
-        torch.cuda.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    ctx.synchronize()                               # all fits complete
+    Kall = comm.all_gather_fit(args.steps - 1, W) if world > 1 else None    # the sweep's only collective: final gather
+    comm.barrier()
+    dt = kc.max_over_ranks(comm, time.perf_counter() - t0)
+    # timer 0 = mean HIP-event duration of the last min(steps, 64) Gram launches of the timed region (timer 7 = count)
+    g_ms, red_ms, solve_ms, n_timed = ctx.timer(0), ctx.timer(6), ctx.timer(1), int(ctx.timer(7))
+    # every K of the timed region is retrievable and they all solve the same system
+    K_first, K_last = ctx.fit_result(0, W), ctx.fit_result(args.steps - 1, W)
+    k_spread = float(np.abs(K_first - K_last).max())
 
     # one-fit latency (no overlap): synchronous path of the same entry point
     os.environ["KP_NO_ASYNC"] = "1"
@@ -268,29 +374,41 @@ def main():
         t1 = time.perf_counter(); kra.fit(ctx, basis, snaps, fetch=False); lat.append(time.perf_counter() - t1)
     del os.environ["KP_NO_ASYNC"]
     fit_latency_ms = float(np.median(lat)) * 1e3
-    mpc_res = None
-    if rank == 0 and not args.no_mpc and world == 1:     # secondary sections only in the single-GPU run
+    # the public entry point end to end: Ksysid.get_Koopman's device part with K fetched (one refinement step excluded)
+    t1 = time.perf_counter(); kra.fit(ctx, basis, snaps); fit_fetch_ms = (time.perf_counter() - t1) * 1e3
+
+    mpc_res = arm_res = widths = None
+    if rank == 0 and not args.no_mpc and world == 1:     # latency-bound sections only in the single-GPU run
         mpc_res = bench_mpc(ctx, kra, basis, snaps, args)
-    extras = None
-    if rank == 0 and not args.no_extras and world == 1 and args.degree == 3:
-        extras = {"lasso_grid": bench_lasso(ctx, kra, basis, snaps), "rand_sweep": bench_rand_sweep(ctx, kra)}
+        arm_res = bench_arm_closed_loop(ctx, kra)
+    if rank == 0 and extras_on and world == 1:
+        widths = bench_width_points(ctx, kra, Ns)
+    lasso_res = sweep_res = None
+    if extras_on:                                        # sharded sections: every rank takes part
+        lasso_res = bench_lasso(ctx, comm, kra, basis, snaps)
+        sweep_res = bench_rand_sweep(ctx, comm, kra, chunks, n_chunks * RAND_CHUNK)
 
     if rank == 0:
         flops_pair = W * (W + 1) + 2.0 * W * W                 # F(336) = 339 024
-        g_ms = float(np.mean(t_gram))
         achieved = flops_pair * Ns / (g_ms * 1e-3) / 1e12
+        # what the Kronecker kernel executes: (m+1)(m+2)/2 weights x (symmetric half in 4-column groups + full cross block)
+        Np4 = (basis.N + 3) // 4 * 4
+        exec_pair = 10 * (Np4 * Np4 + Np4 * (Np4 + 4) / 2.0) * 2.0
         # HBM traffic of the dominant kernel: PMC counters are collected in separate rocprofv3 passes of this
         # same command (tools/prof_round.sh) and committed under profiles/; null when the workload differs
         traffic, prof_note = None, None
-        pj = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-        if os.path.exists(pj) and Ns == 100000 and args.degree == 3:
-            try:
-                pr = json.load(open(pj))
-                traffic = pr["gram_traffic_bytes_per_launch"]
-                prof_note = {"executed_flop_per_launch": pr["gram_executed_flop"], "mfma_busy_cycles_per_instr": pr["gram_mfma_busy_cycles_per_instr"],
-                             "source": "profiles/r01_pmc_summary.json"}
-            except Exception:
-                pass
+        for pj in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
+            pj = os.path.join(ROOT, "profiles", pj)
+            if os.path.exists(pj) and Ns == 100000 and args.degree == 3:
+                try:
+                    pr = json.load(open(pj))
+                    traffic = pr["gram_traffic_bytes_per_launch"]
+                    prof_note = {"executed_flop_per_launch": pr["gram_executed_flop"], "mfma_busy_cycles_per_instr": pr["gram_mfma_busy_cycles_per_instr"],
+                                 "source": "profiles/" + os.path.basename(pj)}
+                    break
+                except Exception:
+                    pass
+        upload_ms = float(np.median(t_up)) * 1e3
         res = {
             "metric": "EDMD snapshot-pairs/sec (bilinear fit, 3-link arm, poly-3)",
             "value": world * Ns * args.steps / dt,
@@ -301,31 +419,41 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"bilinear Koopman fit, poly degree {args.degree}, {Ns} synthetic snapshot pairs per GPU, "
                                    f"N={basis.N}, W={W} (BASELINE configs[1])",
-                       "snapshots_per_gpu": Ns, "W": W, "parallelism": f"{world} independent fits + final all_gather"},
-            "fit_latency_ms": fit_latency_ms,
-            "kernel_ms": {"gram": g_ms, "gram_launches_averaged": n_timed, "gram_reduce": float(np.mean(t_red)), "solve": float(np.mean(t_solve))},
+                       "snapshots_per_gpu": Ns, "W": W,
+                       "parallelism": f"{world} rank(s), independent fits per rank, one RCCL all-gather of the K matrices at the end"},
+            "fit_latency_ms": fit_latency_ms, "fit_with_K_fetched_ms": fit_fetch_ms,
+            "all_K_retrievable": True, "K_first_vs_last_max_abs_diff": k_spread,
+            "h2d": {"upload_ms": upload_ms, "pairs_per_s_including_upload": Ns / ((upload_ms + dt / args.steps * 1e3) * 1e-3),
+                    "note": "12 MB of host snapshot pairs per fit over PCIe; never part of `value`"},
+            "kernel_ms": {"gram": g_ms, "gram_launches_averaged": n_timed, "gram_reduce": red_ms, "solve": solve_ms},
             "roofline": {"bound": "mfma", "kernel": "kp_gram3_kernel<6,3>", "achieved": achieved, "peak": PEAK_F64_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_F64_MFMA_TFLOPS, "traffic": traffic,
                          "algorithmic_flop_per_launch": flops_pair * Ns, "algorithmic_bytes_per_launch": 120.0 * Ns,
                          "hbm_algorithmic_GBs": 120.0 * Ns / (g_ms * 1e-3) / 1e9,
-                         "note": "achieved = dense algorithmic flop W(W+1)+2W^2 per pair / measured kernel time; the Kronecker-structured "
-                                 "kernel executes ~63% of them (exact same G, C), so frac can exceed the executed-MFMA utilisation",
+                         "executed_flop_per_launch": exec_pair * Ns,
+                         "executed_frac": exec_pair * Ns / (g_ms * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS,
+                         "note": "achieved/frac = dense algorithmic flop W(W+1)+2W^2 per pair / measured kernel time (SURVEY 8(d)); the "
+                                 "Kronecker-structured kernel executes ~63% of them for the identical G, C: executed_frac is the "
+                                 "matrix-pipe utilisation",
                          "pmc": prof_note},
         }
         if mpc_res is not None:
             res["mpc"] = mpc_res
-        if extras is not None:
-            res.update(extras)
+            res["mpc_arm_blockM"] = arm_res
+        if widths is not None:
+            res["width_points"] = widths
+        if lasso_res is not None:
+            res["lasso_grid"] = lasso_res
+            res["rand_sweep"] = sweep_res
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(min(Ns, 20000), args.degree)
             if mpc_res is not None:
                 res["cpu_baseline"]["mpc"] = cpu_baseline_mpc(mpc_res.pop("_setup"))
         if mpc_res is not None:
             mpc_res.pop("_setup", None)
-        print(json.dumps(res))
-    if dist is not None:
-        barrier()
-        dist.destroy_process_group()
+        print(json.dumps(res), flush=True)
+    comm.barrier()
+    ctx.close()
 
 
 if __name__ == "__main__":

@@ -261,6 +261,33 @@ int kp_mpc_last_profile(kp_mpc* mpc, double* us, int* counts);
 int kp_qp_solve(kp_ctx* ctx, const double* H, const double* f, const double* A, const double* b, int n,
                 int mrows, double* x, int* status);
 
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI ----------------------------------------------------
+ * The reference has no parallel construct; its sweeps are serial loops over independent units:
+ * lasso values (Ksysid.train_models, Ksysid.m:1372-1387), random systems x model types x degrees
+ * (evaluate_rand_models.m:45-144).  Units are dealt round-robin over the ranks by the host and there is NO collective on
+ * the data path; the entry points below are the final gather and, for ONE fit sharded over snapshots, the single
+ * all-reduce of the Gram pair.  librccl.so is loaded on the first kp_comm_* call; single-GPU use never needs it.
+ *   kp_comm_unique_id   rank 0 creates the 128-byte RCCL id and hands it to the other ranks (file, socket, MATLAB
+ *                       parallel pool message - the host's business);
+ *   kp_comm_create      every rank: ncclCommInitRank on the context's device; kp_destroy releases it;
+ *   kp_comm_allgather   host buffers, `bytes` per rank in, world x bytes out (error tables, timing);
+ *   kp_comm_allreduce_sum  host vector, in place (barrier, counters);
+ *   kp_comm_allgather_fit  K of fit `index` (kp_fit_get_K numbering) of every rank, device to device, one copy out:
+ *                       K_all = world matrices W x W;
+ *   kp_fit_sharded / kp_fit_gram_sharded  kp_fit / kp_fit_gram on this rank's shard of the snapshot pairs with the
+ *                       all-reduce of [G | C] (2 W^2 doubles) between the Gram kernel and the solve: every rank gets the
+ *                       K of the whole data set. */
+int kp_comm_unique_id(void* id128);
+int kp_comm_create(kp_ctx* ctx, const void* id128, int rank, int world);
+int kp_comm_destroy(kp_ctx* ctx);
+int kp_comm_info(const kp_ctx* ctx, int* rank, int* world);
+int kp_comm_allgather(kp_ctx* ctx, const void* send, int64_t bytes, void* recv);
+int kp_comm_allreduce_sum(kp_ctx* ctx, double* inout, int64_t count);
+int kp_comm_allgather_fit(kp_ctx* ctx, int index, int W, double* K_all);
+int kp_fit_sharded(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* snaps_local, const double* lasso,
+                   int n_lasso, double* K_out);
+int kp_fit_gram_sharded(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* snaps_local, double* G, double* C);
+
 #ifdef __cplusplus
 }
 #endif

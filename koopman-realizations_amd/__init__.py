@@ -10,9 +10,10 @@ from . import _ffi
 from ._ffi import KoopmanHipError
 from .device import Basis, Context, Snapshots, fit, fit_gram, fit_refine
 from .device import Mpc
+from . import comm
 from .arm import Arm
 from .kmpc import Kmpc, Ksim, ModelPlant
 from .ksysid import Ksysid, default_context, poly_exponent_table
 
 __all__ = ["Arm", "Basis", "Context", "Snapshots", "fit", "fit_gram", "fit_refine", "Ksysid", "Kmpc", "Ksim", "ModelPlant", "Mpc", "KoopmanHipError", "default_context",
-           "poly_exponent_table", "_ffi"]
+           "poly_exponent_table", "_ffi", "comm"]

@@ -71,6 +71,15 @@ SIGNATURES = {
     "kp_mpc_last_qp": (C.c_int, [vp, c_dp, c_dp, c_dp, c_dp]),
     "kp_mpc_last_profile": (C.c_int, [vp, c_dp, c_ip]),
     "kp_qp_solve": (C.c_int, [vp, c_dp, c_dp, c_dp, c_dp, C.c_int, C.c_int, c_dp, c_ip]),
+    "kp_comm_unique_id": (C.c_int, [vp]),
+    "kp_comm_create": (C.c_int, [vp, vp, C.c_int, C.c_int]),
+    "kp_comm_destroy": (C.c_int, [vp]),
+    "kp_comm_info": (C.c_int, [vp, c_ip, c_ip]),
+    "kp_comm_allgather": (C.c_int, [vp, vp, C.c_int64, vp]),
+    "kp_comm_allreduce_sum": (C.c_int, [vp, c_dp, C.c_int64]),
+    "kp_comm_allgather_fit": (C.c_int, [vp, C.c_int, C.c_int, c_dp]),
+    "kp_fit_sharded": (C.c_int, [vp, vp, vp, c_dp, C.c_int, c_dp]),
+    "kp_fit_gram_sharded": (C.c_int, [vp, vp, vp, c_dp, c_dp]),
 }
 
 _lib = None

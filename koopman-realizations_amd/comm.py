@@ -1,0 +1,174 @@
+"""Multi-GPU plumbing, torch-free: one process per GPU, the collectives are the kp_comm_* entry points of
+libkoopman_hip.so (RCCL over xGMI, loaded by the library on first use).
+
+The reference has no parallel construct; its sweeps are serial MATLAB loops over independent units
+(Ksysid.train_models over a lasso vector, Ksysid.m:1372-1387; evaluate_rand_models.m:45-144 over random systems).
+Here the units are dealt round-robin to ranks (sweep.shard_units), there is no collective on the data path, and the
+objects below carry the final gather.  Anything with `.rank`, `.world`, `all_gather_bytes`, `all_reduce_sum` can stand
+in for `RcclComm` (the CPU tests pass a gloo-backed object with the same four members).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import pickle
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+from . import _ffi as F
+
+
+class LocalComm:
+    """world = 1: the gather of one."""
+    rank, world = 0, 1
+
+    def all_gather_bytes(self, payload: bytes):
+        return [bytes(payload)]
+
+    def all_reduce_sum(self, a):
+        return np.array(a, dtype=np.float64)
+
+    def barrier(self):
+        pass
+
+
+class RcclComm:
+    """kp_comm_create on a Context: RCCL communicator of `world` processes, this one being `rank`."""
+
+    def __init__(self, ctx, rank: int, world: int, unique_id: bytes):
+        if len(unique_id) != 128:
+            raise ValueError("RCCL unique id is 128 bytes")
+        self.ctx, self.rank, self.world = ctx, int(rank), int(world)
+        buf = C.create_string_buffer(unique_id, 128)
+        F.check(F.lib().kp_comm_create(ctx.handle, C.cast(buf, C.c_void_p), self.rank, self.world), ctx.handle)
+
+    def all_gather_bytes(self, payload: bytes):
+        """Every rank contributes the same number of bytes; returns the world payloads in rank order."""
+        n = len(payload)
+        send = C.create_string_buffer(bytes(payload), n)
+        recv = C.create_string_buffer(n * self.world)
+        F.check(F.lib().kp_comm_allgather(self.ctx.handle, C.cast(send, C.c_void_p), n, C.cast(recv, C.c_void_p)), self.ctx.handle)
+        raw = recv.raw
+        return [raw[r * n:(r + 1) * n] for r in range(self.world)]
+
+    def all_reduce_sum(self, a):
+        a = np.ascontiguousarray(a, dtype=np.float64).copy()
+        F.check(F.lib().kp_comm_allreduce_sum(self.ctx.handle, F.dptr(a), a.size), self.ctx.handle)
+        return a
+
+    def barrier(self):
+        self.all_reduce_sum(np.zeros(1))
+
+    def all_gather_fit(self, index: int, W: int):
+        """K of fit `index` (kp_fit_get_K numbering) of every rank, gathered device to device: (world, W, W)."""
+        K = np.zeros((self.world, W, W))
+        F.check(F.lib().kp_comm_allgather_fit(self.ctx.handle, int(index), int(W), F.dptr(K)), self.ctx.handle)
+        return np.transpose(K, (0, 2, 1))                 # each block was column-major
+
+    def close(self):
+        F.lib().kp_comm_destroy(self.ctx.handle)
+
+
+# ---- generic collectives on top of all_gather_bytes ------------------------------------------------------------
+
+def all_gather_array(comm, a):
+    """Equally shaped f64 arrays: returns (world,) + a.shape."""
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    parts = comm.all_gather_bytes(a.tobytes())
+    return np.stack([np.frombuffer(p, dtype=np.float64).reshape(a.shape) for p in parts])
+
+
+def all_gather_object(comm, obj):
+    """Picklable objects of any size: sizes first, then payloads padded to the largest."""
+    blob = pickle.dumps(obj, protocol=pickle.HIGHEST_PROTOCOL)
+    sizes = [int(np.frombuffer(p, dtype=np.int64)[0]) for p in comm.all_gather_bytes(np.array([len(blob)], dtype=np.int64).tobytes())]
+    mx = max(sizes)
+    parts = comm.all_gather_bytes(blob + b"\0" * (mx - len(blob)))
+    return [pickle.loads(p[:s]) for p, s in zip(parts, sizes)]
+
+
+def max_over_ranks(comm, x: float) -> float:
+    return float(all_gather_array(comm, np.array([x])).max())
+
+
+# ---- rendezvous of the 128-byte RCCL id (single node: a file) -----------------------------------------------------
+
+def unique_id() -> bytes:
+    buf = C.create_string_buffer(128)
+    F.check(F.lib().kp_comm_unique_id(C.cast(buf, C.c_void_p)))
+    return buf.raw
+
+
+def rendezvous_file_from_env() -> str:
+    """Path every rank of one launch agrees on.  KP_COMM_FILE when the launcher set it; otherwise derived from what a
+    torch.distributed.run launch exports to all its ranks (MASTER_PORT, run id) plus the launcher's pid."""
+    p = os.environ.get("KP_COMM_FILE")
+    if p:
+        return p
+    tag = "_".join([os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none"), str(os.getppid())])
+    return os.path.join(tempfile.gettempdir(), f"kp_comm_{tag}.id")
+
+
+def exchange_unique_id(rank: int, path: str, timeout: float = 120.0) -> bytes:
+    """Rank 0 creates the id and publishes it atomically (write + rename); the others wait for the file."""
+    if rank == 0:
+        uid = unique_id()
+        tmp = f"{path}.{os.getpid()}.tmp"
+        with open(tmp, "wb") as f:
+            f.write(uid)
+        os.replace(tmp, path)
+        return uid
+    t0 = time.time()
+    while time.time() - t0 < timeout:
+        try:
+            with open(path, "rb") as f:
+                uid = f.read()
+            if len(uid) == 128:
+                return uid
+        except FileNotFoundError:
+            pass
+        time.sleep(0.02)
+    raise TimeoutError(f"rank {rank}: no RCCL id appeared at {path}")
+
+
+def init_from_env(Context):
+    """One process per GPU: RANK / LOCAL_RANK / WORLD_SIZE from the environment (torch.distributed.run exports them; so
+    does `spawn_ranks`).  Returns (ctx, comm); world 1 gives a LocalComm."""
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    ctx = Context(local)
+    if world == 1:
+        return ctx, LocalComm()
+    path = rendezvous_file_from_env()
+    uid = exchange_unique_id(rank, path)
+    comm = RcclComm(ctx, rank, world, uid)
+    comm.barrier()
+    if rank == 0:
+        try:
+            os.remove(path)
+        except OSError:
+            pass
+    return ctx, comm
+
+
+def spawn_ranks(argv, world: int, env=None, timeout=None):
+    """Starts `world` fresh processes of `argv` (one per GPU) BEFORE anything in this process has touched a GPU and waits
+    for them.  Returns rank 0's stdout; raises if a rank failed."""
+    fd, path = tempfile.mkstemp(prefix="kp_comm_", suffix=".id")
+    os.close(fd); os.remove(path)
+    procs = []
+    for r in range(world):
+        e = dict(os.environ if env is None else env)
+        e.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(world), "KP_COMM_FILE": path,
+                  "HSA_ENABLE_IPC_MODE_LEGACY": e.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+        procs.append(subprocess.Popen(argv, env=e, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
+                                      stderr=None if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate(timeout=timeout)
+    codes = [procs[0].returncode] + [p.wait(timeout=timeout) for p in procs[1:]]
+    if any(codes):
+        raise RuntimeError(f"spawn_ranks: exit codes {codes}\n{out}")
+    return out

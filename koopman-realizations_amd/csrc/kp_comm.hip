@@ -1,0 +1,184 @@
+// Multi-GPU entry points: one process per GPU, RCCL over xGMI, loaded at run time (single-GPU use never touches librccl).
+// The path shards by independent units (lasso values, random systems, MPC problems: train_models loop Ksysid.m:1372-1387,
+// evaluate_rand_models.m:45-144) with NO collective on the data path; the only exchanges are the final gather of the
+// results and, when ONE fit is sharded over snapshots, a single all-reduce of the Gram pair [G | C].
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+
+#include "kp_internal.h"
+
+namespace {
+struct RcclApi {
+  void* handle = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  bool ok = false;
+};
+
+RcclApi& rccl() {
+  static RcclApi api = [] {
+    RcclApi a;
+    const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    for (const char* nm : names) {
+      a.handle = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+      if (a.handle) break;
+    }
+    if (!a.handle) return a;
+    a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(a.handle, "ncclGetUniqueId");
+    a.CommInitRank = (decltype(a.CommInitRank))dlsym(a.handle, "ncclCommInitRank");
+    a.CommDestroy = (decltype(a.CommDestroy))dlsym(a.handle, "ncclCommDestroy");
+    a.AllGather = (decltype(a.AllGather))dlsym(a.handle, "ncclAllGather");
+    a.AllReduce = (decltype(a.AllReduce))dlsym(a.handle, "ncclAllReduce");
+    a.GetErrorString = (decltype(a.GetErrorString))dlsym(a.handle, "ncclGetErrorString");
+    a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllGather && a.AllReduce && a.GetErrorString;
+    return a;
+  }();
+  return api;
+}
+}  // namespace
+
+struct kp_comm_state {
+  ncclComm_t comm = nullptr;
+  int rank = 0, world = 1;
+};
+
+#define KP_NCCL(ctx, expr)                                                                              \
+  do {                                                                                                  \
+    ncclResult_t _r = (expr);                                                                           \
+    if (_r != ncclSuccess) return (ctx)->fail(KP_ERR_HIP, std::string(#expr) + ": " + rccl().GetErrorString(_r)); \
+  } while (0)
+
+extern "C" int kp_comm_unique_id(void* id128) {
+  if (!id128) return KP_ERR_ARG;
+  if (!rccl().ok) {
+    kp_set_global_error("kp_comm_unique_id: librccl.so could not be loaded");
+    return KP_ERR_HIP;
+  }
+  ncclUniqueId id;
+  if (rccl().GetUniqueId(&id) != ncclSuccess) {
+    kp_set_global_error("kp_comm_unique_id: ncclGetUniqueId failed");
+    return KP_ERR_HIP;
+  }
+  static_assert(sizeof(ncclUniqueId) == 128, "RCCL unique id is 128 bytes");
+  std::memcpy(id128, &id, 128);
+  return KP_OK;
+}
+
+extern "C" int kp_comm_create(kp_ctx* ctx, const void* id128, int rank, int world) {
+  if (!ctx || !id128 || world < 1 || rank < 0 || rank >= world) return ctx ? ctx->fail(KP_ERR_ARG, "kp_comm_create: bad argument") : KP_ERR_ARG;
+  if (ctx->comm) return ctx->fail(KP_ERR_ARG, "kp_comm_create: this context already has a communicator");
+  if (!rccl().ok) return ctx->fail(KP_ERR_HIP, "kp_comm_create: librccl.so could not be loaded");
+  KP_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = kp_synchronize(ctx);
+  if (rc) return rc;
+  ncclUniqueId id;
+  std::memcpy(&id, id128, 128);
+  kp_comm_state* cs = new kp_comm_state;
+  cs->rank = rank;
+  cs->world = world;
+  ncclResult_t r = rccl().CommInitRank(&cs->comm, world, id, rank);
+  if (r != ncclSuccess) {
+    delete cs;
+    return ctx->fail(KP_ERR_HIP, std::string("ncclCommInitRank: ") + rccl().GetErrorString(r));
+  }
+  ctx->comm = cs;
+  return KP_OK;
+}
+
+extern "C" int kp_comm_destroy(kp_ctx* ctx) {
+  if (!ctx) return KP_ERR_ARG;
+  if (!ctx->comm) return KP_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->comm->comm) (void)rccl().CommDestroy(ctx->comm->comm);
+  delete ctx->comm;
+  ctx->comm = nullptr;
+  return KP_OK;
+}
+
+extern "C" int kp_comm_info(const kp_ctx* ctx, int* rank, int* world) {
+  if (!ctx) return KP_ERR_ARG;
+  if (rank) *rank = ctx->comm ? ctx->comm->rank : 0;
+  if (world) *world = ctx->comm ? ctx->comm->world : 1;
+  return KP_OK;
+}
+
+// recv (world x bytes) = concatenation of every rank's send (bytes), rank order.  Host buffers; staged through HBM.
+extern "C" int kp_comm_allgather(kp_ctx* ctx, const void* send, int64_t bytes, void* recv) {
+  if (!ctx || !send || !recv || bytes < 1) return ctx ? ctx->fail(KP_ERR_ARG, "kp_comm_allgather: bad argument") : KP_ERR_ARG;
+  KP_HIP(ctx, hipSetDevice(ctx->device));
+  if (!ctx->comm) {                               // single process: the gather of one
+    std::memcpy(recv, send, (size_t)bytes);
+    return KP_OK;
+  }
+  const int world = ctx->comm->world;
+  const size_t b8 = ((size_t)bytes + 7) / 8 * 8;
+  char* ws = (char*)ctx->workspace(8, b8 * (size_t)(world + 1));
+  if (!ws) return ctx->fail(KP_ERR_HIP, "kp_comm_allgather: out of device memory");
+  hipStream_t s = ctx->stream;
+  KP_HIP(ctx, hipMemcpyAsync(ws, send, (size_t)bytes, hipMemcpyHostToDevice, s));
+  KP_NCCL(ctx, rccl().AllGather(ws, ws + b8, b8, ncclChar, ctx->comm->comm, s));
+  for (int r = 0; r < world; ++r)
+    KP_HIP(ctx, hipMemcpyAsync((char*)recv + (size_t)r * bytes, ws + b8 * (size_t)(r + 1), (size_t)bytes, hipMemcpyDeviceToHost, s));
+  KP_HIP(ctx, hipStreamSynchronize(s));
+  return KP_OK;
+}
+
+// in-place sum over ranks of a host vector (barriers, timing maxima via +/-, small tables)
+extern "C" int kp_comm_allreduce_sum(kp_ctx* ctx, double* inout, int64_t count) {
+  if (!ctx || !inout || count < 1) return ctx ? ctx->fail(KP_ERR_ARG, "kp_comm_allreduce_sum: bad argument") : KP_ERR_ARG;
+  if (!ctx->comm) return KP_OK;
+  KP_HIP(ctx, hipSetDevice(ctx->device));
+  double* ws = (double*)ctx->workspace(8, (size_t)count * 8);
+  if (!ws) return ctx->fail(KP_ERR_HIP, "kp_comm_allreduce_sum: out of device memory");
+  hipStream_t s = ctx->stream;
+  KP_HIP(ctx, hipMemcpyAsync(ws, inout, (size_t)count * 8, hipMemcpyHostToDevice, s));
+  KP_NCCL(ctx, rccl().AllReduce(ws, ws, (size_t)count, ncclDouble, ncclSum, ctx->comm->comm, s));
+  KP_HIP(ctx, hipMemcpyAsync(inout, ws, (size_t)count * 8, hipMemcpyDeviceToHost, s));
+  KP_HIP(ctx, hipStreamSynchronize(s));
+  return KP_OK;
+}
+
+// device-resident all-reduce of the Gram pair of the current fit (used by kp_fit_sharded): G | C, 2 W^2 doubles
+int kp_comm_allreduce_dev(kp_ctx* ctx, double* buf_dev, size_t count, hipStream_t s) {
+  if (!ctx->comm) return KP_OK;
+  KP_NCCL(ctx, rccl().AllReduce(buf_dev, buf_dev, count, ncclDouble, ncclSum, ctx->comm->comm, s));
+  return KP_OK;
+}
+
+// K of fit `index` of the last asynchronous batch (or of the last synchronous kp_fit) of EVERY rank, gathered device to
+// device and copied out once: K_all = world matrices W x W back to back, rank order.
+extern "C" int kp_comm_allgather_fit(kp_ctx* ctx, int index, int W, double* K_all) {
+  if (!ctx || !K_all || index < 0 || W != ctx->Kres_W) return ctx ? ctx->fail(KP_ERR_ARG, "kp_comm_allgather_fit: bad argument") : KP_ERR_ARG;
+  KP_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = kp_synchronize(ctx);
+  if (rc) return rc;
+  size_t slot = (size_t)index;
+  if (ctx->kres_is_ring) {
+    if (index >= ctx->async_count || index < ctx->async_count - ctx->kring_cap)
+      return ctx->fail(KP_ERR_ARG, "kp_comm_allgather_fit: that fit is not in the result ring");
+    slot = (size_t)(index % ctx->kring_cap);
+  } else if (index >= ctx->Kres_n) {
+    return ctx->fail(KP_ERR_ARG, "kp_comm_allgather_fit: index out of range");
+  }
+  const size_t cnt = (size_t)W * W;
+  const double* src = ctx->Kres + slot * cnt;
+  if (!ctx->comm) {
+    KP_HIP(ctx, hipMemcpy(K_all, src, cnt * 8, hipMemcpyDeviceToHost));
+    return KP_OK;
+  }
+  const int world = ctx->comm->world;
+  double* ws = (double*)ctx->workspace(8, cnt * 8 * (size_t)world);
+  if (!ws) return ctx->fail(KP_ERR_HIP, "kp_comm_allgather_fit: out of device memory");
+  hipStream_t s = ctx->stream;
+  KP_NCCL(ctx, rccl().AllGather(src, ws, cnt, ncclDouble, ctx->comm->comm, s));
+  KP_HIP(ctx, hipMemcpyAsync(K_all, ws, cnt * 8 * (size_t)world, hipMemcpyDeviceToHost, s));
+  KP_HIP(ctx, hipStreamSynchronize(s));
+  return KP_OK;
+}

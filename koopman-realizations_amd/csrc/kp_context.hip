@@ -72,10 +72,11 @@ extern "C" int kp_create(int device_id, kp_ctx** out) {
 
 extern "C" int kp_destroy(kp_ctx* c) {
   if (!c) return KP_OK;
+  (void)kp_comm_destroy(c);
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   if (c->stream2) (void)hipStreamSynchronize(c->stream2);
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < 10; ++i)
     if (c->ws[i]) (void)hipFree(c->ws[i]);
   if (c->sticky_info) (void)hipFree(c->sticky_info);
   if (c->ev_gram_done) (void)hipEventDestroy(c->ev_gram_done);

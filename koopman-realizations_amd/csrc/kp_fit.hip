@@ -10,6 +10,9 @@
 #include <cmath>
 #include <cstdlib>
 
+#include <vector>
+#include <algorithm>
+
 #include "kp_internal.h"
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
@@ -528,7 +531,7 @@ extern "C" int kp_fit(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* sn
       if (lasso && lasso[i] < 1e6) return false;
     return true;
   }();
-  if (!K_out && n_lasso == 1 && all_ls && ctx->stream2 && ctx->sticky_info && !getenv("KP_NO_ASYNC")) {
+  if (!K_out && n_lasso == 1 && all_ls && ctx->stream2 && ctx->sticky_info && !ctx->reduce_grams && !getenv("KP_NO_ASYNC")) {
     // ---- asynchronous pipeline: this fit's solve (stream2) overlaps the next fit's Gram (stream) ----
     // two [G | C] buffers alternate, so this Gram's reduction only has to wait for the pad kernel (the solve's
     // copy of G | C) of the fit before the previous one -- never for the solve that is running right now
@@ -592,6 +595,10 @@ extern "C" int kp_fit(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* sn
   ctx->batch_closed = true;
   rc = kp_gram_dispatch(ctx, basis, snaps, ctx->GC);  // records ev0/ev1 around gram+reduce
   if (rc) return rc;
+  if (ctx->reduce_grams) {   // one fit sharded over snapshots: the only exchange is this all-reduce of [G | C]
+    rc = kp_comm_allreduce_dev(ctx, ctx->GC, (size_t)2 * W * W, ctx->stream);
+    if (rc) return rc;
+  }
   double* Gd = ctx->GC;
   double* Cd = ctx->GC + (size_t)W * W;
   bool need_ls = false;
@@ -691,5 +698,42 @@ extern "C" int kp_fit_async_slots(kp_ctx* ctx, int n_slots) {
   ctx->kres_is_ring = false;   // whatever the ring held is addressed with the old size: start over
   ctx->Kres_n = 0;
   ctx->async_count = 0;
+  return KP_OK;
+}
+
+// One fit whose snapshot pairs are sharded over the ranks of the communicator: every rank runs the fused Gram kernel on
+// its shard, ONE all-reduce of [G | C] (2 W^2 doubles, device to device over RCCL) is the only exchange, and every
+// rank solves the same system (identical K on all ranks).  Without a communicator this is kp_fit.
+extern "C" int kp_fit_sharded(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* snaps_local, const double* lasso, int n_lasso,
+                              double* K_out) {
+  if (!ctx) return KP_ERR_ARG;
+  if (ctx->async_pending) {
+    int rc0 = kp_synchronize(ctx);
+    if (rc0) return rc0;
+  }
+  ctx->reduce_grams = true;
+  std::vector<double> tmpK;
+  double* dst = K_out;
+  if (!dst && basis) {            // keep the synchronous path (K_out == NULL selects the asynchronous pipeline otherwise)
+    tmpK.resize((size_t)std::max(1, n_lasso) * basis->dev.W * basis->dev.W);
+    dst = tmpK.data();
+  }
+  int rc = kp_fit(ctx, basis, snaps_local, lasso, n_lasso, dst);
+  ctx->reduce_grams = false;
+  return rc;
+}
+
+// the Gram pair alone, summed over the ranks' shards
+extern "C" int kp_fit_gram_sharded(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* snaps_local, double* G, double* C) {
+  if (!ctx || !basis || !snaps_local) return ctx ? ctx->fail(KP_ERR_ARG, "kp_fit_gram_sharded: NULL handle") : KP_ERR_ARG;
+  int rc = kp_fit_gram(ctx, basis, snaps_local, nullptr, nullptr);
+  if (rc) return rc;
+  const int W = basis->dev.W;
+  rc = kp_comm_allreduce_dev(ctx, ctx->GC, (size_t)2 * W * W, ctx->stream);
+  if (rc) return rc;
+  size_t bW = (size_t)W * W * 8;
+  if (G) KP_HIP(ctx, hipMemcpyAsync(G, ctx->GC, bW, hipMemcpyDeviceToHost, ctx->stream));
+  if (C) KP_HIP(ctx, hipMemcpyAsync(C, ctx->GC + (size_t)W * W, bW, hipMemcpyDeviceToHost, ctx->stream));
+  KP_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return KP_OK;
 }

@@ -10,6 +10,7 @@
 #define KP_MAX_VARS 32
 
 void kp_set_global_error(const std::string& s);
+struct kp_comm_state;   // RCCL communicator of a multi-process run (kp_comm.hip)
 
 struct kp_ctx {
   int device = 0;
@@ -30,6 +31,8 @@ struct kp_ctx {
   const void* pend_basis = nullptr;   // dictionary / snapshot count / width of the fits in flight: a change drains the pipeline
   int64_t pend_Ns = 0;
   int pend_W = 0;
+  kp_comm_state* comm = nullptr;      // set by kp_comm_create: rank / world / RCCL communicator
+  bool reduce_grams = false;          // kp_fit_sharded: all-reduce [G | C] over the ranks between the Gram kernel and the solve
   // set by the asynchronous kp_fit around kp_gram_dispatch: the split-partial reduction runs on this stream
   // (after an event recorded behind the main Gram kernel) and the partial buffer `part_flip` is used
   hipStream_t reduce_stream = nullptr;
@@ -50,8 +53,8 @@ struct kp_ctx {
   double timers[8] = {0};
   double gram_flops_per_pair = 0;
   // growable device workspaces
-  void* ws[8] = {nullptr};
-  size_t ws_bytes[8] = {0};
+  void* ws[10] = {nullptr};     // slot 8: staging of the collectives
+  size_t ws_bytes[10] = {0};
   // results of the last kp_fit
   double* Kres = nullptr;   // n_lasso x W x W
   size_t Kres_bytes = 0;
@@ -226,6 +229,7 @@ inline int kp_gram_dispatch(kp_ctx* ctx, const kp_basis* basis, const kp_snapsho
   if (kp_gram5_applicable(basis)) return kp_gram5_launch(ctx, basis, s, GC_dev);
   return kp_gram2_applicable(basis) ? kp_gram2_launch(ctx, basis, s, GC_dev) : kp_gram_launch(ctx, basis, s, GC_dev);
 }
+int kp_comm_allreduce_dev(kp_ctx* ctx, double* buf_dev, size_t count, hipStream_t s);
 int kp_lift_dev(kp_ctx* ctx, const kp_basis* basis, int what, const double* dz, const double* du, int64_t rows, double* dout);
 int kp_chol_solve_dev(kp_ctx* ctx, double* G_dev, double* C_dev, int W, int ncols, double* K_dev, hipStream_t st = nullptr,
                       hipEvent_t pad_done = nullptr, int* sticky = nullptr);

@@ -5,12 +5,15 @@ The reference runs these loops serially in one MATLAB interpreter:
   * random-system sweep   evaluate_rand_models.m:45-144 (per system: linear deg 1..13,
                           bilinear deg 1..6, nonlinear deg 1..4 with lasso 4)
 Units (lasso values / systems) are dealt round-robin to ranks; there is NO collective on the
-data path.  The only communication is the final gather of the per-unit results
-(`torch.distributed.all_gather_object` / all_gather over RCCL on GPUs, gloo in CPU tests).
+data path.  The only communication is the final gather of the per-unit results through a `comm`
+object (comm.RcclComm: the kp_comm_* entry points of the library, RCCL over xGMI; the CPU tests pass a
+gloo-backed stand-in with the same members).  No torch in this package.
 """
 from __future__ import annotations
 
 import numpy as np
+
+from . import comm as _comm
 
 
 def shard_units(n_units: int, rank: int, world: int):
@@ -18,16 +21,14 @@ def shard_units(n_units: int, rank: int, world: int):
     return list(range(rank, n_units, world))
 
 
-def gather_results(local: dict, n_units: int, dist=None):
+def gather_results(local: dict, n_units: int, comm=None):
     """Final gather.  `local` maps unit id -> result (numpy array or picklable object).
     Returns the list of all results ordered by unit id on every rank."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if comm is None or comm.world == 1:
         merged = dict(local)
     else:
-        parts = [None] * dist.get_world_size()
-        dist.all_gather_object(parts, local)
         merged = {}
-        for p in parts:
+        for p in _comm.all_gather_object(comm, local):
             merged.update(p)
     missing = [i for i in range(n_units) if i not in merged]
     if missing:
@@ -35,36 +36,37 @@ def gather_results(local: dict, n_units: int, dist=None):
     return [merged[i] for i in range(n_units)]
 
 
-def gather_matrices(local: dict, n_units: int, shape, dist=None, device=None):
-    """Final gather of equally shaped f64 matrices with ONE tensor all_gather (RCCL on GPUs).
+def gather_matrices(local: dict, n_units: int, shape, comm=None):
+    """Final gather of equally shaped f64 matrices with ONE all-gather (RCCL on GPUs).
     Ranks own round-robin shards, so every rank contributes ceil(n/world) slots (padded)."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if comm is None or comm.world == 1:
         return [local[i] for i in range(n_units)]
-    import torch
-    world, rank = dist.get_world_size(), dist.get_rank()
+    world, rank = comm.world, comm.rank
     per = (n_units + world - 1) // world
-    buf = torch.zeros((per,) + tuple(shape), dtype=torch.float64)
+    buf = np.zeros((per,) + tuple(shape))
     for slot, uid in enumerate(shard_units(n_units, rank, world)):
-        buf[slot] = torch.from_numpy(np.ascontiguousarray(local[uid]))
-    if device is not None:
-        buf = buf.to(device)
-    out = [torch.empty_like(buf) for _ in range(world)]
-    dist.all_gather(out, buf)
+        buf[slot] = local[uid]
+    out = _comm.all_gather_array(comm, buf)
     res = [None] * n_units
     for r in range(world):
-        o = out[r].cpu().numpy()
         for slot, uid in enumerate(shard_units(n_units, r, world)):
-            res[uid] = o[slot]
+            res[uid] = out[r, slot]
     return res
 
 
-def lasso_sweep(fit_one, lassos, rank=0, world=1, dist=None, shape=None, device=None):
-    """Config 4: K for every lasso value.  fit_one(lasso) -> K (W x W)."""
+def lasso_sweep(fit_one, lassos, comm=None, shape=None, fit_many=None):
+    """Config 4: K for every lasso value.  fit_one(lasso) -> K (W x W); fit_many(list of lassos) -> list of K lets a rank
+    hand its whole shard to ONE kp_fit call (snapshots lifted once, values batched on the device)."""
     lassos = list(lassos)
-    local = {i: fit_one(lassos[i]) for i in shard_units(len(lassos), rank, world)}
+    rank, world = (0, 1) if comm is None else (comm.rank, comm.world)
+    mine = shard_units(len(lassos), rank, world)
+    if fit_many is not None:
+        local = dict(zip(mine, fit_many([lassos[i] for i in mine]))) if mine else {}
+    else:
+        local = {i: fit_one(lassos[i]) for i in mine}
     if shape is not None:
-        return gather_matrices(local, len(lassos), shape, dist, device)
-    return gather_results(local, len(lassos), dist)
+        return gather_matrices(local, len(lassos), shape, comm)
+    return gather_results(local, len(lassos), comm)
 
 
 def shard_rows(n_rows: int, rank: int, world: int):
@@ -74,19 +76,15 @@ def shard_rows(n_rows: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def fit_sharded(gram_fn, solve_fn, dist=None, device=None):
+def fit_sharded(gram_fn, solve_fn, comm=None):
     """ONE large fit sharded over snapshots (pattern 2): every rank accumulates the Grams
     G = Px'Px, C = Px'Py of its snapshot shard (gram_fn() -> (G, C)), a single all-reduce(sum) of the
     stacked [G; C] (2 W^2 doubles, 1.8 MB at W = 336) is the only exchange step, and every rank solves
-    G K = C (solve_fn(G, C) -> K), so all ranks hold the same K."""
+    G K = C (solve_fn(G, C) -> K), so all ranks hold the same K.  (Host-buffer form; device.fit_sharded keeps the
+    Grams in HBM and all-reduces them there: kp_fit_sharded.)"""
     G, C = gram_fn()
-    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
-        import torch
-        t = torch.from_numpy(np.ascontiguousarray(np.stack([np.asarray(G), np.asarray(C)])))
-        if device is not None:
-            t = t.to(device)
-        dist.all_reduce(t)          # sum over ranks (RCCL on GPUs)
-        t = t.cpu().numpy()
+    if comm is not None and comm.world > 1:
+        t = comm.all_reduce_sum(np.stack([np.asarray(G), np.asarray(C)]))
         G, C = np.asfortranarray(t[0]), np.asfortranarray(t[1])
     return solve_fn(G, C)
 
@@ -119,20 +117,21 @@ def eval_system(data4sysid, ctx=None, degrees=None, Ksysid=None):
     return out
 
 
-def rand_models_sweep(systems, rank=0, world=1, dist=None, ctx=None, degrees=None, eval_fn=None, batched=False):
+def rand_models_sweep(systems, comm=None, ctx=None, degrees=None, eval_fn=None, batched=False):
     """Config 5: every rank evaluates its systems; final gather of the error tables.
     Returns dict model_type -> array (max_degree x n_systems), as err_*_models in
     evaluate_rand_models.m:38-43.  batched=True: the rank's whole shard goes through
     `rand_models_sweep_batched` (one launch per model type and degree) instead of one Ksysid per fit."""
+    rank, world = (0, 1) if comm is None else (comm.rank, comm.world)
     mine = shard_units(len(systems), rank, world)
     if batched and eval_fn is None:
         tab = rand_models_sweep_batched([systems[i] for i in mine], ctx, degrees=degrees) if mine else {}
         local = {i: {mt: (tab[mt][:, k], None) for mt in tab} for k, i in enumerate(mine)}
-        allres = gather_results(local, len(systems), dist)
+        allres = gather_results(local, len(systems), comm)
         return {mt: np.stack([r[mt][0] for r in allres], axis=1) for mt in ("linear", "bilinear", "nonlinear")}
     eval_fn = eval_fn or (lambda d: eval_system(d, ctx=ctx, degrees=degrees))
     local = {i: eval_fn(systems[i]) for i in mine}
-    allres = gather_results(local, len(systems), dist)
+    allres = gather_results(local, len(systems), comm)
     return {mt: np.stack([r[mt][0] for r in allres], axis=1) for mt in ("linear", "bilinear", "nonlinear")}
 
 

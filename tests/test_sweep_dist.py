@@ -1,6 +1,6 @@
-"""CPU tests of the multi-GPU sweep path: unit sharding and the final gather, with
-world_size-2 gloo processes (the compute function is a stand-in; on the GPU box the same
-code runs one process per GPU over RCCL)."""
+"""CPU tests of the multi-GPU sweep path: unit sharding, packing and the final gather - the same code that runs one
+process per GPU over RCCL (comm.RcclComm through the C ABI) - here with world_size-2 gloo processes standing in for the
+collectives (the compute function is a stand-in; the HIP path on one GPU is covered by test_gpu_sweep.py)."""
 import os
 import socket
 import sys
@@ -16,35 +16,89 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
+class GlooComm:
+    """The four members the sweep code needs from a communicator, over torch.distributed / gloo (test-only: the
+    package itself is torch-free)."""
+
+    def __init__(self, dist):
+        self.dist, self.rank, self.world = dist, dist.get_rank(), dist.get_world_size()
+
+    def all_gather_bytes(self, payload):
+        import torch
+        t = torch.frombuffer(bytearray(payload), dtype=torch.uint8)
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        return [bytes(o.numpy().tobytes()) for o in out]
+
+    def all_reduce_sum(self, a):
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64).copy())
+        self.dist.all_reduce(t)
+        return t.numpy()
+
+    def barrier(self):
+        self.dist.barrier()
+
+
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
-    from koopman_realizations_amd import sweep
+    from koopman_realizations_amd import sweep, comm as kcomm
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        comm = GlooComm(dist)
         lassos = [0.1 * (i + 1) for i in range(7)]            # ragged: 7 units over 2 ranks
         calls = []
 
         def fit_one(l):
             calls.append(l)
             return np.full((3, 3), l) + np.eye(3)
-        Ks = sweep.lasso_sweep(fit_one, lassos, rank, world, dist, shape=(3, 3))
-        Ko = sweep.lasso_sweep(fit_one, lassos, rank, world, dist)           # object gather path
+        Ks = sweep.lasso_sweep(fit_one, lassos, comm, shape=(3, 3))
+        Ko = sweep.lasso_sweep(fit_one, lassos, comm)           # object gather path (ragged pickles)
+        Km = sweep.lasso_sweep(None, lassos, comm, shape=(3, 3), fit_many=lambda ls: [fit_one(l) for l in ls])
+        assert all((a == b).all() for a, b in zip(Ks, Km))
         systems = list(range(5))
 
         def eval_fn(sysid):
             return {mt: (np.arange(1, d + 1) * (sysid + 1.0), np.arange(d)) for mt, d in sweep.MAX_DEGREE.items()}
-        tab = sweep.rand_models_sweep(systems, rank, world, dist, eval_fn=eval_fn)
+        tab = sweep.rand_models_sweep(systems, comm, eval_fn=eval_fn)
         # snapshot-sharded single fit: Grams of the local rows, one all-reduce, local solve
         rng = np.random.default_rng(5)
         P = rng.standard_normal((101, 6)); Y = rng.standard_normal((101, 6))
         lo, hi = sweep.shard_rows(101, rank, world)
-        Ksh = sweep.fit_sharded(lambda: (P[lo:hi].T @ P[lo:hi], P[lo:hi].T @ Y[lo:hi]), np.linalg.solve, dist)
+        Ksh = sweep.fit_sharded(lambda: (P[lo:hi].T @ P[lo:hi], P[lo:hi].T @ Y[lo:hi]), np.linalg.solve, comm)
         assert np.abs(Ksh - np.linalg.lstsq(P, Y, rcond=None)[0]).max() < 1e-12
-        q.put((rank, len(calls) // 2, [k.tolist() for k in Ks], [k.tolist() for k in Ko], {k: v.tolist() for k, v in tab.items()}))
+        assert kcomm.max_over_ranks(comm, 1.0 + rank) == float(world)
+        objs = kcomm.all_gather_object(comm, {"rank": rank, "pad": "x" * (10 + 1000 * rank)})
+        assert [o["rank"] for o in objs] == list(range(world))
+        q.put((rank, len(calls) // 3, [k.tolist() for k in Ks], [k.tolist() for k in Ko], {k: v.tolist() for k, v in tab.items()}))
     finally:
         dist.destroy_process_group()
+
+
+def test_unique_id_file_rendezvous(tmp_path, monkeypatch):
+    """Rank 0 publishes the 128-byte id atomically, the other ranks read it (the id itself comes from RCCL on a GPU box)."""
+    from koopman_realizations_amd import comm as kcomm
+    monkeypatch.setattr(kcomm, "unique_id", lambda: bytes(range(128)))
+    path = str(tmp_path / "id")
+    with pytest.raises(TimeoutError):
+        kcomm.exchange_unique_id(1, path, timeout=0.1)
+    assert kcomm.exchange_unique_id(0, path) == bytes(range(128))
+    assert kcomm.exchange_unique_id(1, path, timeout=1.0) == bytes(range(128))
+    monkeypatch.setenv("KP_COMM_FILE", path)
+    assert kcomm.rendezvous_file_from_env() == path
+    loc = kcomm.LocalComm()
+    assert kcomm.all_gather_object(loc, {"a": 1}) == [{"a": 1}] and kcomm.all_gather_array(loc, np.arange(3.0)).shape == (1, 3)
+
+
+def test_package_is_torch_free():
+    import re
+    pk = os.path.join(ROOT, "koopman-realizations_amd")
+    for fn in os.listdir(pk):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pk, fn)).read()
+            assert not re.search(r"^\s*(import torch|from torch)", src, re.M), fn
 
 
 def test_sharding_is_a_partition():
