@@ -375,6 +375,7 @@ def main():
     del os.environ["KP_NO_ASYNC"]
     fit_latency_ms = float(np.median(lat)) * 1e3
     # the public entry point end to end: Ksysid.get_Koopman's device part with K fetched (one refinement step excluded)
+    kra.fit(ctx, basis, snaps)
     t1 = time.perf_counter(); kra.fit(ctx, basis, snaps); fit_fetch_ms = (time.perf_counter() - t1) * 1e3
 
     mpc_res = arm_res = widths = None

@@ -125,10 +125,11 @@ def exchange_unique_id(rank: int, path: str, timeout: float = 120.0) -> bytes:
     t0 = time.time()
     while time.time() - t0 < timeout:
         try:
-            with open(path, "rb") as f:
-                uid = f.read()
-            if len(uid) == 128:
-                return uid
+            if os.path.getmtime(path) >= t0 - 60.0:     # a file left behind by a crashed earlier launch is not ours
+                with open(path, "rb") as f:
+                    uid = f.read()
+                if len(uid) == 128:
+                    return uid
         except FileNotFoundError:
             pass
         time.sleep(0.02)
@@ -140,6 +141,8 @@ def init_from_env(Context):
     does `spawn_ranks`).  Returns (ctx, comm); world 1 gives a LocalComm."""
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if "KP_FORCE_DEVICE" in os.environ:          # debugging on a one-GPU box: all ranks on one device (if RCCL accepts it)
+        local = int(os.environ["KP_FORCE_DEVICE"])
     ctx = Context(local)
     if world == 1:
         return ctx, LocalComm()
