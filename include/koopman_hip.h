@@ -128,8 +128,12 @@ int kp_snapshots_destroy(kp_snapshots* snaps);
  *   accumulations PxTPx = Px'*Px (:1114), PxTPy = Px'*Py (:1125).  Px/Py are never
  *   materialised.  G, C: W x W column-major, caller allocated (either may be NULL).
  * kp_fit_solve: K = Px \ Py (Ksysid.m:1069) from the normal equations G K = C by Cholesky.
- *   ncols = columns of C.  KP_ERR_NOT_SPD when Psi is rank deficient (MATLAB warns and
- *   returns a basic solution there, which is not reproducible).
+ *   ncols = columns of C.  When Psi is rank deficient (arm marker data without dim_red) MATLAB's `\`
+ *   warns and returns a BASIC solution from QR with column pivoting; here: Cholesky with diagonal pivoting selects the
+ *   column subset (same greedy rule in Gram space), K is the least-squares solution over those columns and zero in the
+ *   other rows, the call returns KP_OK, kp_last_error() carries the warning and kp_fit_last_rank the rank (W when G was
+ *   positive definite).  kp_fit does the same on its synchronous path; the asynchronous pipeline (K_out == NULL) reports
+ *   KP_ERR_NOT_SPD from kp_synchronize instead.
  * kp_fit_lasso: solve_KoopmanQP (Ksysid.m:1095-1176, delays = 0):
  *   min 1/2||Px K - Py||_F^2  s.t. ||vec K||_1 <= t,  t = lasso * N (:996).
  * kp_fit: get_Koopman end to end for n_lasso values (train_models loop :1372-1387) on
@@ -139,6 +143,7 @@ int kp_snapshots_destroy(kp_snapshots* snaps);
  */
 int kp_fit_gram(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* snaps, double* G, double* C);
 int kp_fit_solve(kp_ctx* ctx, const double* G, const double* C, int W, int ncols, double* K);
+int kp_fit_last_rank(const kp_ctx* ctx, int* rank);
 int kp_fit_lasso(kp_ctx* ctx, const double* G, const double* C, int W, int ncols, double t,
                  int max_iter, double tol, double* K, int* iters);
 /* nv lasso values on the same Grams at once (the train_models loop over a lasso vector, Ksysid.m:1372-1387, re-lifts

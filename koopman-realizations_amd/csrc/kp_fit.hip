@@ -58,7 +58,8 @@ __device__ __forceinline__ double lane_bcast(double v, int lane) {
 // workgroup barrier.  Writes L (lower) / L' (upper) into A, the block D (LDS, lower part) and the reciprocals
 // Dd of its diagonal.  The inverses of the diagonal blocks, which only the TRSM kernel needs, are formed after the
 // factorisation by kp_chol_finish_kernel, off the critical path.
-__device__ __forceinline__ void chol_diag_block(double* __restrict__ A, int n, int k0, double (*D)[16], double* Dd, int* bad) {
+__device__ __forceinline__ void chol_diag_block(double* __restrict__ A, int n, int k0, double (*D)[16], double* Dd, int* bad,
+                                                const double* __restrict__ odiag) {
   const int lane = threadIdx.x & 63;
   const int r = lane & 15;
   double row[16];
@@ -67,7 +68,9 @@ __device__ __forceinline__ void chol_diag_block(double* __restrict__ A, int n, i
 #pragma unroll
   for (int c = 0; c < 16; ++c) {
     double d = lane_bcast(row[c], c);
-    if (!(d > 0.0)) {
+    // a pivot that is rounding noise of its original diagonal entry (n * 8 eps of it) is as singular as a non-positive
+    // one: the caller falls back to the rank-revealing solve
+    if (!(d > odiag[k0 + c])) {
       if (lane == 0) *bad = 1;
       d = 1.0;
     }
@@ -189,10 +192,12 @@ __global__ __launch_bounds__(CH_NT) void kp_chol_kernel(double* __restrict__ A, 
   double* Pin = sm;                     // A21 as [q][row], leading dimension n
   double* Lt = sm + (size_t)16 * n;     // L21 as [q][row]
   const int tid = threadIdx.x, wave = tid >> 6;
+  __shared__ double odiag[512];         // pivot thresholds: n * 8 eps * original diagonal (0 for the identity padding)
   if (tid == 0) bad = 0;
+  for (int i = tid; i < n; i += CH_NT) odiag[i] = fmax(A[(size_t)i * n + i], 0.0) * ((double)n * 8.0 * 2.220446049250313e-16);
   __syncthreads();
   const int nt = n / 16;
-  if (wave == 0) chol_diag_block(A, n, 0, D, Dd, &bad);
+  if (wave == 0) chol_diag_block(A, n, 0, D, Dd, &bad, odiag);
   __syncthreads();
   if (prof) tlast = clock64();
   for (int kb = 0; kb < nt; ++kb) {
@@ -242,7 +247,7 @@ __global__ __launch_bounds__(CH_NT) void kp_chol_kernel(double* __restrict__ A, 
     CH_TICK(2);
     if (wave == 0) {
 #if KP_CHOL_ABL != 2
-      chol_diag_block(A, n, k0 + 16, D, Dd, &bad);
+      chol_diag_block(A, n, k0 + 16, D, Dd, &bad, odiag);
 #endif
     } else {
       // the triangle of ntb x ntb micro tiles is folded into an (ntb+1) x (ntb/2) rectangle; tiles (0,0),(1,0),(1,1) are done
@@ -376,7 +381,7 @@ int kp_chol_solve_dev(kp_ctx* ctx, double* G_dev, double* C_dev, int W, int ncol
   int* info = (int*)(ws + bG + bC + bD);
   size_t lds_chol = (size_t)2 * 16 * n * 8;
   size_t lds_trsm = ((size_t)n * 16 + 1024) * 8;
-  if (lds_chol > 160 * 1024 - 4096 || lds_trsm > 160 * 1024 || n > 16 * 4 * TR_MAXJ) return ctx->fail(KP_ERR_ARG, "kp_fit_solve: W too large (max 512)");
+  if (lds_chol > 160 * 1024 - 8192 || lds_trsm > 160 * 1024 || n > 16 * 4 * TR_MAXJ) return ctx->fail(KP_ERR_ARG, "kp_fit_solve: W too large (max 512)");
   int64_t tot = (int64_t)n * n + (int64_t)n * ncp;
   hipLaunchKernelGGL(kp_pad_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, G_dev, C_dev, W, ncols, n, ncp, Gp, Cp);
   KP_HIP(ctx, hipGetLastError());
@@ -515,7 +520,23 @@ extern "C" int kp_fit_solve(kp_ctx* ctx, const double* G, const double* C, int W
   float ms = 0;
   (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
   ctx->timers[1] = ms;
-  if (bad) return ctx->fail(KP_ERR_NOT_SPD, "kp_fit_solve: Gram matrix is not numerically positive definite (rank-deficient dictionary)");
+  ctx->last_rank = W;
+  if (bad) {
+    // rank-deficient dictionary: MATLAB's `\` warns and returns a basic solution (QR with column pivoting); same here
+    int r = 0;
+    rc = kp_pivchol_solve_dev(ctx, Gd, Cd, W, ncols, Kd, &r);
+    if (rc) return rc;
+    ctx->last_rank = r;
+    KP_HIP(ctx, hipMemcpyAsync(K, Kd, bC, hipMemcpyDeviceToHost, ctx->stream));
+    KP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->err = "warning: Gram matrix is rank deficient; basic solution returned (kp_fit_last_rank)";
+  }
+  return KP_OK;
+}
+
+extern "C" int kp_fit_last_rank(const kp_ctx* ctx, int* rank) {
+  if (!ctx || !rank) return KP_ERR_ARG;
+  *rank = ctx->last_rank;
   return KP_OK;
 }
 
@@ -644,7 +665,21 @@ extern "C" int kp_fit(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* sn
     float ms = 0;
     if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) ctx->timers[3] = ms;
   }
-  if (bad) return ctx->fail(KP_ERR_NOT_SPD, "kp_fit: Gram matrix is not numerically positive definite (rank-deficient dictionary)");
+  ctx->last_rank = W;
+  if (bad) {
+    // rank-deficient dictionary (Ksysid.m:1069 on the arm data without dim_red): basic solution + rank, like MATLAB's `\`
+    int r = 0;
+    double* Kls = ctx->Kres + (size_t)ls_index * W * W;
+    rc = kp_pivchol_solve_dev(ctx, Gd, Cd, W, W, Kls, &r);
+    if (rc) return rc;
+    ctx->last_rank = r;
+    for (int i = 0; i < n_lasso; ++i)
+      if (i != ls_index && (!lasso || !(lasso[i] < 1e6)))
+        KP_HIP(ctx, hipMemcpyAsync(ctx->Kres + (size_t)i * W * W, Kls, (size_t)W * W * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    if (K_out) KP_HIP(ctx, hipMemcpyAsync(K_out, ctx->Kres, (size_t)n_lasso * W * W * 8, hipMemcpyDeviceToHost, ctx->stream));
+    KP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->err = "warning: Gram matrix is rank deficient; basic solution returned (kp_fit_last_rank)";
+  }
   return KP_OK;
 }
 

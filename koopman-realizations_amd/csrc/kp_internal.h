@@ -53,8 +53,9 @@ struct kp_ctx {
   double timers[8] = {0};
   double gram_flops_per_pair = 0;
   // growable device workspaces
-  void* ws[10] = {nullptr};     // slot 8: staging of the collectives
+  void* ws[10] = {nullptr};     // slot 8: staging of the collectives, 9: rank-revealing solve
   size_t ws_bytes[10] = {0};
+  int last_rank = -1;           // rank found by the most recent solve (W when the Gram matrix was positive definite)
   // results of the last kp_fit
   double* Kres = nullptr;   // n_lasso x W x W
   size_t Kres_bytes = 0;
@@ -229,6 +230,7 @@ inline int kp_gram_dispatch(kp_ctx* ctx, const kp_basis* basis, const kp_snapsho
   if (kp_gram5_applicable(basis)) return kp_gram5_launch(ctx, basis, s, GC_dev);
   return kp_gram2_applicable(basis) ? kp_gram2_launch(ctx, basis, s, GC_dev) : kp_gram_launch(ctx, basis, s, GC_dev);
 }
+int kp_pivchol_solve_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, int W, int ncols, double* K_dev, int* rank);
 int kp_comm_allreduce_dev(kp_ctx* ctx, double* buf_dev, size_t count, hipStream_t s);
 int kp_lift_dev(kp_ctx* ctx, const kp_basis* basis, int what, const double* dz, const double* du, int64_t rows, double* dout);
 int kp_chol_solve_dev(kp_ctx* ctx, double* G_dev, double* C_dev, int W, int ncols, double* K_dev, hipStream_t st = nullptr,

@@ -43,6 +43,12 @@ class Context:
         """Waits for asynchronous fits (fit(..., fetch=False)); raises if one of them failed."""
         F.check(F.lib().kp_synchronize(self._h), self._h)
 
+    def last_rank(self) -> int:
+        """Rank found by the most recent solve (kp_fit_last_rank): W unless the dictionary was rank deficient."""
+        r = C.c_int()
+        F.check(F.lib().kp_fit_last_rank(self._h, C.byref(r)), self._h)
+        return r.value
+
     def fit_async_slots(self, n_slots: int):
         """Size of the result ring of asynchronous fits (fit(..., fetch=False)): the last n_slots fits of a batch stay
         retrievable with fit_result(q)."""

@@ -416,7 +416,12 @@ class Ksysid:
             obj_lasso = np.atleast_1d(self.lasso)
             if np.all(obj_lasso >= 1e6):                                   # :1068 tests the PROPERTY
                 K = fit(self.ctx, self.basis_dev, snaps, [np.inf])[0]
-                if self.ls_refine:                                         # K = Px \ Py (:1069) to QR accuracy
+                rank = self.ctx.last_rank()
+                if rank < self.basis_dev.W:                                # MATLAB's `\`: "Warning: Rank deficient, rank = ..."
+                    import warnings
+                    warnings.warn(f"Rank deficient, rank = {rank} of {self.basis_dev.W}: basic solution returned "
+                                  "(use dim_red=True as example_sysid.m does)", RuntimeWarning)
+                elif self.ls_refine:                                       # K = Px \ Py (:1069) to QR accuracy
                     K = fit_refine(self.ctx, self.basis_dev, snaps, K, int(self.ls_refine))
             else:                                                          # :994-999: t = lasso * N
                 lval = 1e4 if lasso is None else float(lasso)

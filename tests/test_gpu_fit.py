@@ -132,13 +132,57 @@ def test_solve_parity(ctx, W, nc):
     assert np.abs(K - Kref).max() <= 1e-11 * np.abs(Kref).max()
 
 
-def test_solve_reports_rank_deficiency(ctx):
-    P = np.random.default_rng(0).standard_normal((50, 8))
+def _pivoted_qr_basic_solution(Px, Py):
+    """MATLAB's `\\` on a rank-deficient rectangular system (Ksysid.m:1069): Householder QR with column pivoting, rank from
+    the diagonal of R (tolerance max(size) eps |R_11|), basic solution over the first r pivot columns."""
+    import scipy.linalg as sla
+    Q, R, piv = sla.qr(Px, mode="economic", pivoting=True)
+    d = np.abs(np.diag(R))
+    r = int((d > max(Px.shape) * np.finfo(float).eps * d[0]).sum())
+    K = np.zeros((Px.shape[1], Py.shape[1]))
+    K[piv[:r]] = sla.solve_triangular(R[:r, :r], Q[:, :r].T @ Py)
+    return K, r
+
+
+def test_solve_of_rank_deficient_systems_returns_a_basic_solution_and_the_rank(ctx):
+    """kp_fit_solve on singular Gram matrices: no error, a basic solution (zero rows outside the selected columns), the
+    rank, and the residual of LAPACK's pivoted-QR basic solution."""
+    rng = np.random.default_rng(0)
+    P = rng.standard_normal((50, 8)); Y = rng.standard_normal((50, 3))
     P[:, 7] = P[:, 0] + P[:, 1]
-    with pytest.raises(kra.KoopmanHipError) as e:
-        ctx.fit_solve(P.T @ P - 1e-3 * np.eye(8) * 0, P.T @ P[:, :2]) if False else ctx.fit_solve(
-            np.diag([1.0, 1, 1, -1.0]), np.eye(4))
-    assert e.value.code == F.KP_ERR_NOT_SPD
+    K = ctx.fit_solve(P.T @ P, P.T @ Y)
+    assert ctx.last_rank() == 7
+    assert (np.abs(K).sum(axis=1) == 0).sum() == 1                       # one column of Px is left out
+    Kq, r = _pivoted_qr_basic_solution(P, Y)
+    assert r == 7
+    assert np.abs((P @ K - Y) - (P @ Kq - Y)).max() < 1e-10
+    # a full-rank system right after it reports its full rank
+    P2 = rng.standard_normal((60, 8))
+    ctx.fit_solve(P2.T @ P2, P2.T @ rng.standard_normal((60, 2)))
+    assert ctx.last_rank() == 8
+    # an indefinite "Gram" matrix: the pivoting stops at the first non-positive pivot
+    K = ctx.fit_solve(np.diag([1.0, 2.0, 4.0, -1.0]), np.eye(4))
+    assert ctx.last_rank() == 3 and np.allclose(K, np.diag([1.0, 0.5, 0.25, 0.0]))
+
+
+@pytest.mark.parametrize("mt,deg,rank", [("bilinear", 3, 252), ("linear", 2, 28), ("bilinear", 2, 100)])
+def test_fit_arm_data_without_dim_red_is_rank_deficient_like_the_reference(ctx, arm, mt, deg, rank):
+    """The arm's marker coordinates satisfy link-length identities, so the full polynomial dictionaries are exactly rank
+    deficient (poly-3 bilinear 252 of 336, poly-2 lift 25 of 28).  MATLAB's `\\` (Ksysid.m:1069) returns a
+    basic solution from pivoted QR; the device returns one from pivoted Cholesky: same rank, same residual (every
+    basic solution over a column subset spanning range(Px) has the residual of the projection)."""
+    p = arm["pairs"]
+    dic = ko.build_dictionary(mt, 6, 3, ["poly"], [deg])
+    b = make_basis(ctx, dic)
+    snaps = kra.Snapshots(ctx, p["alpha"], p["beta"], p["u"])
+    K = kra.fit(ctx, b, snaps)[0]
+    Px, Py = ko.px_py(dic, p)
+    Kq, r = _pivoted_qr_basic_solution(Px, Py)
+    assert r == rank
+    assert ctx.last_rank() == rank
+    assert (np.abs(K).sum(axis=1) == 0).sum() == dic.W - rank
+    res, resq = Px @ K - Py, Px @ Kq - Py
+    assert np.abs(res - resq).max() < 1e-8 * max(1.0, np.abs(Py).max())
 
 
 @pytest.mark.parametrize("mt,deg,dim_red", [("bilinear", 3, True), ("linear", 3, True), ("nonlinear", 3, True), ("linear", 2, True)])
