@@ -227,8 +227,10 @@ int kp_rollout_nl(kp_ctx* ctx, const kp_basis* basis, int batch, const double* K
  * kp_mpc_set_state_bounds: n scaled-down lower / upper bounds (scaledown.y(state_bounds')', :313); n = 0 removes them.
  *   The reference writes the kron block of E into the first (Np+1) n columns of the stacked lifted state (:306) - not
  *   strided by N - and that is reproduced: the bounded entries are s = i n + j of [z_0; ...; z_Np].  The rows are dense
- *   in U and depend on z for bilinear models; steps with state bounds are single-problem, iters = 1, and go through
- *   the generic QP kernel (KP_ERR_ARG from kp_mpc_step_batch / iters > 1).
+ *   in U and depend on z for bilinear models: such steps assemble the dense constraint matrix per problem and go through
+ *   the generic QP kernel (one wave per problem) - single steps, kp_mpc_step_batch and iters > 1 alike; with iters > 1 the
+ *   constraint matrix stays the one of the current state, as in the reference (A = get_constraintL_bilinear(zrow) is
+ *   formed before the iteration loop, Kmpc.m:861), only H and f follow the predicted lifted states (:874-899).
  * kp_mpc_step: one get_mpcInput (Kmpc.m:329-387) / get_mpcInput_bilinear_iter
  *   (:817-904) call: z is the lifted state (N), u_prev = traj.u(end,:) (m), Yr the
  *   padded, vectorised reference (nproj*(Np+1), :354-365); iters as in :874.

@@ -53,6 +53,8 @@ struct kp_mpc {
   double* sb_A = nullptr;                       // dense constraint matrix of a step: (nrows + sb_rows) x nvar, column-major
   double* sb_b = nullptr;                       // | right-hand sides | row norms | solution x
   int* sb_col = nullptr;                        // ELL column table of a dense matrix: col[k * rows + r] = k
+  size_t sb_cap = 0;                            // problems sb_A / sb_b are sized for
+  double* sb_work = nullptr;                    // [sb_cap][nvar^2 + nvar + nrows]: H, f, b of every problem of a batch
 };
 
 // ---- wave-level helpers (64 lanes): DPP inside 16-lane rows, v_readlane across the 4 rows ----
@@ -503,11 +505,19 @@ __device__ __forceinline__ int qp_goldfarb_idnani(const double* Hq, const double
 }
 
 // ---- generic QP shim kernel -----------------------------------------------------------------
+// One wave per problem.  Problem p = blockIdx.x reads H + p sH, f + p sf, the ELL values / row norms + p sA / p sb and
+// b + p sb, writes x + p n and status[p] (strides in doubles; 0 for a single problem).  sticky: a problem whose status
+// word already carries a failure (an earlier linearisation pass) is left alone.
 __global__ __launch_bounds__(64) void kp_qp_kernel(const double* H, const double* f, EllMat A, const double* b, int n, int mr,
-                                                   double* x, int* status) {
+                                                   double* x, int* status, size_t sH, size_t sf, size_t sA, size_t sb, int sticky) {
   extern __shared__ double sm[];
-  int st = qp_goldfarb_idnani(H, f, A, b, n, mr, sm, x, 1e-10);
-  if (threadIdx.x == 0) *status = st ? KP_ERR_QP_FAIL : KP_OK;
+  const size_t p = blockIdx.x;
+  if (sticky && status[p] != KP_OK) return;
+  EllMat Ap = A;
+  Ap.val = A.val + p * sA;
+  Ap.norm = A.norm + p * sb;
+  int st = qp_goldfarb_idnani(H + p * sH, f + p * sf, Ap, b + p * sb, n, mr, sm, x + p * (size_t)n, 1e-10);
+  if (threadIdx.x == 0) status[p] = st ? KP_ERR_QP_FAIL : KP_OK;
 }
 
 // dense (mr x n, column-major) -> ELL on the host
@@ -574,7 +584,7 @@ extern "C" int kp_qp_solve(kp_ctx* ctx, const double* H, const double* f, const 
     KP_HIP(ctx, hipFuncSetAttribute((const void*)kp_qp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     lds_set = lds;
   }
-  hipLaunchKernelGGL(kp_qp_kernel, dim3(1), dim3(64), lds, s, dH, df, E, db, n, mr, dx, dst);
+  hipLaunchKernelGGL(kp_qp_kernel, dim3(1), dim3(64), lds, s, dH, df, E, db, n, mr, dx, dst, (size_t)0, (size_t)0, (size_t)0, (size_t)0, 0);
   KP_HIP(ctx, hipGetLastError());
   int st = 0;
   KP_HIP(ctx, hipMemcpyAsync(x, dx, (size_t)n * 8, hipMemcpyDeviceToHost, s));
@@ -625,6 +635,8 @@ struct MpcArgs {
   EllMat ell;
   int* warm;            // [1 + nvar] active set of the previous single-problem step (nullptr: cold start)
   int assemble_only;    // stop after the QP data have been exported (state-bound steps solve with the generic QP kernel)
+  const double* U_lin;  // [nb][nvar] or nullptr: re-linearise along the lifted horizon of THESE inputs (pass >= 2 of a
+                        // state-bound step, Kmpc.m:890-895) instead of starting from z
   const double* z;      // [nb][N]      (or nullptr with zeta)
   const double* zeta;   // [nb][nzeta]  (fused lift)
   const double* u_prev; // [nb][m]
@@ -659,7 +671,7 @@ __global__ __launch_bounds__(256) void kp_mpc_step_kernel(MpcArgs a) {
   double* f = Hq + nv * nv;
   double* bq = f + nv;
   double* zh = bq + nr;                  // (Np+1) x N   lifted horizon (iters > 1)
-  double* full = zh + (a.iters > 1 ? (Np + 1) * N : 0);
+  double* full = zh + ((a.iters > 1 || a.U_lin) ? (Np + 1) * N : 0);
   int* st_sh = (int*)(full + (a.has_basis ? a.basis.nfull : 0));   // one slot for the QP status
   double* qpws = (double*)st_sh + 1;
   qpws += (qpws - sm) & 1;                // 16-byte aligned (sm is), by index arithmetic: the pointer stays an LDS pointer
@@ -717,7 +729,35 @@ __global__ __launch_bounds__(256) void kp_mpc_step_kernel(MpcArgs a) {
   }
   int status = 0;
   if (stamps && tid == 0) stamps[1] = wall_clock64();
-  for (int iter = 0; iter < a.iters; ++iter) {
+  // lifted horizon along an input sequence x = [u_0; u_1; ...] (Kmpc.m:891-895)
+  auto lifted_horizon = [&](const double* x) {
+    if (tid < 64) {
+      for (int c = tid; c < N; c += 64) zh[c] = z[c];
+    }
+    __syncthreads();
+    for (int j = 0; j < Np; ++j) {
+      const double* zj = zh + (size_t)j * N;
+      for (int e = tid; e < N; e += 256) {
+        double s = 0.0;
+        for (int c = 0; c < N; ++c) s += a.A[e + (size_t)c * N] * zj[c];
+        for (int i = 0; i < m; ++i) {
+          const double* Bi = a.B + (size_t)i * N * N;
+          double t = 0.0;
+          for (int c = 0; c < N; ++c) t += Bi[e + (size_t)c * N] * zj[c];
+          s += t * x[j * m + i];
+        }
+        zh[(size_t)(j + 1) * N + e] = s;
+      }
+      __syncthreads();
+    }
+  };
+  int iter0 = 0;
+  if (a.U_lin) {                         // (uniform) a later pass of a state-bound step: linearise along the previous solution
+    __syncthreads();
+    lifted_horizon(a.U_lin + (size_t)pb * nv);
+    iter0 = 1;
+  }
+  for (int iter = iter0; iter < iter0 + a.iters; ++iter) {
     // ---- S_k = P_k * Beta(z_k)  (get_costB_bilinear, Kmpc.m:578-585: block i uses z(i,:) when a
     // horizon of lifted states is given, else z) ----
     if (a.model_type == KP_MODEL_BILINEAR) {
@@ -839,27 +879,9 @@ __global__ __launch_bounds__(256) void kp_mpc_step_kernel(MpcArgs a) {
     __syncthreads();
     if (stamps && tid == 0) stamps[5] = wall_clock64();
     status = *st_sh;
-    if (status || iter == a.iters - 1) break;
+    if (status || iter == iter0 + a.iters - 1) break;
     // ---- lifted horizon for the next linearisation (Kmpc.m:891-895) ----
-    if (tid < 64) {
-      for (int c = tid; c < N; c += 64) zh[c] = z[c];
-    }
-    __syncthreads();
-    for (int j = 0; j < Np; ++j) {
-      const double* zj = zh + (size_t)j * N;
-      for (int e = tid; e < N; e += 256) {
-        double s = 0.0;
-        for (int c = 0; c < N; ++c) s += a.A[e + (size_t)c * N] * zj[c];
-        for (int i = 0; i < m; ++i) {
-          const double* Bi = a.B + (size_t)i * N * N;
-          double t = 0.0;
-          for (int c = 0; c < N; ++c) t += Bi[e + (size_t)c * N] * zj[c];
-          s += t * xout[j * m + i];
-        }
-        zh[(size_t)(j + 1) * N + e] = s;
-      }
-      __syncthreads();
-    }
+    lifted_horizon(xout);
   }
   if (tid == 0) a.status[pb] = status ? KP_ERR_QP_FAIL : KP_OK;
 }
@@ -890,6 +912,7 @@ extern "C" int kp_mpc_destroy(kp_mpc* M) {
   if (M->sb_A) (void)hipFree(M->sb_A);
   if (M->sb_b) (void)hipFree(M->sb_b);
   if (M->sb_col) (void)hipFree(M->sb_col);
+  if (M->sb_work) (void)hipFree(M->sb_work);
   delete M;
   return KP_OK;
 }
@@ -1028,12 +1051,18 @@ __global__ __launch_bounds__(256) void kp_mpc_sb_kernel(int model_type, int N, i
                                                         const double* __restrict__ Apow, const double* __restrict__ B,
                                                         const double* __restrict__ Aq, const double* __restrict__ b_in,
                                                         const double* __restrict__ z, const double* __restrict__ lohi,
-                                                        double* __restrict__ Ad, double* __restrict__ bd, double* __restrict__ nrm) {
+                                                        double* __restrict__ Ad, double* __restrict__ bd, double* __restrict__ nrm,
+                                                        size_t b_stride) {
   extern __shared__ double sm[];
   double* Bz = sm;                         // N x m
   double* zs = Bz + N * m;                 // N
   const int tid = threadIdx.x;
   const int mr = nrows + 2 * n_sb * (Np + 1);
+  {                                        // problem p = blockIdx.x of a batch
+    const size_t p = blockIdx.x;
+    b_in += p * b_stride; z += p * N;
+    Ad += p * (size_t)mr * nvar; bd += p * mr; nrm += p * mr;
+  }
   for (int c = tid; c < N; c += 256) zs[c] = z[c];
   __syncthreads();
   for (int e = tid; e < N * m; e += 256) {
@@ -1098,9 +1127,10 @@ extern "C" int kp_mpc_set_state_bounds(kp_mpc* M, int n, const double* lo, const
   kp_ctx* ctx = M->ctx;
   if (n < 0 || n > M->N || (n > 0 && (!lo || !hi))) return ctx->fail(KP_ERR_ARG, "kp_mpc_set_state_bounds: bad argument");
   KP_HIP(ctx, hipSetDevice(ctx->device));
-  double** bufs[] = {&M->sb_lohi, &M->sb_Apow, &M->sb_A, &M->sb_b};
+  double** bufs[] = {&M->sb_lohi, &M->sb_Apow, &M->sb_A, &M->sb_b, &M->sb_work};
   for (double** p : bufs)
     if (*p) { (void)hipFree(*p); *p = nullptr; }
+  M->sb_cap = 0;
   if (M->sb_col) { (void)hipFree(M->sb_col); M->sb_col = nullptr; }
   M->sb_n = 0; M->sb_rows = 0;
   if (n == 0) return KP_OK;
@@ -1112,8 +1142,6 @@ extern "C" int kp_mpc_set_state_bounds(kp_mpc* M, int n, const double* lo, const
   int rc = dev_alloc_copy(ctx, &M->sb_lohi, lh.data(), lh.size());
   if (rc) return rc;
   KP_HIP(ctx, hipMalloc((void**)&M->sb_Apow, (size_t)(kmax + 1) * N * N * 8));
-  KP_HIP(ctx, hipMalloc((void**)&M->sb_A, (size_t)mr * nv * 8));
-  KP_HIP(ctx, hipMalloc((void**)&M->sb_b, (size_t)(2 * mr + nv + 8) * 8));
   std::vector<double> eye((size_t)N * N, 0.0);
   for (int i = 0; i < N; ++i) eye[(size_t)i * N + i] = 1.0;
   KP_HIP(ctx, hipMemcpy(M->sb_Apow, eye.data(), (size_t)N * N * 8, hipMemcpyHostToDevice));
@@ -1137,7 +1165,6 @@ static int mpc_run(kp_mpc* M, const kp_basis* basis, int nb, const double* z, co
   kp_ctx* ctx = M->ctx;
   if (nb < 1 || !u_prev || !Yr || !U_out || iters < 1 || (!z && !zeta)) return ctx->fail(KP_ERR_ARG, "kp_mpc_step: bad argument");
   if (iters > 1 && M->model_type != KP_MODEL_BILINEAR) iters = 1;
-  if (M->sb_n > 0 && (nb != 1 || iters != 1)) return ctx->fail(KP_ERR_ARG, "kp_mpc_step: state bounds need single-problem steps with iters = 1");
   KP_HIP(ctx, hipSetDevice(ctx->device));
   const int N = M->N, m = M->m, Np = M->Np, nproj = M->nproj, nv = M->nvar, nr = M->nrows;
   int nzeta = 0;
@@ -1202,6 +1229,26 @@ static int mpc_run(kp_mpc* M, const kp_basis* basis, int nb, const double* z, co
   a.z_out = a.U + (size_t)nb * nv;
   a.qp_export = nb == 1 ? M->work : nullptr;
   a.assemble_only = M->sb_n > 0 ? 1 : 0;
+  a.U_lin = nullptr;
+  const bool sb = M->sb_n > 0;
+  const int mr_sb = nr + M->sb_rows;
+  if (sb) {
+    // state-bound steps: per problem the exported H, f, b, the dense constraint matrix of the step, right-hand sides,
+    // row norms and the solution of the generic QP kernel
+    if (M->sb_cap < (size_t)nb) {
+      if (M->sb_A) (void)hipFree(M->sb_A);
+      if (M->sb_b) (void)hipFree(M->sb_b);
+      if (M->sb_work) (void)hipFree(M->sb_work);
+      M->sb_A = M->sb_b = M->sb_work = nullptr;
+      M->sb_cap = 0;
+      KP_HIP(ctx, hipMalloc((void**)&M->sb_A, (size_t)nb * mr_sb * nv * 8));
+      KP_HIP(ctx, hipMalloc((void**)&M->sb_b, (size_t)nb * (2 * mr_sb + nv + 1) * 8 + 64));
+      KP_HIP(ctx, hipMalloc((void**)&M->sb_work, (size_t)nb * n_ex * 8));
+      M->sb_cap = (size_t)nb;
+    }
+    a.qp_export = M->sb_work;
+    a.iters = 1;                       // the linearisation passes are driven from the host (the QP runs in its own kernel)
+  }
   static const bool no_warm = getenv("KP_MPC_NO_WARM") != nullptr;
   if (!M->warm) {
     KP_HIP(ctx, hipMalloc((void**)&M->warm, (size_t)(1 + nv) * sizeof(int)));
@@ -1210,7 +1257,7 @@ static int mpc_run(kp_mpc* M, const kp_basis* basis, int nb, const double* z, co
   a.warm = (nb == 1 && !no_warm) ? M->warm : nullptr;
   a.status = zc ? (int*)(M->h_out + M->io_problems * n_out) : M->d_status;
   a.stamps = nb == 1 ? (long long*)(M->work + n_ex) : nullptr;
-  size_t lds = (size_t)mpc_lds_doubles(N, m, Np, nproj, nv, nr, iters, zeta ? basis->dev.nfull : 0) * 8 + 32;
+  size_t lds = (size_t)mpc_lds_doubles(N, m, Np, nproj, nv, nr, (sb && iters > 1) ? 2 : iters, zeta ? basis->dev.nfull : 0) * 8 + 32;
   if (lds > 160 * 1024) return ctx->fail(KP_ERR_ARG, "kp_mpc_step: problem too large for LDS");
   static size_t lds_set[2] = {0, 0};
   const int wk = a.warm != nullptr;
@@ -1220,32 +1267,45 @@ static int mpc_run(kp_mpc* M, const kp_basis* basis, int nb, const double* z, co
     lds_set[wk] = lds;
   }
   KP_HIP(ctx, hipEventRecord(ctx->evp[4], ctx->stream));
-  if (wk) hipLaunchKernelGGL(kp_mpc_step_kernel<true>, dim3(nb), dim3(256), lds, ctx->stream, a);
-  else hipLaunchKernelGGL(kp_mpc_step_kernel<false>, dim3(nb), dim3(256), lds, ctx->stream, a);
-  KP_HIP(ctx, hipGetLastError());
-  if (M->sb_n > 0) {
-    // the step kernel above has assembled H, f and the right-hand sides of the constant rows and stopped there:
-    // dense constraint matrix of this step, then the generic QP kernel
-    const int mr = nr + M->sb_rows;
-    double* bd = M->sb_b;
-    double* nrm = bd + mr;
-    double* dx = nrm + mr;
-    int* dst = (int*)(dx + nv);
-    hipLaunchKernelGGL(kp_mpc_sb_kernel, dim3(1), dim3(256), (size_t)(N * m + N) * 8, ctx->stream, M->model_type, N, m, Np, nv, nr, M->sb_n,
-                       M->sb_kmax, M->sb_Apow, M->B, M->Aq, M->work + (size_t)nv * nv + nv, a.z_out, M->sb_lohi, M->sb_A, bd, nrm);
+  if (!sb) {
+    if (wk) hipLaunchKernelGGL(kp_mpc_step_kernel<true>, dim3(nb), dim3(256), lds, ctx->stream, a);
+    else hipLaunchKernelGGL(kp_mpc_step_kernel<false>, dim3(nb), dim3(256), lds, ctx->stream, a);
     KP_HIP(ctx, hipGetLastError());
-    EllMat E{M->sb_A, M->sb_col, nrm, nv};
-    const size_t lq = (size_t)qp_lds_doubles(nv, mr) * 8 + 64;
+  } else {
+    // Every pass: the step kernel assembles H, f (along the lifted horizon of the previous pass's inputs from pass 2 on,
+    // Kmpc.m:874-895) and the right-hand sides of the constant rows and stops; the dense constraint matrix of the step
+    // is formed ONCE from z (the reference computes A = get_constraintL_bilinear(zrow) before its iteration loop,
+    // Kmpc.m:861); the generic QP kernel solves, one wave per problem.
+    double* bd = M->sb_b;                                   // [nb][mr]
+    double* nrm = bd + (size_t)nb * mr_sb;                  // [nb][mr]
+    double* dx = nrm + (size_t)nb * mr_sb;                  // [nb][nv]
+    int* dst = (int*)(dx + (size_t)nb * nv);                // [nb]
+    const size_t lq = (size_t)qp_lds_doubles(nv, mr_sb) * 8 + 64;
     static size_t lq_set = 0;
     if (lq > lq_set) {
       KP_HIP(ctx, hipFuncSetAttribute((const void*)kp_qp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lq));
       lq_set = lq;
     }
-    hipLaunchKernelGGL(kp_qp_kernel, dim3(1), dim3(64), lq, ctx->stream, M->work, M->work + (size_t)nv * nv, E, bd, nv, mr, dx, dst);
-    KP_HIP(ctx, hipGetLastError());
-    // x and the status into the output block the host reads below
-    KP_HIP(ctx, hipMemcpyAsync(a.U, dx, (size_t)nv * 8, zc ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, ctx->stream));
-    KP_HIP(ctx, hipMemcpyAsync(a.status, dst, sizeof(int), zc ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, ctx->stream));
+    EllMat E{M->sb_A, M->sb_col, nrm, nv};
+    for (int pass = 0; pass < iters; ++pass) {
+      a.U_lin = pass > 0 ? dx : nullptr;
+      if (wk) hipLaunchKernelGGL(kp_mpc_step_kernel<true>, dim3(nb), dim3(256), lds, ctx->stream, a);
+      else hipLaunchKernelGGL(kp_mpc_step_kernel<false>, dim3(nb), dim3(256), lds, ctx->stream, a);
+      KP_HIP(ctx, hipGetLastError());
+      if (pass == 0) {
+        hipLaunchKernelGGL(kp_mpc_sb_kernel, dim3(nb), dim3(256), (size_t)(N * m + N) * 8, ctx->stream, M->model_type, N, m, Np, nv, nr, M->sb_n,
+                           M->sb_kmax, M->sb_Apow, M->B, M->Aq, M->sb_work + (size_t)nv * nv + nv, a.z_out, M->sb_lohi, M->sb_A, bd, nrm, n_ex);
+        KP_HIP(ctx, hipGetLastError());
+      }
+      hipLaunchKernelGGL(kp_qp_kernel, dim3(nb), dim3(64), lq, ctx->stream, M->sb_work, M->sb_work + (size_t)nv * nv, E, bd, nv, mr_sb, dx, dst,
+                         n_ex, n_ex, (size_t)mr_sb * nv, (size_t)mr_sb, pass > 0 ? 1 : 0);
+      KP_HIP(ctx, hipGetLastError());
+    }
+    // x and the status words into the output block the host reads below
+    KP_HIP(ctx, hipMemcpyAsync(a.U, dx, (size_t)nb * nv * 8, zc ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, ctx->stream));
+    KP_HIP(ctx, hipMemcpyAsync(a.status, dst, (size_t)nb * sizeof(int), zc ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, ctx->stream));
+    if (nb == 1)   // kp_mpc_last_qp reads the single-problem export
+      KP_HIP(ctx, hipMemcpyAsync(M->work, M->sb_work, n_ex * 8, hipMemcpyDeviceToDevice, ctx->stream));
   }
   KP_HIP(ctx, hipEventRecord(ctx->evp[5], ctx->stream));
   // one device-to-host copy: x and z of every problem, then the status words

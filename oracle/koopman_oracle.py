@@ -803,7 +803,9 @@ def mpc_qp(s: MpcSetup, z, u_prev, ref, zhor=None):
     Yr = pad_ref(ref, s.Np)
     f = (z @ G + Yr @ D)                               # :369,879
     F, E, c = constraint_FEc(s)
-    L = F + E @ Bh                                     # :324,745
+    # the constraint matrix is formed ONCE from the current lifted state, before the linearisation passes
+    # (A = get_constraintL_bilinear(zrow), Kmpc.m:861, outside the loop of :874-899): it does not follow zhorizon
+    L = F + E @ (Bh if zhor is None else cost_B(s, np.atleast_2d(z)))     # :324,745
     M = E @ Ahat                                       # :325,737
     b = -M @ z + c                                     # :371,862
     m = s.m

@@ -318,8 +318,29 @@ def test_state_bounds_match_literal_kmpc(ctx, mt, N, n, Np):
         hit += ok0 and np.abs(x0 - x).max() > 1e-6
     if (N, n, Np) == (3, 2, 8):
         assert hit >= 1                                                 # here the bounded entries reach step 5: the bounds do bind
-    with pytest.raises(kra.KoopmanHipError):
-        mpc.step_batch(np.zeros((2, N)), np.zeros((2, m)), np.zeros((2, Np + 1)))
+    # the same problems as ONE batched launch sequence (state bounds in kp_mpc_step_batch), and with two linearisation
+    # passes (get_mpcInput_bilinear_iter, Kmpc.m:874-899: H, f follow the predicted lifted states, the constraint matrix
+    # stays the one of the current state, :861)
+    rng2 = np.random.default_rng(7 * N + Np)
+    nbp = 6
+    Zb = 0.15 * rng2.standard_normal((nbp, N)); Zb[:, -1] = 0.5
+    Ub = 0.2 * rng2.standard_normal((nbp, m))
+    refs = [np.full((Np + 1, 1), 0.8 * (-1) ** t_) for t_ in range(nbp)]
+    Yb = np.stack([ko.pad_ref(r_, Np) for r_ in refs])
+    Uall, stall = mpc.step_batch(Zb, Ub, Yb)
+    for p_ in range(nbp):
+        x, lam, ok = ko.qp_solve(*ko.mpc_qp(s, Zb[p_], Ub[p_], refs[p_]))
+        if not ok:
+            assert stall[p_] != 0 and np.isnan(Uall[p_]).all()
+        else:
+            assert stall[p_] == 0 and np.abs(Uall[p_] - x.reshape(Np, m)).max() < 1e-8
+        if mt == "bilinear":
+            U2, st2 = mpc.step(Zb[p_], Ub[p_], Yb[p_], iters=2)
+            Uo, kkt = ko.mpc_step(s, Zb[p_], Ub[p_], refs[p_], iters=2)
+            if np.isnan(Uo).any():
+                assert st2 != 0 and np.isnan(U2).all()
+            else:
+                assert st2 == 0 and np.abs(U2 - Uo).max() < 1e-8
     mpc.set_state_bounds(None, None)
     U, st = mpc.step(z, u_prev, ko.pad_ref(ref, Np))
     x0, _, ok0 = ko.qp_solve(*ko.mpc_qp(ko.MpcSetup(**{**s.__dict__, "state_bounds": None}), z, u_prev, ref))
