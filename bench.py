@@ -264,8 +264,11 @@ def bench_width_points(ctx, kra, Ns):
     tab = kra.poly_exponent_table(6, 3)
     rng = np.random.default_rng(3)
     pcs = np.linalg.qr(rng.standard_normal((84, 27)))[0]
-    for name, basis in (("W200", kra.Basis(ctx, "bilinear", 6, 3, [("poly", tab[6:49])])),
-                        ("W136_pcs", kra.Basis(ctx, "bilinear", 6, 3, [("poly", tab[6:])], pcs))):
+    shapes = [("W200", kra.Basis(ctx, "bilinear", 6, 3, [("poly", tab[6:49])])),
+              ("W136_pcs", kra.Basis(ctx, "bilinear", 6, 3, [("poly", tab[6:])], pcs))]
+    if os.environ.get("KP_BENCH_MORE_WIDTHS"):    # same width without the projection: what the econ lift costs
+        shapes.append(("W136_plain", kra.Basis(ctx, "bilinear", 6, 3, [("poly", tab[6:33])])))
+    for name, basis in shapes:
         W = basis.W
         for _ in range(3):
             kra.fit_gram(ctx, basis, snaps, fetch=False)

@@ -5,6 +5,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <cstring>
 
 #include "kp_internal.h"
@@ -24,8 +25,11 @@ struct RcclApi {
 RcclApi& rccl() {
   static RcclApi api = [] {
     RcclApi a;
-    const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    // the ROCm installation's library first, by path: a process that has also loaded a Python wheel's private copy of
+    // RCCL (built against another HIP runtime) must not get that one under this library's streams and pointers
+    const char* names[] = {getenv("KP_RCCL_PATH"), "/opt/rocm/lib/librccl.so", "librccl.so.1", "librccl.so"};
     for (const char* nm : names) {
+      if (!nm || !*nm) continue;
       a.handle = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
       if (a.handle) break;
     }

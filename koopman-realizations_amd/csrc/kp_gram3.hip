@@ -46,6 +46,11 @@
 #define PSIBUF3 (KT3 * RS3)         // doubles per Psi buffer
 #define PSI03 (2 * POWBUF3)         // LDS: pow[2] | psi[2]
 #define LDS3_DOUBLES (PSI03 + 2 * PSIBUF3)
+// dim_red dictionaries: the projection matrix lives behind the Psi buffers as [column tile of 16 PCs][full column][16]
+// (row stride 16 doubles: the two full columns a 32-lane group reads sit on disjoint banks), at most 32 PCs
+#define PCS03 LDS3_DOUBLES
+#define PCSMAX3 32
+#define LDS3_PCS_DOUBLES (2 * YOFF3 * 16)
 
 struct Gram3Args {
   BasisDev b;
@@ -62,9 +67,12 @@ struct Gram3Args {
                              // then per quad 4 packed B group ids (8 bit each)
   double* part;              // [nsplit][njobs][NQ][NWT][64]
   int njobs;
+  const double* pcs;         // nfull x k_pcs (column-major) or nullptr: econ lift [zeta | pcs' psi_full | 1] (Ksysid.m:1594-1618)
+  int nfull4;                // nfull rounded up to a multiple of 4
 };
 
-template <int NQ, int BM>
+// PCS: econ lift through a projection matrix (dim_red dictionaries)
+template <int NQ, int BM, bool PCS>
 __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
   constexpr int NWT = (BM + 1) * (BM + 2) / 2;
   extern __shared__ __align__(16) double sm[];
@@ -103,6 +111,13 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
 
   // ---- one-time LDS setup: everything zero (padding columns and the zero group stay zero) ----
   for (int e = tid; e < LDS3_DOUBLES; e += 256) sm[e] = 0.0;
+  if (PCS) {   // projection matrix, zero padded to (nfull4 x 32)
+    const int nf4 = a.nfull4;
+    for (int e = tid; e < 2 * nf4 * 16; e += 256) {
+      const int ct = e / (nf4 * 16), r = e - ct * nf4 * 16, c = r >> 4, p = 16 * ct + (r & 15);
+      sm[PCS03 + e] = (c < b.nfull && p < b.k_pcs) ? a.pcs[c + (size_t)p * b.nfull] : 0.0;
+    }
+  }
 
   // ---- lifting thread constants: thread = one (side, column), all KT3 snapshots of the tile ----
   // power table layout [id][snapshot]: the KT3 values of one entry are contiguous (16-byte reads of snapshot pairs)
@@ -211,6 +226,44 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
   using B0 = std::integral_constant<int, 0>;
   using B1 = std::integral_constant<int, 1>;
 
+  // ---- dim_red: econ lift of a lifted tile in place (Ksysid.m:1594-1618: [zeta ; pcs' psi_full ; 1]) ----
+  // The lift above has left the FULL dictionary in the Psi buffer (columns [0, nfull) per side).  pcs' psi is a small
+  // product on the matrix pipe: wave = (side, 4-snapshot group), two 4 x 16 output tiles (32 PCs), contraction over the
+  // full columns.  Reads first, barrier, then the PCs overwrite columns nzeta.., the constant moves to column N - 1 and
+  // the padding of the last 4-column group is cleared; the Gram MFMAs only touch columns < 4 G4 afterwards.
+  auto project = [&](auto buf_c) __attribute__((always_inline)) {
+    constexpr int BUF = decltype(buf_c)::value;
+    const int side = wave >> 1, rg = wave & 1;
+    const int abase = BUF * PSIBUF3 + PSI03 + (4 * rg + lc) * RS3 + side * YOFF3 + (lane >> 4);
+    const int bbase = PCS03 + (lane >> 4) * 16 + 4 * blk + lc;
+    const int nf4 = a.nfull4;
+    // (measured: a software-pipelined or fully unrolled form of this loop is no faster - the phase is bound by its
+    // two barriers and the dependent MFMA chains, not by address arithmetic)
+    double p0 = 0.0, p1 = 0.0;
+    const int bb1 = bbase + nf4 * 16;
+#pragma unroll 3
+    for (int kk = 0; kk < nf4 / 4; ++kk) {
+      const double av = sm[abase + 4 * kk];
+      const double b0 = sm[bbase + kk * 64], b1 = sm[bb1 + kk * 64];
+      p0 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, b0, p0, 0, 0, 0);
+      p1 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, b1, p1, 0, 0, 0);
+    }
+    __syncthreads();
+    {
+      const int srow = BUF * PSIBUF3 + PSI03 + (4 * rg + (lane >> 4)) * RS3 + side * YOFF3;
+      const int pc = 4 * blk + lc;
+      if (pc < b.k_pcs) sm[srow + b.nzeta + pc] = p0;
+      if (pc + 16 < b.k_pcs) sm[srow + b.nzeta + pc + 16] = p1;
+    }
+    if (tid < 2 * KT3) {
+      const int srow = BUF * PSIBUF3 + PSI03 + (tid & (KT3 - 1)) * RS3 + (tid / KT3) * YOFF3;
+      const double one = sm[srow + b.nfull - 1];          // the full dictionary's constant (0 past Ns: the tail mask)
+      sm[srow + b.N - 1] = one;
+      for (int c = b.N; c < 4 * a.G4; ++c) sm[srow + c] = 0.0;
+    }
+    __syncthreads();
+  };
+
   __syncthreads();
   store_raw(B0{}, load_raw());
   __syncthreads();
@@ -222,6 +275,7 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
   }
   store_raw(B1{}, load_raw());
   __syncthreads();
+  if (PCS) project(B0{});
 
   constexpr int NSTEP = (KT3 / 4) * NQ;                 // quad steps (NWT MFMAs each) per snapshot tile
   constexpr int SP = NSTEP / NCH > 0 ? NSTEP / NCH : 1;
@@ -305,6 +359,7 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
 #endif
     store_raw(cur_c, rawreg);
     __syncthreads();
+    if (PCS) project(NXT{});
   };
   auto run_tiles = [&](auto qs_c) __attribute__((always_inline)) {
     int t = 0;
@@ -391,7 +446,7 @@ void kp_gram3_plan_free(kp_gram3_plan* p) {
 // (g, g+1, ..., g+floor(G4/2) mod G4; antipodal pairs once) and all G4 groups of psi_y.
 // All quads (A group, 4 B groups) of all rows form one list; a job (one wave) is nq CONSECUTIVE quads,
 // so it spans at most two A groups when nq <= quads per row, and whole workgroups (4 jobs) fill evenly.
-static int make_plan3(kp_ctx* ctx, int N, int nwt, kp_gram3_plan** out) {
+static int make_plan3(kp_ctx* ctx, int N, int nwt, int nq_cap, kp_gram3_plan** out) {
   kp_gram3_plan* p = new kp_gram3_plan();
   const int G4 = (N + 3) / 4;
   p->G4 = G4;
@@ -424,14 +479,14 @@ static int make_plan3(kp_ctx* ctx, int N, int nwt, kp_gram3_plan** out) {
   int nq = 1;
   double best = 1e300;
   constexpr int NQMAX = 6;   // 7 or 8 quads (140/160 accumulator registers) spill with the 256-register budget of 2 waves per SIMD
-  for (int c = 1; c <= NQMAX && (size_t)c <= maxq; ++c) {
+  for (int c = 1; c <= std::min(NQMAX, nq_cap) && (size_t)c <= maxq; ++c) {
     int waves = ((TQ + c - 1) / c + 3) / 4 * 4;
     double cost = (double)waves * (c * nwt * 33.0 + 400.0);
     if (cost < best) { best = cost; nq = c; }
   }
   if (const char* ov = getenv("KP_GRAM3_NQ")) {   // tuning override
     int v = atoi(ov);
-    if (v >= 1 && v <= NQMAX && (size_t)v <= maxq) nq = v;
+    if (v >= 1 && v <= std::min(NQMAX, nq_cap) && (size_t)v <= maxq) nq = v;
   }
   p->nq = nq;
   std::vector<uint32_t> desc;
@@ -457,31 +512,45 @@ static int make_plan3(kp_ctx* ctx, int N, int nwt, kp_gram3_plan** out) {
   return KP_OK;
 }
 
-template <int NQ, int BM>
+template <int NQ, int BM, bool PCS>
 static hipError_t launch3b(const Gram3Args& a, int grid, size_t lds, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kp_gram3_kernel<NQ, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const size_t lds_max = (size_t)(LDS3_DOUBLES + (PCS ? LDS3_PCS_DOUBLES : 0)) * sizeof(double);
+    hipError_t e = hipFuncSetAttribute((const void*)kp_gram3_kernel<NQ, BM, PCS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((kp_gram3_kernel<NQ, BM>), dim3(grid), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((kp_gram3_kernel<NQ, BM, PCS>), dim3(grid), dim3(256), lds, st, a);
   return hipGetLastError();
 }
 
 template <int NQ>
 static hipError_t launch3(const Gram3Args& a, int bm, int grid, size_t lds, hipStream_t st) {
+  if (a.pcs) {
+    if constexpr (NQ <= 4) {             // more quads per wave spill once the projection is inlined (plans of dim_red dictionaries stay below)
+      switch (bm) {
+        case 1: return launch3b<NQ, 1, true>(a, grid, lds, st);
+        case 2: return launch3b<NQ, 2, true>(a, grid, lds, st);
+        default: return launch3b<NQ, 3, true>(a, grid, lds, st);
+      }
+    } else {
+      return hipErrorInvalidValue;
+    }
+  }
   switch (bm) {
-    case 1: return launch3b<NQ, 1>(a, grid, lds, st);
-    case 2: return launch3b<NQ, 2>(a, grid, lds, st);
-    default: return launch3b<NQ, 3>(a, grid, lds, st);
+    case 1: return launch3b<NQ, 1, false>(a, grid, lds, st);
+    case 2: return launch3b<NQ, 2, false>(a, grid, lds, st);
+    default: return launch3b<NQ, 3, false>(a, grid, lds, st);
   }
 }
 
 bool kp_gram3_applicable(const kp_basis* basis) {
   const BasisDev& b = basis->dev;
   if (getenv("KP_NO_GRAM3")) return false;
-  return b.model_type == KP_MODEL_BILINEAR && basis->fast && basis->max_factors <= NF3 && b.k_pcs == 0 && b.nfull <= YOFF3 &&
+  // dim_red dictionaries: econ layout [zeta | k_pcs principal components | 1], at most 32 components
+  if (b.k_pcs > 0 && (b.k_pcs > PCSMAX3 || b.N != b.nzeta + b.k_pcs + 1 || getenv("KP_NO_GRAM3_PCS"))) return false;
+  return b.model_type == KP_MODEL_BILINEAR && basis->fast && basis->max_factors <= NF3 && b.nfull <= YOFF3 &&
          b.m >= 1 && b.m <= 3 && 2 * (b.nzeta + b.m) * KT3 <= 2 * 256 && 2 * (b.nzeta + b.m) * basis->pow_depth + 1 <= NIDMAX3;
 }
 
@@ -492,11 +561,12 @@ int kp_gram3_launch(kp_ctx* ctx, const kp_basis* basis_c, const kp_snapshots* s,
   const int W = b.W, N = b.N;
   const int BM = b.m, NWT = (BM + 1) * (BM + 2) / 2;
   if (!basis->plan3) {
-    int rc = make_plan3(ctx, N, NWT, &basis->plan3);
+    int rc = make_plan3(ctx, N, NWT, b.k_pcs > 0 ? 4 : 6, &basis->plan3);
     if (rc) return rc;
   }
   kp_gram3_plan& plan = *basis->plan3;
-  const size_t lds = (size_t)LDS3_DOUBLES * sizeof(double);
+  const int nfull4 = (b.nfull + 3) / 4 * 4;
+  const size_t lds = (size_t)(LDS3_DOUBLES + (b.k_pcs > 0 ? 2 * nfull4 * 16 : 0)) * sizeof(double);
   int64_t ktiles = (s->Ns + KT3 - 1) / KT3;
   int ncu = ctx->num_cu > 0 ? ctx->num_cu : 256;
   int wg_per_cu = 2;                                  // __launch_bounds__(256, 2): two workgroups share a CU
@@ -527,6 +597,8 @@ int kp_gram3_launch(kp_ctx* ctx, const kp_basis* basis_c, const kp_snapshots* s,
   a.desc = plan.desc;
   a.part = part;
   a.njobs = plan.njobs;
+  a.pcs = b.k_pcs > 0 ? b.pcs : nullptr;
+  a.nfull4 = nfull4;
   const int grid = plan.nsuper * nsplit;
   // every event record is a barrier packet the command processor works through between two Gram kernels: the
   // pipelined path keeps two (kernel start / end; the end also releases the reduction on the solve stream)

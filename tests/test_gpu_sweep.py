@@ -164,39 +164,54 @@ def test_fit_batch_refinement_reaches_qr_accuracy_on_ill_conditioned_dictionarie
         assert np.abs(K[s] - Kq).max() <= 1e-9 * max(1.0, np.abs(Kq).max())
 
 
-def test_rccl_communicator_through_the_c_abi_single_rank(ctx):
+_RCCL_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import koopman_realizations_amd as kra
+from koopman_realizations_amd import comm as kc, _ffi as F
+from oracle import koopman_oracle as ko
+from conftest import synth_pairs
+c2 = kra.Context(0)
+uid = kc.unique_id()
+assert len(uid) == 128 and any(uid)
+comm = kc.RcclComm(c2, 0, 1, uid)
+assert kc.all_gather_array(comm, np.arange(5.0)).tolist() == [[0.0, 1.0, 2.0, 3.0, 4.0]]
+assert kc.all_gather_object(comm, {"k": [1, 2]}) == [{"k": [1, 2]}]
+assert comm.all_reduce_sum(np.array([1.5, -2.0])).tolist() == [1.5, -2.0]
+comm.barrier()
+p = synth_pairs(4000, 3, 2, seed=4)
+dic = ko.build_dictionary("bilinear", 3, 2, ["poly"], [2])
+b = kra.Basis(c2, "bilinear", 3, 2, [("poly", kra.poly_exponent_table(3, 2)[3:])])
+s = kra.Snapshots(c2, p["alpha"], p["beta"], p["u"])
+Kref = kra.fit(c2, b, s)[0]
+for _ in range(3):
+    kra.fit(c2, b, s, fetch=False)
+Kall = comm.all_gather_fit(2, b.W)
+assert Kall.shape == (1, b.W, b.W) and np.abs(Kall[0] - Kref).max() <= 1e-11 * np.abs(Kref).max()
+K = np.zeros((1, b.W, b.W))
+las = np.array([np.inf])
+F.check(F.lib().kp_fit_sharded(c2.handle, b.handle, s.handle, F.dptr(las), 1, F.dptr(K)), c2.handle)
+assert np.abs(K[0].T - Kref).max() <= 1e-12 * np.abs(Kref).max()
+G = np.zeros((b.W, b.W), order="F"); Cm = np.zeros((b.W, b.W), order="F")
+F.check(F.lib().kp_fit_gram_sharded(c2.handle, b.handle, s.handle, F.dptr(G), F.dptr(Cm)), c2.handle)
+Px, Py = ko.px_py(dic, p)
+assert np.abs(G - Px.T @ Px).max() <= 1e-11 * np.abs(G).max()
+comm.close()
+# the context still works after the communicator is gone
+assert np.abs(kra.fit(c2, b, s)[0] - Kref).max() == 0
+c2.close()
+print("RCCL_OK")
+"""
+
+
+def test_rccl_communicator_through_the_c_abi_single_rank():
     """kp_comm_* with a one-rank RCCL communicator: unique id, ncclCommInitRank, host all-gather / all-reduce, the
     device-to-device gather of a fit result and the sharded fit (all-reduce of [G | C] between Gram kernel and solve).
-    The N-rank path is the same code with world > 1 (one process per GPU; the driver's scaling run)."""
-    from koopman_realizations_amd import comm as kc
-    from conftest import synth_pairs
-    c2 = kra.Context(0)
-    try:
-        uid = kc.unique_id()
-        assert len(uid) == 128 and any(uid)
-        comm = kc.RcclComm(c2, 0, 1, uid)
-        assert kc.all_gather_array(comm, np.arange(5.0)).tolist() == [[0.0, 1.0, 2.0, 3.0, 4.0]]
-        assert kc.all_gather_object(comm, {"k": [1, 2]}) == [{"k": [1, 2]}]
-        assert comm.all_reduce_sum(np.array([1.5, -2.0])).tolist() == [1.5, -2.0]
-        comm.barrier()
-        p = synth_pairs(4000, 3, 2, seed=4)
-        dic = ko.build_dictionary("bilinear", 3, 2, ["poly"], [2])
-        b = kra.Basis(c2, "bilinear", 3, 2, [("poly", kra.poly_exponent_table(3, 2)[3:])])
-        s = kra.Snapshots(c2, p["alpha"], p["beta"], p["u"])
-        Kref = kra.fit(c2, b, s)[0]
-        for _ in range(3):
-            kra.fit(c2, b, s, fetch=False)
-        Kall = comm.all_gather_fit(2, b.W)
-        assert Kall.shape == (1, b.W, b.W) and np.abs(Kall[0] - Kref).max() <= 1e-11 * np.abs(Kref).max()
-        K = np.zeros((1, b.W, b.W))
-        from koopman_realizations_amd import _ffi as F
-        las = np.array([np.inf])
-        F.check(F.lib().kp_fit_sharded(c2.handle, b.handle, s.handle, F.dptr(las), 1, F.dptr(K)), c2.handle)
-        assert np.abs(K[0].T - Kref).max() <= 1e-12 * np.abs(Kref).max()
-        G = np.zeros((b.W, b.W), order="F"); Cm = np.zeros((b.W, b.W), order="F")
-        F.check(F.lib().kp_fit_gram_sharded(c2.handle, b.handle, s.handle, F.dptr(G), F.dptr(Cm)), c2.handle)
-        Px, Py = ko.px_py(dic, p)
-        assert np.abs(G - Px.T @ Px).max() <= 1e-11 * np.abs(G).max()
-        comm.close()
-    finally:
-        c2.close()
+    The N-rank path is the same code with world > 1 (one process per GPU; the driver's scaling run).  Runs in a fresh
+    torch-free interpreter, as bench.py's ranks do."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _RCCL_SCRIPT, root], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
