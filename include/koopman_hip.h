@@ -187,6 +187,26 @@ int kp_fit_async_slots(kp_ctx* ctx, int n_slots);
 int kp_fit_batch(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* snaps, int nb, int64_t Ns_each,
                  double* K_out, double* G_out, double* C_out, int* status_out);
 
+/* The random-system sweep with the data resident on the device (evaluate_rand_models.m:45-144).
+ * kp_traj_upload: data4sysid of nb systems that share one layout (the generated / shipped rand-systems sets): per system
+ *   the merged training trials (Ksysid.merge_trials :380-401: ntrials x T rows, column-major rows x n and rows x m, RAW
+ *   values), and the validation trial (Tv rows).  Y: nb blocks of rows x n; U: nb blocks of rows x m; Yv / Uv likewise.
+ *   The per-system scaling of get_scale (:180-229) is computed on the device (kp_traj_scale fetches it: per system
+ *   [y offset (n) | y factor (n) | u offset (m) | u factor (m)]).
+ * kp_sweep_eval: one (model type, dictionary) of the sweep for ALL systems in one call: scaling + snapshot pairs
+ *   (get_snapshotPairs :941-978, delays = 0, all pairs, the last good one dropped) + fit (as kp_fit_batch; `lasso`
+ *   >= 1e6 or Inf: least squares, else the L1 budget lasso * N of :996, evaluate_rand_models.m:122) + model
+ *   extraction (get_model with the M-projection / get_BLmodel / get_NLmodel) + validation rollout (val_model /
+ *   val_BLmodel / val_NLmodel) + normalised mean error (evaluate_rand_models.m:69-72).  err_out: nb x n
+ *   (system-major); K_out (nb x W x W) and status_out (nb, != 0: singular Gram, err = NaN) may be NULL. */
+typedef struct kp_traj kp_traj;
+int kp_traj_upload(kp_ctx* ctx, const double* Y, const double* U, int nb, int ntrials, int T, int n, int m,
+                   const double* Yv, const double* Uv, int Tv, kp_traj** traj);
+int kp_traj_destroy(kp_traj* traj);
+int kp_traj_scale(kp_traj* traj, double* sc_out);
+int kp_sweep_eval(kp_ctx* ctx, const kp_traj* traj, const kp_basis* basis, double lasso, double* err_out, double* K_out,
+                  int* status_out);
+
 /* Model extraction with the M-projection of get_model (Ksysid.m:1206-1225): from K and
  * the Grams (no second pass over the data): L'L = [A B] G [A B]', L'R = [A B] C(:,1:N).
  * A_out N x N, B_out N x m (= M*A, M*B), M_out N x N.  Linear models only. */

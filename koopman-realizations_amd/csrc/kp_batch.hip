@@ -12,6 +12,8 @@
 // Replaces, for each system: Ksysid.get_Koopman (Ksysid.m:987-1092) with lasso = Inf.
 #include "kp_internal.h"
 #include <algorithm>
+#include <string>
+#include <vector>
 
 #define SB_TS 64      // snapshots per tile
 #define SB_W 16       // maximum Px width
@@ -90,10 +92,23 @@ __device__ __forceinline__ void sb_spd_solve16(const double* Gs, const double* C
 // in further sweeps over the snapshots (the tile E = Py - Px K replaces Py in the same accumulation).  The reference
 // solves Px \ Py by QR (Ksysid.m:1069); the degree-13 dictionaries of the sweep have cond(Px) ~ 1e5, where the plain
 // normal equations are only good to cond^2 eps ~ 1e-6 - one refinement step brings K to the accuracy of the QR solution.
+// Device-resident trajectories of nb systems with one layout (kp_traj): per system the merged training trials
+// (rows = ntrials * T, column-major rows x n / rows x m, RAW values) and the per-system scaling sc = [y offset (n) |
+// y factor (n) | u offset (m) | u factor (m)] (get_scale, Ksysid.m:180-229).  With Y != nullptr the fit kernel forms
+// the scaled snapshot pairs itself (get_snapshotPairs, Ksysid.m:941-978, delays = 0, all pairs in time order): pair p of
+// a system is row (p / (T-1)) T + p % (T-1) and its successor - no pair across a trial seam - and the last good pair
+// is dropped (:960), so a system has ntrials (T - 1) - 1 pairs.
+struct TrajView {
+  const double* Y;
+  const double* U;
+  const double* sc;
+  int ntrials, T, rows, n, m;
+};
+
 __global__ __launch_bounds__(256) void kp_small_fit_kernel(BasisDev b, const double* __restrict__ alpha, const double* __restrict__ beta,
                                                            const double* __restrict__ u, int64_t Ns_total, int Ns, double* __restrict__ Kout,
                                                            double* __restrict__ Gout, double* __restrict__ Cout, int* __restrict__ status,
-                                                           const uint32_t* __restrict__ recipes, int D, int nfmax, int refine) {
+                                                           const uint32_t* __restrict__ recipes, int D, int nfmax, int refine, TrajView tv) {
   extern __shared__ __align__(16) double sm[];
   // LDS: vx[nvars][TS] | vy[nvars][TS] | um[m][TS] | Px[TS][LD] | Py[TS][LD] | Gs[16][LD] | Cs[16][LD] | Ls[16][LD] | Dd[16] | Ks[16][LD] | Xs[16][LD] | pw
   const int nv = b.nvars, m = b.m, N = b.N, W = b.W;
@@ -134,7 +149,15 @@ __global__ __launch_bounds__(256) void kp_small_fit_kernel(BasisDev b, const dou
       for (int e = tid; e < (2 * nv + m) * SB_TS; e += 256) {
         const int v = e / SB_TS, p = e % SB_TS;
         double x = 0.0;
-        if (p < nl) {
+        if (p < nl && tv.Y) {                          // scaled pair straight from the trajectories
+          const int pair = r0 + p, Tm1 = tv.T - 1;
+          const int row = (pair / Tm1) * tv.T + pair % Tm1;
+          const double* sc = tv.sc + (size_t)sys * 2 * (tv.n + tv.m);
+          int var = v < nv ? v : v < 2 * nv ? v - nv : b.nzeta + (v - 2 * nv);        // index into [y (n) ; u (m)]
+          const int shift = (v >= nv && v < 2 * nv && var < b.nzeta) ? 1 : 0;         // beta = the next row of y
+          if (var < b.nzeta) x = (tv.Y[((size_t)sys * tv.n + var) * tv.rows + row + shift] - sc[var]) / sc[tv.n + var];
+          else { var -= b.nzeta; x = (tv.U[((size_t)sys * tv.m + var) * tv.rows + row] - sc[2 * tv.n + var]) / sc[2 * tv.n + tv.m + var]; }
+        } else if (p < nl) {
           const int64_t row = base + r0 + p;
           if (v < nv) x = v < b.nzeta ? alpha[(int64_t)v * Ns_total + row] : u[(int64_t)(v - b.nzeta) * Ns_total + row];
           else if (v < 2 * nv) x = (v - nv) < b.nzeta ? beta[(int64_t)(v - nv) * Ns_total + row] : u[(int64_t)(v - nv - b.nzeta) * Ns_total + row];
@@ -281,7 +304,7 @@ extern "C" int kp_fit_batch(kp_ctx* ctx, const kp_basis* basis, const kp_snapsho
   KP_HIP(ctx, hipEventRecord(ctx->ev0, s));
   hipLaunchKernelGGL(kp_small_fit_kernel, dim3(nb), dim3(256), lds, s, b, snaps->alpha, snaps->beta, snaps->u, snaps->Ns, (int)Ns_each, dK, dG, dC,
                      dS, use_rec ? (const uint32_t*)basis->d_recipes : nullptr, basis->pow_depth, basis->max_factors > 0 ? basis->max_factors : 1,
-                     refine);
+                     refine, TrajView{});
   KP_HIP(ctx, hipGetLastError());
   KP_HIP(ctx, hipEventRecord(ctx->ev1, s));
   KP_HIP(ctx, hipMemcpyAsync(K_out, dK, bW, hipMemcpyDeviceToHost, s));
@@ -370,5 +393,267 @@ extern "C" int kp_model_project_batch(kp_ctx* ctx, const double* K, const double
   if (M_out) KP_HIP(ctx, hipMemcpyAsync(M_out, dM, bA, hipMemcpyDeviceToHost, s));
   if (status_out) KP_HIP(ctx, hipMemcpyAsync(status_out, dS, (size_t)nb * 4, hipMemcpyDeviceToHost, s));
   KP_HIP(ctx, hipStreamSynchronize(s));
+  return KP_OK;
+}
+
+
+// =====================================================================================================================
+// evaluate_rand_models.m:45-144 with the data resident on the device: trajectories uploaded once (kp_traj), then per
+// (model type, degree) ONE call does scaling + snapshot pairs + fit (kp_small_fit_kernel) + model extraction (M-projection
+// of get_model for linear models) + the validation rollout + the normalised mean error (:69-72), and only the error
+// table entries come back.
+// =====================================================================================================================
+struct kp_traj {
+  kp_ctx* ctx = nullptr;
+  int nb = 0, ntrials = 0, T = 0, n = 0, m = 0, Tv = 0;
+  double *Y = nullptr, *U = nullptr, *Yv = nullptr, *Uv = nullptr, *sc = nullptr;
+};
+
+// min / max per column over the training rows of one system -> offset (max+min)/2, factor (max-min)/2 (1 when the range
+// is zero), Ksysid.m:187-210
+__global__ __launch_bounds__(256) void kp_traj_scale_kernel(const double* __restrict__ Y, const double* __restrict__ U, int rows, int n, int m,
+                                                            double* __restrict__ sc) {
+  __shared__ double rmin[4], rmax[4];
+  const int sys = blockIdx.x, tid = threadIdx.x;
+  double* out = sc + (size_t)sys * 2 * (n + m);
+  for (int v = 0; v < n + m; ++v) {
+    const double* col = v < n ? Y + ((size_t)sys * n + v) * rows : U + ((size_t)sys * m + (v - n)) * rows;
+    double lo = 1e300, hi = -1e300;
+    for (int r = tid; r < rows; r += 256) { const double x = col[r]; lo = fmin(lo, x); hi = fmax(hi, x); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { lo = fmin(lo, __shfl_xor(lo, o, 64)); hi = fmax(hi, __shfl_xor(hi, o, 64)); }
+    __syncthreads();
+    if ((tid & 63) == 0) { rmin[tid >> 6] = lo; rmax[tid >> 6] = hi; }
+    __syncthreads();
+    if (tid == 0) {
+      lo = fmin(fmin(rmin[0], rmin[1]), fmin(rmin[2], rmin[3]));
+      hi = fmax(fmax(rmax[0], rmax[1]), fmax(rmax[2], rmax[3]));
+      const double off = (hi + lo) / 2.0, fac = (hi - lo) / 2.0;
+      if (v < n) { out[v] = off; out[n + v] = fac == 0.0 ? 1.0 : fac; }
+      else { out[2 * n + (v - n)] = off; out[2 * n + m + (v - n)] = fac == 0.0 ? 1.0 : fac; }
+    }
+  }
+}
+
+extern "C" int kp_traj_upload(kp_ctx* ctx, const double* Y, const double* U, int nb, int ntrials, int T, int n, int m, const double* Yv,
+                              const double* Uv, int Tv, kp_traj** out) {
+  if (!ctx || !Y || !U || !Yv || !Uv || !out || nb < 1 || ntrials < 1 || T < 3 || n < 1 || m < 1 || Tv < 2)
+    return ctx ? ctx->fail(KP_ERR_ARG, "kp_traj_upload: bad argument") : KP_ERR_ARG;
+  KP_HIP(ctx, hipSetDevice(ctx->device));
+  kp_traj* t = new kp_traj;
+  t->ctx = ctx; t->nb = nb; t->ntrials = ntrials; t->T = T; t->n = n; t->m = m; t->Tv = Tv;
+  const size_t rows = (size_t)ntrials * T;
+  const size_t bY = (size_t)nb * rows * n * 8, bU = (size_t)nb * rows * m * 8, bYv = (size_t)nb * Tv * n * 8, bUv = (size_t)nb * Tv * m * 8;
+  hipError_t e = hipMalloc((void**)&t->Y, bY);
+  if (e == hipSuccess) e = hipMalloc((void**)&t->U, bU);
+  if (e == hipSuccess) e = hipMalloc((void**)&t->Yv, bYv);
+  if (e == hipSuccess) e = hipMalloc((void**)&t->Uv, bUv);
+  if (e == hipSuccess) e = hipMalloc((void**)&t->sc, (size_t)nb * 2 * (n + m) * 8);
+  hipStream_t s = ctx->stream;
+  if (e == hipSuccess) e = hipMemcpyAsync(t->Y, Y, bY, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(t->U, U, bU, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(t->Yv, Yv, bYv, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(t->Uv, Uv, bUv, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(kp_traj_scale_kernel, dim3(nb), dim3(256), 0, s, t->Y, t->U, (int)rows, n, m, t->sc);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (e != hipSuccess) {
+    double* bufs[] = {t->Y, t->U, t->Yv, t->Uv, t->sc};
+    for (double* p : bufs)
+      if (p) (void)hipFree(p);
+    delete t;
+    return ctx->fail(KP_ERR_HIP, std::string("kp_traj_upload: ") + hipGetErrorString(e));
+  }
+  *out = t;
+  return KP_OK;
+}
+
+extern "C" int kp_traj_destroy(kp_traj* t) {
+  if (!t) return KP_OK;
+  double* bufs[] = {t->Y, t->U, t->Yv, t->Uv, t->sc};
+  for (double* p : bufs)
+    if (p) (void)hipFree(p);
+  delete t;
+  return KP_OK;
+}
+
+extern "C" int kp_traj_scale(kp_traj* t, double* sc_out) {
+  if (!t || !sc_out) return KP_ERR_ARG;
+  kp_ctx* ctx = t->ctx;
+  KP_HIP(ctx, hipMemcpy(sc_out, t->sc, (size_t)t->nb * 2 * (t->n + t->m) * 8, hipMemcpyDeviceToHost));
+  return KP_OK;
+}
+
+// Validation rollout + error of one fitted model per system, one wave per system (N <= 16): val_model / val_BLmodel /
+// val_NLmodel (Ksysid.m:1623-1879) on the scaled validation trial, then evaluate_rand_models.m:70-72:
+// err_j = mean_t |y_sim - y_real|_j / (sum_t |y_real|_j / T).  Lane r owns component r of the lifted state.
+__global__ __launch_bounds__(64) void kp_sweep_rollout_kernel(BasisDev b, const double* __restrict__ K, const double* __restrict__ Ap,
+                                                              const double* __restrict__ Bp, const double* __restrict__ Yv,
+                                                              const double* __restrict__ Uv, const double* __restrict__ scv, int Tv,
+                                                              const int* __restrict__ fit_status, double* __restrict__ err) {
+  __shared__ double vsh[KP_MAX_VARS];
+  const int sys = blockIdx.x, lane = threadIdx.x;
+  const int N = b.N, W = b.W, n = b.nzeta, m = b.m, mt = b.model_type;
+  const double* sc = scv + (size_t)sys * 2 * (n + m);
+  const double* Ks = K + (size_t)sys * W * W;
+  const double* yv = Yv + (size_t)sys * Tv * n;
+  const double* uv = Uv + (size_t)sys * Tv * m;
+  const int r = lane < N ? lane : 0;
+  double arow[16], brow[3][16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    arow[c] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) brow[i][c] = 0.0;
+  }
+  if (mt == KP_MODEL_LINEAR) {          // projected model M A, M B (get_model, Ksysid.m:1224-1225)
+#pragma unroll
+    for (int c = 0; c < 16; ++c) if (c < N) arow[c] = Ap[(size_t)sys * N * N + (size_t)c * N + r];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) if (i < m) brow[i][0] = Bp[(size_t)sys * N * m + (size_t)i * N + r];
+  } else if (mt == KP_MODEL_BILINEAR) { // A = UT(1:N,1:N), B = UT(1:N,N+1:end), UT = K' (get_BLmodel, Ksysid.m:1250-1259)
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+      if (c < N) {
+        arow[c] = Ks[c + (size_t)r * W];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) if (i < m) brow[i][c] = Ks[N + N * i + c + (size_t)r * W];
+      }
+  } else {                              // F = K(:,1:nzeta)' basis (get_NLmodel, Ksysid.m:1325-1329): lane c keeps column c of Kf
+#pragma unroll
+    for (int q = 0; q < 16; ++q) if (q < n) arow[q] = Ks[r + (size_t)q * W];
+  }
+  // scaled first validation row -> lifted state
+  if (lane < n) vsh[lane] = (yv[(size_t)lane * Tv] - sc[lane]) / sc[n + lane];
+  if (mt == KP_MODEL_NONLINEAR && lane < m) vsh[n + lane] = (uv[(size_t)lane * Tv] - sc[2 * n + lane]) / sc[2 * n + m + lane];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  double z = 0.0;
+  if (mt != KP_MODEL_NONLINEAR) { if (lane < N) z = kp_eval_col(b, b.cols[lane], vsh, 1); }
+  else if (lane < n) z = vsh[lane];
+  double acc_e = 0.0, acc_a = 0.0;
+  for (int t = 0; t < Tv; ++t) {
+    if (lane < n) {
+      const double yr = (yv[(size_t)lane * Tv + t] - sc[lane]) / sc[n + lane];
+      if (t > 0) acc_e += fabs(z - yr);               // the first simulated row is the measured one (Ksysid.m:1654)
+      acc_a += fabs(yr);
+    }
+    if (t == Tv - 1) break;
+    double ut[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) if (i < m) ut[i] = (uv[(size_t)i * Tv + t] - sc[2 * n + i]) / sc[2 * n + m + i];
+    double zn = 0.0;
+    if (mt == KP_MODEL_LINEAR) {
+#pragma unroll
+      for (int c = 0; c < 16; ++c) if (c < N) zn += arow[c] * sb_bcast(z, c);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) if (i < m) zn += brow[i][0] * ut[i];
+    } else if (mt == KP_MODEL_BILINEAR) {              // z+ = A z + sum_i u_i B_i z (val_BLmodel, Ksysid.m:1772-1787)
+#pragma unroll
+      for (int c = 0; c < 16; ++c)
+        if (c < N) {
+          double w = arow[c];
+#pragma unroll
+          for (int i = 0; i < 3; ++i) if (i < m) w += ut[i] * brow[i][c];
+          zn += w * sb_bcast(z, c);
+        }
+    } else {                                           // zeta+ = Kf psi([zeta; u]) (val_NLmodel, Ksysid.m:1848-1863)
+      if (lane < n) vsh[lane] = z;
+      if (lane < m) vsh[n + lane] = ut[lane];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      const double psi = lane < N ? kp_eval_col(b, b.cols[lane], vsh, 1) : 0.0;
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+        if (q < n) {
+          double sacc = lane < N ? arow[q] * psi : 0.0;
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o, 64);
+          if (lane == q) zn = sacc;
+        }
+      __builtin_amdgcn_wave_barrier();
+    }
+    z = zn;
+  }
+  if (lane < n) {
+    const double bad = fit_status && fit_status[sys] ? __builtin_nan("") : 0.0;
+    err[(size_t)sys * n + lane] = (acc_e / Tv) / (acc_a / Tv) + bad;
+  }
+}
+
+__global__ void kp_l1_flag_kernel(const double* __restrict__ K, int W, double t, int* __restrict__ flags) {
+  const int sys = blockIdx.x;
+  double s = 0.0;
+  for (int e = threadIdx.x; e < W * W; e += 64) s += fabs(K[(size_t)sys * W * W + e]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (threadIdx.x == 0) flags[sys] = s > t ? 1 : 0;
+}
+
+extern "C" int kp_sweep_eval(kp_ctx* ctx, const kp_traj* traj, const kp_basis* basis, double lasso, double* err_out, double* K_out,
+                             int* status_out) {
+  if (!ctx || !traj || !basis || !err_out) return ctx ? ctx->fail(KP_ERR_ARG, "kp_sweep_eval: bad argument") : KP_ERR_ARG;
+  const BasisDev& b = basis->dev;
+  if (b.nzeta != traj->n || b.m != traj->m) return ctx->fail(KP_ERR_ARG, "kp_sweep_eval: trajectory / dictionary dimension mismatch");
+  if (b.W > SB_W || b.k_pcs != 0 || b.N != b.nfull || b.m > 3) return ctx->fail(KP_ERR_ARG, "kp_sweep_eval: needs W <= 16, m <= 3 and no dimension reduction");
+  KP_HIP(ctx, hipSetDevice(ctx->device));
+  if (ctx->async_pending) {
+    int rc0 = kp_synchronize(ctx);
+    if (rc0) return rc0;
+  }
+  const int nb = traj->nb, W = b.W, N = b.N, n = traj->n, m = traj->m;
+  const int Ns = traj->ntrials * (traj->T - 1) - 1;            // get_snapshotPairs: #good - 1 (Ksysid.m:960)
+  const size_t bW = (size_t)nb * W * W * 8, bA = (size_t)nb * N * N * 8, bB = (size_t)nb * N * m * 8;
+  char* ws = (char*)ctx->workspace(6, 3 * bW + bA + bB + (size_t)nb * (n * 8 + 12) + 256);
+  if (!ws) return ctx->fail(KP_ERR_HIP, "kp_sweep_eval: out of device memory");
+  double *dK = (double*)ws, *dG = (double*)(ws + bW), *dC = (double*)(ws + 2 * bW);
+  double *dA = (double*)(ws + 3 * bW), *dB = (double*)(ws + 3 * bW + bA), *dE = (double*)(ws + 3 * bW + bA + bB);
+  int* dS = (int*)(dE + (size_t)nb * n);
+  int* dF = dS + nb;
+  hipStream_t s = ctx->stream;
+  size_t lds = ((size_t)(2 * b.nvars + (b.m > 0 ? b.m : 1)) * SB_TS + 2 * SB_TS * SB_LD + 5 * 16 * SB_LD + 16) * sizeof(double);
+  static const int refine = [] { const char* e = getenv("KP_BATCH_REFINE"); return e ? std::max(0, std::min(4, atoi(e))) : 1; }();
+  const size_t pw_bytes = (size_t)2 * b.nvars * basis->pow_depth * SB_TS * sizeof(double);
+  const bool use_rec = basis->fast && basis->d_recipes && basis->pow_depth >= 1 && lds + pw_bytes <= 64 * 1024;
+  if (use_rec) lds += pw_bytes;
+  TrajView tv{traj->Y, traj->U, traj->sc, traj->ntrials, traj->T, traj->ntrials * traj->T, n, m};
+  KP_HIP(ctx, hipEventRecord(ctx->ev0, s));
+  hipLaunchKernelGGL(kp_small_fit_kernel, dim3(nb), dim3(256), lds, s, b, nullptr, nullptr, nullptr, (int64_t)0, Ns, dK, dG, dC, dS,
+                     use_rec ? (const uint32_t*)basis->d_recipes : nullptr, basis->pow_depth, basis->max_factors > 0 ? basis->max_factors : 1,
+                     refine, tv);
+  KP_HIP(ctx, hipGetLastError());
+  KP_HIP(ctx, hipEventRecord(ctx->ev1, s));
+  if (lasso < 1e6) {
+    // lasso rows of the sweep (nonlinear models, lasso = 4, evaluate_rand_models.m:122): the L1 row is active only when
+    // ||K_LS||_1 > t = lasso N, which the generated and shipped systems never reach; flagged systems are re-solved
+    const double t = lasso * N;
+    hipLaunchKernelGGL(kp_l1_flag_kernel, dim3(nb), dim3(64), 0, s, dK, W, t, dF);
+    KP_HIP(ctx, hipGetLastError());
+    std::vector<int> flags(nb);
+    KP_HIP(ctx, hipMemcpyAsync(flags.data(), dF, (size_t)nb * 4, hipMemcpyDeviceToHost, s));
+    KP_HIP(ctx, hipStreamSynchronize(s));
+    for (int q = 0; q < nb; ++q)
+      if (flags[q]) {
+        int rc = kp_lasso_dev(ctx, dG + (size_t)q * W * W, dC + (size_t)q * W * W, W, W, t, 20000, 1e-10, dK + (size_t)q * W * W, nullptr);
+        if (rc && rc != KP_ERR_NOT_CONVERGED) return rc;
+      }
+  }
+  if (b.model_type == KP_MODEL_LINEAR) {
+    hipLaunchKernelGGL(kp_small_project_kernel, dim3(nb), dim3(256), 0, s, dK, dG, dC, N, m, dA, dB, (double*)nullptr, (int*)nullptr);
+    KP_HIP(ctx, hipGetLastError());
+  }
+  hipLaunchKernelGGL(kp_sweep_rollout_kernel, dim3(nb), dim3(64), 0, s, b, dK, dA, dB, traj->Yv, traj->Uv, traj->sc, traj->Tv, dS, dE);
+  KP_HIP(ctx, hipGetLastError());
+  KP_HIP(ctx, hipMemcpyAsync(err_out, dE, (size_t)nb * n * 8, hipMemcpyDeviceToHost, s));
+  if (K_out) KP_HIP(ctx, hipMemcpyAsync(K_out, dK, bW, hipMemcpyDeviceToHost, s));
+  if (status_out) KP_HIP(ctx, hipMemcpyAsync(status_out, dS, (size_t)nb * 4, hipMemcpyDeviceToHost, s));
+  KP_HIP(ctx, hipStreamSynchronize(s));
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+  ctx->timers[0] = ms;
   return KP_OK;
 }

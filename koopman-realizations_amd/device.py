@@ -283,6 +283,60 @@ class Snapshots:
             pass
 
 
+class Traj:
+    """kp_traj: training / validation trajectories of nb systems with one layout, resident on the device (raw values;
+    the per-system scaling of get_scale is computed there).  Y (nb, rows, n), U (nb, rows, m) with rows = ntrials * T
+    (merged trials), Yv (nb, Tv, n), Uv (nb, Tv, m)."""
+
+    def __init__(self, ctx: Context, Y, U, ntrials, Yv, Uv):
+        self.ctx = ctx
+        Y = np.asarray(Y, dtype=np.float64); U = np.asarray(U, dtype=np.float64)
+        Yv = np.asarray(Yv, dtype=np.float64); Uv = np.asarray(Uv, dtype=np.float64)
+        self.nb, rows, self.n = Y.shape
+        self.m = U.shape[2]
+        self.ntrials, self.T, self.Tv = int(ntrials), rows // int(ntrials), Yv.shape[1]
+        if self.T * self.ntrials != rows:
+            raise ValueError("Traj: rows must be ntrials * T")
+        tr = lambda a: np.ascontiguousarray(np.transpose(a, (0, 2, 1)))        # each system column-major rows x width
+        self._h = F.vp()
+        F.check(F.lib().kp_traj_upload(ctx.handle, F.dptr(tr(Y)), F.dptr(tr(U)), self.nb, self.ntrials, self.T, self.n, self.m,
+                                       F.dptr(tr(Yv)), F.dptr(tr(Uv)), self.Tv, C.byref(self._h)), ctx.handle)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def scale(self):
+        """Per system [y offset (n) | y factor (n) | u offset (m) | u factor (m)] as computed on the device."""
+        sc = np.zeros((self.nb, 2 * (self.n + self.m)))
+        F.check(F.lib().kp_traj_scale(self._h, F.dptr(sc)), self.ctx.handle)
+        return sc
+
+    def sweep_eval(self, basis: "Basis", lasso=np.inf, want_K=False):
+        """kp_sweep_eval: fit + model + validation rollout + normalised mean error of every system for one dictionary.
+        Returns err (nb, n) [, K (nb, W, W)], status (nb,)."""
+        err = np.zeros((self.nb, self.n)); st = np.zeros(self.nb, dtype=np.int32)
+        W = basis.W
+        K = np.zeros((self.nb, W, W)) if want_K else None
+        las = 1e6 if (lasso is None or not np.isfinite(lasso)) else float(lasso)
+        F.check(F.lib().kp_sweep_eval(self.ctx.handle, self._h, basis.handle, las, F.dptr(err), F.dptr(K), st.ctypes.data_as(F.c_ip)),
+                self.ctx.handle)
+        if want_K:
+            return err, np.transpose(K, (0, 2, 1)), st
+        return err, st
+
+    def close(self):
+        if self._h:
+            F.lib().kp_traj_destroy(self._h)
+            self._h = F.vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def fit_gram(ctx: Context, basis: Basis, snaps: Snapshots, fetch=True):
     W = basis.W
     if not fetch:

@@ -135,11 +135,70 @@ def rand_models_sweep(systems, comm=None, ctx=None, degrees=None, eval_fn=None, 
     return {mt: np.stack([r[mt][0] for r in allres], axis=1) for mt in ("linear", "bilinear", "nonlinear")}
 
 
+def _stack_raw(systems):
+    """The systems' trials as stacked raw arrays (no arithmetic): Y (nb, k T, n), U (nb, k T, m), trial count k, and the
+    validation trial Yv, Uv - or None unless every system has the same trial layout (equal counts and lengths, time
+    restarting at every trial: the generated and shipped rand-systems sets)."""
+    try:
+        tr = [d["train"] for d in systems]
+        k = len(tr[0])
+        if any(len(t) != k for t in tr):
+            return None
+        def stacked(key, src):
+            a = np.asarray([[x[key] for x in t] for t in src], dtype=np.float64)   # ValueError when ragged
+            if a.ndim == 3:
+                a = a[..., None]
+            return a.reshape(a.shape[0], a.shape[1] * a.shape[2], -1)
+        Y, U = stacked("y", tr), stacked("u", tr)
+        Tm = stacked("t", tr)[:, :, 0]
+        va = [[d["val"][0]] for d in systems]
+        Yv, Uv = stacked("y", va), stacked("u", va)
+    except ValueError:
+        return None
+    T = Y.shape[1] // k
+    good = Tm[:, :-1] < Tm[:, 1:]                                          # Ksysid.m:948: seams between trials
+    want = np.ones(k * T - 1, dtype=bool); want[T - 1::T] = False            # exactly the seams, nowhere else
+    if not (good == want).all():
+        return None
+    return Y, U, k, Yv, Uv
+
+
 def rand_models_sweep_batched(systems, ctx, degrees=None):
-    """Config 5 on ONE GPU without a host round trip per fit: for every (model type, degree) all systems of the
-    shard are fitted by one `kp_fit_batch` launch (one workgroup per system) and validated by one batched rollout
-    launch.  Same table as `rand_models_sweep` (evaluate_rand_models.m:38-43); requires systems with equally many
-    snapshot pairs (the shipped and generated rand-systems data sets have 9 x 1000) and no delays."""
+    """Config 5 on ONE GPU with the data resident on the device: the trajectories of the shard are uploaded once
+    (`kp_traj_upload`, scaling computed there), then for every (model type, degree) ONE `kp_sweep_eval` call does snapshot
+    pairs + fit + model extraction + validation rollout + normalised error for all systems and returns only the error
+    column.  Same table as `rand_models_sweep` (evaluate_rand_models.m:38-43).  Systems whose trials are not equally
+    shaped go through the host-prepared path (`_sweep_batched_host`)."""
+    from .device import Basis, Traj
+    from .ksysid import poly_exponent_table
+    degrees = degrees or MAX_DEGREE
+    raw = _stack_raw(systems)
+    if raw is None:
+        return _sweep_batched_host(systems, ctx, degrees)
+    Y, U, k, Yv, Uv = raw
+    n, m = Y.shape[2], U.shape[2]
+    traj = Traj(ctx, Y, U, k, Yv, Uv)
+    out = {}
+    try:
+        for mt in ("linear", "bilinear", "nonlinear"):
+            rows = []
+            for j in range(1, degrees[mt] + 1):
+                nv = n + (m if mt == "nonlinear" else 0)
+                basis = Basis(ctx, mt, n, m, [("poly", poly_exponent_table(nv, j)[nv:])], None)
+                try:
+                    err, st = traj.sweep_eval(basis, 4.0 if mt == "nonlinear" else np.inf)      # lasso 4: evaluate_rand_models.m:122
+                    rows.append(err[:, 0])
+                finally:
+                    basis.close()
+            out[mt] = np.stack(rows, axis=0)
+    finally:
+        traj.close()
+    return out
+
+
+def _sweep_batched_host(systems, ctx, degrees=None):
+    """The batched sweep with scaling / snapshot pairs prepared on the host (systems of differing trial layouts): for
+    every (model type, degree) one `kp_fit_batch` launch and one batched rollout launch."""
     from .device import Basis, Snapshots
     from .ksysid import Ksysid, poly_exponent_table
     from . import _ffi as F
