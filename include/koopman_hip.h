@@ -206,6 +206,16 @@ int kp_traj_destroy(kp_traj* traj);
 int kp_traj_scale(kp_traj* traj, double* sc_out);
 int kp_sweep_eval(kp_ctx* ctx, const kp_traj* traj, const kp_basis* basis, double lasso, double* err_out, double* K_out,
                   int* status_out);
+/* kp_sweep_eval for degrees 1..n_deg of a POLYNOMIAL dictionary from ONE pass over the data (evaluate_rand_models.m
+ * :47-143 loops degree by degree; def_polyLift orders monomials by total degree, Ksysid.m:645-648, so the degree-j
+ * dictionary is a column subset of the degree-D one and its Grams are sub-blocks).  `basis` is the dictionary of the
+ * highest degree.  The Grams are accumulated in a Chebyshev internal basis (data are scaled to [-1, 1]) and mapped back
+ * exactly (K_m = T^-1 K_c T): QR-level accuracy of K without a refinement sweep.  err_out: n_deg x nb x n
+ * (degree-major); status_out (n_deg x nb, may be NULL).  kp_sweep_nested_get_K fetches the K matrices (monomial basis,
+ * W_j x W_j each) of one degree of the most recent call (parity checks). */
+int kp_sweep_eval_nested(kp_ctx* ctx, const kp_traj* traj, const kp_basis* basis, double lasso, int n_deg, double* err_out,
+                         int* status_out);
+int kp_sweep_nested_get_K(kp_ctx* ctx, int nb, int Wmax, int n_deg, int deg_index, int W, double* K_out);
 
 /* Model extraction with the M-projection of get_model (Ksysid.m:1206-1225): from K and
  * the Grams (no second pass over the data): L'L = [A B] G [A B]', L'R = [A B] C(:,1:N).

@@ -59,6 +59,8 @@ SIGNATURES = {
     "kp_traj_destroy": (C.c_int, [vp]),
     "kp_traj_scale": (C.c_int, [vp, c_dp]),
     "kp_sweep_eval": (C.c_int, [vp, vp, vp, C.c_double, c_dp, c_dp, c_ip]),
+    "kp_sweep_eval_nested": (C.c_int, [vp, vp, vp, C.c_double, C.c_int, c_dp, c_ip]),
+    "kp_sweep_nested_get_K": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_dp]),
     "kp_fit_refine": (C.c_int, [vp, vp, vp, C.c_int, c_dp]),
     "kp_sym_eig": (C.c_int, [vp, c_dp, C.c_int, c_dp, c_dp, C.POINTER(C.c_int)]),
     "kp_mpc_set_state_bounds": (C.c_int, [vp, C.c_int, c_dp, c_dp]),

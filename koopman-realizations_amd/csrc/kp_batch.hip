@@ -12,6 +12,7 @@
 // Replaces, for each system: Ksysid.get_Koopman (Ksysid.m:987-1092) with lasso = Inf.
 #include "kp_internal.h"
 #include <algorithm>
+#include <cmath>
 #include <string>
 #include <vector>
 
@@ -99,16 +100,17 @@ __device__ __forceinline__ void sb_spd_solve16(const double* Gs, const double* C
 // a system is row (p / (T-1)) T + p % (T-1) and its successor - no pair across a trial seam - and the last good pair
 // is dropped (:960), so a system has ntrials (T - 1) - 1 pairs.
 struct TrajView {
-  const double* Y;
+  const double* Y;      // SCALED in place at upload (kp_traj_apply_scale_kernel): the fit passes only index
   const double* U;
   const double* sc;
   int ntrials, T, rows, n, m;
+  unsigned long long div_magic;   // ceil(2^40 / (T - 1)): pair / (T - 1) = (pair * magic) >> 40 for pair < 2^24
 };
 
 __global__ __launch_bounds__(256) void kp_small_fit_kernel(BasisDev b, const double* __restrict__ alpha, const double* __restrict__ beta,
                                                            const double* __restrict__ u, int64_t Ns_total, int Ns, double* __restrict__ Kout,
                                                            double* __restrict__ Gout, double* __restrict__ Cout, int* __restrict__ status,
-                                                           const uint32_t* __restrict__ recipes, int D, int nfmax, int refine, TrajView tv) {
+                                                           const uint32_t* __restrict__ recipes, int D, int nfmax, int refine, TrajView tv, int cheb) {
   extern __shared__ __align__(16) double sm[];
   // LDS: vx[nvars][TS] | vy[nvars][TS] | um[m][TS] | Px[TS][LD] | Py[TS][LD] | Gs[16][LD] | Cs[16][LD] | Ls[16][LD] | Dd[16] | Ks[16][LD] | Xs[16][LD] | pw
   const int nv = b.nvars, m = b.m, N = b.N, W = b.W;
@@ -149,14 +151,14 @@ __global__ __launch_bounds__(256) void kp_small_fit_kernel(BasisDev b, const dou
       for (int e = tid; e < (2 * nv + m) * SB_TS; e += 256) {
         const int v = e / SB_TS, p = e % SB_TS;
         double x = 0.0;
-        if (p < nl && tv.Y) {                          // scaled pair straight from the trajectories
+        if (p < nl && tv.Y) {                          // pair straight from the (already scaled) trajectories
           const int pair = r0 + p, Tm1 = tv.T - 1;
-          const int row = (pair / Tm1) * tv.T + pair % Tm1;
-          const double* sc = tv.sc + (size_t)sys * 2 * (tv.n + tv.m);
+          const int tr = (int)(((unsigned long long)pair * tv.div_magic) >> 40);
+          const int row = tr * tv.T + (pair - tr * Tm1);
           int var = v < nv ? v : v < 2 * nv ? v - nv : b.nzeta + (v - 2 * nv);        // index into [y (n) ; u (m)]
           const int shift = (v >= nv && v < 2 * nv && var < b.nzeta) ? 1 : 0;         // beta = the next row of y
-          if (var < b.nzeta) x = (tv.Y[((size_t)sys * tv.n + var) * tv.rows + row + shift] - sc[var]) / sc[tv.n + var];
-          else { var -= b.nzeta; x = (tv.U[((size_t)sys * tv.m + var) * tv.rows + row] - sc[2 * tv.n + var]) / sc[2 * tv.n + tv.m + var]; }
+          if (var < b.nzeta) x = tv.Y[((size_t)sys * tv.n + var) * tv.rows + row + shift];
+          else x = tv.U[((size_t)sys * tv.m + (var - b.nzeta)) * tv.rows + row];
         } else if (p < nl) {
           const int64_t row = base + r0 + p;
           if (v < nv) x = v < b.nzeta ? alpha[(int64_t)v * Ns_total + row] : u[(int64_t)(v - b.nzeta) * Ns_total + row];
@@ -170,10 +172,12 @@ __global__ __launch_bounds__(256) void kp_small_fit_kernel(BasisDev b, const dou
         for (int e = tid; e < 2 * nv * SB_TS; e += 256) {
           const int p = e % SB_TS, sv = e / SB_TS;     // sv = side * nv + v; vx | vy are contiguous
           const double x = sm[sv * SB_TS + p];
-          double q = x;
+          double q = x, qm = 1.0;
           for (int k = 0; k < D; ++k) {
             pw[(sv * D + k) * SB_TS + p] = q;
-            q *= x;
+            const double qn = cheb ? 2.0 * x * q - qm : q * x;      // cheb: T_(k+2) = 2 x T_(k+1) - T_k instead of x^(k+2)
+            qm = q;
+            q = qn;
           }
         }
         __syncthreads();
@@ -304,7 +308,7 @@ extern "C" int kp_fit_batch(kp_ctx* ctx, const kp_basis* basis, const kp_snapsho
   KP_HIP(ctx, hipEventRecord(ctx->ev0, s));
   hipLaunchKernelGGL(kp_small_fit_kernel, dim3(nb), dim3(256), lds, s, b, snaps->alpha, snaps->beta, snaps->u, snaps->Ns, (int)Ns_each, dK, dG, dC,
                      dS, use_rec ? (const uint32_t*)basis->d_recipes : nullptr, basis->pow_depth, basis->max_factors > 0 ? basis->max_factors : 1,
-                     refine, TrajView{});
+                     refine, TrajView{}, 0);
   KP_HIP(ctx, hipGetLastError());
   KP_HIP(ctx, hipEventRecord(ctx->ev1, s));
   KP_HIP(ctx, hipMemcpyAsync(K_out, dK, bW, hipMemcpyDeviceToHost, s));
@@ -435,9 +439,26 @@ __global__ __launch_bounds__(256) void kp_traj_scale_kernel(const double* __rest
   }
 }
 
+// scale_data (Ksysid.m:308-343) once, in place: training and validation trials with the training factors
+__global__ void kp_traj_apply_scale_kernel(double* __restrict__ X, int rows, int width, int n, int m, int is_u, const double* __restrict__ sc) {
+  const int sys = blockIdx.y;
+  const double* s = sc + (size_t)sys * 2 * (n + m);
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < rows * width; e += gridDim.x * blockDim.x) {
+    const int v = e / rows;
+    const double off = is_u ? s[2 * n + v] : s[v], fac = is_u ? s[2 * n + m + v] : s[n + v];
+    double* x = X + (size_t)sys * rows * width + e;
+    *x = (*x - off) / fac;
+  }
+}
+
+static TrajView traj_view(const kp_traj* t) {
+  const unsigned long long d = (unsigned long long)(t->T - 1);
+  return TrajView{t->Y, t->U, t->sc, t->ntrials, t->T, t->ntrials * t->T, t->n, t->m, ((1ull << 40) + d - 1) / d};
+}
+
 extern "C" int kp_traj_upload(kp_ctx* ctx, const double* Y, const double* U, int nb, int ntrials, int T, int n, int m, const double* Yv,
                               const double* Uv, int Tv, kp_traj** out) {
-  if (!ctx || !Y || !U || !Yv || !Uv || !out || nb < 1 || ntrials < 1 || T < 3 || n < 1 || m < 1 || Tv < 2)
+  if (!ctx || !Y || !U || !Yv || !Uv || !out || nb < 1 || ntrials < 1 || T < 3 || n < 1 || m < 1 || Tv < 2 || (int64_t)ntrials * T >= (1 << 24))
     return ctx ? ctx->fail(KP_ERR_ARG, "kp_traj_upload: bad argument") : KP_ERR_ARG;
   KP_HIP(ctx, hipSetDevice(ctx->device));
   kp_traj* t = new kp_traj;
@@ -456,6 +477,10 @@ extern "C" int kp_traj_upload(kp_ctx* ctx, const double* Y, const double* U, int
   if (e == hipSuccess) e = hipMemcpyAsync(t->Uv, Uv, bUv, hipMemcpyHostToDevice, s);
   if (e == hipSuccess) {
     hipLaunchKernelGGL(kp_traj_scale_kernel, dim3(nb), dim3(256), 0, s, t->Y, t->U, (int)rows, n, m, t->sc);
+    hipLaunchKernelGGL(kp_traj_apply_scale_kernel, dim3(16, nb), dim3(256), 0, s, t->Y, (int)rows, n, n, m, 0, t->sc);
+    hipLaunchKernelGGL(kp_traj_apply_scale_kernel, dim3(16, nb), dim3(256), 0, s, t->U, (int)rows, m, n, m, 1, t->sc);
+    hipLaunchKernelGGL(kp_traj_apply_scale_kernel, dim3(2, nb), dim3(256), 0, s, t->Yv, Tv, n, n, m, 0, t->sc);
+    hipLaunchKernelGGL(kp_traj_apply_scale_kernel, dim3(2, nb), dim3(256), 0, s, t->Uv, Tv, m, n, m, 1, t->sc);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipStreamSynchronize(s);
@@ -489,17 +514,13 @@ extern "C" int kp_traj_scale(kp_traj* t, double* sc_out) {
 // Validation rollout + error of one fitted model per system, one wave per system (N <= 16): val_model / val_BLmodel /
 // val_NLmodel (Ksysid.m:1623-1879) on the scaled validation trial, then evaluate_rand_models.m:70-72:
 // err_j = mean_t |y_sim - y_real|_j / (sum_t |y_real|_j / T).  Lane r owns component r of the lifted state.
-__global__ __launch_bounds__(64) void kp_sweep_rollout_kernel(BasisDev b, const double* __restrict__ K, const double* __restrict__ Ap,
-                                                              const double* __restrict__ Bp, const double* __restrict__ Yv,
-                                                              const double* __restrict__ Uv, const double* __restrict__ scv, int Tv,
-                                                              const int* __restrict__ fit_status, double* __restrict__ err) {
-  __shared__ double vsh[KP_MAX_VARS];
-  const int sys = blockIdx.x, lane = threadIdx.x;
+// Ks: this system's K (column-major, leading dimension W); Aps / Bps: its projected A (N x N), B (N x m) for linear models
+__device__ __forceinline__ void sweep_rollout_body(const BasisDev& b, const double* __restrict__ Ks, const double* __restrict__ Aps,
+                                                   const double* __restrict__ Bps, const double* __restrict__ yv,
+                                                   const double* __restrict__ uv, int Tv, int bad_fit, double* __restrict__ err_sys,
+                                                   double* vsh) {
+  const int lane = threadIdx.x;
   const int N = b.N, W = b.W, n = b.nzeta, m = b.m, mt = b.model_type;
-  const double* sc = scv + (size_t)sys * 2 * (n + m);
-  const double* Ks = K + (size_t)sys * W * W;
-  const double* yv = Yv + (size_t)sys * Tv * n;
-  const double* uv = Uv + (size_t)sys * Tv * m;
   const int r = lane < N ? lane : 0;
   double arow[16], brow[3][16];
 #pragma unroll
@@ -510,9 +531,9 @@ __global__ __launch_bounds__(64) void kp_sweep_rollout_kernel(BasisDev b, const 
   }
   if (mt == KP_MODEL_LINEAR) {          // projected model M A, M B (get_model, Ksysid.m:1224-1225)
 #pragma unroll
-    for (int c = 0; c < 16; ++c) if (c < N) arow[c] = Ap[(size_t)sys * N * N + (size_t)c * N + r];
+    for (int c = 0; c < 16; ++c) if (c < N) arow[c] = Aps[(size_t)c * N + r];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) if (i < m) brow[i][0] = Bp[(size_t)sys * N * m + (size_t)i * N + r];
+    for (int i = 0; i < 3; ++i) if (i < m) brow[i][0] = Bps[(size_t)i * N + r];
   } else if (mt == KP_MODEL_BILINEAR) { // A = UT(1:N,1:N), B = UT(1:N,N+1:end), UT = K' (get_BLmodel, Ksysid.m:1250-1259)
 #pragma unroll
     for (int c = 0; c < 16; ++c)
@@ -526,8 +547,8 @@ __global__ __launch_bounds__(64) void kp_sweep_rollout_kernel(BasisDev b, const 
     for (int q = 0; q < 16; ++q) if (q < n) arow[q] = Ks[r + (size_t)q * W];
   }
   // scaled first validation row -> lifted state
-  if (lane < n) vsh[lane] = (yv[(size_t)lane * Tv] - sc[lane]) / sc[n + lane];
-  if (mt == KP_MODEL_NONLINEAR && lane < m) vsh[n + lane] = (uv[(size_t)lane * Tv] - sc[2 * n + lane]) / sc[2 * n + m + lane];
+  if (lane < n) vsh[lane] = yv[(size_t)lane * Tv];
+  if (mt == KP_MODEL_NONLINEAR && lane < m) vsh[n + lane] = uv[(size_t)lane * Tv];
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -537,14 +558,14 @@ __global__ __launch_bounds__(64) void kp_sweep_rollout_kernel(BasisDev b, const 
   double acc_e = 0.0, acc_a = 0.0;
   for (int t = 0; t < Tv; ++t) {
     if (lane < n) {
-      const double yr = (yv[(size_t)lane * Tv + t] - sc[lane]) / sc[n + lane];
+      const double yr = yv[(size_t)lane * Tv + t];
       if (t > 0) acc_e += fabs(z - yr);               // the first simulated row is the measured one (Ksysid.m:1654)
       acc_a += fabs(yr);
     }
     if (t == Tv - 1) break;
     double ut[3] = {0.0, 0.0, 0.0};
 #pragma unroll
-    for (int i = 0; i < 3; ++i) if (i < m) ut[i] = (uv[(size_t)i * Tv + t] - sc[2 * n + i]) / sc[2 * n + m + i];
+    for (int i = 0; i < 3; ++i) if (i < m) ut[i] = uv[(size_t)i * Tv + t];
     double zn = 0.0;
     if (mt == KP_MODEL_LINEAR) {
 #pragma unroll
@@ -580,9 +601,20 @@ __global__ __launch_bounds__(64) void kp_sweep_rollout_kernel(BasisDev b, const 
     z = zn;
   }
   if (lane < n) {
-    const double bad = fit_status && fit_status[sys] ? __builtin_nan("") : 0.0;
-    err[(size_t)sys * n + lane] = (acc_e / Tv) / (acc_a / Tv) + bad;
+    const double bad = bad_fit ? __builtin_nan("") : 0.0;
+    err_sys[lane] = (acc_e / Tv) / (acc_a / Tv) + bad;
   }
+}
+
+
+__global__ __launch_bounds__(64) void kp_sweep_rollout_kernel(BasisDev b, const double* __restrict__ K, const double* __restrict__ Ap,
+                                                              const double* __restrict__ Bp, const double* __restrict__ Yv,
+                                                              const double* __restrict__ Uv, const double* __restrict__ scv, int Tv,
+                                                              const int* __restrict__ fit_status, double* __restrict__ err) {
+  __shared__ double vsh[KP_MAX_VARS];
+  const int sys = blockIdx.x, n = b.nzeta, m = b.m;
+  sweep_rollout_body(b, K + (size_t)sys * b.W * b.W, Ap ? Ap + (size_t)sys * b.N * b.N : nullptr, Bp ? Bp + (size_t)sys * b.N * m : nullptr,
+                     Yv + (size_t)sys * Tv * n, Uv + (size_t)sys * Tv * m, Tv, fit_status && fit_status[sys], err + (size_t)sys * n, vsh);
 }
 
 __global__ void kp_l1_flag_kernel(const double* __restrict__ K, int W, double t, int* __restrict__ flags) {
@@ -620,11 +652,11 @@ extern "C" int kp_sweep_eval(kp_ctx* ctx, const kp_traj* traj, const kp_basis* b
   const size_t pw_bytes = (size_t)2 * b.nvars * basis->pow_depth * SB_TS * sizeof(double);
   const bool use_rec = basis->fast && basis->d_recipes && basis->pow_depth >= 1 && lds + pw_bytes <= 64 * 1024;
   if (use_rec) lds += pw_bytes;
-  TrajView tv{traj->Y, traj->U, traj->sc, traj->ntrials, traj->T, traj->ntrials * traj->T, n, m};
+  TrajView tv = traj_view(traj);
   KP_HIP(ctx, hipEventRecord(ctx->ev0, s));
   hipLaunchKernelGGL(kp_small_fit_kernel, dim3(nb), dim3(256), lds, s, b, nullptr, nullptr, nullptr, (int64_t)0, Ns, dK, dG, dC, dS,
                      use_rec ? (const uint32_t*)basis->d_recipes : nullptr, basis->pow_depth, basis->max_factors > 0 ? basis->max_factors : 1,
-                     refine, tv);
+                     refine, tv, 0);
   KP_HIP(ctx, hipGetLastError());
   KP_HIP(ctx, hipEventRecord(ctx->ev1, s));
   if (lasso < 1e6) {
@@ -655,5 +687,325 @@ extern "C" int kp_sweep_eval(kp_ctx* ctx, const kp_traj* traj, const kp_basis* b
   float ms = 0;
   (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
   ctx->timers[0] = ms;
+  return KP_OK;
+}
+
+
+// =====================================================================================================================
+// All degrees of one model type from ONE pass over the data (evaluate_rand_models.m loops degree by degree, :47-143).
+//  * The degree-j polynomial dictionary is a column subset of the degree-D one: def_polyLift orders the monomials by
+//    total degree (Ksysid.m:645-648), so fullBasis_j = the first N_j - 1 columns of fullBasis_D plus the constant, and
+//    Px_j'Px_j, Px_j'Py_j are sub-blocks of the degree-D Grams.
+//  * The Grams are accumulated in a CHEBYSHEV internal basis (the data are scaled to [-1, 1], get_scale): psi_c has
+//    T_e(x_v) where the monomial has x_v^e.  psi_m = S psi_c with an exactly known S (x^a = sum_b s1[a][b] T_b(x), all
+//    coefficients positive: no cancellation), hence  K_m = T^-1 K_c T (T = S'),  G_m = S G_c S',  C_m = S C_c S'.
+//    cond(Px_c) ~ 20-40 where cond(Px_m) ~ 1e5 for the degree-13 dictionaries, so the normal equations in the internal
+//    basis give K_m to ~5e-12 of the QR solution that MATLAB's `\` (Ksysid.m:1069) returns - without the second sweep
+//    over the snapshots that iterative refinement needs.
+// =====================================================================================================================
+struct SweepDeg {
+  int N, W, pad0, pad1;
+  int idx[16];          // column of the degree-D Px for each column of the degree-j Px
+  double Sf[256];       // [r * 16 + c]: psi_m = Sf psi_c (identity on the padding)
+  double Tinv[256];     // (Sf')^-1
+};
+
+__global__ __launch_bounds__(256) void kp_sweep_sub_kernel(const double* __restrict__ Gc, const double* __restrict__ Cc, int Wmax, int nb,
+                                                           const SweepDeg* __restrict__ degs, const int* __restrict__ fit_status,
+                                                           double* __restrict__ Kall, double* __restrict__ Gall,
+                                                           double* __restrict__ Call, int* __restrict__ stat) {
+  __shared__ double Gs[16 * SB_LD], Cs[16 * SB_LD], Xs[16 * SB_LD], Ls[16 * SB_LD], Dd[16], T1[16 * SB_LD], T2[16 * SB_LD], Sf[16 * SB_LD],
+      Ti[16 * SB_LD];
+  __shared__ int bad;
+  const int tid = threadIdx.x, i = tid >> 4, j = tid & 15, sys = blockIdx.x, dj = blockIdx.y;
+  const SweepDeg& d = degs[dj];
+  const int W = d.W;
+  const double* G0 = Gc + (size_t)sys * Wmax * Wmax;
+  const double* C0 = Cc + (size_t)sys * Wmax * Wmax;
+  const bool in = i < W && j < W;
+  Gs[i * SB_LD + j] = in ? G0[d.idx[i] + (size_t)d.idx[j] * Wmax] : (i == j ? 1.0 : 0.0);
+  Cs[i * SB_LD + j] = in ? C0[d.idx[i] + (size_t)d.idx[j] * Wmax] : 0.0;
+  Sf[i * SB_LD + j] = d.Sf[i * 16 + j];
+  Ti[i * SB_LD + j] = d.Tinv[i * 16 + j];
+  if (tid == 0) bad = 0;
+  __syncthreads();
+  sb_spd_solve16(Gs, Cs, Xs, Ls, Dd, &bad);                       // Xs = K_c
+  double a = 0.0, g = 0.0, c = 0.0;                                // X T, G S', C S'  (T[k][j] = Sf[j][k])
+  for (int k = 0; k < 16; ++k) {
+    const double sjk = Sf[j * SB_LD + k];
+    a += Xs[i * SB_LD + k] * sjk;
+    g += Gs[i * SB_LD + k] * sjk;
+    c += Cs[i * SB_LD + k] * sjk;
+  }
+  __syncthreads();
+  T1[i * SB_LD + j] = a; T2[i * SB_LD + j] = g; Ls[i * SB_LD + j] = c;
+  __syncthreads();
+  double km = 0.0, gm = 0.0, cm = 0.0;
+  for (int k = 0; k < 16; ++k) {
+    km += Ti[i * SB_LD + k] * T1[k * SB_LD + j];
+    gm += Sf[i * SB_LD + k] * T2[k * SB_LD + j];
+    cm += Sf[i * SB_LD + k] * Ls[k * SB_LD + j];
+  }
+  const size_t o = ((size_t)dj * nb + sys) * 256;
+  const int isbad = bad || (fit_status && fit_status[sys]);
+  if (in) {
+    Kall[o + (size_t)j * W + i] = isbad ? __builtin_nan("") : km;
+    Gall[o + (size_t)j * W + i] = gm;
+    Call[o + (size_t)j * W + i] = cm;
+  }
+  if (tid == 0) stat[(size_t)dj * nb + sys] = isbad;
+}
+
+// kp_small_project_kernel for every (system, degree) of a nested linear sweep
+__global__ __launch_bounds__(256) void kp_sweep_project_kernel(const double* __restrict__ Kall, const double* __restrict__ Gall,
+                                                               const double* __restrict__ Call, int nb, int m, const SweepDeg* __restrict__ degs,
+                                                               double* __restrict__ Aall, double* __restrict__ Ball) {
+  __shared__ double Ks[16 * SB_LD], Gs[16 * SB_LD], Cs[16 * SB_LD], Ts[16 * SB_LD], LL[16 * SB_LD], LR[16 * SB_LD], Ms[16 * SB_LD], Ls[16 * SB_LD], Dd[16];
+  __shared__ int bad;
+  const int tid = threadIdx.x, i = tid >> 4, j = tid & 15, sys = blockIdx.x, dj = blockIdx.y;
+  const int N = degs[dj].N, W = N + m;
+  const size_t off = ((size_t)dj * nb + sys) * 256;
+  const bool in = i < W && j < W;
+  Ks[i * SB_LD + j] = in ? Kall[off + (size_t)j * W + i] : 0.0;
+  Gs[i * SB_LD + j] = in ? Gall[off + (size_t)j * W + i] : 0.0;
+  Cs[i * SB_LD + j] = in ? Call[off + (size_t)j * W + i] : 0.0;
+  if (tid == 0) bad = 0;
+  __syncthreads();
+  double t = 0.0;
+  if (j < N)
+    for (int w = 0; w < W; ++w) t += Gs[i * SB_LD + w] * Ks[w * SB_LD + j];
+  Ts[i * SB_LD + j] = t;
+  __syncthreads();
+  double ll = 0.0, lr = 0.0;
+  if (i < N && j < N)
+    for (int w = 0; w < W; ++w) {
+      ll += Ks[w * SB_LD + i] * Ts[w * SB_LD + j];
+      lr += Ks[w * SB_LD + i] * Cs[w * SB_LD + j];
+    }
+  LL[i * SB_LD + j] = (i < N && j < N) ? ll : (i == j ? 1.0 : 0.0);
+  LR[i * SB_LD + j] = (i < N && j < N) ? lr : 0.0;
+  __syncthreads();
+  sb_spd_solve16(LL, LR, Ms, Ls, Dd, &bad);
+  const double nanv = __builtin_nan("");
+  double a = 0.0, b = 0.0;
+  if (i < N)
+    for (int k = 0; k < N; ++k) {
+      const double mik = Ms[k * SB_LD + i];
+      if (j < N) a += mik * Ks[j * SB_LD + k];
+      if (j < m) b += mik * Ks[(N + j) * SB_LD + k];
+    }
+  if (i < N && j < N) Aall[off + (size_t)j * N + i] = bad ? nanv : a;
+  if (i < N && j < m) Ball[off + (size_t)j * N + i] = bad ? nanv : b;
+}
+
+__global__ __launch_bounds__(64) void kp_sweep_rollout_nested_kernel(BasisDev b, const SweepDeg* __restrict__ degs, const ColDesc* __restrict__ cols_all,
+                                                                     int nb, const double* __restrict__ Kall, const double* __restrict__ Aall,
+                                                                     const double* __restrict__ Ball, const double* __restrict__ Yv,
+                                                                     const double* __restrict__ Uv, int Tv, const int* __restrict__ stat,
+                                                                     double* __restrict__ err) {
+  __shared__ double vsh[KP_MAX_VARS];
+  const int sys = blockIdx.x, dj = blockIdx.y, n = b.nzeta, m = b.m;
+  BasisDev bj = b;
+  bj.N = degs[dj].N; bj.W = degs[dj].W; bj.nfull = bj.N; bj.cols = cols_all + (size_t)dj * 16;
+  const size_t off = ((size_t)dj * nb + sys) * 256;
+  sweep_rollout_body(bj, Kall + off, Aall ? Aall + off : nullptr, Ball ? Ball + off : nullptr, Yv + (size_t)sys * Tv * n, Uv + (size_t)sys * Tv * m,
+                     Tv, stat[(size_t)dj * nb + sys], err + ((size_t)dj * nb + sys) * n, vsh);
+}
+
+__global__ void kp_l1_flag_all_kernel(const double* __restrict__ Kall, const SweepDeg* __restrict__ degs, int nb, double lasso, int* __restrict__ flags) {
+  const int sys = blockIdx.x, dj = blockIdx.y, W = degs[dj].W;
+  const double* K = Kall + ((size_t)dj * nb + sys) * 256;
+  double s = 0.0;
+  for (int e = threadIdx.x; e < W * W; e += 64) s += fabs(K[e]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (threadIdx.x == 0) flags[(size_t)dj * nb + sys] = s > lasso * degs[dj].N ? 1 : 0;
+}
+
+// 1-D monomial -> Chebyshev coefficients: x^a = sum_b s1[a][b] T_b(x)   (x T_b = (T_(b+1) + T_|b-1|) / 2, x T_0 = T_1)
+static void cheb_table(int dmax, std::vector<std::vector<double>>& s1) {
+  s1.assign(dmax + 1, std::vector<double>(dmax + 1, 0.0));
+  s1[0][0] = 1.0;
+  for (int a = 0; a < dmax; ++a)
+    for (int bq = 0; bq <= a; ++bq) {
+      const double c = s1[a][bq];
+      if (c == 0.0) continue;
+      if (bq == 0) s1[a + 1][1] += c;
+      else { s1[a + 1][bq + 1] += 0.5 * c; s1[a + 1][bq - 1] += 0.5 * c; }
+    }
+}
+
+extern "C" int kp_sweep_eval_nested(kp_ctx* ctx, const kp_traj* traj, const kp_basis* basis, double lasso, int n_deg, double* err_out,
+                                    int* status_out) {
+  if (!ctx || !traj || !basis || !err_out || n_deg < 1) return ctx ? ctx->fail(KP_ERR_ARG, "kp_sweep_eval_nested: bad argument") : KP_ERR_ARG;
+  const BasisDev& b = basis->dev;
+  if (b.nzeta != traj->n || b.m != traj->m) return ctx->fail(KP_ERR_ARG, "kp_sweep_eval_nested: trajectory / dictionary dimension mismatch");
+  if (b.W > SB_W || b.k_pcs != 0 || b.N != b.nfull || b.m > 3 || !basis->fast || basis->h_recipes.size() != (size_t)b.nfull)
+    return ctx->fail(KP_ERR_ARG, "kp_sweep_eval_nested: needs a polynomial dictionary with W <= 16, m <= 3 and no dimension reduction");
+  KP_HIP(ctx, hipSetDevice(ctx->device));
+  if (ctx->async_pending) {
+    int rc0 = kp_synchronize(ctx);
+    if (rc0) return rc0;
+  }
+  const int nb = traj->nb, Wmax = b.W, Nmax = b.N, n = traj->n, m = traj->m, nv = b.nvars, Dp = basis->pow_depth;
+  // exponent multi-index and total degree of every column (from the power-table recipes; the constant is all zeros)
+  std::vector<std::vector<int>> ex(Nmax, std::vector<int>(nv, 0));
+  std::vector<int> deg(Nmax, 0);
+  for (int c = 0; c < Nmax; ++c) {
+    const uint32_t r = basis->h_recipes[c];
+    for (int f = 0; f < 4; ++f) {
+      const uint32_t id = (r >> (8 * f)) & 255u;
+      if (id == 255u) continue;
+      ex[c][id / Dp] += (int)(id % Dp) + 1;
+    }
+    for (int v = 0; v < nv; ++v) deg[c] += ex[c][v];
+  }
+  if (deg[Nmax - 1] != 0) return ctx->fail(KP_ERR_ARG, "kp_sweep_eval_nested: the last dictionary column must be the constant");
+  for (int c = 0; c + 2 < Nmax; ++c)
+    if (deg[c] > deg[c + 1] || deg[c] < 1) return ctx->fail(KP_ERR_ARG, "kp_sweep_eval_nested: monomials must be ordered by total degree");
+  const int dmax = deg[Nmax - 2];
+  if (n_deg > dmax) return ctx->fail(KP_ERR_ARG, "kp_sweep_eval_nested: n_deg exceeds the degree of the dictionary");
+  std::vector<std::vector<double>> s1;
+  cheb_table(dmax, s1);
+  std::vector<SweepDeg> degs(n_deg);
+  std::vector<ColDesc> cols_all((size_t)n_deg * 16, ColDesc{COL_CONST, 0, 0, 0});
+  for (int dj = 0; dj < n_deg; ++dj) {
+    const int j = dj + 1;
+    SweepDeg& d = degs[dj];
+    std::vector<int> psi;                            // columns of psi_D that make psi_j: degree <= j, then the constant
+    for (int c = 0; c + 1 < Nmax; ++c)
+      if (deg[c] <= j) psi.push_back(c);
+    psi.push_back(Nmax - 1);
+    const int Nj = (int)psi.size();
+    d.N = Nj;
+    d.W = b.model_type == KP_MODEL_LINEAR ? Nj + m : b.model_type == KP_MODEL_BILINEAR ? Nj * (m + 1) : Nj;
+    d.pad0 = d.pad1 = 0;
+    // S_psi (Nj x Nj) and its layout inside Sf
+    std::vector<long double> Sp((size_t)Nj * Nj, 0.0L);
+    for (int r = 0; r < Nj; ++r)
+      for (int c = 0; c < Nj; ++c) {
+        long double p = 1.0L;
+        for (int v = 0; v < nv; ++v) {
+          const int a = ex[psi[r]][v], bq = ex[psi[c]][v];
+          p *= bq <= a ? (long double)s1[a][bq] : 0.0L;
+        }
+        Sp[(size_t)r * Nj + c] = p;
+      }
+    std::vector<long double> Sf((size_t)256, 0.0L);
+    for (int q = 0; q < 16; ++q) Sf[q * 16 + q] = 1.0L;
+    for (int q = 0; q < 16; ++q) d.idx[q] = 0;
+    const int nblk = b.model_type == KP_MODEL_BILINEAR ? m + 1 : 1;
+    for (int blk = 0; blk < nblk; ++blk)
+      for (int r = 0; r < Nj; ++r) {
+        d.idx[blk * Nj + r] = blk * Nmax + psi[r];
+        for (int c = 0; c < Nj; ++c) Sf[(size_t)(blk * Nj + r) * 16 + blk * Nj + c] = Sp[(size_t)r * Nj + c];
+      }
+    if (b.model_type == KP_MODEL_LINEAR)
+      for (int i = 0; i < m; ++i) d.idx[Nj + i] = Nmax + i;
+    // Tinv = (Sf')^-1 by Gauss-Jordan in extended precision (Sf is triangular up to the column order, diagonal 2^(1-deg))
+    std::vector<long double> A((size_t)256), I((size_t)256, 0.0L);
+    for (int r = 0; r < 16; ++r)
+      for (int c = 0; c < 16; ++c) A[r * 16 + c] = Sf[c * 16 + r];
+    for (int q = 0; q < 16; ++q) I[q * 16 + q] = 1.0L;
+    for (int k = 0; k < 16; ++k) {
+      int piv = k;
+      for (int r = k + 1; r < 16; ++r)
+        if (fabsl(A[r * 16 + k]) > fabsl(A[piv * 16 + k])) piv = r;
+      if (A[piv * 16 + k] == 0.0L) return ctx->fail(KP_ERR_ARG, "kp_sweep_eval_nested: singular basis change");
+      for (int c = 0; c < 16; ++c) { std::swap(A[k * 16 + c], A[piv * 16 + c]); std::swap(I[k * 16 + c], I[piv * 16 + c]); }
+      const long double inv = 1.0L / A[k * 16 + k];
+      for (int c = 0; c < 16; ++c) { A[k * 16 + c] *= inv; I[k * 16 + c] *= inv; }
+      for (int r = 0; r < 16; ++r)
+        if (r != k && A[r * 16 + k] != 0.0L) {
+          const long double f = A[r * 16 + k];
+          for (int c = 0; c < 16; ++c) { A[r * 16 + c] -= f * A[k * 16 + c]; I[r * 16 + c] -= f * I[k * 16 + c]; }
+        }
+    }
+    for (int q = 0; q < 256; ++q) { d.Sf[q] = (double)Sf[q]; d.Tinv[q] = (double)I[q]; }
+    // column descriptors of psi_j for the rollout's lift
+    for (int r = 0; r < Nj; ++r) {
+      const int c = psi[r];
+      ColDesc cd{COL_CONST, 0, 0, 0};
+      if (c < nv) cd = ColDesc{COL_VAR, c, 0, 0};
+      else if (c + 1 < Nmax) cd = ColDesc{COL_MONO, c - nv, 0, 0};
+      cols_all[(size_t)dj * 16 + r] = cd;
+    }
+  }
+  // device buffers: Gc, Cc, Kc (degree D), per (degree, system) K_m, G_m, C_m, A, B (256 doubles each), errors, flags, tables
+  const size_t bW = (size_t)nb * Wmax * Wmax * 8, bAll = (size_t)n_deg * nb * 256 * 8;
+  const size_t b_tab = (size_t)n_deg * sizeof(SweepDeg), b_cols = cols_all.size() * sizeof(ColDesc);
+  char* ws = (char*)ctx->workspace(6, 3 * bW + 5 * bAll + (size_t)n_deg * nb * (n * 8 + 8) + (size_t)nb * 4 + b_tab + b_cols + 1024);
+  if (!ws) return ctx->fail(KP_ERR_HIP, "kp_sweep_eval_nested: out of device memory");
+  char* q = ws;
+  double* dKc = (double*)q; q += bW;
+  double* dGc = (double*)q; q += bW;
+  double* dCc = (double*)q; q += bW;
+  double* dK = (double*)q; q += bAll;
+  double* dG = (double*)q; q += bAll;
+  double* dC = (double*)q; q += bAll;
+  double* dA = (double*)q; q += bAll;
+  double* dB = (double*)q; q += bAll;
+  double* dE = (double*)q; q += (size_t)n_deg * nb * n * 8;
+  int* dS0 = (int*)q; q += (size_t)nb * 4;
+  int* dS = (int*)q; q += (size_t)n_deg * nb * 4;
+  int* dF = (int*)q; q += (size_t)n_deg * nb * 4;
+  q = (char*)(((uintptr_t)q + 63) & ~(uintptr_t)63);
+  SweepDeg* dT = (SweepDeg*)q; q += b_tab;
+  q = (char*)(((uintptr_t)q + 63) & ~(uintptr_t)63);
+  ColDesc* dCols = (ColDesc*)q;
+  hipStream_t s = ctx->stream;
+  KP_HIP(ctx, hipMemcpyAsync(dT, degs.data(), b_tab, hipMemcpyHostToDevice, s));
+  KP_HIP(ctx, hipMemcpyAsync(dCols, cols_all.data(), b_cols, hipMemcpyHostToDevice, s));
+  const int Ns = traj->ntrials * (traj->T - 1) - 1;
+  size_t lds = ((size_t)(2 * b.nvars + (b.m > 0 ? b.m : 1)) * SB_TS + 2 * SB_TS * SB_LD + 5 * 16 * SB_LD + 16) * sizeof(double);
+  const size_t pw_bytes = (size_t)2 * b.nvars * basis->pow_depth * SB_TS * sizeof(double);
+  if (lds + pw_bytes > 64 * 1024 || !basis->d_recipes) return ctx->fail(KP_ERR_ARG, "kp_sweep_eval_nested: dictionary too large for the power-table lift");
+  lds += pw_bytes;
+  KP_HIP(ctx, hipEventRecord(ctx->ev0, s));
+  hipLaunchKernelGGL(kp_small_fit_kernel, dim3(nb), dim3(256), lds, s, b, nullptr, nullptr, nullptr, (int64_t)0, Ns, dKc, dGc, dCc, dS0,
+                     (const uint32_t*)basis->d_recipes, basis->pow_depth, basis->max_factors > 0 ? basis->max_factors : 1, 0, traj_view(traj), 1);
+  KP_HIP(ctx, hipGetLastError());
+  KP_HIP(ctx, hipEventRecord(ctx->ev1, s));
+  const dim3 grid(nb, n_deg);
+  hipLaunchKernelGGL(kp_sweep_sub_kernel, grid, dim3(256), 0, s, dGc, dCc, Wmax, nb, dT, (const int*)nullptr, dK, dG, dC, dS);
+  KP_HIP(ctx, hipGetLastError());
+  if (lasso < 1e6) {
+    hipLaunchKernelGGL(kp_l1_flag_all_kernel, grid, dim3(64), 0, s, dK, dT, nb, lasso, dF);
+    KP_HIP(ctx, hipGetLastError());
+    std::vector<int> flags((size_t)n_deg * nb);
+    KP_HIP(ctx, hipMemcpyAsync(flags.data(), dF, flags.size() * 4, hipMemcpyDeviceToHost, s));
+    KP_HIP(ctx, hipStreamSynchronize(s));
+    for (size_t e = 0; e < flags.size(); ++e)
+      if (flags[e]) {                                 // L1 row active (never for the shipped / generated systems): lasso solve on (G_m, C_m)
+        const int W = degs[e / nb].W;
+        int rc = kp_lasso_dev(ctx, dG + e * 256, dC + e * 256, W, W, lasso * degs[e / nb].N, 20000, 1e-10, dK + e * 256, nullptr);
+        if (rc && rc != KP_ERR_NOT_CONVERGED) return rc;
+      }
+  }
+  if (b.model_type == KP_MODEL_LINEAR) {
+    hipLaunchKernelGGL(kp_sweep_project_kernel, grid, dim3(256), 0, s, dK, dG, dC, nb, m, dT, dA, dB);
+    KP_HIP(ctx, hipGetLastError());
+  }
+  hipLaunchKernelGGL(kp_sweep_rollout_nested_kernel, grid, dim3(64), 0, s, b, dT, dCols, nb, dK, b.model_type == KP_MODEL_LINEAR ? dA : nullptr,
+                     b.model_type == KP_MODEL_LINEAR ? dB : nullptr, traj->Yv, traj->Uv, traj->Tv, dS, dE);
+  KP_HIP(ctx, hipGetLastError());
+  KP_HIP(ctx, hipMemcpyAsync(err_out, dE, (size_t)n_deg * nb * n * 8, hipMemcpyDeviceToHost, s));
+  if (status_out) KP_HIP(ctx, hipMemcpyAsync(status_out, dS, (size_t)n_deg * nb * 4, hipMemcpyDeviceToHost, s));
+  KP_HIP(ctx, hipStreamSynchronize(s));
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+  ctx->timers[0] = ms;
+  return KP_OK;
+}
+
+// K (degree j, monomial basis) of one nested evaluation, for parity checks: call right after kp_sweep_eval_nested
+extern "C" int kp_sweep_nested_get_K(kp_ctx* ctx, int nb, int Wmax, int n_deg, int deg_index, int W, double* K_out) {
+  if (!ctx || !K_out || deg_index < 0 || deg_index >= n_deg || !ctx->ws[6]) return ctx ? ctx->fail(KP_ERR_ARG, "kp_sweep_nested_get_K: bad argument") : KP_ERR_ARG;
+  const size_t bW = (size_t)nb * Wmax * Wmax * 8;
+  const double* dK = (const double*)((char*)ctx->ws[6] + 3 * bW) + (size_t)deg_index * nb * 256;
+  std::vector<double> tmp((size_t)nb * 256);
+  KP_HIP(ctx, hipMemcpy(tmp.data(), dK, tmp.size() * 8, hipMemcpyDeviceToHost));
+  for (int q = 0; q < nb; ++q)
+    for (int e = 0; e < W * W; ++e) K_out[(size_t)q * W * W + e] = tmp[(size_t)q * 256 + e];
   return KP_OK;
 }

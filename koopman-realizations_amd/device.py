@@ -325,6 +325,23 @@ class Traj:
             return err, np.transpose(K, (0, 2, 1)), st
         return err, st
 
+    def sweep_eval_nested(self, basis: "Basis", n_deg, lasso=np.inf):
+        """kp_sweep_eval_nested: degrees 1..n_deg of the polynomial dictionary `basis` (the highest degree) from one pass
+        over the data.  Returns err (n_deg, nb, n), status (n_deg, nb)."""
+        err = np.zeros((n_deg, self.nb, self.n)); st = np.zeros((n_deg, self.nb), dtype=np.int32)
+        las = 1e6 if (lasso is None or not np.isfinite(lasso)) else float(lasso)
+        F.check(F.lib().kp_sweep_eval_nested(self.ctx.handle, self._h, basis.handle, las, int(n_deg), F.dptr(err), st.ctypes.data_as(F.c_ip)),
+                self.ctx.handle)
+        self._last_nested = (basis.W, int(n_deg))
+        return err, st
+
+    def nested_K(self, deg_index, W):
+        """K (monomial basis, W x W per system) of degree deg_index + 1 of the most recent sweep_eval_nested call."""
+        Wmax, n_deg = self._last_nested
+        K = np.zeros((self.nb, W, W))
+        F.check(F.lib().kp_sweep_nested_get_K(self.ctx.handle, self.nb, Wmax, n_deg, int(deg_index), int(W), F.dptr(K)), self.ctx.handle)
+        return np.transpose(K, (0, 2, 1))
+
     def close(self):
         if self._h:
             F.lib().kp_traj_destroy(self._h)

@@ -163,12 +163,14 @@ def _stack_raw(systems):
     return Y, U, k, Yv, Uv
 
 
-def rand_models_sweep_batched(systems, ctx, degrees=None):
+def rand_models_sweep_batched(systems, ctx, degrees=None, nested=True):
     """Config 5 on ONE GPU with the data resident on the device: the trajectories of the shard are uploaded once
     (`kp_traj_upload`, scaling computed there), then for every (model type, degree) ONE `kp_sweep_eval` call does snapshot
     pairs + fit + model extraction + validation rollout + normalised error for all systems and returns only the error
-    column.  Same table as `rand_models_sweep` (evaluate_rand_models.m:38-43).  Systems whose trials are not equally
-    shaped go through the host-prepared path (`_sweep_batched_host`)."""
+    column.  nested=True: per model type ONE `kp_sweep_eval_nested` call serves all degrees from a single pass over the
+    data (the degree-j dictionary is a column subset of the degree-D one).  Same table as `rand_models_sweep`
+    (evaluate_rand_models.m:38-43).  Systems whose trials are not equally shaped go through the host-prepared path
+    (`_sweep_batched_host`)."""
     from .device import Basis, Traj
     from .ksysid import poly_exponent_table
     degrees = degrees or MAX_DEGREE
@@ -181,12 +183,21 @@ def rand_models_sweep_batched(systems, ctx, degrees=None):
     out = {}
     try:
         for mt in ("linear", "bilinear", "nonlinear"):
+            nv = n + (m if mt == "nonlinear" else 0)
+            D = degrees[mt]
+            basis = Basis(ctx, mt, n, m, [("poly", poly_exponent_table(nv, D)[nv:])], None)
+            try:
+                if nested and basis.W <= 16:          # all degrees from one pass over the data (sub-blocks of the degree-D Grams)
+                    err, st = traj.sweep_eval_nested(basis, D, 4.0 if mt == "nonlinear" else np.inf)      # lasso 4: evaluate_rand_models.m:122
+                    out[mt] = err[:, :, 0]
+                    continue
+            finally:
+                basis.close()
             rows = []
-            for j in range(1, degrees[mt] + 1):
-                nv = n + (m if mt == "nonlinear" else 0)
+            for j in range(1, D + 1):
                 basis = Basis(ctx, mt, n, m, [("poly", poly_exponent_table(nv, j)[nv:])], None)
                 try:
-                    err, st = traj.sweep_eval(basis, 4.0 if mt == "nonlinear" else np.inf)      # lasso 4: evaluate_rand_models.m:122
+                    err, st = traj.sweep_eval(basis, 4.0 if mt == "nonlinear" else np.inf)
                     rows.append(err[:, 0])
                 finally:
                     basis.close()
