@@ -18,10 +18,13 @@
 typedef double double4_t __attribute__((ext_vector_type(4)));
 extern "C" int kp_synchronize(kp_ctx* ctx);
 
+// blockIdx.y = system of a batch: inputs gc_stride doubles apart (G and C of a fit are one [G | C] block), padded
+// outputs n*n / n*ncp apart
 __global__ void kp_pad_kernel(const double* __restrict__ G, const double* __restrict__ C, int W, int ncols, int n, int ncp,
-                              double* __restrict__ Gp, double* __restrict__ Cp) {
+                              double* __restrict__ Gp, double* __restrict__ Cp, size_t gc_stride) {
   int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   int64_t ng = (int64_t)n * n, nc = (int64_t)n * ncp;
+  G += blockIdx.y * gc_stride; C += blockIdx.y * gc_stride; Gp += blockIdx.y * (size_t)ng; Cp += blockIdx.y * (size_t)nc;
   if (e < ng) {
     int i = (int)(e % n), j = (int)(e / n);
     Gp[e] = (i < W && j < W) ? G[(size_t)j * W + i] : (i == j ? 1.0 : 0.0);
@@ -32,8 +35,11 @@ __global__ void kp_pad_kernel(const double* __restrict__ G, const double* __rest
   }
 }
 
-__global__ void kp_unpad_kernel(const double* __restrict__ Xp, int n, int W, int ncols, double* __restrict__ K) {
+// batch: system y writes K + ((k_first + y) % k_cap) * W * ncols (result ring); k_cap = 0: K itself
+__global__ void kp_unpad_kernel(const double* __restrict__ Xp, int n, int W, int ncols, double* __restrict__ K, int ncp, int k_first, int k_cap) {
   int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  Xp += blockIdx.y * (size_t)n * ncp;
+  if (k_cap > 0) K += (size_t)((k_first + (int)blockIdx.y) % k_cap) * W * ncols;
   if (e < (int64_t)W * ncols) {
     int i = (int)(e % W), j = (int)(e / W);
     K[e] = Xp[(size_t)j * n + i];
@@ -148,6 +154,7 @@ __device__ __forceinline__ void chol_tile_update(double* __restrict__ A22, int n
 // block pair per workgroup, and the inverses of the diagonal blocks (one wave each), Dinv[kb][col][row].
 __global__ __launch_bounds__(256) void kp_chol_finish_kernel(double* __restrict__ A, int n, int npair, double* __restrict__ Dinv) {
   __shared__ double T[16][17];
+  A += blockIdx.y * (size_t)n * n; Dinv += blockIdx.y * (size_t)(n / 16) * 256;
   const int p = blockIdx.x, t = threadIdx.x;
   if (p >= npair) {                                  // inverse of diagonal block kb: lane j builds column j
     if (t >= 64) return;
@@ -192,6 +199,7 @@ __global__ __launch_bounds__(CH_NT) void kp_chol_kernel(double* __restrict__ A, 
   double* Pin = sm;                     // A21 as [q][row], leading dimension n
   double* Lt = sm + (size_t)16 * n;     // L21 as [q][row]
   const int tid = threadIdx.x, wave = tid >> 6;
+  A += blockIdx.y * (size_t)n * n; Dinv += blockIdx.y * (size_t)(n / 16) * 256; info += blockIdx.y;   // system of a batch
   __shared__ double odiag[512];         // pivot thresholds: n * 8 eps * original diagonal (0 for the identity padding)
   if (tid == 0) bad = 0;
   for (int i = tid; i < n; i += CH_NT) odiag[i] = fmax(A[(size_t)i * n + i], 0.0) * ((double)n * 8.0 * 2.220446049250313e-16);
@@ -295,6 +303,7 @@ __global__ __launch_bounds__(256) void kp_trsm_kernel(const double* __restrict__
   const int cb = blockIdx.x;
   const int nt = n / 16;
   const int lr = lane >> 4, lc = lane & 15;
+  LU += blockIdx.y * (size_t)n * n; Dinv += blockIdx.y * (size_t)nt * 256; X += blockIdx.y * (size_t)n * gridDim.x * 16;   // system of a batch
   double* Xb = X + (size_t)cb * 16 * n;
   for (int e = tid; e < n * 16; e += 256) {
     int row = e % n, col = e / n;
@@ -367,23 +376,24 @@ __global__ __launch_bounds__(256) void kp_trsm_kernel(const double* __restrict__
   }
 }
 
-// G_dev, C_dev: W x W / W x ncols column-major on the device (not modified); K_dev: W x ncols.
-int kp_chol_solve_dev(kp_ctx* ctx, double* G_dev, double* C_dev, int W, int ncols, double* K_dev, hipStream_t st, hipEvent_t pad_done,
-                      int* sticky) {
+// nb systems [G | C] gc_stride doubles apart (W x W each; ncols = W when nb > 1); system y's K goes to
+// K_dev + ((k_first + y) % k_cap) W ncols (k_cap = 0: K_dev).  One launch sequence for the whole batch.
+int kp_chol_solve_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, int W, int ncols, int nb, size_t gc_stride, double* K_dev,
+                            int k_first, int k_cap, hipStream_t st, hipEvent_t pad_done, int* sticky) {
   if (!st) st = ctx->stream;
   const int n = (W + 15) / 16 * 16, ncp = (ncols + 15) / 16 * 16;
   size_t bG = (size_t)n * n * 8, bC = (size_t)n * ncp * 8, bD = (size_t)(n / 16) * 256 * 8;
-  char* ws = (char*)ctx->workspace(5, bG + bC + bD + 64);
+  char* ws = (char*)ctx->workspace(5, (size_t)nb * (bG + bC + bD) + (size_t)nb * 4 + 64);
   if (!ws) return ctx->fail(KP_ERR_HIP, "kp_fit_solve: out of device memory");
   double* Gp = (double*)ws;
-  double* Cp = (double*)(ws + bG);
-  double* Dinv = (double*)(ws + bG + bC);
-  int* info = (int*)(ws + bG + bC + bD);
+  double* Cp = (double*)(ws + (size_t)nb * bG);
+  double* Dinv = (double*)(ws + (size_t)nb * (bG + bC));
+  int* info = (int*)(ws + (size_t)nb * (bG + bC + bD));
   size_t lds_chol = (size_t)2 * 16 * n * 8;
   size_t lds_trsm = ((size_t)n * 16 + 1024) * 8;
   if (lds_chol > 160 * 1024 - 8192 || lds_trsm > 160 * 1024 || n > 16 * 4 * TR_MAXJ) return ctx->fail(KP_ERR_ARG, "kp_fit_solve: W too large (max 512)");
   int64_t tot = (int64_t)n * n + (int64_t)n * ncp;
-  hipLaunchKernelGGL(kp_pad_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, G_dev, C_dev, W, ncols, n, ncp, Gp, Cp);
+  hipLaunchKernelGGL(kp_pad_kernel, dim3((unsigned)((tot + 255) / 256), nb), dim3(256), 0, st, G_dev, C_dev, W, ncols, n, ncp, Gp, Cp, gc_stride);
   KP_HIP(ctx, hipGetLastError());
   if (pad_done) KP_HIP(ctx, hipEventRecord(pad_done, st));
   static size_t chol_lds_set = 0, trsm_lds_set = 0;
@@ -392,22 +402,29 @@ int kp_chol_solve_dev(kp_ctx* ctx, double* G_dev, double* C_dev, int W, int ncol
     chol_lds_set = lds_chol;
   }
   static const int chol_prof = getenv("KP_CHOL_PROF") ? 1 : 0;
-  hipLaunchKernelGGL(kp_chol_kernel, dim3(1), dim3(CH_NT), lds_chol, st, Gp, n, Dinv, info, sticky, chol_prof);
+  hipLaunchKernelGGL(kp_chol_kernel, dim3(1, nb), dim3(CH_NT), lds_chol, st, Gp, n, Dinv, info, sticky, chol_prof);
   KP_HIP(ctx, hipGetLastError());
   {
-    const int nb = n / 16, npair = nb * (nb - 1) / 2;
-    hipLaunchKernelGGL(kp_chol_finish_kernel, dim3(npair + nb), dim3(256), 0, st, Gp, n, npair, Dinv);
+    const int nbk = n / 16, npair = nbk * (nbk - 1) / 2;
+    hipLaunchKernelGGL(kp_chol_finish_kernel, dim3(npair + nbk, nb), dim3(256), 0, st, Gp, n, npair, Dinv);
   }
   KP_HIP(ctx, hipGetLastError());
   if (lds_trsm > trsm_lds_set) {
     KP_HIP(ctx, hipFuncSetAttribute((const void*)kp_trsm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_trsm));
     trsm_lds_set = lds_trsm;
   }
-  hipLaunchKernelGGL(kp_trsm_kernel, dim3(ncp / 16), dim3(256), lds_trsm, st, Gp, Dinv, n, Cp);
+  hipLaunchKernelGGL(kp_trsm_kernel, dim3(ncp / 16, nb), dim3(256), lds_trsm, st, Gp, Dinv, n, Cp);
   KP_HIP(ctx, hipGetLastError());
-  hipLaunchKernelGGL(kp_unpad_kernel, dim3((unsigned)(((int64_t)W * ncols + 255) / 256)), dim3(256), 0, st, Cp, n, W, ncols, K_dev);
+  hipLaunchKernelGGL(kp_unpad_kernel, dim3((unsigned)(((int64_t)W * ncols + 255) / 256), nb), dim3(256), 0, st, Cp, n, W, ncols, K_dev, ncp, k_first,
+                     k_cap);
   KP_HIP(ctx, hipGetLastError());
   return KP_OK;
+}
+
+// G_dev, C_dev: W x W / W x ncols column-major on the device (not modified); K_dev: W x ncols.
+int kp_chol_solve_dev(kp_ctx* ctx, double* G_dev, double* C_dev, int W, int ncols, double* K_dev, hipStream_t st, hipEvent_t pad_done,
+                      int* sticky) {
+  return kp_chol_solve_batch_dev(ctx, G_dev, C_dev, W, ncols, 1, 0, K_dev, 0, 0, st, pad_done, sticky);
 }
 
 static int check_info(kp_ctx* ctx) {
@@ -446,10 +463,11 @@ static void collect_gram_timers(kp_ctx* ctx, bool solved) {
   }
   if (hipEventElapsedTime(&ms, ctx->evp[ctx->reduce_timed_from], ctx->evp[2]) == hipSuccess) ctx->timers[6] = ms;
   if (solved && hipEventElapsedTime(&ms, ctx->evp[2], ctx->evp[3]) == hipSuccess) ctx->timers[1] = ms;
+  (void)hipGetLastError();   // an event pair that was not recorded in this mode leaves a sticky error behind: not a failure
 }
 
-static int ensure_gc(kp_ctx* ctx, int W) {
-  size_t need = (size_t)4 * W * W * 8;      // two [G | C] buffers: asynchronous fits alternate between them
+static int ensure_gc(kp_ctx* ctx, int W, int slots = 2) {
+  size_t need = (size_t)std::max(2, slots) * 2 * W * W * 8;   // [G | C] buffers: asynchronous fits alternate between two / queue in a ring
   if (ctx->GC_bytes < need) {
     if (ctx->GC) (void)hipFree(ctx->GC);
     ctx->GC = nullptr;
@@ -540,6 +558,25 @@ extern "C" int kp_fit_last_rank(const kp_ctx* ctx, int* rank) {
   return KP_OK;
 }
 
+// Asynchronous pipeline, deferred solves (default): the queued Gram pairs are factored and solved by one batched launch
+// sequence on the Gram stream (Cholesky: one workgroup per fit, all at once; TRSM: W/16 workgroups per fit).
+static int solve_batch_size() {
+  static const int v = [] { const char* e = getenv("KP_SOLVE_BATCH"); return e ? std::max(0, atoi(e)) : 64; }();
+  return v;
+}
+
+static int flush_solves(kp_ctx* ctx) {
+  if (ctx->pend_solves == 0) return KP_OK;
+  const int W = ctx->pend_W;
+  KP_HIP(ctx, hipEventRecord(ctx->ev_solve0, ctx->stream));
+  int rc = kp_chol_solve_batch_dev(ctx, ctx->GC, ctx->GC + (size_t)W * W, W, W, ctx->pend_solves, (size_t)2 * W * W, ctx->Kres, ctx->pend_first,
+                                   ctx->kring_cap, ctx->stream, nullptr, ctx->sticky_info);
+  ctx->pend_solves = 0;
+  if (rc) return rc;
+  KP_HIP(ctx, hipEventRecord(ctx->ev_solve1, ctx->stream));
+  return KP_OK;
+}
+
 extern "C" int kp_fit(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* snaps, const double* lasso, int n_lasso,
                       double* K_out) {
   if (!ctx || !basis || !snaps || n_lasso < 1) return ctx ? ctx->fail(KP_ERR_ARG, "kp_fit: bad argument") : KP_ERR_ARG;
@@ -572,6 +609,25 @@ extern "C" int kp_fit(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* sn
     ctx->pend_basis = (const void*)basis;
     ctx->pend_Ns = snaps->Ns;
     ctx->pend_W = W;
+    const int sbatch = std::min(solve_batch_size(), ctx->kring_cap);
+    if (sbatch >= 1) {
+      // deferred solves: this fit's [G | C] goes into the next slot of the ring; nothing else runs beside the Gram kernel
+      rc = ensure_gc(ctx, W, sbatch);
+      if (rc) return rc;
+      if (ctx->pend_solves == 0) ctx->pend_first = ctx->async_count;
+      double* GCs = ctx->GC + (size_t)ctx->pend_solves * 2 * W * W;
+      ctx->reserve_cus = 0;
+      ctx->reduce_stream = nullptr;
+      ctx->ring_timing = true;
+      rc = kp_gram_dispatch(ctx, basis, snaps, GCs);
+      ctx->ring_timing = false;
+      if (rc) return rc;
+      ++ctx->pend_solves;
+      ++ctx->async_count;
+      ctx->async_pending = true;
+      if (ctx->pend_solves >= sbatch) return flush_solves(ctx);
+      return KP_OK;
+    }
     double* Kslot = ctx->Kres + (size_t)(ctx->async_count % ctx->kring_cap) * W * W;
     const int flip = ctx->gc_flip;
     ctx->gc_flip ^= 1;
@@ -686,6 +742,10 @@ extern "C" int kp_fit(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* sn
 extern "C" int kp_synchronize(kp_ctx* ctx) {
   if (!ctx) return KP_ERR_ARG;
   KP_HIP(ctx, hipSetDevice(ctx->device));
+  {
+    int rcf = flush_solves(ctx);
+    if (rcf) return rcf;
+  }
   KP_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (ctx->stream2) KP_HIP(ctx, hipStreamSynchronize(ctx->stream2));
   int bad = 0;

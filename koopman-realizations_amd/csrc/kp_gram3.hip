@@ -602,15 +602,19 @@ int kp_gram3_launch(kp_ctx* ctx, const kp_basis* basis_c, const kp_snapshots* s,
   const int grid = plan.nsuper * nsplit;
   // every event record is a barrier packet the command processor works through between two Gram kernels: the
   // pipelined path keeps two (kernel start / end; the end also releases the reduction on the solve stream)
-  if (!ctx->reduce_stream) KP_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  const bool pipelined = ctx->reduce_stream || ctx->ring_timing;
+  if (!pipelined) KP_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   hipEvent_t ev_start = ctx->evp[0], ev_end = ctx->evp[1];
-  if (ctx->reduce_stream) {                       // pipelined fits: a ring of event pairs, averaged at kp_synchronize
+  // deferred-solve pipeline: every event record is a barrier packet between two Gram kernels, so only every 4th launch
+  // is timed (the mean over the ring is what kp_synchronize reports)
+  const bool timed = !ctx->ring_timing || (ctx->ring_skip++ & 3) == 0;
+  if (pipelined && timed) {                       // pipelined fits: a ring of event pairs, averaged at kp_synchronize
     ev_start = ctx->ring[2 * ctx->ring_pos];
     ev_end = ctx->ring[2 * ctx->ring_pos + 1];
     ctx->ring_pos = (ctx->ring_pos + 1) % 64;
     if (ctx->ring_n < 64) ++ctx->ring_n;
   }
-  KP_HIP(ctx, hipEventRecord(ev_start, ctx->stream));
+  if (timed) KP_HIP(ctx, hipEventRecord(ev_start, ctx->stream));
   hipError_t e;
   switch (plan.nq) {
     case 1: e = launch3<1>(a, BM, grid, lds, ctx->stream); break;
@@ -621,7 +625,7 @@ int kp_gram3_launch(kp_ctx* ctx, const kp_basis* basis_c, const kp_snapshots* s,
     default: e = launch3<6>(a, BM, grid, lds, ctx->stream); break;
   }
   KP_HIP(ctx, e);
-  KP_HIP(ctx, hipEventRecord(ev_end, ctx->stream));
+  if (timed) KP_HIP(ctx, hipEventRecord(ev_end, ctx->stream));
   hipStream_t rs = ctx->stream;
   if (ctx->reduce_stream) {                       // reduction (and everything after it) belongs to the solve stream
     rs = ctx->reduce_stream;
@@ -633,8 +637,8 @@ int kp_gram3_launch(kp_ctx* ctx, const kp_basis* basis_c, const kp_snapshots* s,
   hipLaunchKernelGGL(kp_gram3_reduce_kernel, dim3(plan.njobs * plan.nq * NWT), dim3(256), 0, rs, part, nsplit, plan.njobs,
                      plan.nq, NWT, BM, plan.desc, plan.G4, N, W, GC_dev, GC_dev + (size_t)W * W);
   KP_HIP(ctx, hipGetLastError());
-  if (!ctx->reduce_stream) KP_HIP(ctx, hipEventRecord(ctx->ev1, rs));
-  KP_HIP(ctx, hipEventRecord(ctx->evp[2], rs));
+  if (!pipelined) KP_HIP(ctx, hipEventRecord(ctx->ev1, rs));
+  if (!ctx->ring_timing) KP_HIP(ctx, hipEventRecord(ctx->evp[2], rs));
   ctx->gram_flops_per_pair = (double)W * (W + 1) + 2.0 * W * W;
   return KP_OK;
 }

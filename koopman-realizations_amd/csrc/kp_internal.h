@@ -31,6 +31,11 @@ struct kp_ctx {
   const void* pend_basis = nullptr;   // dictionary / snapshot count / width of the fits in flight: a change drains the pipeline
   int64_t pend_Ns = 0;
   int pend_W = 0;
+  // deferred solves of the asynchronous pipeline: the Gram pairs of up to solve_batch fits wait in the [G | C] ring and are
+  // factored / solved by ONE batched launch sequence (no CUs held back for a concurrent solve stream)
+  int pend_solves = 0, pend_first = 0;
+  bool ring_timing = false;           // Gram launchers time themselves with the event ring and record nothing else
+  unsigned ring_skip = 0;
   kp_comm_state* comm = nullptr;      // set by kp_comm_create: rank / world / RCCL communicator
   bool reduce_grams = false;          // kp_fit_sharded: all-reduce [G | C] over the ranks between the Gram kernel and the solve
   // set by the asynchronous kp_fit around kp_gram_dispatch: the split-partial reduction runs on this stream
@@ -235,6 +240,8 @@ int kp_comm_allreduce_dev(kp_ctx* ctx, double* buf_dev, size_t count, hipStream_
 int kp_lift_dev(kp_ctx* ctx, const kp_basis* basis, int what, const double* dz, const double* du, int64_t rows, double* dout);
 int kp_chol_solve_dev(kp_ctx* ctx, double* G_dev, double* C_dev, int W, int ncols, double* K_dev, hipStream_t st = nullptr,
                       hipEvent_t pad_done = nullptr, int* sticky = nullptr);
+int kp_chol_solve_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, int W, int ncols, int nb, size_t gc_stride, double* K_dev,
+                            int k_first, int k_cap, hipStream_t st, hipEvent_t pad_done, int* sticky);
 // least-squares solution, PSD guard and Lipschitz constant shared by all lasso values of one fit (kp_lasso.hip)
 struct kp_lasso_prep {
   bool ready = false;

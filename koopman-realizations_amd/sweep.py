@@ -144,11 +144,19 @@ def _stack_raw(systems):
         k = len(tr[0])
         if any(len(t) != k for t in tr):
             return None
-        def stacked(key, src):
-            a = np.asarray([[x[key] for x in t] for t in src], dtype=np.float64)   # ValueError when ragged
-            if a.ndim == 3:
-                a = a[..., None]
-            return a.reshape(a.shape[0], a.shape[1] * a.shape[2], -1)
+        def stacked(key, src):                                             # one preallocated block, filled trial by trial
+            first = np.asarray(src[0][0][key], dtype=np.float64)
+            Tn = first.shape[0]
+            first = first.reshape(Tn, -1)
+            kk = len(src[0])
+            out = np.empty((len(src), kk * Tn, first.shape[1]))
+            for i, t in enumerate(src):
+                for j, x in enumerate(t):
+                    a = np.asarray(x[key], dtype=np.float64)
+                    if a.shape[0] != Tn or a.size != Tn * first.shape[1]:
+                        raise ValueError("ragged trials")
+                    out[i, j * Tn:(j + 1) * Tn] = a.reshape(Tn, -1)
+            return out
         Y, U = stacked("y", tr), stacked("u", tr)
         Tm = stacked("t", tr)[:, :, 0]
         va = [[d["val"][0]] for d in systems]
