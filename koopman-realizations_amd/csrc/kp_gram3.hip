@@ -80,8 +80,13 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int super = blockIdx.x % a.nsuper;
-  const int split = blockIdx.x / a.nsuper;
+  // XCD-aware order: workgroups b and b + 8 share an XCD (round-robin dispatch) and its L2, so consecutive LOGICAL ids -
+  // the nsuper workgroups of one snapshot split, which read the same raw tiles - are dealt to one XCD: the tile is
+  // fetched from HBM once per split instead of once per workgroup (a speed matter only; any mapping is correct)
+  const int per_xcd = gridDim.x / 8;
+  const int logical = (int)blockIdx.x < per_xcd * 8 ? ((int)blockIdx.x % 8) * per_xcd + (int)blockIdx.x / 8 : (int)blockIdx.x;
+  const int super = logical % a.nsuper;
+  const int split = logical / a.nsuper;
   const int job = super * 4 + wave;
   const int nzm = b.nzeta + b.m;
   const int nrawrows = 2 * nzm;
