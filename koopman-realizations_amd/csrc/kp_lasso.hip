@@ -310,6 +310,158 @@ __global__ __launch_bounds__(256) void kp_lasso_final_kernel(const double* __res
 }
 
 // ------------------------------------------------------------------------------------------------
+// One FISTA iteration's projection step as ONE launch: V, the threshold search, the soft threshold and the momentum
+// scalars (kp_lasso_v / newton x P / final above are the multi-launch form, kept as the fallback).  A value is handled
+// by wpv workgroups of 1024 threads (its slice of V is re-read from L2 every pass); they exchange their partial sums
+// through per-workgroup slots in global memory: payload written with agent-scope (sc1, write-through) stores, the storing
+// lane's s_waitcnt vmcnt(0), then the sequence number as the flag; readers poll the flags with agent-scope loads and read
+// the payload with agent-scope loads (MI355X_MICROARCH.md, "Valid forms").  Every workgroup sums the slots in the same
+// order, so all of them take the same branch at every pass.  All wpv x nba workgroups must be resident at once (the
+// host sizes wpv for one workgroup per CU); every spin is bounded and a time-out is reported, never a hang.
+// ------------------------------------------------------------------------------------------------
+#define LP_NT 1024
+#define LP_MAXW 32
+#define LP_MAXPASS 40
+struct LassoXchg {                   // per value
+  double slot[2][LP_MAXW][4];        // [parity][workgroup][3 values + pad]
+  unsigned flag[LP_MAXW];            // sequence number of the workgroup's latest publication
+  unsigned timeout;
+};
+
+// sums (op 0) or maxima (op 1) of three values over the wpv workgroups of this value; result valid in every thread
+__device__ __forceinline__ bool lp_exchange(double& a, double& b, double& c, int op_b_c_max, LassoXchg* xc, int w, int wpv, unsigned seq,
+                                            double (*red)[3], double* res) {
+  const int tid = threadIdx.x, wv = tid >> 6;
+  // workgroup-level reduction first
+  if (op_b_c_max) { a = wave_sum(a); b = wave_max(b); c = wave_max(c); }
+  else { a = wave_sum(a); b = wave_sum(b); c = wave_sum(c); }
+  if ((tid & 63) == 0) { red[wv][0] = a; red[wv][1] = b; red[wv][2] = c; }
+  __syncthreads();
+  if (tid == 0) {
+    double sa = 0.0, sb = op_b_c_max ? 0.0 : 0.0, sc = 0.0;
+    for (int q = 0; q < LP_NT / 64; ++q) {
+      sa += red[q][0];
+      if (op_b_c_max) { sb = fmax(sb, red[q][1]); sc = fmax(sc, red[q][2]); }
+      else { sb += red[q][1]; sc += red[q][2]; }
+    }
+    double* sl = xc->slot[seq & 1][w];
+    __hip_atomic_store(&sl[0], sa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&sl[1], sb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&sl[2], sc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(&xc->flag[w], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // one poller per peer workgroup
+  __shared__ int ok_sh;
+  if (tid == 0) ok_sh = 1;
+  __syncthreads();
+  if (tid < wpv) {
+    int spins = 0;
+    bool ok = true;
+    while ((int)(__hip_atomic_load(&xc->flag[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq) < 0) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > (1 << 22)) { ok = false; break; }
+    }
+    const double* sl = xc->slot[seq & 1][tid];
+    red[tid][0] = __hip_atomic_load(&sl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    red[tid][1] = __hip_atomic_load(&sl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    red[tid][2] = __hip_atomic_load(&sl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!ok) { ok_sh = 0; atomicAdd(&xc->timeout, 1u); }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double sa = 0.0, sb = 0.0, sc = 0.0;
+    for (int q = 0; q < wpv; ++q) {                  // fixed order: identical in every workgroup
+      sa += red[q][0];
+      if (op_b_c_max) { sb = fmax(sb, red[q][1]); sc = fmax(sc, red[q][2]); }
+      else { sb += red[q][1]; sc += red[q][2]; }
+    }
+    res[0] = sa; res[1] = sb; res[2] = sc;
+  }
+  __syncthreads();
+  a = res[0]; b = res[1]; c = res[2];
+  const bool ok = ok_sh != 0;
+  __syncthreads();
+  return ok;
+}
+
+__global__ __launch_bounds__(LP_NT) void kp_lasso_project_kernel(const double* __restrict__ Kc, const double* __restrict__ Ko,
+                                                                 const double* __restrict__ GKc, const double* __restrict__ GKo,
+                                                                 const double* __restrict__ C, int64_t n, double* __restrict__ V,
+                                                                 double* __restrict__ Kn, LassoState* __restrict__ stv,
+                                                                 LassoXchg* __restrict__ xcv, unsigned seq0) {
+  __shared__ double red[LP_MAXW > LP_NT / 64 ? LP_MAXW : LP_NT / 64][3];
+  __shared__ double res[3];
+  const int w = blockIdx.x, wpv = gridDim.x, val = blockIdx.y, tid = threadIdx.x;
+  LassoState* st = stv + val;
+  LassoXchg* xc = xcv + val;
+  const int64_t o = (int64_t)val * n;
+  Kc += o; Ko += o; GKc += o; GKo += o; V += o; Kn += o;
+  const int64_t chunk = (n + wpv - 1) / wpv, i0 = (int64_t)w * chunk, i1 = min(n, i0 + chunk);
+  const double mom = st->mom, invL = st->invL, tball = st->t;
+  double theta = st->theta;
+  unsigned seq = seq0;
+  // V = Y - (G Y - C) / L and the first Newton step from the previous threshold
+  double tot = 0.0, ss = 0.0, cc = 0.0;
+  for (int64_t i = i0 + tid; i < i1; i += LP_NT) {
+    const double k = Kc[i], g = GKc[i];
+    const double y = k + mom * (k - Ko[i]);
+    const double gy = g + mom * (g - GKo[i]);
+    const double v = y - (gy - C[i]) * invL;
+    V[i] = v;
+    const double a = fabs(v);
+    tot += a;
+    if (a > theta) { ss += a; cc += 1.0; }
+  }
+  bool ok = lp_exchange(tot, ss, cc, 0, xc, w, wpv, ++seq, red, res);
+  bool done = false;
+  int passes = 1;
+  if (tot <= tball) { theta = 0.0; done = true; }
+  else theta = cc > 0.0 ? fmax((ss - tball) / cc, 0.0) : (tot - tball) / (double)n;
+  // Michelot passes: monotone from the first step on, stop exactly at the fixed point
+  while (!done && ok && passes < LP_MAXPASS) {
+    ss = 0.0; cc = 0.0;
+    double z = 0.0;
+    for (int64_t i = i0 + tid; i < i1; i += LP_NT) {
+      const double a = fabs(V[i]);
+      if (a > theta) { ss += a; cc += 1.0; }
+    }
+    ok = lp_exchange(ss, cc, z, 0, xc, w, wpv, ++seq, red, res);
+    const double nt = cc > 0.0 ? (ss - tball) / cc : theta;
+    if (nt > theta) theta = nt; else done = true;
+    ++passes;
+  }
+  // Kn = soft(V, theta); restart test <Y - Kn, Kn - K> > 0; statistics
+  double dot = 0.0, chg = 0.0, kmx = 0.0;
+  for (int64_t i = i0 + tid; i < i1; i += LP_NT) {
+    const double v = V[i], k = Kc[i];
+    const double a = fabs(v) - theta;
+    const double kn = a > 0.0 ? copysign(a, v) : 0.0;
+    const double y = k + mom * (k - Ko[i]);
+    Kn[i] = kn;
+    dot += (y - kn) * (kn - k);
+    chg = fmax(chg, fabs(kn - k));
+    kmx = fmax(kmx, fabs(kn));
+  }
+  ok = lp_exchange(dot, chg, kmx, 1, xc, w, wpv, ++seq, red, res) && ok;
+  if (w == 0 && tid == 0) {
+    const double tk = st->tk;
+    const bool restart = dot > 0.0;
+    const double tn = restart ? 1.0 : 0.5 * (1.0 + sqrt(1.0 + 4.0 * tk * tk));
+    st->mom = restart ? 0.0 : (tk - 1.0) / tn;
+    st->tk = tn;
+    st->theta = theta;
+    st->tot = tot;
+    st->change = chg;
+    st->kmax = kmx;
+    st->restarts += restart ? 1 : 0;
+    if (!done || !ok) st->notconv += 1;
+    st->maxpasses = max(st->maxpasses, passes);
+    st->passes = passes;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Active-set polish.  FISTA identifies the support and the signs of the optimum long before it has converged; on a
 // fixed support S_j / sign pattern s_j per column the KKT system of the QP (Ksysid.m:1126-1137: stationarity
 // G k_j - c_j + theta s_j = 0 on S_j, one multiplier theta >= 0 for the L1 row, sum |k| = t) is LINEAR:
@@ -547,8 +699,8 @@ int kp_lasso_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, in
   if (nb == 0) return KP_OK;
   // buffers, nb matrices each: K x3 (old, current, new), GK x2, V, polish A / B / G Kh; per-column sums; states
   const size_t bB = (size_t)nb * bK;
-  const size_t b_pab = (size_t)nb * ncols * 2 * 8, b_st = (size_t)nb * sizeof(LassoState);
-  char* ws = (char*)ctx->workspace(7, 9 * bB + b_pab + b_st + (size_t)nb * 4 + 512);
+  const size_t b_pab = (size_t)nb * ncols * 2 * 8, b_st = (size_t)nb * sizeof(LassoState), b_xc = (size_t)nb * sizeof(LassoXchg);
+  char* ws = (char*)ctx->workspace(7, 9 * bB + b_pab + b_st + b_xc + (size_t)nb * 4 + 1024);
   if (!ws) return ctx->fail(KP_ERR_HIP, "kp_fit_lasso: out of device memory");
   double* Kb[3] = {(double*)ws, (double*)(ws + bB), (double*)(ws + 2 * bB)};
   double* GKb[2] = {(double*)(ws + 3 * bB), (double*)(ws + 4 * bB)};
@@ -558,6 +710,13 @@ int kp_lasso_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, in
   double* GKh = (double*)(ws + 8 * bB);
   double* pab = (double*)(ws + 9 * bB);
   LassoState* st = (LassoState*)(ws + 9 * bB + b_pab);
+  LassoXchg* xchg = (LassoXchg*)(ws + 9 * bB + b_pab + ((b_st + 255) & ~(size_t)255));
+  KP_HIP(ctx, hipMemsetAsync(xchg, 0, b_xc, s));
+  // one launch per projection (kp_lasso_project_kernel) unless disabled; the multi-launch kernels are the fallback after
+  // a reported time-out of its cross-workgroup exchange
+  static const bool fused_env = getenv("KP_LASSO_NO_FUSED") == nullptr;
+  bool fused = fused_env;
+  unsigned seq = 0;
   KP_HIP(ctx, hipMemsetAsync(ws, 0, 5 * bB, s));                  // FISTA from K = 0
   const size_t head = offsetof(LassoState, part);
   std::vector<char> hbuf(b_st, 0);
@@ -580,10 +739,19 @@ int kp_lasso_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, in
   for (int v = 0; v < nb; ++v) slot_val[v] = act[v];
   while (it < max_iter && nba > 0) {
     const dim3 grid(nblk, nba);
+    // workgroups per value of the fused projection: all of them resident at once, one per CU
+    const int ncu = ctx->num_cu > 0 ? ctx->num_cu : 256;
+    const int wpv = std::max(1, std::min(LP_MAXW, ncu / nba));
     for (int c = 0; c < check_every && it < max_iter; ++c, ++it) {
-      hipLaunchKernelGGL(kp_lasso_v_kernel, grid, dim3(256), 0, s, Kb[kc], Kb[ko], GKb[gc], GKb[go], C_dev, n, V, st);
-      for (int p = 0; p < P; ++p) hipLaunchKernelGGL(kp_lasso_newton_kernel, grid, dim3(256), 0, s, V, n, st);
-      hipLaunchKernelGGL(kp_lasso_final_kernel, grid, dim3(256), 0, s, V, Kb[kc], Kb[ko], n, Kb[kn], st);
+      if (fused && nba <= ncu) {
+        hipLaunchKernelGGL(kp_lasso_project_kernel, dim3(wpv, nba), dim3(LP_NT), 0, s, Kb[kc], Kb[ko], GKb[gc], GKb[go], C_dev, n, V, Kb[kn], st, xchg,
+                           seq);
+        seq += LP_MAXPASS + 4;
+      } else {
+        hipLaunchKernelGGL(kp_lasso_v_kernel, grid, dim3(256), 0, s, Kb[kc], Kb[ko], GKb[gc], GKb[go], C_dev, n, V, st);
+        for (int p = 0; p < P; ++p) hipLaunchKernelGGL(kp_lasso_newton_kernel, grid, dim3(256), 0, s, V, n, st);
+        hipLaunchKernelGGL(kp_lasso_final_kernel, grid, dim3(256), 0, s, V, Kb[kc], Kb[ko], n, Kb[kn], st);
+      }
       // rotate: old <- current, current <- new; then the product of the new current (all values: one wide product)
       const int tmp = ko; ko = kc; kc = kn; kn = tmp;
       std::swap(go, gc);
@@ -597,7 +765,16 @@ int kp_lasso_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, in
     }
     KP_HIP(ctx, hipGetLastError());
     KP_HIP(ctx, hipMemcpy2DAsync(hbuf.data(), sizeof(LassoState), st, sizeof(LassoState), head, nba, hipMemcpyDeviceToHost, s));
+    std::vector<unsigned> touts(nba, 0u);
+    if (fused)
+      KP_HIP(ctx, hipMemcpy2DAsync(touts.data(), sizeof(unsigned), &xchg[0].timeout, sizeof(LassoXchg), sizeof(unsigned), nba, hipMemcpyDeviceToHost, s));
     KP_HIP(ctx, hipStreamSynchronize(s));
+    for (unsigned tq : touts)
+      if (tq) {                                      // an exchange of the one-launch projection timed out (workgroups not co-resident):
+        fused = false;                               // continue with the multi-launch kernels, which need no residency
+        KP_HIP(ctx, hipMemsetAsync(xchg, 0, b_xc, s));
+        break;
+      }
     bool all_exact = true;
     int maxp = 0;
     for (int v = nba - 1; v >= 0; --v) {             // downwards: the slot moved into a hole has been examined already
