@@ -4,11 +4,15 @@
 // here: accelerated projected gradient (FISTA with gradient restart), projection onto the L1 ball by
 // Newton's method on the piecewise-linear threshold equation (Michelot's fixed point, warm-started with
 // the previous iteration's threshold).  Everything runs as multi-workgroup kernels:
-//   * G K by an MFMA kernel (v_mfma_f64_4x4x4_4b_f64; G symmetric, so G K = G'K is a Gram-type product)
+//   * all lasso values of a fit form one batch: G [K_1 ... K_nv] is a single wide MFMA product (v_mfma_f64_4x4x4_4b_f64;
+//     G symmetric, so G K = G'K is a Gram-type product); values that are finished leave the batch (compaction)
 //   * the momentum is applied algebraically: Y = K + mom (K - Kold) and G Y = GK + mom (GK - GKold), so one
 //     product per iteration suffices and the restart decision of iteration i is a scalar read by iteration i+1
-//   * every global reduction finishes in the last workgroup to arrive (ticket counter), which also updates
-//     the scalar state - no host round trips except the convergence check every 20 iterations
+//   * an iteration is TWO launches: the product, and kp_lasso_project_kernel (V, threshold search, soft threshold,
+//     momentum scalars; cross-workgroup sums through write-through slots, bounded spins); the separate v / newton / final
+//     kernels (every reduction finished by the last workgroup to arrive) are the fallback
+//   * every 10 iterations the host reads the states: a value ends when its active-set candidate (Cholesky per column on
+//     the current support) satisfies every optimality condition of the QP, or when the iteration has converged
 #include <algorithm>
 #include <cmath>
 #include <vector>
@@ -320,7 +324,7 @@ __global__ __launch_bounds__(256) void kp_lasso_final_kernel(const double* __res
 // host sizes wpv for one workgroup per CU); every spin is bounded and a time-out is reported, never a hang.
 // ------------------------------------------------------------------------------------------------
 #define LP_NT 1024
-#define LP_MAXW 32
+#define LP_MAXW 64
 #define LP_MAXPASS 40
 struct LassoXchg {                   // per value
   double slot[2][LP_MAXW][4];        // [parity][workgroup][3 values + pad]
@@ -741,7 +745,8 @@ int kp_lasso_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, in
     const dim3 grid(nblk, nba);
     // workgroups per value of the fused projection: all of them resident at once, one per CU
     const int ncu = ctx->num_cu > 0 ? ctx->num_cu : 256;
-    const int wpv = std::max(1, std::min(LP_MAXW, ncu / nba));
+    static const int wcap = [] { const char* e = getenv("KP_LASSO_WPV"); return e ? std::max(1, std::min(LP_MAXW, atoi(e))) : 32; }();
+    const int wpv = std::max(1, std::min(wcap, ncu / nba));
     for (int c = 0; c < check_every && it < max_iter; ++c, ++it) {
       if (fused && nba <= ncu) {
         hipLaunchKernelGGL(kp_lasso_project_kernel, dim3(wpv, nba), dim3(LP_NT), 0, s, Kb[kc], Kb[ko], GKb[gc], GKb[go], C_dev, n, V, Kb[kn], st, xchg,
