@@ -39,36 +39,57 @@ def synth_pairs(Ns, nz=6, m=3, seed=0):
     return alpha, beta, u
 
 
-def cpu_baseline(Ns_sample, degree, seconds=9.0):
+def cpu_baseline(Ns_sample, degree, seconds=8.0):
     """The oracle's restatement of get_Koopman on the host cores, on a bounded sample of the same workload: the lift of
-    every row (Ksysid.m:1030-1065) + `Px \\ Py` (:1069).  MATLAB's mldivide on a rectangular system is a QR solve with
-    column pivoting, so the solve here is LAPACK gelsy (not the SVD lstsq).  Two rows: one thread (the reference's
-    interpreter is single threaded apart from BLAS) and all host cores."""
-    import scipy.linalg as sla
-    import threadpoolctl
-    from oracle import koopman_oracle as ko
+    every row (Ksysid.m:1030-1065) + `Px \\ Py` (:1069; MATLAB's mldivide on a rectangular system is a Householder QR
+    solve).  Compiled C (oracle/koopman_oracle_c.c, OpenMP) when its library is there, else numpy + LAPACK gelsy.  Two
+    rows: all host cores (`value`) and one thread (the reference's interpreter is single threaded apart from BLAS)."""
     alpha, beta, u = synth_pairs(Ns_sample, seed=123)
-    pairs = {"alpha": alpha, "beta": beta, "u": u}
-    dic = ko.build_dictionary("bilinear", 6, 3, ["poly"], [degree])
+    try:
+        from oracle import c_oracle, koopman_oracle as ko
+        c_oracle.lib()
+        exps = ko.poly_exponents(6, degree)[6:]
+        W = (6 + len(exps) + 1) * 4
 
-    def one():
-        Px, Py = ko.px_py(dic, pairs)
-        return sla.lstsq(Px, Py, lapack_driver="gelsy", check_finite=False)[0]
-
-    def timed(limit):
-        t0 = time.perf_counter(); reps = 0
-        while True:
-            one(); reps += 1
-            if time.perf_counter() - t0 > limit:
-                break
-        return (time.perf_counter() - t0) / reps, reps
-    all_cores = max([p_.get("num_threads", 1) for p_ in threadpoolctl.threadpool_info()] + [1])
-    dt_all, reps_all = timed(seconds)
-    with threadpoolctl.threadpool_limits(1):
+        def timed(limit):
+            t0 = time.perf_counter(); reps = 0
+            while True:
+                c_oracle.get_koopman("bilinear", 6, 3, exps, alpha, beta, u); reps += 1
+                if time.perf_counter() - t0 > limit:
+                    break
+            return (time.perf_counter() - t0) / reps, reps
+        all_cores = c_oracle.lib().ko_max_threads()
+        dt_all, reps_all = timed(seconds)
+        c_oracle.lib().ko_set_threads(1)
         dt_1, reps_1 = timed(seconds)
-    W = dic.W
+        c_oracle.lib().ko_set_threads(all_cores)
+        how = "compiled C restatement (per-row lift + Householder QR, OpenMP)"
+    except (ImportError, OSError):
+        import scipy.linalg as sla
+        import threadpoolctl
+        from oracle import koopman_oracle as ko
+        pairs = {"alpha": alpha, "beta": beta, "u": u}
+        dic = ko.build_dictionary("bilinear", 6, 3, ["poly"], [degree])
+        W = dic.W
+
+        def one():
+            Px, Py = ko.px_py(dic, pairs)
+            return sla.lstsq(Px, Py, lapack_driver="gelsy", check_finite=False)[0]
+
+        def timed(limit):
+            t0 = time.perf_counter(); reps = 0
+            while True:
+                one(); reps += 1
+                if time.perf_counter() - t0 > limit:
+                    break
+            return (time.perf_counter() - t0) / reps, reps
+        all_cores = max([p_.get("num_threads", 1) for p_ in threadpoolctl.threadpool_info()] + [1])
+        dt_all, reps_all = timed(seconds)
+        with threadpoolctl.threadpool_limits(1):
+            dt_1, reps_1 = timed(seconds)
+        how = "numpy lift + LAPACK QR (gelsy)"
     return {"value": Ns_sample / dt_all, "unit": "snapshot-pairs/s", "cores": int(all_cores), "kind": "port",
-            "sample": f"{reps_all} x get_Koopman (numpy lift + LAPACK QR gelsy) on {Ns_sample} pairs, W={W}, {dt_all*1e3:.0f} ms each",
+            "sample": f"{reps_all} x get_Koopman, {how}, on {Ns_sample} pairs, W={W}, {dt_all*1e3:.0f} ms each",
             "one_thread": {"value": Ns_sample / dt_1, "cores": 1,
                            "sample": f"{reps_1} x the same on one thread, {dt_1*1e3:.0f} ms each"}}
 
