@@ -396,11 +396,8 @@ int kp_chol_solve_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_de
   hipLaunchKernelGGL(kp_pad_kernel, dim3((unsigned)((tot + 255) / 256), nb), dim3(256), 0, st, G_dev, C_dev, W, ncols, n, ncp, Gp, Cp, gc_stride);
   KP_HIP(ctx, hipGetLastError());
   if (pad_done) KP_HIP(ctx, hipEventRecord(pad_done, st));
-  static size_t chol_lds_set = 0, trsm_lds_set = 0;
-  if (lds_chol > chol_lds_set) {
-    KP_HIP(ctx, hipFuncSetAttribute((const void*)kp_chol_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_chol));
-    chol_lds_set = lds_chol;
-  }
+  static KpLdsCache chol_lds, trsm_lds;
+  KP_HIP(ctx, kp_ensure_lds(chol_lds, (const void*)kp_chol_kernel, lds_chol));
   static const int chol_prof = getenv("KP_CHOL_PROF") ? 1 : 0;
   hipLaunchKernelGGL(kp_chol_kernel, dim3(1, nb), dim3(CH_NT), lds_chol, st, Gp, n, Dinv, info, sticky, chol_prof);
   KP_HIP(ctx, hipGetLastError());
@@ -409,10 +406,7 @@ int kp_chol_solve_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_de
     hipLaunchKernelGGL(kp_chol_finish_kernel, dim3(npair + nbk, nb), dim3(256), 0, st, Gp, n, npair, Dinv);
   }
   KP_HIP(ctx, hipGetLastError());
-  if (lds_trsm > trsm_lds_set) {
-    KP_HIP(ctx, hipFuncSetAttribute((const void*)kp_trsm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_trsm));
-    trsm_lds_set = lds_trsm;
-  }
+  KP_HIP(ctx, kp_ensure_lds(trsm_lds, (const void*)kp_trsm_kernel, lds_trsm));
   hipLaunchKernelGGL(kp_trsm_kernel, dim3(ncp / 16, nb), dim3(256), lds_trsm, st, Gp, Dinv, n, Cp);
   KP_HIP(ctx, hipGetLastError());
   hipLaunchKernelGGL(kp_unpad_kernel, dim3((unsigned)(((int64_t)W * ncols + 255) / 256), nb), dim3(256), 0, st, Cp, n, W, ncols, K_dev, ncp, k_first,

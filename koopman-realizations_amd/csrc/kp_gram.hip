@@ -370,11 +370,10 @@ static int make_plan(kp_ctx* ctx, int W, kp_gram_plan** out) {
 
 template <int NACC, bool FAST>
 static hipError_t launch_gram(const GramArgs& a, int grid, size_t lds, hipStream_t st, bool) {
-  static size_t lds_set = 0;   // per instantiation: largest dynamic-LDS size granted so far
-  if (lds > lds_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kp_gram_kernel<NACC, FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static KpLdsCache lds_cache;   // per instantiation and device: largest dynamic-LDS size granted so far
+  {
+    hipError_t e = kp_ensure_lds(lds_cache, (const void*)kp_gram_kernel<NACC, FAST>, lds);
     if (e != hipSuccess) return e;
-    lds_set = lds;
   }
   hipLaunchKernelGGL((kp_gram_kernel<NACC, FAST>), dim3(grid), dim3(256), lds, st, a);
   return hipGetLastError();

@@ -393,11 +393,10 @@ static int make_plan2(kp_ctx* ctx, int W, kp_gram2_plan** out) {
 
 template <int NACC, int BM>
 static hipError_t launch2b(const Gram2Args& a, int grid, size_t lds, hipStream_t st) {
-  static size_t lds_set = 0;
-  if (lds > lds_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kp_gram2_kernel<NACC, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static KpLdsCache lds_cache;
+  {
+    hipError_t e = kp_ensure_lds(lds_cache, (const void*)kp_gram2_kernel<NACC, BM>, lds);
     if (e != hipSuccess) return e;
-    lds_set = lds;
   }
   hipLaunchKernelGGL((kp_gram2_kernel<NACC, BM>), dim3(grid), dim3(NTHR), lds, st, a);
   return hipGetLastError();

@@ -519,12 +519,11 @@ static int make_plan3(kp_ctx* ctx, int N, int nwt, int nq_cap, kp_gram3_plan** o
 
 template <int NQ, int BM, bool PCS>
 static hipError_t launch3b(const Gram3Args& a, int grid, size_t lds, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static KpLdsCache lds_cache;
+  {
     const size_t lds_max = (size_t)(LDS3_DOUBLES + (PCS ? LDS3_PCS_DOUBLES : 0)) * sizeof(double);
-    hipError_t e = hipFuncSetAttribute((const void*)kp_gram3_kernel<NQ, BM, PCS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+    hipError_t e = kp_ensure_lds(lds_cache, (const void*)kp_gram3_kernel<NQ, BM, PCS>, lds_max);
     if (e != hipSuccess) return e;
-    attr_set = true;
   }
   hipLaunchKernelGGL((kp_gram3_kernel<NQ, BM, PCS>), dim3(grid), dim3(256), lds, st, a);
   return hipGetLastError();

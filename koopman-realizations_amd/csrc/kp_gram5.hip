@@ -373,11 +373,10 @@ static int make_plan5(kp_ctx* ctx, const kp_basis* basis, kp_gram5_plan** out) {
 
 template <int NT, int NF>
 static hipError_t launch5b(const Gram5Args& a, int grid, size_t lds, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kp_gram5_kernel<NT, NF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static KpLdsCache lds_cache;
+  {
+    hipError_t e = kp_ensure_lds(lds_cache, (const void*)kp_gram5_kernel<NT, NF>, lds);
     if (e != hipSuccess) return e;
-    attr_set = true;
   }
   hipLaunchKernelGGL((kp_gram5_kernel<NT, NF>), dim3(grid), dim3(256), lds, st, a);
   return hipGetLastError();

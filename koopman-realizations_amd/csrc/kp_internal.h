@@ -106,6 +106,20 @@ struct BasisDev {
   const double* pcs;      // nfull x k_pcs column-major
 };
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a PER-DEVICE setting: one cache entry per (call site, device), so a
+// second context on another GPU of the same process gets its own attribute call
+struct KpLdsCache { size_t set[32] = {}; };
+inline hipError_t kp_ensure_lds(KpLdsCache& c, const void* func, size_t lds) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (lds > c.set[dev]) {
+    hipError_t e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    c.set[dev] = lds;
+  }
+  return hipSuccess;
+}
+
 struct kp_gram_plan;
 void kp_gram_plan_free(kp_gram_plan* p);
 struct kp_gram2_plan;

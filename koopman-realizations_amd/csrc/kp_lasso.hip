@@ -90,11 +90,10 @@ __global__ __launch_bounds__(256) void kp_symm_gemm_naive_kernel(const double* _
 static hipError_t symm_gemm(hipStream_t st, const double* G, const double* X, int W, int nc, double* C) {
   const size_t lds = (size_t)((W + 3) & ~3) * SG_RS * 8;
   if (lds <= 156 * 1024) {
-    static size_t lds_set = 0;
-    if (lds > lds_set) {
-      hipError_t e = hipFuncSetAttribute((const void*)kp_symm_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static KpLdsCache lds_cache;
+    {
+      hipError_t e = kp_ensure_lds(lds_cache, (const void*)kp_symm_gemm_kernel, lds);
       if (e != hipSuccess) return e;
-      lds_set = lds;
     }
     hipLaunchKernelGGL(kp_symm_gemm_kernel, dim3((W + 15) / 16, (nc + 31) / 32), dim3(512), lds, st, G, X, W, nc, C);
   } else {

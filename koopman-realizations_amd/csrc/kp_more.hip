@@ -323,12 +323,9 @@ extern "C" int kp_rollout(kp_ctx* ctx, int model_type, int batch, const double* 
     const int tcmax = (int)std::min<size_t>(RO_TC, (128 * 1024 - lds_model) / ((size_t)(m + n_out) * 8));
     if (tcmax < 1) return ctx->fail(KP_ERR_ARG, "kp_rollout: model too large for the LDS staging");
     const size_t lds = lds_model + (size_t)(m + n_out) * tcmax * 8;
-    static bool attr = false;
-    if (!attr) {
-      KP_HIP(ctx, hipFuncSetAttribute((const void*)kp_rollout_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-      KP_HIP(ctx, hipFuncSetAttribute((const void*)kp_rollout_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-      attr = true;
-    }
+    static KpLdsCache lds_c0, lds_c1;
+    KP_HIP(ctx, kp_ensure_lds(lds_c0, (const void*)kp_rollout_kernel<false>, 128 * 1024));
+    KP_HIP(ctx, kp_ensure_lds(lds_c1, (const void*)kp_rollout_kernel<true>, 128 * 1024));
     if (N <= 64)
       hipLaunchKernelGGL(kp_rollout_kernel<true>, dim3(batch), dim3(64), lds, s, bil, dA, dB, N, m, dz, dU, T, n_out, dY, stageA, stageB, tcmax);
     else

@@ -579,11 +579,8 @@ extern "C" int kp_qp_solve(kp_ctx* ctx, const double* H, const double* f, const 
   EllMat E{dV, dC, dn, K};
   size_t lds = (size_t)qp_lds_doubles(n, mr) * 8;
   if (lds > 160 * 1024) return ctx->fail(KP_ERR_ARG, "kp_qp_solve: problem too large");
-  static size_t lds_set = 0;
-  if (lds > lds_set) {
-    KP_HIP(ctx, hipFuncSetAttribute((const void*)kp_qp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    lds_set = lds;
-  }
+  static KpLdsCache qp_lds;
+  KP_HIP(ctx, kp_ensure_lds(qp_lds, (const void*)kp_qp_kernel, lds));
   hipLaunchKernelGGL(kp_qp_kernel, dim3(1), dim3(64), lds, s, dH, df, E, db, n, mr, dx, dst, (size_t)0, (size_t)0, (size_t)0, (size_t)0, 0);
   KP_HIP(ctx, hipGetLastError());
   int st = 0;
@@ -1259,13 +1256,9 @@ static int mpc_run(kp_mpc* M, const kp_basis* basis, int nb, const double* z, co
   a.stamps = nb == 1 ? (long long*)(M->work + n_ex) : nullptr;
   size_t lds = (size_t)mpc_lds_doubles(N, m, Np, nproj, nv, nr, (sb && iters > 1) ? 2 : iters, zeta ? basis->dev.nfull : 0) * 8 + 32;
   if (lds > 160 * 1024) return ctx->fail(KP_ERR_ARG, "kp_mpc_step: problem too large for LDS");
-  static size_t lds_set[2] = {0, 0};
+  static KpLdsCache step_lds[2];
   const int wk = a.warm != nullptr;
-  if (lds > lds_set[wk]) {
-    KP_HIP(ctx, hipFuncSetAttribute(wk ? (const void*)kp_mpc_step_kernel<true> : (const void*)kp_mpc_step_kernel<false>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    lds_set[wk] = lds;
-  }
+  KP_HIP(ctx, kp_ensure_lds(step_lds[wk], wk ? (const void*)kp_mpc_step_kernel<true> : (const void*)kp_mpc_step_kernel<false>, lds));
   KP_HIP(ctx, hipEventRecord(ctx->evp[4], ctx->stream));
   if (!sb) {
     if (wk) hipLaunchKernelGGL(kp_mpc_step_kernel<true>, dim3(nb), dim3(256), lds, ctx->stream, a);
@@ -1281,11 +1274,8 @@ static int mpc_run(kp_mpc* M, const kp_basis* basis, int nb, const double* z, co
     double* dx = nrm + (size_t)nb * mr_sb;                  // [nb][nv]
     int* dst = (int*)(dx + (size_t)nb * nv);                // [nb]
     const size_t lq = (size_t)qp_lds_doubles(nv, mr_sb) * 8 + 64;
-    static size_t lq_set = 0;
-    if (lq > lq_set) {
-      KP_HIP(ctx, hipFuncSetAttribute((const void*)kp_qp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lq));
-      lq_set = lq;
-    }
+    static KpLdsCache sbqp_lds;
+    KP_HIP(ctx, kp_ensure_lds(sbqp_lds, (const void*)kp_qp_kernel, lq));
     EllMat E{M->sb_A, M->sb_col, nrm, nv};
     for (int pass = 0; pass < iters; ++pass) {
       a.U_lin = pass > 0 ? dx : nullptr;

@@ -6,6 +6,7 @@ All arithmetic of the hot path happens inside libkoopman_hip.so on the GPU.
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -19,6 +20,7 @@ class Context:
         self._h = F.vp()
         F.check(F.lib().kp_create(int(device_id), C.byref(self._h)))
         self.device_id = device_id
+        self._children = weakref.WeakSet()       # Basis / Snapshots / Mpc / Traj handles: they hold pointers into this context
 
     @property
     def handle(self):
@@ -61,7 +63,13 @@ class Context:
         return K
 
     def close(self):
+        """Destroys the child handles first (their destroy calls dereference the context), then the context."""
         if self._h:
+            for ch in list(getattr(self, "_children", ())):
+                try:
+                    ch.close()
+                except Exception:
+                    pass
             F.lib().kp_destroy(self._h)
             self._h = F.vp()
 
@@ -196,6 +204,7 @@ class Basis:
         """blocks: list of ('poly', exps[rows,nvars] uint8) | ('fourier', deg) | ('gaussian', centres[nvars,k])
         | ('hermite', orders[rows,nvars] uint8) | ('fourier_sparser', multipliers[rows,2*nvars] uint8)."""
         self.ctx = ctx
+        ctx._children.add(self)
         nvars = nzeta + (m if model_type == "nonlinear" else 0)
         btype, bcount, exps, centres = [], [], [], []
         for kind, arg in blocks:
@@ -261,6 +270,7 @@ class Snapshots:
 
     def __init__(self, ctx: Context, alpha, beta, u):
         self.ctx = ctx
+        ctx._children.add(self)
         a = F.fcol(alpha); b = F.fcol(beta); uu = F.fcol(u)
         self.Ns, self.nzeta, self.m = a.shape[0], a.shape[1], uu.shape[1]
         self._h = F.vp()
@@ -290,6 +300,7 @@ class Traj:
 
     def __init__(self, ctx: Context, Y, U, ntrials, Yv, Uv):
         self.ctx = ctx
+        ctx._children.add(self)
         Y = np.asarray(Y, dtype=np.float64); U = np.asarray(U, dtype=np.float64)
         Yv = np.asarray(Yv, dtype=np.float64); Uv = np.asarray(Uv, dtype=np.float64)
         self.nb, rows, self.n = Y.shape
@@ -391,6 +402,7 @@ class Mpc:
     def __init__(self, ctx: Context, model_type, A, B, Np, proj, q_run, q_term, r, lo=None, hi=None,
                  slope_lim=None, smooth_lim=None):
         self.ctx = ctx
+        ctx._children.add(self)
         A = F.fcol(A); B = F.fcol(B); proj = F.fcol(np.atleast_2d(proj))
         self.N, self.m, self.Np, self.nproj = A.shape[0], len(np.atleast_1d(r)), int(Np), proj.shape[0]
         r = np.ascontiguousarray(np.atleast_1d(r), dtype=np.float64)

@@ -161,7 +161,9 @@ class Ksysid:
         self.traindata = self.get_scale(merged)                            # :122
         self.valdata = [self.scale_data(v) for v in data4sysid["val"]]    # :123-126
         self.snapshotPairs = self.get_snapshotPairs(self.traindata, self.snapshots)   # :134
-        Px = self.lift_snapshots(self.snapshotPairs) if (self.dim_red and self._pca_host) else None   # :137-141
+        # pca of dictionaries wider than the device eigensolver takes (kp_sym_eig: n <= 256, e.g. poly-3 on a delayed arm
+        # state): lift on the device, SVD of the lifted matrix on the host - as the reference's `pca` does
+        Px = self.lift_snapshots(self.snapshotPairs) if (self.dim_red and (self._pca_host or self.basis_dev.nfull > 256)) else None   # :137-141
         self.get_econ_observables(Px)                                      # :142
         self.lift = _Lift(self)
 
