@@ -58,7 +58,14 @@ def cpu_baseline(Ns_sample, degree, seconds=8.0):
                 if time.perf_counter() - t0 > limit:
                     break
             return (time.perf_counter() - t0) / reps, reps
-        all_cores = c_oracle.lib().ko_max_threads()
+        # "all cores" = the cores this process may run on (a 256-thread OpenMP team on a box that grants fewer turns the
+        # per-column barriers of the QR into time slicing), at most 32
+        try:
+            avail = len(os.sched_getaffinity(0))
+        except AttributeError:
+            avail = os.cpu_count() or 1
+        all_cores = max(1, min(c_oracle.lib().ko_max_threads(), avail, 32))
+        c_oracle.lib().ko_set_threads(all_cores)
         dt_all, reps_all = timed(seconds)
         c_oracle.lib().ko_set_threads(1)
         dt_1, reps_1 = timed(seconds)
