@@ -237,7 +237,9 @@ def bench_rand_sweep(ctx, comm, kra, chunks, n_systems):
     sweep.rand_models_sweep_batched(mine[:4], ctx)                           # warm-up
     comm.barrier()
     t0 = time.perf_counter()
-    tab = sweep.rand_models_sweep_batched(mine, ctx) if mine else {}
+    raw = sweep._stack_raw(mine) if mine else None                           # data4sysid structs -> one block per quantity (host)
+    t_stack = time.perf_counter() - t0
+    tab = (sweep.rand_models_sweep_arrays(*raw, ctx=ctx) if raw is not None else sweep.rand_models_sweep_batched(mine, ctx)) if mine else {}
     t_local = time.perf_counter() - t0
     local = {i: {mt: tab[mt][:, k] for mt in tab} for k, i in enumerate(ids)}
     allres = sweep.gather_results(local, n_systems, comm)
@@ -246,7 +248,8 @@ def bench_rand_sweep(ctx, comm, kra, chunks, n_systems):
     lin = np.stack([r["linear"] for r in allres], axis=1)
     mean, _ = sweep.sweep_statistics(lin)
     return {"systems": n_systems, "distinct_systems": True, "seconds": dt, "systems_per_s": n_systems / dt, "n_gpus": comm.world,
-            "rank0_compute_seconds": t_local, "fits_per_system": int(sum(v.shape[0] for v in tab.values())) if tab else 23,
+            "rank0_compute_seconds": t_local, "rank0_host_gather_seconds": t_stack, "rank0_upload_and_device_seconds": t_local - t_stack,
+            "fits_per_system": int(sum(v.shape[0] for v in tab.values())) if tab else 23,
             "mean_linear_error_deg1_deg13": [float(mean[0]), float(mean[-1])],
             "workload": "evaluate_rand_models.m on 1024 generated 1-D random systems (Rsys restatement), 23 fits + validation "
                         "rollouts each, 128-system chunks round-robin over the ranks (BASELINE configs[4])"}

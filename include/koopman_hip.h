@@ -39,6 +39,7 @@ typedef struct kp_snapshots kp_snapshots; /* snapshot pairs resident in HBM     
 typedef struct kp_mpc kp_mpc;             /* condensed MPC problem on device       */
 
 /* ---- context ------------------------------------------------------------------- */
+int kp_device_count(int* count);          /* GPUs visible to this process (0 without a GPU); does not create a context */
 int kp_create(int device_id, kp_ctx** ctx);
 int kp_destroy(kp_ctx* ctx);
 const char* kp_last_error(const kp_ctx* ctx);   /* ctx may be NULL: last global error */

@@ -33,6 +33,7 @@ class KpBasisDesc(C.Structure):
 
 # name -> (restype, argtypes); every symbol of include/koopman_hip.h
 SIGNATURES = {
+    "kp_device_count": (C.c_int, [c_ip]),
     "kp_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
     "kp_destroy": (C.c_int, [vp]),
     "kp_last_error": (C.c_char_p, [vp]),

@@ -143,6 +143,10 @@ def init_from_env(Context):
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
     if "KP_FORCE_DEVICE" in os.environ:          # debugging on a one-GPU box: all ranks on one device (if RCCL accepts it)
         local = int(os.environ["KP_FORCE_DEVICE"])
+    ndev = C.c_int(0)
+    F.lib().kp_device_count(C.byref(ndev))
+    if 0 < ndev.value <= local:                  # the launcher restricted this rank's visible devices (e.g. one per rank)
+        local %= ndev.value
     ctx = Context(local)
     if world == 1:
         return ctx, LocalComm()

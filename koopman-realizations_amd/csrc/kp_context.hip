@@ -99,6 +99,17 @@ extern "C" int kp_destroy(kp_ctx* c) {
   return KP_OK;
 }
 
+extern "C" int kp_device_count(int* count) {
+  if (!count) return KP_ERR_ARG;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    n = 0;
+  }
+  *count = n;
+  return KP_OK;
+}
+
 extern "C" const char* kp_last_error(const kp_ctx* c) {
   if (c) return c->err.c_str();
   std::lock_guard<std::mutex> l(g_err_mu);

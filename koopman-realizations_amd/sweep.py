@@ -185,7 +185,16 @@ def rand_models_sweep_batched(systems, ctx, degrees=None, nested=True):
     raw = _stack_raw(systems)
     if raw is None:
         return _sweep_batched_host(systems, ctx, degrees)
-    Y, U, k, Yv, Uv = raw
+    return rand_models_sweep_arrays(*raw, ctx=ctx, degrees=degrees, nested=nested)
+
+
+def rand_models_sweep_arrays(Y, U, k, Yv, Uv, ctx, degrees=None, nested=True):
+    """The batched sweep on already stacked raw trajectories: Y (nb, k T, n), U (nb, k T, m) = the k training trials of
+    every system back to back, Yv / Uv (nb, Tv, ·) the validation trial (what `_stack_raw` builds from the reference's
+    data4sysid structs; a generator or loader that produces the blocks directly skips that gathering)."""
+    from .device import Basis, Traj
+    from .ksysid import poly_exponent_table
+    degrees = degrees or MAX_DEGREE
     n, m = Y.shape[2], U.shape[2]
     traj = Traj(ctx, Y, U, k, Yv, Uv)
     out = {}

@@ -51,3 +51,29 @@ def test_simulation_and_data4sysid_layout():
     sets = Rsys.save_data(data)
     assert len(sets) == 2 and len(sets[0]["train"]) == 2 and len(sets[0]["val"]) == 1
     assert sets[1]["val"][0] is data[2][1]
+
+
+def test_fast_generator_matches_the_scalar_one():
+    """simulate_systems_fast (all trajectories as numpy lanes, per-lane ode45 step control) = simulate_systems to rounding,
+    with the same random stream."""
+    a = Rsys(3, 5, 3, 2, seed=4); b = Rsys(3, 5, 3, 2, seed=4)
+    da = a.simulate_systems(0.6, 0.01, 3, np.array([[0.3]]))
+    db = b.simulate_systems_fast(0.6, 0.01, 3, np.array([[0.3]]))
+    for j in range(3):
+        for i in range(3):
+            assert np.array_equal(da[j][i]["u"], db[j][i]["u"])
+            assert np.abs(da[j][i]["y"] - db[j][i]["y"]).max() < 1e-13
+
+
+def test_sweep_stacking_of_data4sysid_structs():
+    """The sweep's host gathering: equally shaped trials become one block per quantity; ragged layouts are refused (they
+    take the per-system path)."""
+    from koopman_realizations_amd import sweep
+    r = Rsys(4, 3, 2, 2, seed=2)
+    sets = Rsys.save_data(r.simulate_systems_fast(0.5, 0.01, 4, np.zeros((1, 1))))
+    Y, U, k, Yv, Uv = sweep._stack_raw(sets)
+    assert Y.shape == (4, 3 * 51, 1) and U.shape == (4, 3 * 51, 1) and k == 3 and Yv.shape == (4, 51, 1)
+    assert np.array_equal(Y[2, 51:102, 0], sets[2]["train"][1]["y"][:, 0]) and np.array_equal(Uv[3, :, 0], sets[3]["val"][0]["u"][:, 0])
+    sets[1]["train"][2] = {k_: v[:40] for k_, v in sets[1]["train"][2].items()}
+    assert sweep._stack_raw(sets) is None
+    assert sweep._stack_raw([{"train": sets[0]["train"][:2], "val": sets[0]["val"]}, sets[2]]) is None
