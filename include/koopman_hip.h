@@ -145,6 +145,10 @@ int kp_snapshots_destroy(kp_snapshots* snaps);
 int kp_fit_gram(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* snaps, double* G, double* C);
 int kp_fit_solve(kp_ctx* ctx, const double* G, const double* C, int W, int ncols, double* K);
 int kp_fit_last_rank(const kp_ctx* ctx, int* rank);
+/* min_i L_ii^2 / G_ii of the most recent synchronous least-squares solve (kp_fit with K_out, kp_fit_solve): about
+ * 1 / cond(G) = 1 / cond(Px)^2.  MATLAB's `\` (Ksysid.m:1069) is a QR solve; the normal equations lose cond(G) eps against
+ * it, so a ratio above ~1e-5 means K is already at QR accuracy (1e-11) and kp_fit_refine's pass over the data is not needed. */
+int kp_fit_last_pivot_ratio(const kp_ctx* ctx, double* ratio);
 int kp_fit_lasso(kp_ctx* ctx, const double* G, const double* C, int W, int ncols, double t,
                  int max_iter, double tol, double* K, int* iters);
 /* nv lasso values on the same Grams at once (the train_models loop over a lasso vector, Ksysid.m:1372-1387, re-lifts

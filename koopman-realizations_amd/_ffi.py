@@ -49,6 +49,7 @@ SIGNATURES = {
     "kp_fit_gram": (C.c_int, [vp, vp, vp, c_dp, c_dp]),
     "kp_fit_solve": (C.c_int, [vp, c_dp, c_dp, C.c_int, C.c_int, c_dp]),
     "kp_fit_last_rank": (C.c_int, [vp, c_ip]),
+    "kp_fit_last_pivot_ratio": (C.c_int, [vp, c_dp]),
     "kp_fit_lasso": (C.c_int, [vp, c_dp, c_dp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double, c_dp, c_ip]),
     "kp_fit_lasso_batch": (C.c_int, [vp, c_dp, c_dp, C.c_int, C.c_int, c_dp, C.c_int, C.c_int, C.c_double, c_dp, c_ip]),
     "kp_fit": (C.c_int, [vp, vp, vp, c_dp, C.c_int, c_dp]),

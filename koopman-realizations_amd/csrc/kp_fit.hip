@@ -421,14 +421,38 @@ int kp_chol_solve_dev(kp_ctx* ctx, double* G_dev, double* C_dev, int W, int ncol
   return kp_chol_solve_batch_dev(ctx, G_dev, C_dev, W, ncols, 1, 0, K_dev, 0, 0, st, pad_done, sticky);
 }
 
+// smallest pivot of the factorisation relative to its original diagonal entry, min_i L_ii^2 / G_ii: ~1 / cond(G) - what
+// the normal equations lose against the QR solve of `\` is cond(G) eps, so the caller can tell whether K needs the
+// refinement pass over the data (kp_fit_refine) at all
+__global__ __launch_bounds__(256) void kp_pivot_ratio_kernel(const double* __restrict__ Lp, int n, const double* __restrict__ G, int W,
+                                                             double* __restrict__ out) {
+  __shared__ double red[4];
+  double r = 1e300;
+  for (int i = threadIdx.x; i < W; i += 256) {
+    const double l = Lp[(size_t)i * n + i], g = G[(size_t)i * W + i];
+    r = fmin(r, g > 0.0 ? l * l / g : 0.0);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) r = fmin(r, __shfl_xor(r, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = r;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = fmin(fmin(red[0], red[1]), fmin(red[2], red[3]));
+}
+
 static int check_info(kp_ctx* ctx) {
   // info word sits behind the padded buffers of workspace 5; read it back (stream is synced by callers)
   return KP_OK;
 }
 
-static int read_chol_info(kp_ctx* ctx, int W, int ncols, int* bad) {
+static int read_chol_info(kp_ctx* ctx, int W, int ncols, int* bad, const double* G_dev = nullptr) {
   const int n = (W + 15) / 16 * 16, ncp = (ncols + 15) / 16 * 16;
   size_t off = (size_t)n * n * 8 + (size_t)n * ncp * 8 + (size_t)(n / 16) * 256 * 8;
+  double* ratio_dev = (double*)((char*)ctx->ws[5] + off + 8);
+  if (G_dev) {     // the factor is still in the padded buffer at the head of workspace 5
+    hipLaunchKernelGGL(kp_pivot_ratio_kernel, dim3(1), dim3(256), 0, ctx->stream, (const double*)ctx->ws[5], n, G_dev, W, ratio_dev);
+    KP_HIP(ctx, hipGetLastError());
+    KP_HIP(ctx, hipMemcpyAsync(&ctx->last_pivot_ratio, ratio_dev, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  }
   KP_HIP(ctx, hipMemcpyAsync(bad, (char*)ctx->ws[5] + off, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   KP_HIP(ctx, hipStreamSynchronize(ctx->stream));
   (void)check_info;
@@ -527,7 +551,7 @@ extern "C" int kp_fit_solve(kp_ctx* ctx, const double* G, const double* C, int W
   KP_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   KP_HIP(ctx, hipMemcpyAsync(K, Kd, bC, hipMemcpyDeviceToHost, ctx->stream));
   int bad = 0;
-  rc = read_chol_info(ctx, W, ncols, &bad);
+  rc = read_chol_info(ctx, W, ncols, &bad, Gd);
   if (rc) return rc;
   float ms = 0;
   (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
@@ -543,6 +567,12 @@ extern "C" int kp_fit_solve(kp_ctx* ctx, const double* G, const double* C, int W
     KP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->err = "warning: Gram matrix is rank deficient; basic solution returned (kp_fit_last_rank)";
   }
+  return KP_OK;
+}
+
+extern "C" int kp_fit_last_pivot_ratio(const kp_ctx* ctx, double* ratio) {
+  if (!ctx || !ratio) return KP_ERR_ARG;
+  *ratio = ctx->last_pivot_ratio;
   return KP_OK;
 }
 
@@ -705,7 +735,7 @@ extern "C" int kp_fit(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* sn
   if (K_out) KP_HIP(ctx, hipMemcpyAsync(K_out, ctx->Kres, (size_t)n_lasso * W * W * 8, hipMemcpyDeviceToHost, ctx->stream));
   int bad = 0;
   if (ls_index >= 0) {
-    rc = read_chol_info(ctx, W, W, &bad);
+    rc = read_chol_info(ctx, W, W, &bad, Gd);
     if (rc) return rc;
   } else {
     KP_HIP(ctx, hipStreamSynchronize(ctx->stream));

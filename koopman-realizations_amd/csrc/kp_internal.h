@@ -61,6 +61,7 @@ struct kp_ctx {
   void* ws[10] = {nullptr};     // slot 8: staging of the collectives, 9: rank-revealing solve
   size_t ws_bytes[10] = {0};
   int last_rank = -1;           // rank found by the most recent solve (W when the Gram matrix was positive definite)
+  double last_pivot_ratio = 1.0; // min_i L_ii^2 / G_ii of the most recent synchronous least-squares solve (~1 / cond(G))
   // results of the last kp_fit
   double* Kres = nullptr;   // n_lasso x W x W
   size_t Kres_bytes = 0;

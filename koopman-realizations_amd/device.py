@@ -51,6 +51,12 @@ class Context:
         F.check(F.lib().kp_fit_last_rank(self._h, C.byref(r)), self._h)
         return r.value
 
+    def last_pivot_ratio(self) -> float:
+        """min_i L_ii^2 / G_ii of the most recent synchronous least-squares solve (~1 / cond(G))."""
+        r = C.c_double()
+        F.check(F.lib().kp_fit_last_pivot_ratio(self._h, C.byref(r)), self._h)
+        return r.value
+
     def fit_async_slots(self, n_slots: int):
         """Size of the result ring of asynchronous fits (fit(..., fetch=False)): the last n_slots fits of a batch stay
         retrievable with fit_result(q)."""

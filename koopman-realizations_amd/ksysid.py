@@ -423,7 +423,9 @@ class Ksysid:
                     import warnings
                     warnings.warn(f"Rank deficient, rank = {rank} of {self.basis_dev.W}: basic solution returned "
                                   "(use dim_red=True as example_sysid.m does)", RuntimeWarning)
-                elif self.ls_refine:                                       # K = Px \ Py (:1069) to QR accuracy
+                elif self.ls_refine and self.ctx.last_pivot_ratio() < 1e-5:
+                    # K = Px \ Py (:1069) to QR accuracy: the normal equations lose cond(G) eps ~ eps / pivot ratio; above
+                    # 1e-5 they are already at 1e-11 and the pass over the lifted data buys nothing
                     K = fit_refine(self.ctx, self.basis_dev, snaps, K, int(self.ls_refine))
             else:                                                          # :994-999: t = lasso * N
                 lval = 1e4 if lasso is None else float(lasso)
