@@ -691,6 +691,145 @@ extern "C" int kp_sweep_eval(kp_ctx* ctx, const kp_traj* traj, const kp_basis* b
 }
 
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Gram pass of the nested sweep: G = Px'Px, C = Px'Py of every system straight from its (scaled) trajectories, monomial /
+// Chebyshev dictionaries through the power-table recipes, W <= 16.  One workgroup per system, 128 snapshot pairs per tile:
+//   * thread (side, p) lifts ONE side of ONE pair: fills its own column of the power table (no barrier between the fill
+//     and the reads: a thread only reads what it wrote), forms the N columns and writes its row of Px or Py;
+//   * the raw values of the NEXT tile are loaded into registers before the current tile is processed (the global-memory
+//     latency is off the critical path; the per-tile chain raw load -> barrier -> table -> barrier -> lift -> barrier of
+//     kp_small_fit_kernel is what kept that kernel at a tenth of the f64 rate);
+//   * accumulation as there: a lane owns one 4 x 4 block of G and of C for 8 of the 128 pairs, three 16-byte LDS reads
+//     per 32 FMAs, the 16 snapshot groups summed in a fixed order at the end.
+// Two barriers per 128 pairs.  No solve here: kp_sweep_sub_kernel factors the sub-blocks of every degree.
+// ---------------------------------------------------------------------------------------------------------------------
+#define TG_TS 128
+__global__ __launch_bounds__(256) void kp_traj_gram_kernel(BasisDev b, const uint32_t* __restrict__ recipes, int D, int nfmax, TrajView tv,
+                                                           int Ns, int cheb, double* __restrict__ Gout, double* __restrict__ Cout) {
+  extern __shared__ __align__(16) double sm[];
+  // LDS: Px[TS][LD] | Py[TS][LD] | pw[side][v * D + e - 1][TS] | Gs[16][LD] | Cs[16][LD]
+  const int nv = b.nvars, m = b.m, N = b.N, W = b.W, nz = b.nzeta;
+  double* Px = sm;
+  double* Py = Px + TG_TS * SB_LD;
+  double* pw = Py + TG_TS * SB_LD;
+  double* Gs = pw + 2 * nv * D * TG_TS;
+  double* Cs = Gs + 16 * SB_LD;
+  __shared__ uint32_t recs[SB_W];
+  const int tid = threadIdx.x, sys = blockIdx.x;
+  if (tid < N) recs[tid] = recipes[tid];
+  for (int e = tid; e < 2 * TG_TS * SB_LD; e += 256) Px[e] = 0.0;          // unused columns stay zero
+  const int side = tid >> 7, p = tid & (TG_TS - 1);
+  const int blk = tid & 15, grp = tid >> 4;
+  const int bi = (blk >> 2) * 4, bj = (blk & 3) * 4;
+  const int Tm1 = tv.T - 1;
+  double g[4][4], c[4][4];
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int y = 0; y < 4; ++y) g[x][y] = c[x][y] = 0.0;
+  // raw values of a pair for this thread's side: the nv dictionary variables ([y] or [y; u]), then the m inputs
+  double raw[KP_MAX_VARS > 8 ? 8 : KP_MAX_VARS], rin[3];
+  auto load_raw = [&](int r0) {
+    const int pair = r0 + p;
+    const bool ok = pair < Ns;
+    const int tr = ok ? (int)(((unsigned long long)pair * tv.div_magic) >> 40) : 0;
+    const int row = ok ? tr * tv.T + (pair - tr * Tm1) : 0;
+#pragma unroll
+    for (int v = 0; v < 8; ++v)
+      if (v < nv) {
+        double x = v < nz ? tv.Y[((size_t)sys * tv.n + v) * tv.rows + row + side] : tv.U[((size_t)sys * tv.m + (v - nz)) * tv.rows + row];
+        raw[v] = ok ? x : 0.0;
+      }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      if (i < m) rin[i] = ok ? tv.U[((size_t)sys * tv.m + i) * tv.rows + row] : 0.0;
+    return ok;
+  };
+  bool ok_next = load_raw(0);
+  __syncthreads();
+  for (int r0 = 0; r0 < Ns; r0 += TG_TS) {
+    // ---- lift of this thread's (side, pair) from the registers loaded one tile ago ----
+    const bool ok = ok_next;
+    double* mypw = pw + (size_t)side * nv * D * TG_TS + p;
+#pragma unroll
+    for (int v = 0; v < 8; ++v)
+      if (v < nv) {
+        const double x = raw[v];
+        double q = x, qm = 1.0;
+        for (int k = 0; k < D; ++k) {
+          mypw[(v * D + k) * TG_TS] = q;
+          const double qn = cheb ? 2.0 * x * q - qm : q * x;
+          qm = q;
+          q = qn;
+        }
+      }
+    double uin[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) uin[i] = i < m ? rin[i] : 0.0;
+    double* P = (side ? Py : Px) + p * SB_LD;
+    for (int col = 0; col < N; ++col) {
+      const uint32_t rc = recs[col];
+      double val = ok ? 1.0 : 0.0;
+      for (int f = 0; f < nfmax; ++f) {
+        const uint32_t id = (rc >> (8 * f)) & 255u;
+        const double t = mypw[(id == 255u ? 0u : id) * TG_TS];
+        val *= id == 255u ? 1.0 : t;
+      }
+      P[col] = val;
+      if (b.model_type == KP_MODEL_BILINEAR)
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+          if (i < m) P[(i + 1) * N + col] = val * uin[i];
+    }
+    if (b.model_type == KP_MODEL_LINEAR)
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+        if (i < m) P[N + i] = uin[i];
+    // the next tile's raw values: in flight while this tile is accumulated
+    ok_next = load_raw(r0 + TG_TS);
+    __syncthreads();
+    // ---- accumulation: 16 blocks x 16 snapshot groups of 8 ----
+#pragma unroll 2
+    for (int s_ = 0; s_ < TG_TS / 16; ++s_) {
+      const double* xr = Px + (grp * (TG_TS / 16) + s_) * SB_LD;
+      const double* yr = Py + (grp * (TG_TS / 16) + s_) * SB_LD;
+      const double2 xa = *reinterpret_cast<const double2*>(xr + bi), xb = *reinterpret_cast<const double2*>(xr + bi + 2);
+      const double2 ja = *reinterpret_cast<const double2*>(xr + bj), jb = *reinterpret_cast<const double2*>(xr + bj + 2);
+      const double2 ya = *reinterpret_cast<const double2*>(yr + bj), yb = *reinterpret_cast<const double2*>(yr + bj + 2);
+      const double xi[4] = {xa.x, xa.y, xb.x, xb.y}, xj[4] = {ja.x, ja.y, jb.x, jb.y}, yj[4] = {ya.x, ya.y, yb.x, yb.y};
+#pragma unroll
+      for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+          g[x][y] += xi[x] * xj[y];
+          c[x][y] += xi[x] * yj[y];
+        }
+    }
+    __syncthreads();
+  }
+  // sum of the 16 snapshot groups in a fixed order
+  const int gi = tid >> 4, gj = tid & 15;
+  Gs[gi * SB_LD + gj] = 0.0;
+  Cs[gi * SB_LD + gj] = 0.0;
+  for (int t = 0; t < 16; ++t) {
+    __syncthreads();
+    if (grp == t) {
+#pragma unroll
+      for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+          Gs[(bi + x) * SB_LD + bj + y] += g[x][y];
+          Cs[(bi + x) * SB_LD + bj + y] += c[x][y];
+        }
+    }
+  }
+  __syncthreads();
+  if (gi < W && gj < W) {
+    Gout[(size_t)sys * W * W + (size_t)gj * W + gi] = Gs[gi * SB_LD + gj];
+    Cout[(size_t)sys * W * W + (size_t)gj * W + gi] = Cs[gi * SB_LD + gj];
+  }
+}
+
 // =====================================================================================================================
 // All degrees of one model type from ONE pass over the data (evaluate_rand_models.m loops degree by degree, :47-143).
 //  * The degree-j polynomial dictionary is a column subset of the degree-D one: def_polyLift orders the monomials by
@@ -810,6 +949,140 @@ __global__ __launch_bounds__(64) void kp_sweep_rollout_nested_kernel(BasisDev b,
   const size_t off = ((size_t)dj * nb + sys) * 256;
   sweep_rollout_body(bj, Kall + off, Aall ? Aall + off : nullptr, Ball ? Ball + off : nullptr, Yv + (size_t)sys * Tv * n, Uv + (size_t)sys * Tv * m,
                      Tv, stat[(size_t)dj * nb + sys], err + ((size_t)dj * nb + sys) * n, vsh);
+}
+
+// Validation rollouts of the nested sweep, FOUR (system, degree) jobs per wave: a job lives in one 16-lane row (N <= 16),
+// lane r of the row owns component r of the lifted state.  z+ = A z column by column: z[c] is broadcast inside every row by
+// ds_swizzle (LDS crossbar, no VALU slot) and lane r adds A[r][c] z[c] - N FMAs per step for all four jobs, instead of
+// sixteen v_readlane broadcasts per job.
+template <int CTRL>
+__device__ __forceinline__ double sb_row_ror(double v) {       // lane l of a 16-lane row receives from lane (l - n) mod 16
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double sb_row_sum(double v) {        // sum over the 16 lanes of a row, in every lane
+  v += sb_row_ror<0x128>(v);
+  v += sb_row_ror<0x124>(v);
+  v += sb_row_ror<0x122>(v);
+  v += sb_row_ror<0x121>(v);
+  return v;
+}
+
+__global__ __launch_bounds__(64) void kp_sweep_rollout4_kernel(BasisDev b, const SweepDeg* __restrict__ degs, const ColDesc* __restrict__ cols_all,
+                                                               int nb, int n_deg, const double* __restrict__ Kall, const double* __restrict__ Aall,
+                                                               const double* __restrict__ Ball, const double* __restrict__ Yv,
+                                                               const double* __restrict__ Uv, int Tv, const int* __restrict__ stat,
+                                                               double* __restrict__ err) {
+  __shared__ double vsh[4][KP_MAX_VARS];
+  const int lane = threadIdx.x, q = lane >> 4, r = lane & 15;
+  const int njobs = nb * n_deg;
+  int job = blockIdx.x * 4 + q;
+  const bool live = job < njobs;
+  if (!live) job = njobs - 1;
+  const int dj = job / nb, sys = job - dj * nb;
+  const int n = b.nzeta, m = b.m, mt = b.model_type;
+  const int N = degs[dj].N, W = degs[dj].W;
+  BasisDev bj = b;
+  bj.N = N; bj.W = W; bj.nfull = N; bj.cols = cols_all + (size_t)dj * 16;
+  const size_t off = ((size_t)dj * nb + sys) * 256;
+  const double* Ks = Kall + off;
+  const double* yv = Yv + (size_t)sys * Tv * n;
+  const double* uv = Uv + (size_t)sys * Tv * m;
+  const bool rin = r < N;
+  // row r of the model matrices: ak[c] = A[r][c], bk[i][c] = B_i[r][c]
+  double ak[16], bk[3][16], bl[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    const bool in = rin && c < N;
+    double a = 0.0;
+    if (mt == KP_MODEL_LINEAR) a = in ? Aall[off + (size_t)c * N + r] : 0.0;
+    else if (mt == KP_MODEL_BILINEAR) a = in ? Ks[c + (size_t)r * W] : 0.0;
+    ak[c] = a;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) bk[i][c] = (mt == KP_MODEL_BILINEAR && i < m && in) ? Ks[N + N * i + c + (size_t)r * W] : 0.0;
+  }
+  // columns to visit: the widest of the wave's four jobs (consecutive jobs share their degree except at a boundary)
+  int Nw = N;
+  Nw = max(Nw, __builtin_amdgcn_readlane(N, 16));
+  Nw = max(Nw, __builtin_amdgcn_readlane(N, 32));
+  Nw = max(Nw, __builtin_amdgcn_readlane(N, 48));
+  Nw = __builtin_amdgcn_readfirstlane(max(Nw, __builtin_amdgcn_readlane(N, 0)));
+  if (mt == KP_MODEL_LINEAR)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) bl[i] = (i < m && rin) ? Ball[off + (size_t)i * N + r] : 0.0;
+  double kf[4] = {0.0, 0.0, 0.0, 0.0};             // nonlinear: lane c keeps column c of Kf = K(:, 1:n)' (n <= 4 outputs)
+  if (mt == KP_MODEL_NONLINEAR)
+#pragma unroll
+    for (int o = 0; o < 4; ++o) kf[o] = (o < n && rin) ? Ks[r + (size_t)o * W] : 0.0;
+  // first validation row -> lifted state
+  if (r < n) vsh[q][r] = yv[(size_t)r * Tv];
+  if (mt == KP_MODEL_NONLINEAR && r < m) vsh[q][n + r] = uv[(size_t)r * Tv];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  double z = 0.0;
+  if (mt != KP_MODEL_NONLINEAR) { if (rin) z = kp_eval_col(bj, bj.cols[r], vsh[q], 1); }
+  else if (r < n) z = vsh[q][r];
+  double acc_e = 0.0, acc_a = 0.0;
+  double yr = r < n ? yv[(size_t)r * Tv] : 0.0;
+  double ut[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) ut[i] = i < m ? uv[(size_t)i * Tv] : 0.0;
+  for (int t = 0; t < Tv; ++t) {
+    if (r < n) {
+      if (t > 0) acc_e += fabs(z - yr);               // the first simulated row is the measured one (Ksysid.m:1654)
+      acc_a += fabs(yr);
+    }
+    if (t == Tv - 1) break;
+    // values of the next step: in flight during this one (chunks of several steps held in register arrays were
+    // measured too and were slower)
+    const double yr_n = r < n ? yv[(size_t)r * Tv + t + 1] : 0.0;
+    double ut_n[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) ut_n[i] = i < m ? uv[(size_t)i * Tv + t + 1] : 0.0;
+    double zn = 0.0;
+    if (mt != KP_MODEL_NONLINEAR) {
+      // z+ = (A + sum_i u_i B_i) z  (val_model :1685 / val_BLmodel :1783); linear: B u added below.  z[c] reaches every
+      // lane of its row through ds_swizzle (bit mode: lane' = (lane & 0x10) | c inside each half of 32 lanes - a
+      // crossbar operation of the LDS unit, no VALU slot), so a step costs N FMAs (+ N m for the bilinear coefficient)
+#define KP_COL_STEP(CC)                                                                                        \
+      if (CC < Nw) {                                                                                           \
+        double w = ak[CC];                                                                                     \
+        if (mt == KP_MODEL_BILINEAR) { w += ut[0] * bk[0][CC]; if (m > 1) w += ut[1] * bk[1][CC]; if (m > 2) w += ut[2] * bk[2][CC]; } \
+        const int zlo = __builtin_amdgcn_ds_swizzle(__double2loint(z), ((CC) << 5) | 0x10);                    \
+        const int zhi = __builtin_amdgcn_ds_swizzle(__double2hiint(z), ((CC) << 5) | 0x10);                    \
+        zn += w * __hiloint2double(zhi, zlo);                                                                  \
+      }
+      KP_COL_STEP(0) KP_COL_STEP(1) KP_COL_STEP(2) KP_COL_STEP(3) KP_COL_STEP(4) KP_COL_STEP(5) KP_COL_STEP(6) KP_COL_STEP(7)
+      KP_COL_STEP(8) KP_COL_STEP(9) KP_COL_STEP(10) KP_COL_STEP(11) KP_COL_STEP(12) KP_COL_STEP(13) KP_COL_STEP(14) KP_COL_STEP(15)
+#undef KP_COL_STEP
+      if (mt == KP_MODEL_LINEAR) zn += bl[0] * ut[0] + bl[1] * ut[1] + bl[2] * ut[2];
+    } else {                                           // zeta+ = Kf psi([zeta; u]) (val_NLmodel, Ksysid.m:1848-1863)
+      if (r < n) vsh[q][r] = z;
+      if (r < m) vsh[q][n + r] = ut[r];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      const double psi = rin ? kp_eval_col(bj, bj.cols[r], vsh[q], 1) : 0.0;
+#pragma unroll
+      for (int o = 0; o < 4; ++o)
+        if (o < n) {
+          const double sacc = sb_row_sum(kf[o] * psi);
+          if (r == o) zn = sacc;
+        }
+      __builtin_amdgcn_wave_barrier();
+    }
+    z = zn;
+    yr = yr_n;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) ut[i] = ut_n[i];
+  }
+  if (live && r < n) {
+    const double bad = stat[(size_t)dj * nb + sys] ? __builtin_nan("") : 0.0;
+    err[((size_t)dj * nb + sys) * n + r] = (acc_e / Tv) / (acc_a / Tv) + bad;
+  }
 }
 
 __global__ void kp_l1_flag_all_kernel(const double* __restrict__ Kall, const SweepDeg* __restrict__ degs, int nb, double lasso, int* __restrict__ flags) {
@@ -957,15 +1230,20 @@ extern "C" int kp_sweep_eval_nested(kp_ctx* ctx, const kp_traj* traj, const kp_b
   KP_HIP(ctx, hipMemcpyAsync(dT, degs.data(), b_tab, hipMemcpyHostToDevice, s));
   KP_HIP(ctx, hipMemcpyAsync(dCols, cols_all.data(), b_cols, hipMemcpyHostToDevice, s));
   const int Ns = traj->ntrials * (traj->T - 1) - 1;
-  size_t lds = ((size_t)(2 * b.nvars + (b.m > 0 ? b.m : 1)) * SB_TS + 2 * SB_TS * SB_LD + 5 * 16 * SB_LD + 16) * sizeof(double);
-  const size_t pw_bytes = (size_t)2 * b.nvars * basis->pow_depth * SB_TS * sizeof(double);
-  if (lds + pw_bytes > 64 * 1024 || !basis->d_recipes) return ctx->fail(KP_ERR_ARG, "kp_sweep_eval_nested: dictionary too large for the power-table lift");
-  lds += pw_bytes;
+  if (!basis->d_recipes || nv > 8) return ctx->fail(KP_ERR_ARG, "kp_sweep_eval_nested: dictionary not supported by the power-table lift");
+  const size_t lds = ((size_t)2 * TG_TS * SB_LD + (size_t)2 * nv * Dp * TG_TS + 2 * 16 * SB_LD) * sizeof(double);
+  if (lds > 150 * 1024) return ctx->fail(KP_ERR_ARG, "kp_sweep_eval_nested: dictionary too large for the power-table lift");
+  {
+    static KpLdsCache tg_lds;
+    KP_HIP(ctx, kp_ensure_lds(tg_lds, (const void*)kp_traj_gram_kernel, lds));
+  }
+  KP_HIP(ctx, hipMemsetAsync(dS0, 0, (size_t)nb * 4, s));
   KP_HIP(ctx, hipEventRecord(ctx->ev0, s));
-  hipLaunchKernelGGL(kp_small_fit_kernel, dim3(nb), dim3(256), lds, s, b, nullptr, nullptr, nullptr, (int64_t)0, Ns, dKc, dGc, dCc, dS0,
-                     (const uint32_t*)basis->d_recipes, basis->pow_depth, basis->max_factors > 0 ? basis->max_factors : 1, 0, traj_view(traj), 1);
+  hipLaunchKernelGGL(kp_traj_gram_kernel, dim3(nb), dim3(256), lds, s, b, (const uint32_t*)basis->d_recipes, Dp, basis->max_factors > 0 ? basis->max_factors : 1,
+                     traj_view(traj), Ns, 1, dGc, dCc);
   KP_HIP(ctx, hipGetLastError());
   KP_HIP(ctx, hipEventRecord(ctx->ev1, s));
+  (void)dKc;
   const dim3 grid(nb, n_deg);
   hipLaunchKernelGGL(kp_sweep_sub_kernel, grid, dim3(256), 0, s, dGc, dCc, Wmax, nb, dT, (const int*)nullptr, dK, dG, dC, dS);
   KP_HIP(ctx, hipGetLastError());
@@ -986,8 +1264,14 @@ extern "C" int kp_sweep_eval_nested(kp_ctx* ctx, const kp_traj* traj, const kp_b
     hipLaunchKernelGGL(kp_sweep_project_kernel, grid, dim3(256), 0, s, dK, dG, dC, nb, m, dT, dA, dB);
     KP_HIP(ctx, hipGetLastError());
   }
-  hipLaunchKernelGGL(kp_sweep_rollout_nested_kernel, grid, dim3(64), 0, s, b, dT, dCols, nb, dK, b.model_type == KP_MODEL_LINEAR ? dA : nullptr,
-                     b.model_type == KP_MODEL_LINEAR ? dB : nullptr, traj->Yv, traj->Uv, traj->Tv, dS, dE);
+  static const bool rollout4 = getenv("KP_SWEEP_NO_ROLLOUT4") == nullptr;
+  if (rollout4 && n <= 4)
+    hipLaunchKernelGGL(kp_sweep_rollout4_kernel, dim3((nb * n_deg + 3) / 4), dim3(64), 0, s, b, dT, dCols, nb, n_deg, dK,
+                       b.model_type == KP_MODEL_LINEAR ? dA : nullptr, b.model_type == KP_MODEL_LINEAR ? dB : nullptr, traj->Yv, traj->Uv, traj->Tv,
+                       dS, dE);
+  else
+    hipLaunchKernelGGL(kp_sweep_rollout_nested_kernel, grid, dim3(64), 0, s, b, dT, dCols, nb, dK, b.model_type == KP_MODEL_LINEAR ? dA : nullptr,
+                       b.model_type == KP_MODEL_LINEAR ? dB : nullptr, traj->Yv, traj->Uv, traj->Tv, dS, dE);
   KP_HIP(ctx, hipGetLastError());
   KP_HIP(ctx, hipMemcpyAsync(err_out, dE, (size_t)n_deg * nb * n * 8, hipMemcpyDeviceToHost, s));
   if (status_out) KP_HIP(ctx, hipMemcpyAsync(status_out, dS, (size_t)n_deg * nb * 4, hipMemcpyDeviceToHost, s));
