@@ -43,6 +43,8 @@ struct kp_mpc {
   size_t work_problems = 0;
   double *d_in = nullptr, *d_out = nullptr;     // d_out: x (nvar) and z (N) per problem, then the status words
   double *h_in = nullptr, *h_out = nullptr;     // pinned staging buffers: one copy in, one copy out per step
+  unsigned long long* h_flag = nullptr;         // pinned: [0] sequence number of the last finished single step, [1] start, [2] end stamp
+  unsigned long long step_seq = 0;
   int* warm = nullptr;                          // device: [count, rows...] optimal active set of the last single step
   int* d_status = nullptr;                      // points into d_out
   size_t io_problems = 0;
@@ -643,6 +645,8 @@ struct MpcArgs {
   double* qp_export;    // [nb][nvar*nvar + nvar + nrows] or nullptr
   int* status;          // [nb]
   long long* stamps;    // [8] wall_clock64 stamps + [8] counters of problem 0 (diagnostics), or nullptr
+  unsigned long long* done_flag;   // pinned host word: the kernel stores done_seq there when its outputs are visible (or nullptr)
+  unsigned long long done_seq;
 };
 
 // LDS (doubles): z N | beta N*m | S Np*nproj*m | e (Np+1)*nproj | Hq nvar^2 | f nvar | b nrows | zh (Np+1)*N (iters>1)
@@ -881,6 +885,17 @@ __global__ __launch_bounds__(256) void kp_mpc_step_kernel(MpcArgs a) {
     lifted_horizon(xout);
   }
   if (tid == 0) a.status[pb] = status ? KP_ERR_QP_FAIL : KP_OK;
+  if (a.done_flag && pb == 0) {
+    // single zero-copy step: tell the spinning host thread that U, z and the status are in its memory.  Every wave has
+    // waited for its stores at the barrier; lane 0 then releases at system scope and stores the sequence number.
+    __syncthreads();
+    if (tid == 0) {
+      __threadfence_system();
+      if (stamps) { a.done_flag[1] = (unsigned long long)stamps[0]; a.done_flag[2] = (unsigned long long)wall_clock64(); }
+      __threadfence_system();
+      __hip_atomic_store(&a.done_flag[0], a.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
 }
 
 // ---- host API ------------------------------------------------------------------------------------
@@ -1254,12 +1269,26 @@ static int mpc_run(kp_mpc* M, const kp_basis* basis, int nb, const double* z, co
   a.warm = (nb == 1 && !no_warm) ? M->warm : nullptr;
   a.status = zc ? (int*)(M->h_out + M->io_problems * n_out) : M->d_status;
   a.stamps = nb == 1 ? (long long*)(M->work + n_ex) : nullptr;
+  // single zero-copy step without state bounds: the host does not go through hipStreamSynchronize (a 15-20 us wake-up) or
+  // event records - the kernel stores a sequence number into pinned memory behind its outputs and the host spins on it
+  static const bool no_spin = getenv("KP_MPC_NO_SPIN") != nullptr;
+  const bool spin = zc && !sb && !no_spin;
+  a.done_flag = nullptr;
+  a.done_seq = 0;
+  if (spin) {
+    if (!M->h_flag) {
+      KP_HIP(ctx, hipHostMalloc((void**)&M->h_flag, 64, hipHostMallocDefault));
+      memset(M->h_flag, 0, 64);
+    }
+    a.done_flag = M->h_flag;
+    a.done_seq = ++M->step_seq;
+  }
   size_t lds = (size_t)mpc_lds_doubles(N, m, Np, nproj, nv, nr, (sb && iters > 1) ? 2 : iters, zeta ? basis->dev.nfull : 0) * 8 + 32;
   if (lds > 160 * 1024) return ctx->fail(KP_ERR_ARG, "kp_mpc_step: problem too large for LDS");
   static KpLdsCache step_lds[2];
   const int wk = a.warm != nullptr;
   KP_HIP(ctx, kp_ensure_lds(step_lds[wk], wk ? (const void*)kp_mpc_step_kernel<true> : (const void*)kp_mpc_step_kernel<false>, lds));
-  KP_HIP(ctx, hipEventRecord(ctx->evp[4], ctx->stream));
+  if (!spin) KP_HIP(ctx, hipEventRecord(ctx->evp[4], ctx->stream));
   if (!sb) {
     if (wk) hipLaunchKernelGGL(kp_mpc_step_kernel<true>, dim3(nb), dim3(256), lds, ctx->stream, a);
     else hipLaunchKernelGGL(kp_mpc_step_kernel<false>, dim3(nb), dim3(256), lds, ctx->stream, a);
@@ -1297,11 +1326,19 @@ static int mpc_run(kp_mpc* M, const kp_basis* basis, int nb, const double* z, co
     if (nb == 1)   // kp_mpc_last_qp reads the single-problem export
       KP_HIP(ctx, hipMemcpyAsync(M->work, M->sb_work, n_ex * 8, hipMemcpyDeviceToDevice, ctx->stream));
   }
-  KP_HIP(ctx, hipEventRecord(ctx->evp[5], ctx->stream));
+  if (!spin) KP_HIP(ctx, hipEventRecord(ctx->evp[5], ctx->stream));
   // one device-to-host copy: x and z of every problem, then the status words
   const size_t out_bytes = M->io_problems * n_out * 8 + (size_t)nb * sizeof(int);
   if (!zc) KP_HIP(ctx, hipMemcpyAsync(M->h_out, M->d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
-  KP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  bool spun = false;
+  if (spin) {
+    volatile unsigned long long* fl = M->h_flag;
+    for (long it = 0; it < 20000000L; ++it) {          // a few ms at most; a slower kernel falls through to the stream wait
+      if (__atomic_load_n(&fl[0], __ATOMIC_ACQUIRE) == a.done_seq) { spun = true; break; }
+      __builtin_ia32_pause();
+    }
+  }
+  if (!spun) KP_HIP(ctx, hipStreamSynchronize(ctx->stream));
   // x = [u_0; u_1; ...] (m each)  ->  U (Np x m column-major) = reshape(x,[m,Np])'  (Kmpc.m:884)
   const double* x = M->h_out;
   const int* st = (const int*)(M->h_out + M->io_problems * n_out);
@@ -1312,7 +1349,8 @@ static int mpc_run(kp_mpc* M, const kp_basis* basis, int nb, const double* z, co
     if (status) status[p] = st[p];
   }
   float ms = 0;
-  if (hipEventElapsedTime(&ms, ctx->evp[4], ctx->evp[5]) == hipSuccess) ctx->timers[2] = ms;
+  if (spin) ctx->timers[2] = (double)(M->h_flag[2] - M->h_flag[1]) * 1e-5;        // wall_clock64 ticks of 10 ns -> ms
+  else if (hipEventElapsedTime(&ms, ctx->evp[4], ctx->evp[5]) == hipSuccess) ctx->timers[2] = ms;
   return KP_OK;
 }
 
