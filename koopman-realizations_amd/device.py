@@ -411,6 +411,7 @@ class Mpc:
         ctx._children.add(self)
         A = F.fcol(A); B = F.fcol(B); proj = F.fcol(np.atleast_2d(proj))
         self.N, self.m, self.Np, self.nproj = A.shape[0], len(np.atleast_1d(r)), int(Np), proj.shape[0]
+        self._zcall = None
         r = np.ascontiguousarray(np.atleast_1d(r), dtype=np.float64)
         lo_ = None if lo is None else np.ascontiguousarray(lo, dtype=np.float64)
         hi_ = None if hi is None else np.ascontiguousarray(hi, dtype=np.float64)
@@ -447,13 +448,21 @@ class Mpc:
         return U, st.value
 
     def step_zeta(self, basis: Basis, zeta, u_prev, Yr, iters=1):
-        zeta = np.ascontiguousarray(zeta, dtype=np.float64); up = np.ascontiguousarray(u_prev, dtype=np.float64)
-        yr = np.ascontiguousarray(Yr, dtype=np.float64)
-        U = np.zeros((self.Np, self.m), order="F"); z = np.zeros(self.N)
-        st = C.c_int()
-        F.check(F.lib().kp_mpc_step_zeta(self._h, basis.handle, F.dptr(zeta), F.dptr(up), F.dptr(yr), int(iters),
-                                         F.dptr(U), F.dptr(z), C.byref(st)), self.ctx.handle)
-        return U, z, st.value
+        """One controller call with the lift fused in front (Kmpc.m:842).  This is the call inside a closed loop, so the
+        marshalling is kept off its path: argument buffers and their ctypes pointers are made once per (controller,
+        dictionary) and the inputs are copied into them."""
+        cb = self._zcall
+        if cb is None or cb[0] is not basis:
+            zb = np.zeros(basis.nzeta); ub = np.zeros(self.m); yb = np.zeros(self.nproj * (self.Np + 1))
+            Ub = np.zeros((self.Np, self.m), order="F"); zo = np.zeros(self.N); st = C.c_int()
+            cb = self._zcall = (basis, zb, ub, yb, Ub, zo, st, F.dptr(zb), F.dptr(ub), F.dptr(yb), F.dptr(Ub), F.dptr(zo), C.byref(st),
+                                F.lib().kp_mpc_step_zeta)
+        _, zb, ub, yb, Ub, zo, st, pz, pu, py, pU, pzo, pst, fn = cb
+        zb[...] = zeta; ub[...] = u_prev; yb[...] = Yr
+        rc = fn(self._h, basis._h, pz, pu, py, int(iters), pU, pzo, pst)
+        if rc:
+            F.check(rc, self.ctx.handle)
+        return Ub.copy(order="F"), zo.copy(), st.value
 
     def step_batch(self, Z, U_prev, YR):
         """Z (nb,N), U_prev (nb,m), YR (nb, nproj*(Np+1)) -> U (nb, Np, m), status (nb,)."""
