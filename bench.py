@@ -420,7 +420,12 @@ def main():
         widths = bench_width_points(ctx, kra, Ns)
     lasso_res = sweep_res = None
     if extras_on:                                        # sharded sections: every rank takes part
-        lasso_res = bench_lasso(ctx, comm, kra, basis, snaps)
+        # the grid belongs to ONE fit: every rank holds the same snapshot matrix (rank 0's) for this section
+        snaps_l = snaps
+        if rank != 0:
+            a0, b0, u0 = synth_pairs(Ns, seed=0)
+            snaps_l = kra.Snapshots(ctx, a0, b0, u0)
+        lasso_res = bench_lasso(ctx, comm, kra, basis, snaps_l)
         sweep_res = bench_rand_sweep(ctx, comm, kra, chunks, n_chunks * RAND_CHUNK)
 
     if rank == 0:

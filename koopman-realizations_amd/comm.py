@@ -73,6 +73,47 @@ class RcclComm:
         F.lib().kp_comm_destroy(self.ctx.handle)
 
 
+class FileComm:
+    """Debugging stand-in for RcclComm on a box with fewer GPUs than ranks (RCCL refuses two ranks on one device): the
+    same four members, collectives through files in a directory all ranks share.  Selected with KP_COMM_BACKEND=file;
+    never the measured path."""
+
+    def __init__(self, ctx, rank: int, world: int, directory: str):
+        self.ctx, self.rank, self.world, self.dir, self.seq = ctx, int(rank), int(world), directory, 0
+        os.makedirs(directory, exist_ok=True)
+
+    def all_gather_bytes(self, payload: bytes, timeout: float = 300.0):
+        self.seq += 1
+        mine = os.path.join(self.dir, f"{self.seq}_{self.rank}")
+        with open(mine + ".tmp", "wb") as f:
+            f.write(bytes(payload))
+        os.replace(mine + ".tmp", mine)
+        out = []
+        t0 = time.time()
+        for r in range(self.world):
+            path = os.path.join(self.dir, f"{self.seq}_{r}")
+            while not os.path.exists(path):
+                if time.time() - t0 > timeout:
+                    raise TimeoutError(f"FileComm: rank {r} never wrote step {self.seq}")
+                time.sleep(0.001)
+            with open(path, "rb") as f:
+                out.append(f.read())
+        return out
+
+    def all_reduce_sum(self, a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        return all_gather_array(self, a).sum(axis=0)
+
+    def barrier(self):
+        self.all_gather_bytes(b"x")
+
+    def all_gather_fit(self, index: int, W: int):
+        return all_gather_array(self, np.ascontiguousarray(self.ctx.fit_result(index, W)))
+
+    def close(self):
+        pass
+
+
 # ---- generic collectives on top of all_gather_bytes ------------------------------------------------------------
 
 def all_gather_array(comm, a):
@@ -151,6 +192,8 @@ def init_from_env(Context):
     if world == 1:
         return ctx, LocalComm()
     path = rendezvous_file_from_env()
+    if os.environ.get("KP_COMM_BACKEND") == "file":      # debugging only: see FileComm
+        return ctx, FileComm(ctx, rank, world, path + ".d")
     uid = exchange_unique_id(rank, path)
     comm = RcclComm(ctx, rank, world, uid)
     comm.barrier()
