@@ -365,6 +365,11 @@ def main():
     n_chunks = max(1, args.rand_systems // RAND_CHUNK)
     chunks = gen_rand_systems([c for c in range(n_chunks) if c % world == rank]) if extras_on else {}
 
+    # the generated systems are ~35k long-lived Python objects: keep the cyclic collector from walking them inside the timed
+    # regions (a generation-2 pass costs milliseconds and lands wherever the allocation counter trips)
+    import gc
+    gc.collect()
+    gc.freeze()
     import koopman_realizations_amd as kra
     ctx, comm = kc.init_from_env(kra.Context)      # one process per GPU; RCCL communicator through the C ABI when world > 1
     Ns = args.snapshots

@@ -638,6 +638,12 @@ extern "C" int kp_fit(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* sn
       // deferred solves: this fit's [G | C] goes into the next slot of the ring; nothing else runs beside the Gram kernel
       rc = ensure_gc(ctx, W, sbatch);
       if (rc) return rc;
+      {   // the batched solve's padded workspace, sized for a full batch NOW: growing it at the first full flush would put a
+          // hipFree / hipMalloc of ~150 MB (tens of ms) in the middle of the pipeline
+        const int np_ = (W + 15) / 16 * 16;
+        const size_t per = (size_t)np_ * np_ * 8 * 2 + (size_t)(np_ / 16) * 256 * 8;
+        if (!ctx->workspace(5, (size_t)sbatch * per + (size_t)sbatch * 4 + 64)) return ctx->fail(KP_ERR_HIP, "kp_fit: out of device memory");
+      }
       if (ctx->pend_solves == 0) ctx->pend_first = ctx->async_count;
       double* GCs = ctx->GC + (size_t)ctx->pend_solves * 2 * W * W;
       ctx->reserve_cus = 0;
