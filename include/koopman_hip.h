@@ -11,7 +11,8 @@
  *   - every pointer is a HOST pointer unless the name ends in _dev or the type is an
  *     opaque handle; the library copies in/out and never keeps caller pointers;
  *   - every function returns KP_OK (0) or a negative kp_status; kp_last_error() gives text;
- *   - handles own device memory and are freed by the matching *_destroy;
+ *   - handles own device memory and are freed by the matching *_destroy; kp_basis, kp_snapshots, kp_traj and kp_mpc
+ *     handles point into the kp_ctx they were created on and must be destroyed BEFORE it (kp_destroy does not track them);
  *   - calls on one kp_ctx are serialised by the caller (MATLAB is single threaded);
  *     the library synchronises its stream before returning host results.
  */
