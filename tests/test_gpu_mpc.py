@@ -242,14 +242,14 @@ def test_kmpc_ksim_mirror_example_control_flow(ctx, golden):
     assert np.abs(ks.scaleup_u(Uo[1]) - res["U"][1]).max() < 1e-7
 
 
-def _example_control(ctx, golden, mt):
+def _example_control(ctx, golden, mt, input_bounds=(-7 * np.pi / 8, 7 * np.pi / 8)):
     g = golden["arm_data"]; gp = golden["arm_plant"]
     lens = g["train_len"]; off = np.concatenate([[0], np.cumsum(lens)])
     train = [{"t": g["train_t"][a:b], "y": g["train_y"][a:b], "u": g["train_u"][a:b]} for a, b in zip(off[:-1], off[1:])]
     val = [{"t": g["val_t"], "y": g["val_y"], "u": g["val_u"]}]
     ks = kra.Ksysid({"train": train, "val": val}, ctx=ctx, model_type=mt, obs_type=["poly"], obs_degree=[3],
                     snapshots=np.inf, lasso=[np.inf], delays=0, dim_red=True).train_models()
-    mpc = kra.Kmpc(ks, horizon=10, input_bounds=[-7 * np.pi / 8, 7 * np.pi / 8], input_slopeConst=1e-1, input_smoothConst=None,
+    mpc = kra.Kmpc(ks, horizon=10, input_bounds=list(input_bounds), input_slopeConst=1e-1, input_smoothConst=None,
                    state_bounds=None, cost_running=10, cost_terminal=100, cost_input=0.1 * np.array([3e-2, 2e-2, 1e-2]),
                    projmtx=ks.model["C"][-2:, :])
     params = {k[2:]: (float(gp[k]) if gp[k].ndim == 0 else gp[k]) for k in gp.files if k.startswith("p_")}
@@ -271,6 +271,26 @@ def test_example_control_true_arm_closed_loop_bilinear(ctx, golden):
     assert (du <= 1e-1 * ks.params["scale"]["u_factor"].mean() * ks.params["scale"]["u_factor"] + 1e-8).all()
     # the end effector ends within 1 cm of the stored run's end point
     assert np.abs(res["Y"][-1, -2:] - golden["arm_blockM"]["bilin_Y"][-1, -2:]).max() < 1e-2
+
+
+def test_free_running_closed_loop_reproduces_the_stored_matlab_run(ctx, golden):
+    """The whole chain with nothing teacher-forced: fit on the device, Kmpc on the device, the arm plant integrated by
+    the ode45 restatement, 300 closed-loop steps (Ksim.m:167-270).  With the constraint set the stored sequences were
+    generated under (slope constraint only, see test_oracle_golden.py) the free-running loop stays on the stored MATLAB
+    trajectory `res_bilin`: outputs to 1e-4, inputs to 2e-3 (of a +-2.7 range; differences of quadprog's 1e-8-level
+    optimum are fed back through the plant 300 times), mean tracking error to 6 digits.  The linear loop is a chaotic
+    limit cycle (stored mean error 0.74): it is compared over its first 100 steps only."""
+    ks, mpc, sim = _example_control(ctx, golden, "bilinear", input_bounds=())
+    res = sim.run_trial_mpc(golden["blockM_ref"]["y"], None, None)
+    st = golden["arm_blockM"]
+    assert np.abs(res["Y"] - st["bilin_Y"][:301]).max() < 1e-4
+    assert np.abs(res["U"][:300] - st["bilin_U"][:300]).max() < 2e-3
+    stored = float(golden["arm_plant"]["bilin_err"].mean())
+    assert abs(res["err"].mean() - stored) < 1e-6 * stored * 10
+    ks, mpc, sim = _example_control(ctx, golden, "linear", input_bounds=())
+    res = sim.run_trial_mpc(golden["blockM_ref"]["y"][:112], None, None)
+    assert np.abs(res["Y"][:100] - st["lin_Y"][:100]).max() < 1e-2
+    assert np.abs(res["U"][:100] - st["lin_U"][:100]).max() < 5e-2
 
 
 def test_example_control_linear_first_input_matches_stored_run(ctx, golden):
