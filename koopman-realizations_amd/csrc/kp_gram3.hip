@@ -253,6 +253,10 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
       p0 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, b0, p0, 0, 0, 0);
       p1 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, b1, p1, 0, 0, 0);
     }
+    // the full dictionary's constant (0 past Ns: the tail mask) is read BEFORE the barrier: with nzeta + k_pcs >= nfull
+    // the components written below land on its column
+    const int crow = BUF * PSIBUF3 + PSI03 + (tid & (KT3 - 1)) * RS3 + ((tid / KT3) & 1) * YOFF3;
+    const double one = sm[crow + b.nfull - 1];
     __syncthreads();
     {
       const int srow = BUF * PSIBUF3 + PSI03 + (4 * rg + (lane >> 4)) * RS3 + side * YOFF3;
@@ -261,10 +265,8 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
       if (pc + 16 < b.k_pcs) sm[srow + b.nzeta + pc + 16] = p1;
     }
     if (tid < 2 * KT3) {
-      const int srow = BUF * PSIBUF3 + PSI03 + (tid & (KT3 - 1)) * RS3 + (tid / KT3) * YOFF3;
-      const double one = sm[srow + b.nfull - 1];          // the full dictionary's constant (0 past Ns: the tail mask)
-      sm[srow + b.N - 1] = one;
-      for (int c = b.N; c < 4 * a.G4; ++c) sm[srow + c] = 0.0;
+      sm[crow + b.N - 1] = one;
+      for (int c = b.N; c < 4 * a.G4; ++c) sm[crow + c] = 0.0;
     }
     __syncthreads();
   };

@@ -184,6 +184,18 @@ extern "C" int kp_model_project(kp_ctx* ctx, const double* K, const double* G, c
   KP_HIP(ctx, gemm(s, 1, 0, N, N, W, 1.0, Kd, W, Cd, W, 0.0, LtR, N));     // K1' C(:,1:N)
   int rc = kp_chol_solve_dev(ctx, LtL, LtR, N, N, Mt);                       // M' = (L'L) \ (L'R)
   if (rc) return rc;
+  {
+    int bad = 0;
+    const int np = (N + 15) / 16 * 16;
+    size_t off = (size_t)np * np * 8 + (size_t)np * np * 8 + (size_t)(np / 16) * 256 * 8;
+    KP_HIP(ctx, hipMemcpyAsync(&bad, (char*)ctx->ws[5] + off, sizeof(int), hipMemcpyDeviceToHost, s));
+    KP_HIP(ctx, hipStreamSynchronize(s));
+    if (bad) {   // L is rank deficient (a rank-deficient K): `M = L \ R` (Ksysid.m:1218) returns a basic solution; same here
+      int r = 0;
+      rc = kp_pivchol_solve_dev(ctx, LtL, LtR, N, N, Mt, &r);
+      if (rc) return rc;
+    }
+  }
   int64_t nn = (int64_t)N * N;
   hipLaunchKernelGGL(kp_transpose_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, s, Kd, N, N, W, At);   // A = K(1:N,1:N)'
   if (m > 0) {
@@ -197,14 +209,7 @@ extern "C" int kp_model_project(kp_ctx* ctx, const double* K, const double* G, c
   KP_HIP(ctx, hipMemcpyAsync(A_out, MA, bN, hipMemcpyDeviceToHost, s));
   if (m > 0) KP_HIP(ctx, hipMemcpyAsync(B_out, MB, (size_t)N * m * 8, hipMemcpyDeviceToHost, s));
   KP_HIP(ctx, hipMemcpyAsync(M_out, Md, bN, hipMemcpyDeviceToHost, s));
-  int bad = 0;
-  {
-    const int np = (N + 15) / 16 * 16;
-    size_t off = (size_t)np * np * 8 + (size_t)np * np * 8 + (size_t)(np / 16) * 256 * 8;
-    KP_HIP(ctx, hipMemcpyAsync(&bad, (char*)ctx->ws[5] + off, sizeof(int), hipMemcpyDeviceToHost, s));
-  }
   KP_HIP(ctx, hipStreamSynchronize(s));
-  if (bad) return ctx->fail(KP_ERR_NOT_SPD, "kp_model_project: L'L is not positive definite");
   return KP_OK;
 }
 

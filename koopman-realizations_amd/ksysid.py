@@ -7,10 +7,9 @@ arrays with MATLAB's shapes (rows = time steps / snapshots).  All heavy arithmet
 this file only does what the MATLAB host does around those calls: option parsing,
 scaling bookkeeping, snapshot selection, dictionary description.
 
-loaded=True (Ksysid.m:539-626: lifted state psi (x) [1; w] for a load vector w) is expressed with the same device
-kernels: for monomial dictionaries w_i * psi_k is again a monomial, over the variables [zeta; w], so the loaded
-dictionary is an exponent table and the columns only have to be put back into the reference's block order
-(`_loaded_perm`).  Limits: 'poly' observables, no dim_red.
+loaded=True (Ksysid.m:539-626: lifted state [1; w] (x) psi for a load vector w) is expressed with the same device
+kernels: [1; u] (x) [1; w] (x) psi is the bilinear row of psi for a pseudo-input built from u and w, so any dictionary
+(every obs_type, with or without dim_red) goes through the Kronecker Gram kernels unchanged (`_def_observables_loaded`).
 Not supported (KP scope): time_type='continuous'.
 """
 from __future__ import annotations
@@ -90,7 +89,7 @@ class _Lift:
         """lift.econ_full_loaded (Ksysid.m:1606-1612): [psi, w_1 psi, ...] with psi = econ_full(v)."""
         return self._o._lift_loaded(F.LIFT_FULL, v, w, None)
 
-    full_loaded = econ_full_loaded        # no dim_red for loaded systems here: the two coincide (:1444)
+    full_loaded = econ_full_loaded        # the handle the reference keeps after dim_red is the econ one (:1524)
 
     def econ_full_loaded_input(self, zeta, w, u):
         """lift.econ_full_loaded_input (Ksysid.m:1580-1591), bilinear only: kron(eye(m+1), full_loaded) * [1; u]."""
@@ -149,8 +148,6 @@ class Ksysid:
         p["nd"] = int(self.delays)
         p["nzeta"] = p["n"] * (p["nd"] + 1) + p["m"] * p["nd"]             # :86
         p["nw"] = np.atleast_2d(np.asarray(data["w"], dtype=np.float64)).reshape(len(t0), -1).shape[1] if self.loaded else 0   # :89-93
-        if self.loaded and (self.dim_red or any(k != "poly" for k in self.obs_type)):
-            raise NotImplementedError("loaded systems: 'poly' observables without dim_red")
         self.basis_loaded_dev = None
         self._gauss_centres = gaussian_centres
         self._rng = np.random.default_rng(snapshot_seed)
@@ -165,6 +162,8 @@ class Ksysid:
         # state): lift on the device, SVD of the lifted matrix on the host - as the reference's `pca` does
         Px = self.lift_snapshots(self.snapshotPairs) if (self.dim_red and (self._pca_host or self.basis_dev.nfull > 256)) else None   # :137-141
         self.get_econ_observables(Px)                                      # :142
+        if self.loaded and not self._host_only:
+            self._def_observables_loaded()                                 # :112-113 (after dim_red: the econ_* loaded lifts, :1521-1565)
         self.lift = _Lift(self)
 
     # ---- dictionary ----------------------------------------------------------------
@@ -202,64 +201,76 @@ class Ksysid:
         self.basis_dev = Basis(self.ctx, self.model_type, p["nzeta"], p["m"], blocks, None)
         p["N"] = self.basis_dev.nfull                                      # :534
         self.basis["blocks"] = blocks
-        if self.loaded:
-            self._def_observables_loaded()
 
     def _def_observables_loaded(self):
-        """def_observables_loaded (Ksysid.m:539-626).  Reference order of the loaded dictionary: blocks
-        [psi ; w_1 psi ; ... ; w_nw psi] (:596-599) with psi = [zeta ; poly blocks ; 1] over zeta (or [zeta ; u] for
-        'nonlinear').  Device dictionary: the same monomials over the variables [zeta ; w] ([zeta ; w ; u] for
-        'nonlinear'), which the library orders [identity of every variable ; given rows ; 1]; `_loaded_perm[c]` is the
-        device column of reference column c."""
+        """def_observables_loaded (Ksysid.m:539-626) and the econ_* loaded lifts (:1580-1612).  The loaded lifted state
+        is [1; w] (x) psi with psi = econ_full (any dictionary, with or without dim_red), the bilinear row
+        [1; u] (x) [1; w] (x) psi (:1587-1590) - by associativity the ordinary bilinear row of psi for the pseudo-input
+        ([1; u] (x) [1; w]) minus its leading 1, in the reference's column order.  So the device dictionary of a loaded
+        system is the unloaded one declared 'bilinear' with a pseudo-input:
+          bilinear   zeta,        pseudo-input kron([1;u],[1;w])(2:end)           width N (nw+1)(m+1)
+          nonlinear  [zeta; u],   pseudo-input w                                   width N (nw+1)        (:1036)
+          linear     zeta,        pseudo-input [w; u]; the reference's row [ [1;w] (x) psi , u ] (:1056-1063) is the
+                     column subset `_loaded_sub` of it (u_j = u_j * the constant observable that ends psi)."""
         p = self.params
-        nz, nw, m = p["nzeta"], p["nw"], p["m"]
-        nonlin = self.model_type == "nonlinear"
-        nv_ref = self._nvars                                      # nzeta (+ m)
-        nv_dev = nz + nw + (m if nonlin else 0)
-        E = np.vstack([np.eye(nv_ref, dtype=np.uint8)] + [np.asarray(b[1], dtype=np.uint8) for b in self._blocks] +
-                      [np.zeros((1, nv_ref), dtype=np.uint8)])    # psi: identity, poly rows of every block, constant
-        col = list(range(nz)) + ([nz + nw + j for j in range(m)] if nonlin else [])      # reference variable -> device variable
-        rows = np.zeros(((nw + 1) * E.shape[0], nv_dev), dtype=np.uint8)
-        for i in range(nw + 1):
-            blk = rows[i * E.shape[0]:(i + 1) * E.shape[0]]
-            blk[:, col] = E
-            if i > 0:
-                blk[:, nz + i - 1] = 1                            # times w_i
-        poly, perm = [], np.zeros(rows.shape[0], dtype=np.int64)
-        for c, r in enumerate(rows):
-            tot = int(r.sum())
-            if tot == 0:
-                perm[c] = -1                                      # constant: last device column
-            elif tot == 1:
-                perm[c] = int(np.argmax(r))                       # a bare variable: identity part
-            else:
-                perm[c] = nv_dev + len(poly); poly.append(r)
-        perm[perm < 0] = nv_dev + len(poly)
-        self.basis_loaded_dev = Basis(self.ctx, self.model_type, nz + nw, m, [("poly", np.array(poly, dtype=np.uint8).reshape(-1, nv_dev))], None)
-        assert self.basis_loaded_dev.nfull == rows.shape[0] and sorted(perm) == list(range(rows.shape[0]))
-        self._loaded_perm = perm
-        NL = rows.shape[0]
-        if self.model_type == "bilinear":                         # [Psi_L ; u_1 Psi_L ; ...]
-            self._loaded_perm_W = np.concatenate([b * NL + perm for b in range(m + 1)])
-        elif self.model_type == "linear":                         # [Psi_L ; u]
-            self._loaded_perm_W = np.concatenate([perm, NL + np.arange(m)])
+        nz, nw, m, N = p["nzeta"], p["nw"], p["m"], p["N"]
+        pcs = self.basis.get("pcs")
+        NL = N * (nw + 1)
+        if self.model_type == "bilinear":
+            nvar, mp, sub = nz, (m + 1) * (nw + 1) - 1, None
+        elif self.model_type == "nonlinear":
+            nvar, mp, sub = nz + m, nw, None
         else:
-            self._loaded_perm_W = perm
+            nvar, mp = nz, nw + m
+            sub = np.concatenate([np.arange(NL), NL + N * np.arange(m) + N - 1])
+        self.basis_loaded_dev = Basis(self.ctx, "bilinear", nvar, mp, self._blocks, pcs)
+        assert self.basis_loaded_dev.N == N
+        self._loaded_sub = sub
+
+    def _loaded_args(self, v, w, u):
+        """(state rows, pseudo-input rows) of the device dictionary of a loaded system."""
+        p = self.params; nw, m = p["nw"], p["m"]
+        rows = v.shape[0]
+        Wl = np.asarray(w, dtype=np.float64).reshape(rows, -1)
+        if self.model_type == "nonlinear":
+            return v, Wl
+        uu = np.zeros((rows, m)) if u is None else np.asarray(u, dtype=np.float64).reshape(rows, -1)
+        if self.model_type == "linear":
+            return v, np.hstack([Wl, uu])
+        one = np.ones((rows, 1))
+        wu = (np.hstack([one, uu])[:, :, None] * np.hstack([one, Wl])[:, None, :]).reshape(rows, -1)
+        return v, wu[:, 1:]
 
     def _lift_loaded(self, what, v, w, u):
-        """Rows of the loaded lift in the reference's column order; v = zeta (or [zeta, u] for 'nonlinear')."""
-        p = self.params; nz, m = p["nzeta"], p["m"]
+        """Rows of the loaded lift in the reference's column order; v = zeta (or [zeta, u] for 'nonlinear').
+        LIFT_FULL: [1; w] (x) psi (econ_full_loaded, :1606-1612); LIFT_ROW: the row of Px (:1034-1064)."""
         V = np.asarray(v, dtype=np.float64); vec = V.ndim == 1 or (V.ndim == 2 and V.shape[1] == 1)
         V = V.reshape(1, -1) if vec else V
-        Wl = np.asarray(w, dtype=np.float64).reshape(V.shape[0], -1)
-        zw = np.hstack([V[:, :nz], Wl])
-        if self.model_type == "nonlinear":
-            uu = V[:, nz:nz + m]
-        else:
-            uu = None if u is None else np.asarray(u, dtype=np.float64).reshape(V.shape[0], -1)
-        out = self.basis_loaded_dev.lift(what, zw, uu)
-        out = out[:, self._loaded_perm_W if what == F.LIFT_ROW else self._loaded_perm]
+        x, pu = self._loaded_args(V, w, u)
+        out = self.basis_loaded_dev.lift(F.LIFT_ROW, x, pu)
+        NL = self.params["N"] * (self.params["nw"] + 1)
+        if what != F.LIFT_ROW:
+            out = out[:, :NL]
+        elif self._loaded_sub is not None:
+            out = out[:, self._loaded_sub]
         return out[0] if vec else out
+
+    def _loaded_snapshots(self, sp):
+        w = np.asarray(sp["w"], dtype=np.float64).reshape(len(sp["alpha"]), -1)
+        if self.model_type == "nonlinear":
+            a, b = np.hstack([sp["alpha"], sp["u"]]), np.hstack([sp["beta"], sp["u"]])       # :1036-1037
+        else:
+            a, b = sp["alpha"], sp["beta"]
+        _, pu = self._loaded_args(a, w, sp["u"])
+        return Snapshots(self.ctx, a, b, pu), w
+
+    def _loaded_grams(self, snaps):
+        """Px'Px, Px'Py of the loaded rows (for 'linear': the sub-matrices of the pseudo-input Grams)."""
+        G, Cm = fit_gram(self.ctx, self.basis_loaded_dev, snaps)
+        if self._loaded_sub is not None:
+            ix = np.ix_(self._loaded_sub, self._loaded_sub)
+            G, Cm = np.asfortranarray(G[ix]), np.asfortranarray(Cm[ix])
+        return G, Cm
 
     # ---- data handling ---------------------------------------------------------------
     @staticmethod
@@ -442,21 +453,24 @@ class Ksysid:
         return koop
 
     def _get_Koopman_loaded(self, sp, lasso, want_PxPy):
-        """get_Koopman with loads (Ksysid.m:1005-1092): the fit runs on the device over the variables [zeta ; w]
-        (w is the same on both sides of a pair); K comes back in the reference's column order."""
+        """get_Koopman with loads (Ksysid.m:1005-1092): lift, Grams and solve on the device through the pseudo-input
+        dictionary (`_def_observables_loaded`); K comes back in the reference's column order."""
         N = self.params["N"]; NL = N * (self.params["nw"] + 1)
-        w = np.asarray(sp["w"], dtype=np.float64).reshape(len(sp["alpha"]), -1)
-        snaps = Snapshots(self.ctx, np.hstack([sp["alpha"], w]), np.hstack([sp["beta"], w]), sp["u"])
+        snaps, w = self._loaded_snapshots(sp)
+        ls = bool(np.all(np.atleast_1d(self.lasso) >= 1e6))
+        lval = 1e4 if lasso is None else float(lasso)
         try:
-            if np.all(np.atleast_1d(self.lasso) >= 1e6):
-                Kd = fit(self.ctx, self.basis_loaded_dev, snaps, [np.inf])[0]
-            else:                                                          # t = lasso * N (:996); the library scales by ITS N
-                lval = 1e4 if lasso is None else float(lasso)
-                Kd = fit(self.ctx, self.basis_loaded_dev, snaps, [lval * N / self.basis_loaded_dev.N])[0]
+            if self._loaded_sub is None:
+                K = fit(self.ctx, self.basis_loaded_dev, snaps, [np.inf] if ls else [lval])[0]     # t = lasso * N (:996)
+            else:
+                G, Cm = self._loaded_grams(snaps)
+                K = self.ctx.fit_solve(G, Cm) if ls else self.ctx.fit_lasso(G, Cm, lval * N)[0]
+            if ls and self.ctx.last_rank() < K.shape[0]:
+                import warnings
+                warnings.warn(f"Rank deficient, rank = {self.ctx.last_rank()} of {K.shape[0]}: basic solution returned", RuntimeWarning)
         finally:
             snaps.close()
-        P = self._loaded_perm_W
-        koop = {"K": np.asfortranarray(Kd[np.ix_(P, P)]), "u": sp["u"], "alpha": sp["alpha"], "w": w}
+        koop = {"K": K, "u": sp["u"], "alpha": sp["alpha"], "w": w}
         if want_PxPy:                                                      # :1085-1086
             koop["Px"] = self._lift_loaded(F.LIFT_ROW, sp["alpha"], w, sp["u"])[:, :NL] if self.model_type != "nonlinear" else \
                 self._lift_loaded(F.LIFT_FULL, np.hstack([sp["alpha"], sp["u"]]), w, None)
@@ -493,14 +507,11 @@ class Ksysid:
         K = koopData["K"]
         if self.loaded:                                                    # :1192-1200: every size is N (nw + 1)
             N = N * (p["nw"] + 1)
-            w = koopData["w"]
-            snaps = Snapshots(self.ctx, np.hstack([koopData["alpha"], w]), np.hstack([koopData["beta"], w]), koopData["u"])
+            snaps, _ = self._loaded_snapshots(koopData)
             try:
-                Gd, Cd = fit_gram(self.ctx, self.basis_loaded_dev, snaps)
+                G, Cm = self._loaded_grams(snaps)
             finally:
                 snaps.close()
-            P = self._loaded_perm_W
-            G, Cm = np.asfortranarray(Gd[np.ix_(P, P)]), np.asfortranarray(Cd[np.ix_(P, P)])
         else:
             snaps = Snapshots(self.ctx, koopData["alpha"], koopData["beta"], koopData["u"])
             try:
@@ -583,15 +594,12 @@ class Ksysid:
         cuts = [0] + [j for j in range(1, T - 1) if np.any(wreal[j] != wreal[j - 1])] + [T - 1]
         if kind == "nonlinear":
             Kf = model["Kf"]
-            Kd = np.zeros((nz + nw, NL))
-            Kd[:nz, self._loaded_perm] = Kf                                   # reference column c -> device column perm[c]
-            for i in range(nw):
-                Kd[nz + i, nz + i] = 1.0                                      # the load is carried along unchanged
             zs = np.zeros((T, nz)); zs[0] = zetareal[0]
             for a, b in zip(cuts[:-1], cuts[1:]):
-                if b > a:
-                    seg = self.ctx.rollout_nl(self.basis_loaded_dev, Kd, np.concatenate([zs[a], wreal[a]]), ureal[a:b + 1])
-                    zs[a:b + 1] = seg[:, :nz]
+                if b > a:                                                     # F = (sum_i wt_i Kf(:, block i)) psi([zeta; u])
+                    wt = np.concatenate([[1.0], wreal[a]])
+                    Keff = np.ascontiguousarray(sum(wt[i] * Kf[:, i * N:(i + 1) * N] for i in range(nw + 1)))
+                    zs[a:b + 1] = self.ctx.rollout_nl(self.basis_dev, Keff, zs[a], ureal[a:b + 1])[:, :nz]
             return self._results(t, ureal, zs[:, :n], yreal)
         A, B = model["A"], model["B"]
         Y = np.zeros((T, N)); Y[0] = self.lift.econ_full(zetareal[0])

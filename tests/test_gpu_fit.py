@@ -76,6 +76,24 @@ def test_lift_and_gram_parity(ctx, mt, nz, m, types, degs, dim_red):
     assert (G2 == G).all() and (C2 == C).all()   # fixed-order reduction: bitwise reproducible
 
 
+@pytest.mark.parametrize("nz,m,deg,k", [(2, 2, 3, 8), (2, 1, 3, 9), (2, 2, 3, 10), (3, 1, 2, 7), (1, 3, 4, 4), (4, 2, 2, 13)])
+def test_gram_with_as_many_principal_axes_as_functions(ctx, nz, m, deg, k):
+    """dim_red dictionaries whose econ layout [zeta | k axes | 1] is as wide as (or wider than) the full dictionary:
+    the in-kernel projection writes the axes over the column that held the full dictionary's constant."""
+    pairs = synth_pairs(1003, nz, m, seed=21)
+    dic = ko.build_dictionary("bilinear", nz, m, ["poly"], [deg])
+    assert k <= dic.basis.nfull
+    dic.pcs = np.linalg.qr(np.random.default_rng(k).standard_normal((dic.basis.nfull, dic.basis.nfull)))[0][:, :k].copy()
+    b = make_basis(ctx, dic)
+    assert b.N == nz + k + 1
+    Px, Py = ko.px_py(dic, pairs)
+    np.testing.assert_allclose(b.lift(F.LIFT_ROW, pairs["alpha"], pairs["u"]), Px, atol=1e-13, rtol=0)
+    snaps = kra.Snapshots(ctx, pairs["alpha"], pairs["beta"], pairs["u"])
+    G, C = kra.fit_gram(ctx, b, snaps)
+    Gr, Cr = ko.gram(Px, Py)
+    assert np.abs(G - Gr).max() <= 1e-12 * np.abs(Gr).max() and np.abs(C - Cr).max() <= 1e-12 * np.abs(Gr).max()
+
+
 @pytest.mark.parametrize("Ns", [1, 7, 8, 9, 64, 2048])
 def test_gram_edge_sizes(ctx, Ns):
     pairs = synth_pairs(Ns, 2, 1, seed=3)

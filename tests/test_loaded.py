@@ -106,6 +106,65 @@ def test_gpu_loaded_fit_model_and_validation_match_oracle(kra, mt, deg, nw):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mt,types,degs,dim_red,nw", [
+    ("bilinear", ["poly"], [5], True, 1), ("linear", ["poly"], [5], True, 2), ("nonlinear", ["poly"], [4], True, 1),
+    ("linear", ["poly"], [3], True, 1),                # 8 of 9 principal axes + zeta: rank deficient by construction
+    ("bilinear", ["fourier"], [2], False, 1), ("linear", ["poly", "gaussian"], [2, 4], False, 1),
+    ("nonlinear", ["hermite"], [2], False, 2), ("linear", ["fourier_sparser"], [2], False, 1)])
+def test_gpu_loaded_any_dictionary_and_dim_red(kra, mt, types, degs, dim_red, nw):
+    """Loaded systems with every kind of observable and with dim_red (Ksysid.m:539-626 + :1521-1565, :1580-1612): lift
+    rows, K, the model matrices and the validation rollout against the oracle's literal kron construction."""
+    trials = make_trials(8, 150, nw=nw, seed=11)
+    nv = 2 + (1 if mt == "nonlinear" else 0)
+    cen = [np.random.default_rng(3).uniform(-1, 1, (nv, d)) for t, d in zip(types, degs) if t == "gaussian"] or None
+    ks = kra.Ksysid({"train": trials[:6], "val": trials[6:]}, gaussian_centres=cen, model_type=mt, obs_type=types, obs_degree=degs,
+                    loaded=True, dim_red=dim_red)
+    ks.train_models()
+    sp = ks.snapshotPairs
+    dic = ko.Dictionary(mt, 2, 1, ko.make_basis(nv, types, degs, cen), ks.basis["pcs"] if dim_red else None)
+    assert dic.N == ks.params["N"]
+    koop = ko.get_koopman_loaded(dic, sp)
+    assert np.abs(ks.koopData["Px"] - koop["Px"]).max() < 1e-12 and np.abs(ks.koopData["Py"] - koop["Py"]).max() < 1e-12
+    K = ks.koopData["K"]
+    assert K.shape == koop["K"].shape
+    Pxw = ko.lift_rows_loaded(dic, sp["alpha"], sp["u"], sp["w"]); Pyw = ko.lift_rows_loaded(dic, sp["beta"], sp["u"], sp["w"])
+    sv = np.linalg.svd(Pxw, compute_uv=False)
+    if sv[-1] > 1e-10 * sv[0]:
+        assert np.abs(K - koop["K"]).max() <= max(2e-8, 50 * (sv[0] / sv[-1]) ** 2 * 2.2e-16) * max(1.0, np.abs(koop["K"]).max())
+    else:                                              # `\` on a rank-deficient Px: a basic solution with the least-squares residual
+        keep = np.abs(K).sum(axis=1) > 0               # (directions below sqrt(W 64 eps) of the largest are dropped in Gram space)
+        assert 0 < keep.sum() < K.shape[0]
+        r_dev = np.linalg.norm(Pxw @ K - Pyw)
+        r_sub = np.linalg.norm(Pxw[:, keep] @ np.linalg.lstsq(Pxw[:, keep], Pyw, rcond=None)[0] - Pyw)
+        assert r_dev <= r_sub * (1 + 1e-6) + 1e-9
+    omdl = {"linear": ko.get_model_loaded, "bilinear": ko.get_blmodel_loaded, "nonlinear": ko.get_nlmodel_loaded}[mt](dic, dict(koop, K=K), 2)
+    for key in (("A", "B") if mt != "nonlinear" else ("Kf",)):
+        assert np.abs(ks.model[key] - omdl[key]).max() <= 5e-7 * max(1.0, np.abs(omdl[key]).max()), key
+    val = {"linear": ks.val_model, "bilinear": ks.val_BLmodel, "nonlinear": ks.val_NLmodel}[mt]
+    v = dict(ks.valdata[0]); w2 = v["w"].copy(); w2[70:] = -0.5 * w2[70:]; v["w"] = w2
+    res = val(ks.model, v); ores = ko.val_model_loaded(dic, ks.model, v, 0, mt)
+    ok = np.isfinite(ores["sim_y"]).all(axis=1) & (np.abs(ores["sim_y"]).max(axis=1) < 1e3)
+    assert ok[:20].all() and np.abs(res["sim"]["y"][ok] - ores["sim_y"][ok]).max() < 1e-8
+    # single-row lifts through the handles Kmpc uses
+    z = ks.lift.econ_full_loaded(np.concatenate([sp["alpha"][3], sp["u"][3]]) if mt == "nonlinear" else sp["alpha"][3], sp["w"][3])
+    assert np.abs(z - koop["Px"][3, :dic.N * (nw + 1)]).max() < 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mt", ["linear", "bilinear"])
+def test_gpu_loaded_lasso_matches_oracle(kra, mt):
+    """solve_KoopmanQP on the loaded rows (Ksysid.m:1068-1081): t = lasso * N with the UNLOADED N (:996)."""
+    trials = make_trials(8, 120, nw=1, seed=13)
+    ks = kra.Ksysid({"train": trials[:6], "val": trials[6:]}, model_type=mt, obs_type=["poly"], obs_degree=[2], loaded=True, lasso=0.5)
+    ks.train_models()
+    dic = ko.build_dictionary(mt, 2, 1, ["poly"], [2])
+    koop = ko.get_koopman_loaded(dic, ks.snapshotPairs, lasso=0.5, obj_lasso=0.5)
+    K = ks.koopData["K"]
+    assert abs(np.abs(K).sum() - 0.5 * dic.N) < 1e-6 * dic.N                      # the L1 budget is active
+    assert np.abs(K - koop["K"]).max() < 1e-5 * max(1.0, np.abs(koop["K"]).max())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("mt", ["linear", "bilinear"])
 def test_gpu_loaded_mpc_step_and_load_estimators(kra, mt):
     nw = 2 if mt == "linear" else 1
