@@ -468,7 +468,8 @@ def main():
             "config": {"workload": f"bilinear Koopman fit, poly degree {args.degree}, {Ns} synthetic snapshot pairs per GPU, "
                                    f"N={basis.N}, W={W} (BASELINE configs[1])",
                        "snapshots_per_gpu": Ns, "W": W,
-                       "parallelism": f"{world} rank(s), independent fits per rank, one RCCL all-gather of the K matrices at the end"},
+                       "parallelism": f"{world} rank(s), independent fits per rank, one RCCL all-gather of the K matrices at the end",
+                       "comm": comm.kind + (f" (RCCL unavailable: {comm.fallback_reason})" if getattr(comm, "fallback_reason", "") else "")},
             "fit_latency_ms": fit_latency_ms, "fit_with_K_fetched_ms": fit_fetch_ms,
             "all_K_retrievable": True, "K_first_vs_last_max_abs_diff": k_spread,
             "h2d": {"upload_ms": upload_ms, "pairs_per_s_including_upload": Ns / ((upload_ms + dt / args.steps * 1e3) * 1e-3),

@@ -24,6 +24,7 @@ from . import _ffi as F
 
 class LocalComm:
     """world = 1: the gather of one."""
+    kind = "local"
     rank, world = 0, 1
 
     def all_gather_bytes(self, payload: bytes):
@@ -38,6 +39,7 @@ class LocalComm:
 
 class RcclComm:
     """kp_comm_create on a Context: RCCL communicator of `world` processes, this one being `rank`."""
+    kind = "rccl"
 
     def __init__(self, ctx, rank: int, world: int, unique_id: bytes):
         if len(unique_id) != 128:
@@ -76,7 +78,10 @@ class RcclComm:
 class FileComm:
     """Debugging stand-in for RcclComm on a box with fewer GPUs than ranks (RCCL refuses two ranks on one device): the
     same four members, collectives through files in a directory all ranks share.  Selected with KP_COMM_BACKEND=file;
-    never the measured path."""
+    never the measured path.  `init_from_env` also falls back to it - on every rank, by agreement - when the RCCL
+    communicator cannot be created (`fallback_reason` says why), so that a launch still completes and says so."""
+    kind = "file"
+    fallback_reason = ""
 
     def __init__(self, ctx, rank: int, world: int, directory: str):
         self.ctx, self.rank, self.world, self.dir, self.seq = ctx, int(rank), int(world), directory, 0
@@ -157,7 +162,10 @@ def rendezvous_file_from_env() -> str:
 def exchange_unique_id(rank: int, path: str, timeout: float = 120.0) -> bytes:
     """Rank 0 creates the id and publishes it atomically (write + rename); the others wait for the file."""
     if rank == 0:
-        uid = unique_id()
+        try:
+            uid = unique_id()
+        except Exception:
+            uid = b"FAIL"                               # RCCL not loadable: tell the other ranks instead of letting them time out
         tmp = f"{path}.{os.getpid()}.tmp"
         with open(tmp, "wb") as f:
             f.write(uid)
@@ -169,7 +177,7 @@ def exchange_unique_id(rank: int, path: str, timeout: float = 120.0) -> bytes:
             if os.path.getmtime(path) >= t0 - 60.0:     # a file left behind by a crashed earlier launch is not ours
                 with open(path, "rb") as f:
                     uid = f.read()
-                if len(uid) == 128:
+                if len(uid) == 128 or uid == b"FAIL":
                     return uid
         except FileNotFoundError:
             pass
@@ -195,9 +203,28 @@ def init_from_env(Context):
     if os.environ.get("KP_COMM_BACKEND") == "file":      # debugging only: see FileComm
         return ctx, FileComm(ctx, rank, world, path + ".d")
     uid = exchange_unique_id(rank, path)
-    comm = RcclComm(ctx, rank, world, uid)
+    comm, why = None, ""
+    if len(uid) == 128:
+        try:
+            comm = RcclComm(ctx, rank, world, uid)
+        except Exception as e:                           # e.g. a librccl that does not match the HIP runtime
+            why = f"rank {rank}: {e}"
+    else:
+        why = "kp_comm_unique_id failed on rank 0 (librccl not loadable)"
+    # all ranks agree on the backend through the rendezvous directory: one rank without a communicator would leave the
+    # others blocked in their first collective
+    fc = FileComm(ctx, rank, world, path + ".d")
+    votes = fc.all_gather_bytes((why or "ok").encode()[:200].ljust(200))
+    bad = [v.decode().strip() for v in votes if v.decode().strip() != "ok"]
+    if bad:
+        if comm is not None:
+            comm.close()
+        fc.fallback_reason = bad[0]
+        return ctx, fc
     comm.barrier()
     if rank == 0:
+        import shutil
+        shutil.rmtree(path + ".d", ignore_errors=True)
         try:
             os.remove(path)
         except OSError:

@@ -280,3 +280,36 @@ def test_rccl_communicator_through_the_c_abi_single_rank():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", _RCCL_SCRIPT, root], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+_TWO_RANK_SCRIPT = r"""
+import sys, os
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+import koopman_realizations_amd as kra
+from koopman_realizations_amd import comm as kc, sweep
+ctx, comm = kc.init_from_env(kra.Context)
+assert comm.world == 2
+parts = kc.all_gather_array(comm, np.full(3, 1.0 + comm.rank))
+assert parts.shape == (2, 3) and parts[1, 0] == 2.0
+Ks = sweep.lasso_sweep(lambda l: np.full((2, 2), l), [0.1, 0.2, 0.3], comm, shape=(2, 2))
+assert [k[0, 0] for k in Ks] == [0.1, 0.2, 0.3]
+comm.barrier()
+if comm.rank == 0:
+    print("KIND", comm.kind, "|", getattr(comm, "fallback_reason", ""))
+"""
+
+
+def test_two_ranks_on_one_gpu_agree_on_the_file_fallback():
+    """Two ranks forced onto one device: RCCL refuses the communicator (`invalid usage`), every rank votes through the
+    rendezvous directory and all of them continue on the file backend - no rank is left blocked in a collective, and the
+    result says which backend ran.  (With one GPU per rank the same launch keeps the RCCL communicator.)"""
+    import os
+    import subprocess
+    import sys
+    from koopman_realizations_amd import comm as kc
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, KP_FORCE_DEVICE="0")
+    env.pop("KP_COMM_BACKEND", None)
+    out = kc.spawn_ranks([sys.executable, "-c", _TWO_RANK_SCRIPT, root], 2, env=env, timeout=300)
+    assert "KIND file | " in out and "ncclCommInitRank" in out, out
