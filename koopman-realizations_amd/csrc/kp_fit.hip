@@ -397,10 +397,14 @@ int kp_chol_solve_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_de
   KP_HIP(ctx, hipGetLastError());
   if (pad_done) KP_HIP(ctx, hipEventRecord(pad_done, st));
   static KpLdsCache chol_lds, trsm_lds;
-  KP_HIP(ctx, kp_ensure_lds(chol_lds, (const void*)kp_chol_kernel, lds_chol));
-  static const int chol_prof = getenv("KP_CHOL_PROF") ? 1 : 0;
-  hipLaunchKernelGGL(kp_chol_kernel, dim3(1, nb), dim3(CH_NT), lds_chol, st, Gp, n, Dinv, info, sticky, chol_prof);
-  KP_HIP(ctx, hipGetLastError());
+  static const int chol_prof = getenv("KP_CHOL_PROF") ? atoi(getenv("KP_CHOL_PROF")) : 0;
+  if (kp_chol_ll_applicable(n)) {                 // n <= 352: left-looking factorisation on the matrix pipe (kp_chol_ll.hip)
+    KP_HIP(ctx, kp_chol_ll_launch(Gp, n, nb, info, sticky, chol_prof, st));
+  } else {
+    KP_HIP(ctx, kp_ensure_lds(chol_lds, (const void*)kp_chol_kernel, lds_chol));
+    hipLaunchKernelGGL(kp_chol_kernel, dim3(1, nb), dim3(CH_NT), lds_chol, st, Gp, n, Dinv, info, sticky, chol_prof);
+    KP_HIP(ctx, hipGetLastError());
+  }
   {
     const int nbk = n / 16, npair = nbk * (nbk - 1) / 2;
     hipLaunchKernelGGL(kp_chol_finish_kernel, dim3(npair + nbk, nb), dim3(256), 0, st, Gp, n, npair, Dinv);

@@ -250,6 +250,9 @@ inline int kp_gram_dispatch(kp_ctx* ctx, const kp_basis* basis, const kp_snapsho
   if (kp_gram5_applicable(basis)) return kp_gram5_launch(ctx, basis, s, GC_dev);
   return kp_gram2_applicable(basis) ? kp_gram2_launch(ctx, basis, s, GC_dev) : kp_gram_launch(ctx, basis, s, GC_dev);
 }
+// kp_chol_ll.hip: left-looking single-workgroup Cholesky for n <= 352 (in place, lower triangle; `info` as kp_chol_kernel)
+bool kp_chol_ll_applicable(int n);
+hipError_t kp_chol_ll_launch(double* Gp, int n, int nb, int* info, int* sticky, int prof, hipStream_t st);
 int kp_pivchol_solve_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, int W, int ncols, double* K_dev, int* rank);
 int kp_comm_allreduce_dev(kp_ctx* ctx, double* buf_dev, size_t count, hipStream_t s);
 int kp_lift_dev(kp_ctx* ctx, const kp_basis* basis, int what, const double* dz, const double* du, int64_t rows, double* dout);
