@@ -114,16 +114,20 @@ __device__ __forceinline__ void ll_product(double (&acc)[LL_TMAX][4], const doub
       for (int t = 0; t < TW; ++t) an[p][t] = ap[(size_t)(4 * min(ks_lo + p, last)) * n + 16 * t];
       __builtin_amdgcn_sched_barrier(0);
     }
+    // B operands one k-step ahead: their LDS round trip would otherwise sit in front of every k-step
+    const double2* bp0 = reinterpret_cast<const double2*>(Bs + (4 * ks_lo + kq) * 16 + jj * 4);
+    double2 n01 = bp0[0], n23 = bp0[1];
     for (int ks = ks_lo; ks < ks_hi; ks += PF) {
 #pragma unroll
       for (int p = 0; p < PF; ++p) {
         const int kc = ks + p;
         // the sign goes on the B operand (4 values) and the L operands feed the MFMAs from the registers they were loaded
         // into; their refill for step kc + PF is issued after the MFMAs of step kc
-        const double2* bp = reinterpret_cast<const double2*>(Bs + (4 * min(kc, last) + kq) * 16 + jj * 4);
-        double2 b01 = bp[0], b23 = bp[1];
         const bool on = kc <= last;
-        const double b0 = on ? -b01.x : 0.0, b1 = on ? -b01.y : 0.0, b2 = on ? -b23.x : 0.0, b3 = on ? -b23.y : 0.0;
+        const double b0 = on ? -n01.x : 0.0, b1 = on ? -n01.y : 0.0, b2 = on ? -n23.x : 0.0, b3 = on ? -n23.y : 0.0;
+        const double2* bp = reinterpret_cast<const double2*>(Bs + (4 * min(kc + 1, last) + kq) * 16 + jj * 4);
+        n01 = bp[0];
+        n23 = bp[1];
 #pragma unroll
         for (int t = 0; t < TW; ++t) {
           acc[t][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(an[p][t], b0, acc[t][0], 0, 0, 0);
