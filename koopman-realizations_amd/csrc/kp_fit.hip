@@ -376,6 +376,190 @@ __global__ __launch_bounds__(256) void kp_trsm_kernel(const double* __restrict__
   }
 }
 
+static bool trsm_old_sel() {
+  static const bool v = getenv("KP_TRSM_OLD") != nullptr;
+  return v;
+}
+
+// ---- block substitution, second form: right-looking, one barrier per step, v_mfma_f64_4x4x4 --------------------------
+// Forward  L Y = C  and backward  L' K = Y  for 16 right-hand sides by a 4-wave workgroup.  Row block i belongs to wave
+// i % 4, which keeps its residual R_i = C_i - sum_j L_ij Y_j in accumulators.  Step j: the owner of row j applies the pending
+// update with Y_{j-1} to that row first, multiplies by the inverse diagonal block and publishes Y_j (LDS); everyone else
+// meanwhile applies Y_{j-1} to the rest of their rows; ONE barrier (LDS-only: the L tiles of column j, requested just before
+// it, stay in flight).  The left-looking form above has two barriers, a 4-way partial-sum exchange and conditional loads (a
+// drained queue) per step - and uses v_mfma_f64_16x16x4, which runs at half the rate of the 4x4x4 form on gfx950 (140 against
+// 4 x 16.5 cycles per 2048 flop): a 16 x 16 x 16 tile product is 16 MFMAs here (blocks = the 4 row groups of the tile; the B
+// operand - a 4 x 4 block of Y_j - is shared by the blocks).
+#define TR2_MAXR 8   // row blocks per wave: ceil(32 / 4)  =>  n <= 512
+namespace {
+
+__device__ __forceinline__ int tr2_col(int c) { return (c & 3) * 4 + (c >> 2); }   // LDS column order: a lane's 4 J are contiguous
+
+// an[q][K] = -(A operand of tile (row(q), column block jc)): rows 4 blk + jj of the tile, column 4 K + kq
+template <int CNT>
+__device__ __forceinline__ void tr2_load(double (&an)[TR2_MAXR][4], const double* __restrict__ LU, int n, int jc, const int (&rowof)[TR2_MAXR], int kq,
+                                         int blk, int jj) {
+#pragma unroll
+  for (int q = 0; q < CNT; ++q)
+#pragma unroll
+    for (int K = 0; K < 4; ++K) an[q][K] = -LU[(size_t)(jc * 16 + 4 * K + kq) * n + rowof[q] * 16 + 4 * blk + jj];
+}
+
+// slots [q0, CNT): R -= L Y  (16 MFMAs per tile: 4 independent chains of 4)
+template <int CNT>
+__device__ __forceinline__ void tr2_update(double (&acc)[TR2_MAXR][4], const double (&an)[TR2_MAXR][4], const double (&bv)[4][4], int q0) {
+#pragma unroll
+  for (int q = 0; q < CNT; ++q) {
+    if (q < q0) continue;
+#pragma unroll
+    for (int K = 0; K < 4; ++K)
+#pragma unroll
+      for (int J = 0; J < 4; ++J) acc[q][J] = __builtin_amdgcn_mfma_f64_4x4x4f64(an[q][K], bv[K][J], acc[q][J], 0, 0, 0);
+  }
+}
+
+// B operands of a 16-row block of xs: b[K][J] = X(4 K + kq, 4 J + jj)
+__device__ __forceinline__ void tr2_read_b(const double* __restrict__ xs, int j, int kq, int jj, double (&b)[4][4]) {
+#pragma unroll
+  for (int K = 0; K < 4; ++K) {
+    const double2* p = reinterpret_cast<const double2*>(xs + (j * 16 + 4 * K + kq) * 16 + jj * 4);
+    const double2 v01 = p[0], v23 = p[1];
+    b[K][0] = v01.x; b[K][1] = v01.y; b[K][2] = v23.x; b[K][3] = v23.y;
+  }
+}
+
+}  // namespace
+
+#define TR2_SWITCH(CALL)                                                                   \
+  switch (cnt) {                                                                           \
+    case 1: { constexpr int C_ = 1; CALL; } break;                                         \
+    case 2: { constexpr int C_ = 2; CALL; } break;                                         \
+    case 3: { constexpr int C_ = 3; CALL; } break;                                         \
+    case 4: { constexpr int C_ = 4; CALL; } break;                                         \
+    case 5: { constexpr int C_ = 5; CALL; } break;                                         \
+    case 6: { constexpr int C_ = 6; CALL; } break;                                         \
+    case 7: { constexpr int C_ = 7; CALL; } break;                                         \
+    case 8: { constexpr int C_ = 8; CALL; } break;                                         \
+    default: break;                                                                        \
+  }
+
+__global__ __launch_bounds__(256) void kp_trsm2_kernel(const double* __restrict__ LU, const double* __restrict__ Dinv, int n,
+                                                      double* __restrict__ X) {
+  extern __shared__ __align__(16) double xs[];  // [n][16] X block, columns in tr2_col order
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cb = blockIdx.x;
+  const int nt = n / 16;
+  const int kq = lane >> 4, blk = (lane >> 2) & 3, jj = lane & 3;
+  LU += blockIdx.y * (size_t)n * n; Dinv += blockIdx.y * (size_t)nt * 256; X += blockIdx.y * (size_t)n * gridDim.x * 16;   // system of a batch
+  double* Xb = X + (size_t)cb * 16 * n;
+  for (int e = tid; e < n * 16; e += 256) {
+    int row = e % n, col = e / n;
+    xs[row * 16 + tr2_col(col)] = Xb[(size_t)col * n + row];       // C block -> LDS (overwritten by Y, then K)
+  }
+  __syncthreads();
+  const int nown = wave < nt ? (nt - wave + 3) / 4 : 0;    // row blocks wave, wave + 4, ... < nt
+  for (int dir = 0; dir < 2; ++dir) {                      // 0: L Y = C (forward), 1: L' K = Y (backward)
+    // slot q <-> row block, the rows that retire LAST first, so that the rows a step still reaches are always the slots
+    // [0, cnt) and the row that retires next is slot cnt - 1: forward rows retire ascending (slot 0 = the largest row),
+    // backward descending (slot 0 = the smallest)
+    int rowof[TR2_MAXR];
+#pragma unroll
+    for (int q = 0; q < TR2_MAXR; ++q) rowof[q] = q < nown ? (dir == 0 ? wave + 4 * (nown - 1 - q) : wave + 4 * q) : 0;
+    double acc[TR2_MAXR][4];                               // R(4 blk + kq, 4 J + jj) of the slot's row block
+#pragma unroll
+    for (int q = 0; q < TR2_MAXR; ++q) {
+      const double2* p = reinterpret_cast<const double2*>(xs + (rowof[q] * 16 + 4 * blk + kq) * 16 + jj * 4);
+      const double2 v01 = p[0], v23 = p[1];
+      acc[q][0] = v01.x; acc[q][1] = v01.y; acc[q][2] = v23.x; acc[q][3] = v23.y;
+    }
+    // owned rows strictly beyond row j in sweep direction (= the rows the update with X_j reaches)
+    auto beyond = [&](int j) {
+      const int c = dir == 0 ? nown - (j < wave ? 0 : (j - wave) / 4 + 1) : (j <= wave ? 0 : (j - wave + 3) / 4);
+      return min(max(c, 0), nown);
+    };
+    const int j0 = dir == 0 ? 0 : nt - 1, jstep = dir == 0 ? 1 : -1;
+    // inverse diagonal block (A operand: row 4 blk + jj, column 4 K + kq; transposed in the backward sweep) of the next
+    // row this wave retires, requested one ownership period ahead
+    auto load_dinv = [&](int j, double (&dv)[4]) {
+      const int jc = min(max(j, 0), nt - 1);
+#pragma unroll
+      for (int K = 0; K < 4; ++K) {
+        const int r = 4 * blk + jj, c = 4 * K + kq;
+        dv[K] = dir == 0 ? Dinv[(size_t)jc * 256 + c * 16 + r] : Dinv[(size_t)jc * 256 + r * 16 + c];
+      }
+    };
+    double dv[4];
+    {
+      int jf = j0;                                          // first row this wave retires
+      while (jf >= 0 && jf < nt && (jf & 3) != wave) jf += jstep;
+      load_dinv(jf, dv);
+    }
+    double an[TR2_MAXR][4];
+    double bv[4][4];
+    int cnt = nown;                                        // rows reached by "X_{j0 - jstep}": all of them (nothing pending)
+    for (int it = 0; it < nt; ++it) {
+      const int j = j0 + it * jstep;
+      const bool owner = (j & 3) == wave;
+      // here: an / bv = tiles of column j - jstep for the slots [0, cnt) and X_{j - jstep} (it > 0), not yet applied
+      if (owner) {
+        const int qj = cnt - 1;                            // slot of row j
+        if (it > 0) { TR2_SWITCH((tr2_update<C_>(acc, an, bv, C_ - 1))); }      // row j alone
+        double rj[4];
+#pragma unroll
+        for (int J = 0; J < 4; ++J) rj[J] = acc[0][J];
+#pragma unroll
+        for (int q = 1; q < TR2_MAXR; ++q)
+          if (q == qj) {
+#pragma unroll
+            for (int J = 0; J < 4; ++J) rj[J] = acc[q][J];
+          }
+        // R_j through LDS into the B-operand layout (only this wave touches block j of xs now), times the inverse block
+        {
+          double2* p = reinterpret_cast<double2*>(xs + (j * 16 + 4 * blk + kq) * 16 + jj * 4);
+          double2 v01, v23;
+          v01.x = rj[0]; v01.y = rj[1]; v23.x = rj[2]; v23.y = rj[3];
+          p[0] = v01; p[1] = v23;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        double br[4][4];
+        tr2_read_b(xs, j, kq, jj, br);
+        double y[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int K = 0; K < 4; ++K)
+#pragma unroll
+          for (int J = 0; J < 4; ++J) y[J] = __builtin_amdgcn_mfma_f64_4x4x4f64(dv[K], br[K][J], y[J], 0, 0, 0);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                    // all lanes have read R_j before Y_j replaces it
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        {
+          double2* p = reinterpret_cast<double2*>(xs + (j * 16 + 4 * blk + kq) * 16 + jj * 4);
+          double2 v01, v23;
+          v01.x = y[0]; v01.y = y[1]; v23.x = y[2]; v23.y = y[3];
+          p[0] = v01; p[1] = v23;
+        }
+        load_dinv(j + 4 * jstep, dv);
+        if (it > 0) { TR2_SWITCH((tr2_update<C_ - 1>(acc, an, bv, 0))); }      // the rest of this wave's rows
+      } else if (it > 0) {
+        TR2_SWITCH((tr2_update<C_>(acc, an, bv, 0)));
+      }
+      // tiles of column j for the rows beyond it: requested now, used after the barrier
+      cnt = beyond(j);
+      TR2_SWITCH((tr2_load<C_>(an, LU, n, j, rowof, kq, blk, jj)));
+      // LDS-only barrier: the tile loads just issued stay in flight across it (a __syncthreads would wait for them)
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      tr2_read_b(xs, j, kq, jj, bv);
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < n * 16; e += 256) {
+    int row = e % n, col = e / n;
+    Xb[(size_t)col * n + row] = xs[row * 16 + tr2_col(col)];
+  }
+}
+
 // nb systems [G | C] gc_stride doubles apart (W x W each; ncols = W when nb > 1); system y's K goes to
 // K_dev + ((k_first + y) % k_cap) W ncols (k_cap = 0: K_dev).  One launch sequence for the whole batch.
 int kp_chol_solve_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, int W, int ncols, int nb, size_t gc_stride, double* K_dev,
@@ -410,8 +594,9 @@ int kp_chol_solve_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_de
     hipLaunchKernelGGL(kp_chol_finish_kernel, dim3(npair + nbk, nb), dim3(256), 0, st, Gp, n, npair, Dinv);
   }
   KP_HIP(ctx, hipGetLastError());
-  KP_HIP(ctx, kp_ensure_lds(trsm_lds, (const void*)kp_trsm_kernel, lds_trsm));
-  hipLaunchKernelGGL(kp_trsm_kernel, dim3(ncp / 16, nb), dim3(256), lds_trsm, st, Gp, Dinv, n, Cp);
+  KP_HIP(ctx, kp_ensure_lds(trsm_lds, trsm_old_sel() ? (const void*)kp_trsm_kernel : (const void*)kp_trsm2_kernel, lds_trsm));
+  if (trsm_old_sel()) hipLaunchKernelGGL(kp_trsm_kernel, dim3(ncp / 16, nb), dim3(256), lds_trsm, st, Gp, Dinv, n, Cp);
+  else hipLaunchKernelGGL(kp_trsm2_kernel, dim3(ncp / 16, nb), dim3(256), lds_trsm, st, Gp, Dinv, n, Cp);
   KP_HIP(ctx, hipGetLastError());
   hipLaunchKernelGGL(kp_unpad_kernel, dim3((unsigned)(((int64_t)W * ncols + 255) / 256), nb), dim3(256), 0, st, Cp, n, W, ncols, K_dev, ncp, k_first,
                      k_cap);
