@@ -99,8 +99,9 @@ int kp_basis_destroy(kp_basis* basis);
  * W = width of Px (:1019-1028): N+m linear, N(m+1) bilinear, N nonlinear. */
 int kp_basis_dims(const kp_basis* basis, int* nvars, int* nfull, int* N, int* W);
 
-/* Symmetric eigendecomposition S = V diag(lam) V' of an n x n matrix (n <= 256, column-major, host pointers) on the
- * device (parallel cyclic Jacobi, one workgroup): the `pca` step of get_econ_observables (Ksysid.m:1498) - principal
+/* Symmetric eigendecomposition S = V diag(lam) V' of an n x n matrix (n <= 1024, column-major, host pointers) on the
+ * device (parallel cyclic Jacobi; several workgroups with a grid barrier per round for n > 40): the `pca` step of
+ * get_econ_observables (Ksysid.m:1498) - principal
  * axes = eigenvectors of the covariance of the lifted snapshots, which kp_fit_gram provides without forming the lifted
  * matrix (the dictionary's constant column carries the column sums).  Eigenvalues are returned UNSORTED (lam[i]
  * belongs to column i of V); sweeps (may be NULL) receives the number of Jacobi sweeps. */

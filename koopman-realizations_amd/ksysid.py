@@ -158,9 +158,10 @@ class Ksysid:
         self.traindata = self.get_scale(merged)                            # :122
         self.valdata = [self.scale_data(v) for v in data4sysid["val"]]    # :123-126
         self.snapshotPairs = self.get_snapshotPairs(self.traindata, self.snapshots)   # :134
-        # pca of dictionaries wider than the device eigensolver takes (kp_sym_eig: n <= 256, e.g. poly-3 on a delayed arm
-        # state): lift on the device, SVD of the lifted matrix on the host - as the reference's `pca` does
-        Px = self.lift_snapshots(self.snapshotPairs) if (self.dim_red and (self._pca_host or self.basis_dev.nfull > 256)) else None   # :137-141
+        # pca of dictionaries wider than the fused Gram kernel takes (covariance width nfull + m > 560, e.g. poly-3 on a delayed
+        # arm state: 816 functions): lift on the device, SVD of the lifted matrix on the host - as the reference's `pca` does
+        wide = self.basis_dev.nfull + self.params["m"] > 560
+        Px = self.lift_snapshots(self.snapshotPairs) if (self.dim_red and (self._pca_host or wide)) else None   # :137-141
         self.get_econ_observables(Px)                                      # :142
         if self.loaded and not self._host_only:
             self._def_observables_loaded()                                 # :112-113 (after dim_red: the econ_* loaded lifts, :1521-1565)
@@ -392,10 +393,15 @@ class Ksysid:
         else:
             sp = self.snapshotPairs
             snaps = Snapshots(self.ctx, sp["alpha"], sp["beta"], sp["u"])
+            # full dictionary: Psi'Psi is the leading block of the LINEAR row [psi, u] (the bilinear row psi (x) [1; u] would
+            # compute (m + 1)^2 times as much, and be too wide for the Gram kernels from nfull = 140 on)
+            pb = Basis(self.ctx, "linear", p["nzeta"], p["m"], self._blocks, None) if self.model_type == "bilinear" else self.basis_dev
             try:
-                G, _ = fit_gram(self.ctx, self.basis_dev, snaps)          # full dictionary: Psi'Psi is the leading block
+                G, _ = fit_gram(self.ctx, pb, snaps)
             finally:
                 snaps.close()
+                if pb is not self.basis_dev:
+                    pb.close()
             Nf = self.basis_dev.nfull
             Gf = G[:Nf, :Nf]
             cnt = Gf[Nf - 1, Nf - 1]                                     # constant observable: number of snapshots

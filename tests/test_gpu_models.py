@@ -214,3 +214,19 @@ def test_device_pca_and_econ_lift_reproduce_stored_Z(ctx, golden, arm, which):
     assert ks.basis["pcs"].shape == (84, 27) and ks.params["N"] == 34
     Z = ks.lift.econ_full(ks.scaledown_y(r[which + "_Y"][:300]))
     assert np.abs(Z - r[which + "_Z"]).max() < 1e-11                      # measured 8e-14 (the oracle's LAPACK SVD chain: 1.4e-14)
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 40, 41, 85, 220, 257, 600])
+def test_sym_eig_matches_lapack(ctx, n):
+    """kp_sym_eig (the eigensolver behind `pca`, Ksysid.m:1498): one-workgroup Jacobi up to n = 40, the multi-workgroup form
+    (ping-pong S, one grid barrier per round; odd n: one index sits out every round) above - against LAPACK on a
+    covariance with a spectrum decaying over six decades."""
+    rng = np.random.default_rng(n)
+    X = rng.standard_normal((max(4 * n, 50), n)) * np.logspace(0, -6, n)
+    S = np.atleast_2d(np.cov(X, rowvar=False))
+    w, V, sweeps = ctx.sym_eig(S)
+    wl = np.linalg.eigvalsh(S)[::-1]
+    scale = np.abs(wl).max()
+    assert 0 < sweeps < 30
+    assert np.abs(w - wl).max() <= 1e-13 * scale * max(1, n / 50)
+    assert np.abs(S @ V - V * w).max() <= 1e-12 * scale and np.abs(V.T @ V - np.eye(n)).max() <= 1e-12
