@@ -220,7 +220,7 @@ def gen_rand_systems(chunks):
     import multiprocessing as mp
     if not chunks:
         return {}
-    nproc = min(len(chunks), max(1, (os.cpu_count() or 2) - 1))
+    nproc = min(len(chunks), max(1, min(len(os.sched_getaffinity(0)), os.cpu_count() or 2) - 1))
     if nproc == 1:
         return {c: _rand_chunk(c) for c in chunks}
     with mp.get_context("fork").Pool(nproc) as pool:
@@ -387,8 +387,11 @@ def main():
     # the solve of fit i (second HIP stream) overlaps the fused Gram kernel of fit i+1; each K lands in its own slot of
     # the device result ring; everything is drained and the ranks' last K matrices are gathered (RCCL, device to
     # device) inside the timed region.
-    for _ in range(64):                             # one full batch of deferred solves first: every buffer of the pipeline at
-        kra.fit(ctx, basis, snaps, fetch=False)     # its final size, every kernel variant loaded (not counted as warm-up)
+    # one queue as deep as the timed region's first (at least one full batch of deferred solves): every buffer of the pipeline
+    # and of the HIP runtime (kernel-argument and signal pools grow with the queue depth) at its final size, every kernel
+    # variant loaded (not counted as warm-up)
+    for _ in range(max(64, args.steps)):
+        kra.fit(ctx, basis, snaps, fetch=False)
     ctx.synchronize()
     for _ in range(args.warmup):
         kra.fit(ctx, basis, snaps, fetch=False)
@@ -399,6 +402,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         kra.fit(ctx, basis, snaps, fetch=False)     # enqueue: Gram on stream 1, solve on stream 2
+    t_enq = time.perf_counter() - t0                # host time to enqueue all fits (the device drains behind it)
     ctx.synchronize()                               # all fits complete
     Kall = comm.all_gather_fit(args.steps - 1, W) if world > 1 else None    # the sweep's only collective: final gather
     comm.barrier()
@@ -470,6 +474,7 @@ def main():
                        "snapshots_per_gpu": Ns, "W": W,
                        "parallelism": f"{world} rank(s), independent fits per rank, one RCCL all-gather of the K matrices at the end",
                        "comm": comm.kind + (f" (RCCL unavailable: {comm.fallback_reason})" if getattr(comm, "fallback_reason", "") else "")},
+            "host_enqueue_ms_per_step": t_enq / args.steps * 1e3,
             "fit_latency_ms": fit_latency_ms, "fit_with_K_fetched_ms": fit_fetch_ms,
             "all_K_retrievable": True, "K_first_vs_last_max_abs_diff": k_spread,
             "h2d": {"upload_ms": upload_ms, "pairs_per_s_including_upload": Ns / ((upload_ms + dt / args.steps * 1e3) * 1e-3),

@@ -3,6 +3,7 @@
 # separate runs (never combined with trace domains other than --kernel-trace).
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_r02
+rm -rf $O; mkdir -p $O
 B="python3 $R/bench.py --no-cpu-baseline --no-mpc --no-extras --steps 50 --warmup 5"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- $B > $O.trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- $B > $O.fetch.log 2>&1
