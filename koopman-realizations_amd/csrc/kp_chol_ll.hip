@@ -136,62 +136,72 @@ __device__ __forceinline__ void ll_tiles(int n, int k1, int pw, int& tbeg, int& 
   tbeg = pw >= 0 ? pw * tq + min(pw, tr) : 0;
 }
 
-// Product of panel k+1 over the finished columns [0, 4 nks): acc(t, m) = - sum_j L(rows of tile t, j) L(k1 + 4 m + jj, j), the L
+// Product of panel k+1 over the finished columns [4 ks_lo, 4 ks_hi): acc(t, m) = - sum_j L(rows of tile t, j) L(k1 + 4 m + jj, j), the L
 // operands from memory (PF k-steps in flight), the B operands from U (rows < k0 hold -L(k1 + c, j) at U[c][j]), one k-step ahead.
 // Straight-line code for a given number of tiles TW: the compiler's s_waitcnt placement then counts the loads exactly (a
 // conditional load anywhere in the loop would make it drain the queue every k-step).  Steps past the end re-read the last
 // one against a zero B operand.
+template <int TW, int PF, bool EXACT>
+__device__ __forceinline__ void ll_product_body(double (&acc)[LL_TMAX][4], const double* __restrict__ ap, int n, const double* __restrict__ U, int ldu,
+                                                int ks_lo, int ks_hi, int kq, int jj) {
+  const int last = ks_hi - 1, cmax = n / 4 - 1;          // last k-step of the range / of the matrix (prefetch clamp)
+  double an[PF][TW];
+  // (the scheduling barriers keep the load groups in program order, so that the wait before a group's first use is
+  // "all but the PF - 1 younger groups" and not "all")
+#pragma unroll
+  for (int p = 0; p < PF; ++p) {
+#pragma unroll
+    for (int t = 0; t < TW; ++t) an[p][t] = ap[(size_t)(4 * min(ks_lo + p, EXACT ? cmax : last)) * n + 16 * t];
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  double bn[4];
+  const double* bp0 = U + jj * ldu + kq;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) bn[m] = bp0[(4 * m) * ldu + 4 * ks_lo];
+  for (int ks = ks_lo; ks < ks_hi; ks += PF) {
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+      const int kc = ks + p;
+      // the sign is on the B operand (U holds -L in its B-operand rows) and the L operands feed the MFMAs from the registers they
+      // were loaded into; their refill for step kc + PF is issued after the MFMAs of step kc.  EXACT (the range is a whole
+      // number of groups): no masking of the B operand, and its prefetch address is linear in kc (immediate offsets; the read
+      // one step past the range stays inside U)
+      double b[4];
+      if (EXACT) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) b[m] = bn[m];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) bn[m] = bp0[(4 * m) * ldu + 4 * (kc + 1)];
+      } else {
+        const bool on = kc <= last;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) b[m] = on ? bn[m] : 0.0;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) bn[m] = bp0[(4 * m) * ldu + 4 * min(kc + 1, last)];
+      }
+#pragma unroll
+      for (int t = 0; t < TW; ++t)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[t][m] = __builtin_amdgcn_mfma_f64_4x4x4f64(an[p][t], b[m], acc[t][m], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      const size_t off = (size_t)(4 * min(kc + PF, EXACT ? cmax : last)) * n;
+#pragma unroll
+      for (int t = 0; t < TW; ++t) an[p][t] = ap[off + 16 * t];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
 template <int TW, int PF>
 __device__ __forceinline__ void ll_product_mem(double (&acc)[LL_TMAX][4], const double* __restrict__ ap, int n, const double* __restrict__ U, int ldu,
-                                               int nks, int kq, int jj) {
+                                               int ks_lo, int ks_hi, int kq, int jj) {
 #pragma unroll
   for (int t = 0; t < TW; ++t)
 #pragma unroll
     for (int m = 0; m < 4; ++m) acc[t][m] = 0.0;
-  if (nks > 0) {
-    const int last = nks - 1;
-    double an[PF][TW];
-    // (the scheduling barriers keep the load groups in program order, so that the wait before a group's first use is
-    // "all but the PF - 1 younger groups" and not "all")
-#pragma unroll
-    for (int p = 0; p < PF; ++p) {
-#pragma unroll
-      for (int t = 0; t < TW; ++t) an[p][t] = ap[(size_t)(4 * min(p, last)) * n + 16 * t];
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    double bn[4];
-    {
-      const double* bp = U + jj * ldu + kq;
-#pragma unroll
-      for (int m = 0; m < 4; ++m) bn[m] = bp[(4 * m) * ldu];
-    }
-    for (int ks = 0; ks < nks; ks += PF) {
-#pragma unroll
-      for (int p = 0; p < PF; ++p) {
-        const int kc = ks + p;
-        // the sign is on the B operand (U holds -L in its B-operand rows) and the L operands feed the MFMAs from the registers they
-        // were loaded into; their refill for step kc + PF is issued after the MFMAs of step kc
-        const bool on = kc <= last;
-        double b[4];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) b[m] = on ? bn[m] : 0.0;
-        {
-          const double* bp = U + jj * ldu + 4 * min(kc + 1, last) + kq;
-#pragma unroll
-          for (int m = 0; m < 4; ++m) bn[m] = bp[(4 * m) * ldu];
-        }
-#pragma unroll
-        for (int t = 0; t < TW; ++t)
-#pragma unroll
-          for (int m = 0; m < 4; ++m) acc[t][m] = __builtin_amdgcn_mfma_f64_4x4x4f64(an[p][t], b[m], acc[t][m], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        const size_t off = (size_t)(4 * min(kc + PF, last)) * n;
-#pragma unroll
-        for (int t = 0; t < TW; ++t) an[p][t] = ap[off + 16 * t];
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-  }
+  if (ks_lo >= ks_hi) return;
+  if ((ks_hi - ks_lo) % PF == 0) ll_product_body<TW, PF, true>(acc, ap, n, U, ldu, ks_lo, ks_hi, kq, jj);
+  else ll_product_body<TW, PF, false>(acc, ap, n, U, ldu, ks_lo, ks_hi, kq, jj);
 }
 
 // The last 16 columns (panel k itself, just computed): L operands U[c][row], B operands U[c'][k0 + c]; then the panel of A (An)
@@ -299,6 +309,7 @@ __global__ __launch_bounds__(LL_NT) void kp_chol_ll_kernel(double* __restrict__ 
     ll_tiles(n, k1, wave - 1, tbeg, Tw);
     const int row0 = k1 + 16 * tbeg;               // first row of this wave's tiles
     double* An = (kb + 1) & 1 ? An1 : An0;         // panel k+1 of A
+    const bool late = ntq >= 1 && ntq < LL_NPW && k1 >= 256;     // (the partial sums need 256 free rows in the panel buffers)
     // ---- B operands of the next product, U[c][j] = L(k1 + c, j), in the rows of U that S no longer uses: the columns of the
     //      previous panel here, the older ones were staged by wave 0 during the previous panel's last phase ----
     if (ntq > 0 && k0 > 0 && tid < 256) {
@@ -312,12 +323,40 @@ __global__ __launch_bounds__(LL_NT) void kp_chol_ll_kernel(double* __restrict__ 
       ll_diag16(U, ldu, k0, Dm, Dd, I4, &bad, odiag);
       if (prof) tph[4] += clock64() - tlast;       // the diagonal block alone
 
+    } else if (late) {
+      // Late panels: fewer tiles than product waves and 60-76 k-steps each, at ~220 cycles of fixed cost per k-step.  Tiles are
+      // taken in PAIRS (8 MFMAs per k-step instead of 4); the (pair, k-step) items, pair-major, are cut into 7 equal ranges; a
+      // range touches at most two pairs, whose partial sums go to LDS (the rows < k1 of the two panel buffers are unused by
+      // now) and are added up in a fixed order by each tile's owner in the last phase.
+      const int K = k0 / 4, npair = (ntq + 1) / 2, Ltot = npair * K, pw = wave - 1;
+      const int lo = pw * Ltot / LL_NPW, hi = (pw + 1) * Ltot / LL_NPW;
+      const int pa = lo / K;
+#pragma unroll
+      for (int piece = 0; piece < 2; ++piece) {
+        const int pr = pa + piece;                                                   // tile pair 2 pr, 2 pr + 1
+        const int ks_lo = piece == 0 ? lo - pa * K : 0, ks_hi = min(K, hi - pr * K);
+        double accp[LL_TMAX][4];
+        const int t0 = min(2 * pr, ntq - 1);
+        const double* ap = A + (size_t)kq * n + k1 + 16 * t0 + 4 * blk + jj;
+        const bool two = 2 * pr + 1 < ntq;
+        if (two) ll_product_mem<2, 4>(accp, ap, n, U, ldu, ks_lo, ks_hi, kq, jj);   // (an empty range leaves zeros)
+        else {
+          ll_product_mem<1, 8>(accp, ap, n, U, ldu, ks_lo, ks_hi, kq, jj);
+#pragma unroll
+          for (int m = 0; m < 4; ++m) accp[1][m] = 0.0;
+        }
+        double* sc = piece == 0 ? An : ((kb + 2) & 1 ? An1 : An0);
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+          for (int m = 0; m < 4; ++m) sc[(2 * pw + (m >> 1)) * ldu + t2 * 128 + (m & 1) * 64 + lane_v] = accp[t2][m];
+      }
     } else {
       const double* ap = A + (size_t)kq * n + row0 + 4 * blk + jj;                 // + 4 ks n + 16 t : L(row0 + 16 t + 4 blk + i, 4 ks + kq)
       switch (Tw) {
-        case 1: ll_product_mem<1, 8>(acc, ap, n, U, ldu, k0 / 4, kq, jj); break;
-        case 2: ll_product_mem<2, 4>(acc, ap, n, U, ldu, k0 / 4, kq, jj); break;
-        case 3: ll_product_mem<3, 3>(acc, ap, n, U, ldu, k0 / 4, kq, jj); break;
+        case 1: if (kb & 1) ll_product_mem<1, 4>(acc, ap, n, U, ldu, 0, k0 / 4, kq, jj); else ll_product_mem<1, 8>(acc, ap, n, U, ldu, 0, k0 / 4, kq, jj); break;
+        case 2: ll_product_mem<2, 4>(acc, ap, n, U, ldu, 0, k0 / 4, kq, jj); break;
+        case 3: ll_product_mem<3, 4>(acc, ap, n, U, ldu, 0, k0 / 4, kq, jj); break;
         default: break;
       }
     }
@@ -361,6 +400,22 @@ __global__ __launch_bounds__(LL_NT) void kp_chol_ll_kernel(double* __restrict__ 
     LL_TICK(2);
     // ---- waves 1-7: the 16 new columns, + the panel of A, S of panel k+1 back into U  |  wave 0: stores and staging ----
     if (!pwave) ll_store_diag(Dm, A, n, k0, lane_v);
+    if (late && Tw == 1) {                         // the owner of tile wave - 1 collects its partial sums, waves and pieces in order
+      const int K = k0 / 4, npair = (ntq + 1) / 2, Ltot = npair * K, mine = wave - 1;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) acc[0][m] = 0.0;
+      for (int w = 0; w < LL_NPW; ++w) {
+        const int lo = w * Ltot / LL_NPW, hi = (w + 1) * Ltot / LL_NPW;
+        const int pa = lo / K;
+        for (int piece = 0; piece < 2; ++piece) {
+          const int pr = pa + piece;
+          if (pr != (mine >> 1) || min(K, hi - pr * K) <= (piece == 0 ? lo - pa * K : 0)) continue;
+          const double* sc = piece == 0 ? An : ((kb + 2) & 1 ? An1 : An0);
+#pragma unroll
+          for (int m = 0; m < 4; ++m) acc[0][m] += sc[(2 * w + (m >> 1)) * ldu + (mine & 1) * 128 + (m & 1) * 64 + lane_v];
+        }
+      }
+    }
     if (pwave) {
       switch (Tw) {
         case 1: ll_product_lds<1>(acc, U, An, ldu, k0, row0, kq, blk, jj); break;
