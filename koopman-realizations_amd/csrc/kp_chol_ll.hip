@@ -18,10 +18,10 @@
 //               of L that become B operands and the panel of A itself (global -> LDS, 8 loads in flight per lane);
 //   waves 1-7   MEANWHILE form the product of panel k+1 over the columns < k0 (everything that does not depend on panel
 //               k), 1-3 row tiles each, L operands fetched 3-8 k-steps ahead, B operands one k-step ahead;
-//   all waves   L21' = L11^-1 S21' by 4 x 4 block forward substitution (the output layout of one MFMA is the B-operand layout
-//               of the next: no transposes), stored to memory and kept in LDS in place of S;
-//   waves 1-7   finish the product of panel k+1 with the 16 new columns straight from LDS, add the panel of A and leave
-//               S of panel k+1 where the L21 of their rows was.
+//   waves 1-7   then form L21' = L11^-1 S21' of their OWN tiles by 4 x 4 block forward substitution (the output layout of one MFMA
+//               is the B-operand layout of the next: no transposes), store it, and - its registers being at the same time the A
+//               operands of the 16 new columns - finish the product of panel k+1 with them, add the panel of A and leave S of
+//               panel k+1 in LDS where S of panel k was.
 // LDS: U[16][n] holds, for panel k, S(c, row) at rows >= k0 and - in the rows < k0 that S no longer needs - the B operands
 // L(k0 + 16 + c, j) of the next product; two buffers An[2][16][n] take the panels of A in turn.
 // L' (upper triangle) and the inverses of the 16 x 16 diagonal blocks, which only the TRSM kernel needs, are produced
@@ -204,24 +204,74 @@ __device__ __forceinline__ void ll_product_mem(double (&acc)[LL_TMAX][4], const 
   else ll_product_body<TW, PF, false>(acc, ap, n, U, ldu, ks_lo, ks_hi, kq, jj);
 }
 
-// The last 16 columns (panel k itself, just computed): L operands U[c][row], B operands U[c'][k0 + c]; then the panel of A (An)
-// is added and S of panel k+1 goes back to U over the rows of this wave's tiles.
+// L21 of this wave's OWN tiles (the rows it will finish panel k+1 for): X' = L11^-1 S' by 4 x 4 block forward substitution.  A
+// operand (i = lane & 3, k = lane >> 4): a 4 x 4 block of L11 / an inverse diagonal block, the same for all 4 MFMA blocks; B
+// operand and output (k or i = lane >> 4, j = lane & 3): X'(4 J + k, 4 blk + j) - identical layouts, no transposes; and the
+// output x[t][J] is at the same time the A operand (rows 4 blk + jj, column 4 J + kq) of the 16 new columns' product.  X goes
+// to memory; the tile of rows k1 .. k1+15 also leaves -X in U as the B operands of the new columns.
 template <int TW>
-__device__ __forceinline__ void ll_product_lds(double (&acc)[LL_TMAX][4], double* __restrict__ U, const double* __restrict__ An, int ldu, int k0,
-                                               int row0, int kq, int blk, int jj) {
+__device__ __forceinline__ void ll_l21_own(double (&x)[LL_TMAX][4], const double* __restrict__ U, double* __restrict__ Ub, double* __restrict__ A, int n,
+                                           int ldu, int k0, int row0, bool first_tile, const double (*Dm)[LL_DS], const double (*I4)[16], int kq, int blk,
+                                           int jj) {
+  const int ai = jj, ak = kq;
+  const double i0 = I4[0][ai * 4 + ak], i1 = I4[1][ai * 4 + ak], i2 = I4[2][ai * 4 + ak], i3 = I4[3][ai * 4 + ak];
+  const double m10 = -Dm[4 + ai][ak], m20 = -Dm[8 + ai][ak], m21 = -Dm[8 + ai][4 + ak];
+  const double m30 = -Dm[12 + ai][ak], m31 = -Dm[12 + ai][4 + ak], m32 = -Dm[12 + ai][8 + ak];
+  double sv[TW][4];
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
-    double b[4], a[TW];
+  for (int t = 0; t < TW; ++t)
 #pragma unroll
-    for (int m = 0; m < 4; ++m) b[m] = U[(4 * m + jj) * ldu + k0 + 4 * ks + kq];
+    for (int J = 0; J < 4; ++J) sv[t][J] = U[(4 * J + kq) * ldu + row0 + 16 * t + 4 * blk + jj];
 #pragma unroll
-    for (int t = 0; t < TW; ++t) a[t] = U[(4 * ks + kq) * ldu + row0 + 16 * t + 4 * blk + jj];
+  for (int t = 0; t < TW; ++t) x[t][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(i0, sv[t][0], 0.0, 0, 0, 0);
+#pragma unroll
+  for (int t = 0; t < TW; ++t) {
+    sv[t][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(m10, x[t][0], sv[t][1], 0, 0, 0);
+    sv[t][2] = __builtin_amdgcn_mfma_f64_4x4x4f64(m20, x[t][0], sv[t][2], 0, 0, 0);
+    sv[t][3] = __builtin_amdgcn_mfma_f64_4x4x4f64(m30, x[t][0], sv[t][3], 0, 0, 0);
+  }
+#pragma unroll
+  for (int t = 0; t < TW; ++t) x[t][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(i1, sv[t][1], 0.0, 0, 0, 0);
+#pragma unroll
+  for (int t = 0; t < TW; ++t) {
+    sv[t][2] = __builtin_amdgcn_mfma_f64_4x4x4f64(m21, x[t][1], sv[t][2], 0, 0, 0);
+    sv[t][3] = __builtin_amdgcn_mfma_f64_4x4x4f64(m31, x[t][1], sv[t][3], 0, 0, 0);
+  }
+#pragma unroll
+  for (int t = 0; t < TW; ++t) x[t][2] = __builtin_amdgcn_mfma_f64_4x4x4f64(i2, sv[t][2], 0.0, 0, 0, 0);
+#pragma unroll
+  for (int t = 0; t < TW; ++t) sv[t][3] = __builtin_amdgcn_mfma_f64_4x4x4f64(m32, x[t][2], sv[t][3], 0, 0, 0);
+#pragma unroll
+  for (int t = 0; t < TW; ++t) x[t][3] = __builtin_amdgcn_mfma_f64_4x4x4f64(i3, sv[t][3], 0.0, 0, 0, 0);
+#pragma unroll
+  for (int t = 0; t < TW; ++t) {
+    double* dst = A + (size_t)(k0 + kq) * n + row0 + 16 * t + 4 * blk + jj;   // L(r, k0 + 4 J + kq)
+#pragma unroll
+    for (int J = 0; J < 4; ++J) dst[(size_t)(4 * J) * n] = x[t][J];
+  }
+  if (first_tile) {                                  // rows k1 .. k1+15 (row0 = k1): U[c'][k0 + 4 J + kq] = -L(k1 + c', k0 + 4 J + kq)
+    double* db = Ub + (4 * blk + jj) * ldu + k0 + kq;
+#pragma unroll
+    for (int J = 0; J < 4; ++J) db[4 * J] = -x[0][J];
+  }
+}
+
+// The 16 new columns: acc(t, m) += X(rows of t, k0 + 4 J + k) * (-L(k1 + 4 m + j, k0 + 4 J + k)), the A operands straight from the
+// L21 registers, the B operands from U; then the panel of A (An) is added and S of panel k+1 goes to U over this wave's rows.
+template <int TW>
+__device__ __forceinline__ void ll_finish_own(double (&acc)[LL_TMAX][4], const double (&x)[LL_TMAX][4], double* __restrict__ U,
+                                              const double* __restrict__ An, int ldu, int k0, int row0, int kq, int blk, int jj) {
+  double b[4][4];
+#pragma unroll
+  for (int J = 0; J < 4; ++J)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) b[J][m] = U[(4 * m + jj) * ldu + k0 + 4 * J + kq];
+#pragma unroll
+  for (int J = 0; J < 4; ++J)
 #pragma unroll
     for (int t = 0; t < TW; ++t)
 #pragma unroll
-      for (int m = 0; m < 4; ++m) acc[t][m] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[t], b[m], acc[t][m], 0, 0, 0);
-  }
-  ll_wave_sync();                                  // this wave's reads of its rows are done before it overwrites them
+      for (int m = 0; m < 4; ++m) acc[t][m] = __builtin_amdgcn_mfma_f64_4x4x4f64(x[t][J], b[J][m], acc[t][m], 0, 0, 0);
 #pragma unroll
   for (int t = 0; t < TW; ++t)
 #pragma unroll
@@ -365,41 +415,22 @@ __global__ __launch_bounds__(LL_NT) void kp_chol_ll_kernel(double* __restrict__ 
     if (prof == 2 && lane == 0 && blockIdx.y == 0) kp_chol_ll_pt[0][kb][wave] = (int)(clock64() - tlast);
     __syncthreads();
     LL_TICK(1);
-    // ---- L21' = L11^-1 S21' by 4 x 4 block forward substitution, all waves; the result replaces S in U ----
-    if (ntq > 0) {
-      // A operand (i = lane & 3, k = lane >> 4): a 4 x 4 block of L11 / an inverse diagonal block, the same for all blocks; B
-      // operand and output (k or i = lane >> 4, j = lane & 3): X'(4 J + k, 4 blk + j) - identical layouts
-      const int ai = jj, ak = kq;
-      const double i0 = I4[0][ai * 4 + ak], i1 = I4[1][ai * 4 + ak], i2 = I4[2][ai * 4 + ak], i3 = I4[3][ai * 4 + ak];
-      const double m10 = -Dm[4 + ai][ak], m20 = -Dm[8 + ai][ak], m21 = -Dm[8 + ai][4 + ak];
-      const double m30 = -Dm[12 + ai][ak], m31 = -Dm[12 + ai][4 + ak], m32 = -Dm[12 + ai][8 + ak];
-      for (int t = 1 + wave; t < ntp; t += 8) {
-        const int r = k0 + 16 * t + 4 * blk + jj;
-        const double s0 = U[(0 + kq) * ldu + r], s1 = U[(4 + kq) * ldu + r], s2 = U[(8 + kq) * ldu + r], s3 = U[(12 + kq) * ldu + r];
-        const double x0 = __builtin_amdgcn_mfma_f64_4x4x4f64(i0, s0, 0.0, 0, 0, 0);
-        double t1 = __builtin_amdgcn_mfma_f64_4x4x4f64(m10, x0, s1, 0, 0, 0);
-        double t2 = __builtin_amdgcn_mfma_f64_4x4x4f64(m20, x0, s2, 0, 0, 0);
-        double t3 = __builtin_amdgcn_mfma_f64_4x4x4f64(m30, x0, s3, 0, 0, 0);
-        const double x1 = __builtin_amdgcn_mfma_f64_4x4x4f64(i1, t1, 0.0, 0, 0, 0);
-        t2 = __builtin_amdgcn_mfma_f64_4x4x4f64(m21, x1, t2, 0, 0, 0);
-        t3 = __builtin_amdgcn_mfma_f64_4x4x4f64(m31, x1, t3, 0, 0, 0);
-        const double x2 = __builtin_amdgcn_mfma_f64_4x4x4f64(i2, t2, 0.0, 0, 0, 0);
-        t3 = __builtin_amdgcn_mfma_f64_4x4x4f64(m32, x2, t3, 0, 0, 0);
-        const double x3 = __builtin_amdgcn_mfma_f64_4x4x4f64(i3, t3, 0.0, 0, 0, 0);
-        double* dst = A + (size_t)(k0 + kq) * n + r;                // L(r, k0 + 4 J + kq)
-        dst[0] = x0; dst[(size_t)4 * n] = x1; dst[(size_t)8 * n] = x2; dst[(size_t)12 * n] = x3;
-        double* du = U + kq * ldu + r;
-        du[0] = x0; du[4 * ldu] = x1; du[8 * ldu] = x2; du[12 * ldu] = x3;
-        if (t == 1) {                                               // rows k1 .. k1+15: B operands of the 16 new columns
-          double* db = U + (r - k1) * ldu + k0 + kq;
-          db[0] = -x0; db[4] = -x1; db[8] = -x2; db[12] = -x3;
-        }
+    // ---- L21 of every product wave's own tiles (registers + memory; -X of the first tile into U)  |  wave 0: L11 to memory ----
+    double xo[LL_TMAX][4];
+    if (pwave) {
+      switch (Tw) {
+        case 1: ll_l21_own<1>(xo, U, U, A, n, ldu, k0, row0, tbeg == 0, Dm, I4, kq, blk, jj); break;
+        case 2: ll_l21_own<2>(xo, U, U, A, n, ldu, k0, row0, tbeg == 0, Dm, I4, kq, blk, jj); break;
+        case 3: ll_l21_own<3>(xo, U, U, A, n, ldu, k0, row0, tbeg == 0, Dm, I4, kq, blk, jj); break;
+        default: break;
       }
+    } else {
+      ll_store_diag(Dm, A, n, k0, lane_v);
     }
-    __syncthreads();                                // L of this panel is in memory (and in U) before anyone reads it
+    // (LDS-only: the stores of L stay in flight; the barrier at the end of the panel waits for them before anyone reads L)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     LL_TICK(2);
     // ---- waves 1-7: the 16 new columns, + the panel of A, S of panel k+1 back into U  |  wave 0: stores and staging ----
-    if (!pwave) ll_store_diag(Dm, A, n, k0, lane_v);
     if (late && Tw == 1) {                         // the owner of tile wave - 1 collects its partial sums, waves and pieces in order
       const int K = k0 / 4, npair = (ntq + 1) / 2, Ltot = npair * K, mine = wave - 1;
 #pragma unroll
@@ -418,9 +449,9 @@ __global__ __launch_bounds__(LL_NT) void kp_chol_ll_kernel(double* __restrict__ 
     }
     if (pwave) {
       switch (Tw) {
-        case 1: ll_product_lds<1>(acc, U, An, ldu, k0, row0, kq, blk, jj); break;
-        case 2: ll_product_lds<2>(acc, U, An, ldu, k0, row0, kq, blk, jj); break;
-        case 3: ll_product_lds<3>(acc, U, An, ldu, k0, row0, kq, blk, jj); break;
+        case 1: ll_finish_own<1>(acc, xo, U, An, ldu, k0, row0, kq, blk, jj); break;
+        case 2: ll_finish_own<2>(acc, xo, U, An, ldu, k0, row0, kq, blk, jj); break;
+        case 3: ll_finish_own<3>(acc, xo, U, An, ldu, k0, row0, kq, blk, jj); break;
         default: break;
       }
     }
