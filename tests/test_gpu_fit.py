@@ -140,6 +140,20 @@ def test_gram_linearity_in_snapshots(ctx):
     assert G[dic.N - 1, dic.N - 1] == 100000.0
 
 
+def test_solve_parity_at_every_panel_count(ctx):
+    """Every padded order 16 .. 352 of the left-looking Cholesky (its tile dealing, the overlapped diagonal block and the
+    late-panel (tile pair, k-step) ranges change with the number of panels) and of the right-looking block substitution,
+    plus the orders around the switch to round 1's kernels (> 352)."""
+    rng = np.random.default_rng(99)
+    for W in list(range(9, 353, 16)) + [352, 353, 368, 400]:
+        P = rng.standard_normal((3 * W + 20, W)); Y = rng.standard_normal((3 * W + 20, 5))
+        G, C = P.T @ P, P.T @ Y
+        K = ctx.fit_solve(G, C)
+        Kref = np.linalg.solve(G, C)
+        assert ctx.last_rank() == W
+        assert np.abs(K - Kref).max() <= 1e-10 * np.abs(Kref).max(), W
+
+
 @pytest.mark.parametrize("W,nc", [(5, 5), (16, 16), (17, 3), (32, 1), (33, 7), (48, 48), (136, 136), (336, 336), (500, 16)])
 def test_solve_parity(ctx, W, nc):
     rng = np.random.default_rng(W)
