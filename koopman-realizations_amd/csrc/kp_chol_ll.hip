@@ -14,8 +14,7 @@
 // kernel if nothing runs beside it:
 //   wave 0      panel wave: factors the diagonal block of panel k in registers (lane r of every 16-lane row owns row r; pivots
 //               and multipliers travel by ONE DP-ALU DPP move each, v_mov_b64_dpp row_newbcast) and inverts its four 4 x 4
-//               diagonal blocks; later, while the others finish the next panel, it stages that panel's successor: the rows
-//               of L that become B operands and the panel of A itself (global -> LDS, 8 loads in flight per lane);
+//               diagonal blocks;
 //   waves 1-7   MEANWHILE form the product of panel k+1 over the columns < k0 (everything that does not depend on panel
 //               k), 1-3 row tiles each, L operands fetched 3-8 k-steps ahead, B operands one k-step ahead;
 //   waves 1-7   then form L21' = L11^-1 S21' of their OWN tiles by 4 x 4 block forward substitution (the output layout of one MFMA
@@ -23,7 +22,9 @@
 //               operands of the 16 new columns - finish the product of panel k+1 with them, add the panel of A and leave S of
 //               panel k+1 in LDS where S of panel k was.
 // LDS: U[16][n] holds, for panel k, S(c, row) at rows >= k0 and - in the rows < k0 that S no longer needs - the B operands
-// L(k0 + 16 + c, j) of the next product; two buffers An[2][16][n] take the panels of A in turn.
+// -L(k0 + 16 + c, j) of the next product; two buffers An[2][16][n] take the panels of A in turn.  The staging copies (rows of L
+// that become B operands, the next-but-one panel of A; global -> LDS, 8 loads in flight per thread) are dealt to all waves,
+// each doing its share after its own work of a phase.  Late panels (fewer tiles than product waves): see `late` below.
 // L' (upper triangle) and the inverses of the 16 x 16 diagonal blocks, which only the TRSM kernel needs, are produced
 // afterwards by kp_chol_finish_kernel, off the critical path.
 #include "kp_internal.h"
