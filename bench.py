@@ -370,6 +370,8 @@ def main():
     import gc
     gc.collect()
     gc.freeze()
+    if chunks:
+        time.sleep(0.5)                            # let the generator's worker processes be reaped before the launch-rate-bound region
     import koopman_realizations_amd as kra
     ctx, comm = kc.init_from_env(kra.Context)      # one process per GPU; RCCL communicator through the C ABI when world > 1
     Ns = args.snapshots
