@@ -230,3 +230,35 @@ def test_sym_eig_matches_lapack(ctx, n):
     assert 0 < sweeps < 30
     assert np.abs(w - wl).max() <= 1e-13 * scale * max(1, n / 50)
     assert np.abs(S @ V - V * w).max() <= 1e-12 * scale and np.abs(V.T @ V - np.eye(n)).max() <= 1e-12
+
+
+def test_train_models_with_a_vector_of_lasso_values_and_sampled_snapshots(ctx):
+    """train_models(lasso vector) (Ksysid.m:1344-1389): one koopData / candidate per value, `model` = the first candidate; and the
+    constructor's `snapshots` < Inf (:960-975): that many pairs drawn without replacement from the good ones."""
+    from tests._loaded_system import make_trials
+    trials = [{k: v for k, v in t.items() if k != "w"} for t in make_trials(6, 200, nw=1, seed=21)]
+    lass = [0.3, 2.0, np.inf]
+    ks = kra.Ksysid({"train": trials[:5], "val": trials[5:]}, ctx=ctx, model_type="bilinear", obs_type=["poly"], obs_degree=[2], lasso=lass,
+                    snapshots=400)
+    sp = ks.snapshotPairs
+    assert sp["alpha"].shape == (400, 2) and sp["u"].shape == (400, 1)
+    full = kra.Ksysid({"train": trials[:5], "val": trials[5:]}, ctx=ctx, model_type="bilinear", obs_type=["poly"], obs_degree=[2], lasso=lass)
+    allp = {tuple(np.round(np.concatenate([a, b, u]), 12)) for a, b, u in zip(full.snapshotPairs["alpha"], full.snapshotPairs["beta"], full.snapshotPairs["u"])}
+    mine = [tuple(np.round(np.concatenate([a, b, u]), 12)) for a, b, u in zip(sp["alpha"], sp["beta"], sp["u"])]
+    assert len(set(mine)) == 400 and set(mine) <= allp                          # a subset of the good pairs, no repeats
+    ks.train_models()
+    assert isinstance(ks.candidates, list) and len(ks.candidates) == 3 and len(ks.koopData) == 3
+    assert [c["lasso"] for c in ks.candidates] == [0.3, 2.0, 1e6] and ks.model is ks.candidates[0]
+    dic = ko.build_dictionary("bilinear", 2, 1, ["poly"], [2])
+    Px, Py = ko.px_py(dic, sp)
+    G, C = ko.gram(Px, Py)
+    Kls = np.linalg.solve(G, C)
+    for kd, lv in zip(ks.koopData, [0.3, 2.0, 1e6]):
+        K = kd["K"]
+        t = lv * dic.N                                                         # :996
+        if np.abs(Kls).sum() <= t:
+            assert np.abs(K - Kls).max() < 1e-8 * max(1.0, np.abs(Kls).max())
+        else:
+            Ko = ko.koopman_lasso(G, C, t)
+            assert abs(np.abs(K).sum() - t) < 1e-6 * t and np.abs(K - Ko).max() < 1e-5 * max(1.0, np.abs(Ko).max())
+    assert np.abs(ks.candidates[1]["A"] - ks.koopData[1]["K"].T[:dic.N, :dic.N]).max() == 0      # get_BLmodel slices K' (:1261)
