@@ -119,7 +119,7 @@ __device__ __forceinline__ bool eig_grid_barrier(unsigned* ctr, unsigned target)
     bool ok = true;
     while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
       __builtin_amdgcn_s_sleep(1);
-      if (++spins > (1 << 24)) { ok = false; break; }   // a workgroup that never became resident: give up instead of hanging
+      if (++spins > (1 << 19)) { ok = false; break; }   // ~1 s: a peer that never became resident - give up instead of hanging
     }
     __threadfence();
     ok_sh = ok ? 1 : 0;
@@ -277,7 +277,18 @@ extern "C" int kp_sym_eig(kp_ctx* ctx, const double* S, int n, double* V_out, do
   int sw[2] = {0, 0};
   KP_HIP(ctx, hipMemcpyAsync(sw, dsw, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
   KP_HIP(ctx, hipStreamSynchronize(s));
-  if (multi && sw[0] == 0) return ctx->fail(KP_ERR_HIP, "kp_sym_eig: the workgroups of the eigensolver did not all become resident");
+  if (multi && sw[0] == 0) {
+    // a workgroup gave up waiting at the grid barrier (its peers were not all resident: a GPU shared with another process).
+    // The one-workgroup form needs no peers.
+    if (n > EIG_MAXN) return ctx->fail(KP_ERR_HIP, "kp_sym_eig: the workgroups of the eigensolver did not all become resident");
+    KP_HIP(ctx, hipMemcpyAsync(dS, S, bS, hipMemcpyHostToDevice, s));
+    KP_HIP(ctx, hipMemsetAsync(dsw, 0, 64, s));
+    hipLaunchKernelGGL(kp_jacobi_eig_kernel, dim3(1), dim3(256), 0, s, dS, dV, n, 30, 1e-15, dsw);
+    KP_HIP(ctx, hipGetLastError());
+    KP_HIP(ctx, hipMemcpyAsync(sw, dsw, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+    KP_HIP(ctx, hipStreamSynchronize(s));
+    sw[1] = 0;
+  }
   std::vector<double> Sd(bS / 8);
   KP_HIP(ctx, hipMemcpyAsync(Sd.data(), (multi && sw[1]) ? dS1 : dS, bS, hipMemcpyDeviceToHost, s));
   KP_HIP(ctx, hipMemcpyAsync(V_out, dV, bS, hipMemcpyDeviceToHost, s));

@@ -393,7 +393,9 @@ static bool trsm_old_sel() {
 #define TR2_MAXR 8   // row blocks per wave: ceil(32 / 4)  =>  n <= 512
 namespace {
 
-__device__ __forceinline__ int tr2_col(int c) { return (c & 3) * 4 + (c >> 2); }   // LDS column order: a lane's 4 J are contiguous
+// LDS column order of a block of 4 NJ right-hand sides: a lane's NJ values (columns 4 J + jj) are contiguous
+template <int NJ>
+__device__ __forceinline__ int tr2_col(int c) { return (c & 3) * NJ + (c >> 2); }
 
 // an[q][K] = -(A operand of tile (row(q), column block jc)): rows 4 blk + jj of the tile, column 4 K + kq
 template <int CNT>
@@ -405,27 +407,55 @@ __device__ __forceinline__ void tr2_load(double (&an)[TR2_MAXR][4], const double
     for (int K = 0; K < 4; ++K) an[q][K] = -LU[(size_t)(jc * 16 + 4 * K + kq) * n + rowof[q] * 16 + 4 * blk + jj];
 }
 
-// slots [q0, CNT): R -= L Y  (16 MFMAs per tile: 4 independent chains of 4)
-template <int CNT>
-__device__ __forceinline__ void tr2_update(double (&acc)[TR2_MAXR][4], const double (&an)[TR2_MAXR][4], const double (&bv)[4][4], int q0) {
+// slots [q0, CNT): R -= L Y  (4 NJ MFMAs per tile: NJ independent chains of 4)
+template <int CNT, int NJ>
+__device__ __forceinline__ void tr2_update(double (&acc)[TR2_MAXR][NJ], const double (&an)[TR2_MAXR][4], const double (&bv)[4][NJ], int q0) {
 #pragma unroll
   for (int q = 0; q < CNT; ++q) {
     if (q < q0) continue;
 #pragma unroll
     for (int K = 0; K < 4; ++K)
 #pragma unroll
-      for (int J = 0; J < 4; ++J) acc[q][J] = __builtin_amdgcn_mfma_f64_4x4x4f64(an[q][K], bv[K][J], acc[q][J], 0, 0, 0);
+      for (int J = 0; J < NJ; ++J) acc[q][J] = __builtin_amdgcn_mfma_f64_4x4x4f64(an[q][K], bv[K][J], acc[q][J], 0, 0, 0);
+  }
+}
+
+// the NJ values of a lane in row `row` of xs (row stride 4 NJ doubles)
+template <int NJ>
+__device__ __forceinline__ void tr2_get(const double* __restrict__ xs, int row, int jj, double (&v)[NJ]) {
+  const double* p = xs + row * (4 * NJ) + jj * NJ;
+  if constexpr (NJ == 4) {
+    const double2 v01 = reinterpret_cast<const double2*>(p)[0], v23 = reinterpret_cast<const double2*>(p)[1];
+    v[0] = v01.x; v[1] = v01.y; v[2] = v23.x; v[3] = v23.y;
+  } else if constexpr (NJ == 2) {
+    const double2 v01 = reinterpret_cast<const double2*>(p)[0];
+    v[0] = v01.x; v[1] = v01.y;
+  } else {
+    v[0] = p[0];
+  }
+}
+
+template <int NJ>
+__device__ __forceinline__ void tr2_put(double* __restrict__ xs, int row, int jj, const double (&v)[NJ]) {
+  double* p = xs + row * (4 * NJ) + jj * NJ;
+  if constexpr (NJ == 4) {
+    double2 v01, v23;
+    v01.x = v[0]; v01.y = v[1]; v23.x = v[2]; v23.y = v[3];
+    reinterpret_cast<double2*>(p)[0] = v01; reinterpret_cast<double2*>(p)[1] = v23;
+  } else if constexpr (NJ == 2) {
+    double2 v01;
+    v01.x = v[0]; v01.y = v[1];
+    reinterpret_cast<double2*>(p)[0] = v01;
+  } else {
+    p[0] = v[0];
   }
 }
 
 // B operands of a 16-row block of xs: b[K][J] = X(4 K + kq, 4 J + jj)
-__device__ __forceinline__ void tr2_read_b(const double* __restrict__ xs, int j, int kq, int jj, double (&b)[4][4]) {
+template <int NJ>
+__device__ __forceinline__ void tr2_read_b(const double* __restrict__ xs, int j, int kq, int jj, double (&b)[4][NJ]) {
 #pragma unroll
-  for (int K = 0; K < 4; ++K) {
-    const double2* p = reinterpret_cast<const double2*>(xs + (j * 16 + 4 * K + kq) * 16 + jj * 4);
-    const double2 v01 = p[0], v23 = p[1];
-    b[K][0] = v01.x; b[K][1] = v01.y; b[K][2] = v23.x; b[K][3] = v23.y;
-  }
+  for (int K = 0; K < 4; ++K) tr2_get<NJ>(xs, j * 16 + 4 * K + kq, jj, b[K]);
 }
 
 }  // namespace
@@ -443,19 +473,23 @@ __device__ __forceinline__ void tr2_read_b(const double* __restrict__ xs, int j,
     default: break;                                                                        \
   }
 
-__global__ __launch_bounds__(256) void kp_trsm2_kernel(const double* __restrict__ LU, const double* __restrict__ Dinv, int n,
+// NJ = right-hand sides per workgroup / 4.  One system: NJ = 1 (W / 4 workgroups, the shortest serial chain per step); a batch
+// of systems: NJ = 4 (every workgroup reads all of L: fewer, wider workgroups keep that traffic down).
+template <int NJ>
+__global__ __launch_bounds__(256) void kp_trsm2_kernel(const double* __restrict__ LU, const double* __restrict__ Dinv, int n, int ncp,
                                                       double* __restrict__ X) {
-  extern __shared__ __align__(16) double xs[];  // [n][16] X block, columns in tr2_col order
+  extern __shared__ __align__(16) double xs[];  // [n][4 NJ] X block, columns in tr2_col order
+  constexpr int NC = 4 * NJ;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int cb = blockIdx.x;
   const int nt = n / 16;
   const int kq = lane >> 4, blk = (lane >> 2) & 3, jj = lane & 3;
-  LU += blockIdx.y * (size_t)n * n; Dinv += blockIdx.y * (size_t)nt * 256; X += blockIdx.y * (size_t)n * gridDim.x * 16;   // system of a batch
-  double* Xb = X + (size_t)cb * 16 * n;
-  for (int e = tid; e < n * 16; e += 256) {
+  LU += blockIdx.y * (size_t)n * n; Dinv += blockIdx.y * (size_t)nt * 256; X += blockIdx.y * (size_t)n * ncp;   // system of a batch
+  double* Xb = X + (size_t)cb * NC * n;
+  for (int e = tid; e < n * NC; e += 256) {
     int row = e % n, col = e / n;
-    xs[row * 16 + tr2_col(col)] = Xb[(size_t)col * n + row];       // C block -> LDS (overwritten by Y, then K)
+    xs[row * NC + tr2_col<NJ>(col)] = Xb[(size_t)col * n + row];       // C block -> LDS (overwritten by Y, then K)
   }
   __syncthreads();
   const int nown = wave < nt ? (nt - wave + 3) / 4 : 0;    // row blocks wave, wave + 4, ... < nt
@@ -466,13 +500,9 @@ __global__ __launch_bounds__(256) void kp_trsm2_kernel(const double* __restrict_
     int rowof[TR2_MAXR];
 #pragma unroll
     for (int q = 0; q < TR2_MAXR; ++q) rowof[q] = q < nown ? (dir == 0 ? wave + 4 * (nown - 1 - q) : wave + 4 * q) : 0;
-    double acc[TR2_MAXR][4];                               // R(4 blk + kq, 4 J + jj) of the slot's row block
+    double acc[TR2_MAXR][NJ];                              // R(4 blk + kq, 4 J + jj) of the slot's row block
 #pragma unroll
-    for (int q = 0; q < TR2_MAXR; ++q) {
-      const double2* p = reinterpret_cast<const double2*>(xs + (rowof[q] * 16 + 4 * blk + kq) * 16 + jj * 4);
-      const double2 v01 = p[0], v23 = p[1];
-      acc[q][0] = v01.x; acc[q][1] = v01.y; acc[q][2] = v23.x; acc[q][3] = v23.y;
-    }
+    for (int q = 0; q < TR2_MAXR; ++q) tr2_get<NJ>(xs, rowof[q] * 16 + 4 * blk + kq, jj, acc[q]);
     // owned rows strictly beyond row j in sweep direction (= the rows the update with X_j reaches)
     auto beyond = [&](int j) {
       const int c = dir == 0 ? nown - (j < wave ? 0 : (j - wave) / 4 + 1) : (j <= wave ? 0 : (j - wave + 3) / 4);
@@ -496,7 +526,7 @@ __global__ __launch_bounds__(256) void kp_trsm2_kernel(const double* __restrict_
       load_dinv(jf, dv);
     }
     double an[TR2_MAXR][4];
-    double bv[4][4];
+    double bv[4][NJ];
     int cnt = nown;                                        // rows reached by "X_{j0 - jstep}": all of them (nothing pending)
     for (int it = 0; it < nt; ++it) {
       const int j = j0 + it * jstep;
@@ -504,59 +534,51 @@ __global__ __launch_bounds__(256) void kp_trsm2_kernel(const double* __restrict_
       // here: an / bv = tiles of column j - jstep for the slots [0, cnt) and X_{j - jstep} (it > 0), not yet applied
       if (owner) {
         const int qj = cnt - 1;                            // slot of row j
-        if (it > 0) { TR2_SWITCH((tr2_update<C_>(acc, an, bv, C_ - 1))); }      // row j alone
-        double rj[4];
+        if (it > 0) { TR2_SWITCH((tr2_update<C_, NJ>(acc, an, bv, C_ - 1))); }      // row j alone
+        double rj[NJ];
 #pragma unroll
-        for (int J = 0; J < 4; ++J) rj[J] = acc[0][J];
+        for (int J = 0; J < NJ; ++J) rj[J] = acc[0][J];
 #pragma unroll
         for (int q = 1; q < TR2_MAXR; ++q)
           if (q == qj) {
 #pragma unroll
-            for (int J = 0; J < 4; ++J) rj[J] = acc[q][J];
+            for (int J = 0; J < NJ; ++J) rj[J] = acc[q][J];
           }
         // R_j through LDS into the B-operand layout (only this wave touches block j of xs now), times the inverse block
-        {
-          double2* p = reinterpret_cast<double2*>(xs + (j * 16 + 4 * blk + kq) * 16 + jj * 4);
-          double2 v01, v23;
-          v01.x = rj[0]; v01.y = rj[1]; v23.x = rj[2]; v23.y = rj[3];
-          p[0] = v01; p[1] = v23;
-        }
+        tr2_put<NJ>(xs, j * 16 + 4 * blk + kq, jj, rj);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        double br[4][4];
-        tr2_read_b(xs, j, kq, jj, br);
-        double y[4] = {0.0, 0.0, 0.0, 0.0};
+        double br[4][NJ];
+        tr2_read_b<NJ>(xs, j, kq, jj, br);
+        double y[NJ];
+#pragma unroll
+        for (int J = 0; J < NJ; ++J) y[J] = 0.0;
 #pragma unroll
         for (int K = 0; K < 4; ++K)
 #pragma unroll
-          for (int J = 0; J < 4; ++J) y[J] = __builtin_amdgcn_mfma_f64_4x4x4f64(dv[K], br[K][J], y[J], 0, 0, 0);
+          for (int J = 0; J < NJ; ++J) y[J] = __builtin_amdgcn_mfma_f64_4x4x4f64(dv[K], br[K][J], y[J], 0, 0, 0);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();                    // all lanes have read R_j before Y_j replaces it
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        {
-          double2* p = reinterpret_cast<double2*>(xs + (j * 16 + 4 * blk + kq) * 16 + jj * 4);
-          double2 v01, v23;
-          v01.x = y[0]; v01.y = y[1]; v23.x = y[2]; v23.y = y[3];
-          p[0] = v01; p[1] = v23;
-        }
+        tr2_put<NJ>(xs, j * 16 + 4 * blk + kq, jj, y);
         load_dinv(j + 4 * jstep, dv);
-        if (it > 0) { TR2_SWITCH((tr2_update<C_ - 1>(acc, an, bv, 0))); }      // the rest of this wave's rows
+        if (it > 0) { TR2_SWITCH((tr2_update<C_ - 1, NJ>(acc, an, bv, 0))); }      // the rest of this wave's rows
       } else if (it > 0) {
-        TR2_SWITCH((tr2_update<C_>(acc, an, bv, 0)));
+        TR2_SWITCH((tr2_update<C_, NJ>(acc, an, bv, 0)));
       }
       // tiles of column j for the rows beyond it: requested now, used after the barrier
       cnt = beyond(j);
       TR2_SWITCH((tr2_load<C_>(an, LU, n, j, rowof, kq, blk, jj)));
       // LDS-only barrier: the tile loads just issued stay in flight across it (a __syncthreads would wait for them)
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      tr2_read_b(xs, j, kq, jj, bv);
+      tr2_read_b<NJ>(xs, j, kq, jj, bv);
     }
     __syncthreads();
   }
-  for (int e = tid; e < n * 16; e += 256) {
+  for (int e = tid; e < n * NC; e += 256) {
     int row = e % n, col = e / n;
-    Xb[(size_t)col * n + row] = xs[row * 16 + tr2_col(col)];
+    Xb[(size_t)col * n + row] = xs[row * NC + tr2_col<NJ>(col)];
   }
 }
 
@@ -594,9 +616,16 @@ int kp_chol_solve_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_de
     hipLaunchKernelGGL(kp_chol_finish_kernel, dim3(npair + nbk, nb), dim3(256), 0, st, Gp, n, npair, Dinv);
   }
   KP_HIP(ctx, hipGetLastError());
-  KP_HIP(ctx, kp_ensure_lds(trsm_lds, trsm_old_sel() ? (const void*)kp_trsm_kernel : (const void*)kp_trsm2_kernel, lds_trsm));
-  if (trsm_old_sel()) hipLaunchKernelGGL(kp_trsm_kernel, dim3(ncp / 16, nb), dim3(256), lds_trsm, st, Gp, Dinv, n, Cp);
-  else hipLaunchKernelGGL(kp_trsm2_kernel, dim3(ncp / 16, nb), dim3(256), lds_trsm, st, Gp, Dinv, n, Cp);
+  if (trsm_old_sel()) {
+    KP_HIP(ctx, kp_ensure_lds(trsm_lds, (const void*)kp_trsm_kernel, lds_trsm));
+    hipLaunchKernelGGL(kp_trsm_kernel, dim3(ncp / 16, nb), dim3(256), lds_trsm, st, Gp, Dinv, n, Cp);
+  } else if (nb == 1) {       // one system: 4 right-hand sides per workgroup - the shortest serial chain per step (LDS <= 16 KB)
+    hipLaunchKernelGGL((kp_trsm2_kernel<1>), dim3(ncp / 4, nb), dim3(256), (size_t)n * 4 * 8, st, Gp, Dinv, n, ncp, Cp);
+  } else {                    // a batch: 16 per workgroup, every workgroup reads all of L
+    static KpLdsCache trsm2_lds;
+    KP_HIP(ctx, kp_ensure_lds(trsm2_lds, (const void*)kp_trsm2_kernel<4>, (size_t)n * 16 * 8));
+    hipLaunchKernelGGL((kp_trsm2_kernel<4>), dim3(ncp / 16, nb), dim3(256), (size_t)n * 16 * 8, st, Gp, Dinv, n, ncp, Cp);
+  }
   KP_HIP(ctx, hipGetLastError());
   hipLaunchKernelGGL(kp_unpad_kernel, dim3((unsigned)(((int64_t)W * ncols + 255) / 256), nb), dim3(256), 0, st, Cp, n, W, ncols, K_dev, ncp, k_first,
                      k_cap);
