@@ -37,16 +37,51 @@ class LocalComm:
         pass
 
 
+def single_node_defaults():
+    """RCCL reads its environment when the library initialises.  All ranks of a launch sit on ONE node here (the xGMI
+    mesh), so - unless the caller chose otherwise - the bootstrap sockets use the loopback interface and the InfiniBand
+    probe is skipped: an interface that cannot reach itself on a sandboxed box makes ncclCommInitRank wait for ever.
+    A launch that names another master address keeps RCCL's own interface search."""
+    if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost", "::1"):
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        os.environ.setdefault("NCCL_IB_DISABLE", "1")
+
+
+class RcclInitTimeout(TimeoutError):
+    pass
+
+
 class RcclComm:
-    """kp_comm_create on a Context: RCCL communicator of `world` processes, this one being `rank`."""
+    """kp_comm_create on a Context: RCCL communicator of `world` processes, this one being `rank`.  The call runs under a
+    watchdog (KP_COMM_INIT_TIMEOUT seconds, default 120): a bootstrap that never completes raises RcclInitTimeout instead
+    of blocking the launch (the blocked thread is abandoned; `init_from_env` then agrees on the file backend)."""
     kind = "rccl"
 
-    def __init__(self, ctx, rank: int, world: int, unique_id: bytes):
+    def __init__(self, ctx, rank: int, world: int, unique_id: bytes, timeout: float | None = None):
         if len(unique_id) != 128:
             raise ValueError("RCCL unique id is 128 bytes")
         self.ctx, self.rank, self.world = ctx, int(rank), int(world)
+        single_node_defaults()
         buf = C.create_string_buffer(unique_id, 128)
-        F.check(F.lib().kp_comm_create(ctx.handle, C.cast(buf, C.c_void_p), self.rank, self.world), ctx.handle)
+        if timeout is None:
+            timeout = float(os.environ.get("KP_COMM_INIT_TIMEOUT", "120"))
+        box = {}
+
+        def run():
+            try:
+                box["rc"] = F.lib().kp_comm_create(ctx.handle, C.cast(buf, C.c_void_p), self.rank, self.world)
+            except BaseException as e:                    # noqa: BLE001 - handed to the caller's thread
+                box["exc"] = e
+
+        import threading
+        th = threading.Thread(target=run, name="kp_comm_create", daemon=True)
+        th.start()
+        th.join(timeout)
+        if th.is_alive():
+            raise RcclInitTimeout(f"rank {rank}: ncclCommInitRank did not return within {timeout:.0f} s")
+        if "exc" in box:
+            raise box["exc"]
+        F.check(box["rc"], ctx.handle)
 
     def all_gather_bytes(self, payload: bytes):
         """Every rank contributes the same number of bytes; returns the world payloads in rank order."""
@@ -144,6 +179,7 @@ def max_over_ranks(comm, x: float) -> float:
 # ---- rendezvous of the 128-byte RCCL id (single node: a file) -----------------------------------------------------
 
 def unique_id() -> bytes:
+    single_node_defaults()
     buf = C.create_string_buffer(128)
     F.check(F.lib().kp_comm_unique_id(C.cast(buf, C.c_void_p)))
     return buf.raw

@@ -92,6 +92,35 @@ def test_unique_id_file_rendezvous(tmp_path, monkeypatch):
     assert kcomm.all_gather_object(loc, {"a": 1}) == [{"a": 1}] and kcomm.all_gather_array(loc, np.arange(3.0)).shape == (1, 3)
 
 
+def test_communicator_creation_runs_under_a_watchdog(monkeypatch):
+    """A bootstrap that never completes raises RcclInitTimeout (init_from_env then votes for the file backend); errors of
+    a call that does return pass through; single-node launches default the bootstrap to the loopback interface."""
+    import time as _t
+    import types
+    from koopman_realizations_amd import comm as kcomm, _ffi as F
+
+    class Ctx:
+        handle = None
+
+    slow = types.SimpleNamespace(kp_comm_create=lambda *a: _t.sleep(5.0) or 0)
+    monkeypatch.setattr(F, "lib", lambda: slow)
+    monkeypatch.delenv("NCCL_SOCKET_IFNAME", raising=False)
+    monkeypatch.delenv("MASTER_ADDR", raising=False)
+    t0 = _t.time()
+    with pytest.raises(kcomm.RcclInitTimeout):
+        kcomm.RcclComm(Ctx(), 0, 2, bytes(128), timeout=0.2)
+    assert _t.time() - t0 < 2.0
+    assert os.environ["NCCL_SOCKET_IFNAME"] == "lo"
+    ok = types.SimpleNamespace(kp_comm_create=lambda *a: 0)
+    monkeypatch.setattr(F, "lib", lambda: ok)
+    monkeypatch.setattr(F, "check", lambda rc, h=None: None)
+    assert kcomm.RcclComm(Ctx(), 1, 2, bytes(128), timeout=5.0).rank == 1
+    monkeypatch.delenv("NCCL_SOCKET_IFNAME", raising=False)
+    monkeypatch.setenv("MASTER_ADDR", "10.0.0.7")          # another node named: RCCL keeps its own interface search
+    kcomm.single_node_defaults()
+    assert "NCCL_SOCKET_IFNAME" not in os.environ
+
+
 def test_package_is_torch_free():
     import re
     pk = os.path.join(ROOT, "koopman-realizations_amd")
