@@ -124,6 +124,16 @@ int kp_lift(kp_ctx* ctx, const kp_basis* basis, int what, const double* zeta, co
  * (Ksysid.m:977-979).  The random draw (:974-975) stays on the MATLAB host. */
 int kp_snapshots_upload(kp_ctx* ctx, const double* alpha, const double* beta, const double* u,
                         int64_t Ns, int nzeta, int m, kp_snapshots** snaps);
+/* Refills an existing object from new host arrays of the same column counts (a caller that hands a new
+ * snapshotPairs struct to every Ksysid.get_Koopman call, Ksysid.m:987, keeps two objects and fills them alternately).
+ * Returns as soon as the caller's arrays have been copied into the library's pinned staging ring - they may be reused
+ * or freed at once; the transfer itself runs on the context's copy stream behind every kernel already enqueued that
+ * reads the object and ahead of every later one (events, no device synchronisation), so it overlaps the Gram kernel
+ * of another object.  Ns may differ from the previous contents (the arrays grow when needed, which drains the
+ * pipeline once).  Both entry points stage through pinned memory in chunks copied by KP_COPY_THREADS host threads
+ * (default 4 on hosts with >= 16 cores) while the DMA of earlier chunks is already running. */
+int kp_snapshots_update(kp_ctx* ctx, kp_snapshots* snaps, const double* alpha, const double* beta, const double* u,
+                        int64_t Ns);
 int kp_snapshots_destroy(kp_snapshots* snaps);
 
 /* ---- EDMD fit ---------------------------------------------------------------------

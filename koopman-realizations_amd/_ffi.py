@@ -45,6 +45,7 @@ SIGNATURES = {
     "kp_basis_dims": (C.c_int, [vp, c_ip, c_ip, c_ip, c_ip]),
     "kp_lift": (C.c_int, [vp, vp, C.c_int, c_dp, c_dp, C.c_int64, c_dp]),
     "kp_snapshots_upload": (C.c_int, [vp, c_dp, c_dp, c_dp, C.c_int64, C.c_int, C.c_int, C.POINTER(vp)]),
+    "kp_snapshots_update": (C.c_int, [vp, vp, c_dp, c_dp, c_dp, C.c_int64]),
     "kp_snapshots_destroy": (C.c_int, [vp]),
     "kp_fit_gram": (C.c_int, [vp, vp, vp, c_dp, c_dp]),
     "kp_fit_solve": (C.c_int, [vp, c_dp, c_dp, C.c_int, C.c_int, c_dp]),

@@ -305,11 +305,13 @@ extern "C" int kp_fit_batch(kp_ctx* ctx, const kp_basis* basis, const kp_snapsho
   const size_t pw_bytes = (size_t)2 * b.nvars * basis->pow_depth * SB_TS * sizeof(double);
   const bool use_rec = basis->fast && basis->d_recipes && basis->pow_depth >= 1 && lds + pw_bytes <= 64 * 1024;
   if (use_rec) lds += pw_bytes;
+  KP_HIP(ctx, kp_snaps_acquire(snaps, s));
   KP_HIP(ctx, hipEventRecord(ctx->ev0, s));
   hipLaunchKernelGGL(kp_small_fit_kernel, dim3(nb), dim3(256), lds, s, b, snaps->alpha, snaps->beta, snaps->u, snaps->Ns, (int)Ns_each, dK, dG, dC,
                      dS, use_rec ? (const uint32_t*)basis->d_recipes : nullptr, basis->pow_depth, basis->max_factors > 0 ? basis->max_factors : 1,
                      refine, TrajView{}, 0);
   KP_HIP(ctx, hipGetLastError());
+  KP_HIP(ctx, kp_snaps_release(snaps, s));
   KP_HIP(ctx, hipEventRecord(ctx->ev1, s));
   KP_HIP(ctx, hipMemcpyAsync(K_out, dK, bW, hipMemcpyDeviceToHost, s));
   if (G_out) KP_HIP(ctx, hipMemcpyAsync(G_out, dG, bW, hipMemcpyDeviceToHost, s));

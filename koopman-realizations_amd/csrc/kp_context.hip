@@ -74,6 +74,7 @@ extern "C" int kp_destroy(kp_ctx* c) {
   if (!c) return KP_OK;
   (void)kp_comm_destroy(c);
   (void)hipSetDevice(c->device);
+  kp_stage_destroy(c);
   (void)hipStreamSynchronize(c->stream);
   if (c->stream2) (void)hipStreamSynchronize(c->stream2);
   for (int i = 0; i < 10; ++i)
@@ -300,47 +301,7 @@ extern "C" int kp_basis_dims(const kp_basis* b, int* nvars, int* nfull, int* N, 
 // snapshots
 // ------------------------------------------------------------------------------------
 
-extern "C" int kp_snapshots_upload(kp_ctx* ctx, const double* alpha, const double* beta, const double* u, int64_t Ns,
-                                   int nzeta, int m, kp_snapshots** out) {
-  if (!ctx || !out || Ns < 0 || nzeta < 1 || m < 0 || (Ns > 0 && (!alpha || !beta || (m > 0 && !u))))
-    return ctx ? ctx->fail(KP_ERR_ARG, "kp_snapshots_upload: bad argument") : KP_ERR_ARG;
-  *out = nullptr;
-  KP_HIP(ctx, hipSetDevice(ctx->device));
-  kp_snapshots* s = new kp_snapshots();
-  s->ctx = ctx;
-  s->Ns = Ns;
-  s->nzeta = nzeta;
-  s->m = m;
-  // every array carries 64 doubles of zero padding: the Gram kernels prefetch up to two snapshot tiles past the
-  // end of a row without bounds checks (the values are masked, the addresses must be mapped)
-  const size_t pad = 64 * sizeof(double);
-  size_t bz = (size_t)Ns * nzeta * sizeof(double), bu = (size_t)Ns * m * sizeof(double);
-  hipError_t e = hipSuccess;
-  if ((e = hipMalloc((void**)&s->alpha, bz + pad)) == hipSuccess && (e = hipMalloc((void**)&s->beta, bz + pad)) == hipSuccess &&
-      (e = hipMemset((char*)s->alpha + bz, 0, pad)) == hipSuccess && (e = hipMemset((char*)s->beta + bz, 0, pad)) == hipSuccess && bz) {
-    if ((e = hipMemcpy(s->alpha, alpha, bz, hipMemcpyHostToDevice)) == hipSuccess)
-      e = hipMemcpy(s->beta, beta, bz, hipMemcpyHostToDevice);
-  }
-  if (e == hipSuccess && (e = hipMalloc((void**)&s->u, bu + pad)) == hipSuccess &&
-      (e = hipMemset((char*)s->u + bu, 0, pad)) == hipSuccess && bu)
-    e = hipMemcpy(s->u, u, bu, hipMemcpyHostToDevice);
-  if (e != hipSuccess) {
-    kp_snapshots_destroy(s);
-    return ctx->fail(KP_ERR_HIP, std::string("kp_snapshots_upload: ") + hipGetErrorString(e));
-  }
-  *out = s;
-  return KP_OK;
-}
-
-extern "C" int kp_snapshots_destroy(kp_snapshots* s) {
-  if (!s) return KP_OK;
-  (void)hipSetDevice(s->ctx->device);
-  if (s->alpha) (void)hipFree(s->alpha);
-  if (s->beta) (void)hipFree(s->beta);
-  if (s->u) (void)hipFree(s->u);
-  delete s;
-  return KP_OK;
-}
+// kp_snapshots_upload / kp_snapshots_update / kp_snapshots_destroy: kp_upload.hip (staged, chunked host -> HBM copy)
 
 // ------------------------------------------------------------------------------------
 // standalone lift kernel: lift.full / lift.econ_full / Px rows for a batch of points

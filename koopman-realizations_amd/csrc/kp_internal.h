@@ -12,8 +12,11 @@
 void kp_set_global_error(const std::string& s);
 struct kp_comm_state;   // RCCL communicator of a multi-process run (kp_comm.hip)
 
+struct kp_stage;   // kp_upload.hip: copy stream, pinned staging ring and copy threads of the host -> HBM path
+
 struct kp_ctx {
   int device = 0;
+  kp_stage* stage = nullptr;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipEvent_t evp[6] = {nullptr};   // gram start, gram end, reduce end, solve end, spare x2
@@ -156,7 +159,26 @@ struct kp_snapshots {
   double* alpha = nullptr;  // Ns x nzeta col-major
   double* beta = nullptr;
   double* u = nullptr;      // Ns x m
+  int64_t cap_rows = 0;     // rows the arrays were allocated for (kp_snapshots_update refills them in place)
+  // kp_snapshots_update (kp_upload.hip): the refill runs on the copy stream; `ev_ready` follows its last DMA, `ev_read`
+  // the last kernel that read the arrays (recorded only once the object has been refilled: `streaming`)
+  hipEvent_t ev_ready = nullptr, ev_read = nullptr;
+  mutable bool dma_pending = false, read_pending = false;
+  bool streaming = false;
 };
+void kp_stage_destroy(kp_ctx* ctx);
+// Around every launch sequence that reads a snapshot object.  All readers run on ctx->stream, so one wait orders the
+// later ones too.
+inline hipError_t kp_snaps_acquire(const kp_snapshots* s, hipStream_t st) {
+  if (!s->dma_pending) return hipSuccess;
+  s->dma_pending = false;
+  return hipStreamWaitEvent(st, s->ev_ready, 0);
+}
+inline hipError_t kp_snaps_release(const kp_snapshots* s, hipStream_t st) {
+  if (!s->streaming) return hipSuccess;
+  s->read_pending = true;
+  return hipEventRecord(s->ev_read, st);
+}
 
 // --- device helpers shared by the lift and gram kernels -----------------------------
 
@@ -246,9 +268,14 @@ bool kp_gram5_applicable(const kp_basis* basis);
 int kp_gram5_launch(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* s, double* GC_dev);
 inline int kp_gram_dispatch(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* s, double* GC_dev) {
   ctx->reduce_timed_from = 1;
-  if (kp_gram3_applicable(basis)) return kp_gram3_launch(ctx, basis, s, GC_dev);
-  if (kp_gram5_applicable(basis)) return kp_gram5_launch(ctx, basis, s, GC_dev);
-  return kp_gram2_applicable(basis) ? kp_gram2_launch(ctx, basis, s, GC_dev) : kp_gram_launch(ctx, basis, s, GC_dev);
+  KP_HIP(ctx, kp_snaps_acquire(s, ctx->stream));
+  const int rc = kp_gram3_applicable(basis)   ? kp_gram3_launch(ctx, basis, s, GC_dev)
+                 : kp_gram5_applicable(basis) ? kp_gram5_launch(ctx, basis, s, GC_dev)
+                 : kp_gram2_applicable(basis) ? kp_gram2_launch(ctx, basis, s, GC_dev)
+                                              : kp_gram_launch(ctx, basis, s, GC_dev);
+  if (rc) return rc;
+  KP_HIP(ctx, kp_snaps_release(s, ctx->stream));
+  return KP_OK;
 }
 // kp_chol_ll.hip: left-looking single-workgroup Cholesky for n <= 352 (in place, lower triangle; `info` as kp_chol_kernel)
 bool kp_chol_ll_applicable(int n);

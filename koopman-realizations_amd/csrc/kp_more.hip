@@ -123,6 +123,7 @@ extern "C" int kp_fit_refine(kp_ctx* ctx, const kp_basis* basis, const kp_snapsh
   rc = kp_lift_dev(ctx, basis, KP_LIFT_ROW, snaps->alpha, snaps->u, Ns, Px);
   if (!rc) rc = kp_lift_dev(ctx, basis, KP_LIFT_ROW, snaps->beta, snaps->u, Ns, Py);
   if (rc) return rc;
+  KP_HIP(ctx, kp_snaps_release(snaps, s));
   KP_HIP(ctx, hipMemcpyAsync(Kd, K, bW, hipMemcpyHostToDevice, s));
   for (int it = 0; it < steps; ++it) {
     KP_HIP(ctx, hipMemcpyAsync(E, Py, bP, hipMemcpyDeviceToDevice, s));

@@ -283,6 +283,16 @@ class Snapshots:
         F.check(F.lib().kp_snapshots_upload(ctx.handle, F.dptr(a), F.dptr(b), F.dptr(uu), self.Ns, self.nzeta, self.m,
                                             C.byref(self._h)), ctx.handle)
 
+    def update(self, alpha, beta, u):
+        """kp_snapshots_update: new pairs into the same device arrays.  Returns once the host arrays are staged; the
+        transfer overlaps whatever the device is doing with OTHER snapshot objects (keep two and alternate)."""
+        a = F.fcol(alpha); b = F.fcol(beta); uu = F.fcol(u)
+        if a.shape[1] != self.nzeta or uu.shape[1] != self.m or b.shape != a.shape or uu.shape[0] != a.shape[0]:
+            raise ValueError("Snapshots.update: column counts must match the object")
+        F.check(F.lib().kp_snapshots_update(self.ctx.handle, self._h, F.dptr(a), F.dptr(b), F.dptr(uu), a.shape[0]), self.ctx.handle)
+        self.Ns = a.shape[0]
+        return self
+
     @property
     def handle(self):
         return self._h

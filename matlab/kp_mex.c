@@ -14,6 +14,7 @@
  *   d   = kp_mex('basis_dims', b)                                       [nvars nfull N W]
  *   P   = kp_mex('lift', h, b, what, zeta, u)                           kp_lift (what: 0 full, 1 econ, 2 row of Px)
  *   s   = kp_mex('snapshots_upload', h, alpha, beta, u)                 kp_snapshots_upload
+ *         kp_mex('snapshots_update', h, s, alpha, beta, u)                kp_snapshots_update (refill in place, returns once staged)
  *         kp_mex('snapshots_destroy', s) / kp_mex('basis_destroy', b) / kp_mex('mpc_destroy', m)
  *   K   = kp_mex('fit', h, b, s, lasso)                                 kp_fit: W x W x numel(lasso)   (get_Koopman, train_models)
  *   [G,C] = kp_mex('fit_gram', h, b, s)                                 kp_fit_gram
@@ -131,6 +132,10 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     check(kp_snapshots_upload(c, dbl(prhs[2]), dbl(prhs[3]), dbl(prhs[4]), (int64_t)mxGetM(prhs[2]), (int)mxGetN(prhs[2]),
                               (int)mxGetN(prhs[4]), &s), c);
     plhs[0] = put_handle(s);
+  } else if (!strcmp(cmd, "snapshots_update")) {
+    kp_ctx* c = (kp_ctx*)get_handle(prhs[1]);
+    kp_snapshots* s = (kp_snapshots*)get_handle(prhs[2]);
+    check(kp_snapshots_update(c, s, dbl(prhs[3]), dbl(prhs[4]), dbl(prhs[5]), (int64_t)mxGetM(prhs[3])), c);
   } else if (!strcmp(cmd, "fit")) {
     kp_ctx* c = (kp_ctx*)get_handle(prhs[1]);
     kp_basis* b = (kp_basis*)get_handle(prhs[2]);

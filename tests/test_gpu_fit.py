@@ -294,6 +294,49 @@ def test_async_fit_pipeline_matches_synchronous_result(ctx):
     ctx.synchronize()                            # the sticky flag was cleared
 
 
+def test_snapshot_objects_refilled_from_the_host_while_fits_are_in_flight(ctx):
+    """kp_snapshots_update: new pairs into an existing object through the pinned staging ring and the copy stream.  Two
+    objects filled alternately while the fits of the other one are queued: every K equals the fit of a freshly uploaded
+    object; the host arrays may be overwritten as soon as update() returns; the snapshot count may shrink and grow."""
+    dic = ko.build_dictionary("bilinear", 6, 3, ["poly"], [3])
+    b = make_basis(ctx, dic)
+    W = b.W
+    sets = [synth_pairs(20000, seed=40 + i) for i in range(5)]
+    Kref = []
+    for p in sets:
+        s = kra.Snapshots(ctx, p["alpha"], p["beta"], p["u"])
+        kra.fit(ctx, b, s, fetch=False)
+        Kref.append(ctx.fit_result(0, W).copy())
+        s.close()
+    ring = [kra.Snapshots(ctx, sets[0]["alpha"], sets[0]["beta"], sets[0]["u"]) for _ in range(2)]
+    order = [1, 2, 3, 4, 0, 2, 4, 1]
+    for i, k in enumerate(order):
+        a, be, u = (np.asfortranarray(sets[k][f]).copy(order="F") for f in ("alpha", "beta", "u"))
+        ring[i % 2].update(a, be, u)
+        a[:] = np.nan; be[:] = np.nan; u[:] = np.nan          # the caller's arrays are free again
+        kra.fit(ctx, b, ring[i % 2], fetch=False)
+    ctx.synchronize()
+    for i, k in enumerate(order):
+        assert np.abs(ctx.fit_result(i, W) - Kref[k]).max() <= 1e-13 * np.abs(Kref[k]).max(), (i, k)
+    # another snapshot count: fewer rows reuse the arrays, more rows reallocate them (drains the pipeline)
+    small, big = synth_pairs(7001, seed=50), synth_pairs(26003, seed=51)
+    for p in (small, big, small):
+        Ks = kra.fit(ctx, b, kra.Snapshots(ctx, p["alpha"], p["beta"], p["u"]))[0]
+        ring[0].update(p["alpha"], p["beta"], p["u"])
+        assert ring[0].Ns == p["alpha"].shape[0]
+        Ku = kra.fit(ctx, b, ring[0])[0]
+        assert np.array_equal(Ku, Ks)
+        G, Cm = kra.fit_gram(ctx, b, ring[0])
+        Px, Py = ko.px_py(dic, p)
+        assert np.abs(G - Px.T @ Px).max() <= 1e-11 * np.abs(G).max() and np.abs(Cm - Px.T @ Py).max() <= 1e-11 * np.abs(Cm).max()
+    with pytest.raises(ValueError):
+        ring[0].update(small["alpha"][:, :5], small["beta"][:, :5], small["u"])
+    # an object that was never refilled keeps working beside the streaming ones (no events recorded for it)
+    s0 = kra.Snapshots(ctx, sets[0]["alpha"], sets[0]["beta"], sets[0]["u"])
+    kra.fit(ctx, b, s0, fetch=False)
+    assert np.abs(ctx.fit_result(0, W) - Kref[0]).max() <= 1e-13 * np.abs(Kref[0]).max()
+
+
 @pytest.mark.parametrize("mt,deg,steps,tol", [("bilinear", 2, 1, 1e-10), ("linear", 2, 1, 1e-10), ("bilinear", 3, 1, 1e-12), ("nonlinear", 2, 2, 1e-10)])
 def test_fit_refine_reaches_qr_accuracy(ctx, arm, mt, deg, steps, tol):
     """kp_fit_refine: K += G^-1 Px'(Py - Px K) with the residual taken from the lifted rows.  On the arm data with
