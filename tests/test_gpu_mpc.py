@@ -149,6 +149,39 @@ def test_batch_matches_single(ctx, arm, golden, arm_models):
     assert np.abs(Ub - np.array(Us)).max() < 1e-11
 
 
+@pytest.mark.parametrize("mt", ["linear", "bilinear"])
+def test_qp_solver_is_insensitive_to_rounding_level_noise_at_degenerate_vertices(ctx, arm, golden, arm_models, mt):
+    """The stored runs sit on vertices with more tight rows than variables (slope rows of saturated moves; no input box,
+    as in the stored runs).  The device active-set solve of those QPs must not depend on the rounding of their assembly:
+    H and f perturbed at the 1e-9 relative level (b is left alone - the pinned first input is a pair of opposite
+    inequalities, Kmpc.m:865-870) still solve, to the oracle's optimum of the perturbed problem."""
+    dic, mdl = arm_models[mt]
+    s = example_control_setup(arm, mt, dic, mdl, with_bounds=False)
+    mpc = make_mpc(ctx, s)
+    rng = np.random.default_rng(7)
+    degenerate = 0
+    r = golden["arm_blockM"]
+    key = "lin" if mt == "linear" else "bilin"
+    refs = golden["blockM_ref"]["y"]
+    ysc = (refs - arm["scale"]["y_offset"][-2:]) / arm["scale"]["y_factor"][-2:]
+    for k in range(5, 295, 12):                      # the stored run's own states and (unclipped) previous inputs
+        z = ko.econ_full(dic, ko.scaledown(arm["scale"], "y", r[key + "_Y"][k])[None, :])[0]
+        u_prev = ko.scaledown(arm["scale"], "u", r[key + "_U"][k])
+        U, st = mpc.step(z, u_prev, ko.pad_ref(ysc[k:k + 11], s.Np))
+        assert st == 0
+        H, f, A, b = mpc.last_qp()
+        for rep in range(2):
+            fp = f * (1 + 1e-9 * rng.standard_normal(f.shape))
+            E = 1e-9 * rng.standard_normal(H.shape) * np.sqrt(np.outer(np.diag(H), np.diag(H)))
+            Hp = H + 0.5 * (E + E.T)
+            x, stq = ctx.qp_solve(Hp, fp, A, b)
+            xo, lam, ok = ko.qp_solve(Hp, fp, A, b)
+            assert ok and stq == 0 and np.abs(x - xo).max() < 1e-8, (k, rep, stq)
+        degenerate += int((np.abs(A @ xo - b) < 1e-9).sum() > H.shape[0])
+    if mt == "linear":
+        assert degenerate >= 5                       # the case this test is about does occur
+
+
 def test_infeasible_qp_returns_nan_like_the_gurobi_shim(ctx, arm, golden, arm_models):
     dic, mdl = arm_models["bilinear"]
     s = example_control_setup(arm, "bilinear", dic, mdl)
