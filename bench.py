@@ -501,7 +501,7 @@ def main():
                     "note": f"{15 * 8 * Ns / 1e6:.0f} MB of host snapshot pairs per fit over PCIe (pageable host arrays, staged through pinned "
                             "chunks); streamed = two device objects refilled alternately, transfer overlapping the other "
                             "object's Gram kernel; never part of `value`"},
-            "kernel_ms": {"gram": g_ms, "gram_launches_averaged": n_timed, "gram_reduce": red_ms if red_ms > 0 else None,   # not timed inside the pipeline (rocprofv3: profiles/r02_bench_kernel_stats.csv) "solve": solve_ms},
+            "kernel_ms": {"gram": g_ms, "gram_launches_averaged": n_timed, "gram_reduce": red_ms if red_ms > 0 else None, "solve": solve_ms},
             "roofline": {"bound": "mfma", "kernel": "kp_gram3_kernel<6,3>", "achieved": achieved, "peak": PEAK_F64_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_F64_MFMA_TFLOPS, "traffic": traffic,
                          "algorithmic_flop_per_launch": flops_pair * Ns, "algorithmic_bytes_per_launch": 120.0 * Ns,

@@ -44,3 +44,15 @@ def test_fails_loudly_without_a_gpu(built):
     import koopman_realizations_amd as kra
     with pytest.raises(kra.KoopmanHipError):
         kra.Context(0)
+
+
+def test_entry_points_of_the_driver_compile_and_parse_their_arguments():
+    """bench.py and __graft_entry__.py are run by the driver, not imported by any other test: a syntax error there would
+    only show at round end.  Byte-compile both and let bench.py parse the driver's flags (no GPU work: --help exits first)."""
+    import py_compile
+    import subprocess
+    import sys
+    for f in ("bench.py", "__graft_entry__.py"):
+        py_compile.compile(os.path.join(ROOT, f), doraise=True)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "--gpus" in r.stdout and "--steps" in r.stdout and "--warmup" in r.stdout
