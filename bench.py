@@ -392,7 +392,9 @@ def main():
     # one queue as deep as the timed region's first (at least one full batch of deferred solves): every buffer of the pipeline
     # and of the HIP runtime (kernel-argument and signal pools grow with the queue depth) at its final size, every kernel
     # variant loaded (not counted as warm-up)
-    for _ in range(max(64, args.steps)):
+    # ... and the device at its sustained clock: the first ~60 Gram launches after an idle or lightly loaded stretch run
+    # 470 -> 405 us (profiles/r02_gram_launch_durations.txt), so the queue is 256 fits (110 ms) deep
+    for _ in range(max(256, args.steps)):
         kra.fit(ctx, basis, snaps, fetch=False)
     ctx.synchronize()
     for _ in range(args.warmup):
@@ -432,8 +434,8 @@ def main():
     streamed_ms = None
     if rank == 0 and world == 1:
         ring2 = [snaps, kra.Snapshots(ctx, alpha, beta, u)]
-        n_st = 32
-        for rep in range(2):
+        n_st = 64
+        for rep in range(3):                        # the last pass counts (the section above left the device lightly loaded)
             t1 = time.perf_counter()
             for i in range(n_st):
                 ring2[i % 2].update(alpha, beta, u)
