@@ -337,6 +337,40 @@ def test_snapshot_objects_refilled_from_the_host_while_fits_are_in_flight(ctx):
     assert np.abs(ctx.fit_result(0, W) - Kref[0]).max() <= 1e-13 * np.abs(Kref[0]).max()
 
 
+_POOL_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import koopman_realizations_amd as kra
+from oracle import koopman_oracle as ko
+from conftest import synth_pairs
+from test_gpu_fit import make_basis
+ctx = kra.Context(0)
+dic = ko.build_dictionary("bilinear", 6, 3, ["poly"], [2])
+b = make_basis(ctx, dic)
+sets = [synth_pairs(30011 + 977 * i, seed=60 + i) for i in range(4)]
+ring = [kra.Snapshots(ctx, sets[0]["alpha"], sets[0]["beta"], sets[0]["u"]) for _ in range(2)]
+for rep in range(3):
+    for i, p in enumerate(sets):
+        s = ring[i % 2].update(p["alpha"], p["beta"], p["u"])
+        G, C = kra.fit_gram(ctx, b, s)
+        Px, Py = ko.px_py(dic, p)
+        assert np.abs(G - Px.T @ Px).max() <= 1e-11 * np.abs(G).max() and np.abs(C - Px.T @ Py).max() <= 1e-11 * np.abs(C).max(), (rep, i)
+print("POOL_OK")
+"""
+
+
+def test_staged_upload_with_copy_threads_and_small_chunks():
+    """The chunked host -> HBM path with its worker threads forced on (4 threads, 64 KB chunks, no size threshold: ~60
+    chunks per refill handed between threads) - the configuration large snapshot matrices use - against the oracle's Grams."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, KP_COPY_THREADS="4", KP_COPY_CHUNK_KB="64", KP_COPY_POOL_MIN_MB="0")
+    r = subprocess.run([sys.executable, "-c", _POOL_SCRIPT, root], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "POOL_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
 @pytest.mark.parametrize("mt,deg,steps,tol", [("bilinear", 2, 1, 1e-10), ("linear", 2, 1, 1e-10), ("bilinear", 3, 1, 1e-12), ("nonlinear", 2, 2, 1e-10)])
 def test_fit_refine_reaches_qr_accuracy(ctx, arm, mt, deg, steps, tol):
     """kp_fit_refine: K += G^-1 Px'(Py - Px K) with the residual taken from the lifted rows.  On the arm data with
