@@ -585,7 +585,10 @@ int kp_gram3_launch(kp_ctx* ctx, const kp_basis* basis_c, const kp_snapshots* s,
   size_t per_split = (size_t)plan.njobs * plan.nq * NWT * 64;
   // asynchronous fits: two partial buffers, so that the next Gram kernel may run while the solve stream reduces this one
   const size_t part_bytes = ((size_t)nsplit * per_split * 8 + 255) & ~(size_t)255;
-  char* part_base = (char*)ctx->workspace(4, part_bytes * (ctx->reduce_stream ? 2 : 1));
+  // sized for the largest split count of this dictionary at once: a workspace that grows with the snapshot count would put
+  // a hipFree + hipMalloc of ~80 MB (17 ms, and a device synchronisation) into the first large fit of a running pipeline
+  const size_t part_max = ((size_t)std::max<int64_t>(nsplit, (int64_t)ncu * wg_per_cu / plan.nsuper) * per_split * 8 + 255) & ~(size_t)255;
+  char* part_base = (char*)ctx->workspace(4, part_max * (ctx->reduce_stream ? 2 : 1));
   if (!part_base) return ctx->fail(KP_ERR_HIP, "kp_fit_gram: out of device memory");
   double* part = (double*)(part_base + (ctx->reduce_stream ? (size_t)ctx->part_flip * part_bytes : 0));
 
