@@ -664,6 +664,22 @@ __global__ __launch_bounds__(256) void kp_mpc_step_kernel(MpcArgs a) {
   const int tid = threadIdx.x;
   const int pb = blockIdx.x;
   const int N = a.N, m = a.m, Np = a.Np, nproj = a.nproj, nv = a.nvar, nr = a.nrows;
+  // warm start: the previous step's active rows and their (sparse) constraint entries are fetched NOW, so that their three
+  // dependent global loads (set size -> row ids -> entries, ~0.5 us each from L2) hide behind the lift and the assembly
+  int warm_q0 = 0, warm_row = 0;
+  double warm_val[QP_KLDS];
+  int warm_col[QP_KLDS];
+  if (WARM && a.warm) {
+    warm_q0 = a.warm[0];
+    if (tid < nv) warm_row = a.warm[1 + tid];
+    if (a.ell.K <= QP_KLDS) {
+#pragma unroll
+      for (int k = 0; k < QP_KLDS; ++k) {
+        warm_val[k] = (tid < nv && k < a.ell.K) ? a.ell.val[k * nr + warm_row] : 0.0;
+        warm_col[k] = (tid < nv && k < a.ell.K) ? a.ell.col[k * nr + warm_row] : 0;
+      }
+    }
+  }
   double* z = sm;
   double* beta = z + N;                  // N x m  (Beta(z) = B kron(I,z), Ksysid.m:1288-1289)
   double* S = beta + N * m;              // [Np][nproj x m]
@@ -846,28 +862,70 @@ __global__ __launch_bounds__(256) void kp_mpc_step_kernel(MpcArgs a) {
     // multiplier is negative and add the newly violated ones
     int wq = 0;
     if (WARM && a.warm && !hbad) {
-      wq = min(a.warm[0], nv);
+      if (iter != iter0) {                     // later linearisation passes start from the set the previous pass left
+        warm_q0 = a.warm[0];
+        if (tid < nv) warm_row = a.warm[1 + tid];
+        if (a.ell.K <= QP_KLDS) {
+#pragma unroll
+          for (int k = 0; k < QP_KLDS; ++k) {
+            warm_val[k] = (tid < nv && k < a.ell.K) ? a.ell.val[k * nr + warm_row] : 0.0;
+            warm_col[k] = (tid < nv && k < a.ell.K) ? a.ell.col[k * nr + warm_row] : 0;
+          }
+        }
+      }
+      wq = min(warm_q0, nv);
       double* HNw = qpws + nv * nv;
       double* Sw = qpws + 2 * nv * nv;
       int* actw = (int*)(qpws + 3 * nv * nv + 9 * nv) + nv + (nv & 1);     // the solver's act[] (behind apv and apc)
       if (wq > 0) {
-        for (int c = tid; c < wq; c += 256) actw[c] = a.warm[1 + c];
-        __syncthreads();
         const int K = a.ell.K;
-        for (int e = tid; e < nv * wq; e += 256) {
-          const int i = e % nv, c = e / nv, row = actw[c];
-          double sacc = 0.0;
-          for (int k = 0; k < K; ++k) sacc += a.ell.val[k * nr + row] * qpws[i + a.ell.col[k * nr + row] * nv];
-          HNw[i + c * nv] = sacc;
+        if (K <= QP_KLDS) {
+          // rows staged in LDS (Hq is free between the two inverses): val [wq][4] | col [wq][4]; no global access and
+          // no integer division in the two products (lane = row of the result, waves stride the columns)
+          double* sv = Hq;
+          int* sc = (int*)(Hq + QP_KLDS * nv);
+          if (tid < wq) {
+            actw[tid] = warm_row;
+#pragma unroll
+            for (int k = 0; k < QP_KLDS; ++k) {
+              sv[tid * QP_KLDS + k] = warm_val[k];
+              sc[tid * QP_KLDS + k] = warm_col[k];
+            }
+          }
+          __syncthreads();
+          const int li_ = tid & 63, w4 = tid >> 6;
+          if (li_ < nv)
+            for (int c = w4; c < wq; c += 4) {
+              double sacc = 0.0;
+              for (int k = 0; k < K; ++k) sacc += sv[c * QP_KLDS + k] * qpws[li_ + sc[c * QP_KLDS + k] * nv];
+              HNw[li_ + c * nv] = sacc;
+            }
+          __syncthreads();
+          if (li_ < wq)
+            for (int c2 = w4; c2 < wq; c2 += 4) {
+              double sacc = 0.0;
+              for (int k = 0; k < K; ++k) sacc += sv[li_ * QP_KLDS + k] * HNw[sc[li_ * QP_KLDS + k] + c2 * nv];
+              Sw[li_ + c2 * nv] = sacc;
+            }
+          __syncthreads();
+        } else {
+          for (int c = tid; c < wq; c += 256) actw[c] = a.warm[1 + c];
+          __syncthreads();
+          for (int e = tid; e < nv * wq; e += 256) {
+            const int i = e % nv, c = e / nv, row = actw[c];
+            double sacc = 0.0;
+            for (int k = 0; k < K; ++k) sacc += a.ell.val[k * nr + row] * qpws[i + a.ell.col[k * nr + row] * nv];
+            HNw[i + c * nv] = sacc;
+          }
+          __syncthreads();
+          for (int e = tid; e < wq * wq; e += 256) {
+            const int c = e % wq, c2 = e / wq, row = actw[c];
+            double sacc = 0.0;
+            for (int k = 0; k < K; ++k) sacc += a.ell.val[k * nr + row] * HNw[a.ell.col[k * nr + row] + c2 * nv];
+            Sw[c + c2 * nv] = sacc;
+          }
+          __syncthreads();
         }
-        __syncthreads();
-        for (int e = tid; e < wq * wq; e += 256) {
-          const int c = e % wq, c2 = e / wq, row = actw[c];
-          double sacc = 0.0;
-          for (int k = 0; k < K; ++k) sacc += a.ell.val[k * nr + row] * HNw[a.ell.col[k * nr + row] + c2 * nv];
-          Sw[c + c2 * nv] = sacc;
-        }
-        __syncthreads();
         if (wg_spd_inverse_pp(Sw, Hq, wq, nv)) wq = 0;   // dependent rows: cold start
       }
     }

@@ -23,7 +23,7 @@ __device__ __forceinline__ double wg_recip(double p) {
 // (row, column) advance by (256 % nt, 256 / nt) with one carry; the tile loop is NOT unrolled (unrolled, the 4-tile
 // version needed 218 VGPRs and cost the batched MPC kernel a third of its occupancy).
 template <bool MULTI>
-__device__ __forceinline__ int wg_spd_inverse_tiles(double* X, double* Y, int n, int ld) {
+__device__ __forceinline__ int wg_spd_inverse_tiles(double* X, double* Y, int n, int ld, double thr) {
   const int tid = threadIdx.x;
   const int nt = n >> 1;
   int bad = 0;
@@ -35,7 +35,7 @@ __device__ __forceinline__ int wg_spd_inverse_tiles(double* X, double* Y, int n,
   for (int k = 0; k < n; ++k) {
     const double piv = X[k + k * ld];
     const double* Xk = X + k * ld;
-    if (!(piv > 0.0)) bad = 1;
+    if (!(piv > thr)) bad = 1;
     double ip = 0.0;
     int ti = ti0, tj = tj0;
 #pragma unroll 1
@@ -81,14 +81,14 @@ __device__ __forceinline__ int wg_spd_inverse_tiles(double* X, double* Y, int n,
 // Per-element version for odd n without room for a padding row (ld == n).  Thread tid owns elements e = tid + 256 t;
 // their (row, column) pairs advance by (256 % n, 256 / n) with one carry: no integer division in the pivot loop and no
 // per-thread index table (a fully unrolled 16-entry table cost 248 VGPRs and halved the occupancy of the batched kernel).
-__device__ __forceinline__ int wg_spd_inverse_elems(double* X, double* Y, int n, int ld) {
+__device__ __forceinline__ int wg_spd_inverse_elems(double* X, double* Y, int n, int ld, double thr) {
   const int tid = threadIdx.x;
   int bad = 0;
   const int di = 256 % n, dj = 256 / n, i0 = tid % n, j0 = tid / n;
   const int ne = (n * n + 255) >> 8;
   for (int k = 0; k < n; ++k) {
     const double piv = X[k + k * ld];
-    if (!(piv > 0.0)) bad = 1;
+    if (!(piv > thr)) bad = 1;
     const double ip = wg_recip(piv);
     const double* Xk = X + k * ld;
     int i = i0, j = j0;
@@ -130,8 +130,23 @@ __device__ __forceinline__ int wg_spd_inverse_elems(double* X, double* Y, int n,
 // version applies and row / column n of X are overwritten.
 __device__ __forceinline__ int wg_spd_inverse_pp(double* X, double* Y, int n, int ld) {
   const int tid = threadIdx.x;
+  // "not positive definite" means a pivot (a diagonal entry of a Schur complement, >= lambda_min) that is not above
+  // 1e-13 of the largest diagonal entry: a matrix of condition > 1e13 has no meaningful inverse in doubles.  A bare
+  // `pivot > 0` lets the rounding decide for numerically singular matrices (the inverse Schur complement of an active
+  // set taken over from a primal-degenerate vertex - nearly dependent rows - is one), and the caller then iterates on noise.
+  double dmax = 0.0;
+  for (int k = 0; k < n; k += 8) {                 // eight independent reads per round trip (clamped index: repeats are harmless)
+    double d[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int kk = min(k + j, n - 1);
+      d[j] = X[kk + kk * ld];
+    }
+    dmax = fmax(dmax, fmax(fmax(fmax(d[0], d[1]), fmax(d[2], d[3])), fmax(fmax(d[4], d[5]), fmax(d[6], d[7]))));
+  }
+  const double thr = 1e-13 * dmax;
   if ((n & 1) && ld == n) {
-    const int bad = wg_spd_inverse_elems(X, Y, n, ld);          // odd number of steps: the result is in Y
+    const int bad = wg_spd_inverse_elems(X, Y, n, ld, thr);     // odd number of steps: the result is in Y
     for (int e = tid; e < n * n; e += 256) X[e] = Y[e];
     __syncthreads();
     return bad;
@@ -144,6 +159,6 @@ __device__ __forceinline__ int wg_spd_inverse_pp(double* X, double* Y, int n, in
     __syncthreads();
     ++n;
   }
-  if (n <= 32) return wg_spd_inverse_tiles<false>(X, Y, n, ld);
-  return wg_spd_inverse_tiles<true>(X, Y, n, ld);
+  if (n <= 32) return wg_spd_inverse_tiles<false>(X, Y, n, ld, thr);
+  return wg_spd_inverse_tiles<true>(X, Y, n, ld, thr);
 }
