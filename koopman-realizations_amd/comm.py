@@ -53,7 +53,7 @@ class RcclInitTimeout(TimeoutError):
 
 class RcclComm:
     """kp_comm_create on a Context: RCCL communicator of `world` processes, this one being `rank`.  The call runs under a
-    watchdog (KP_COMM_INIT_TIMEOUT seconds, default 120): a bootstrap that never completes raises RcclInitTimeout instead
+    watchdog (KP_COMM_INIT_TIMEOUT seconds, default 240): a bootstrap that never completes raises RcclInitTimeout instead
     of blocking the launch (the blocked thread is abandoned; `init_from_env` then agrees on the file backend)."""
     kind = "rccl"
 
@@ -64,7 +64,7 @@ class RcclComm:
         single_node_defaults()
         buf = C.create_string_buffer(unique_id, 128)
         if timeout is None:
-            timeout = float(os.environ.get("KP_COMM_INIT_TIMEOUT", "120"))
+            timeout = float(os.environ.get("KP_COMM_INIT_TIMEOUT", "240"))
         box = {}
 
         def run():
@@ -122,7 +122,7 @@ class FileComm:
         self.ctx, self.rank, self.world, self.dir, self.seq = ctx, int(rank), int(world), directory, 0
         os.makedirs(directory, exist_ok=True)
 
-    def all_gather_bytes(self, payload: bytes, timeout: float = 300.0):
+    def all_gather_bytes(self, payload: bytes, timeout: float = 600.0):
         self.seq += 1
         mine = os.path.join(self.dir, f"{self.seq}_{self.rank}")
         with open(mine + ".tmp", "wb") as f:
@@ -195,7 +195,7 @@ def rendezvous_file_from_env() -> str:
     return os.path.join(tempfile.gettempdir(), f"kp_comm_{tag}.id")
 
 
-def exchange_unique_id(rank: int, path: str, timeout: float = 120.0) -> bytes:
+def exchange_unique_id(rank: int, path: str, timeout: float = 300.0) -> bytes:
     """Rank 0 creates the id and publishes it atomically (write + rename); the others wait for the file."""
     if rank == 0:
         try:
