@@ -235,9 +235,12 @@ def bench_rand_sweep(ctx, comm, kra, chunks, n_systems):
     mine = [s_ for c in sorted(chunks) for s_ in chunks[c]]
     ids = [c * RAND_CHUNK + k for c in sorted(chunks) for k in range(RAND_CHUNK)]
     sweep.rand_models_sweep_batched(mine[:4], ctx)                           # warm-up
+    if mine:
+        sweep._stack_raw(mine, ctx)          # the context's page-locked gather buffers at their final size (untimed, like every
+                                             # other buffer of the pipeline); the timed pass below gathers and uploads again
     comm.barrier()
     t0 = time.perf_counter()
-    raw = sweep._stack_raw(mine) if mine else None                           # data4sysid structs -> one block per quantity (host)
+    raw = sweep._stack_raw(mine, ctx) if mine else None                      # data4sysid structs -> one block per quantity (host)
     t_stack = time.perf_counter() - t0
     tab = (sweep.rand_models_sweep_arrays(*raw, ctx=ctx) if raw is not None else sweep.rand_models_sweep_batched(mine, ctx)) if mine else {}
     t_local = time.perf_counter() - t0

@@ -136,6 +136,13 @@ int kp_snapshots_update(kp_ctx* ctx, kp_snapshots* snaps, const double* alpha, c
                         int64_t Ns);
 int kp_snapshots_destroy(kp_snapshots* snaps);
 
+/* Page-locked host memory owned by the context (freed by kp_host_free or kp_destroy).  A host side that ASSEMBLES its
+ * inputs - evaluate_rand_models.m gathers `data4sysid_all{i}.train{j}.y/.u` of every system before the sweep
+ * (evaluate_rand_models.m:45-59; kp_traj_upload takes them as one block) - writes them here once: no first-touch page
+ * faults in the gather, and every upload from such a buffer is a direct DMA at PCIe speed instead of a staged copy. */
+int kp_host_alloc(kp_ctx* ctx, int64_t bytes, void** ptr);
+int kp_host_free(kp_ctx* ctx, void* ptr);
+
 /* ---- EDMD fit ---------------------------------------------------------------------
  * kp_fit_gram: the fused per-row lift loop of get_Koopman (Ksysid.m:1030-1065) and the
  *   accumulations PxTPx = Px'*Px (:1114), PxTPy = Px'*Py (:1125).  Px/Py are never

@@ -47,6 +47,8 @@ SIGNATURES = {
     "kp_snapshots_upload": (C.c_int, [vp, c_dp, c_dp, c_dp, C.c_int64, C.c_int, C.c_int, C.POINTER(vp)]),
     "kp_snapshots_update": (C.c_int, [vp, vp, c_dp, c_dp, c_dp, C.c_int64]),
     "kp_snapshots_destroy": (C.c_int, [vp]),
+    "kp_host_alloc": (C.c_int, [vp, C.c_int64, C.POINTER(vp)]),
+    "kp_host_free": (C.c_int, [vp, vp]),
     "kp_fit_gram": (C.c_int, [vp, vp, vp, c_dp, c_dp]),
     "kp_fit_solve": (C.c_int, [vp, c_dp, c_dp, C.c_int, C.c_int, c_dp]),
     "kp_fit_last_rank": (C.c_int, [vp, c_ip]),

@@ -17,6 +17,7 @@ struct kp_stage;   // kp_upload.hip: copy stream, pinned staging ring and copy t
 struct kp_ctx {
   int device = 0;
   kp_stage* stage = nullptr;
+  std::vector<void*> host_blocks;       // kp_host_alloc: page-locked host buffers handed to the caller
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipEvent_t evp[6] = {nullptr};   // gram start, gram end, reduce end, solve end, spare x2
@@ -167,6 +168,7 @@ struct kp_snapshots {
   bool streaming = false;
 };
 void kp_stage_destroy(kp_ctx* ctx);
+void kp_host_free_all(kp_ctx* ctx);
 // Around every launch sequence that reads a snapshot object.  All readers run on ctx->stream, so one wait orders the
 // later ones too.
 inline hipError_t kp_snaps_acquire(const kp_snapshots* s, hipStream_t st) {

@@ -325,3 +325,34 @@ extern "C" int kp_snapshots_destroy(kp_snapshots* s) {
   delete s;
   return KP_OK;
 }
+
+// ---- page-locked host buffers for callers that assemble their inputs (see koopman_hip.h) ------------------------------
+extern "C" int kp_host_alloc(kp_ctx* ctx, int64_t bytes, void** ptr) {
+  if (!ctx || !ptr || bytes < 1) return ctx ? ctx->fail(KP_ERR_ARG, "kp_host_alloc: bad argument") : KP_ERR_ARG;
+  *ptr = nullptr;
+  KP_HIP(ctx, hipSetDevice(ctx->device));
+  void* p = nullptr;
+  KP_HIP(ctx, hipHostMalloc(&p, (size_t)bytes, hipHostMallocDefault));
+  ctx->host_blocks.push_back(p);
+  *ptr = p;
+  return KP_OK;
+}
+
+extern "C" int kp_host_free(kp_ctx* ctx, void* ptr) {
+  if (!ctx) return KP_ERR_ARG;
+  if (!ptr) return KP_OK;
+  for (size_t i = 0; i < ctx->host_blocks.size(); ++i)
+    if (ctx->host_blocks[i] == ptr) {
+      ctx->host_blocks.erase(ctx->host_blocks.begin() + (long)i);
+      KP_HIP(ctx, hipSetDevice(ctx->device));
+      KP_HIP(ctx, hipDeviceSynchronize());          // no transfer from the block may still be in flight
+      KP_HIP(ctx, hipHostFree(ptr));
+      return KP_OK;
+    }
+  return ctx->fail(KP_ERR_ARG, "kp_host_free: not a block of this context");
+}
+
+void kp_host_free_all(kp_ctx* ctx) {
+  for (void* p : ctx->host_blocks) (void)hipHostFree(p);
+  ctx->host_blocks.clear();
+}

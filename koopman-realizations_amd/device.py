@@ -68,8 +68,26 @@ class Context:
         F.check(F.lib().kp_fit_get_K(self._h, int(index), int(W), F.dptr(K)), self._h)
         return K
 
+    def host_array(self, name: str, shape):
+        """A float64 C-ordered array in page-locked host memory owned by this context (kp_host_alloc), kept under `name`
+        and reused by later calls that fit into it: gathers written there cause no page faults and upload by direct DMA.
+        The contents belong to the caller until the next host_array(name, ...) call."""
+        n = int(np.prod(shape))
+        pool = self.__dict__.setdefault("_host_pool", {})
+        ent = pool.get(name)
+        if ent is None or ent[1] < n:
+            if ent is not None:
+                F.check(F.lib().kp_host_free(self._h, ent[0]), self._h)
+            p = F.vp()
+            cap = n + n // 8 + 512
+            F.check(F.lib().kp_host_alloc(self._h, cap * 8, C.byref(p)), self._h)
+            ent = (p, cap, np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_double)), shape=(cap,)))
+            pool[name] = ent
+        return ent[2][:n].reshape(shape)
+
     def close(self):
         """Destroys the child handles first (their destroy calls dereference the context), then the context."""
+        self.__dict__.pop("_host_pool", None)        # the blocks themselves are freed by kp_destroy
         if self._h:
             for ch in list(getattr(self, "_children", ())):
                 try:

@@ -135,38 +135,47 @@ def rand_models_sweep(systems, comm=None, ctx=None, degrees=None, eval_fn=None, 
     return {mt: np.stack([r[mt][0] for r in allres], axis=1) for mt in ("linear", "bilinear", "nonlinear")}
 
 
-def _stack_raw(systems):
+def _stack_raw(systems, ctx=None):
     """The systems' trials as stacked raw arrays (no arithmetic): Y (nb, k T, n), U (nb, k T, m), trial count k, and the
     validation trial Yv, Uv - or None unless every system has the same trial layout (equal counts and lengths, time
-    restarting at every trial: the generated and shipped rand-systems sets)."""
+    restarting at every trial: the generated and shipped rand-systems sets).  With a device context the blocks are
+    gathered into its page-locked host arrays (Context.host_array, reused from call to call: no first-touch page faults -
+    they were two thirds of this function's time - and the upload that follows is a direct DMA); the returned arrays are
+    then views that stay valid until the next call with the same context."""
     try:
         tr = [d["train"] for d in systems]
         k = len(tr[0])
         if any(len(t) != k for t in tr):
             return None
-        def stacked(key, src):                                             # one preallocated block, filled trial by trial
-            first = np.asarray(src[0][0][key], dtype=np.float64)
-            Tn = first.shape[0]
-            first = first.reshape(Tn, -1)
-            kk = len(src[0])
-            out = np.empty((len(src), kk * Tn, first.shape[1]))
-            for i, t in enumerate(src):
-                for j, x in enumerate(t):
-                    a = np.asarray(x[key], dtype=np.float64)
-                    if a.shape[0] != Tn or a.size != Tn * first.shape[1]:
-                        raise ValueError("ragged trials")
-                    out[i, j * Tn:(j + 1) * Tn] = a.reshape(Tn, -1)
+
+        def stacked(key, src, name):                                       # ONE C-level gather per quantity
+            arrs = [x[key] for t in src for x in t]
+            a0 = np.asarray(arrs[0])
+            Tn = a0.shape[0]
+            w = a0.size // max(Tn, 1)
+            try:
+                uniform = {(a.shape, a.dtype) for a in arrs} == {(a0.shape, np.dtype(np.float64))}
+            except AttributeError:                                           # lists / scalars among the trials
+                uniform = False
+            if not uniform:
+                arrs = [np.asarray(a, dtype=np.float64) for a in arrs]
+                if len({a.shape for a in arrs}) != 1:
+                    raise ValueError("ragged trials")
+            shape = (len(src), len(src[0]) * Tn, w)
+            out = ctx.host_array("sweep_" + name, shape) if ctx is not None else np.empty(shape)
+            flat = out.reshape((-1,) + a0.shape[1:]) if a0.ndim > 1 else out.reshape(-1)
+            np.concatenate(arrs, axis=0, out=flat)
             return out
-        Y, U = stacked("y", tr), stacked("u", tr)
-        Tm = stacked("t", tr)[:, :, 0]
+        Y, U = stacked("y", tr, "Y"), stacked("u", tr, "U")
+        Tm = stacked("t", tr, "t")[:, :, 0]
         va = [[d["val"][0]] for d in systems]
-        Yv, Uv = stacked("y", va), stacked("u", va)
+        Yv, Uv = stacked("y", va, "Yv"), stacked("u", va, "Uv")
     except ValueError:
         return None
     T = Y.shape[1] // k
-    good = Tm[:, :-1] < Tm[:, 1:]                                          # Ksysid.m:948: seams between trials
-    want = np.ones(k * T - 1, dtype=bool); want[T - 1::T] = False            # exactly the seams, nowhere else
-    if not (good == want).all():
+    good = Tm[:, :-1] < Tm[:, 1:]                                          # Ksysid.m:948: seams between trials ...
+    seams = good[:, T - 1::T]                                              # ... exactly at the trial joins, nowhere else
+    if seams.any() or int(np.count_nonzero(good)) != good.size - seams.size:
         return None
     return Y, U, k, Yv, Uv
 
@@ -182,7 +191,7 @@ def rand_models_sweep_batched(systems, ctx, degrees=None, nested=True):
     from .device import Basis, Traj
     from .ksysid import poly_exponent_table
     degrees = degrees or MAX_DEGREE
-    raw = _stack_raw(systems)
+    raw = _stack_raw(systems, ctx)
     if raw is None:
         return _sweep_batched_host(systems, ctx, degrees)
     return rand_models_sweep_arrays(*raw, ctx=ctx, degrees=degrees, nested=nested)

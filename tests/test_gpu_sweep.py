@@ -161,6 +161,27 @@ def test_device_resident_sweep_on_generated_systems(ctx):
     traj.close()
 
 
+def test_gather_into_page_locked_host_arrays_gives_the_same_sweep(ctx):
+    """sweep._stack_raw with a context writes the stacked trials into the context's page-locked arrays (kp_host_alloc),
+    reused and regrown from call to call; blocks and error table equal those of the plain numpy gather."""
+    from koopman_realizations_amd import rsys
+    r = rsys.Rsys(12, 3, 3, 2, seed=5)
+    systems = rsys.Rsys.save_data(r.simulate_systems_fast(2.0, 0.01, 5, np.zeros((1, 1))))
+    plain = sweep._stack_raw(systems)
+    for n in (4, 12, 7):                                    # grow, then reuse a larger block for a smaller gather
+        pinned = sweep._stack_raw(systems[:n], ctx)
+        ref = sweep._stack_raw(systems[:n])
+        for a, b in zip(pinned, ref):
+            assert np.array_equal(a, b)
+    h = ctx.host_array("sweep_Y", (3, 5))
+    h[:] = 1.0
+    assert ctx.host_array("sweep_Y", (3, 5)).sum() == 15.0  # same block again
+    tab_p = sweep.rand_models_sweep_arrays(*sweep._stack_raw(systems, ctx), ctx=ctx, degrees={"linear": 3, "bilinear": 2, "nonlinear": 2})
+    tab_n = sweep.rand_models_sweep_arrays(*plain, ctx=ctx, degrees={"linear": 3, "bilinear": 2, "nonlinear": 2})
+    for mt in tab_n:
+        assert np.array_equal(tab_p[mt], tab_n[mt])
+
+
 def test_fit_batch_matches_single_fits(ctx, golden):
     """K, G, C of kp_fit_batch against kp_fit_gram / kp_fit_solve system by system; singular systems are flagged."""
     from conftest import synth_pairs
