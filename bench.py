@@ -405,6 +405,12 @@ def main():
     ctx.synchronize()
     if world > 1:
         comm.all_gather_fit(args.warmup - 1 if args.warmup else 0, W) if args.warmup else None
+    # the synchronisation above ended with the warm-up's few one-workgroup factorisations: 0.3 ms of a nearly idle device,
+    # after which the Gram kernel needs ~20 launches to come back from 420 to 405 us (same file).  A short queue of Gram
+    # launches alone (no solves) leaves only the host's own latency between the last busy kernel and the timed region.
+    for _ in range(32):
+        kra.fit_gram(ctx, basis, snaps, fetch=False)
+    ctx.synchronize()
     comm.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
