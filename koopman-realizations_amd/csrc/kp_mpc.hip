@@ -22,6 +22,7 @@
 
 #define QP_MAXN 64       // variables (one wave handles <= 64)
 #define QP_MAXIT 2000
+#define QP_MAX_RELEASE 6   // rows a warm start may release before it is abandoned for the cold start
 
 struct kp_mpc {
   kp_ctx* ctx = nullptr;
@@ -286,6 +287,7 @@ __device__ __forceinline__ int qp_goldfarb_idnani(const double* Hq, const double
   };
   if (warm_q > 0 && !bad) {
     q = warm_q;
+    int n_rel = 0;
     while (q > 0) {
       // lam = Sinv (N x0 - b)
       for (int c = lane; c < q; c += 64) {
@@ -308,6 +310,14 @@ __device__ __forceinline__ int qp_goldfarb_idnani(const double* Hq, const double
       wave_argmin(lmin, l);
       WSYNC();
       if (!(lmin < 0.0)) break;             // dual feasible
+      // Every release is a rank-1 downdate of the inverse Schur complement, and their errors accumulate.  A set that
+      // needs more than a few is not the neighbourhood a warm start is for (another reference, another state): give
+      // it up - the cold start is exact - instead of iterating on a degraded inverse.
+      if (++n_rel > QP_MAX_RELEASE) {
+        for (int c = lane; c < q; c += 64) isact[act[c]] = 0;
+        q = 0;
+        break;
+      }
       drop_active(l);
     }
     // x = x0 - H^-1 N lam
