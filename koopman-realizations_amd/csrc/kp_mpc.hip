@@ -405,7 +405,7 @@ __device__ __forceinline__ int qp_goldfarb_idnani(const double* Hq, const double
       QP_TICK(6);
       for (int c = lane; c < q; c += 64) {
         double s = 0.0;
-#pragma unroll 4
+#pragma unroll 8
         for (int k = 0; k < q; ++k) s += Sinv[c + k * n] * d[k];
         r[c] = s;
       }
@@ -414,7 +414,7 @@ __device__ __forceinline__ int qp_goldfarb_idnani(const double* Hq, const double
       double apz_l = 0.0, apx_l = 0.0;
       for (int i = lane; i < n; i += 64) {
         double s = hp[i];
-#pragma unroll 4
+#pragma unroll 8
         for (int c = 0; c < q; ++c) s -= HN[i + c * n] * r[c];
         zd[i] = s;
         apz_l += ap[i] * s;
