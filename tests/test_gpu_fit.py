@@ -265,6 +265,9 @@ def test_async_fit_pipeline_matches_synchronous_result(ctx):
     ctx.synchronize()
     for i in range(3):
         assert np.abs(ctx.fit_result(i, W) - Ksync[i]).max() <= tol(Ksync[i])
+    Kst = ctx.fit_results(0, 3, W)               # the same three through the page-locked stack (column-major blocks)
+    for i in range(3):
+        assert np.array_equal(Kst[i].T, ctx.fit_result(i, W))
     with pytest.raises(kra.KoopmanHipError):
         ctx.fit_result(3, W)                     # not part of the batch
     # ring shorter than the batch: the oldest results are gone and say so
