@@ -124,7 +124,8 @@ struct EllMat {
 // act: n ints | isact: mr bytes | LDS copy of the constraint rows when K <= QP_KLDS: val mr*K, col mr*K ints, norm mr, b mr
 #define QP_KLDS 4
 __host__ __device__ inline int qp_lds_doubles(int n, int mr) {
-  return 3 * n * n + 9 * n + 2 * ((n + 1) / 2) + (mr + 7) / 8 + 8 + mr * QP_KLDS + (mr * QP_KLDS + 1) / 2 + 2 * mr + 2;
+  return 3 * n * n + 9 * n + 2 * ((n + 1) / 2) + (mr + 7) / 8 + 8 + mr * QP_KLDS + (mr * QP_KLDS + 1) / 2 + 2 * mr + 2 +
+         64;   // (the last 64: scalar exchanges of the workgroup-wide solver)
 }
 
 // Wave-local synchronisation: LDS operations of one wave complete in issue order, so lanes only
@@ -516,6 +517,337 @@ __device__ __forceinline__ int qp_goldfarb_idnani(const double* Hq, const double
   return status;
 }
 
+// ---- the same dual active-set iteration by the WHOLE workgroup (256 threads) ----------------------------------------------
+// For n <= 32 variables with the constraint rows in LDS (K <= QP_KLDS) and H^-1 already formed by the caller.  One wave
+// spends an iteration in dependent chains: a 30-term dot product per lane (r = S^-1 d, z = hp - HN r), 30 columns of the
+// bordering update per lane, two rows of the violation scan per lane.  Here every such loop is two-dimensional:
+//   * matrix-vector products: 8 adjacent lanes share a row and split the columns (4 terms each), summed by DPP
+//     (quad_perm x2 + row_half_mirror);
+//   * bordering / removal updates of S^-1: thread (i = tid & 31, j = tid >> 5, +8, ..) owns elements, no chains at all;
+//   * violation scan: one row per thread;
+// and the few scalars that steer the iteration (most violated row, step lengths) go through LDS: each wave reduces, lane 0
+// stores, barrier, every thread combines the four entries in the same order - the control flow is uniform.
+// Same algorithm, thresholds and data layout as qp_goldfarb_idnani (the products are summed in another order: results
+// agree to rounding).  ~10 barriers per iteration.  red: 64 doubles of LDS for the exchanges.
+struct WgX {
+  double* v;
+  int* i;
+};
+__device__ __forceinline__ void wgx_argmax(double& v, int& idx, WgX x) {
+  wave_argmax(v, idx);
+  if ((threadIdx.x & 63) == 0) { x.v[threadIdx.x >> 6] = v; x.i[threadIdx.x >> 6] = idx; }
+  __syncthreads();
+  double b = x.v[0];
+  int bi = x.i[0];
+#pragma unroll
+  for (int w = 1; w < 4; ++w) {
+    const double c = x.v[w];
+    const int ci = x.i[w];
+    if (c > b) { b = c; bi = ci; }
+  }
+  v = b; idx = bi;
+}
+__device__ __forceinline__ void wgx_argmin(double& v, int& idx, WgX x) {
+  wave_argmin(v, idx);
+  if ((threadIdx.x & 63) == 0) { x.v[threadIdx.x >> 6] = v; x.i[threadIdx.x >> 6] = idx; }
+  __syncthreads();
+  double b = x.v[0];
+  int bi = x.i[0];
+#pragma unroll
+  for (int w = 1; w < 4; ++w) {
+    const double c = x.v[w];
+    const int ci = x.i[w];
+    if (c < b) { b = c; bi = ci; }
+  }
+  v = b; idx = bi;
+}
+// two sums at once (a over x.v[0..4), b over x.v[4..8))
+__device__ __forceinline__ void wgx_sum2(double& a, double& b, WgX x) {
+  a = wave_sum(a);
+  b = wave_sum(b);
+  if ((threadIdx.x & 63) == 0) { x.v[threadIdx.x >> 6] = a; x.v[4 + (threadIdx.x >> 6)] = b; }
+  __syncthreads();
+  a = (x.v[0] + x.v[1]) + (x.v[2] + x.v[3]);
+  b = (x.v[4] + x.v[5]) + (x.v[6] + x.v[7]);
+}
+__device__ __forceinline__ double sum8(double v) {      // over the 8 adjacent lanes of an aligned group, in every lane
+  v += dpp_mov<0xB1>(v);
+  v += dpp_mov<0x4E>(v);
+  v += dpp_mov<0x141>(v);
+  return v;
+}
+
+__device__ __forceinline__ int qp_gi_wg(const double* f, const EllMat A, const double* bvec, int n, int mr, double* ws, double* red,
+                                        double* x_out, double tol, long long* stamps, int hinv_bad, int warm_q, int* warm_out) {
+  const int tid = threadIdx.x;
+  double* Hinv = ws;
+  double* HN = Hinv + n * n;
+  double* Sinv = HN + n * n;
+  double* x = Sinv + n * n;
+  double* hp = x + n;
+  double* r = hp + n;
+  double* lam = r + n;
+  double* d = lam + n;
+  double* zd = d + n;
+  double* ap = zd + n;
+  double* fl = ap + n;
+  double* apv = fl + n;
+  int* apc = (int*)(apv + n);
+  int* act = apc + n + (n & 1);
+  unsigned char* isact = (unsigned char*)(act + n + (n & 1));
+  double* lval = (double*)isact + ((mr + 7) >> 3);
+  double* lnorm = lval + mr * QP_KLDS;
+  double* lb = lnorm + mr;
+  int* lcol = (int*)(lb + mr);
+  // exchange areas (distinct per reduction site: a site is not reached again before every thread has read it)
+  WgX xs{red, (int*)(red + 4)}, xr{red + 8, (int*)(red + 12)}, xq{red + 16, (int*)(red + 28)}, xw{red + 32, (int*)(red + 36)};
+  const int K = A.K;
+  for (int e = tid; e < mr * K; e += 256) { lval[e] = A.val[e]; lcol[e] = A.col[e]; }
+  for (int e = tid; e < mr; e += 256) {
+    const double nr_ = A.norm[e];
+    lnorm[e] = nr_ == 0.0 ? 0.0 : 1.0 / nr_;
+    lb[e] = bvec[e];
+    isact[e] = 0;
+  }
+  for (int e = tid; e < n; e += 256) {
+    fl[e] = f[e];
+    ap[e] = 0.0;
+  }
+  __syncthreads();
+  for (int c = tid; c < warm_q; c += 256) isact[act[c]] = 1;
+  // x = -Hinv f : row i = tid >> 3, the 8 lanes of a group split the columns
+  const int gi = tid >> 3, gp = tid & 7;
+  {
+    double s_ = 0.0;
+    if (gi < n)
+      for (int j = gp; j < n; j += 8) s_ += Hinv[gi + j * n] * fl[j];
+    s_ = sum8(s_);
+    if (gi < n && gp == 0) x[gi] = -s_;
+  }
+  __syncthreads();
+  if (stamps && tid == 0) stamps[4] = wall_clock64();
+  int q = 0;
+  int status = 1;
+  int it = hinv_bad ? QP_MAXIT : 0;
+  // r_out[c] = sum_k M[c + k n] v[k], c < rows, k < cols   (all threads; caller places the barrier)
+  auto matvec = [&](const double* M, const double* v, int rows, int cols, double* out) {
+    double s_ = 0.0;
+    if (gi < rows)
+      for (int k = gp; k < cols; k += 8) s_ += M[gi + k * n] * v[k];
+    s_ = sum8(s_);
+    if (gi < rows && gp == 0) out[gi] = s_;
+  };
+  // removal of active constraint l: swap with the last one, then the rank-1 downdate that deletes the last index
+  auto drop_active = [&](int l) {
+    const int last = q - 1;
+    if (l != last) {
+      if (tid < q) {                                  // columns l <-> last
+        const double a_ = Sinv[tid + l * n], b_ = Sinv[tid + last * n];
+        Sinv[tid + l * n] = b_;
+        Sinv[tid + last * n] = a_;
+      }
+      if (tid >= 64 && tid < 64 + n) {                // (another wave) columns of HN
+        const int i = tid - 64;
+        const double a_ = HN[i + l * n];
+        HN[i + l * n] = HN[i + last * n];
+        HN[i + last * n] = a_;
+      }
+      if (tid == 128) {
+        const int ta = act[l]; act[l] = act[last]; act[last] = ta;
+        const double tl = lam[l]; lam[l] = lam[last]; lam[last] = tl;
+      }
+      __syncthreads();
+      if (tid < q) {                                  // rows l <-> last
+        const double a_ = Sinv[l + tid * n], b_ = Sinv[last + tid * n];
+        Sinv[l + tid * n] = b_;
+        Sinv[last + tid * n] = a_;
+      }
+      __syncthreads();
+    }
+    const double isl = 1.0 / Sinv[last + last * n];
+    {
+      const int i = tid & 31;
+      if (i < last) {
+        const double ri = Sinv[i + last * n] * isl;
+        for (int j = tid >> 5; j < last; j += 8) Sinv[i + j * n] -= ri * Sinv[last + j * n];
+      }
+    }
+    if (tid == 0) isact[act[last]] = 0;
+    --q;
+    __syncthreads();
+  };
+  if (warm_q > 0 && !hinv_bad) {
+    q = warm_q;
+    int n_rel = 0;
+    while (q > 0) {
+      if (tid < q) {
+        const int row = act[tid];
+        double v = -lb[row];
+        for (int k = 0; k < K; ++k) v += lval[k * mr + row] * x[lcol[k * mr + row]];
+        d[tid] = v;
+      }
+      __syncthreads();
+      matvec(Sinv, d, q, q, lam);
+      __syncthreads();
+      double lmin = tid < q ? lam[tid] : 1e300;
+      int l = tid < q ? tid : 0x7fffffff;
+      wgx_argmin(lmin, l, xw);
+      if (!(lmin < 0.0)) break;
+      if (++n_rel > QP_MAX_RELEASE) {
+        if (tid < q) isact[act[tid]] = 0;
+        q = 0;
+        break;
+      }
+      drop_active(l);
+    }
+    // x = x0 - HN lam
+    {
+      double s_ = 0.0;
+      if (gi < n)
+        for (int c = gp; c < q; c += 8) s_ += HN[gi + c * n] * lam[c];
+      s_ = sum8(s_);
+      __syncthreads();
+      if (gi < n && gp == 0) x[gi] -= s_;
+    }
+    __syncthreads();
+  }
+  while (it < QP_MAXIT) {
+    ++it;
+    // ---- most violated inactive constraint ----
+    double best = -1e300;
+    int bestp = 0x7fffffff;
+    int infeas = 0;
+    for (int row = tid; row < mr; row += 256) {
+      double v = -lb[row];
+      for (int k = 0; k < K; ++k) v += lval[k * mr + row] * x[lcol[k * mr + row]];
+      const double in_ = lnorm[row];
+      const double sv_ = v * in_;
+      infeas |= (in_ == 0.0 && v > tol) ? 1 : 0;
+      if (in_ != 0.0 && !isact[row] && sv_ > best) { best = sv_; bestp = row; }
+    }
+    infeas = __any(infeas);
+    if ((tid & 63) == 0) xs.i[4 + (tid >> 6)] = infeas;     // rides on the barrier of the arg max
+    wgx_argmax(best, bestp, xs);
+    infeas = xs.i[4] | xs.i[5] | xs.i[6] | xs.i[7];
+    if (infeas) break;
+    if (best <= tol) {
+      status = 0;
+      break;
+    }
+    const int p = bestp;
+    const double bp = lb[p];
+    if (tid < K) {
+      const double v = lval[tid * mr + p];
+      const int cidx = lcol[tid * mr + p];
+      apv[tid] = v;
+      apc[tid] = cidx;
+      if (v != 0.0) ap[cidx] = v;
+    }
+    __syncthreads();
+    double app = 0.0;
+    if (tid < n) {                                   // (n <= 32: wave 0 alone holds the terms of a_p'H^-1 a_p)
+      double s_ = 0.0;
+      for (int k = 0; k < K; ++k) s_ += apv[k] * Hinv[tid + apc[k] * n];
+      hp[tid] = s_;
+      app = s_ * ap[tid];
+    }
+    if (tid < 64) {
+      app = wave_sum(app);
+      if (tid == 0) xq.v[0] = app;
+    }
+    __syncthreads();                                 // (also publishes hp)
+    app = xq.v[0];
+    double lam_p = 0.0;
+    bool fail = false;
+    while (it < QP_MAXIT) {
+      ++it;
+      if (tid < q) {
+        double s_ = 0.0;
+        for (int k = 0; k < K; ++k) s_ += apv[k] * HN[apc[k] + tid * n];
+        d[tid] = s_;
+      }
+      __syncthreads();
+      matvec(Sinv, d, q, q, r);
+      __syncthreads();
+      // zd = hp - HN r ; a_p'zd ; a_p'x
+      double apz = 0.0, apx = 0.0;
+      {
+        double s_ = 0.0;
+        if (gi < n)
+          for (int c = gp; c < q; c += 8) s_ += HN[gi + c * n] * r[c];
+        s_ = sum8(s_);
+        if (gi < n && gp == 0) {
+          const double z_ = hp[gi] - s_;
+          zd[gi] = z_;
+          apz = ap[gi] * z_;
+          apx = ap[gi] * x[gi];
+        }
+      }
+      wgx_sum2(apz, apx, xr);                       // (publishes zd)
+      double t1 = 1e300;
+      int l = 0x7fffffff;
+      if (tid < q && r[tid] > 1e-13) {
+        t1 = lam[tid] / r[tid];
+        l = tid;
+      }
+      wgx_argmin(t1, l, xw);
+      const bool t2fin = apz > 1e-13 * app;
+      const double t2 = t2fin ? (apx - bp) / apz : 1e300;
+      const double t = fmin(t1, t2);
+      if (!(t < 1e299)) {
+        fail = true;
+        break;
+      }
+      if (tid < q) lam[tid] -= t * r[tid];
+      lam_p += t;
+      if (t2fin && tid >= 64 && tid < 64 + n) x[tid - 64] -= t * zd[tid - 64];
+      __syncthreads();
+      if (t2 <= t1) {
+        if (q >= n) {
+          fail = true;
+          break;
+        }
+        const double ib = 1.0 / apz;
+        {
+          const int i = tid & 31;
+          if (i < q) {
+            const double ri = r[i] * ib;
+            for (int j = tid >> 5; j < q; j += 8) Sinv[i + j * n] += ri * r[j];
+          }
+        }
+        if (tid < q) {
+          Sinv[tid + q * n] = -r[tid] * ib;
+          Sinv[q + tid * n] = -r[tid] * ib;
+        }
+        if (tid >= 64 && tid < 64 + n) HN[tid - 64 + q * n] = hp[tid - 64];
+        if (tid == 128) {
+          Sinv[q + q * n] = ib;
+          act[q] = p;
+          lam[q] = lam_p;
+          isact[p] = 1;
+        }
+        ++q;
+        __syncthreads();
+        break;
+      }
+      drop_active(l);
+    }
+    if (tid < K) ap[apc[tid]] = 0.0;
+    __syncthreads();
+    if (fail) break;
+  }
+  if (stamps && tid == 0) {
+    stamps[8] = it;
+    stamps[9] = q;
+  }
+  for (int i = tid; i < n; i += 256) x_out[i] = status == 0 ? x[i] : __builtin_nan("");
+  if (warm_out) {
+    if (tid == 0) warm_out[0] = status == 0 ? q : 0;
+    for (int c = tid; c < q; c += 256) warm_out[1 + c] = act[c];
+  }
+  return status;
+}
+
 // ---- generic QP shim kernel -----------------------------------------------------------------
 // One wave per problem.  Problem p = blockIdx.x reads H + p sH, f + p sf, the ELL values / row norms + p sA / p sb and
 // b + p sb, writes x + p n and status[p] (strides in doubles; 0 for a single problem).  sticky: a problem whose status
@@ -657,6 +989,7 @@ struct MpcArgs {
   long long* stamps;    // [8] wall_clock64 stamps + [8] counters of problem 0 (diagnostics), or nullptr
   unsigned long long* done_flag;   // pinned host word: the kernel stores done_seq there when its outputs are visible (or nullptr)
   unsigned long long done_seq;
+  int qp_wg;            // active-set iteration by the whole workgroup (qp_gi_wg) when the problem qualifies
 };
 
 // LDS (doubles): z N | beta N*m | S Np*nproj*m | e (Np+1)*nproj | Hq nvar^2 | f nvar | b nrows | zh (Np+1)*N (iters>1)
@@ -939,7 +1272,13 @@ __global__ __launch_bounds__(256) void kp_mpc_step_kernel(MpcArgs a) {
         if (wg_spd_inverse_pp(Sw, Hq, wq, nv)) wq = 0;   // dependent rows: cold start
       }
     }
-    if (tid < 64) {
+    // single-problem launches: the iteration by all four waves (12 % faster cold solves; in the batched kernel it would
+    // cost the third workgroup per CU and is slower: 1.64 against 1.27 ms per 4096 problems)
+    if (WARM && a.qp_wg && nv <= 32 && a.ell.K <= QP_KLDS) {
+      const int st = qp_gi_wg(f, a.ell, bq, nv, nr, qpws, qpws + qp_lds_doubles(nv, nr) - 64, xout, 1e-10, stamps, hbad, wq,
+                              WARM ? a.warm : nullptr);
+      if (tid == 0) *st_sh = st;
+    } else if (tid < 64) {
       int st = WARM ? qp_goldfarb_idnani(Hq, f, a.ell, bq, nv, nr, qpws, xout, 1e-10, stamps, have_hinv, hbad, wq, a.warm)
                     : qp_goldfarb_idnani(Hq, f, a.ell, bq, nv, nr, qpws, xout, 1e-10, stamps, have_hinv, hbad);
       if (tid == 0) *st_sh = st;
@@ -1330,6 +1669,8 @@ static int mpc_run(kp_mpc* M, const kp_basis* basis, int nb, const double* z, co
     a.iters = 1;                       // the linearisation passes are driven from the host (the QP runs in its own kernel)
   }
   static const bool no_warm = getenv("KP_MPC_NO_WARM") != nullptr;
+  static const int qp_wg = [] { const char* e = getenv("KP_QP_WG"); return e ? atoi(e) : 1; }();
+  a.qp_wg = qp_wg;
   if (!M->warm) {
     KP_HIP(ctx, hipMalloc((void**)&M->warm, (size_t)(1 + nv) * sizeof(int)));
     KP_HIP(ctx, hipMemsetAsync(M->warm, 0, (size_t)(1 + nv) * sizeof(int), ctx->stream));
