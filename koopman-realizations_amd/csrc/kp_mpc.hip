@@ -19,6 +19,7 @@
 #include <cstring>
 
 #include "kp_internal.h"
+#include "kp_wg_inverse.h"
 
 #define QP_MAXN 64       // variables (one wave handles <= 64)
 #define QP_MAXIT 2000
@@ -664,7 +665,7 @@ __device__ __forceinline__ int qp_gi_wg(const double* f, const EllMat A, const d
       }
       __syncthreads();
     }
-    const double isl = 1.0 / Sinv[last + last * n];
+    const double isl = wg_recip(Sinv[last + last * n]);
     {
       const int i = tid & 31;
       if (i < last) {
@@ -787,12 +788,12 @@ __device__ __forceinline__ int qp_gi_wg(const double* f, const EllMat A, const d
       double t1 = 1e300;
       int l = 0x7fffffff;
       if (tid < q && r[tid] > 1e-13) {
-        t1 = lam[tid] / r[tid];
+        t1 = lam[tid] * wg_recip(r[tid]);
         l = tid;
       }
       wgx_argmin(t1, l, xw);
       const bool t2fin = apz > 1e-13 * app;
-      const double t2 = t2fin ? (apx - bp) / apz : 1e300;
+      const double t2 = t2fin ? (apx - bp) * wg_recip(apz) : 1e300;
       const double t = fmin(t1, t2);
       if (!(t < 1e299)) {
         fail = true;
@@ -807,7 +808,7 @@ __device__ __forceinline__ int qp_gi_wg(const double* f, const EllMat A, const d
           fail = true;
           break;
         }
-        const double ib = 1.0 / apz;
+        const double ib = wg_recip(apz);
         {
           const int i = tid & 31;
           if (i < q) {
@@ -966,7 +967,6 @@ __global__ __launch_bounds__(256) void kp_mpc_setup_kernel(const double* __restr
   }
 }
 
-#include "kp_wg_inverse.h"
 
 struct MpcArgs {
   BasisDev basis;   // used when zeta != nullptr (fused lift)
