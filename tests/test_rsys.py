@@ -77,3 +77,14 @@ def test_sweep_stacking_of_data4sysid_structs():
     sets[1]["train"][2] = {k_: v[:40] for k_, v in sets[1]["train"][2].items()}
     assert sweep._stack_raw(sets) is None
     assert sweep._stack_raw([{"train": sets[0]["train"][:2], "val": sets[0]["val"]}, sets[2]]) is None
+    # the seam test of Ksysid.m:948 (time restarts exactly at the trial joins): a glitch inside a trial, or trials whose
+    # clocks run on, are refused; lists in place of arrays are accepted
+    import copy
+    sets = Rsys.save_data(r.simulate_systems_fast(0.5, 0.01, 4, np.zeros((1, 1))))
+    bad = copy.deepcopy(sets); bad[1]["train"][2]["t"][20] = bad[1]["train"][2]["t"][19]
+    assert sweep._stack_raw(bad) is None
+    bad = copy.deepcopy(sets); bad[0]["train"][1]["t"] = bad[0]["train"][1]["t"] + 100.0
+    assert sweep._stack_raw(bad) is None
+    lst = copy.deepcopy(sets); lst[0]["train"][0] = {k_: v.tolist() for k_, v in lst[0]["train"][0].items()}
+    Yl = sweep._stack_raw(lst)[0]
+    assert np.array_equal(Yl, sweep._stack_raw(sets)[0])
