@@ -68,9 +68,9 @@ classdef KsysidHip < Ksysid
             if obj.lasso >= 1e6             % :1068 tests the PROPERTY
                 lasso = Inf;
             end
-            s = kp_mex( 'snapshots_upload' , obj.hip.ctx , snapshotPairs.alpha , snapshotPairs.beta , snapshotPairs.u );
+            % the context's resident snapshot object, refilled in place (no device allocation per call; staged transfer)
+            s = kp_mex( 'snapshots_resident' , obj.hip.ctx , snapshotPairs.alpha , snapshotPairs.beta , snapshotPairs.u );
             K = kp_mex( 'fit' , obj.hip.ctx , obj.hip.basis , s , lasso );
-            kp_mex( 'snapshots_destroy' , s );
             N = obj.params.N;
             Px = kp_mex( 'lift' , obj.hip.ctx , obj.hip.basis , 2 , snapshotPairs.alpha , snapshotPairs.u );
             Py = kp_mex( 'lift' , obj.hip.ctx , obj.hip.basis , 2 , snapshotPairs.beta , snapshotPairs.u );
@@ -91,9 +91,8 @@ classdef KsysidHip < Ksysid
                 return;
             end
             sp = obj.snapshotPairs;
-            s = kp_mex( 'snapshots_upload' , obj.hip.ctx , sp.alpha , sp.beta , sp.u );
+            s = kp_mex( 'snapshots_resident' , obj.hip.ctx , sp.alpha , sp.beta , sp.u );
             Ks = kp_mex( 'fit' , obj.hip.ctx , obj.hip.basis , s , lasso(:)' );
-            kp_mex( 'snapshots_destroy' , s );
             N = obj.params.N;
             Px = kp_mex( 'lift' , obj.hip.ctx , obj.hip.basis , 2 , sp.alpha , sp.u );
             Py = kp_mex( 'lift' , obj.hip.ctx , obj.hip.basis , 2 , sp.beta , sp.u );

@@ -15,6 +15,7 @@
  *   P   = kp_mex('lift', h, b, what, zeta, u)                           kp_lift (what: 0 full, 1 econ, 2 row of Px)
  *   s   = kp_mex('snapshots_upload', h, alpha, beta, u)                 kp_snapshots_upload
  *         kp_mex('snapshots_update', h, s, alpha, beta, u)                kp_snapshots_update (refill in place, returns once staged)
+ *   s   = kp_mex('snapshots_resident', h, alpha, beta, u)               the context's own resident object, refilled (owned by the MEX file)
  *         kp_mex('snapshots_destroy', s) / kp_mex('basis_destroy', b) / kp_mex('mpc_destroy', m)
  *   K   = kp_mex('fit', h, b, s, lasso)                                 kp_fit: W x W x numel(lasso)   (get_Koopman, train_models)
  *   [G,C] = kp_mex('fit_gram', h, b, s)                                 kp_fit_gram
@@ -36,10 +37,18 @@
 #define MAXH 64
 static kp_ctx* g_ctx[MAXH];
 static int g_nctx = 0;
+/* one resident snapshot object per context, refilled in place ('snapshots_resident'): a value-class method such as
+ * KsysidHip.get_Koopman cannot keep a handle between calls, the locked MEX file can */
+static kp_snapshots* g_snaps[MAXH];
+static int g_snaps_nz[MAXH], g_snaps_m[MAXH];
 
 static void at_exit(void) {
   for (int i = 0; i < g_nctx; ++i)
-    if (g_ctx[i]) kp_destroy(g_ctx[i]);
+    if (g_ctx[i]) {
+      if (g_snaps[i]) kp_snapshots_destroy(g_snaps[i]);
+      g_snaps[i] = NULL;
+      kp_destroy(g_ctx[i]);
+    }
   g_nctx = 0;
 }
 
@@ -79,7 +88,11 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
   } else if (!strcmp(cmd, "destroy")) {
     kp_ctx* c = (kp_ctx*)get_handle(prhs[1]);
     for (int i = 0; i < g_nctx; ++i)
-      if (g_ctx[i] == c) g_ctx[i] = NULL;
+      if (g_ctx[i] == c) {
+        if (g_snaps[i]) kp_snapshots_destroy(g_snaps[i]);
+        g_snaps[i] = NULL;
+        g_ctx[i] = NULL;
+      }
     kp_destroy(c);
   } else if (!strcmp(cmd, "basis_create")) {
     kp_ctx* c = (kp_ctx*)get_handle(prhs[1]);
@@ -132,6 +145,27 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     check(kp_snapshots_upload(c, dbl(prhs[2]), dbl(prhs[3]), dbl(prhs[4]), (int64_t)mxGetM(prhs[2]), (int)mxGetN(prhs[2]),
                               (int)mxGetN(prhs[4]), &s), c);
     plhs[0] = put_handle(s);
+  } else if (!strcmp(cmd, "snapshots_resident")) {
+    /* s = kp_mex('snapshots_resident', h, alpha, beta, u): the context's resident object, refilled in place
+     * (kp_snapshots_update: no hipMalloc / hipFree per call, staged chunked transfer); owned by the MEX file - do not destroy */
+    kp_ctx* c = (kp_ctx*)get_handle(prhs[1]);
+    const int nz = (int)mxGetN(prhs[2]), m_ = (int)mxGetN(prhs[4]);
+    int slot = -1;
+    for (int i = 0; i < g_nctx; ++i)
+      if (g_ctx[i] == c) slot = i;
+    if (slot < 0) mexErrMsgIdAndTxt("kp:handle", "snapshots_resident: unknown context");
+    if (g_snaps[slot] && (g_snaps_nz[slot] != nz || g_snaps_m[slot] != m_)) {
+      kp_snapshots_destroy(g_snaps[slot]);
+      g_snaps[slot] = NULL;
+    }
+    if (!g_snaps[slot]) {
+      check(kp_snapshots_upload(c, dbl(prhs[2]), dbl(prhs[3]), dbl(prhs[4]), (int64_t)mxGetM(prhs[2]), nz, m_, &g_snaps[slot]), c);
+      g_snaps_nz[slot] = nz;
+      g_snaps_m[slot] = m_;
+    } else {
+      check(kp_snapshots_update(c, g_snaps[slot], dbl(prhs[2]), dbl(prhs[3]), dbl(prhs[4]), (int64_t)mxGetM(prhs[2])), c);
+    }
+    plhs[0] = put_handle(g_snaps[slot]);
   } else if (!strcmp(cmd, "snapshots_update")) {
     kp_ctx* c = (kp_ctx*)get_handle(prhs[1]);
     kp_snapshots* s = (kp_snapshots*)get_handle(prhs[2]);
