@@ -423,6 +423,18 @@ class Ksysid:
         p["N"] = self.basis_dev.N                                          # :1512-1516
 
     # ---- fitting ---------------------------------------------------------------------------
+    def _resident_snapshots(self, alpha, beta, u):
+        """One device snapshot object per Ksysid, refilled in place by every get_Koopman call (kp_snapshots_update: no device
+        allocation per call, staged chunked transfer) - what matlab/KsysidHip.m does with kp_mex('snapshots_resident')."""
+        a = np.asarray(alpha); uu = np.asarray(u)
+        cur = getattr(self, "_snaps_res", None)
+        if cur is not None and cur.handle and cur.nzeta == a.shape[1] and cur.m == uu.shape[1]:
+            return cur.update(alpha, beta, u)
+        if cur is not None:
+            cur.close()
+        self._snaps_res = Snapshots(self.ctx, alpha, beta, u)
+        return self._snaps_res
+
     def get_Koopman(self, snapshotPairs, lasso=None, want_PxPy=True):
         """Ksysid.m:987-1092.  The per-row lift loop, Px'Px / Px'Py and the solve run on the
         GPU; Px/Py are only materialised (kp_lift) for the koopData fields the reference
@@ -430,7 +442,7 @@ class Ksysid:
         N = self.params["N"]
         if self.loaded:
             return self._get_Koopman_loaded(snapshotPairs, lasso, want_PxPy)
-        snaps = Snapshots(self.ctx, snapshotPairs["alpha"], snapshotPairs["beta"], snapshotPairs["u"])
+        snaps = self._resident_snapshots(snapshotPairs["alpha"], snapshotPairs["beta"], snapshotPairs["u"])
         try:
             obj_lasso = np.atleast_1d(self.lasso)
             if np.all(obj_lasso >= 1e6):                                   # :1068 tests the PROPERTY
@@ -451,7 +463,7 @@ class Ksysid:
                 else:
                     K = fit(self.ctx, self.basis_dev, snaps, [lval])[0]
         finally:
-            snaps.close()
+            pass                                                           # the object stays resident for the next call
         koop = {"K": K, "u": snapshotPairs["u"], "alpha": snapshotPairs["alpha"]}
         if want_PxPy:
             koop["Px"] = self.basis_dev.lift(F.LIFT_ROW, snapshotPairs["alpha"], snapshotPairs["u"])[:, :N]
