@@ -824,14 +824,23 @@ extern "C" int kp_fit(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* sn
   if (!ctx || !basis || !snaps || n_lasso < 1) return ctx ? ctx->fail(KP_ERR_ARG, "kp_fit: bad argument") : KP_ERR_ARG;
   KP_HIP(ctx, hipSetDevice(ctx->device));
   const int W = basis->dev.W, N = basis->dev.N;
-  int rc = ensure_gc(ctx, W);
-  if (rc) return rc;
   const bool all_ls = [&] {
     for (int i = 0; i < n_lasso; ++i)
       if (lasso && lasso[i] < 1e6) return false;
     return true;
   }();
-  if (!K_out && n_lasso == 1 && all_ls && ctx->stream2 && ctx->sticky_info && !ctx->reduce_grams && !getenv("KP_NO_ASYNC")) {
+  const bool go_async = !K_out && n_lasso == 1 && all_ls && ctx->stream2 && ctx->sticky_info && !ctx->reduce_grams && !getenv("KP_NO_ASYNC");
+  int rc;
+  // The [G | C] ring may hold queued Gram pairs that are not solved yet (deferred, batched solves): drain the pipeline
+  // BEFORE any buffer of it can be reallocated for another width - ensure_gc frees and reallocates GC when the new W needs
+  // more room - and before a synchronous fit reuses it.
+  if (ctx->async_pending && (!go_async || ctx->pend_basis != (const void*)basis || ctx->pend_Ns != snaps->Ns || ctx->pend_W != W)) {
+    rc = kp_synchronize(ctx);
+    if (rc) return rc;
+  }
+  rc = ensure_gc(ctx, W);
+  if (rc) return rc;
+  if (go_async) {
     // ---- asynchronous pipeline: this fit's solve (stream2) overlaps the next fit's Gram (stream) ----
     // two [G | C] buffers alternate, so this Gram's reduction only has to wait for the pad kernel (the solve's
     // copy of G | C) of the fit before the previous one -- never for the solve that is running right now

@@ -14,92 +14,20 @@
 //   * every 10 iterations the host reads the states: a value ends when its active-set candidate (Cholesky per column on
 //     the current support) satisfies every optimality condition of the QP, or when the iteration has converged
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstring>
 #include <vector>
 
 #include "kp_internal.h"
+#include "kp_symm_gemm.h"
 
-// ------------------------------------------------------------------------------------------------
-// C (W x nc) = G (W x W, symmetric) * X (W x nc), column-major.  Workgroup: 16 output rows x 32 output
-// columns; the whole contraction range of both operands is staged in LDS once ([r][16 G cols | 32 X cols]),
-// then 8 waves x (one 4-row group, half of the k-steps) x 2 quads run without barriers.
-// ------------------------------------------------------------------------------------------------
-#define SG_RS 49   // odd: the staging writes (lanes = consecutive rows) and the operand reads both spread over the banks
-__global__ __launch_bounds__(512) void kp_symm_gemm_kernel(const double* __restrict__ G, const double* __restrict__ X, int W, int nc,
-                                                           double* __restrict__ C) {
-  extern __shared__ double sm[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r0c = blockIdx.x * 16;       // output rows = columns of G'
-  const int c0 = blockIdx.y * 32;        // output columns
-  const int Wp = (W + 3) & ~3;
-  // consecutive threads: consecutive rows of one column (coalesced); all 48 columns (loads) of a row in flight
-  for (int r = tid; r < Wp; r += 512) {
-    double v[48];
-#pragma unroll
-    for (int col = 0; col < 48; ++col) {
-      const int gc = col < 16 ? r0c + col : c0 + col - 16;
-      const bool ok = r < W && (col < 16 ? gc < W : gc < nc);
-      const double* src = col < 16 ? G : X;
-      v[col] = ok ? src[r + (size_t)gc * W] : 0.0;
-    }
-#pragma unroll
-    for (int col = 0; col < 48; ++col) sm[r * SG_RS + col] = v[col];
-  }
-  __syncthreads();
-  // 8 waves: A group = wave & 3 (4 output rows), half of the contraction range = wave >> 2
-  const int lrow = (lane >> 4) * SG_RS, blk = (lane >> 2) & 3, lc = lane & 3;
-  const int ao = lrow + 4 * (wave & 3) + lc;
-  const int bo0 = lrow + 16 + 4 * blk + lc, bo1 = bo0 + 16;
-  double acc0 = 0.0, acc1 = 0.0;
-  const int nk = Wp / 4, kh = (nk + 1) / 2;
-  const int k0 = (wave >> 2) * kh, k1 = min(nk, k0 + kh);
-#pragma unroll 6
-  for (int k = k0; k < k1; ++k) {
-    const double a = sm[k * 4 * SG_RS + ao];
-    const double b0 = sm[k * 4 * SG_RS + bo0], b1 = sm[k * 4 * SG_RS + bo1];
-    acc0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b0, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b1, acc1, 0, 0, 0);
-  }
-  __syncthreads();                       // operands are consumed: reuse the LDS for the split-k partials
-  if (wave >= 4) { sm[(wave - 4) * 128 + lane] = acc0; sm[(wave - 4) * 128 + 64 + lane] = acc1; }
-  __syncthreads();
-  if (wave < 4) {
-    acc0 += sm[wave * 128 + lane];
-    acc1 += sm[wave * 128 + 64 + lane];
-    // D lane: column j = lane & 3 of block (lane >> 2) & 3, row i = lane >> 4
-    const int io = r0c + 4 * wave + (lane >> 4);
-    const int j0 = c0 + 4 * blk + lc, j1 = j0 + 16;
-    if (io < W) {
-      if (j0 < nc) C[io + (size_t)j0 * W] = acc0;
-      if (j1 < nc) C[io + (size_t)j1 * W] = acc1;
-    }
-  }
-}
-
-// fallback for W too large for the LDS staging above: one thread per output element
-__global__ __launch_bounds__(256) void kp_symm_gemm_naive_kernel(const double* __restrict__ G, const double* __restrict__ X, int W, int nc,
-                                                                 double* __restrict__ C) {
-  int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (e >= (int64_t)W * nc) return;
-  const int i = (int)(e % W), j = (int)(e / W);
-  double s = 0.0;
-  for (int k = 0; k < W; ++k) s += G[i + (size_t)k * W] * X[k + (size_t)j * W];
-  C[i + (size_t)j * W] = s;
-}
-
+// C (W x nc) = G (W x W, symmetric) * X (W x nc): kp_symm_gemm.h (k-blocked, double-buffered 4x4x4-MFMA tiles; a
+// stage-everything kernel for the few columns of the last running values)
 static hipError_t symm_gemm(hipStream_t st, const double* G, const double* X, int W, int nc, double* C) {
-  const size_t lds = (size_t)((W + 3) & ~3) * SG_RS * 8;
-  if (lds <= 156 * 1024) {
-    static KpLdsCache lds_cache;
-    {
-      hipError_t e = kp_ensure_lds(lds_cache, (const void*)kp_symm_gemm_kernel, lds);
-      if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(kp_symm_gemm_kernel, dim3((W + 15) / 16, (nc + 31) / 32), dim3(512), lds, st, G, X, W, nc, C);
-  } else {
-    hipLaunchKernelGGL(kp_symm_gemm_naive_kernel, dim3((unsigned)(((int64_t)W * nc + 255) / 256)), dim3(256), 0, st, G, X, W, nc, C);
-  }
-  return hipGetLastError();
+  static const int variant = [] { const char* e = getenv("KP_SYMM_GEMM"); return e ? atoi(e) : 0; }();
+  return kp_symm_gemm2(st, G, X, W, nc, C, variant);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -155,6 +83,8 @@ struct LassoState {
   unsigned long long pol_res;        // bits of max |g + theta sign(k)| on the support (non-negative double)
   int done, notconv, passes, maxpasses, restarts;
   int pol_bad;                       // polish rejected: bit 0 sign flip / theta, bit 1 multiplier bound off the support, bit 2 column too dense / singular
+  int pol_nchg;                      // entries that enter or leave the candidate's support in the next active-set round
+  int pol_on;                        // this value takes part in the current active-set round
   unsigned counter;
   double part[LS_NBLK][3];
 };
@@ -481,6 +411,7 @@ __global__ __launch_bounds__(64) void kp_lasso_polish_cols_kernel(const double* 
   __shared__ double A[PL_CAP][PL_CAP + 1];
   __shared__ int idx[PL_CAP];
   LassoState* st = stv + blockIdx.y;
+  if (!st->pol_on) return;
   const int j = blockIdx.x, lane = threadIdx.x;
   const int64_t o = (int64_t)blockIdx.y * n + (int64_t)j * W;
   const double* k = Kc + o;
@@ -568,6 +499,7 @@ __global__ __launch_bounds__(256) void kp_lasso_polish_combine_kernel(const doub
   __shared__ double red[4][3];
   __shared__ double th_sh;
   LassoState* st = stv + blockIdx.y;
+  if (!st->pol_on) return;
   const int64_t o = (int64_t)blockIdx.y * n;
   const double* pv = pab + (int64_t)blockIdx.y * ncols * 2;
   double sa = 0.0, sb = 0.0, z = 0.0;
@@ -593,26 +525,41 @@ __global__ __launch_bounds__(256) void kp_lasso_polish_combine_kernel(const doub
   if (any_flip && (threadIdx.x & 63) == 0) atomicOr(&st->pol_bad, 1);
 }
 
-// optimality of the candidate on the FULL problem: g = G Kh - C; off the support |g| <= theta, on it g + theta s = 0
+// optimality of the candidate on the FULL problem: g = G Kh - C; off the support |g| <= theta, on it g + theta s = 0.
+// Also writes the pattern of the NEXT active-set round (a primal-dual active-set step of the QP): entries of the support
+// whose candidate value lost the sign of the pattern leave it, entries off the support whose multiplier bound is violated
+// enter it with the sign that lowers the objective; pol_nchg counts both.  `pat` and `next` may be the same array.
 __global__ __launch_bounds__(256) void kp_lasso_polish_check_kernel(const double* __restrict__ GKh, const double* __restrict__ C,
-                                                                    const double* __restrict__ Kc, int64_t n,
-                                                                    LassoState* __restrict__ stv) {
+                                                                    const double* pat, const double* __restrict__ Kh, int64_t n,
+                                                                    LassoState* __restrict__ stv, double* next) {
   LassoState* st = stv + blockIdx.y;
+  if (!st->pol_on) return;
   const int64_t o = (int64_t)blockIdx.y * n;
   const double th = st->pol_theta;
   const double lim = th * (1.0 + 1e-9);
   double ron = 0.0;
-  int off_bad = 0;
+  int off_bad = 0, nchg = 0;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const double g = GKh[o + i] - C[i], kc = Kc[o + i];
-    if (kc != 0.0) ron = fmax(ron, fabs(g + (kc > 0.0 ? th : -th)));
-    else if (fabs(g) > lim) off_bad = 1;
+    const double g = GKh[o + i] - C[i], kc = pat[o + i];
+    double nx = kc;
+    if (kc != 0.0) {
+      ron = fmax(ron, fabs(g + (kc > 0.0 ? th : -th)));
+      if (!(Kh[o + i] * kc > 0.0)) { nx = 0.0; ++nchg; }
+    } else if (fabs(g) > lim) {
+      off_bad = 1;
+      nx = g > 0.0 ? -1.0 : 1.0;
+      ++nchg;
+    }
+    next[o + i] = nx;
   }
   ron = wave_max(ron);
   const int any_off = __any(off_bad);
+#pragma unroll
+  for (int q = 32; q > 0; q >>= 1) nchg += __shfl_xor(nchg, q, 64);
   if ((threadIdx.x & 63) == 0) {
     if (ron > 0.0) atomicMax(&st->pol_res, (unsigned long long)__double_as_longlong(ron));
     if (any_off) atomicOr(&st->pol_bad, 2);
+    if (nchg) atomicAdd(&st->pol_nchg, nchg);
   }
 }
 
@@ -621,7 +568,16 @@ __global__ void kp_lasso_ctl_kernel(LassoState* __restrict__ stv, int nb) {
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= nb) return;
   LassoState* st = stv + v;
-  st->notconv = 0; st->maxpasses = 0; st->pol_bad = 0; st->pol_res = 0ull;
+  st->notconv = 0; st->maxpasses = 0; st->pol_bad = 0; st->pol_res = 0ull; st->pol_nchg = 0; st->pol_on = 1;
+}
+
+// between the active-set rounds of one check: the values in `on` go on, their round statistics are cleared
+__global__ void kp_lasso_round_kernel(LassoState* __restrict__ stv, int nb, const int* __restrict__ on) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= nb) return;
+  LassoState* st = stv + v;
+  st->pol_on = on[v];
+  if (on[v]) { st->pol_bad = 0; st->pol_res = 0ull; st->pol_nchg = 0; }
 }
 
 __global__ __launch_bounds__(256) void kp_l1norm_kernel(const double* __restrict__ K, int64_t n, double* out) {
@@ -726,7 +682,7 @@ int kp_lasso_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, in
   auto hs = [&](int v) -> LassoState& { return *reinterpret_cast<LassoState*>(hbuf.data() + (size_t)v * sizeof(LassoState)); };
   for (int v = 0; v < nb; ++v) {
     LassoState& h = hs(v);
-    h.tk = 1.0; h.mom = 0.0; h.theta = 0.0; h.t = t[act[v]]; h.invL = 1.0 / prep->L; h.change = 1e300;
+    h.tk = 1.0; h.mom = 0.0; h.theta = 0.0; h.t = t[act[v]]; h.invL = 1.0 / prep->L; h.change = 1e300; h.pol_on = 1;
   }
   KP_HIP(ctx, hipMemcpyAsync(st, hbuf.data(), b_st, hipMemcpyHostToDevice, s));
   const int nblk = (int)std::min<int64_t>(LS_NBLK, (n + 255) / 256);
@@ -735,18 +691,25 @@ int kp_lasso_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, in
   int it = 0;
   static const int check_every = [] { const char* e = getenv("KP_LASSO_CHECK"); return e ? std::max(1, atoi(e)) : 10; }();
   static const bool polish = getenv("KP_LASSO_NO_POLISH") == nullptr;
+  static const int first_check = [] { const char* e = getenv("KP_LASSO_FIRST_CHECK"); return e ? std::max(1, atoi(e)) : check_every; }();
+  static const int as_rounds = [] { const char* e = getenv("KP_LASSO_ROUNDS"); return e ? std::max(0, atoi(e)) : 8; }();
+  const int as_cap = (int)std::max<int64_t>(64, n / 8);     // more exchanges than this: the iterate is not near the optimum yet
+  int* on_dev = (int*)((char*)xchg + b_xc);
   // Values that have their answer leave the batch: the running values occupy slots [0, nba) of every buffer (the last
   // running slot is moved into the hole), so the wide product and every grid shrink with the work that is left.
   int nba = nb;
   std::vector<int> slot_val(nb);
   for (int v = 0; v < nb; ++v) slot_val[v] = act[v];
+  static const bool trace = getenv("KP_LASSO_TRACE") != nullptr;
+  const auto t_start = std::chrono::steady_clock::now();
   while (it < max_iter && nba > 0) {
     const dim3 grid(nblk, nba);
     // workgroups per value of the fused projection: all of them resident at once, one per CU
     const int ncu = ctx->num_cu > 0 ? ctx->num_cu : 256;
     static const int wcap = [] { const char* e = getenv("KP_LASSO_WPV"); return e ? std::max(1, std::min(LP_MAXW, atoi(e))) : 32; }();
     const int wpv = std::max(1, std::min(wcap, ncu / nba));
-    for (int c = 0; c < check_every && it < max_iter; ++c, ++it) {
+    const int block_len = it == 0 ? first_check : check_every;
+    for (int c = 0; c < block_len && it < max_iter; ++c, ++it) {
       if (fused && nba <= ncu) {
         hipLaunchKernelGGL(kp_lasso_project_kernel, dim3(wpv, nba), dim3(LP_NT), 0, s, Kb[kc], Kb[ko], GKb[gc], GKb[go], C_dev, n, V, Kb[kn], st, xchg,
                            seq);
@@ -761,18 +724,103 @@ int kp_lasso_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, in
       std::swap(go, gc);
       KP_HIP(ctx, symm_gemm(s, prep->Gw, Kb[kc], W, nba * ncols, GKb[gc]));
     }
-    if (polish) {   // candidate from the current support / signs: Kh lands in the free "new" buffer
-      hipLaunchKernelGGL(kp_lasso_polish_cols_kernel, dim3(ncols, nba), dim3(64), 0, s, prep->Gw, C_dev, Kb[kc], W, ncols, n, st, Ah, Bh, pab);
-      hipLaunchKernelGGL(kp_lasso_polish_combine_kernel, grid, dim3(256), 0, s, Ah, Bh, Kb[kc], pab, ncols, n, Kb[kn], st);
+    // candidate from a support / sign pattern (round 0: the current iterate's): Kh lands in the free "new" buffer, the
+    // pattern of the next round in V (free between the iterations)
+    auto polish_round = [&](const double* pat) -> int {
+      const dim3 g2(nblk, nba);
+      hipLaunchKernelGGL(kp_lasso_polish_cols_kernel, dim3(ncols, nba), dim3(64), 0, s, prep->Gw, C_dev, pat, W, ncols, n, st, Ah, Bh, pab);
+      hipLaunchKernelGGL(kp_lasso_polish_combine_kernel, g2, dim3(256), 0, s, Ah, Bh, pat, pab, ncols, n, Kb[kn], st);
       KP_HIP(ctx, symm_gemm(s, prep->Gw, Kb[kn], W, nba * ncols, GKh));
-      hipLaunchKernelGGL(kp_lasso_polish_check_kernel, grid, dim3(256), 0, s, GKh, C_dev, Kb[kc], n, st);
+      hipLaunchKernelGGL(kp_lasso_polish_check_kernel, g2, dim3(256), 0, s, GKh, C_dev, pat, Kb[kn], n, st, V);
+      return KP_OK;
+    };
+    auto read_states = [&]() -> int {
+      KP_HIP(ctx, hipGetLastError());
+      KP_HIP(ctx, hipMemcpy2DAsync(hbuf.data(), sizeof(LassoState), st, sizeof(LassoState), head, nba, hipMemcpyDeviceToHost, s));
+      return KP_OK;
+    };
+    auto accepted = [&](const LassoState& h) {
+      const double pres = __builtin_bit_cast(double, h.pol_res);
+      return polish && h.pol_bad == 0 && h.pol_theta >= 0.0 && pres <= 1e-9 * std::max(h.pol_theta, 1e-300);
+    };
+    std::vector<int> last_chg(nba, 1 << 29);
+    // values that have their answer leave the batch (the last running slot moves into the hole: iterates, products, the
+    // pattern of the active-set rounds and the state)
+    auto retire = [&]() -> int {
+      for (int v = nba - 1; v >= 0; --v) {             // downwards: the slot moved into a hole has been examined already
+        const LassoState& h = hs(v);
+        const double pres = __builtin_bit_cast(double, h.pol_res);
+        const bool pol_ok = accepted(h);
+        const bool conv = h.notconv == 0 && h.change <= tol * std::max(1.0, h.kmax);
+        if (trace && nba <= 4)
+          fprintf(stderr, "   value %d: polish flags %d theta %.6e residual %.3e exchanges %d | fista theta %.6e change %.3e kmax %.3e passes %d restarts %d%s\n",
+                  slot_val[v], h.pol_bad, h.pol_theta, pres, h.pol_nchg, h.theta, h.change, h.kmax, h.maxpasses, h.restarts,
+                  pol_ok ? " -> polished" : conv ? " -> converged" : "");
+        if (!(pol_ok || conv)) continue;
+        KP_HIP(ctx, hipMemcpyAsync(K_dev[slot_val[v]], (pol_ok ? Kb[kn] : Kb[kc]) + (size_t)v * n, bK, hipMemcpyDeviceToDevice, s));
+        if (iters) iters[slot_val[v]] = it;
+        const int last = nba - 1;
+        if (v != last) {
+          double* mv[5] = {Kb[ko], Kb[kc], GKb[go], GKb[gc], V};
+          for (double* bsrc : mv) KP_HIP(ctx, hipMemcpyAsync(bsrc + (size_t)v * n, bsrc + (size_t)last * n, bK, hipMemcpyDeviceToDevice, s));
+          KP_HIP(ctx, hipMemcpyAsync(st + v, st + last, head, hipMemcpyDeviceToDevice, s));
+          memcpy(&hs(v), &hs(last), head);
+          slot_val[v] = slot_val[last];
+          last_chg[v] = last_chg[last];
+        }
+        --nba;
+      }
+      return KP_OK;
+    };
+    if (polish) {
+      const int rc = polish_round(Kb[kc]);
+      if (rc) return rc;
     }
-    KP_HIP(ctx, hipGetLastError());
-    KP_HIP(ctx, hipMemcpy2DAsync(hbuf.data(), sizeof(LassoState), st, sizeof(LassoState), head, nba, hipMemcpyDeviceToHost, s));
+    {
+      const int rc = read_states();
+      if (rc) return rc;
+    }
     std::vector<unsigned> touts(nba, 0u);
     if (fused)
       KP_HIP(ctx, hipMemcpy2DAsync(touts.data(), sizeof(unsigned), &xchg[0].timeout, sizeof(LassoXchg), sizeof(unsigned), nba, hipMemcpyDeviceToHost, s));
     KP_HIP(ctx, hipStreamSynchronize(s));
+    if (trace)
+      fprintf(stderr, "kp_lasso: iteration %d, %d values running, %.3f ms since start\n", it, nba,
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
+    {
+      const int rc = retire();
+      if (rc) return rc;
+    }
+    // Active-set rounds: a candidate that fails only because a few entries have the wrong membership (sign lost on the
+    // support, multiplier bound violated off it) is a few exchanges away from the optimum long before the iteration gets
+    // there; the check kernel has left the exchanged pattern in V.  Rounds go on while the exchanges shrink.
+    if (polish) {
+      std::vector<int> on(nba);
+      for (int r = 1; r <= as_rounds && nba > 0; ++r) {
+        int n_on = 0;
+        for (int v = 0; v < nba; ++v) {
+          const LassoState& h = hs(v);
+          on[v] = !(h.pol_bad & 4) && h.pol_nchg > 0 && h.pol_nchg <= as_cap && h.pol_nchg < 2 * last_chg[v] && h.pol_theta > 0.0;
+          last_chg[v] = h.pol_nchg;
+          n_on += on[v];
+        }
+        if (trace) {
+          fprintf(stderr, "   round %d: %d of %d values go on; exchanges", r, n_on, nba);
+          for (int v = 0; v < nba && v < 48; ++v) fprintf(stderr, " %d", hs(v).pol_nchg);
+          fprintf(stderr, "\n");
+        }
+        if (!n_on) break;
+        KP_HIP(ctx, hipMemcpyAsync(on_dev, on.data(), (size_t)nba * 4, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(kp_lasso_round_kernel, dim3((nba + 63) / 64), dim3(64), 0, s, st, nba, on_dev);
+        int rc = polish_round(V);
+        if (rc) return rc;
+        rc = read_states();
+        if (rc) return rc;
+        KP_HIP(ctx, hipStreamSynchronize(s));
+        rc = retire();
+        if (rc) return rc;
+      }
+    }
     for (unsigned tq : touts)
       if (tq) {                                      // an exchange of the one-launch projection timed out (workgroups not co-resident):
         fused = false;                               // continue with the multi-launch kernels, which need no residency
@@ -781,27 +829,9 @@ int kp_lasso_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, in
       }
     bool all_exact = true;
     int maxp = 0;
-    for (int v = nba - 1; v >= 0; --v) {             // downwards: the slot moved into a hole has been examined already
-      const LassoState& h = hs(v);
-      const double pres = __builtin_bit_cast(double, h.pol_res);
-      const bool pol_ok = polish && h.pol_bad == 0 && h.pol_theta >= 0.0 && pres <= 1e-9 * std::max(h.pol_theta, 1e-300);
-      const bool exact = h.notconv == 0;
-      const bool conv = exact && h.change <= tol * std::max(1.0, h.kmax);
-      if (!(pol_ok || conv)) {
-        all_exact &= exact;
-        maxp = std::max(maxp, h.maxpasses);
-        continue;
-      }
-      KP_HIP(ctx, hipMemcpyAsync(K_dev[slot_val[v]], (pol_ok ? Kb[kn] : Kb[kc]) + (size_t)v * n, bK, hipMemcpyDeviceToDevice, s));
-      if (iters) iters[slot_val[v]] = it;
-      const int last = nba - 1;
-      if (v != last) {
-        double* mv[4] = {Kb[ko], Kb[kc], GKb[go], GKb[gc]};
-        for (double* bsrc : mv) KP_HIP(ctx, hipMemcpyAsync(bsrc + (size_t)v * n, bsrc + (size_t)last * n, bK, hipMemcpyDeviceToDevice, s));
-        KP_HIP(ctx, hipMemcpyAsync(st + v, st + last, head, hipMemcpyDeviceToDevice, s));
-        slot_val[v] = slot_val[last];
-      }
-      --nba;
+    for (int v = 0; v < nba; ++v) {
+      all_exact &= hs(v).notconv == 0;
+      maxp = std::max(maxp, hs(v).maxpasses);
     }
     if (nba == 0) break;
     // adapt the number of Newton passes to what the values still running needed in the last block

@@ -297,6 +297,35 @@ def test_async_fit_pipeline_matches_synchronous_result(ctx):
     ctx.synchronize()                            # the sticky flag was cleared
 
 
+def test_queued_fits_survive_a_wider_dictionary_arriving_without_a_synchronise(ctx):
+    """Deferred, batched solves: the [G | C] ring holds queued Gram pairs that are not solved yet.  A fit with a much wider
+    dictionary (ring buffer has to grow) issued WITHOUT synchronising must first drain the queue - not reallocate the ring
+    under it: the three narrow fits' results of the closed batch are lost by design (new batch), but the wide fit and a
+    following narrow batch must be right and no spurious NOT_SPD may be reported."""
+    small = make_basis(ctx, ko.build_dictionary("linear", 6, 3, ["poly"], [1]))          # W = 10
+    wide = make_basis(ctx, ko.build_dictionary("bilinear", 6, 3, ["poly"], [3]))         # W = 336 > 6 x 10
+    p = synth_pairs(6000, seed=41)
+    snaps = kra.Snapshots(ctx, p["alpha"], p["beta"], p["u"])
+    Ks_ref = kra.fit(ctx, small, snaps)[0]
+    Kw_ref = kra.fit(ctx, wide, snaps)[0]
+    ctx2 = kra.Context(0)                       # fresh context: its ring starts at the narrow size
+    try:
+        small2 = make_basis(ctx2, ko.build_dictionary("linear", 6, 3, ["poly"], [1]))
+        wide2 = make_basis(ctx2, ko.build_dictionary("bilinear", 6, 3, ["poly"], [3]))
+        snaps2 = kra.Snapshots(ctx2, p["alpha"], p["beta"], p["u"])
+        for _ in range(3):
+            kra.fit(ctx2, small2, snaps2, fetch=False)
+        kra.fit(ctx2, wide2, snaps2, fetch=False)          # no synchronise in between
+        assert np.abs(ctx2.fit_result(0, wide2.W) - Kw_ref).max() <= 1e-10 * np.abs(Kw_ref).max()
+        for _ in range(3):
+            kra.fit(ctx2, small2, snaps2, fetch=False)
+        ctx2.synchronize()                                  # would raise NOT_SPD if a queued pair had been clobbered
+        for i in range(3):
+            assert np.abs(ctx2.fit_result(i, small2.W) - Ks_ref).max() <= 1e-10 * np.abs(Ks_ref).max()
+    finally:
+        ctx2.close()
+
+
 def test_snapshot_objects_refilled_from_the_host_while_fits_are_in_flight(ctx):
     """kp_snapshots_update: new pairs into an existing object through the pinned staging ring and the copy stream.  Two
     objects filled alternately while the fits of the other one are queued: every K equals the fit of a freshly uploaded
