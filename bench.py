@@ -183,13 +183,24 @@ def bench_lasso(ctx, comm, kra, basis, snaps, n_values=64):
     from koopman_realizations_amd import sweep, comm as kc
     W = basis.W
     vals = list(np.geomspace(1e-2, 1e2, n_values))
-    fit_many = lambda ls: kra.fit(ctx, basis, snaps, ls)
+    fit_dev = lambda ls: kra.fit(ctx, basis, snaps, ls, fetch=False)      # the shard's K stack stays in HBM
     mine = sweep.shard_units(n_values, comm.rank, comm.world)
-    kra.fit(ctx, basis, snaps, [vals[i] for i in mine[:1]])               # warm-up (allocations, RCCL channels)
-    sweep.gather_matrices({i: np.zeros((W, W)) for i in mine}, n_values, (W, W), comm)
+    per = (n_values + comm.world - 1) // comm.world
+    kra.fit(ctx, basis, snaps, [vals[i] for i in mine[:1]], fetch=False)  # warm-up (allocations, RCCL channels)
+    sweep.lasso_sweep_device(ctx, fit_dev, vals, W, comm)                 # ... and every buffer at its final size
     comm.barrier()
     t0 = time.perf_counter()
-    Ks = sweep.lasso_sweep(None, vals, comm, shape=(W, W), fit_many=fit_many)
+    t_g = [0.0]
+    _gather = kc.all_gather_fits
+
+    def timed_gather(*a, **k):
+        t1 = time.perf_counter(); r = _gather(*a, **k); t_g[0] = time.perf_counter() - t1
+        return r
+    kc.all_gather_fits = timed_gather
+    try:
+        Ks = sweep.lasso_sweep_device(ctx, fit_dev, vals, W, comm)
+    finally:
+        kc.all_gather_fits = _gather
     comm.barrier()
     dt = kc.max_over_ranks(comm, time.perf_counter() - t0)
     l1 = np.array([np.abs(K).sum() for K in Ks])
@@ -198,7 +209,8 @@ def bench_lasso(ctx, comm, kra, basis, snaps, n_values=64):
     return {"values": n_values, "seconds": dt, "values_per_s": n_values / dt, "ms_per_value": dt / n_values * 1e3, "W": W,
             "n_gpus": comm.world, "active_constraints": active,
             "budget_met": bool(np.all(l1 <= t * (1 + 1e-9) + 1e-12)),
-            "device_ms_rank0": ctx.timer(3),
+            "device_ms_rank0": ctx.timer(3), "gather_ms_rank0": t_g[0] * 1e3,
+            "gather": f"K stack of the shard gathered device to device ({comm.kind}), one DMA of {n_values * W * W * 8 / 1e6:.0f} MB into a page-locked block",
             "workload": "64 lasso values (t/N log-spaced 1e-2..1e2) on the bilinear poly-3 fit, 1e5 pairs, sharded round-robin, "
                         "K stack gathered (BASELINE configs[3])"}
 

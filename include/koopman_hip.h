@@ -335,6 +335,11 @@ int kp_qp_solve(kp_ctx* ctx, const double* H, const double* f, const double* A, 
  *   kp_comm_allreduce_sum  host vector, in place (barrier, counters);
  *   kp_comm_allgather_fit  K of fit `index` (kp_fit_get_K numbering) of every rank, device to device, one copy out:
  *                       K_all = world matrices W x W;
+ *   kp_comm_allgather_fits  the K STACK of a shard: fits first .. first + count - 1 of every rank (the lasso grid of
+ *                       train_models, Ksysid.m:1372-1387, values dealt round-robin: rank r holds values r, r + world, ...),
+ *                       ONE ncclAllGather of count W^2 doubles straight from the result buffer and one copy out (give it a
+ *                       kp_host_alloc block: direct DMA); K_all = world x count matrices W x W, rank-major.  A rank whose
+ *                       shard is shorter than `count` contributes unspecified padding slots;
  *   kp_fit_sharded / kp_fit_gram_sharded  kp_fit / kp_fit_gram on this rank's shard of the snapshot pairs with the
  *                       all-reduce of [G | C] (2 W^2 doubles) between the Gram kernel and the solve: every rank gets the
  *                       K of the whole data set. */
@@ -345,6 +350,7 @@ int kp_comm_info(const kp_ctx* ctx, int* rank, int* world);
 int kp_comm_allgather(kp_ctx* ctx, const void* send, int64_t bytes, void* recv);
 int kp_comm_allreduce_sum(kp_ctx* ctx, double* inout, int64_t count);
 int kp_comm_allgather_fit(kp_ctx* ctx, int index, int W, double* K_all);
+int kp_comm_allgather_fits(kp_ctx* ctx, int first, int count, int W, double* K_all);
 int kp_fit_sharded(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* snaps_local, const double* lasso,
                    int n_lasso, double* K_out);
 int kp_fit_gram_sharded(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* snaps_local, double* G, double* C);

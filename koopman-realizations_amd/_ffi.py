@@ -90,6 +90,7 @@ SIGNATURES = {
     "kp_comm_allgather": (C.c_int, [vp, vp, C.c_int64, vp]),
     "kp_comm_allreduce_sum": (C.c_int, [vp, c_dp, C.c_int64]),
     "kp_comm_allgather_fit": (C.c_int, [vp, C.c_int, C.c_int, c_dp]),
+    "kp_comm_allgather_fits": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, c_dp]),
     "kp_fit_sharded": (C.c_int, [vp, vp, vp, c_dp, C.c_int, c_dp]),
     "kp_fit_gram_sharded": (C.c_int, [vp, vp, vp, c_dp, c_dp]),
 }

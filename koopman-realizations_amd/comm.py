@@ -92,6 +92,15 @@ class RcclComm:
         raw = recv.raw
         return [raw[r * n:(r + 1) * n] for r in range(self.world)]
 
+    def all_gather_array_direct(self, a):
+        """Equally shaped f64 arrays without intermediate byte strings: the library reads `a` and writes the (world,) +
+        a.shape result where numpy holds them."""
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        out = np.empty((self.world,) + a.shape)
+        F.check(F.lib().kp_comm_allgather(self.ctx.handle, a.ctypes.data_as(C.c_void_p), a.nbytes, out.ctypes.data_as(C.c_void_p)),
+                self.ctx.handle)
+        return out
+
     def all_reduce_sum(self, a):
         a = np.ascontiguousarray(a, dtype=np.float64).copy()
         F.check(F.lib().kp_comm_allreduce_sum(self.ctx.handle, F.dptr(a), a.size), self.ctx.handle)
@@ -99,6 +108,13 @@ class RcclComm:
 
     def barrier(self):
         self.all_reduce_sum(np.zeros(1))
+
+    def all_gather_fits(self, first: int, count: int, W: int):
+        """The K stacks (fits first .. first + count - 1, kp_fit_get_K numbering) of every rank: ONE RCCL all-gather from the
+        device result buffer and one DMA into a page-locked block of the context; (world, count, W, W), blocks column-major."""
+        out = self.ctx.host_array("Kgather", (self.world, int(count), int(W), int(W)))
+        F.check(F.lib().kp_comm_allgather_fits(self.ctx.handle, int(first), int(count), int(W), F.dptr(out)), self.ctx.handle)
+        return out
 
     def all_gather_fit(self, index: int, W: int):
         """K of fit `index` (kp_fit_get_K numbering) of every rank, gathered device to device: (world, W, W)."""
@@ -159,8 +175,30 @@ class FileComm:
 def all_gather_array(comm, a):
     """Equally shaped f64 arrays: returns (world,) + a.shape."""
     a = np.ascontiguousarray(a, dtype=np.float64)
+    direct = getattr(comm, "all_gather_array_direct", None)
+    if direct is not None:
+        return direct(a)
     parts = comm.all_gather_bytes(a.tobytes())
     return np.stack([np.frombuffer(p, dtype=np.float64).reshape(a.shape) for p in parts])
+
+
+def all_gather_fits(comm, ctx, first: int, count: int, W: int, have: int | None = None):
+    """K stacks of a sharded sweep, (world, count, W, W) with column-major blocks: fits first .. first + count - 1 of every
+    rank's device result buffer (`have` = how many of them this rank really computed; the rest is padding).  RCCL: one
+    device-to-device all-gather + one DMA (kp_comm_allgather_fits); one rank: the DMA alone; any other `comm` (file / gloo
+    stand-ins): the rank's stack through a page-locked block, then the stand-in's array gather."""
+    fn = getattr(comm, "all_gather_fits", None)
+    if fn is not None:
+        return fn(first, count, W)
+    have = count if have is None else min(int(have), int(count))
+    if comm is None or comm.world == 1:
+        out = ctx.host_array("Kgather", (1, int(count), int(W), int(W)))
+        F.check(F.lib().kp_comm_allgather_fits(ctx.handle, int(first), int(count), int(W), F.dptr(out)), ctx.handle)
+        return out
+    mine = np.zeros((int(count), W, W))
+    if have:
+        mine[:have] = ctx.fit_results(first, have, W)
+    return all_gather_array(comm, mine)
 
 
 def all_gather_object(comm, obj):

@@ -5,6 +5,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
@@ -183,6 +184,64 @@ extern "C" int kp_comm_allgather_fit(kp_ctx* ctx, int index, int W, double* K_al
   hipStream_t s = ctx->stream;
   KP_NCCL(ctx, rccl().AllGather(src, ws, cnt, ncclDouble, ctx->comm->comm, s));
   KP_HIP(ctx, hipMemcpyAsync(K_all, ws, cnt * 8 * (size_t)world, hipMemcpyDeviceToHost, s));
+  KP_HIP(ctx, hipStreamSynchronize(s));
+  return KP_OK;
+}
+
+// The K stack of this rank's shard of a sweep - fits first .. first + count - 1 (kp_fit_get_K numbering: the values of the
+// last synchronous kp_fit, or the fits of the last asynchronous batch) - of EVERY rank: one ncclAllGather of count W^2
+// doubles straight from the result buffer, one copy out.  K_all = world x count matrices, rank-major.  Ranks whose shard is
+// shorter than `count` (ragged round-robin deal) contribute padding slots of unspecified content.
+extern "C" int kp_comm_allgather_fits(kp_ctx* ctx, int first, int count, int W, double* K_all) {
+  if (!ctx || !K_all || first < 0 || count < 1 || W < 1) return ctx ? ctx->fail(KP_ERR_ARG, "kp_comm_allgather_fits: bad argument") : KP_ERR_ARG;
+  KP_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = kp_synchronize(ctx);
+  if (rc) return rc;
+  const size_t cnt = (size_t)W * W;
+  const int world = ctx->comm ? ctx->comm->world : 1;
+  hipStream_t s = ctx->stream;
+  const bool have = ctx->Kres && W == ctx->Kres_W;          // a rank with an EMPTY shard has no results at all: all padding
+  if (!have && world == 1) return ctx->fail(KP_ERR_ARG, "kp_comm_allgather_fits: no results of that width");
+  // contiguous source of `count` slots: the result buffer itself when the range is inside it (and does not wrap in the
+  // ring), else a staging copy of what there is
+  const double* src = nullptr;
+  int avail = 0;                                             // valid fits from `first` on
+  if (have) {
+    if (ctx->kres_is_ring) {
+      if (first + count > ctx->async_count && world == 1) return ctx->fail(KP_ERR_ARG, "kp_comm_allgather_fits: range not in the result ring");
+      if (first < ctx->async_count - ctx->kring_cap) return ctx->fail(KP_ERR_ARG, "kp_comm_allgather_fits: range no longer in the result ring");
+      avail = std::max(0, std::min(count, ctx->async_count - first));
+    } else {
+      if (first + count > ctx->Kres_n && world == 1) return ctx->fail(KP_ERR_ARG, "kp_comm_allgather_fits: index out of range");
+      avail = std::max(0, std::min(count, ctx->Kres_n - first));
+    }
+  }
+  const int slot0 = have && ctx->kres_is_ring ? first % ctx->kring_cap : first;
+  const bool wraps = have && ctx->kres_is_ring && slot0 + avail > ctx->kring_cap;
+  const bool inside = have && !wraps && avail == count;
+  double* ws = nullptr;
+  if (world > 1 || !inside) {
+    ws = (double*)ctx->workspace(8, cnt * 8 * (size_t)count * (size_t)(world + 1));
+    if (!ws) return ctx->fail(KP_ERR_HIP, "kp_comm_allgather_fits: out of device memory");
+  }
+  if (inside) {
+    src = ctx->Kres + (size_t)slot0 * cnt;
+  } else {
+    for (int i = 0; i < avail; ++i) {
+      const size_t sl = ctx->kres_is_ring ? (size_t)((first + i) % ctx->kring_cap) : (size_t)(first + i);
+      KP_HIP(ctx, hipMemcpyAsync(ws + (size_t)i * cnt, ctx->Kres + sl * cnt, cnt * 8, hipMemcpyDeviceToDevice, s));
+    }
+    if (avail < count) KP_HIP(ctx, hipMemsetAsync(ws + (size_t)avail * cnt, 0, (size_t)(count - avail) * cnt * 8, s));
+    src = ws;
+  }
+  if (world == 1) {
+    KP_HIP(ctx, hipMemcpyAsync(K_all, src, cnt * 8 * (size_t)count, hipMemcpyDeviceToHost, s));
+    KP_HIP(ctx, hipStreamSynchronize(s));
+    return KP_OK;
+  }
+  double* all = ws + (size_t)count * cnt;
+  KP_NCCL(ctx, rccl().AllGather(src, all, cnt * (size_t)count, ncclDouble, ctx->comm->comm, s));
+  KP_HIP(ctx, hipMemcpyAsync(K_all, all, cnt * 8 * (size_t)count * (size_t)world, hipMemcpyDeviceToHost, s));
   KP_HIP(ctx, hipStreamSynchronize(s));
   return KP_OK;
 }

@@ -79,3 +79,35 @@ def test_lasso_without_polish_agrees(ctx, config3, monkeypatch):
     G, C, l1 = config3["G"], config3["C"], config3["l1"]
     Kp, itp = ctx.fit_lasso_batch(G, C, [0.3 * l1])
     assert ko.lasso_kkt_residual(G, C, Kp[0], 0.3 * l1) <= 1e-10 * np.abs(C).max()     # polished: optimum to rounding
+
+
+def test_lasso_grid_through_the_device_resident_gather(ctx, config3):
+    """sweep.lasso_sweep_device: the shard's K stack stays in the device result buffer (kp_fit with K_out = NULL), one
+    kp_comm_allgather_fits brings it to a page-locked block; same K as the fetched path, in grid order, LS values included."""
+    from koopman_realizations_amd import sweep, comm as kc
+    b, snaps, l1, N = config3["basis"], config3["snaps"], config3["l1"], config3["N"]
+    las = [np.inf, 0.6 * l1 / N, 0.05 * l1 / N, 1e4, 0.2 * l1 / N]
+    ref = kra.fit(ctx, b, snaps, las)
+    got = sweep.lasso_sweep_device(ctx, lambda ls: kra.fit(ctx, b, snaps, ls, fetch=False), las, b.W, kc.LocalComm())
+    assert len(got) == len(las)
+    for Kr, Kg in zip(ref, got):
+        assert np.array_equal(Kr, Kg)
+    # a sub-range and the error paths of the entry point
+    part = kc.all_gather_fits(kc.LocalComm(), ctx, 1, 2, b.W)
+    assert np.array_equal(part[0, 0].T, ref[1]) and np.array_equal(part[0, 1].T, ref[2])
+    with pytest.raises(kra.KoopmanHipError):
+        kc.all_gather_fits(kc.LocalComm(), ctx, 3, 5, b.W)          # past the last value
+
+
+def test_active_set_rounds_end_sparse_values_early_and_exactly(ctx, config3):
+    """The polish's active-set rounds (exchange the entries whose membership is wrong, re-solve) reach the optimum of
+    sparse values within the first check blocks; the answer satisfies the optimality conditions to rounding and equals the
+    plain iteration's optimum."""
+    G, C, l1 = config3["G"], config3["C"], config3["l1"]
+    fr = np.array([0.5, 0.2, 0.05, 0.02])
+    Ks, iters = ctx.fit_lasso_batch(G, C, fr * l1)
+    cmax = np.abs(C).max()
+    assert max(iters) <= 60, iters
+    for f, K in zip(fr, Ks):
+        assert ko.lasso_kkt_residual(G, C, K, f * l1) <= 1e-12 * cmax
+        assert abs(np.abs(K).sum() - f * l1) <= 1e-12 * f * l1

@@ -58,6 +58,21 @@ def _worker(rank, world, port, q):
         Ko = sweep.lasso_sweep(fit_one, lassos, comm)           # object gather path (ragged pickles)
         Km = sweep.lasso_sweep(None, lassos, comm, shape=(3, 3), fit_many=lambda ls: [fit_one(l) for l in ls])
         assert all((a == b).all() for a, b in zip(Ks, Km))
+        # device-resident K stack (sweep.lasso_sweep_device): the rank's shard stays in the "device" result buffer (a stand-in
+        # context here), ONE gather of per-rank stacks with a padding slot on the short rank, column-major blocks
+        class FakeCtx:
+            def __init__(self):
+                self.stack = None
+
+            def fit_results(self, first, count, W):
+                return self.stack[first:first + count]
+        fctx = FakeCtx()
+
+        def fit_device(ls):
+            # each block column-major, as the device result buffer holds it
+            fctx.stack = np.ascontiguousarray(np.transpose(np.stack([np.full((3, 3), l) + np.arange(9.0).reshape(3, 3) for l in ls]), (0, 2, 1)))
+        Kd = sweep.lasso_sweep_device(fctx, fit_device, lassos, 3, comm)
+        assert len(Kd) == 7 and all(np.array_equal(k, np.full((3, 3), l) + np.arange(9.0).reshape(3, 3)) for k, l in zip(Kd, lassos))
         systems = list(range(5))
 
         def eval_fn(sysid):
