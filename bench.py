@@ -209,7 +209,7 @@ def bench_lasso(ctx, comm, kra, basis, snaps, n_values=64):
     return {"values": n_values, "seconds": dt, "values_per_s": n_values / dt, "ms_per_value": dt / n_values * 1e3, "W": W,
             "n_gpus": comm.world, "active_constraints": active,
             "budget_met": bool(np.all(l1 <= t * (1 + 1e-9) + 1e-12)),
-            "device_ms_rank0": ctx.timer(3), "gather_ms_rank0": t_g[0] * 1e3,
+            "device_ms_rank0": ctx.timer(3), "gather_ms_rank0": t_g[0] * 1e3, "_gemm": (ctx.timer(8), ctx.timer(9)) if ctx.timer(9) > 0 else None,
             "gather": f"K stack of the shard gathered device to device ({comm.kind}), one DMA of {n_values * W * W * 8 / 1e6:.0f} MB into a page-locked block",
             "workload": "64 lasso values (t/N log-spaced 1e-2..1e2) on the bilinear poly-3 fit, 1e5 pairs, sharded round-robin, "
                         "K stack gathered (BASELINE configs[3])"}
@@ -265,6 +265,7 @@ def bench_rand_sweep(ctx, comm, kra, chunks, n_systems):
     return {"systems": n_systems, "distinct_systems": True, "seconds": dt, "systems_per_s": n_systems / dt, "n_gpus": comm.world,
             "rank0_compute_seconds": t_local, "rank0_host_gather_seconds": t_stack, "rank0_upload_and_device_seconds": t_local - t_stack,
             "fits_per_system": int(sum(v.shape[0] for v in tab.values())) if tab else 23,
+            "_gram": dict(ctx.__dict__.get("_sweep_gram", {})),
             "mean_linear_error_deg1_deg13": [float(mean[0]), float(mean[-1])],
             "workload": "evaluate_rand_models.m on 1024 generated 1-D random systems (Rsys restatement), 23 fits + validation "
                         "rollouts each, 128-system chunks round-robin over the ranks (BASELINE configs[4])"}
@@ -300,34 +301,56 @@ def bench_arm_closed_loop(ctx, kra):
                         "3-link data, model as plant (BASELINE configs[2])"}
 
 
+def roofline_block(kernel, exec_flop, dense_flop, ms, note=None, **extra):
+    """One kernel's line: `achieved` / `frac` count what the kernel EXECUTES on the matrix pipe (MFMA instructions x 512 flop,
+    padding included) - never above 1; the dense-equivalent figure (SURVEY 8(d)'s per-unit count of the products the reference
+    forms) stands beside it."""
+    t = ms * 1e-3
+    out = {"kernel": kernel, "bound": "mfma", "ms": ms, "achieved": exec_flop / t / 1e12, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s",
+           "frac": exec_flop / t / 1e12 / PEAK_F64_MFMA_TFLOPS, "executed_flop_per_launch": exec_flop,
+           "dense_equivalent_flop_per_launch": dense_flop, "dense_equivalent_achieved": dense_flop / t / 1e12,
+           "dense_equivalent_frac": dense_flop / t / 1e12 / PEAK_F64_MFMA_TFLOPS}
+    if note:
+        out["note"] = note
+    out.update(extra)
+    return out
+
+
 def bench_width_points(ctx, kra, Ns):
-    """SURVEY 8(d)'s other two fit shapes next to W = 336: W = 200 (N = 50: the first 49 poly-3 rows + constant) and W = 136
-    (N = 34: econ lift through a pcs matrix, the shape of example_sysid.m with dim_red).  Kernel time of the fused
-    lift+Gram launch and its algorithmic rate F(W) Ns / t."""
+    """SURVEY 8(d)'s other fit shapes next to W = 336 - W = 200 (N = 50: the first 49 poly-3 rows + constant) and W = 136
+    (N = 34: econ lift through a pcs matrix, the shape of example_sysid.m with dim_red) - and two non-polynomial
+    dictionaries (def_fourierLift Ksysid.m:694-731, def_gaussianLift :790-817).  Kernel time of the fused lift+Gram launch
+    measured like the headline's: mean HIP-event duration over a queue of pipelined fits (a lone synchronous launch after an
+    idle stretch runs at a lower clock, profiles/r02_gram_launch_durations.txt)."""
     out = {}
     a, b, u = synth_pairs(Ns, seed=5)
     snaps = kra.Snapshots(ctx, a, b, u)
+    a3, b3, u3 = synth_pairs(Ns, 3, 3, seed=6)
+    snaps3 = kra.Snapshots(ctx, a3, b3, u3)
     tab = kra.poly_exponent_table(6, 3)
     rng = np.random.default_rng(3)
     pcs = np.linalg.qr(rng.standard_normal((84, 27)))[0]
-    shapes = [("W200", kra.Basis(ctx, "bilinear", 6, 3, [("poly", tab[6:49])])),
-              ("W136_pcs", kra.Basis(ctx, "bilinear", 6, 3, [("poly", tab[6:])], pcs))]
+    centres = rng.uniform(-1, 1, (6, 20))
+    shapes = [("W200", kra.Basis(ctx, "bilinear", 6, 3, [("poly", tab[6:49])]), snaps, "kp_gram3_kernel<6,3,false>"),
+              ("W136_pcs", kra.Basis(ctx, "bilinear", 6, 3, [("poly", tab[6:])], pcs), snaps, "kp_gram3_kernel<.,3,true>"),
+              ("fourier1_nzeta3", kra.Basis(ctx, "bilinear", 3, 3, [("fourier", 1)]), snaps3, None),
+              ("gaussian20", kra.Basis(ctx, "bilinear", 6, 3, [("gaussian", centres)]), snaps, None)]
     if os.environ.get("KP_BENCH_MORE_WIDTHS"):    # same width without the projection: what the econ lift costs
-        shapes.append(("W136_plain", kra.Basis(ctx, "bilinear", 6, 3, [("poly", tab[6:33])])))
-    for name, basis in shapes:
+        shapes.append(("W136_plain", kra.Basis(ctx, "bilinear", 6, 3, [("poly", tab[6:33])]), snaps, "kp_gram3_kernel"))
+    for name, basis, sn, kern in shapes:
         W = basis.W
-        for _ in range(3):
-            kra.fit_gram(ctx, basis, snaps, fetch=False)
-        g = []
-        for _ in range(10):
-            kra.fit_gram(ctx, basis, snaps, fetch=False); g.append(ctx.timer(0))
-        ms = float(np.median(g))
+        for _ in range(48):                        # untimed queue: kernel variants loaded, clock up
+            kra.fit(ctx, basis, sn, fetch=False)
+        ctx.synchronize()
+        for _ in range(64):
+            kra.fit(ctx, basis, sn, fetch=False)
+        ctx.synchronize()
+        ms, n_l, ex = ctx.timer(0), int(ctx.timer(7)), ctx.timer(10)
         F_ = W * (W + 1) + 2.0 * W * W
-        out[name] = {"W": W, "N": basis.N, "gram_ms": ms, "algorithmic_TFLOPs": F_ * Ns / (ms * 1e-3) / 1e12,
-                     "frac_of_f64_mfma_peak": F_ * Ns / (ms * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS,
-                     "pairs_per_s_gram_only": Ns / (ms * 1e-3)}
+        out[name] = {"W": W, "N": basis.N, "gram_ms": ms, "launches_averaged": n_l, "pairs_per_s_gram_only": Ns / (ms * 1e-3),
+                     "roofline": roofline_block(kern or "fused lift+Gram (see DESIGN 3.1 for the variant)", ex * Ns, F_ * Ns, ms)}
         basis.close()
-    snaps.close()
+    snaps.close(); snaps3.close()
     return out
 
 
@@ -434,6 +457,7 @@ def main():
     dt = kc.max_over_ranks(comm, time.perf_counter() - t0)
     # timer 0 = mean HIP-event duration of the last min(steps, 64) Gram launches of the timed region (timer 7 = count)
     g_ms, red_ms, solve_ms, n_timed = ctx.timer(0), ctx.timer(6), ctx.timer(1), int(ctx.timer(7))
+    exec_pair_head = ctx.timer(10)          # flop per pair this kernel executes on the matrix pipe (padding included)
     # every K of the timed region is retrievable and they all solve the same system
     K_first, K_last = ctx.fit_result(0, W), ctx.fit_result(args.steps - 1, W)
     k_spread = float(np.abs(K_first - K_last).max())
@@ -487,15 +511,14 @@ def main():
         sweep_res = bench_rand_sweep(ctx, comm, kra, chunks, n_chunks * RAND_CHUNK)
 
     if rank == 0:
-        flops_pair = W * (W + 1) + 2.0 * W * W                 # F(336) = 339 024
-        achieved = flops_pair * Ns / (g_ms * 1e-3) / 1e12
-        # what the Kronecker kernel executes: (m+1)(m+2)/2 weights x (symmetric half in 4-column groups + full cross block)
-        Np4 = (basis.N + 3) // 4 * 4
-        exec_pair = 10 * (Np4 * Np4 + Np4 * (Np4 + 4) / 2.0) * 2.0
+        flops_pair = W * (W + 1) + 2.0 * W * W                 # F(336) = 339 024, the dense products the reference forms
+        # what the Kronecker kernel executes on the matrix pipe for the identical G, C (kp_timer_get 10: jobs x quads x weights
+        # MFMA instructions per 4 snapshots, 512 flop each, padding included)
+        exec_pair = exec_pair_head
         # HBM traffic of the dominant kernel: PMC counters are collected in separate rocprofv3 passes of this
         # same command (tools/prof_round.sh) and committed under profiles/; null when the workload differs
         traffic, prof_note = None, None
-        for pj in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
+        for pj in ("r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
             pj = os.path.join(ROOT, "profiles", pj)
             if os.path.exists(pj) and Ns == 100000 and args.degree == 3:
                 try:
@@ -530,16 +553,15 @@ def main():
                             "chunks); streamed = two device objects refilled alternately, transfer overlapping the other "
                             "object's Gram kernel; never part of `value`"},
             "kernel_ms": {"gram": g_ms, "gram_launches_averaged": n_timed, "gram_reduce": red_ms if red_ms > 0 else None, "solve": solve_ms},
-            "roofline": {"bound": "mfma", "kernel": "kp_gram3_kernel<6,3>", "achieved": achieved, "peak": PEAK_F64_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_F64_MFMA_TFLOPS, "traffic": traffic,
-                         "algorithmic_flop_per_launch": flops_pair * Ns, "algorithmic_bytes_per_launch": 120.0 * Ns,
-                         "hbm_algorithmic_GBs": 120.0 * Ns / (g_ms * 1e-3) / 1e9,
-                         "executed_flop_per_launch": exec_pair * Ns,
-                         "executed_frac": exec_pair * Ns / (g_ms * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS,
-                         "note": "achieved/frac = dense algorithmic flop W(W+1)+2W^2 per pair / measured kernel time (SURVEY 8(d)); the "
-                                 "Kronecker-structured kernel executes ~63% of them for the identical G, C: executed_frac is the "
-                                 "matrix-pipe utilisation",
-                         "pmc": prof_note},
+            "untimed_prewarm_launches": {"pipelined_fits": max(256, args.steps), "gram_only": 32,
+                                         "why": "clock ramp: the first ~60 Gram launches after an idle stretch run 470 -> 405 us "
+                                                "(profiles/r02_gram_launch_durations.txt); `warmup` counts only the driver's W"},
+            "roofline": dict(roofline_block("kp_gram3_kernel<6,3,false>", exec_pair * Ns, flops_pair * Ns, g_ms,
+                                            note="frac = flop the kernel executes on the matrix pipe / mean kernel time of the timed region (HIP "
+                                                 "events on the launch stream) / f64 matrix peak; dense_equivalent_* = SURVEY 8(d)'s W(W+1)+2W^2 "
+                                                 "per pair (the Kronecker kernel produces the identical G, C with ~63% of those flop)"),
+                             traffic=traffic, algorithmic_bytes_per_launch=120.0 * Ns,
+                             hbm_algorithmic_GBs=120.0 * Ns / (g_ms * 1e-3) / 1e9, pmc=prof_note),
         }
         if mpc_res is not None:
             res["mpc"] = mpc_res
@@ -549,6 +571,31 @@ def main():
         if lasso_res is not None:
             res["lasso_grid"] = lasso_res
             res["rand_sweep"] = sweep_res
+        # per-kernel rooflines of the secondary paths (the same fields as `roofline`; profiles/r03_*_kernel_stats.csv hold
+        # the rocprofv3 rows of the same kernels)
+        kern = []
+        if widths is not None:
+            kern += [dict(w["roofline"], point=k_) for k_, w in widths.items()]
+        if lasso_res is not None and lasso_res.get("_gemm"):
+            g_ms_, g_cols = lasso_res.pop("_gemm")
+            fl = 2.0 * W * W * g_cols
+            Wp_ = -(-W // 112) * 112 if W == 336 else W          # row padding of the tile grid (none at W = 336)
+            kern.append(dict(roofline_block("kp_symm_gemm2_kernel<7,.>", 2.0 * Wp_ * W * (-(-g_cols // 32) * 32), fl, g_ms_,
+                                            note="first (widest) product G [K_1 .. K_nv] of the lasso grid's FISTA iteration"),
+                             point=f"lasso product {W}x{W}x{int(g_cols)}"))
+        if sweep_res is not None and sweep_res.get("_gram"):
+            for mt, (ms_, W_, pairs) in sweep_res.pop("_gram").items():
+                dense = (W_ * (W_ + 1) + 2.0 * W_ * W_) * pairs
+                blk = roofline_block("kp_traj_gram_kernel", 2.0 * 2 * 16 * 16 * pairs, dense, ms_,
+                                     note="W <= 16: one padded 16 x 16 tile per Gram; 24 B per pair, so the pass is also priced against HBM")
+                blk.update({"hbm_GBs": 24.0 * pairs / (ms_ * 1e-3) / 1e9, "hbm_frac": 24.0 * pairs / (ms_ * 1e-3) / 1e9 / PEAK_HBM_GBS})
+                kern.append(dict(blk, point=f"rand sweep {mt} pass, W={W_}, {int(pairs)} pairs"))
+        if lasso_res is not None:
+            lasso_res.pop("_gemm", None)
+        if sweep_res is not None:
+            sweep_res.pop("_gram", None)
+        if kern:
+            res["kernels"] = kern
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(min(Ns, 20000), args.degree)
             if mpc_res is not None:

@@ -49,7 +49,9 @@ int kp_device_info(const kp_ctx* ctx, char* name, int name_len, int* num_cu, int
 /* milliseconds spent in the device part of the most recent call of each kind
  * (HIP events on the library stream): which = 0 fused lift+Gram kernel, 1 solve, 2 mpc step, 3 lasso, 4 lift, 5 rollout, 6 Gram partial reduction.
  * After a run of pipelined fits (kp_fit with K_out == NULL) timer 0 is the MEAN duration of the last (up to 64) Gram
- * launches and which = 7 the number of launches in that mean. */
+ * launches and which = 7 the number of launches in that mean.  which = 8: the first (widest) product G [K_1 ... K_nv] of the
+ * most recent lasso batch, 9: its number of columns (kp_symm_gemm2_kernel: the FISTA iteration's product); 10: flop per snapshot pair the most recent
+ * fused lift+Gram launch EXECUTES on the matrix pipe (padding and, for dim_red dictionaries, the projection included). */
 int kp_timer_get(const kp_ctx* ctx, int which, double* ms);
 /* Device pointer + byte size of the library stream's raw handle, for profilers/benchmarks
  * that want to bracket work with their own HIP events: returns hipStream_t as void*. */

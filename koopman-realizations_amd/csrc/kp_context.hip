@@ -132,7 +132,7 @@ extern "C" int kp_device_info(const kp_ctx* c, char* name, int name_len, int* nu
 }
 
 extern "C" int kp_timer_get(const kp_ctx* c, int which, double* ms) {
-  if (!c || !ms || which < 0 || which >= 8) return KP_ERR_ARG;
+  if (!c || !ms || which < 0 || which >= 12) return KP_ERR_ARG;
   *ms = c->timers[which];
   return KP_OK;
 }

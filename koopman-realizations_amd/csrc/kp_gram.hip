@@ -449,5 +449,6 @@ int kp_gram_launch(kp_ctx* ctx, const kp_basis* basis_c, const kp_snapshots* s, 
   KP_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   KP_HIP(ctx, hipEventRecord(ctx->evp[2], ctx->stream));
   ctx->gram_flops_per_pair = (double)W * (W + 1) + 2.0 * W * W;
+  ctx->timers[10] = (double)plan.njobs * plan.nacc * 512.0;   // executed on the matrix pipe per pair: 16 x 16 tiles incl. padding (timer 10)
   return KP_OK;
 }

@@ -649,5 +649,8 @@ int kp_gram3_launch(kp_ctx* ctx, const kp_basis* basis_c, const kp_snapshots* s,
   if (!pipelined) KP_HIP(ctx, hipEventRecord(ctx->ev1, rs));
   if (!ctx->ring_timing) KP_HIP(ctx, hipEventRecord(ctx->evp[2], rs));
   ctx->gram_flops_per_pair = (double)W * (W + 1) + 2.0 * W * W;
+  // executed on the matrix pipe per pair (timer 10): jobs (padding included) x quads x weights MFMAs per 4 snapshots, 512 flop
+  // each; dim_red: + the projection pcs' psi of every workgroup of a split (2 x nfull4 / 4 MFMAs per wave and tile)
+  ctx->timers[10] = (double)plan.njobs * plan.nq * NWT * 128.0 + (b.k_pcs > 0 ? (double)plan.nsuper * nfull4 * 128.0 : 0.0);
   return KP_OK;
 }

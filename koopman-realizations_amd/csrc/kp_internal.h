@@ -59,7 +59,7 @@ struct kp_ctx {
   int64_t hbm_bytes = 0;
   std::string name;
   mutable std::string err;
-  double timers[8] = {0};
+  double timers[12] = {0};
   double gram_flops_per_pair = 0;
   // growable device workspaces
   void* ws[10] = {nullptr};     // slot 8: staging of the collectives, 9: rank-revealing solve

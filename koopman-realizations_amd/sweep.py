@@ -230,7 +230,11 @@ def rand_models_sweep_arrays(Y, U, k, Yv, Uv, ctx, degrees=None, nested=True):
             try:
                 if nested and basis.W <= 16:          # all degrees from one pass over the data (sub-blocks of the degree-D Grams)
                     err, st = traj.sweep_eval_nested(basis, D, 4.0 if mt == "nonlinear" else np.inf)      # lasso 4: evaluate_rand_models.m:122
-                    out[mt] = err[:, :, 0]
+                    # a system whose batched fit failed (Gram not positive definite, lasso not converged) has no model: NaN,
+                    # as the reference's own `\` would propagate, instead of whatever the rollout made of it
+                    out[mt] = np.where(st != 0, np.nan, err[:, :, 0])
+                    # kernel time of this model type's Gram pass (kp_traj_gram_kernel), its width and pair count: bench line
+                    ctx.__dict__.setdefault("_sweep_gram", {})[mt] = (ctx.timer(0), basis.W, Y.shape[0] * (k * (Y.shape[1] // k - 1) - 1))
                     continue
             finally:
                 basis.close()
@@ -239,7 +243,7 @@ def rand_models_sweep_arrays(Y, U, k, Yv, Uv, ctx, degrees=None, nested=True):
                 basis = Basis(ctx, mt, n, m, [("poly", poly_exponent_table(nv, j)[nv:])], None)
                 try:
                     err, st = traj.sweep_eval(basis, 4.0 if mt == "nonlinear" else np.inf)
-                    rows.append(err[:, 0])
+                    rows.append(np.where(st != 0, np.nan, err[:, 0]))
                 finally:
                     basis.close()
             out[mt] = np.stack(rows, axis=0)
