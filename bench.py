@@ -284,6 +284,11 @@ def bench_arm_closed_loop(ctx, kra):
     ks = kra.Ksysid({"train": train, "val": val}, ctx=ctx, model_type="bilinear", obs_type=["poly"], obs_degree=[3],
                     snapshots=np.inf, lasso=[np.inf], delays=0, dim_red=True).train_models()
     t_sysid = time.perf_counter() - t0
+    for _ in range(3):
+        ks.get_Koopman(ks.snapshotPairs)
+    tg = []
+    for _ in range(15):
+        t1 = time.perf_counter(); ks.get_Koopman(ks.snapshotPairs); tg.append(time.perf_counter() - t1)
     mpc = kra.Kmpc(ks, horizon=10, input_bounds=[-7 * np.pi / 8, 7 * np.pi / 8], input_slopeConst=1e-1, input_smoothConst=None,
                    state_bounds=None, cost_running=10, cost_terminal=100, cost_input=0.1 * np.array([3e-2, 2e-2, 1e-2]),
                    projmtx=ks.model["C"][-2:, :])
@@ -296,6 +301,8 @@ def bench_arm_closed_loop(ctx, kra):
     err = float(np.mean(np.linalg.norm(res["Y"][1:] @ proj.T - res["R"][1:], axis=1)))
     return {"steps": n, "steps_per_s": n / dt, "controller_us_per_step": float(np.median(res["comp_time"])) * 1e6, "N": int(ks.params["N"]),
             "mean_tracking_error": err, "sysid_seconds": t_sysid,
+            "get_koopman_end_to_end_ms": float(np.median(tg)) * 1e3, "get_koopman_pairs": int(ks.snapshotPairs["alpha"].shape[0]),
+            "get_koopman_W": int(ks.basis_dev.W),
             "reference_recorded": "MATLAB R2019a stored comp_time of the same controller shape: median 8.7 ms/step",
             "workload": "bilinear Kmpc horizon 10 on the block-M reference, arm model N=34 (poly-3, dim_red) from the shipped "
                         "3-link data, model as plant (BASELINE configs[2])"}
@@ -314,6 +321,36 @@ def roofline_block(kernel, exec_flop, dense_flop, ms, note=None, **extra):
         out["note"] = note
     out.update(extra)
     return out
+
+
+def bench_get_koopman(ctx, kra, Ns):
+    """The drop-in call end to end: `koopData = Ksysid.get_Koopman(snapshotPairs)` (Ksysid.m:987-1092) through the host
+    mirror - host arrays in (pageable numpy, as MATLAB hands mxArrays over), koopData with K on the host out: refill of the
+    resident snapshot object + fused Gram + solve + K fetch.  koopData.Px / .Py (:1085-1086) are materialised on first
+    access; what that costs is timed separately.  Config 2's shape (bilinear poly-3, W = 336) on a synthetic trial."""
+    rng = np.random.default_rng(11)
+    T = Ns + 1
+    y = np.cumsum(rng.standard_normal((T, 6)), axis=0) * 0.01
+    y = np.tanh(y + 0.3 * rng.standard_normal((T, 6)))
+    u = rng.uniform(-1, 1, (T, 3))
+    t = np.arange(T) * 0.01
+    trial = {"t": t, "y": y, "u": u}
+    val = {"t": t[:400], "y": y[:400], "u": u[:400]}
+    ks = kra.Ksysid({"train": [trial], "val": [val]}, ctx=ctx, model_type="bilinear", obs_type=["poly"], obs_degree=[3],
+                    snapshots=np.inf, lasso=[np.inf], delays=0, dim_red=False)
+    sp = ks.snapshotPairs
+    for _ in range(3):
+        ks.get_Koopman(sp)
+    ts = []
+    for _ in range(15):
+        t1 = time.perf_counter(); kd = ks.get_Koopman(sp); ts.append(time.perf_counter() - t1)
+    t1 = time.perf_counter(); px = kd["Px"]; py = kd["Py"]; t_pxpy = time.perf_counter() - t1
+    kd = ks.get_Koopman(sp)
+    t1 = time.perf_counter(); px = kd["Px"]; py = kd["Py"]; t_pxpy = min(t_pxpy, time.perf_counter() - t1)
+    return {"get_koopman_end_to_end_ms": float(np.median(ts)) * 1e3, "pairs": int(sp["alpha"].shape[0]), "W": int(ks.basis_dev.W),
+            "PxPy_on_first_access_ms": t_pxpy * 1e3, "PxPy_bytes": int(px.nbytes + py.nbytes),
+            "note": "host arrays in -> koopData (K on the host) out, through Ksysid.get_Koopman of the host mirror; Px/Py = the econ "
+                    "lift (N columns), materialised lazily"}
 
 
 def bench_width_points(ctx, kra, Ns):
@@ -498,8 +535,10 @@ def main():
     if rank == 0 and not args.no_mpc and world == 1:     # latency-bound sections only in the single-GPU run
         mpc_res = bench_mpc(ctx, kra, basis, snaps, args)
         arm_res = bench_arm_closed_loop(ctx, kra)
+    gk_res = None
     if rank == 0 and extras_on and world == 1:
         widths = bench_width_points(ctx, kra, Ns)
+        gk_res = bench_get_koopman(ctx, kra, Ns)
     lasso_res = sweep_res = None
     if extras_on:                                        # sharded sections: every rank takes part
         # the grid belongs to ONE fit: every rank holds the same snapshot matrix (rank 0's) for this section
@@ -568,6 +607,8 @@ def main():
             res["mpc_arm_blockM"] = arm_res
         if widths is not None:
             res["width_points"] = widths
+        if gk_res is not None:
+            res["get_koopman"] = gk_res
         if lasso_res is not None:
             res["lasso_grid"] = lasso_res
             res["rand_sweep"] = sweep_res

@@ -348,6 +348,9 @@ int kp_qp_solve(kp_ctx* ctx, const double* H, const double* f, const double* A, 
 int kp_comm_unique_id(void* id128);
 int kp_comm_create(kp_ctx* ctx, const void* id128, int rank, int world);
 int kp_comm_destroy(kp_ctx* ctx);
+/* the caller's watchdog gave up on a kp_comm_create that is still blocked in another thread: the context stays without a
+ * communicator even if that call returns later (the launch has agreed on another backend meanwhile) */
+int kp_comm_abandon(kp_ctx* ctx);
 int kp_comm_info(const kp_ctx* ctx, int* rank, int* world);
 int kp_comm_allgather(kp_ctx* ctx, const void* send, int64_t bytes, void* recv);
 int kp_comm_allreduce_sum(kp_ctx* ctx, double* inout, int64_t count);

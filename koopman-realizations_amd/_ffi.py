@@ -89,6 +89,7 @@ SIGNATURES = {
     "kp_comm_info": (C.c_int, [vp, c_ip, c_ip]),
     "kp_comm_allgather": (C.c_int, [vp, vp, C.c_int64, vp]),
     "kp_comm_allreduce_sum": (C.c_int, [vp, c_dp, C.c_int64]),
+    "kp_comm_abandon": (C.c_int, [vp]),
     "kp_comm_allgather_fit": (C.c_int, [vp, C.c_int, C.c_int, c_dp]),
     "kp_comm_allgather_fits": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, c_dp]),
     "kp_fit_sharded": (C.c_int, [vp, vp, vp, c_dp, C.c_int, c_dp]),

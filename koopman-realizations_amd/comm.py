@@ -78,6 +78,12 @@ class RcclComm:
         th.start()
         th.join(timeout)
         if th.is_alive():
+            # the blocked thread stays behind; tell the library that whatever it returns later must not become this
+            # context's communicator (the launch goes on with another backend)
+            try:
+                F.lib().kp_comm_abandon(ctx.handle)
+            except Exception:                             # noqa: BLE001 - stand-in libraries of the CPU tests
+                pass
             raise RcclInitTimeout(f"rank {rank}: ncclCommInitRank did not return within {timeout:.0f} s")
         if "exc" in box:
             raise box["exc"]
@@ -233,6 +239,22 @@ def rendezvous_file_from_env() -> str:
     return os.path.join(tempfile.gettempdir(), f"kp_comm_{tag}.id")
 
 
+LAUNCH_NONCE_SEP = b"|nonce|"
+
+
+def launch_nonce(path: str) -> str:
+    """The 16 hex characters rank 0 wrote behind the id: the rendezvous directory of the backend vote is named after them,
+    so a directory left behind by an earlier launch with the same KP_COMM_FILE is never read."""
+    try:
+        with open(path, "rb") as f:
+            raw = f.read()
+        if raw[-len(LAUNCH_NONCE_SEP) - 16:-16] == LAUNCH_NONCE_SEP:
+            return raw[-16:].decode()
+    except OSError:
+        pass
+    return "0"
+
+
 def exchange_unique_id(rank: int, path: str, timeout: float = 300.0) -> bytes:
     """Rank 0 creates the id and publishes it atomically (write + rename); the others wait for the file."""
     if rank == 0:
@@ -242,7 +264,7 @@ def exchange_unique_id(rank: int, path: str, timeout: float = 300.0) -> bytes:
             uid = b"FAIL"                               # RCCL not loadable: tell the other ranks instead of letting them time out
         tmp = f"{path}.{os.getpid()}.tmp"
         with open(tmp, "wb") as f:
-            f.write(uid)
+            f.write(uid + LAUNCH_NONCE_SEP + os.urandom(8).hex().encode())     # the nonce names this launch's vote directory
         os.replace(tmp, path)
         return uid
     t0 = time.time()
@@ -251,6 +273,7 @@ def exchange_unique_id(rank: int, path: str, timeout: float = 300.0) -> bytes:
             if os.path.getmtime(path) >= t0 - 60.0:     # a file left behind by a crashed earlier launch is not ours
                 with open(path, "rb") as f:
                     uid = f.read()
+                uid = uid[:-len(LAUNCH_NONCE_SEP) - 16] if uid[-len(LAUNCH_NONCE_SEP) - 16:-16] == LAUNCH_NONCE_SEP else uid
                 if len(uid) == 128 or uid == b"FAIL":
                     return uid
         except FileNotFoundError:
@@ -287,7 +310,8 @@ def init_from_env(Context):
         why = "kp_comm_unique_id failed on rank 0 (librccl not loadable)"
     # all ranks agree on the backend through the rendezvous directory: one rank without a communicator would leave the
     # others blocked in their first collective
-    fc = FileComm(ctx, rank, world, path + ".d")
+    vote_dir = f"{path}.{launch_nonce(path)}.d"
+    fc = FileComm(ctx, rank, world, vote_dir)
     votes = fc.all_gather_bytes((why or "ok").encode()[:200].ljust(200))
     bad = [v.decode().strip() for v in votes if v.decode().strip() != "ok"]
     if bad:
@@ -298,7 +322,7 @@ def init_from_env(Context):
     comm.barrier()
     if rank == 0:
         import shutil
-        shutil.rmtree(path + ".d", ignore_errors=True)
+        shutil.rmtree(vote_dir, ignore_errors=True)
         try:
             os.remove(path)
         except OSError:

@@ -92,7 +92,22 @@ extern "C" int kp_comm_create(kp_ctx* ctx, const void* id128, int rank, int worl
     delete cs;
     return ctx->fail(KP_ERR_HIP, std::string("ncclCommInitRank: ") + rccl().GetErrorString(r));
   }
+  if (ctx->comm_abandoned.load()) {
+    // the caller's watchdog gave up on this bootstrap and the launch went on without RCCL (kp_comm_abandon): a communicator
+    // that appears now must not be published - the other ranks will never enter a collective on it
+    (void)rccl().CommDestroy(cs->comm);
+    delete cs;
+    return ctx->fail(KP_ERR_HIP, "kp_comm_create: abandoned by the caller before ncclCommInitRank returned");
+  }
   ctx->comm = cs;
+  return KP_OK;
+}
+
+// The caller's watchdog timed out on kp_comm_create (still blocked in another thread): from now on this context runs
+// without a communicator, whatever that call does later.
+extern "C" int kp_comm_abandon(kp_ctx* ctx) {
+  if (!ctx) return KP_ERR_ARG;
+  ctx->comm_abandoned.store(true);
   return KP_OK;
 }
 

@@ -819,6 +819,8 @@ static int flush_solves(kp_ctx* ctx) {
   return KP_OK;
 }
 
+int kp_flush_pending(kp_ctx* ctx) { return flush_solves(ctx); }
+
 extern "C" int kp_fit(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* snaps, const double* lasso, int n_lasso,
                       double* K_out) {
   if (!ctx || !basis || !snaps || n_lasso < 1) return ctx ? ctx->fail(KP_ERR_ARG, "kp_fit: bad argument") : KP_ERR_ARG;

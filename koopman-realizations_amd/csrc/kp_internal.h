@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -41,6 +42,7 @@ struct kp_ctx {
   bool ring_timing = false;           // Gram launchers time themselves with the event ring and record nothing else
   unsigned ring_skip = 0;
   kp_comm_state* comm = nullptr;      // set by kp_comm_create: rank / world / RCCL communicator
+  std::atomic<bool> comm_abandoned{false};   // kp_comm_abandon: a bootstrap still blocked in another thread must not publish `comm`
   bool reduce_grams = false;          // kp_fit_sharded: all-reduce [G | C] over the ranks between the Gram kernel and the solve
   // set by the asynchronous kp_fit around kp_gram_dispatch: the split-partial reduction runs on this stream
   // (after an event recorded behind the main Gram kernel) and the partial buffer `part_flip` is used
@@ -269,6 +271,8 @@ int kp_gram3_launch(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* s, d
 bool kp_gram5_applicable(const kp_basis* basis);
 int kp_gram5_launch(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* s, double* GC_dev);
 inline int kp_gram_dispatch(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* s, double* GC_dev) {
+  if (s->Ns > 0 && (!s->alpha || !s->beta || (s->m > 0 && !s->u)))    // an object whose refill failed part-way (kp_snapshots_update)
+    return ctx->fail(KP_ERR_ARG, "kp_fit: the snapshot object holds no device arrays (a failed kp_snapshots_update?)");
   ctx->reduce_timed_from = 1;
   KP_HIP(ctx, kp_snaps_acquire(s, ctx->stream));
   const int rc = kp_gram3_applicable(basis)   ? kp_gram3_launch(ctx, basis, s, GC_dev)
@@ -284,6 +288,8 @@ bool kp_chol_ll_applicable(int n);
 hipError_t kp_chol_ll_launch(double* Gp, int n, int nb, int* info, int* sticky, int prof, hipStream_t st);
 int kp_pivchol_solve_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, int W, int ncols, double* K_dev, int* rank);
 int kp_comm_allreduce_dev(kp_ctx* ctx, double* buf_dev, size_t count, hipStream_t s);
+// queued (deferred) solves of the asynchronous pipeline are launched; nothing is waited for, no status is consumed (kp_fit.hip)
+int kp_flush_pending(kp_ctx* ctx);
 int kp_lift_dev(kp_ctx* ctx, const kp_basis* basis, int what, const double* dz, const double* du, int64_t rows, double* dout);
 int kp_chol_solve_dev(kp_ctx* ctx, double* G_dev, double* C_dev, int W, int ncols, double* K_dev, hipStream_t st = nullptr,
                       hipEvent_t pad_done = nullptr, int* sticky = nullptr);

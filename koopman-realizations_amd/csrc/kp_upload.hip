@@ -298,12 +298,23 @@ extern "C" int kp_snapshots_update(kp_ctx* ctx, kp_snapshots* s, const double* a
   KP_HIP(ctx, hipSetDevice(ctx->device));
   bool fresh = false;
   if (Ns > s->cap_rows) {                            // grow: the old arrays must be idle before they are freed
-    int rc = kp_synchronize(ctx);
+    // idle the device WITHOUT consuming the deferred status of earlier fits (a NOT_SPD of a queued fit belongs to the
+    // caller's next kp_synchronize / kp_fit_get_K, not to this refill): flush the queued solves, then wait for the streams
+    int rc = kp_flush_pending(ctx);
     if (rc) return rc;
+    KP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->stream2) KP_HIP(ctx, hipStreamSynchronize(ctx->stream2));
     if (ctx->stage) KP_HIP(ctx, hipStreamSynchronize(ctx->stage->copy_stream));
     free_arrays(s);
     hipError_t e = alloc_arrays(s, Ns);
-    if (e != hipSuccess) return ctx->fail(KP_ERR_HIP, std::string("kp_snapshots_update: ") + hipGetErrorString(e));
+    if (e != hipSuccess) {
+      // alloc_arrays may have failed part-way: leave an EMPTY object (no rows, no arrays) - a later fit on it fails with
+      // "no snapshots" instead of launching kernels on null pointers
+      free_arrays(s);
+      s->Ns = 0;
+      s->cap_rows = 0;
+      return ctx->fail(KP_ERR_HIP, std::string("kp_snapshots_update: ") + hipGetErrorString(e));
+    }
     fresh = true;
   }
   int rc = fill(ctx, s, alpha, beta, u, Ns, fresh);

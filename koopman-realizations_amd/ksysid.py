@@ -106,6 +106,30 @@ class _Lift:
         return out[0] if vec else out
 
 
+class KoopData(dict):
+    """koopData of get_Koopman (Ksysid.m:1084-1091): a dict whose `Px` / `Py` entries are materialised (device lift + the
+    transfer of Ns x N doubles each) the first time they are read."""
+
+    def lazy(self, key, make):
+        self.__dict__.setdefault("_lazy", {})[key] = make
+
+    def __missing__(self, key):
+        make = self.__dict__.get("_lazy", {}).pop(key, None)
+        if make is None:
+            raise KeyError(key)
+        self[key] = val = make()
+        return val
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or key in self.__dict__.get("_lazy", {})
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def keys(self):
+        return list(dict.keys(self)) + list(self.__dict__.get("_lazy", {}))
+
+
 class Ksysid:
     """Koopman-based system identification (mirror of classdef Ksysid, Ksysid.m:1)."""
 
@@ -352,9 +376,10 @@ class Ksysid:
             data, _ = self.get_zeta(data)
         if "snapshots" in data:                                            # :932-938
             s = data["snapshots"]
-            sp = {"alpha": np.asarray(s["alpha"], float), "beta": np.asarray(s["beta"], float), "u": np.asarray(s["u"], float)}
+            # column-major, MATLAB's own layout: what the library uploads without a host-side copy on every get_Koopman
+            sp = {"alpha": F.fcol(s["alpha"]), "beta": F.fcol(s["beta"]), "u": F.fcol(s["u"])}
             if "w" in s:
-                sp["w"] = np.asarray(s["w"], float)
+                sp["w"] = F.fcol(s["w"])
             return sp
         nd = self.params["nd"]
         t = np.asarray(data["t"], dtype=np.float64).ravel()
@@ -364,9 +389,9 @@ class Ksysid:
         if num > num_max - 1:                                              # :963-967
             num = num_max
         index = self._rng.permutation(num_max)[:int(num)]                  # :974-975
-        sp = {"alpha": before[index], "beta": after[index], "u": u[index]}
+        sp = {"alpha": F.fcol(before[index]), "beta": F.fcol(after[index]), "u": F.fcol(u[index])}     # column-major (MATLAB's layout)
         if "wzeta" in data:                                                # :953-957, :980-982
-            sp["w"] = data["wzeta"][:-1][good][index]
+            sp["w"] = F.fcol(data["wzeta"][:-1][good][index])
         return sp
 
     # ---- dimension reduction -----------------------------------------------------------
@@ -464,10 +489,20 @@ class Ksysid:
                     K = fit(self.ctx, self.basis_dev, snaps, [lval])[0]
         finally:
             pass                                                           # the object stays resident for the next call
-        koop = {"K": K, "u": snapshotPairs["u"], "alpha": snapshotPairs["alpha"]}
+        koop = KoopData({"K": K, "u": snapshotPairs["u"], "alpha": snapshotPairs["alpha"]})
         if want_PxPy:
-            koop["Px"] = self.basis_dev.lift(F.LIFT_ROW, snapshotPairs["alpha"], snapshotPairs["u"])[:, :N]
-            koop["Py"] = self.basis_dev.lift(F.LIFT_ROW, snapshotPairs["beta"], snapshotPairs["u"])[:, :N]
+            # koopData.Px / .Py = Px(:, 1:N), Py(:, 1:N) (:1085-1086).  For linear and bilinear rows the first N columns ARE
+            # the econ lift psi(x) (rows [psi(x), u] / psi(x) (x) [1; u], :1049-1063), so the device lifts N columns instead
+            # of the W-wide row block (4x less over PCIe at the bilinear config); nonlinear rows are psi([x; u]) (W = N).
+            # Nothing of this package reads them (get_model takes the Grams, kp_model_project): they are materialised at
+            # first access - `koopData["Px"]` - not on every fit.
+            sp = snapshotPairs
+            if self.model_type == "nonlinear":
+                koop.lazy("Px", lambda: self.basis_dev.lift(F.LIFT_ROW, sp["alpha"], sp["u"])[:, :N])
+                koop.lazy("Py", lambda: self.basis_dev.lift(F.LIFT_ROW, sp["beta"], sp["u"])[:, :N])
+            else:
+                koop.lazy("Px", lambda: self.basis_dev.lift(F.LIFT_ECON, sp["alpha"]))
+                koop.lazy("Py", lambda: self.basis_dev.lift(F.LIFT_ECON, sp["beta"]))
         return koop
 
     def _get_Koopman_loaded(self, sp, lasso, want_PxPy):

@@ -6,8 +6,8 @@
  * One entry point, dispatched on a command string; opaque handles travel as uint64 scalars.  MATLAB arrays are
  * column-major doubles, which is the library's own layout, so matrices are passed without copies or transposes.
  *
- *   h   = kp_mex('create', device_id)                                   kp_create
- *         kp_mex('destroy', h)                                          kp_destroy
+ *   h   = kp_mex('create', device_id)                                   kp_create: the device's shared context (+1 reference)
+ *         kp_mex('destroy', h)                                          drops a reference; kp_destroy at the last one
  *   b   = kp_mex('basis_create', h, desc)                               kp_basis_create; desc: struct with fields model_type,
  *                                                                       nzeta, m, block_type (int32 row), block_count (int32 row),
  *                                                                       poly_exps (uint8, nvars x rows), gauss_centres, pcs
@@ -34,22 +34,35 @@
 #include "koopman_hip.h"
 #include "mex.h"
 
-#define MAXH 64
-static kp_ctx* g_ctx[MAXH];
-static int g_nctx = 0;
+/* ONE context per device, shared by every KsysidHip / KmpcHip object of the MATLAB session and reference counted:
+ * value-class objects are copied and dropped freely (a loop like evaluate_rand_models.m builds a Ksysid per system and
+ * degree), so a context per object would leak a HIP context, its streams and its workspaces per object.  'create' hands
+ * out the device's context (creating it on first use), 'destroy' drops one reference; mexAtExit releases what is left. */
+#define MAXDEV 16
+static kp_ctx* g_ctx[MAXDEV];
+static int g_refs[MAXDEV];
 /* one resident snapshot object per context, refilled in place ('snapshots_resident'): a value-class method such as
  * KsysidHip.get_Koopman cannot keep a handle between calls, the locked MEX file can */
-static kp_snapshots* g_snaps[MAXH];
-static int g_snaps_nz[MAXH], g_snaps_m[MAXH];
+static kp_snapshots* g_snaps[MAXDEV];
+static int g_snaps_nz[MAXDEV], g_snaps_m[MAXDEV];
+
+static void release_slot(int i) {
+  if (!g_ctx[i]) return;
+  if (g_snaps[i]) kp_snapshots_destroy(g_snaps[i]);
+  g_snaps[i] = NULL;
+  kp_destroy(g_ctx[i]);
+  g_ctx[i] = NULL;
+  g_refs[i] = 0;
+}
 
 static void at_exit(void) {
-  for (int i = 0; i < g_nctx; ++i)
-    if (g_ctx[i]) {
-      if (g_snaps[i]) kp_snapshots_destroy(g_snaps[i]);
-      g_snaps[i] = NULL;
-      kp_destroy(g_ctx[i]);
-    }
-  g_nctx = 0;
+  for (int i = 0; i < MAXDEV; ++i) release_slot(i);
+}
+
+static int slot_of(const kp_ctx* c) {
+  for (int i = 0; i < MAXDEV; ++i)
+    if (g_ctx[i] == c && c) return i;
+  return -1;
 }
 
 static void* get_handle(const mxArray* a) {
@@ -81,19 +94,15 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
   if (!mexIsLocked()) { mexLock(); mexAtExit(at_exit); }
 
   if (!strcmp(cmd, "create")) {
-    kp_ctx* c = NULL;
-    check(kp_create(nrhs > 1 ? (int)mxGetScalar(prhs[1]) : 0, &c), NULL);
-    if (g_nctx < MAXH) g_ctx[g_nctx++] = c;
-    plhs[0] = put_handle(c);
+    const int dev = nrhs > 1 ? (int)mxGetScalar(prhs[1]) : 0;
+    if (dev < 0 || dev >= MAXDEV) mexErrMsgIdAndTxt("kp:usage", "create: device id out of range");
+    if (!g_ctx[dev]) check(kp_create(dev, &g_ctx[dev]), NULL);
+    ++g_refs[dev];
+    plhs[0] = put_handle(g_ctx[dev]);
   } else if (!strcmp(cmd, "destroy")) {
-    kp_ctx* c = (kp_ctx*)get_handle(prhs[1]);
-    for (int i = 0; i < g_nctx; ++i)
-      if (g_ctx[i] == c) {
-        if (g_snaps[i]) kp_snapshots_destroy(g_snaps[i]);
-        g_snaps[i] = NULL;
-        g_ctx[i] = NULL;
-      }
-    kp_destroy(c);
+    const int slot = slot_of((kp_ctx*)get_handle(prhs[1]));
+    if (slot < 0) mexErrMsgIdAndTxt("kp:handle", "destroy: unknown context");
+    if (--g_refs[slot] <= 0) release_slot(slot);
   } else if (!strcmp(cmd, "basis_create")) {
     kp_ctx* c = (kp_ctx*)get_handle(prhs[1]);
     const mxArray* d = prhs[2];
@@ -150,9 +159,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
      * (kp_snapshots_update: no hipMalloc / hipFree per call, staged chunked transfer); owned by the MEX file - do not destroy */
     kp_ctx* c = (kp_ctx*)get_handle(prhs[1]);
     const int nz = (int)mxGetN(prhs[2]), m_ = (int)mxGetN(prhs[4]);
-    int slot = -1;
-    for (int i = 0; i < g_nctx; ++i)
-      if (g_ctx[i] == c) slot = i;
+    const int slot = slot_of(c);
     if (slot < 0) mexErrMsgIdAndTxt("kp:handle", "snapshots_resident: unknown context");
     if (g_snaps[slot] && (g_snaps_nz[slot] != nz || g_snaps_m[slot] != m_)) {
       kp_snapshots_destroy(g_snaps[slot]);

@@ -262,3 +262,29 @@ def test_train_models_with_a_vector_of_lasso_values_and_sampled_snapshots(ctx):
             Ko = ko.koopman_lasso(G, C, t)
             assert abs(np.abs(K).sum() - t) < 1e-6 * t and np.abs(K - Ko).max() < 1e-5 * max(1.0, np.abs(Ko).max())
     assert np.abs(ks.candidates[1]["A"] - ks.koopData[1]["K"].T[:dic.N, :dic.N]).max() == 0      # get_BLmodel slices K' (:1261)
+
+
+@pytest.mark.parametrize("mt", ["linear", "bilinear", "nonlinear"])
+def test_koopdata_px_py_are_the_first_N_row_columns_and_materialise_lazily(ctx, golden, mt):
+    """koopData.Px / .Py = Px(:, 1:N), Py(:, 1:N) (Ksysid.m:1085-1086): the mirror lifts the N econ columns (linear /
+    bilinear rows start with psi(x), :1049-1063) at first access instead of the W-wide row block on every fit; same numbers
+    as the oracle's literal rows."""
+    g = golden["rand_systems"]
+    n = 1001
+    train = [{"t": g["s0_train_t"][i * n:(i + 1) * n], "y": g["s0_train_y"][i * n:(i + 1) * n], "u": g["s0_train_u"][i * n:(i + 1) * n]}
+             for i in range(3)]
+    val = [{"t": g["s0_val_t"], "y": g["s0_val_y"], "u": g["s0_val_u"]}]
+    ks = kra.Ksysid({"train": train, "val": val}, ctx=ctx, model_type=mt, obs_type=["poly"], obs_degree=[3],
+                    snapshots=np.inf, lasso=[np.inf], delays=0, dim_red=False)
+    p = ks.params
+    koop = ks.get_Koopman(ks.snapshotPairs)
+    assert "Px" in koop and "Py" in koop and not dict.__contains__(koop, "Px")          # promised, not yet made
+    assert set(koop.keys()) >= {"K", "Px", "Py", "u", "alpha"}
+    dic = ko.build_dictionary(mt, p["nzeta"], p["m"], ["poly"], [3])
+    Px, Py = ko.px_py(dic, ks.snapshotPairs)
+    N = p["N"]
+    assert koop["Px"].shape == (Px.shape[0], N) and dict.__contains__(koop, "Px")
+    assert np.abs(koop["Px"] - Px[:, :N]).max() < 1e-13 and np.abs(koop["Py"] - Py[:, :N]).max() < 1e-13
+    assert koop.get("Px") is koop["Px"] and koop.get("nothing", 7) == 7
+    with pytest.raises(KeyError):
+        koop["nothing"]
