@@ -243,6 +243,59 @@ extern "C" int kp_basis_create(kp_ctx* ctx, const kp_basis_desc* d, kp_basis** o
       if (rc0) { delete b; return rc0; }
     }
   }
+  // extended recipes (kp_gram3): monomials, fourier products and gaussians as products of <= 3 table entries
+  {
+    int Dp = 1, df = 0;
+    for (size_t i = 0; i < (size_t)n_mono * nvars; ++i) Dp = std::max(Dp, (int)d->poly_exps[i]);
+    for (const ColDesc& c : cols)
+      if (c.kind == COL_FOURIER) df = std::max(df, c.aux);
+    const int D = Dp + 2 * df;
+    bool ok = nvars * D < 128 && n_gauss <= 64;
+    int max_nf = 1;
+    std::vector<uint32_t> rec(cols.size(), 0xffffffffu);
+    for (size_t c = 0; c < cols.size() && ok; ++c) {
+      uint32_t r = 0xffffffffu;
+      int nf = 0;
+      auto push = [&](int id) {
+        if (nf == 3) { ok = false; return; }
+        r = (r & ~(0xffu << (8 * nf))) | ((uint32_t)id << (8 * nf));
+        ++nf;
+        max_nf = std::max(max_nf, nf);
+      };
+      switch (cols[c].kind) {
+        case COL_VAR: push(cols[c].arg * D); break;
+        case COL_MONO: {
+          const uint8_t* e = d->poly_exps + (size_t)cols[c].arg * nvars;
+          for (int vv = 0; vv < nvars && ok; ++vv)
+            if (e[vv]) push(vv * D + e[vv] - 1);
+          break;
+        }
+        case COL_FOURIER: {     // mixed-radix digits, last variable fastest (kp_eval_col): 0 -> 1, 2j-1 -> cos, 2j -> sin(2 pi j x)
+          const int radix = 2 * cols[c].aux + 1;
+          int idx = cols[c].arg;
+          for (int vv = nvars - 1; vv >= 0 && ok; --vv) {
+            const int dg = idx % radix;
+            idx /= radix;
+            if (dg) push(vv * D + Dp + 2 * (((dg + 1) >> 1) - 1) + ((dg & 1) ? 0 : 1));
+          }
+          break;
+        }
+        case COL_GAUSS: push(128 + cols[c].arg); break;
+        case COL_CONST: break;
+        default: ok = false;
+      }
+      rec[c] = r;
+    }
+    b->fast_ext = ok;
+    b->ext_Dp = Dp;
+    b->ext_df = df;
+    b->ext_ng = n_gauss;
+    b->ext_max_factors = max_nf;
+    if (ok) {
+      int rc0 = upload(ctx, &b->d_recipes_ext, rec.data(), rec.size() * 4);
+      if (rc0) { kp_basis_destroy(b); return rc0; }
+    }
+  }
   BasisDev& v = b->dev;
   v.model_type = d->model_type;
   v.nzeta = d->nzeta;
@@ -281,6 +334,7 @@ extern "C" int kp_basis_destroy(kp_basis* b) {
   if (b->d_centres) (void)hipFree(b->d_centres);
   if (b->d_pcs) (void)hipFree(b->d_pcs);
   if (b->d_recipes) (void)hipFree(b->d_recipes);
+  if (b->d_recipes_ext) (void)hipFree(b->d_recipes_ext);
   kp_gram_plan_free(b->plan);
   kp_gram2_plan_free(b->plan2);
   kp_gram3_plan_free(b->plan3);

@@ -51,6 +51,12 @@
 #define PCS03 LDS3_DOUBLES
 #define PCSMAX3 32
 #define LDS3_PCS_DOUBLES (2 * YOFF3 * 16)
+// fourier / gaussian dictionaries (EXT): the per-variable table also holds cos / sin(2 pi j x) behind the powers, and one
+// entry per (side, gaussian centre) behind the constant; the centres live in LDS where the projection matrix would
+#define GC03 LDS3_DOUBLES
+#define GAUSSMAX3 32                // centres (2 sides x 32 x KT3 values per tile = two items per thread)
+#define GNZMAX3 8                   // state variables of a gaussian dictionary
+#define LDS3_GAUSS_DOUBLES (GAUSSMAX3 * GNZMAX3)
 
 struct Gram3Args {
   BasisDev b;
@@ -69,10 +75,14 @@ struct Gram3Args {
   int njobs;
   const double* pcs;         // nfull x k_pcs (column-major) or nullptr: econ lift [zeta | pcs' psi_full | 1] (Ksysid.m:1594-1618)
   int nfull4;                // nfull rounded up to a multiple of 4
+  // EXT: table entries per variable = Dp powers, then df (cos, sin) pairs (D = Dp + 2 df); ng gaussian centres (nzeta each)
+  int Dp, df, ng;
+  const double* centres;
 };
 
 // PCS: econ lift through a projection matrix (dim_red dictionaries)
-template <int NQ, int BM, bool PCS>
+// EXT: fourier (def_fourierLift, Ksysid.m:694-731) and gaussian (def_gaussianLift, :790-817) blocks through the same table
+template <int NQ, int BM, bool PCS, bool EXT = false>
 __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
   constexpr int NWT = (BM + 1) * (BM + 2) / 2;
   extern __shared__ __align__(16) double sm[];
@@ -116,6 +126,9 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
 
   // ---- one-time LDS setup: everything zero (padding columns and the zero group stay zero) ----
   for (int e = tid; e < LDS3_DOUBLES; e += 256) sm[e] = 0.0;
+  if (EXT) {   // gaussian centres (centre-major, nzeta coordinates each)
+    for (int e = tid; e < a.ng * b.nzeta; e += 256) sm[GC03 + e] = a.centres[e];
+  }
   if (PCS) {   // projection matrix, zero padded to (nfull4 x 32)
     const int nf4 = a.nfull4;
     for (int e = tid; e < 2 * nf4 * 16; e += 256) {
@@ -135,7 +148,7 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
 #pragma unroll
     for (int f = 0; f < NF3; ++f) {
       const int id = (int)((r >> (8 * f)) & 255u);
-      fa[f] = (id == 255 ? CID : lside * nzm * D + id) * PST3;
+      fa[f] = (id == 255 ? CID : (EXT && id >= 128) ? CID + 1 + lside * a.ng + (id - 128) : lside * nzm * D + id) * PST3;
     }
   }
   const int woff = PSI03 + (lvalid ? lside * YOFF3 + lcol : SOFF3 + (tid & 31));
@@ -165,8 +178,10 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
   // thread keeps a running pointer and a running count of the snapshots left in its row
   constexpr int LR = 2;
   const int nld = (nrawrows * KT3 + 255) / 256;     // wave-uniform number of active j
+  constexpr int LG = EXT ? 2 : 0;                   // gaussian items (side, centre, snapshot) per thread
   struct RawRegs { double v[LR]; bool ok; };
   bool ld_on[LR];
+  bool ld_isz[LR];                                  // row of a state variable (EXT: gets the trigonometric entries)
   const double* ld_ptr[LR];
   const int ld_s = tid & (KT3 - 1);                 // the same snapshot for every j (256 is a multiple of KT3)
   const int ld_dst0 = (tid / KT3) * D * PST3 + ld_s;
@@ -179,6 +194,23 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
     const int rr = r % nzm;
     const double* src = rr < b.nzeta ? ((r < nzm ? a.alpha : a.beta) + (int64_t)rr * a.Ns) : (a.u + (int64_t)(rr - b.nzeta) * a.Ns);
     ld_ptr[j] = src + kt0 * KT3 + ld_s;
+    ld_isz[j] = ld_on[j] && rr < b.nzeta;
+  }
+  // EXT: gaussian item q of this thread = (side, centre) for snapshot ld_s; it reads the nzeta raw values of its side itself
+  // (the same cache lines the row loaders fetch) and writes exp(-|zeta - c|^2) into the table entry of its centre
+  bool g_on[LG > 0 ? LG : 1];
+  const double* g_ptr[LG > 0 ? LG : 1];
+  int g_dst[LG > 0 ? LG : 1], g_cen[LG > 0 ? LG : 1];
+  if (EXT) {
+#pragma unroll
+    for (int q = 0; q < LG; ++q) {
+      const int gi = tid + q * 256;
+      g_on[q] = gi < 2 * a.ng * KT3;
+      const int gc = g_on[q] ? (gi / KT3) % a.ng : 0, gside = g_on[q] ? gi / (KT3 * a.ng) : 0;
+      g_ptr[q] = (gside ? a.beta : a.alpha) + kt0 * KT3 + ld_s;
+      g_dst[q] = (CID + 1 + gside * a.ng + gc) * PST3 + ld_s;
+      g_cen[q] = GC03 + gc * b.nzeta;
+    }
   }
   auto load_raw = [&]() __attribute__((always_inline)) -> RawRegs {                // next tile of this workgroup's range
     RawRegs x;
@@ -187,8 +219,8 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
     for (int j = 0; j < LR; ++j) {
       x.v[j] = 0.0;
       if (j < nld) {
-        const double v = *ld_ptr[j];
-        x.v[j] = x.ok ? v : 0.0;
+        x.v[j] = *ld_ptr[j];        // no arithmetic on the loaded value here: its first use (store_raw, at the END of a tile) is
+                                    // where the wave waits for the load - the tail mask is applied there
         ld_ptr[j] += KT3;
       }
     }
@@ -201,12 +233,41 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
     for (int j = 0; j < LR; ++j) {
       if (j < nld && ld_on[j]) {
         double* dst = sm + BUF * POWBUF3 + ld_dst0 + j * 32 * D * PST3;
-        double p = x.v[j];
-        for (int e = 0; e < D; ++e) {
+        const double xv = x.ok ? x.v[j] : 0.0;        // snapshots past Ns: every power is 0 (the tail mask)
+        double p = xv;
+        const int Dp = EXT ? a.Dp : D;
+        for (int e = 0; e < Dp; ++e) {
           dst[e * PST3] = p;
-          p *= x.v[j];
+          p *= xv;
+        }
+        if (EXT && a.df > 0 && ld_isz[j]) {
+          // cos / sin(2 pi j x), j = 1..df, by the angle-addition recurrence; 0 past Ns (the tail mask: cos 0 = 1 would count)
+          double s1, c1;
+          sincospi(2.0 * xv, &s1, &c1);               // exact range reduction (the argument is 2 x, not 2 pi x)
+          double cj = x.ok ? c1 : 0.0, sj = x.ok ? s1 : 0.0, cm = x.ok ? 1.0 : 0.0, sm1 = 0.0;
+          for (int h = 0; h < a.df; ++h) {
+            dst[(Dp + 2 * h) * PST3] = cj;
+            dst[(Dp + 2 * h + 1) * PST3] = sj;
+            const double cn = 2.0 * c1 * cj - cm, sn = 2.0 * c1 * sj - sm1;
+            cm = cj; sm1 = sj; cj = cn; sj = sn;
+          }
         }
       }
+    }
+    if (EXT) {
+      // the raw values of the item's snapshot are fetched HERE, not with the row loads at the start of the tile: the row
+      // loaders have pulled the same cache lines a tile ago, and 16 doubles held across the tile's MFMA loop would spill
+#pragma unroll
+      for (int q = 0; q < LG; ++q)
+        if (g_on[q]) {
+          double r2 = 0.0;
+          for (int i = 0; i < b.nzeta; ++i) {
+            const double dlt = g_ptr[q][(int64_t)i * a.Ns] - sm[g_cen[q] + i];
+            r2 += dlt * dlt;
+          }
+          g_ptr[q] += KT3;
+          sm[BUF * POWBUF3 + g_dst[q]] = x.ok ? exp(-r2) : 0.0;
+        }
     }
     if (tid < KT3) sm[BUF * POWBUF3 + CID * PST3 + tid] = x.ok ? 1.0 : 0.0;
   };
@@ -519,15 +580,15 @@ static int make_plan3(kp_ctx* ctx, int N, int nwt, int nq_cap, kp_gram3_plan** o
   return KP_OK;
 }
 
-template <int NQ, int BM, bool PCS>
+template <int NQ, int BM, bool PCS, bool EXT = false>
 static hipError_t launch3b(const Gram3Args& a, int grid, size_t lds, hipStream_t st) {
   static KpLdsCache lds_cache;
   {
-    const size_t lds_max = (size_t)(LDS3_DOUBLES + (PCS ? LDS3_PCS_DOUBLES : 0)) * sizeof(double);
-    hipError_t e = kp_ensure_lds(lds_cache, (const void*)kp_gram3_kernel<NQ, BM, PCS>, lds_max);
+    const size_t lds_max = (size_t)(LDS3_DOUBLES + (PCS ? LDS3_PCS_DOUBLES : 0) + (EXT ? LDS3_GAUSS_DOUBLES : 0)) * sizeof(double);
+    hipError_t e = kp_ensure_lds(lds_cache, (const void*)kp_gram3_kernel<NQ, BM, PCS, EXT>, lds_max);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL((kp_gram3_kernel<NQ, BM, PCS>), dim3(grid), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((kp_gram3_kernel<NQ, BM, PCS, EXT>), dim3(grid), dim3(256), lds, st, a);
   return hipGetLastError();
 }
 
@@ -544,6 +605,13 @@ static hipError_t launch3(const Gram3Args& a, int bm, int grid, size_t lds, hipS
       return hipErrorInvalidValue;
     }
   }
+  if (a.df > 0 || a.ng > 0) {            // fourier / gaussian entries in the table
+    switch (bm) {
+      case 1: return launch3b<NQ, 1, false, true>(a, grid, lds, st);
+      case 2: return launch3b<NQ, 2, false, true>(a, grid, lds, st);
+      default: return launch3b<NQ, 3, false, true>(a, grid, lds, st);
+    }
+  }
   switch (bm) {
     case 1: return launch3b<NQ, 1, false>(a, grid, lds, st);
     case 2: return launch3b<NQ, 2, false>(a, grid, lds, st);
@@ -551,9 +619,20 @@ static hipError_t launch3(const Gram3Args& a, int bm, int grid, size_t lds, hipS
   }
 }
 
+// fourier / gaussian blocks as table entries (EXT kernel): not with a projection, <= GAUSSMAX3 centres, <= GNZMAX3 variables
+static bool gram3_ext(const kp_basis* basis) {
+  const BasisDev& b = basis->dev;
+  return basis->fast_ext && (basis->ext_df > 0 || basis->ext_ng > 0) && b.k_pcs == 0 && basis->ext_ng <= GAUSSMAX3 &&
+         (basis->ext_ng == 0 || b.nzeta <= GNZMAX3) && !getenv("KP_NO_GRAM3_EXT");
+}
+
 bool kp_gram3_applicable(const kp_basis* basis) {
   const BasisDev& b = basis->dev;
   if (getenv("KP_NO_GRAM3")) return false;
+  if (gram3_ext(basis))
+    return b.model_type == KP_MODEL_BILINEAR && basis->ext_max_factors <= NF3 && b.nfull <= YOFF3 && b.m >= 1 && b.m <= 3 &&
+           2 * (b.nzeta + b.m) * KT3 <= 2 * 256 &&
+           2 * (b.nzeta + b.m) * (basis->ext_Dp + 2 * basis->ext_df) + 1 + 2 * basis->ext_ng <= NIDMAX3;
   // dim_red dictionaries: econ layout [zeta | k_pcs principal components | 1], at most 32 components
   if (b.k_pcs > 0 && (b.k_pcs > PCSMAX3 || b.N != b.nzeta + b.k_pcs + 1 || getenv("KP_NO_GRAM3_PCS"))) return false;
   return b.model_type == KP_MODEL_BILINEAR && basis->fast && basis->max_factors <= NF3 && b.nfull <= YOFF3 &&
@@ -567,12 +646,16 @@ int kp_gram3_launch(kp_ctx* ctx, const kp_basis* basis_c, const kp_snapshots* s,
   const int W = b.W, N = b.N;
   const int BM = b.m, NWT = (BM + 1) * (BM + 2) / 2;
   if (!basis->plan3) {
-    int rc = make_plan3(ctx, N, NWT, b.k_pcs > 0 ? 4 : 6, &basis->plan3);
+    // fourier / gaussian tables: the transcendental code's constants and temporaries cost ~40 registers, so fewer quads
+    // (accumulators) per wave or the kernel spills (measured: 4 quads per wave is the fastest cap, tools/gram_shapes_probe.py)
+    static const int ext_cap = [] { const char* e = getenv("KP_GRAM3_EXT_NQ"); return e ? atoi(e) : 4; }();
+    int rc = make_plan3(ctx, N, NWT, b.k_pcs > 0 ? 4 : gram3_ext(basis) ? ext_cap : 6, &basis->plan3);
     if (rc) return rc;
   }
   kp_gram3_plan& plan = *basis->plan3;
   const int nfull4 = (b.nfull + 3) / 4 * 4;
-  const size_t lds = (size_t)(LDS3_DOUBLES + (b.k_pcs > 0 ? 2 * nfull4 * 16 : 0)) * sizeof(double);
+  const bool ext = gram3_ext(basis);
+  const size_t lds = (size_t)(LDS3_DOUBLES + (b.k_pcs > 0 ? 2 * nfull4 * 16 : 0) + (ext ? LDS3_GAUSS_DOUBLES : 0)) * sizeof(double);
   int64_t ktiles = (s->Ns + KT3 - 1) / KT3;
   int ncu = ctx->num_cu > 0 ? ctx->num_cu : 256;
   int wg_per_cu = 2;                                  // __launch_bounds__(256, 2): two workgroups share a CU
@@ -601,8 +684,12 @@ int kp_gram3_launch(kp_ctx* ctx, const kp_basis* basis_c, const kp_snapshots* s,
   a.G4 = plan.G4;
   a.nsuper = plan.nsuper;
   a.ktiles_per_split = kps;
-  a.D = basis->pow_depth;
-  a.recipes = (const uint32_t*)basis->d_recipes;
+  a.D = ext ? basis->ext_Dp + 2 * basis->ext_df : basis->pow_depth;
+  a.recipes = (const uint32_t*)(ext ? basis->d_recipes_ext : basis->d_recipes);
+  a.Dp = ext ? basis->ext_Dp : basis->pow_depth;
+  a.df = ext ? basis->ext_df : 0;
+  a.ng = ext ? basis->ext_ng : 0;
+  a.centres = b.centres;
   a.desc = plan.desc;
   a.part = part;
   a.njobs = plan.njobs;

@@ -153,6 +153,13 @@ struct kp_basis {
   kp_gram3_plan* plan3 = nullptr;  // plan of the Kronecker (bilinear) Gram kernel
   kp_gram5_plan* plan5 = nullptr;  // plan of the dense 4x4x4 Gram kernel (linear / nonlinear monomial dictionaries)
   std::vector<uint32_t> h_recipes; // host copy of the recipes (valid if fast)
+  // extended recipes of the Kronecker Gram kernel (kp_gram3): besides powers, the per-variable table may hold the
+  // harmonics cos / sin(2 pi j x) of fourier blocks (Ksysid.m:694-731) and, behind the per-variable entries, one entry per
+  // gaussian centre (Ksysid.m:790-817).  Entry layout per variable: x^1 .. x^Dp | cos(2 pi x), sin(2 pi x), ... (df pairs);
+  // recipe ids: < 128 variable entries (v * D + e, D = Dp + 2 df), 128 + c gaussian centre c, 255 the constant
+  bool fast_ext = false;
+  int ext_Dp = 1, ext_df = 0, ext_ng = 0, ext_max_factors = 1;
+  void* d_recipes_ext = nullptr;
 };
 
 struct kp_snapshots {

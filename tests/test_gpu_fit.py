@@ -45,6 +45,10 @@ CASES = [
     ("linear", 2, 1, ["hermite"], [3], True),                # Ksysid.m:820-851
     ("bilinear", 2, 1, ["fourier_sparser"], [2], False),     # Ksysid.m:734-786
     ("nonlinear", 2, 1, ["poly", "hermite", "fourier_sparser"], [2, 2, 1], True),
+    # fourier / gaussian blocks as table entries of the Kronecker kernel (kp_gram3_kernel<.,.,false,true>)
+    ("bilinear", 3, 3, ["fourier"], [1], False),             # (1 + 2)^3 - 1 = 26 functions, products of <= 3 harmonics
+    ("bilinear", 6, 3, ["gaussian"], [20], False),           # def_gaussianLift with 20 centres (Ksysid.m:790-817)
+    ("bilinear", 2, 1, ["fourier", "gaussian", "poly"], [2, 7, 3], False),   # second harmonics by the recurrence, all three kinds
 ]
 
 
