@@ -3,8 +3,9 @@ classdef KmpcHip < Kmpc
     %   Drop-in: replace `Kmpc(` by `KmpcHip(` in example_control.m / Kmpc_setup.m (sysid_class must be a KsysidHip);
     %   Ksim.run_trial_mpc calls get_mpcInput / get_mpcInput_bilinear_iter exactly as before (Ksim.m:206-216) and still
     %   tests any(isnan(U)) for solver failure (:220).  Overridden: the three per-step entry points (Kmpc.m:329-387,
-    %   750-814, 817-904: lift, get_costB/H/G/D_bilinear, constraint rows, quadprog).  The constructor of the parent
-    %   still assembles its own cost / constraint matrices (used by nothing below, kept for inspection).
+    %   750-814, 817-904: lift, get_costB/H/G/D_bilinear, constraint rows, quadprog) and, for loaded models, the load
+    %   estimators (Kmpc.m:1298-1445: regression assembled on the host, lsqlin replaced by the device QP).  The constructor
+    %   of the parent still assembles its own cost / constraint matrices (used by nothing below, kept for inspection).
     %   mpc_type 'nonlinear' (fmincon) stays the parent's.
 
     properties
@@ -40,11 +41,15 @@ classdef KmpcHip < Kmpc
                 smooth = obj.params.Ts^2 * obj.input_smoothConst * mean( obj.params.scale.u_factor );   % :294,706
             end
             mt = double( strcmp( obj.model_type , 'bilinear' ) );
+            % loaded models: A, B already have the loaded sizes N (nw+1) (Ksysid.m:1192-1200, :1251-1259)
             obj.hip.mpc = kp_mex( 'mpc_create' , sysid_class.hip.ctx , mt , obj.model.A , obj.model.B , obj.horizon , ...
                                   obj.projmtx , obj.cost_running , obj.cost_terminal , r , lo , hi , slope , smooth );
             if ~isempty( obj.state_bounds )              % :313
                 sb = obj.scaledown.y( obj.state_bounds' )';
                 kp_mex( 'mpc_set_state_bounds' , obj.hip.mpc , sb(:,1) , sb(:,2) );
+            end
+            if obj.loaded                                % the parent's lift handle, served by the device (Ksysid.m:1606-1612)
+                obj.lift.econ_full_loaded = sysid_class.lift.econ_full_loaded;
             end
         end
 
@@ -60,6 +65,11 @@ classdef KmpcHip < Kmpc
                 ref = [ ref ; kron( ones( Np + 1 - size(ref,1) , 1 ) , ref(end,:) ) ];
             end
             Yr = reshape( ref' , [] , 1 );
+            if obj.loaded                                % :347-348, :771-772, :839-840: lift with the current load estimate
+                z = obj.lift.econ_full_loaded( zeta , traj.what( end , : )' );
+                U = kp_mex( 'mpc_step' , obj.hip.mpc , z , traj.u(end,:)' , Yr , iters );
+                return;
+            end
             [ U , z ] = kp_mex( 'mpc_step_zeta' , obj.hip.mpc , obj.hip.sys.hip.basis , zeta , traj.u(end,:)' , Yr , iters );
         end
 
@@ -73,6 +83,85 @@ classdef KmpcHip < Kmpc
 
         function [ U , z ] = get_mpcInput_bilinear_iter( obj , traj , ref , iter )
             [ U , z ] = obj.hip_step( traj , ref , iter );             % Kmpc.m:817-904
+        end
+
+        function [ what , resnorm ] = hip_lsqlin_load( obj , Cl , dl , whatpast , pin_last_zero )
+            % the lsqlin call of the estimators (Kmpc.m:1354, :1442): min |C x - d|^2, x = [1;w], x_1 = 1, -1 <= w <= 1
+            % and, with a previous estimate, |w_i - whatpast_i| <= 0.01 - a strictly convex QP in the free loads, solved on
+            % the device (kp_qp_solve: min 1/2 x'Hx + f'x, A x <= b)
+            nw = obj.params.nw;
+            free = 1 : nw;
+            if pin_last_zero && nw >= 1
+                free = 1 : nw - 1;
+            end
+            what = zeros( nw , 1 );
+            if ~isempty( free )
+                Cf = Cl( : , 1 + free );
+                r = dl - Cl( : , 1 );
+                nf = numel( free );
+                lo = -ones( nf , 1 ); hi = ones( nf , 1 );
+                if ~isempty( whatpast )
+                    wp = whatpast( end , free )';
+                    lo = max( lo , wp - 0.01 ); hi = min( hi , wp + 0.01 );
+                end
+                Aq = [ eye(nf) ; -eye(nf) ]; bq = [ hi ; -lo ];
+                what( free ) = kp_mex( 'qp_solve' , obj.hip.sys.hip.ctx , 2 * (Cf' * Cf) , -2 * (Cf' * r) , Aq , bq );
+            end
+            res = Cl * [ 1 ; what ] - dl;
+            resnorm = res' * res;
+        end
+
+        function [ what , resnorm ] = estimate_load_linear( obj , ypast , upast , whatpast )
+            % Kmpc.m:1298-1356.  The shipped code pins the LAST load to zero through the debugging equality
+            % Aeq = blkdiag(1,0,1) (:1350), which only has the right size for nw = 2; reproduced for nw = 2
+            if size( upast , 1 ) ~= size( ypast , 1 )
+                error( 'Input arguments must have the same number of rows' );
+            end
+            if nargin < 4, whatpast = []; end
+            traj.y = ypast; traj.u = upast;
+            [ ~ , zp ] = obj.get_zeta( traj );
+            hor = size( zp , 1 ); nz = obj.params.nzeta; nw = obj.params.nw; nd = obj.params.nd;
+            G = obj.lift.econ_full( zp( 1:hor-1 , : )' )';        % psi of every past state, ONE device call (rows = states)
+            CA = obj.model.A( 1:nz , : ); CB = obj.model.B( 1:nz , : );
+            Cl = zeros( nz * (hor-1) , nw + 1 ); dl = zeros( nz * (hor-1) , 1 );
+            for i = 1 : hor-1                                   % :1320-1333
+                rows = nz*(i-1)+1 : nz*i;
+                Cl( rows , : ) = CA * kron( eye(nw+1) , G(i,:)' );
+                dl( rows ) = zp( i+1 , 1:nz )' - CB * upast( nd+i , : )';
+            end
+            [ what , resnorm ] = obj.hip_lsqlin_load( Cl , dl , whatpast , nw == 2 );
+        end
+
+        function [ what , resnorm ] = estimate_load_bilinear( obj , ypast , upast , whatpast )
+            % Kmpc.m:1360-1444
+            if size( upast , 1 ) ~= size( ypast , 1 )
+                error( 'Input arguments must have the same number of rows' );
+            end
+            if nargin < 4, whatpast = []; end
+            traj.y = ypast; traj.u = upast;
+            [ ~ , zp ] = obj.get_zeta( traj );
+            hor = size( zp , 1 ); nz = obj.params.nzeta; nw = obj.params.nw; m = obj.params.m;
+            NL = obj.params.N * ( nw + 1 );
+            G = obj.lift.econ_full( zp( 1:hor-1 , : )' )';
+            Cl = zeros( nz * (hor-1) , nw + 1 ); dl = zeros( nz * (hor-1) , 1 );
+            for i = 1 : hor-1                                   % :1384-1394
+                Om = kron( eye(nw+1) , G(i,:)' );
+                Ai = obj.model.A( 1:nz , : );
+                for j = 1 : m
+                    Ai = Ai + upast(i,j) * obj.model.B( 1:nz , (j-1)*NL+1 : j*NL );
+                end
+                rows = nz*(i-1)+1 : nz*i;
+                Cl( rows , : ) = Ai * Om;
+                dl( rows ) = zp( i+1 , 1:nz )';
+            end
+            [ what , resnorm ] = obj.hip_lsqlin_load( Cl , dl , whatpast , false );
+        end
+
+        function delete_hip( obj )
+            % value class: the owning script releases the device problem when it is done (or mexAtExit does at session end)
+            if isfield( obj.hip , 'mpc' )
+                kp_mex( 'mpc_destroy' , obj.hip.mpc );
+            end
         end
     end
 end

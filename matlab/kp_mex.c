@@ -19,12 +19,14 @@
  *         kp_mex('snapshots_destroy', s) / kp_mex('basis_destroy', b) / kp_mex('mpc_destroy', m)
  *   K   = kp_mex('fit', h, b, s, lasso)                                 kp_fit: W x W x numel(lasso)   (get_Koopman, train_models)
  *   [G,C] = kp_mex('fit_gram', h, b, s)                                 kp_fit_gram
+ *   K   = kp_mex('fit_solve', h, G, C) / kp_mex('fit_lasso', h, G, C, t)  kp_fit_solve / kp_fit_lasso on given Grams
  *   r   = kp_mex('last_rank', h)                                        kp_fit_last_rank
  *   [A,B,M] = kp_mex('model_project', h, K, G, C, N, m)                 kp_model_project (get_model, Ksysid.m:1206-1225)
  *   Y   = kp_mex('rollout', h, model_type, A, B, z0, U, n_out)          kp_rollout (val_model / val_BLmodel)
  *   m   = kp_mex('mpc_create', h, model_type, A, B, Np, proj, q_run, q_term, r, lo, hi, slope, smooth)
  *         kp_mex('mpc_set_state_bounds', m, lo, hi)
  *   [U,z] = kp_mex('mpc_step_zeta', m, b, zeta, u_prev, Yr, iters)      kp_mpc_step_zeta; U is NaN when the QP failed
+ *   U   = kp_mex('mpc_step', m, z, u_prev, Yr, iters)                   kp_mpc_step (lifted state given: loaded models)
  *   x   = kp_mex('qp_solve', h, H, f, A, b)                             kp_qp_solve (signature of quadprog_gurobi.m:1)
  */
 #include <math.h>
@@ -196,6 +198,20 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     mxArray* Cm = mxCreateDoubleMatrix(W, W, mxREAL);
     check(kp_fit_gram(c, b, (kp_snapshots*)get_handle(prhs[3]), mxGetPr(plhs[0]), mxGetPr(Cm)), c);
     if (nlhs > 1) plhs[1] = Cm; else mxDestroyArray(Cm);
+  } else if (!strcmp(cmd, "fit_solve")) {
+    /* K = kp_mex('fit_solve', h, G, C): G K = C on the device (kp_fit_solve) */
+    kp_ctx* c = (kp_ctx*)get_handle(prhs[1]);
+    const int W = (int)mxGetM(prhs[2]), nc = (int)mxGetN(prhs[3]);
+    plhs[0] = mxCreateDoubleMatrix(W, nc, mxREAL);
+    check(kp_fit_solve(c, dbl(prhs[2]), dbl(prhs[3]), W, nc, mxGetPr(plhs[0])), c);
+  } else if (!strcmp(cmd, "fit_lasso")) {
+    /* K = kp_mex('fit_lasso', h, G, C, t): min 1/2 ||Px K - Py||^2 s.t. ||vec K||_1 <= t from the Grams (solve_KoopmanQP,
+     * Ksysid.m:1095-1176; the caller forms t = lasso * N, :996) */
+    kp_ctx* c = (kp_ctx*)get_handle(prhs[1]);
+    const int W = (int)mxGetM(prhs[2]), nc = (int)mxGetN(prhs[3]);
+    int iters = 0;
+    plhs[0] = mxCreateDoubleMatrix(W, nc, mxREAL);
+    check(kp_fit_lasso(c, dbl(prhs[2]), dbl(prhs[3]), W, nc, mxGetScalar(prhs[4]), 20000, 1e-10, mxGetPr(plhs[0]), &iters), c);
   } else if (!strcmp(cmd, "last_rank")) {
     int r = -1;
     check(kp_fit_last_rank((kp_ctx*)get_handle(prhs[1]), &r), NULL);
@@ -241,6 +257,15 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     check(kp_mpc_step_zeta(mp, b, dbl(prhs[3]), dbl(prhs[4]), dbl(prhs[5]), nrhs > 6 ? (int)mxGetScalar(prhs[6]) : 1, mxGetPr(plhs[0]),
                            mxGetPr(z), &status), NULL);
     if (nlhs > 1) plhs[1] = z; else mxDestroyArray(z);
+  } else if (!strcmp(cmd, "mpc_step")) {
+    /* U = kp_mex('mpc_step', m, z, u_prev, Yr, iters): the step from an already lifted state (loaded models lift with the
+     * current load estimate on the host side of the boundary, Kmpc.m:347-348) */
+    kp_mpc* mp = (kp_mpc*)get_handle(prhs[1]);
+    int nvar, nrows, status = 0;
+    check(kp_mpc_dims(mp, &nvar, &nrows), NULL);
+    const int m = (int)mxGetNumberOfElements(prhs[3]), Np = nvar / m;
+    plhs[0] = mxCreateDoubleMatrix(Np, m, mxREAL);
+    check(kp_mpc_step(mp, dbl(prhs[2]), dbl(prhs[3]), dbl(prhs[4]), nrhs > 5 ? (int)mxGetScalar(prhs[5]) : 1, mxGetPr(plhs[0]), &status), NULL);
   } else if (!strcmp(cmd, "qp_solve")) {
     kp_ctx* c = (kp_ctx*)get_handle(prhs[1]);
     const int n = (int)mxGetM(prhs[2]), mr = (int)mxGetM(prhs[4]);
