@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
   // ---- raw loader; rows: [alpha(nzeta) u(m) | beta(nzeta) u(m)] ----
   // value e = tid + j*256 of a tile -> (row e / KT3, snapshot e % KT3); tiles are loaded in order, so every
   // thread keeps a running pointer and a running count of the snapshots left in its row
-  constexpr int LR = 2;
+  constexpr int LR = 1;                             // 2 (nzeta + m) KT3 <= 256 raw values per tile (kp_gram3_applicable): one per thread
   const int nld = (nrawrows * KT3 + 255) / 256;     // wave-uniform number of active j
   constexpr int LG = EXT ? 2 : 0;                   // gaussian items (side, centre, snapshot) per thread
   struct RawRegs { double v[LR]; bool ok; };
@@ -631,12 +631,12 @@ bool kp_gram3_applicable(const kp_basis* basis) {
   if (getenv("KP_NO_GRAM3")) return false;
   if (gram3_ext(basis))
     return b.model_type == KP_MODEL_BILINEAR && basis->ext_max_factors <= NF3 && b.nfull <= YOFF3 && b.m >= 1 && b.m <= 3 &&
-           2 * (b.nzeta + b.m) * KT3 <= 2 * 256 &&
+           2 * (b.nzeta + b.m) * KT3 <= 256 &&
            2 * (b.nzeta + b.m) * (basis->ext_Dp + 2 * basis->ext_df) + 1 + 2 * basis->ext_ng <= NIDMAX3;
   // dim_red dictionaries: econ layout [zeta | k_pcs principal components | 1], at most 32 components
   if (b.k_pcs > 0 && (b.k_pcs > PCSMAX3 || b.N != b.nzeta + b.k_pcs + 1 || getenv("KP_NO_GRAM3_PCS"))) return false;
   return b.model_type == KP_MODEL_BILINEAR && basis->fast && basis->max_factors <= NF3 && b.nfull <= YOFF3 &&
-         b.m >= 1 && b.m <= 3 && 2 * (b.nzeta + b.m) * KT3 <= 2 * 256 && 2 * (b.nzeta + b.m) * basis->pow_depth + 1 <= NIDMAX3;
+         b.m >= 1 && b.m <= 3 && 2 * (b.nzeta + b.m) * KT3 <= 256 && 2 * (b.nzeta + b.m) * basis->pow_depth + 1 <= NIDMAX3;
 }
 
 int kp_gram3_launch(kp_ctx* ctx, const kp_basis* basis_c, const kp_snapshots* s, double* GC_dev) {
