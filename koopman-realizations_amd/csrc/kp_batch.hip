@@ -955,8 +955,8 @@ __global__ __launch_bounds__(64) void kp_sweep_rollout_nested_kernel(BasisDev b,
 
 // Validation rollouts of the nested sweep, FOUR (system, degree) jobs per wave: a job lives in one 16-lane row (N <= 16),
 // lane r of the row owns component r of the lifted state.  z+ = A z column by column: z[c] is broadcast inside every row by
-// ds_swizzle (LDS crossbar, no VALU slot) and lane r adds A[r][c] z[c] - N FMAs per step for all four jobs, instead of
-// sixteen v_readlane broadcasts per job.
+// a DPP row_newbcast move and lane r adds A[r][c] z[c] - N moves + N FMAs per step for all four jobs, instead of sixteen
+// v_readlane broadcasts per job.
 template <int CTRL>
 __device__ __forceinline__ double sb_row_ror(double v) {       // lane l of a 16-lane row receives from lane (l - n) mod 16
   int lo = __double2loint(v), hi = __double2hiint(v);
@@ -1047,15 +1047,15 @@ __global__ __launch_bounds__(64) void kp_sweep_rollout4_kernel(BasisDev b, const
     double zn = 0.0;
     if (mt != KP_MODEL_NONLINEAR) {
       // z+ = (A + sum_i u_i B_i) z  (val_model :1685 / val_BLmodel :1783); linear: B u added below.  z[c] reaches every
-      // lane of its row through ds_swizzle (bit mode: lane' = (lane & 0x10) | c inside each half of 32 lanes - a
-      // crossbar operation of the LDS unit, no VALU slot), so a step costs N FMAs (+ N m for the bilinear coefficient)
+      // lane of its 16-lane row by ONE DP-ALU DPP move (v_mov_b64_dpp row_newbcast:c).  (Round 2 broadcast it with two
+      // ds_swizzle per column: with 13 waves per CU the LDS crossbar was the bound.  Also tried here: the trial staged in
+      // LDS in 16-step chunks fetched a chunk ahead, instead of the one-step-ahead global loads below - slower, 1.37 against
+      // 0.96 ms per pass.)
 #define KP_COL_STEP(CC)                                                                                        \
       if (CC < Nw) {                                                                                           \
         double w = ak[CC];                                                                                     \
         if (mt == KP_MODEL_BILINEAR) { w += ut[0] * bk[0][CC]; if (m > 1) w += ut[1] * bk[1][CC]; if (m > 2) w += ut[2] * bk[2][CC]; } \
-        const int zlo = __builtin_amdgcn_ds_swizzle(__double2loint(z), ((CC) << 5) | 0x10);                    \
-        const int zhi = __builtin_amdgcn_ds_swizzle(__double2hiint(z), ((CC) << 5) | 0x10);                    \
-        zn += w * __hiloint2double(zhi, zlo);                                                                  \
+        zn += w * __builtin_amdgcn_update_dpp(0.0, z, 0x150 + (CC), 0xf, 0xf, false);                          \
       }
       KP_COL_STEP(0) KP_COL_STEP(1) KP_COL_STEP(2) KP_COL_STEP(3) KP_COL_STEP(4) KP_COL_STEP(5) KP_COL_STEP(6) KP_COL_STEP(7)
       KP_COL_STEP(8) KP_COL_STEP(9) KP_COL_STEP(10) KP_COL_STEP(11) KP_COL_STEP(12) KP_COL_STEP(13) KP_COL_STEP(14) KP_COL_STEP(15)
