@@ -1,4 +1,4 @@
-import sys; sys.path.insert(0, ".")
+import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, koopman_realizations_amd as kra, bench
 ctx = kra.Context(0)
 a,b,u = bench.synth_pairs(100000)

@@ -1,13 +1,14 @@
 #!/usr/bin/env python3
-"""Condenses the rocprofv3 output of tools/prof_round.sh (gpurun_out/prof_r02/*) into
-profiles/r02_pmc_summary.json (per-kernel mean of every counter, per launch) and copies the
-kernel-trace statistics to profiles/r02_bench_kernel_stats.csv.  For each pass the newest run
+"""Condenses the rocprofv3 output of tools/prof_round.sh (gpurun_out/prof_<round>/*, KP_ROUND, default r03) into
+profiles/<round>_pmc_summary.json (per-kernel mean of every counter, per launch) and copies the
+kernel-trace statistics to profiles/<round>_bench_kernel_stats.csv.  For each pass the newest run
 (most recently written files) is used."""
 import csv, glob, json, os, re, shutil, sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", "prof_r02")
+ROUND = os.environ.get("KP_ROUND", "r03")
+SRC = os.path.join(ROOT, "gpurun_out", "prof_" + ROUND)
 
 
 def newest(pattern):
@@ -43,7 +44,7 @@ def main():
             if k.startswith("kp_"):
                 out["kernels"][k]["avg_us"] = float(r["AverageNs"]) / 1e3
                 out["kernels"][k]["calls"] = int(r["Calls"])
-        shutil.copy(st, os.path.join(ROOT, "profiles", "r02_bench_kernel_stats.csv"))
+        shutil.copy(st, os.path.join(ROOT, "profiles", ROUND + "_bench_kernel_stats.csv"))
     out["notes"] = {
         "FETCH_SIZE/WRITE_SIZE": "rocprofv3 reports kilobytes per launch; per MI355X_MICROARCH.md gfx950 FETCH_SIZE reports half the bytes of a wide "
                                  "coalesced read: it is doubled for roofline.traffic (our reads are 8 B per lane, a width the guide "
@@ -65,7 +66,7 @@ def main():
         out["gram_algorithmic_flop"] = 33902400000.0
         out["gram_mfma_busy_cycles_per_instr"] = k["SQ_VALU_MFMA_BUSY_CYCLES"] / k["SQ_INSTS_VALU_MFMA_MOPS_F64"]
         out["gram_lds_conflict_fraction"] = k["SQ_LDS_BANK_CONFLICT"] / k["SQ_LDS_IDX_ACTIVE"]
-    json.dump(out, open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(ROOT, "profiles", ROUND + "_pmc_summary.json"), "w"), indent=1)
     g = [k for k in out["kernels"] if k.startswith("kp_gram3_kernel")]
     for k in g:
         print(k, json.dumps(out["kernels"][k], indent=1))

@@ -2,7 +2,7 @@
 # rocprofv3 passes for the round's profile bundle: kernel trace/stats, then PMC counters in
 # separate runs (never combined with trace domains other than --kernel-trace).
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_r02
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_${KP_ROUND:-r03}
 rm -rf $O; mkdir -p $O
 B="python3 $R/bench.py --no-cpu-baseline --no-mpc --no-extras --steps 50 --warmup 5"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- $B > $O.trace.log 2>&1
