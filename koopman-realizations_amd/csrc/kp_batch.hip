@@ -739,12 +739,13 @@ __global__ __launch_bounds__(256) void kp_traj_gram_kernel(BasisDev b, const uin
 #pragma unroll
     for (int v = 0; v < 8; ++v)
       if (v < nv) {
-        double x = v < nz ? tv.Y[((size_t)sys * tv.n + v) * tv.rows + row + side] : tv.U[((size_t)sys * tv.m + (v - nz)) * tv.rows + row];
-        raw[v] = ok ? x : 0.0;
+        // no arithmetic on the loaded value here (not even the tail mask): the wave would wait for the load on the spot
+        // instead of at its use, a whole accumulation phase later
+        raw[v] = v < nz ? tv.Y[((size_t)sys * tv.n + v) * tv.rows + row + side] : tv.U[((size_t)sys * tv.m + (v - nz)) * tv.rows + row];
       }
 #pragma unroll
     for (int i = 0; i < 3; ++i)
-      if (i < m) rin[i] = ok ? tv.U[((size_t)sys * tv.m + i) * tv.rows + row] : 0.0;
+      if (i < m) rin[i] = tv.U[((size_t)sys * tv.m + i) * tv.rows + row];
     return ok;
   };
   bool ok_next = load_raw(0);
@@ -756,7 +757,7 @@ __global__ __launch_bounds__(256) void kp_traj_gram_kernel(BasisDev b, const uin
 #pragma unroll
     for (int v = 0; v < 8; ++v)
       if (v < nv) {
-        const double x = raw[v];
+        const double x = ok ? raw[v] : 0.0;               // pairs past Ns: zero row (the constant column carries `ok` too)
         double q = x, qm = 1.0;
         for (int k = 0; k < D; ++k) {
           mypw[(v * D + k) * TG_TS] = q;
@@ -767,7 +768,7 @@ __global__ __launch_bounds__(256) void kp_traj_gram_kernel(BasisDev b, const uin
       }
     double uin[3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) uin[i] = i < m ? rin[i] : 0.0;
+    for (int i = 0; i < 3; ++i) uin[i] = (i < m && ok) ? rin[i] : 0.0;
     double* P = (side ? Py : Px) + p * SB_LD;
     for (int col = 0; col < N; ++col) {
       const uint32_t rc = recs[col];

@@ -1,6 +1,7 @@
 """CPU tests of the host-side mirror's own logic (no device calls): monomial tables and
 snapshot selection agree with the oracle's independent restatement."""
 import numpy as np
+import pytest
 
 from koopman_realizations_amd.ksysid import poly_exponent_table
 from oracle import koopman_oracle as ko
@@ -32,3 +33,43 @@ def test_matlab_wrappers_call_only_commands_the_gateway_implements():
     for fn in ("KsysidHip.m", "KmpcHip.m", "quadprog_hip.m"):
         used |= set(re.findall(r"kp_mex\(\s*'(\w+)'", open(os.path.join(root, "matlab", fn)).read()))
     assert used and used <= impl, used - impl
+
+
+def test_host_gather_helper_matches_numpy_and_rejects_what_it_cannot_take():
+    """_kp_gather (csrc/kp_pygather.c, built by the csrc Makefile): the buffer-protocol gather behind sweep._stack_raw gives
+    what np.concatenate gives, reports unequal piece lengths, refuses non-float64 pieces (the caller then converts through
+    numpy) and pieces that overflow the destination; _stack_raw falls back to None on ragged trials either way."""
+    import numpy as np
+    import __graft_entry__ as ge
+    ge.build()
+    from koopman_realizations_amd import sweep, _kp_gather
+    rng = np.random.default_rng(0)
+    pieces = [rng.standard_normal((17, 2)) for _ in range(300)]
+    out = np.zeros((300 * 17, 2))
+    n, same = _kp_gather.gather(pieces, out.ctypes.data, out.nbytes, 3)
+    assert n == out.nbytes and same is True and np.array_equal(out, np.concatenate(pieces, axis=0))
+    big = [rng.standard_normal(40000) for _ in range(40)]          # > 8 MB: the threaded path
+    outb = np.zeros(40 * 40000)
+    assert _kp_gather.gather(big, outb.ctypes.data, outb.nbytes, 4)[0] == outb.nbytes and np.array_equal(outb, np.concatenate(big))
+    assert _kp_gather.gather([np.zeros(3), np.zeros(4)], out.ctypes.data, out.nbytes)[1] is False
+    with pytest.raises(TypeError):
+        _kp_gather.gather([np.arange(4)], out.ctypes.data, out.nbytes)                      # int64
+    with pytest.raises(ValueError):
+        _kp_gather.gather([np.zeros(10)], out.ctypes.data, 8)
+    with pytest.raises((TypeError, BufferError, ValueError)):
+        _kp_gather.gather([np.zeros((4, 4))[:, ::2]], out.ctypes.data, out.nbytes)          # not contiguous
+    tq = np.arange(11) * 0.1
+    systems = [{"train": [{"t": tq.copy(), "y": rng.standard_normal((11, 1)), "u": rng.standard_normal((11, 1))} for _ in range(3)],
+                "val": [{"t": tq.copy(), "y": rng.standard_normal((11, 1)), "u": rng.standard_normal((11, 1))}]} for _ in range(5)]
+    a = sweep._stack_raw(systems)
+    helper, sweep._kp_gather = sweep._kp_gather, None
+    try:
+        b = sweep._stack_raw(systems)
+    finally:
+        sweep._kp_gather = helper
+    assert all(np.array_equal(x, y) if isinstance(x, np.ndarray) else x == y for x, y in zip(a, b))
+    systems[2]["train"][1]["y"] = [[float(v)] for v in systems[2]["train"][1]["y"][:, 0]]    # a list among the arrays: numpy path
+    c = sweep._stack_raw(systems)
+    assert np.array_equal(c[0], a[0])
+    systems[1]["train"][0]["y"] = systems[1]["train"][0]["y"][:10]                          # ragged: no stacked form
+    assert sweep._stack_raw(systems) is None
