@@ -42,19 +42,21 @@ def synth_pairs(Ns, nz=6, m=3, seed=0):
 def cpu_baseline(Ns_sample, degree, seconds=8.0):
     """The oracle's restatement of get_Koopman on the host cores, on a bounded sample of the same workload: the lift of
     every row (Ksysid.m:1030-1065) + `Px \\ Py` (:1069; MATLAB's mldivide on a rectangular system is a Householder QR
-    solve).  Compiled C (oracle/koopman_oracle_c.c, OpenMP) when its library is there, else numpy + LAPACK gelsy.  Two
+    solve).  The CPU backend of the same C ABI (oracle/koopman_cpu_abi.c over oracle/koopman_oracle_c.c, OpenMP), called exactly
+    as the GPU library is (kp_create -> kp_basis_create -> kp_snapshots_upload -> kp_fit), else numpy + LAPACK gelsy.  Two
     rows: all host cores (`value`) and one thread (the reference's interpreter is single threaded apart from BLAS)."""
     alpha, beta, u = synth_pairs(Ns_sample, seed=123)
     try:
-        from oracle import c_oracle, koopman_oracle as ko
-        c_oracle.lib()
+        from oracle import cpu_abi, koopman_oracle as ko
+        cl = cpu_abi.lib()
         exps = ko.poly_exponents(6, degree)[6:]
-        W = (6 + len(exps) + 1) * 4
+        fitobj = cpu_abi.CpuFit("bilinear", 6, 3, exps, alpha, beta, u)     # kp_create / kp_basis_create / kp_snapshots_upload
+        W = fitobj.W
 
         def timed(limit):
             t0 = time.perf_counter(); reps = 0
             while True:
-                c_oracle.get_koopman("bilinear", 6, 3, exps, alpha, beta, u); reps += 1
+                fitobj.fit(); reps += 1                                     # kp_fit: lift of every row + Householder QR
                 if time.perf_counter() - t0 > limit:
                     break
             return (time.perf_counter() - t0) / reps, reps
@@ -64,13 +66,14 @@ def cpu_baseline(Ns_sample, degree, seconds=8.0):
             avail = len(os.sched_getaffinity(0))
         except AttributeError:
             avail = os.cpu_count() or 1
-        all_cores = max(1, min(c_oracle.lib().ko_max_threads(), avail, 32))
-        c_oracle.lib().ko_set_threads(all_cores)
+        all_cores = max(1, min(cl.ko_max_threads(), avail, 32))
+        cl.ko_set_threads(all_cores)
         dt_all, reps_all = timed(seconds)
-        c_oracle.lib().ko_set_threads(1)
+        cl.ko_set_threads(1)
         dt_1, reps_1 = timed(seconds)
-        c_oracle.lib().ko_set_threads(all_cores)
-        how = "compiled C restatement (per-row lift + Householder QR, OpenMP)"
+        cl.ko_set_threads(all_cores)
+        fitobj.close()
+        how = "CPU backend of the same C ABI (oracle/libkoopman_cpu.so: kp_fit = per-row lift + Householder QR, OpenMP)"
     except (ImportError, OSError):
         import scipy.linalg as sla
         import threadpoolctl

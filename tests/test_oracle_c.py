@@ -42,3 +42,32 @@ def test_c_oracle_on_the_arm_pairs_subset(co, arm):
     K = co.get_koopman("linear", 6, 3, np.zeros((0, 6), np.uint8), p["alpha"], p["beta"], p["u"])
     Kref = ko.koopman_ls(Px, Py)
     assert np.abs(K - Kref).max() <= 1e-9 * np.abs(Kref).max()
+
+
+def test_cpu_backend_of_the_same_c_abi_reproduces_the_oracle(co):
+    """oracle/libkoopman_cpu.so exports the fit path of include/koopman_hip.h on the host (its source includes the header: the
+    signatures are the compiler-checked ones) and is driven through the product binding's own argument types: kp_create ->
+    kp_basis_create -> kp_snapshots_upload -> kp_fit / kp_fit_gram / kp_lift.  This is what bench.py times as cpu_baseline."""
+    from oracle import cpu_abi
+    from koopman_realizations_amd import _ffi as F
+    hdr = open(os.path.join(ROOT, "include", "koopman_hip.h")).read()
+    out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "oracle", "libkoopman_cpu.so")], capture_output=True, text=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if " T kp_" in ln}
+    assert exported == set(cpu_abi.EXPORTS) and all(f"{n}(" in hdr and n in F.SIGNATURES for n in exported)
+    for mt, deg, nz, m in [("bilinear", 3, 6, 3), ("linear", 2, 4, 2), ("nonlinear", 2, 3, 2)]:
+        p = synth_pairs(1200, nz, m, seed=9)
+        dic = ko.build_dictionary(mt, nz, m, ["poly"], [deg])
+        nv = nz + (m if mt == "nonlinear" else 0)
+        fit = cpu_abi.CpuFit(mt, nz, m, ko.poly_exponents(nv, deg)[nv:], p["alpha"], p["beta"], p["u"])
+        try:
+            Px, Py = ko.px_py(dic, p)
+            assert (fit.N, fit.W) == (dic.N, dic.W)
+            Kref = ko.koopman_ls(Px, Py)
+            assert np.abs(fit.fit() - Kref).max() <= 1e-10 * np.abs(Kref).max()
+            G, Cm = fit.gram()
+            assert np.abs(G - Px.T @ Px).max() <= 1e-12 * np.abs(G).max() and np.abs(Cm - Px.T @ Py).max() <= 1e-12 * np.abs(G).max()
+            assert np.abs(fit.lift(F.LIFT_ROW, p["alpha"][:50], p["u"][:50]) - Px[:50]).max() < 1e-14
+            full = fit.lift(F.LIFT_FULL, p["alpha"][:50], p["u"][:50] if mt == "nonlinear" else None)
+            assert np.abs(full - Px[:50, :dic.N]).max() < 1e-14
+        finally:
+            fit.close()
