@@ -111,3 +111,28 @@ def test_active_set_rounds_end_sparse_values_early_and_exactly(ctx, config3):
     for f, K in zip(fr, Ks):
         assert ko.lasso_kkt_residual(G, C, K, f * l1) <= 1e-12 * cmax
         assert abs(np.abs(K).sum() - f * l1) <= 1e-12 * f * l1
+
+
+def test_the_64_value_grid_of_configs3_is_optimal_value_by_value(ctx, config3):
+    """BASELINE configs[3] at its full size: lasso = t/N log-spaced over [1e-2, 1e2], 64 values in ONE kp_fit call
+    (what bench.py's lasso_grid section times).  Every value with an active constraint meets the budget and the optimality
+    conditions of the reference's QP (Ksysid.m:1126-1137) to quadprog's own tolerance; every value whose budget exceeds
+    ||K_LS||_1 is the least-squares solution bit for bit; the active-set rounds finish the whole grid within 60 iterations."""
+    b, snaps, G, C, l1, N = config3["basis"], config3["snaps"], config3["G"], config3["C"], config3["l1"], config3["N"]
+    vals = np.geomspace(1e-2, 1e2, 64)
+    Ks = kra.fit(ctx, b, snaps, list(vals))
+    cmax = np.abs(C).max()
+    n_active = 0
+    for lv, K in zip(vals, Ks):
+        t = lv * N
+        if t >= l1 * (1 + 1e-12):
+            assert np.array_equal(K, Ks[-1])                         # inactive: the LS answer (the last value is inactive too)
+            continue
+        n_active += 1
+        assert abs(np.abs(K).sum() - t) <= 1e-9 * t, lv
+        assert ko.lasso_kkt_residual(G, C, K, t) <= 1e-8 * cmax, lv
+    assert n_active == 42
+    assert np.abs(Ks[-1] - config3["Kls"]).max() <= 1e-12 * np.abs(config3["Kls"]).max()
+    # sparsity grows monotonically as the budget shrinks (up to ties)
+    nnz = [int((K != 0).sum()) for K in Ks[:42]]
+    assert all(a <= b_ + 2 for a, b_ in zip(nnz[:-1], nnz[1:])), nnz
