@@ -594,7 +594,7 @@ int kp_chol_solve_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_de
   double* Gp = (double*)ws;
   double* Cp = (double*)(ws + (size_t)nb * bG);
   double* Dinv = (double*)(ws + (size_t)nb * (bG + bC));
-  int* info = (int*)(ws + (size_t)nb * (bG + bC + bD));
+  int* info = (int*)(ws + (size_t)nb * (bG + bC + bD));   // nb = 1: kp_chol_info_offset(W, ncols), the readers' formula
   size_t lds_chol = (size_t)2 * 16 * n * 8;
   size_t lds_trsm = ((size_t)n * 16 + 1024) * 8;
   if (lds_chol > 160 * 1024 - 8192 || lds_trsm > 160 * 1024 || n > 16 * 4 * TR_MAXJ) return ctx->fail(KP_ERR_ARG, "kp_fit_solve: W too large (max 512)");
@@ -663,8 +663,8 @@ static int check_info(kp_ctx* ctx) {
 }
 
 static int read_chol_info(kp_ctx* ctx, int W, int ncols, int* bad, const double* G_dev = nullptr) {
-  const int n = (W + 15) / 16 * 16, ncp = (ncols + 15) / 16 * 16;
-  size_t off = (size_t)n * n * 8 + (size_t)n * ncp * 8 + (size_t)(n / 16) * 256 * 8;
+  const int n = (W + 15) / 16 * 16;
+  const size_t off = kp_chol_info_offset(W, ncols);
   double* ratio_dev = (double*)((char*)ctx->ws[5] + off + 8);
   if (G_dev) {     // the factor is still in the padded buffer at the head of workspace 5
     hipLaunchKernelGGL(kp_pivot_ratio_kernel, dim3(1), dim3(256), 0, ctx->stream, (const double*)ctx->ws[5], n, G_dev, W, ratio_dev);

@@ -300,6 +300,13 @@ int kp_flush_pending(kp_ctx* ctx);
 int kp_lift_dev(kp_ctx* ctx, const kp_basis* basis, int what, const double* dz, const double* du, int64_t rows, double* dout);
 int kp_chol_solve_dev(kp_ctx* ctx, double* G_dev, double* C_dev, int W, int ncols, double* K_dev, hipStream_t st = nullptr,
                       hipEvent_t pad_done = nullptr, int* sticky = nullptr);
+// Where kp_chol_solve_dev leaves its info word (non-zero: a non-positive pivot) in workspace 5, behind the padded copies of
+// G (np x np), C (np x ncp) and the inverted diagonal blocks: the ONE place that knows the layout (kp_fit.hip, kp_lasso.hip and
+// kp_more.hip read the word through it).
+inline size_t kp_chol_info_offset(int W, int ncols) {
+  const size_t np = (size_t)(W + 15) / 16 * 16, ncp = (size_t)(ncols + 15) / 16 * 16;
+  return np * np * 8 + np * ncp * 8 + (np / 16) * 256 * 8;
+}
 int kp_chol_solve_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, int W, int ncols, int nb, size_t gc_stride, double* K_dev,
                             int k_first, int k_cap, hipStream_t st, hipEvent_t pad_done, int* sticky);
 // least-squares solution, PSD guard and Lipschitz constant shared by all lasso values of one fit (kp_lasso.hip)

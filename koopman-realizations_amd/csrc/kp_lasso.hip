@@ -614,8 +614,7 @@ int kp_lasso_prepare(kp_ctx* ctx, const double* G_dev, const double* C_dev, int 
   if (rc) return rc;
   hipLaunchKernelGGL(kp_l1norm_kernel, dim3(1), dim3(256), 0, s, p->Kls, n, scal);
   {
-    const int np = (W + 15) / 16 * 16, ncp = (ncols + 15) / 16 * 16;
-    size_t off = (size_t)np * np * 8 + (size_t)np * ncp * 8 + (size_t)(np / 16) * 256 * 8;
+    const size_t off = kp_chol_info_offset(W, ncols);
     KP_HIP(ctx, hipMemcpyAsync(&p->bad, (char*)ctx->ws[5] + off, sizeof(int), hipMemcpyDeviceToHost, s));
   }
   KP_HIP(ctx, hipMemcpyAsync(&p->l1_ls, scal, 8, hipMemcpyDeviceToHost, s));

@@ -187,8 +187,7 @@ extern "C" int kp_model_project(kp_ctx* ctx, const double* K, const double* G, c
   if (rc) return rc;
   {
     int bad = 0;
-    const int np = (N + 15) / 16 * 16;
-    size_t off = (size_t)np * np * 8 + (size_t)np * np * 8 + (size_t)(np / 16) * 256 * 8;
+    const size_t off = kp_chol_info_offset(N, N);
     KP_HIP(ctx, hipMemcpyAsync(&bad, (char*)ctx->ws[5] + off, sizeof(int), hipMemcpyDeviceToHost, s));
     KP_HIP(ctx, hipStreamSynchronize(s));
     if (bad) {   // L is rank deficient (a rank-deficient K): `M = L \ R` (Ksysid.m:1218) returns a basic solution; same here
