@@ -318,6 +318,10 @@ __device__ __forceinline__ bool lp_exchange(double& a, double& b, double& c, int
   return ok;
 }
 
+// EPT > 0: the workgroup's slice of V stays in REGISTERS (EPT elements per thread) between its passes - V is neither written
+// to nor re-read from memory (at 42 running values a slice is 18 816 elements = 19 per thread; the Michelot passes then cost
+// their exchange only).  EPT = 0: the slice goes through the V buffer (any size).
+template <int EPT>
 __global__ __launch_bounds__(LP_NT) void kp_lasso_project_kernel(const double* __restrict__ Kc, const double* __restrict__ Ko,
                                                                  const double* __restrict__ GKc, const double* __restrict__ GKo,
                                                                  const double* __restrict__ C, int64_t n, double* __restrict__ V,
@@ -334,17 +338,36 @@ __global__ __launch_bounds__(LP_NT) void kp_lasso_project_kernel(const double* _
   const double mom = st->mom, invL = st->invL, tball = st->t;
   double theta = st->theta;
   unsigned seq = seq0;
+  double vr[EPT > 0 ? EPT : 1];
   // V = Y - (G Y - C) / L and the first Newton step from the previous threshold
   double tot = 0.0, ss = 0.0, cc = 0.0;
-  for (int64_t i = i0 + tid; i < i1; i += LP_NT) {
-    const double k = Kc[i], g = GKc[i];
-    const double y = k + mom * (k - Ko[i]);
-    const double gy = g + mom * (g - GKo[i]);
-    const double v = y - (gy - C[i]) * invL;
-    V[i] = v;
-    const double a = fabs(v);
-    tot += a;
-    if (a > theta) { ss += a; cc += 1.0; }
+  if (EPT > 0) {
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int64_t i = i0 + tid + (int64_t)e * LP_NT;
+      double v = 0.0;
+      if (i < i1) {
+        const double k = Kc[i], g = GKc[i];
+        const double y = k + mom * (k - Ko[i]);
+        const double gy = g + mom * (g - GKo[i]);
+        v = y - (gy - C[i]) * invL;
+      }
+      vr[e] = v;
+      const double a = fabs(v);
+      tot += a;
+      if (a > theta) { ss += a; cc += 1.0; }
+    }
+  } else {
+    for (int64_t i = i0 + tid; i < i1; i += LP_NT) {
+      const double k = Kc[i], g = GKc[i];
+      const double y = k + mom * (k - Ko[i]);
+      const double gy = g + mom * (g - GKo[i]);
+      const double v = y - (gy - C[i]) * invL;
+      V[i] = v;
+      const double a = fabs(v);
+      tot += a;
+      if (a > theta) { ss += a; cc += 1.0; }
+    }
   }
   bool ok = lp_exchange(tot, ss, cc, 0, xc, w, wpv, ++seq, red, res);
   bool done = false;
@@ -355,9 +378,17 @@ __global__ __launch_bounds__(LP_NT) void kp_lasso_project_kernel(const double* _
   while (!done && ok && passes < LP_MAXPASS) {
     ss = 0.0; cc = 0.0;
     double z = 0.0;
-    for (int64_t i = i0 + tid; i < i1; i += LP_NT) {
-      const double a = fabs(V[i]);
-      if (a > theta) { ss += a; cc += 1.0; }
+    if (EPT > 0) {
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        const double a = fabs(vr[e]);                   // elements past the slice are 0: never above a threshold >= 0
+        if (a > theta) { ss += a; cc += 1.0; }
+      }
+    } else {
+      for (int64_t i = i0 + tid; i < i1; i += LP_NT) {
+        const double a = fabs(V[i]);
+        if (a > theta) { ss += a; cc += 1.0; }
+      }
     }
     ok = lp_exchange(ss, cc, z, 0, xc, w, wpv, ++seq, red, res);
     const double nt = cc > 0.0 ? (ss - tball) / cc : theta;
@@ -366,15 +397,32 @@ __global__ __launch_bounds__(LP_NT) void kp_lasso_project_kernel(const double* _
   }
   // Kn = soft(V, theta); restart test <Y - Kn, Kn - K> > 0; statistics
   double dot = 0.0, chg = 0.0, kmx = 0.0;
-  for (int64_t i = i0 + tid; i < i1; i += LP_NT) {
-    const double v = V[i], k = Kc[i];
-    const double a = fabs(v) - theta;
-    const double kn = a > 0.0 ? copysign(a, v) : 0.0;
-    const double y = k + mom * (k - Ko[i]);
-    Kn[i] = kn;
-    dot += (y - kn) * (kn - k);
-    chg = fmax(chg, fabs(kn - k));
-    kmx = fmax(kmx, fabs(kn));
+  if (EPT > 0) {
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const int64_t i = i0 + tid + (int64_t)e * LP_NT;
+      if (i < i1) {
+        const double v = vr[e], k = Kc[i];
+        const double a = fabs(v) - theta;
+        const double kn = a > 0.0 ? copysign(a, v) : 0.0;
+        const double y = k + mom * (k - Ko[i]);
+        Kn[i] = kn;
+        dot += (y - kn) * (kn - k);
+        chg = fmax(chg, fabs(kn - k));
+        kmx = fmax(kmx, fabs(kn));
+      }
+    }
+  } else {
+    for (int64_t i = i0 + tid; i < i1; i += LP_NT) {
+      const double v = V[i], k = Kc[i];
+      const double a = fabs(v) - theta;
+      const double kn = a > 0.0 ? copysign(a, v) : 0.0;
+      const double y = k + mom * (k - Ko[i]);
+      Kn[i] = kn;
+      dot += (y - kn) * (kn - k);
+      chg = fmax(chg, fabs(kn - k));
+      kmx = fmax(kmx, fabs(kn));
+    }
   }
   ok = lp_exchange(dot, chg, kmx, 1, xc, w, wpv, ++seq, red, res) && ok;
   if (w == 0 && tid == 0) {
@@ -761,8 +809,17 @@ int kp_lasso_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, in
     const int block_len = it == 0 ? first_check : check_every;
     for (int c = 0; c < block_len && it < max_iter; ++c, ++it) {
       if (fused && nba <= ncu) {
-        hipLaunchKernelGGL(kp_lasso_project_kernel, dim3(wpv, nba), dim3(LP_NT), 0, s, Kb[kc], Kb[ko], GKb[gc], GKb[go], C_dev, n, V, Kb[kn], st, xchg,
-                           seq);
+        // elements of a workgroup's slice per thread: in registers up to 24
+        const int64_t ept = ((n + wpv - 1) / wpv + LP_NT - 1) / LP_NT;
+        static const bool no_regs = getenv("KP_LASSO_V_IN_MEMORY") != nullptr;
+#define KP_LP_LAUNCH(E) hipLaunchKernelGGL(kp_lasso_project_kernel<E>, dim3(wpv, nba), dim3(LP_NT), 0, s, Kb[kc], Kb[ko], GKb[gc], GKb[go], C_dev, n, V, \
+                                           Kb[kn], st, xchg, seq)
+        if (no_regs || ept > 24) KP_LP_LAUNCH(0);
+        else if (ept <= 4) KP_LP_LAUNCH(4);
+        else if (ept <= 8) KP_LP_LAUNCH(8);
+        else if (ept <= 16) KP_LP_LAUNCH(16);
+        else KP_LP_LAUNCH(24);
+#undef KP_LP_LAUNCH
         seq += LP_MAXPASS + 4;
       } else {
         hipLaunchKernelGGL(kp_lasso_v_kernel, grid, dim3(256), 0, s, Kb[kc], Kb[ko], GKb[gc], GKb[go], C_dev, n, V, st);
