@@ -223,7 +223,7 @@ extern "C" int kp_comm_allgather_fits(kp_ctx* ctx, int first, int count, int W, 
   int avail = 0;                                             // valid fits from `first` on
   if (have) {
     if (ctx->kres_is_ring) {
-      if (first + count > ctx->async_count && world == 1) return ctx->fail(KP_ERR_ARG, "kp_comm_allgather_fits: range not in the result ring");
+      if (first + count > ctx->async_count && world == 1) return ctx->fail(KP_ERR_ARG, "kp_comm_allgather_fits: range not in the result ring");   // one rank: nobody else to pad for
       if (first < ctx->async_count - ctx->kring_cap) return ctx->fail(KP_ERR_ARG, "kp_comm_allgather_fits: range no longer in the result ring");
       avail = std::max(0, std::min(count, ctx->async_count - first));
     } else {
@@ -235,7 +235,7 @@ extern "C" int kp_comm_allgather_fits(kp_ctx* ctx, int first, int count, int W, 
   const bool wraps = have && ctx->kres_is_ring && slot0 + avail > ctx->kring_cap;
   const bool inside = have && !wraps && avail == count;
   double* ws = nullptr;
-  if (world > 1 || !inside) {
+  if (ctx->comm || !inside) {
     ws = (double*)ctx->workspace(8, cnt * 8 * (size_t)count * (size_t)(world + 1));
     if (!ws) return ctx->fail(KP_ERR_HIP, "kp_comm_allgather_fits: out of device memory");
   }
@@ -249,7 +249,7 @@ extern "C" int kp_comm_allgather_fits(kp_ctx* ctx, int first, int count, int W, 
     if (avail < count) KP_HIP(ctx, hipMemsetAsync(ws + (size_t)avail * cnt, 0, (size_t)(count - avail) * cnt * 8, s));
     src = ws;
   }
-  if (world == 1) {
+  if (!ctx->comm) {                               // no communicator: the gather of one (with one, a one-rank ncclAllGather runs)
     KP_HIP(ctx, hipMemcpyAsync(K_all, src, cnt * 8 * (size_t)count, hipMemcpyDeviceToHost, s));
     KP_HIP(ctx, hipStreamSynchronize(s));
     return KP_OK;

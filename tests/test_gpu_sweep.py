@@ -294,6 +294,15 @@ K = np.zeros((1, b.W, b.W))
 las = np.array([np.inf])
 F.check(F.lib().kp_fit_sharded(c2.handle, b.handle, s.handle, F.dptr(las), 1, F.dptr(K)), c2.handle)
 assert np.abs(K[0].T - Kref).max() <= 1e-12 * np.abs(Kref).max()
+# the K stack of a shard through ONE ncclAllGather from the device result buffer (kp_comm_allgather_fits): the lasso grid's gather
+from koopman_realizations_amd import sweep
+l1 = np.abs(Kref).sum()
+las3 = [np.inf, 0.5 * l1 / b.N, 0.1 * l1 / b.N]
+ref3 = kra.fit(c2, b, s, las3)
+got3 = sweep.lasso_sweep_device(c2, lambda ls: kra.fit(c2, b, s, ls, fetch=False), las3, b.W, comm)
+assert len(got3) == 3 and all(np.array_equal(x, y) for x, y in zip(ref3, got3))
+part = comm.all_gather_fits(1, 2, b.W)
+assert part.shape == (1, 2, b.W, b.W) and np.array_equal(part[0, 1].T, ref3[2])
 G = np.zeros((b.W, b.W), order="F"); Cm = np.zeros((b.W, b.W), order="F")
 F.check(F.lib().kp_fit_gram_sharded(c2.handle, b.handle, s.handle, F.dptr(G), F.dptr(Cm)), c2.handle)
 Px, Py = ko.px_py(dic, p)
