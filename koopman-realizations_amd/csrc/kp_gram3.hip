@@ -31,6 +31,9 @@
 #ifndef KP_ABL3
 #define KP_ABL3 0
 #endif
+#ifndef KP_RAW_STEP
+#define KP_RAW_STEP 1   // MFMA step of a tile behind which the raw loads of the tile after next are issued
+#endif
 #define KT3 8     // snapshots per LDS tile (two k-steps)
 #define NF3 3     // single-variable powers per column (recipes with 4 factors use the general monomial kernel)
 // LDS row (doubles): psi_x [0,96) | psi_y [96,192) | zero group [192,196) | weights [196,208) | scratch [208,240)
@@ -357,7 +360,10 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
     constexpr int QS = decltype(qs_c)::value;
     using NXT = std::integral_constant<int, 1 - CUR>;
     constexpr int PB = CUR * PSIBUF3;
-    const RawRegs rawreg = load_raw();
+    // The raw loads of the tile after next are issued INSIDE the MFMA loop (behind step KP_RAW_STEP), not here: registers the
+    // compiler has spilled are reloaded at the top of the tile, and a scratch reload behind a global load waits for that
+    // load too (vmcnt counts in order) - with the load up here every wave sat out its HBM latency at the start of every tile.
+    RawRegs rawreg;
     lift_begin(NXT{});
     double bvs[NSTEP];
     double aw[NWT];
@@ -391,6 +397,7 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
 #pragma unroll
     for (int step = 0; step < NSTEP; ++step) {
       const int kk = step / NQ, q = step % NQ;
+      if (step == (NSTEP > KP_RAW_STEP ? KP_RAW_STEP : 0)) rawreg = load_raw();
       if (q == 0) {
         weigh(avn0);
         if (QS < NQ) av1 = avn1;

@@ -292,6 +292,8 @@ static inline hipError_t kp_symm_gemm_small(hipStream_t st, const double* G, con
 // variant: 0 = by shape; 1 = small-column kernel; 2 / 3 = tiled kernel with 32 / 64 columns per workgroup
 static inline hipError_t kp_symm_gemm2(hipStream_t st, const double* G, const double* X, int W, int nc, double* C, int variant = 0) {
   if (W <= 0 || nc <= 0) return hipSuccess;
+  // the tiled kernel addresses X with 32-bit byte offsets from a uniform base (one VGPR per staged row)
+  if ((uint64_t)nc * (uint64_t)W * 8u >= (1ull << 32)) variant = 1;
   if (variant == 0) {
     const int64_t cols_rows = (int64_t)nc * ((W + 15) / 16);      // 16-row x 1-column units of output
     variant = W < 48 || cols_rows <= SG2_SMALL_UNITS ? 1 : cols_rows <= SG2_MID_UNITS ? 2 : 3;
