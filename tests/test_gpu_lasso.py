@@ -136,3 +136,40 @@ def test_the_64_value_grid_of_configs3_is_optimal_value_by_value(ctx, config3):
     # sparsity grows monotonically as the budget shrinks (up to ties)
     nnz = [int((K != 0).sum()) for K in Ks[:42]]
     assert all(a <= b_ + 2 for a, b_ in zip(nnz[:-1], nnz[1:])), nnz
+
+
+def test_bench_timers_of_the_fit_and_lasso_paths(ctx, config3):
+    """kp_timer_get 10: flop per pair the fused Gram launch EXECUTES on the matrix pipe (what bench.py's roofline.frac is
+    priced with): 28 jobs x 6 quads x 10 weights x 128 = 215 040 at the configs[1] dictionary - 63 % of the dense-equivalent
+    W(W+1) + 2W^2 = 339 024.  Timers 8 / 9: the widest product of the last lasso batch and its columns."""
+    b, snaps, G, C, l1 = config3["basis"], config3["snaps"], config3["G"], config3["C"], config3["l1"]
+    kra.fit_gram(ctx, b, snaps, fetch=False)
+    assert ctx.timer(10) == 215040.0 and ctx.timer(0) > 0
+    ctx.fit_lasso_batch(G, C, np.array([0.5, 0.3, 0.1]) * l1)
+    assert ctx.timer(9) == 3 * 336 and 0 < ctx.timer(8) < 5.0
+
+
+def test_one_shot_polish_without_active_set_rounds_gives_the_same_optimum(ctx, config3, monkeypatch):
+    """KP_LASSO_ROUNDS is read once per process, so the round-free path is exercised in a fresh interpreter: same optimum to
+    1e-9, more iterations."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    G, C, l1 = config3["G"], config3["C"], config3["l1"]
+    Kr, itr = ctx.fit_lasso_batch(G, C, [0.2 * l1])
+    script = ("import sys, numpy as np; sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + '/tests')\n"
+              "import koopman_realizations_amd as kra\n"
+              "d = np.load(sys.argv[2]); c = kra.Context(0)\n"
+              "K, it = c.fit_lasso_batch(d['G'], d['C'], [float(d['t'])])\n"
+              "np.savez(sys.argv[3], K=K[0], it=it[0])\n")
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        np.savez(os.path.join(td, "in.npz"), G=G, C=C, t=0.2 * l1)
+        env = dict(os.environ, KP_LASSO_ROUNDS="0")
+        r = subprocess.run([sys.executable, "-c", script, root, os.path.join(td, "in.npz"), os.path.join(td, "out.npz")], env=env,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        o = np.load(os.path.join(td, "out.npz"))
+        assert np.abs(o["K"] - Kr[0]).max() <= 1e-9 * np.abs(Kr[0]).max()
+        assert int(o["it"]) >= int(itr[0])
