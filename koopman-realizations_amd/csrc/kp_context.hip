@@ -60,6 +60,7 @@ extern "C" int kp_create(int device_id, kp_ctx** out) {
   (void)hipEventCreateWithFlags(&c->ev_solve0, evf);
   (void)hipEventCreateWithFlags(&c->ev_solve1, evf);
   if (hipMalloc((void**)&c->sticky_info, sizeof(int)) == hipSuccess) (void)hipMemset(c->sticky_info, 0, sizeof(int));
+  if (hipHostMalloc((void**)&c->pin_small, 64, hipHostMallocDefault) != hipSuccess) c->pin_small = nullptr;
   hipDeviceProp_t p;
   if (hipGetDeviceProperties(&p, device_id) == hipSuccess) {
     c->num_cu = p.multiProcessorCount;
@@ -80,6 +81,7 @@ extern "C" int kp_destroy(kp_ctx* c) {
   for (int i = 0; i < 10; ++i)
     if (c->ws[i]) (void)hipFree(c->ws[i]);
   if (c->sticky_info) (void)hipFree(c->sticky_info);
+  if (c->pin_small) (void)hipHostFree(c->pin_small);
   if (c->ev_gram_done) (void)hipEventDestroy(c->ev_gram_done);
   if (c->ev_pad_done) (void)hipEventDestroy(c->ev_pad_done);
   if (c->ev_pad_done2) (void)hipEventDestroy(c->ev_pad_done2);

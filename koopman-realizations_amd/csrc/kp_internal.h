@@ -56,6 +56,7 @@ struct kp_ctx {
   int part_flip = 0;
   int reduce_timed_from = 1;   // evp index that marks the start of the last partial reduction
   int* sticky_info = nullptr;       // device word: set by any deferred factorisation that hit a non-positive pivot
+  double* pin_small = nullptr;      // 64 bytes of page-locked host memory: small results (info word + pivot ratio) come back in ONE direct DMA
   int reserve_cus = 0;              // CUs left free by the Gram grid so the solve of the previous fit can run beside it
   int num_cu = 0;
   int64_t hbm_bytes = 0;
