@@ -82,6 +82,7 @@ extern "C" int kp_destroy(kp_ctx* c) {
     if (c->ws[i]) (void)hipFree(c->ws[i]);
   if (c->sticky_info) (void)hipFree(c->sticky_info);
   if (c->pin_small) (void)hipHostFree(c->pin_small);
+  if (c->pin_scratch) (void)hipHostFree(c->pin_scratch);
   if (c->ev_gram_done) (void)hipEventDestroy(c->ev_gram_done);
   if (c->ev_pad_done) (void)hipEventDestroy(c->ev_pad_done);
   if (c->ev_pad_done2) (void)hipEventDestroy(c->ev_pad_done2);
@@ -131,6 +132,23 @@ extern "C" int kp_device_info(const kp_ctx* c, char* name, int name_len, int* nu
   if (num_cu) *num_cu = c->num_cu;
   if (hbm) *hbm = c->hbm_bytes;
   return KP_OK;
+}
+
+void* kp_pinned_scratch(kp_ctx* ctx, size_t bytes) {
+  if (ctx->pin_scratch_bytes >= bytes) return ctx->pin_scratch;
+  if (ctx->pin_scratch) {
+    (void)hipStreamSynchronize(ctx->stream);            // no DMA into the old block may still be in flight
+    (void)hipHostFree(ctx->pin_scratch);
+  }
+  ctx->pin_scratch = nullptr;
+  ctx->pin_scratch_bytes = 0;
+  const size_t cap = (bytes + 4095) & ~(size_t)4095;
+  if (hipHostMalloc(&ctx->pin_scratch, cap, hipHostMallocDefault) != hipSuccess) {
+    ctx->pin_scratch = nullptr;
+    return nullptr;
+  }
+  ctx->pin_scratch_bytes = cap;
+  return ctx->pin_scratch;
 }
 
 extern "C" int kp_timer_get(const kp_ctx* c, int which, double* ms) {

@@ -56,6 +56,8 @@ struct kp_ctx {
   int part_flip = 0;
   int reduce_timed_from = 1;   // evp index that marks the start of the last partial reduction
   int* sticky_info = nullptr;       // device word: set by any deferred factorisation that hit a non-positive pivot
+  void* pin_scratch = nullptr;      // growable page-locked host scratch (kp_pinned_scratch): small results read back by direct DMA
+  size_t pin_scratch_bytes = 0;
   double* pin_small = nullptr;      // 64 bytes of page-locked host memory: small results (info word + pivot ratio) come back in ONE direct DMA
   int reserve_cus = 0;              // CUs left free by the Gram grid so the solve of the previous fit can run beside it
   int num_cu = 0;
@@ -177,6 +179,8 @@ struct kp_snapshots {
   mutable bool dma_pending = false, read_pending = false;
   bool streaming = false;
 };
+// page-locked host scratch of at least `bytes` (contents not preserved across calls that grow it); nullptr on failure
+void* kp_pinned_scratch(kp_ctx* ctx, size_t bytes);
 void kp_stage_destroy(kp_ctx* ctx);
 void kp_host_free_all(kp_ctx* ctx);
 // Around every launch sequence that reads a snapshot object.  All readers run on ctx->stream, so one wait orders the

@@ -619,6 +619,19 @@ __global__ void kp_lasso_ctl_kernel(LassoState* __restrict__ stv, int nb) {
   st->notconv = 0; st->maxpasses = 0; st->pol_bad = 0; st->pol_res = 0ull; st->pol_nchg = 0; st->pol_on = 1;
 }
 
+// what the host reads after a block / round: the head of every running value's state (everything in front of the partial-sum
+// slots) and the time-out word of its exchange area, packed into 128-byte records - ONE small direct DMA into page-locked
+// memory instead of two strided copies into pageable buffers
+#define LS_REC 128
+__global__ void kp_lasso_pack_kernel(const LassoState* __restrict__ stv, const LassoXchg* __restrict__ xcv, int nb, int head, char* __restrict__ out) {
+  const int v = blockIdx.x, t = threadIdx.x;              // 32 threads x 4 bytes
+  if (v >= nb) return;
+  unsigned w = 0u;
+  if (4 * t < head) w = ((const unsigned*)(stv + v))[t];
+  else if (4 * t == LS_REC - 8) w = xcv ? xcv[v].timeout : 0u;
+  ((unsigned*)(out + (size_t)v * LS_REC))[t] = w;
+}
+
 // between the active-set rounds of one check: the values in `on` go on, their round statistics are cleared
 __global__ void kp_lasso_round_kernel(LassoState* __restrict__ stv, int nb, const int* __restrict__ on) {
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
@@ -756,7 +769,9 @@ int kp_lasso_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, in
   // buffers, nb matrices each: K x3 (old, current, new), GK x2, V, polish A / B / G Kh; per-column sums; states
   const size_t bB = (size_t)nb * bK;
   const size_t b_pab = (size_t)nb * ncols * 2 * 8, b_st = (size_t)nb * sizeof(LassoState), b_xc = (size_t)nb * sizeof(LassoXchg);
-  char* ws = (char*)ctx->workspace(7, 9 * bB + b_pab + b_st + b_xc + (size_t)nb * 4 + 1024);
+  char* ws = (char*)ctx->workspace(7, 9 * bB + b_pab + b_st + b_xc + (size_t)nb * 4 + (size_t)nb * LS_REC + 1024 + 256);
+  char* hrec = (char*)kp_pinned_scratch(ctx, (size_t)nb * LS_REC + (size_t)nb * 4);   // page-locked: records, then the round's `on` flags
+  if (!hrec) return ctx->fail(KP_ERR_HIP, "kp_fit_lasso: out of page-locked host memory");
   if (!ws) return ctx->fail(KP_ERR_HIP, "kp_fit_lasso: out of device memory");
   double* Kb[3] = {(double*)ws, (double*)(ws + bB), (double*)(ws + 2 * bB)};
   double* GKb[2] = {(double*)(ws + 3 * bB), (double*)(ws + 4 * bB)};
@@ -792,6 +807,8 @@ int kp_lasso_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, in
   static const int as_rounds = [] { const char* e = getenv("KP_LASSO_ROUNDS"); return e ? std::max(0, atoi(e)) : 8; }();
   const int as_cap = (int)std::max<int64_t>(64, n / 8);     // more exchanges than this: the iterate is not near the optimum yet
   int* on_dev = (int*)((char*)xchg + b_xc);
+  char* rec_dev = (char*)(((uintptr_t)(on_dev + nb) + 255) & ~(uintptr_t)255);
+  int* on_host = (int*)(hrec + (size_t)nb * LS_REC);
   // Values that have their answer leave the batch: the running values occupy slots [0, nba) of every buffer (the last
   // running slot is moved into the hole), so the wide product and every grid shrink with the work that is left.
   int nba = nb;
@@ -848,9 +865,18 @@ int kp_lasso_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, in
       return KP_OK;
     };
     auto read_states = [&]() -> int {
+      static_assert(offsetof(LassoState, part) <= LS_REC - 8, "state head does not fit the packed record");
+      hipLaunchKernelGGL(kp_lasso_pack_kernel, dim3(nba), dim3(32), 0, s, st, fused ? xchg : (const LassoXchg*)nullptr, nba, (int)head, rec_dev);
       KP_HIP(ctx, hipGetLastError());
-      KP_HIP(ctx, hipMemcpy2DAsync(hbuf.data(), sizeof(LassoState), st, sizeof(LassoState), head, nba, hipMemcpyDeviceToHost, s));
+      KP_HIP(ctx, hipMemcpyAsync(hrec, rec_dev, (size_t)nba * LS_REC, hipMemcpyDeviceToHost, s));
       return KP_OK;
+    };
+    // after the synchronisation: records -> the host copies of the states
+    auto unpack_states = [&](std::vector<unsigned>* touts) {
+      for (int v = 0; v < nba; ++v) {
+        memcpy(&hs(v), hrec + (size_t)v * LS_REC, head);
+        if (touts) memcpy(&(*touts)[v], hrec + (size_t)v * LS_REC + LS_REC - 8, 4);
+      }
     };
     auto accepted = [&](const LassoState& h) {
       const double pres = __builtin_bit_cast(double, h.pol_res);
@@ -894,9 +920,8 @@ int kp_lasso_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, in
       if (rc) return rc;
     }
     std::vector<unsigned> touts(nba, 0u);
-    if (fused)
-      KP_HIP(ctx, hipMemcpy2DAsync(touts.data(), sizeof(unsigned), &xchg[0].timeout, sizeof(LassoXchg), sizeof(unsigned), nba, hipMemcpyDeviceToHost, s));
     KP_HIP(ctx, hipStreamSynchronize(s));
+    unpack_states(&touts);
     if (gemm_timed_cols) {
       float gms = 0;
       if (hipEventElapsedTime(&gms, ctx->evp[4], ctx->evp[5]) == hipSuccess) { ctx->timers[8] = gms; ctx->timers[9] = gemm_timed_cols; }
@@ -928,13 +953,15 @@ int kp_lasso_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, in
           fprintf(stderr, "\n");
         }
         if (!n_on) break;
-        KP_HIP(ctx, hipMemcpyAsync(on_dev, on.data(), (size_t)nba * 4, hipMemcpyHostToDevice, s));
+        memcpy(on_host, on.data(), (size_t)nba * 4);
+        KP_HIP(ctx, hipMemcpyAsync(on_dev, on_host, (size_t)nba * 4, hipMemcpyHostToDevice, s));
         hipLaunchKernelGGL(kp_lasso_round_kernel, dim3((nba + 63) / 64), dim3(64), 0, s, st, nba, on_dev);
         int rc = polish_round(V);
         if (rc) return rc;
         rc = read_states();
         if (rc) return rc;
         KP_HIP(ctx, hipStreamSynchronize(s));
+        unpack_states(nullptr);
         rc = retire();
         if (rc) return rc;
       }
