@@ -619,6 +619,20 @@ __global__ void kp_lasso_ctl_kernel(LassoState* __restrict__ stv, int nb) {
   st->notconv = 0; st->maxpasses = 0; st->pol_bad = 0; st->pol_res = 0ull; st->pol_nchg = 0; st->pol_on = 1;
 }
 
+// Device-to-device copies of a retirement pass (answers to their destinations, the last running slots into the holes) as ONE
+// launch per 48 copies instead of one runtime copy command each (about 200 per 64-value grid, 3 us apiece).  The copies of a
+// pass never overlap each other's sources (a slot moved into a hole has been examined and is a survivor) except through the
+// ORDER of the old implementation: answer out first, then the move into that slot - kept by running answers and moves as
+// separate launches.
+#define LS_COPIES 48
+struct LassoCopyList { const double* src[LS_COPIES]; double* dst[LS_COPIES]; long long n[LS_COPIES]; };
+__global__ __launch_bounds__(256) void kp_lasso_copy_kernel(LassoCopyList l) {
+  const double* __restrict__ s = l.src[blockIdx.y];
+  double* __restrict__ d = l.dst[blockIdx.y];
+  const long long n = l.n[blockIdx.y];
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) d[i] = s[i];
+}
+
 // what the host reads after a block / round: the head of every running value's state (everything in front of the partial-sum
 // slots) and the time-out word of its exchange area, packed into 128-byte records - ONE small direct DMA into page-locked
 // memory instead of two strided copies into pageable buffers
@@ -885,7 +899,24 @@ int kp_lasso_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, in
     std::vector<int> last_chg(nba, 1 << 29);
     // values that have their answer leave the batch (the last running slot moves into the hole: iterates, products, the
     // pattern of the active-set rounds and the state)
+    std::vector<std::pair<const double*, double*>> cp_out, cp_mv;      // (source, destination), bK bytes each
+    auto flush_copies = [&](std::vector<std::pair<const double*, double*>>& v) -> int {
+      for (size_t i0 = 0; i0 < v.size(); i0 += LS_COPIES) {
+        LassoCopyList l;
+        const int cnt = (int)std::min<size_t>(LS_COPIES, v.size() - i0);
+        for (int k = 0; k < cnt; ++k) { l.src[k] = v[i0 + k].first; l.dst[k] = v[i0 + k].second; l.n[k] = (long long)n; }
+        hipLaunchKernelGGL(kp_lasso_copy_kernel, dim3((unsigned)std::min<int64_t>(64, (n + 255) / 256), cnt), dim3(256), 0, s, l);
+        KP_HIP(ctx, hipGetLastError());
+      }
+      v.clear();
+      return KP_OK;
+    };
     auto retire = [&]() -> int {
+      // Moves are chained through slots (the slot moved into hole v may itself be moved again when a lower slot retires), so
+      // the SOURCE of every copy is resolved to where the data lies before this pass: `where[slot]` = original slot index.
+      std::vector<int> where(nba);
+      for (int v = 0; v < nba; ++v) where[v] = v;
+      const int nba0 = nba;
       for (int v = nba - 1; v >= 0; --v) {             // downwards: the slot moved into a hole has been examined already
         const LassoState& h = hs(v);
         const double pres = __builtin_bit_cast(double, h.pol_res);
@@ -896,12 +927,12 @@ int kp_lasso_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, in
                   slot_val[v], h.pol_bad, h.pol_theta, pres, h.pol_nchg, h.theta, h.change, h.kmax, h.maxpasses, h.restarts,
                   pol_ok ? " -> polished" : conv ? " -> converged" : "");
         if (!(pol_ok || conv)) continue;
-        KP_HIP(ctx, hipMemcpyAsync(K_dev[slot_val[v]], (pol_ok ? Kb[kn] : Kb[kc]) + (size_t)v * n, bK, hipMemcpyDeviceToDevice, s));
+        // the answer lies where slot v's data lay at the start of the pass (where[v]); Kh of a slot is never moved
+        cp_out.push_back({(pol_ok ? Kb[kn] + (size_t)v * n : Kb[kc] + (size_t)where[v] * n), K_dev[slot_val[v]]});
         if (iters) iters[slot_val[v]] = it;
         const int last = nba - 1;
         if (v != last) {
-          double* mv[5] = {Kb[ko], Kb[kc], GKb[go], GKb[gc], V};
-          for (double* bsrc : mv) KP_HIP(ctx, hipMemcpyAsync(bsrc + (size_t)v * n, bsrc + (size_t)last * n, bK, hipMemcpyDeviceToDevice, s));
+          where[v] = where[last];
           KP_HIP(ctx, hipMemcpyAsync(st + v, st + last, head, hipMemcpyDeviceToDevice, s));
           memcpy(&hs(v), &hs(last), head);
           slot_val[v] = slot_val[last];
@@ -909,7 +940,17 @@ int kp_lasso_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, in
         }
         --nba;
       }
-      return KP_OK;
+      // answers first (they read slots that the moves below overwrite), then every surviving slot that changed place - straight
+      // from its original position
+      int rc = flush_copies(cp_out);
+      if (rc) return rc;
+      for (int v = 0; v < nba; ++v)
+        if (where[v] != v) {
+          double* mv[5] = {Kb[ko], Kb[kc], GKb[go], GKb[gc], V};
+          for (double* bsrc : mv) cp_mv.push_back({bsrc + (size_t)where[v] * n, bsrc + (size_t)v * n});
+        }
+      (void)nba0;
+      return flush_copies(cp_mv);
     };
     if (polish) {
       const int rc = polish_round(Kb[kc]);
