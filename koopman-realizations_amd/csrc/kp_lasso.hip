@@ -802,7 +802,27 @@ int kp_lasso_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, in
   static const bool fused_env = getenv("KP_LASSO_NO_FUSED") == nullptr;
   bool fused = fused_env;
   unsigned seq = 0;
-  KP_HIP(ctx, hipMemsetAsync(ws, 0, 5 * bB, s));                  // FISTA from K = 0
+  KP_HIP(ctx, hipMemsetAsync(ws, 0, 5 * bB, s));                  // FISTA from K = 0 ...
+  // ... unless the least-squares solution is usable: with old = current = K_LS and both products = G K_LS = C the first
+  // step has zero gradient and zero momentum, so its projection IS proj_{L1 <= t}(K_LS) - the soft-thresholded LS solution,
+  // whose support is close to the answer's for budgets near |K_LS|_1 and no worse than zero for small ones
+  static const bool cold_start = getenv("KP_LASSO_COLD_START") != nullptr;
+  if (!cold_start && !prep->bad) {
+    std::vector<std::pair<const double*, double*>> init;
+    for (int v = 0; v < nb; ++v) {
+      init.push_back({prep->Kls, (double*)ws + (size_t)v * n});                       // K old
+      init.push_back({prep->Kls, (double*)(ws + bB) + (size_t)v * n});                // K current
+      init.push_back({C_dev, (double*)(ws + 3 * bB) + (size_t)v * n});                // G K old
+      init.push_back({C_dev, (double*)(ws + 4 * bB) + (size_t)v * n});                // G K current
+    }
+    for (size_t i0 = 0; i0 < init.size(); i0 += LS_COPIES) {
+      LassoCopyList l;
+      const int cnt = (int)std::min<size_t>(LS_COPIES, init.size() - i0);
+      for (int k = 0; k < cnt; ++k) { l.src[k] = init[i0 + k].first; l.dst[k] = init[i0 + k].second; l.n[k] = (long long)n; }
+      hipLaunchKernelGGL(kp_lasso_copy_kernel, dim3((unsigned)std::min<int64_t>(64, (n + 255) / 256), cnt), dim3(256), 0, s, l);
+    }
+    KP_HIP(ctx, hipGetLastError());
+  }
   const size_t head = offsetof(LassoState, part);
   std::vector<char> hbuf(b_st, 0);
   auto hs = [&](int v) -> LassoState& { return *reinterpret_cast<LassoState*>(hbuf.data() + (size_t)v * sizeof(LassoState)); };
@@ -817,7 +837,7 @@ int kp_lasso_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, in
   int it = 0;
   static const int check_every = [] { const char* e = getenv("KP_LASSO_CHECK"); return e ? std::max(1, atoi(e)) : 10; }();
   static const bool polish = getenv("KP_LASSO_NO_POLISH") == nullptr;
-  static const int first_check = [] { const char* e = getenv("KP_LASSO_FIRST_CHECK"); return e ? std::max(1, atoi(e)) : check_every; }();
+  static const int first_check = [] { const char* e = getenv("KP_LASSO_FIRST_CHECK"); return e ? std::max(1, atoi(e)) : (getenv("KP_LASSO_COLD_START") ? check_every : 4); }();
   static const int as_rounds = [] { const char* e = getenv("KP_LASSO_ROUNDS"); return e ? std::max(0, atoi(e)) : 8; }();
   const int as_cap = (int)std::max<int64_t>(64, n / 8);     // more exchanges than this: the iterate is not near the optimum yet
   int* on_dev = (int*)((char*)xchg + b_xc);

@@ -149,9 +149,11 @@ def test_bench_timers_of_the_fit_and_lasso_paths(ctx, config3):
     assert ctx.timer(9) == 3 * 336 and 0 < ctx.timer(8) < 5.0
 
 
-def test_one_shot_polish_without_active_set_rounds_gives_the_same_optimum(ctx, config3, monkeypatch):
-    """KP_LASSO_ROUNDS is read once per process, so the round-free path is exercised in a fresh interpreter: same optimum to
-    1e-9, more iterations."""
+@pytest.mark.parametrize("knob", [{"KP_LASSO_ROUNDS": "0"}, {"KP_LASSO_COLD_START": "1"}], ids=["no_rounds", "cold_start"])
+def test_one_shot_polish_without_active_set_rounds_gives_the_same_optimum(ctx, config3, knob):
+    """KP_LASSO_ROUNDS / KP_LASSO_COLD_START are read once per process, so the round-free path and the start from K = 0
+    (default: from the least-squares solution) are exercised in a fresh interpreter: same optimum to 1e-9, no fewer
+    iterations."""
     import os
     import subprocess
     import sys
@@ -166,7 +168,7 @@ def test_one_shot_polish_without_active_set_rounds_gives_the_same_optimum(ctx, c
     import tempfile
     with tempfile.TemporaryDirectory() as td:
         np.savez(os.path.join(td, "in.npz"), G=G, C=C, t=0.2 * l1)
-        env = dict(os.environ, KP_LASSO_ROUNDS="0")
+        env = dict(os.environ, **knob)
         r = subprocess.run([sys.executable, "-c", script, root, os.path.join(td, "in.npz"), os.path.join(td, "out.npz")], env=env,
                            capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
