@@ -655,52 +655,66 @@ __global__ void kp_lasso_round_kernel(LassoState* __restrict__ stv, int nb, cons
   if (on[v]) { st->pol_bad = 0; st->pol_res = 0ull; st->pol_nchg = 0; }
 }
 
-__global__ __launch_bounds__(256) void kp_l1norm_kernel(const double* __restrict__ K, int64_t n, double* out) {
+// Deterministic two-stage sums: KP_RED_PARTS workgroups write one partial each (SQ: squares, else absolute values), one wave
+// adds them in a fixed order.  (Round 2 summed the 1e5-element arrays of a lasso fit in ONE workgroup: 0.10 / 0.03 ms each.)
+#define KP_RED_PARTS 64
+template <bool SQ>
+__global__ __launch_bounds__(256) void kp_reduce_partial_kernel(const double* __restrict__ A, int64_t n, double* __restrict__ part) {
   __shared__ double r[4];
   double s = 0.0;
-  for (int64_t i = threadIdx.x; i < n; i += 256) s += fabs(K[i]);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)KP_RED_PARTS * 256) {
+    const double a = A[i];
+    s += SQ ? a * a : fabs(a);
+  }
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) r[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) out[0] = r[0] + r[1] + r[2] + r[3];
+  if (threadIdx.x == 0) part[blockIdx.x] = r[0] + r[1] + r[2] + r[3];
+}
+__global__ __launch_bounds__(64) void kp_reduce_final_kernel(const double* __restrict__ part, double* __restrict__ out) {
+  const double s = wave_sum(part[threadIdx.x]);
+  if (threadIdx.x == 0) out[0] = s;
 }
 
-__global__ void kp_add_diag_kernel(double* G, int W, double v) {
+__global__ void kp_lasso_prep_pack_kernel(const int* __restrict__ info, const double* __restrict__ l1, double* __restrict__ out) {
+  out[0] = l1[0];
+  out[1] = info[0] != 0 ? 1.0 : 0.0;
+}
+__global__ void kp_add_diag_if_kernel(double* G, int W, double v, const int* __restrict__ flag) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < W) G[i + (size_t)i * W] += v;
+  if (i < W && flag[0] != 0) G[i + (size_t)i * W] += v;
 }
 
-// |A|_F of an n2-element array by one workgroup; acc[0] += weight * log |A|_F, nrm[0] = |A|_F (init: acc[0] starts at 0)
-__global__ __launch_bounds__(1024) void kp_frob_kernel(const double* __restrict__ A, int64_t n2, double weight, int init, double* __restrict__ acc,
-                                                       double* __restrict__ nrm) {
-  __shared__ double red[16];
-  double s = 0.0;
-  for (int64_t i = threadIdx.x; i < n2; i += 1024) s += A[i] * A[i];
-  s = wave_sum(s);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double t = 0.0;
-    for (int q = 0; q < 16; ++q) t += red[q];
-    const double nr = sqrt(t);
-    nrm[0] = nr;
-    acc[0] = (init ? 0.0 : acc[0]) + weight * log(nr);
-  }
-}
-__global__ __launch_bounds__(256) void kp_scale_inv_kernel(double* __restrict__ A, int64_t n2, const double* __restrict__ nrm) {
+// A *= 1 / sqrt(sumsq[0])
+__global__ __launch_bounds__(256) void kp_scale_inv_kernel(double* __restrict__ A, int64_t n2, const double* __restrict__ sumsq) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const double inv = 1.0 / nrm[0];
+  const double inv = 1.0 / sqrt(sumsq[0]);
   if (i < n2) A[i] *= inv;
 }
-__global__ void kp_exp_kernel(const double* __restrict__ acc, double* __restrict__ out) {
-  out[0] = exp(acc[0]) * (1.0 + 1e-12);
+// out = |G|_F |A_K|_F^(1 / 2^K) (1 + 1e-12) from the two sums of squares; an underflowed |A_K|_F leaves the Frobenius bound
+__global__ void kp_exp_kernel(const double* __restrict__ ss0, const double* __restrict__ ssK, double inv_pow, double* __restrict__ out) {
+  const double f = sqrt(ss0[0]);
+  out[0] = (ssK[0] > 0.0 ? f * exp(0.5 * inv_pow * log(ssK[0])) : f) * (1.0 + 1e-12);
+}
+
+// (source, destination) pairs of n doubles each, LS_COPIES per launch
+static int lasso_copies(kp_ctx* ctx, hipStream_t s, std::vector<std::pair<const double*, double*>>& v, int64_t n) {
+  for (size_t i0 = 0; i0 < v.size(); i0 += LS_COPIES) {
+    LassoCopyList l;
+    const int cnt = (int)std::min<size_t>(LS_COPIES, v.size() - i0);
+    for (int k = 0; k < cnt; ++k) { l.src[k] = v[i0 + k].first; l.dst[k] = v[i0 + k].second; l.n[k] = (long long)n; }
+    hipLaunchKernelGGL(kp_lasso_copy_kernel, dim3((unsigned)std::min<int64_t>(64, (n + 255) / 256), cnt), dim3(256), 0, s, l);
+    KP_HIP(ctx, hipGetLastError());
+  }
+  v.clear();
+  return KP_OK;
 }
 
 // Least-squares solution + its L1 norm, PSD guard and Lipschitz constant: shared by all lasso values of one fit.
 int kp_lasso_prepare(kp_ctx* ctx, const double* G_dev, const double* C_dev, int W, int ncols, kp_lasso_prep* p) {
   const int64_t n = (int64_t)W * ncols;
   const size_t bK = (size_t)n * 8, bG = (size_t)W * W * 8;
-  char* ws = (char*)ctx->workspace(3, bK + 3 * bG + (size_t)2 * W * 8 + 256);
+  char* ws = (char*)ctx->workspace(3, bK + 3 * bG + (size_t)2 * W * 8 + 1024);
   if (!ws) return ctx->fail(KP_ERR_HIP, "kp_fit_lasso: out of device memory");
   p->Kls = (double*)ws;
   p->Gw = (double*)(ws + bK);
@@ -715,20 +729,19 @@ int kp_lasso_prepare(kp_ctx* ctx, const double* G_dev, const double* C_dev, int 
   KP_HIP(ctx, hipMemcpyAsync(p->Gw, G_dev, bG, hipMemcpyDeviceToDevice, s));
   int rc = kp_chol_solve_dev(ctx, p->Gw, const_cast<double*>(C_dev), W, ncols, p->Kls);
   if (rc) return rc;
-  hipLaunchKernelGGL(kp_l1norm_kernel, dim3(1), dim3(256), 0, s, p->Kls, n, scal);
-  {
-    const size_t off = kp_chol_info_offset(W, ncols);
-    KP_HIP(ctx, hipMemcpyAsync(&p->bad, (char*)ctx->ws[5] + off, sizeof(int), hipMemcpyDeviceToHost, s));
-  }
-  KP_HIP(ctx, hipMemcpyAsync(&p->l1_ls, scal, 8, hipMemcpyDeviceToHost, s));
-  KP_HIP(ctx, hipStreamSynchronize(s));
-  // PSD guard of Ksysid.m:1117-1120: a non-PD Gram gets 1e-6 on the diagonal
-  if (p->bad) hipLaunchKernelGGL(kp_add_diag_kernel, dim3((W + 255) / 256), dim3(256), 0, s, p->Gw, W, 1e-6);
+  double* part = scal + 8;                        // KP_RED_PARTS partial sums
+  hipLaunchKernelGGL(kp_reduce_partial_kernel<false>, dim3(KP_RED_PARTS), dim3(256), 0, s, p->Kls, n, part);
+  hipLaunchKernelGGL(kp_reduce_final_kernel, dim3(1), dim3(64), 0, s, part, scal);
+  const int* info_dev = (const int*)((char*)ctx->ws[5] + kp_chol_info_offset(W, ncols));
+  hipLaunchKernelGGL(kp_lasso_prep_pack_kernel, dim3(1), dim3(1), 0, s, info_dev, scal, scal + 3);   // scal[3] = |K_LS|_1, scal[4] = info
+  // PSD guard of Ksysid.m:1117-1120: a non-PD Gram gets 1e-6 on the diagonal (decided on the device: no host round trip here)
+  hipLaunchKernelGGL(kp_add_diag_if_kernel, dim3((W + 255) / 256), dim3(256), 0, s, p->Gw, W, 1e-6, info_dev);
   // Lipschitz constant of the gradient = lambda_max(G).  Round 2: 60 power iterations (120 launches, 0.7 ms) whose estimate
   // approaches lambda_max from BELOW.  Now an UPPER bound by repeated squaring on the matrix pipe: A_0 = G / |G|_F,
-  // A_k = A_(k-1)^2 / n_k with n_k = |A_(k-1)^2|_F (powers of a symmetric matrix stay symmetric: the product kernel's
-  // premise); lambda_max(A_K) <= |A_K|_F = 1 unwinds to  lambda_max(G) <= |G|_F exp(sum_k log n_k / 2^k), which exceeds
-  // lambda_max by at most the factor rank^(1 / 2^(K+1)) (K = 6: <= 1.05 at W = 336, a few 1e-3 for the spectra met here).
+  // A_k = A_(k-1)^2 (powers of a symmetric matrix stay symmetric: the product kernel's premise);
+  // lambda_max(A_0)^(2^K) = lambda_max(A_K) <= |A_K|_F, so lambda_max(G) <= |G|_F |A_K|_F^(1 / 2^K), which exceeds lambda_max
+  // by at most the factor rank^(1 / 2^(K+1)) (K = 6: <= 1.05 at W = 336, a few 1e-3 for the spectra met here).  No
+  // normalisation between the squarings: lambda_max(A_0) >= W^(-1/2), so |A_6|_F >= W^(-32) - far inside the f64 range.
   static const bool power_it = getenv("KP_LASSO_POWER_IT") != nullptr;
   if (power_it) {
     hipLaunchKernelGGL(kp_pw_norm_kernel, dim3(1), dim3(256), 0, s, yv, W, vec, scal, 1);
@@ -740,20 +753,25 @@ int kp_lasso_prepare(kp_ctx* ctx, const double* G_dev, const double* C_dev, int 
     const int64_t n2 = (int64_t)W * W;
     const unsigned nblk = (unsigned)((n2 + 255) / 256);
     KP_HIP(ctx, hipMemcpyAsync(Pa, p->Gw, bG, hipMemcpyDeviceToDevice, s));
-    hipLaunchKernelGGL(kp_frob_kernel, dim3(1), dim3(1024), 0, s, Pa, n2, 1.0, 1, scal + 1, scal + 2);
-    hipLaunchKernelGGL(kp_scale_inv_kernel, dim3(nblk), dim3(256), 0, s, Pa, n2, scal + 2);
-    double wgt = 0.5;
-    for (int k = 0; k < 6; ++k, wgt *= 0.5) {
+    hipLaunchKernelGGL(kp_reduce_partial_kernel<true>, dim3(KP_RED_PARTS), dim3(256), 0, s, Pa, n2, part);
+    hipLaunchKernelGGL(kp_reduce_final_kernel, dim3(1), dim3(64), 0, s, part, scal + 1);
+    hipLaunchKernelGGL(kp_scale_inv_kernel, dim3(nblk), dim3(256), 0, s, Pa, n2, scal + 1);
+    const int K2 = 6;
+    for (int k = 0; k < K2; ++k) {
       KP_HIP(ctx, symm_gemm(s, Pa, Pa, W, W, Pb));
-      hipLaunchKernelGGL(kp_frob_kernel, dim3(1), dim3(1024), 0, s, Pb, n2, wgt, 0, scal + 1, scal + 2);
-      hipLaunchKernelGGL(kp_scale_inv_kernel, dim3(nblk), dim3(256), 0, s, Pb, n2, scal + 2);
       std::swap(Pa, Pb);
     }
-    hipLaunchKernelGGL(kp_exp_kernel, dim3(1), dim3(1), 0, s, scal + 1, scal);
+    hipLaunchKernelGGL(kp_reduce_partial_kernel<true>, dim3(KP_RED_PARTS), dim3(256), 0, s, Pa, n2, part);
+    hipLaunchKernelGGL(kp_reduce_final_kernel, dim3(1), dim3(64), 0, s, part, scal + 2);
+    hipLaunchKernelGGL(kp_exp_kernel, dim3(1), dim3(1), 0, s, scal + 1, scal + 2, 1.0 / (double)(1 << K2), scal);
   }
   KP_HIP(ctx, hipGetLastError());
-  KP_HIP(ctx, hipMemcpyAsync(&p->L, scal, 8, hipMemcpyDeviceToHost, s));
+  // L, -, -, |K_LS|_1, info: one DMA (into the context's page-locked words when it has them), one synchronisation
+  double back[5];
+  double* dst = ctx->pin_small ? ctx->pin_small : back;
+  KP_HIP(ctx, hipMemcpyAsync(dst, scal, sizeof(back), hipMemcpyDeviceToHost, s));
   KP_HIP(ctx, hipStreamSynchronize(s));
+  p->L = dst[0]; p->l1_ls = dst[3]; p->bad = dst[4] != 0.0;
   if (!(p->L > 0.0)) return ctx->fail(KP_ERR_ARG, "kp_fit_lasso: Gram matrix is zero");
   p->ready = true;
   return KP_OK;
@@ -773,10 +791,15 @@ int kp_lasso_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, in
   const size_t bK = (size_t)n * 8;
   hipStream_t s = ctx->stream;
   std::vector<int> act;                              // values whose L1 constraint is active
-  for (int v = 0; v < nv; ++v) {
-    if (iters) iters[v] = 0;
-    if (!prep->bad && prep->l1_ls <= t[v]) KP_HIP(ctx, hipMemcpyAsync(K_dev[v], prep->Kls, bK, hipMemcpyDeviceToDevice, s));
-    else act.push_back(v);
+  {
+    std::vector<std::pair<const double*, double*>> ls;      // the others get the least-squares solution
+    for (int v = 0; v < nv; ++v) {
+      if (iters) iters[v] = 0;
+      if (!prep->bad && prep->l1_ls <= t[v]) ls.push_back({prep->Kls, K_dev[v]});
+      else act.push_back(v);
+    }
+    const int rc = lasso_copies(ctx, s, ls, n);
+    if (rc) return rc;
   }
   const int nb = (int)act.size();
   if (nb == 0) return KP_OK;
@@ -815,13 +838,8 @@ int kp_lasso_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, in
       init.push_back({C_dev, (double*)(ws + 3 * bB) + (size_t)v * n});                // G K old
       init.push_back({C_dev, (double*)(ws + 4 * bB) + (size_t)v * n});                // G K current
     }
-    for (size_t i0 = 0; i0 < init.size(); i0 += LS_COPIES) {
-      LassoCopyList l;
-      const int cnt = (int)std::min<size_t>(LS_COPIES, init.size() - i0);
-      for (int k = 0; k < cnt; ++k) { l.src[k] = init[i0 + k].first; l.dst[k] = init[i0 + k].second; l.n[k] = (long long)n; }
-      hipLaunchKernelGGL(kp_lasso_copy_kernel, dim3((unsigned)std::min<int64_t>(64, (n + 255) / 256), cnt), dim3(256), 0, s, l);
-    }
-    KP_HIP(ctx, hipGetLastError());
+    const int rc = lasso_copies(ctx, s, init, n);
+    if (rc) return rc;
   }
   const size_t head = offsetof(LassoState, part);
   std::vector<char> hbuf(b_st, 0);
@@ -920,17 +938,7 @@ int kp_lasso_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, in
     // values that have their answer leave the batch (the last running slot moves into the hole: iterates, products, the
     // pattern of the active-set rounds and the state)
     std::vector<std::pair<const double*, double*>> cp_out, cp_mv;      // (source, destination), bK bytes each
-    auto flush_copies = [&](std::vector<std::pair<const double*, double*>>& v) -> int {
-      for (size_t i0 = 0; i0 < v.size(); i0 += LS_COPIES) {
-        LassoCopyList l;
-        const int cnt = (int)std::min<size_t>(LS_COPIES, v.size() - i0);
-        for (int k = 0; k < cnt; ++k) { l.src[k] = v[i0 + k].first; l.dst[k] = v[i0 + k].second; l.n[k] = (long long)n; }
-        hipLaunchKernelGGL(kp_lasso_copy_kernel, dim3((unsigned)std::min<int64_t>(64, (n + 255) / 256), cnt), dim3(256), 0, s, l);
-        KP_HIP(ctx, hipGetLastError());
-      }
-      v.clear();
-      return KP_OK;
-    };
+    auto flush_copies = [&](std::vector<std::pair<const double*, double*>>& v) -> int { return lasso_copies(ctx, s, v, n); };
     auto retire = [&]() -> int {
       // Moves are chained through slots (the slot moved into hole v may itself be moved again when a lower slot retires), so
       // the SOURCE of every copy is resolved to where the data lies before this pass: `where[slot]` = original slot index.
