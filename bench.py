@@ -394,6 +394,33 @@ def bench_width_points(ctx, kra, Ns):
     return out
 
 
+def bench_ns_points(ctx, kra, basis, sizes=(11999, 1000000, 10000000)):
+    """SURVEY 8(d)'s other snapshot counts on the headline dictionary (W = 336): 11 999 (the shipped arm data set), 1e6
+    and 1e7 pairs per fit, all resident in HBM (1.2 GB at 1e7).  Same measurement as the headline: a queue of pipelined fits,
+    kernel time = mean HIP-event duration of the fused lift+Gram launch, wall time per fit over the queue."""
+    out = {}
+    W = basis.W
+    F_ = W * (W + 1) + 2.0 * W * W
+    for Ns in sizes:
+        a, b, u = synth_pairs(Ns, seed=9)
+        sn = kra.Snapshots(ctx, a, b, u)
+        del a, b, u
+        n_q = int(max(8, min(64, 4e7 // Ns)))
+        for _ in range(n_q):
+            kra.fit(ctx, basis, sn, fetch=False)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_q):
+            kra.fit(ctx, basis, sn, fetch=False)
+        ctx.synchronize()
+        dt = (time.perf_counter() - t0) / n_q
+        ms, n_l, ex = ctx.timer(0), int(ctx.timer(7)), ctx.timer(10)
+        out[f"Ns{Ns}"] = {"snapshots": Ns, "fits_queued": n_q, "ms_per_fit": dt * 1e3, "pairs_per_s": Ns / dt, "gram_ms": ms,
+                          "launches_averaged": n_l, "roofline": roofline_block("fused lift+Gram, W=336", ex * Ns, F_ * Ns, ms)}
+        sn.close()
+    return out
+
+
 def cpu_baseline_mpc(pack):
     """The oracle's literal Kmpc step (Bhat from dense matrix powers, 4 rebuilds folded into one,
     exact active-set QP) on the host, on a bounded sample of the same problems."""
@@ -534,15 +561,42 @@ def main():
             streamed_ms = (time.perf_counter() - t1) / n_st * 1e3
         ring2[1].close()
 
-    mpc_res = arm_res = widths = None
+    mpc_res = arm_res = widths = ns_pts = None
     if rank == 0 and not args.no_mpc and world == 1:     # latency-bound sections only in the single-GPU run
         mpc_res = bench_mpc(ctx, kra, basis, snaps, args)
         arm_res = bench_arm_closed_loop(ctx, kra)
     gk_res = None
     if rank == 0 and extras_on and world == 1:
         widths = bench_width_points(ctx, kra, Ns)
+        ns_pts = bench_ns_points(ctx, kra, basis) if (Ns == 100000 and args.degree == 3) else None
         gk_res = bench_get_koopman(ctx, kra, Ns)
-    lasso_res = sweep_res = None
+    lasso_res = sweep_res = shard_res = None
+    if extras_on and world > 1:
+        # SURVEY 8(e) pattern 2: ONE fit whose snapshots are sharded over the ranks (strong scaling: the total is fixed) - local
+        # Gram kernel, one all-reduce of [G | C] (1.8 MB) on the device, the same solve on every rank.  Needs the RCCL
+        # communicator (without one kp_fit_sharded is the local fit and the block says so).
+        shard_res = {}
+        for Ns_tot in (100000, 10000000):
+            try:
+                per = Ns_tot // world
+                a_s, b_s, u_s = synth_pairs(per, seed=100 + rank)
+                sn_s = kra.Snapshots(ctx, a_s, b_s, u_s)
+                del a_s, b_s, u_s
+                n_q = 16 if Ns_tot <= 1000000 else 4
+                for _ in range(3):
+                    kra.fit_sharded(ctx, basis, sn_s)
+                comm.barrier()
+                t1 = time.perf_counter()
+                for _ in range(n_q):
+                    kra.fit_sharded(ctx, basis, sn_s)
+                comm.barrier()
+                dt_s = kc.max_over_ranks(comm, (time.perf_counter() - t1) / n_q)
+                sn_s.close()
+                shard_res[f"Ns{Ns_tot}"] = {"snapshots_total": per * world, "ms_per_fit": dt_s * 1e3, "pairs_per_s": per * world / dt_s,
+                                             "exchange": "one all-reduce of 2 W^2 doubles (RCCL, device to device)" if comm.kind == "rccl"
+                                             else f"none: comm is '{comm.kind}', every rank fitted its own shard only"}
+            except Exception as e:                      # never let this section take the line down
+                shard_res[f"Ns{Ns_tot}"] = {"error": repr(e)[:300]}
     if extras_on:                                        # sharded sections: every rank takes part
         # the grid belongs to ONE fit: every rank holds the same snapshot matrix (rank 0's) for this section
         snaps_l = snaps
@@ -610,8 +664,12 @@ def main():
             res["mpc_arm_blockM"] = arm_res
         if widths is not None:
             res["width_points"] = widths
+        if ns_pts is not None:
+            res["snapshot_count_points"] = ns_pts
         if gk_res is not None:
             res["get_koopman"] = gk_res
+        if shard_res is not None:
+            res["snapshot_sharded_fit"] = dict(shard_res, scaling="strong")
         if lasso_res is not None:
             res["lasso_grid"] = lasso_res
             res["rand_sweep"] = sweep_res
@@ -620,6 +678,8 @@ def main():
         kern = []
         if widths is not None:
             kern += [dict(w["roofline"], point=k_) for k_, w in widths.items()]
+        if ns_pts is not None:
+            kern += [dict(w["roofline"], point="W336 " + k_) for k_, w in ns_pts.items()]
         if lasso_res is not None and lasso_res.get("_gemm"):
             g_ms_, g_cols = lasso_res.pop("_gemm")
             fl = 2.0 * W * W * g_cols

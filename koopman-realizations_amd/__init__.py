@@ -8,12 +8,12 @@ name carries a hyphen to match the reference's repository name).
 """
 from . import _ffi
 from ._ffi import KoopmanHipError
-from .device import Basis, Context, Snapshots, fit, fit_gram, fit_refine
+from .device import Basis, Context, Snapshots, fit, fit_gram, fit_gram_sharded, fit_refine, fit_sharded
 from .device import Mpc
 from . import comm
 from .arm import Arm
 from .kmpc import Kmpc, Ksim, ModelPlant
 from .ksysid import Ksysid, default_context, poly_exponent_table
 
-__all__ = ["Arm", "Basis", "Context", "Snapshots", "fit", "fit_gram", "fit_refine", "Ksysid", "Kmpc", "Ksim", "ModelPlant", "Mpc", "KoopmanHipError", "default_context",
+__all__ = ["Arm", "Basis", "Context", "Snapshots", "fit", "fit_gram", "fit_gram_sharded", "fit_refine", "fit_sharded", "Ksysid", "Kmpc", "Ksim", "ModelPlant", "Mpc", "KoopmanHipError", "default_context",
            "poly_exponent_table", "_ffi", "comm"]

@@ -431,6 +431,27 @@ def fit(ctx: Context, basis: Basis, snaps: Snapshots, lasso=None, fetch=True):
     return [np.asfortranarray(K[i].T) for i in range(len(las))]
 
 
+def fit_sharded(ctx: Context, basis: Basis, snaps_local: Snapshots, lasso=None):
+    """ONE fit whose snapshot pairs are sharded over the ranks of the context's RCCL communicator (SURVEY 8(e), pattern 2;
+    kp_fit_sharded): fused Gram kernel on the local shard, one device-to-device all-reduce of [G | C], the same solve on every
+    rank - identical K everywhere.  Without a communicator this is `fit` on the local snapshots."""
+    if lasso is None:
+        lasso = [np.inf]
+    las = np.ascontiguousarray(np.atleast_1d(np.asarray(lasso, dtype=np.float64)))
+    W = basis.W
+    K = np.zeros((len(las), W, W))
+    F.check(F.lib().kp_fit_sharded(ctx.handle, basis.handle, snaps_local.handle, F.dptr(las), len(las), F.dptr(K)), ctx.handle)
+    return [np.asfortranarray(K[i].T) for i in range(len(las))]
+
+
+def fit_gram_sharded(ctx: Context, basis: Basis, snaps_local: Snapshots):
+    """(G, C) of the union of the ranks' shards: local Gram kernel + one all-reduce (kp_fit_gram_sharded)."""
+    W = basis.W
+    G = np.zeros((W, W), order="F"); Cm = np.zeros((W, W), order="F")
+    F.check(F.lib().kp_fit_gram_sharded(ctx.handle, basis.handle, snaps_local.handle, F.dptr(G), F.dptr(Cm)), ctx.handle)
+    return G, Cm
+
+
 def fit_refine(ctx: Context, basis: Basis, snaps: Snapshots, K, steps=1):
     """kp_fit_refine: `steps` x  K += G^-1 Px'(Py - Px K) with the residual taken from the data (QR-level accuracy for
     ill-conditioned dictionaries; MATLAB's mldivide is a QR solve, Ksysid.m:1069)."""

@@ -290,10 +290,8 @@ for _ in range(3):
     kra.fit(c2, b, s, fetch=False)
 Kall = comm.all_gather_fit(2, b.W)
 assert Kall.shape == (1, b.W, b.W) and np.abs(Kall[0] - Kref).max() <= 1e-11 * np.abs(Kref).max()
-K = np.zeros((1, b.W, b.W))
-las = np.array([np.inf])
-F.check(F.lib().kp_fit_sharded(c2.handle, b.handle, s.handle, F.dptr(las), 1, F.dptr(K)), c2.handle)
-assert np.abs(K[0].T - Kref).max() <= 1e-12 * np.abs(Kref).max()
+Ksh = kra.fit_sharded(c2, b, s)[0]                      # kp_fit_sharded: Gram kernel, all-reduce of [G | C], solve
+assert np.abs(Ksh - Kref).max() <= 1e-12 * np.abs(Kref).max()
 # the K stack of a shard through ONE ncclAllGather from the device result buffer (kp_comm_allgather_fits): the lasso grid's gather
 from koopman_realizations_amd import sweep
 l1 = np.abs(Kref).sum()
@@ -303,8 +301,7 @@ got3 = sweep.lasso_sweep_device(c2, lambda ls: kra.fit(c2, b, s, ls, fetch=False
 assert len(got3) == 3 and all(np.array_equal(x, y) for x, y in zip(ref3, got3))
 part = comm.all_gather_fits(1, 2, b.W)
 assert part.shape == (1, 2, b.W, b.W) and np.array_equal(part[0, 1].T, ref3[2])
-G = np.zeros((b.W, b.W), order="F"); Cm = np.zeros((b.W, b.W), order="F")
-F.check(F.lib().kp_fit_gram_sharded(c2.handle, b.handle, s.handle, F.dptr(G), F.dptr(Cm)), c2.handle)
+G, Cm = kra.fit_gram_sharded(c2, b, s)
 Px, Py = ko.px_py(dic, p)
 assert np.abs(G - Px.T @ Px).max() <= 1e-11 * np.abs(G).max()
 comm.close()
