@@ -83,3 +83,29 @@ def test_wide_dictionary_falls_back_to_general_kernel(ctx):
     Px, Py = ko.px_py(dic, p)
     assert np.abs(G - Px.T @ Px).max() <= 1e-12 * np.abs(Px.T @ Px).max()
     assert np.abs(C - Px.T @ Py).max() <= 1e-12 * np.abs(Px.T @ Px).max()
+
+
+def test_lasso_on_a_rank_deficient_gram_uses_the_psd_guard(ctx):
+    """Two identical state columns make a third of the degree-2 dictionary dependent: the Gram matrix is singular (its
+    smallest eigenvalue is rounding noise of either sign).  solve_KoopmanQP adds 1e-6 to the diagonal when an eigenvalue is
+    negative (Ksysid.m:1117-1120); the device does the same when the factorisation breaks down, and the answers are the
+    optima of THAT problem: KKT residual of the guarded QP at rounding level for active budgets, the guarded least-squares
+    solution for an inactive one."""
+    rng = np.random.default_rng(4)
+    Ns = 4000
+    a = rng.uniform(-1, 1, (Ns, 3)); a[:, 2] = a[:, 0]
+    u = rng.uniform(-1, 1, (Ns, 2))
+    b_ = np.clip(a + 0.05 * np.tanh(np.hstack([a, u]) @ rng.standard_normal((5, 3))), -1, 1); b_[:, 2] = b_[:, 0]
+    basis = kra.Basis(ctx, "bilinear", 3, 2, [("poly", kra.poly_exponent_table(3, 2)[3:])])
+    snaps = kra.Snapshots(ctx, a, b_, u)
+    G, C = kra.fit_gram(ctx, basis, snaps)
+    assert np.linalg.matrix_rank(G) < basis.W
+    Gg = G + 1e-6 * np.eye(basis.W)
+    Kg = np.linalg.solve(Gg, C)
+    l1 = np.abs(Kg).sum()
+    Ks, its = ctx.fit_lasso_batch(G, C, [2.0 * l1, 0.8 * l1, 0.3 * l1, 0.05 * l1])
+    assert all(np.isfinite(K).all() for K in Ks)
+    assert np.abs(Ks[0] - Kg).max() <= 1e-6 * np.abs(Kg).max()                 # inactive budget: the guarded LS solution
+    for K, fr in zip(Ks[1:], (0.8, 0.3, 0.05)):
+        assert abs(np.abs(K).sum() / (fr * l1) - 1.0) <= 1e-9
+        assert ko.lasso_kkt_residual(Gg, C, K, fr * l1) <= 1e-9 * np.abs(C).max()
