@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <atomic>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -19,6 +20,7 @@ struct kp_ctx {
   int device = 0;
   kp_stage* stage = nullptr;
   std::vector<void*> host_blocks;       // kp_host_alloc: page-locked host buffers handed to the caller
+  std::mutex host_mu;                   // ... a gathering host thread may ask for one while another thread drives the device
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipEvent_t evp[6] = {nullptr};   // gram start, gram end, reduce end, solve end, spare x2

@@ -344,7 +344,10 @@ extern "C" int kp_host_alloc(kp_ctx* ctx, int64_t bytes, void** ptr) {
   KP_HIP(ctx, hipSetDevice(ctx->device));
   void* p = nullptr;
   KP_HIP(ctx, hipHostMalloc(&p, (size_t)bytes, hipHostMallocDefault));
-  ctx->host_blocks.push_back(p);
+  {
+    std::lock_guard<std::mutex> lk(ctx->host_mu);
+    ctx->host_blocks.push_back(p);
+  }
   *ptr = p;
   return KP_OK;
 }
@@ -352,14 +355,21 @@ extern "C" int kp_host_alloc(kp_ctx* ctx, int64_t bytes, void** ptr) {
 extern "C" int kp_host_free(kp_ctx* ctx, void* ptr) {
   if (!ctx) return KP_ERR_ARG;
   if (!ptr) return KP_OK;
-  for (size_t i = 0; i < ctx->host_blocks.size(); ++i)
-    if (ctx->host_blocks[i] == ptr) {
-      ctx->host_blocks.erase(ctx->host_blocks.begin() + (long)i);
-      KP_HIP(ctx, hipSetDevice(ctx->device));
-      KP_HIP(ctx, hipDeviceSynchronize());          // no transfer from the block may still be in flight
-      KP_HIP(ctx, hipHostFree(ptr));
-      return KP_OK;
-    }
+  bool mine = false;
+  {
+    std::lock_guard<std::mutex> lk(ctx->host_mu);
+    for (size_t i = 0; i < ctx->host_blocks.size() && !mine; ++i)
+      if (ctx->host_blocks[i] == ptr) {
+        ctx->host_blocks.erase(ctx->host_blocks.begin() + (long)i);
+        mine = true;
+      }
+  }
+  if (mine) {
+    KP_HIP(ctx, hipSetDevice(ctx->device));
+    KP_HIP(ctx, hipDeviceSynchronize());            // no transfer from the block may still be in flight
+    KP_HIP(ctx, hipHostFree(ptr));
+    return KP_OK;
+  }
   return ctx->fail(KP_ERR_ARG, "kp_host_free: not a block of this context");
 }
 

@@ -20,7 +20,7 @@ try:                                     # host-side gather helper (plain C exte
 except ImportError:                      # pragma: no cover - the helper is optional
     _kp_gather = None
 import os as _os
-_GATHER_THREADS = max(1, min(8, len(_os.sched_getaffinity(0)) if hasattr(_os, "sched_getaffinity") else (_os.cpu_count() or 1)))
+_GATHER_THREADS = max(1, min(12, len(_os.sched_getaffinity(0)) if hasattr(_os, "sched_getaffinity") else (_os.cpu_count() or 1)))
 
 
 def shard_units(n_units: int, rank: int, world: int):
@@ -157,13 +157,14 @@ def rand_models_sweep(systems, comm=None, ctx=None, degrees=None, eval_fn=None, 
     return {mt: np.stack([r[mt][0] for r in allres], axis=1) for mt in ("linear", "bilinear", "nonlinear")}
 
 
-def _stack_raw(systems, ctx=None):
+def _stack_raw(systems, ctx=None, slot=""):  # slot: suffix of the buffer names (a caller that keeps two gathers alive)
     """The systems' trials as stacked raw arrays (no arithmetic): Y (nb, k T, n), U (nb, k T, m), trial count k, and the
     validation trial Yv, Uv - or None unless every system has the same trial layout (equal counts and lengths, time
     restarting at every trial: the generated and shipped rand-systems sets).  With a device context the blocks are
     gathered into its page-locked host arrays (Context.host_array, reused from call to call: no first-touch page faults -
     they were two thirds of this function's time - and the upload that follows is a direct DMA); the returned arrays are
-    then views that stay valid until the next call with the same context."""
+    then views that stay valid until the next call with the same context and `slot` (a suffix of the buffer names: the
+    pipelined sweep gathers one chunk while the previous one is still being uploaded)."""
     try:
         tr = [d["train"] for d in systems]
         k = len(tr[0])
@@ -171,22 +172,23 @@ def _stack_raw(systems, ctx=None):
             return None
 
         def stacked(key, src, name):                                       # ONE C-level gather per quantity
-            arrs = [x[key] for t in src for x in t]
-            a0 = np.asarray(arrs[0])
+            a0 = np.asarray(src[0][0][key])
             Tn = a0.shape[0]
             w = a0.size // max(Tn, 1)
             shape = (len(src), len(src[0]) * Tn, w)
-            out = ctx.host_array("sweep_" + name, shape) if ctx is not None else np.empty(shape)
+            out = ctx.host_array("sweep_" + name + slot, shape) if ctx is not None else np.empty(shape)
             if _kp_gather is not None:
                 # buffer-protocol pointers + multi-threaded memcpy with the GIL released (csrc/kp_pygather.c): np.concatenate
-                # spends ~1.7 us of set-up per 8 KB trial array, 60 ms for the 33 000 arrays of 1024 systems
+                # spends ~1.7 us of set-up per 8 KB trial array, 60 ms for the 33 000 arrays of 1024 systems.  The helper
+                # walks systems -> trials -> trial[key] itself (the flattening comprehension cost as much as the copy)
                 try:
-                    nbytes, same = _kp_gather.gather(arrs, out.ctypes.data, out.nbytes, _GATHER_THREADS)
+                    nbytes, same = _kp_gather.gather(src, out.ctypes.data, out.nbytes, _GATHER_THREADS, key)
                     if nbytes != out.nbytes or not same:
                         raise ValueError("ragged trials")
                     return out
                 except TypeError:                                            # lists / other dtypes among the trials: numpy converts
                     pass
+            arrs = [x[key] for t in src for x in t]
             try:
                 uniform = {(a.shape, a.dtype) for a in arrs} == {(a0.shape, np.dtype(np.float64))}
             except AttributeError:                                           # lists / scalars among the trials
@@ -199,15 +201,26 @@ def _stack_raw(systems, ctx=None):
             np.concatenate(arrs, axis=0, out=flat)
             return out
         Y, U = stacked("y", tr, "Y"), stacked("u", tr, "U")
-        Tm = stacked("t", tr, "t")[:, :, 0]
+        T = Y.shape[1] // k
+        # Ksysid.m:948: seams between trials exactly at the trial joins, nowhere else.  The time vectors are only LOOKED at
+        # (threads, no copy: csrc/kp_pygather.c); stacking them and comparing in numpy cost a third of this function
+        seams_ok = None
+        if _kp_gather is not None and hasattr(_kp_gather, "trials_increasing"):
+            try:
+                ok_, same_ = _kp_gather.trials_increasing(tr, k, _GATHER_THREADS, "t")
+                seams_ok = bool(ok_) and bool(same_) and len(tr[0][0]["t"]) == T
+            except TypeError:
+                seams_ok = None
+        if seams_ok is None:
+            Tm = stacked("t", tr, "t")[:, :, 0]
+            good = Tm[:, :-1] < Tm[:, 1:]
+            seams = good[:, T - 1::T]
+            seams_ok = not (seams.any() or int(np.count_nonzero(good)) != good.size - seams.size)
+        if not seams_ok:
+            return None
         va = [[d["val"][0]] for d in systems]
         Yv, Uv = stacked("y", va, "Yv"), stacked("u", va, "Uv")
     except ValueError:
-        return None
-    T = Y.shape[1] // k
-    good = Tm[:, :-1] < Tm[:, 1:]                                          # Ksysid.m:948: seams between trials ...
-    seams = good[:, T - 1::T]                                              # ... exactly at the trial joins, nowhere else
-    if seams.any() or int(np.count_nonzero(good)) != good.size - seams.size:
         return None
     return Y, U, k, Yv, Uv
 

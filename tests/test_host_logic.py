@@ -52,6 +52,17 @@ def test_host_gather_helper_matches_numpy_and_rejects_what_it_cannot_take():
     outb = np.zeros(40 * 40000)
     assert _kp_gather.gather(big, outb.ctypes.data, outb.nbytes, 4)[0] == outb.nbytes and np.array_equal(outb, np.concatenate(big))
     assert _kp_gather.gather([np.zeros(3), np.zeros(4)], out.ctypes.data, out.nbytes)[1] is False
+    # the nested form: systems -> trials -> trial[key], walked by the helper itself
+    nested = [[{"y": pieces[3 * i + j], "u": None} for j in range(3)] for i in range(100)]
+    out2 = np.zeros_like(out)
+    assert _kp_gather.gather(nested, out2.ctypes.data, out2.nbytes, 2, "y") == (out.nbytes, True)
+    assert np.array_equal(out2, np.concatenate(pieces, axis=0))
+    with pytest.raises(KeyError):
+        _kp_gather.gather(nested, out2.ctypes.data, out2.nbytes, 2, "t")
+    with pytest.raises(TypeError):
+        _kp_gather.gather(nested, out2.ctypes.data, out2.nbytes, 2, "u")                     # None is no buffer
+    with pytest.raises(TypeError):
+        _kp_gather.gather([[pieces[0]]], out2.ctypes.data, out2.nbytes, 2, "y")              # trials must be dicts
     with pytest.raises(TypeError):
         _kp_gather.gather([np.arange(4)], out.ctypes.data, out.nbytes)                      # int64
     with pytest.raises(ValueError):
@@ -73,3 +84,48 @@ def test_host_gather_helper_matches_numpy_and_rejects_what_it_cannot_take():
     assert np.array_equal(c[0], a[0])
     systems[1]["train"][0]["y"] = systems[1]["train"][0]["y"][:10]                          # ragged: no stacked form
     assert sweep._stack_raw(systems) is None
+
+
+def test_seam_check_of_the_stacked_sweep_agrees_with_the_numpy_form():
+    """_kp_gather.trials_increasing (the seam test of Ksysid.m:948 asked of all trials at once, without copying the time
+    vectors): a clock that runs on across a trial join, a repeated or decreasing time stamp inside a trial and a NaN all
+    refuse the stacked form, exactly as the numpy comparison does; the big (threaded) case agrees too."""
+    import numpy as np
+    import __graft_entry__ as ge
+    ge.build()
+    from koopman_realizations_amd import sweep, _kp_gather
+    rng = np.random.default_rng(1)
+    tq = np.arange(11) * 0.1
+
+    def systems(nsys=4):
+        return [{"train": [{"t": tq.copy(), "y": rng.standard_normal((11, 1)), "u": rng.standard_normal((11, 1))} for _ in range(3)],
+                 "val": [{"t": tq.copy(), "y": rng.standard_normal((11, 1)), "u": rng.standard_normal((11, 1))}]} for _ in range(nsys)]
+
+    def both(sy):
+        a = sweep._stack_raw(sy)
+        helper, sweep._kp_gather = sweep._kp_gather, None
+        try:
+            b = sweep._stack_raw(sy)
+        finally:
+            sweep._kp_gather = helper
+        assert (a is None) == (b is None)
+        return a
+
+    assert both(systems()) is not None
+    s1 = systems(); s1[1]["train"][1]["t"] = tq + 1.1            # clock runs on over the join 0 -> 1: the pair across it would count
+    assert both(s1) is None
+    s2 = systems(); s2[3]["train"][2]["t"][5] = s2[3]["train"][2]["t"][4]      # repeated stamp inside a trial
+    assert both(s2) is None
+    s3 = systems(); s3[0]["train"][0]["t"][7] = np.nan
+    assert both(s3) is None
+    s4 = systems(); s4[2]["train"][2]["t"] = tq + 5.0            # later start of the LAST trial of a system still restarts vs the next system's
+    assert both(s4) is None                                       # ... but not vs its own predecessor: 1.0 < 5.0 runs on
+    big = [np.arange(3000) * 0.01 for _ in range(600)]            # > 8 MB: threads
+    assert _kp_gather.trials_increasing(big, 10, 4) == (True, True)
+    big[431] = big[431].copy(); big[431][2999] = big[431][2998]
+    assert _kp_gather.trials_increasing(big, 10, 4)[0] is False
+    assert _kp_gather.trials_increasing([tq, tq[:5]], 2, 1) == (True, False)
+    with pytest.raises(TypeError):
+        _kp_gather.trials_increasing([np.arange(4)], 1, 1)
+    with pytest.raises(ValueError):
+        _kp_gather.trials_increasing([tq, tq, tq], 2, 1)
