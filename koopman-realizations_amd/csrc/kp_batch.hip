@@ -973,6 +973,10 @@ __device__ __forceinline__ double sb_row_sum(double v) {        // sum over the 
   return v;
 }
 
+// MT: the model type at compile time - the row of B_i (96 registers) exists only in the bilinear instantiation; with the type
+// a run-time value every instantiation carried it, 2 waves per SIMD fitted and the 3328 waves of the linear pass (13 degrees
+// x 1024 systems) ran in two rounds.
+template <int MT>
 __global__ __launch_bounds__(64) void kp_sweep_rollout4_kernel(BasisDev b, const SweepDeg* __restrict__ degs, const ColDesc* __restrict__ cols_all,
                                                                int nb, int n_deg, const double* __restrict__ Kall, const double* __restrict__ Aall,
                                                                const double* __restrict__ Ball, const double* __restrict__ Yv,
@@ -985,7 +989,8 @@ __global__ __launch_bounds__(64) void kp_sweep_rollout4_kernel(BasisDev b, const
   const bool live = job < njobs;
   if (!live) job = njobs - 1;
   const int dj = job / nb, sys = job - dj * nb;
-  const int n = b.nzeta, m = b.m, mt = b.model_type;
+  const int n = b.nzeta, m = b.m;
+  constexpr int mt = MT;
   const int N = degs[dj].N, W = degs[dj].W;
   BasisDev bj = b;
   bj.N = N; bj.W = W; bj.nfull = N; bj.cols = cols_all + (size_t)dj * 16;
@@ -995,7 +1000,8 @@ __global__ __launch_bounds__(64) void kp_sweep_rollout4_kernel(BasisDev b, const
   const double* uv = Uv + (size_t)sys * Tv * m;
   const bool rin = r < N;
   // row r of the model matrices: ak[c] = A[r][c], bk[i][c] = B_i[r][c]
-  double ak[16], bk[3][16], bl[3] = {0.0, 0.0, 0.0};
+  constexpr int NBK = MT == KP_MODEL_BILINEAR ? 3 : 1;      // (a zero-length array is not allowed)
+  double ak[16], bk[NBK][16], bl[3] = {0.0, 0.0, 0.0};
 #pragma unroll
   for (int c = 0; c < 16; ++c) {
     const bool in = rin && c < N;
@@ -1003,8 +1009,12 @@ __global__ __launch_bounds__(64) void kp_sweep_rollout4_kernel(BasisDev b, const
     if (mt == KP_MODEL_LINEAR) a = in ? Aall[off + (size_t)c * N + r] : 0.0;
     else if (mt == KP_MODEL_BILINEAR) a = in ? Ks[c + (size_t)r * W] : 0.0;
     ak[c] = a;
+    if constexpr (MT == KP_MODEL_BILINEAR) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) bk[i][c] = (mt == KP_MODEL_BILINEAR && i < m && in) ? Ks[N + N * i + c + (size_t)r * W] : 0.0;
+      for (int i = 0; i < 3; ++i) bk[i][c] = (i < m && in) ? Ks[N + N * i + c + (size_t)r * W] : 0.0;
+    } else {
+      bk[0][c] = 0.0;
+    }
   }
   // columns to visit: the widest of the wave's four jobs (consecutive jobs share their degree except at a boundary)
   int Nw = N;
@@ -1019,6 +1029,26 @@ __global__ __launch_bounds__(64) void kp_sweep_rollout4_kernel(BasisDev b, const
   if (mt == KP_MODEL_NONLINEAR)
 #pragma unroll
     for (int o = 0; o < 4; ++o) kf[o] = (o < n && rin) ? Ks[r + (size_t)o * W] : 0.0;
+  // nonlinear: column r of the dictionary over [zeta; u] as packed exponents (4 bits per variable, <= 8 variables), so that a
+  // step evaluates psi from registers - zeta_i by a DPP broadcast from lane i of the row, u_i from the lane's own copy -
+  // instead of kp_eval_col's exponent bytes from global memory and the trip through LDS (two wave barriers per step)
+  unsigned epack = 0;
+  bool nl_fast = false;
+  if constexpr (MT == KP_MODEL_NONLINEAR) {
+    bool ok = n <= 4 && m <= 3;
+    if (rin && ok) {
+      const ColDesc c = bj.cols[r];
+      if (c.kind == COL_VAR) epack = 1u << (4 * c.arg);
+      else if (c.kind == COL_MONO) {
+        for (int i = 0; i < bj.nvars; ++i) {
+          const unsigned e = bj.exps[(size_t)c.arg * bj.nvars + i];
+          ok = ok && e < 16;
+          epack |= (e & 15u) << (4 * i);
+        }
+      } else if (c.kind != COL_CONST) ok = false;
+    }
+    nl_fast = __all(ok);
+  }
   // first validation row -> lifted state
   if (r < n) vsh[q][r] = yv[(size_t)r * Tv];
   if (mt == KP_MODEL_NONLINEAR && r < m) vsh[q][n + r] = uv[(size_t)r * Tv];
@@ -1033,54 +1063,90 @@ __global__ __launch_bounds__(64) void kp_sweep_rollout4_kernel(BasisDev b, const
   double ut[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) ut[i] = i < m ? uv[(size_t)i * Tv] : 0.0;
-  for (int t = 0; t < Tv; ++t) {
-    if (r < n) {
-      if (t > 0) acc_e += fabs(z - yr);               // the first simulated row is the measured one (Ksysid.m:1654)
-      acc_a += fabs(yr);
-    }
-    if (t == Tv - 1) break;
-    // values of the next step: in flight during this one (chunks of several steps held in register arrays were
-    // measured too and were slower)
-    const double yr_n = r < n ? yv[(size_t)r * Tv + t + 1] : 0.0;
-    double ut_n[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) ut_n[i] = i < m ? uv[(size_t)i * Tv + t + 1] : 0.0;
-    double zn = 0.0;
-    if (mt != KP_MODEL_NONLINEAR) {
-      // z+ = (A + sum_i u_i B_i) z  (val_model :1685 / val_BLmodel :1783); linear: B u added below.  z[c] reaches every
-      // lane of its 16-lane row by ONE DP-ALU DPP move (v_mov_b64_dpp row_newbcast:c).  (Round 2 broadcast it with two
-      // ds_swizzle per column: with 13 waves per CU the LDS crossbar was the bound.  Also tried here: the trial staged in
-      // LDS in 16-step chunks fetched a chunk ahead, instead of the one-step-ahead global loads below - slower, 1.37 against
-      // 0.96 ms per pass.)
-#define KP_COL_STEP(CC)                                                                                        \
-      if (CC < Nw) {                                                                                           \
-        double w = ak[CC];                                                                                     \
-        if (mt == KP_MODEL_BILINEAR) { w += ut[0] * bk[0][CC]; if (m > 1) w += ut[1] * bk[1][CC]; if (m > 2) w += ut[2] * bk[2][CC]; } \
-        zn += w * __builtin_amdgcn_update_dpp(0.0, z, 0x150 + (CC), 0xf, 0xf, false);                          \
+  // The time loop with the column count of the wave's widest job as a compile-time constant: with `if (c < Nw)` around every
+  // column the 16 scalar compare-and-branch pairs of a step cost a lone wave more than its arithmetic (0.4 us per step at
+  // degree 13).  (Also measured: the trial fetched in 4-step register chunks a chunk ahead, or staged in LDS in 16-step
+  // chunks, instead of the one-step-ahead loads below - no faster: the step time is the dependent chain, not the loads.)
+  auto run = [&](auto nwc) {
+    constexpr int NW = decltype(nwc)::value;
+    for (int t = 0; t < Tv; ++t) {
+      if (r < n) {
+        if (t > 0) acc_e += fabs(z - yr);               // the first simulated row is the measured one (Ksysid.m:1654)
+        acc_a += fabs(yr);
       }
-      KP_COL_STEP(0) KP_COL_STEP(1) KP_COL_STEP(2) KP_COL_STEP(3) KP_COL_STEP(4) KP_COL_STEP(5) KP_COL_STEP(6) KP_COL_STEP(7)
-      KP_COL_STEP(8) KP_COL_STEP(9) KP_COL_STEP(10) KP_COL_STEP(11) KP_COL_STEP(12) KP_COL_STEP(13) KP_COL_STEP(14) KP_COL_STEP(15)
-#undef KP_COL_STEP
-      if (mt == KP_MODEL_LINEAR) zn += bl[0] * ut[0] + bl[1] * ut[1] + bl[2] * ut[2];
-    } else {                                           // zeta+ = Kf psi([zeta; u]) (val_NLmodel, Ksysid.m:1848-1863)
-      if (r < n) vsh[q][r] = z;
-      if (r < m) vsh[q][n + r] = ut[r];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      const double psi = rin ? kp_eval_col(bj, bj.cols[r], vsh[q], 1) : 0.0;
+      if (t == Tv - 1) break;
+      const double yr_n = r < n ? yv[(size_t)r * Tv + t + 1] : 0.0;      // values of the next step: in flight during this one
+      double ut_n[3];
 #pragma unroll
-      for (int o = 0; o < 4; ++o)
-        if (o < n) {
-          const double sacc = sb_row_sum(kf[o] * psi);
-          if (r == o) zn = sacc;
+      for (int i = 0; i < 3; ++i) ut_n[i] = i < m ? uv[(size_t)i * Tv + t + 1] : 0.0;
+      double zn = 0.0;
+      if constexpr (MT != KP_MODEL_NONLINEAR) {
+        // z+ = (A + sum_i u_i B_i) z  (val_model :1685 / val_BLmodel :1783); linear: B u added below.  z[c] reaches every
+        // lane of its 16-lane row by ONE DP-ALU DPP move (v_mov_b64_dpp row_newbcast:c).  (Round 2 broadcast it with two
+        // ds_swizzle per column: with 13 waves per CU the LDS crossbar was the bound.)  Two partial sums: half the chain.
+        double zn1 = 0.0;
+#define KP_COL_STEP(CC, ACC)                                                                                   \
+        if constexpr (CC < NW) {                                                                                 \
+          double w = ak[CC];                                                                                     \
+          if constexpr (MT == KP_MODEL_BILINEAR) { w += ut[0] * bk[0][CC]; if (m > 1) w += ut[1] * bk[1][CC]; if (m > 2) w += ut[2] * bk[2][CC]; } \
+          ACC += w * __builtin_amdgcn_update_dpp(0.0, z, 0x150 + (CC), 0xf, 0xf, false);                         \
         }
-      __builtin_amdgcn_wave_barrier();
-    }
-    z = zn;
-    yr = yr_n;
+        KP_COL_STEP(0, zn) KP_COL_STEP(1, zn1) KP_COL_STEP(2, zn) KP_COL_STEP(3, zn1) KP_COL_STEP(4, zn) KP_COL_STEP(5, zn1)
+        KP_COL_STEP(6, zn) KP_COL_STEP(7, zn1) KP_COL_STEP(8, zn) KP_COL_STEP(9, zn1) KP_COL_STEP(10, zn) KP_COL_STEP(11, zn1)
+        KP_COL_STEP(12, zn) KP_COL_STEP(13, zn1) KP_COL_STEP(14, zn) KP_COL_STEP(15, zn1)
+#undef KP_COL_STEP
+        zn += zn1;
+        if constexpr (MT == KP_MODEL_LINEAR) zn += bl[0] * ut[0] + bl[1] * ut[1] + bl[2] * ut[2];
+      } else {                                           // zeta+ = Kf psi([zeta; u]) (val_NLmodel, Ksysid.m:1848-1863)
+        double psi;
+        if (nl_fast) {
+          psi = rin ? 1.0 : 0.0;
+#define KP_NL_VAR(I, X)                                                                  \
+          {                                                                               \
+            const double x_ = X;                                                          \
+            const int e_ = (int)((epack >> (4 * (I))) & 15u);                             \
+            for (int k_ = 0; k_ < e_; ++k_) psi *= x_;                                    \
+          }
+          KP_NL_VAR(0, __builtin_amdgcn_update_dpp(0.0, z, 0x150, 0xf, 0xf, false))
+          if (n > 1) KP_NL_VAR(1, __builtin_amdgcn_update_dpp(0.0, z, 0x151, 0xf, 0xf, false))
+          if (n > 2) KP_NL_VAR(2, __builtin_amdgcn_update_dpp(0.0, z, 0x152, 0xf, 0xf, false))
+          if (n > 3) KP_NL_VAR(3, __builtin_amdgcn_update_dpp(0.0, z, 0x153, 0xf, 0xf, false))
+          KP_NL_VAR(n, ut[0])
+          if (m > 1) KP_NL_VAR(n + 1, ut[1])
+          if (m > 2) KP_NL_VAR(n + 2, ut[2])
+#undef KP_NL_VAR
+        } else {
+          if (r < n) vsh[q][r] = z;
+          if (r < m) vsh[q][n + r] = ut[r];
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+          psi = rin ? kp_eval_col(bj, bj.cols[r], vsh[q], 1) : 0.0;
+          __builtin_amdgcn_wave_barrier();
+        }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) ut[i] = ut_n[i];
+        for (int o = 0; o < 4; ++o)
+          if (o < n) {
+            const double sacc = sb_row_sum(kf[o] * psi);
+            if (r == o) zn = sacc;
+          }
+      }
+      z = zn;
+      yr = yr_n;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) ut[i] = ut_n[i];
+    }
+  };
+  if constexpr (MT == KP_MODEL_NONLINEAR) {
+    run(std::integral_constant<int, 0>{});
+  } else {
+    switch (Nw) {
+#define KP_NW_CASE(V) case V: run(std::integral_constant<int, V>{}); break;
+      KP_NW_CASE(1) KP_NW_CASE(2) KP_NW_CASE(3) KP_NW_CASE(4) KP_NW_CASE(5) KP_NW_CASE(6) KP_NW_CASE(7) KP_NW_CASE(8)
+      KP_NW_CASE(9) KP_NW_CASE(10) KP_NW_CASE(11) KP_NW_CASE(12) KP_NW_CASE(13) KP_NW_CASE(14) KP_NW_CASE(15)
+#undef KP_NW_CASE
+      default: run(std::integral_constant<int, 16>{}); break;
+    }
   }
   if (live && r < n) {
     const double bad = stat[(size_t)dj * nb + sys] ? __builtin_nan("") : 0.0;
@@ -1268,11 +1334,14 @@ extern "C" int kp_sweep_eval_nested(kp_ctx* ctx, const kp_traj* traj, const kp_b
     KP_HIP(ctx, hipGetLastError());
   }
   static const bool rollout4 = getenv("KP_SWEEP_NO_ROLLOUT4") == nullptr;
-  if (rollout4 && n <= 4)
-    hipLaunchKernelGGL(kp_sweep_rollout4_kernel, dim3((nb * n_deg + 3) / 4), dim3(64), 0, s, b, dT, dCols, nb, n_deg, dK,
-                       b.model_type == KP_MODEL_LINEAR ? dA : nullptr, b.model_type == KP_MODEL_LINEAR ? dB : nullptr, traj->Yv, traj->Uv, traj->Tv,
-                       dS, dE);
-  else
+  if (rollout4 && n <= 4) {
+#define KP_ROLL4(MT_) hipLaunchKernelGGL(kp_sweep_rollout4_kernel<MT_>, dim3((nb * n_deg + 3) / 4), dim3(64), 0, s, b, dT, dCols, nb, n_deg, dK, \
+                                         MT_ == KP_MODEL_LINEAR ? dA : nullptr, MT_ == KP_MODEL_LINEAR ? dB : nullptr, traj->Yv, traj->Uv, traj->Tv, dS, dE)
+    if (b.model_type == KP_MODEL_LINEAR) KP_ROLL4(KP_MODEL_LINEAR);
+    else if (b.model_type == KP_MODEL_BILINEAR) KP_ROLL4(KP_MODEL_BILINEAR);
+    else KP_ROLL4(KP_MODEL_NONLINEAR);
+#undef KP_ROLL4
+  } else
     hipLaunchKernelGGL(kp_sweep_rollout_nested_kernel, grid, dim3(64), 0, s, b, dT, dCols, nb, dK, b.model_type == KP_MODEL_LINEAR ? dA : nullptr,
                        b.model_type == KP_MODEL_LINEAR ? dB : nullptr, traj->Yv, traj->Uv, traj->Tv, dS, dE);
   KP_HIP(ctx, hipGetLastError());
