@@ -833,6 +833,215 @@ __global__ __launch_bounds__(256) void kp_traj_gram_kernel(BasisDev b, const uin
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same Gram pass on the matrix pipe (round 3).  kp_traj_gram_kernel above writes the lifted rows Px, Py to LDS and every
+// thread re-reads them for its register block (three 16-byte reads per 32 FMAs): the LDS was busy 60 % of the time and the pass
+// ran at 0.15-0.23 of the f64 rate.  Here NO lifted row exists: the power table (T_e(x_v) or x_v^e, the inputs, the tail
+// mask, 1 and 0 as extra entries, per (side, pair)) is the only thing in LDS, and a lane builds the operands of
+// v_mfma_f64_4x4x4_4b itself as products of F table entries through byte offsets fixed at kernel start:
+//   A (row group g)  psi_x[pair k][col 4g + i],  i = lane & 3, k = lane >> 4       (4 values)
+//   B                psi_x | psi_y [pair k][col 4 blk + i],  blk = (lane >> 2) & 3   (1 + 1 values)
+// 6 F ds_read_b64 and 8 MFMAs per 4 pairs and wave (G and C, 16 x 16 each), no address arithmetic (the k-step enters the
+// immediate offset); entry stride 129 doubles: the 16 lanes of a read pass that want 16 different entries of one pair hit 16
+// different bank pairs.  A wave owns every fourth 4-pair step of a tile; the four partial sums meet in LDS at the end.
+// One barrier per 128 pairs (the table is double buffered).  F = factors per operand value: bilinear columns psi_c u_i get
+// their own table entries (UPRO: the filling thread multiplies once per pair what every lane would multiply per step).
+// Measured per pass of 1024 systems x 9999 pairs (linear degree 13 | bilinear 6 | nonlinear 4): 0.74 | 0.59 | 0.88 ms ->
+// 0.29 | 0.30 | 0.35 ms.  Timing-only ablations of the linear pass: without the MFMA phase 0.12 ms, with an empty tile loop
+// 0.04 ms - the matrix phase (0.17 ms) runs at the instruction's rate (4 workgroups per CU x 78 tiles x 64 MFMAs x 16.5
+// cycles), and since nothing on the VALU overlaps an f64 MFMA on the same SIMD the table fill and the loads ADD to it.  What
+// mattered on the way: raw values 4 tiles ahead instead of 1, and ONE copy of the tile body (unrolled over the prefetch
+// stages, the variables and the tail case the kernel was 115 KB of code and no faster than 0.33 ms).
+// ---------------------------------------------------------------------------------------------------------------------
+#define TGM_STR 129
+#define TGM_PD 4                                      // tiles of raw values in flight per thread
+#define TGM_NV 4                                      // dictionary variables ([zeta] or [zeta; u]) this kernel takes
+template <int F, int DC, int NVC, bool UPRO>
+__global__ __launch_bounds__(256, 2) void kp_traj_gram_mfma_kernel(BasisDev b, const uint32_t* __restrict__ recipes, int D_rt, TrajView tv, int Ns,
+                                                                    double* __restrict__ Gout, double* __restrict__ Cout) {
+  extern __shared__ __align__(16) double sm[];
+  const int nv = b.nvars, m = b.m, N = b.N, W = b.W, nz = b.nzeta;
+  const int D = DC > 0 ? DC : D_rt;                   // DC: the table depth at compile time (the sweep's 13 / 6 / 4): unrolled fill
+  // table entries per (side, pair): powers | inputs | mask | 1 | 0 [| u_i x powers, i < m: `upro`, bilinear dictionaries - a
+  // column psi_c u_i then costs the lanes no extra factor (6 multiplies per 4 pairs and lane) but the filling thread D]
+  const int E = nv * D + m + 3 + (UPRO ? m * nv * D : 0);
+  const int id_u = nv * D, id_mask = id_u + m, id_one = id_mask + 1, id_zero = id_mask + 2, id_up = id_mask + 3;
+  const int buf_doubles = 2 * E * TGM_STR;            // one buffer: [side][entry][TGM_STR]
+  double* tab = sm;                                   // two buffers
+  double* Gs = sm;                                    // [4 waves][2][16][16]: the partial sums, over the table once it is dead
+  __shared__ uint32_t recs[SB_W];
+  const int tid = threadIdx.x, sys = blockIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid < N) recs[tid] = recipes[tid];
+  const int side = tid >> 7, p = tid & (TG_TS - 1);
+  const int Tm1 = tv.T - 1;
+  // constant entries of both buffers
+  for (int e = tid; e < 2 * 2 * 2 * TGM_STR; e += 256) {
+    const int pp = e % TGM_STR, which = (e / TGM_STR) & 1, sd = (e / (2 * TGM_STR)) & 1, bf = e / (4 * TGM_STR);
+    tab[bf * buf_doubles + (sd * E + (which ? id_zero : id_one)) * TGM_STR + pp] = which ? 0.0 : 1.0;
+  }
+  __syncthreads();
+  // ---- this lane's six operand values as F byte offsets each (entries of pair lane >> 4 of k-step `wave`) ----
+  const int li = lane & 3, kq = lane >> 4, blk = (lane >> 2) & 3;
+  int off[6][F];
+#pragma unroll
+  for (int sl = 0; sl < 6; ++sl) {
+    const int c = sl < 4 ? 4 * sl + li : 4 * blk + li;          // column of Px (slots 0-4) or Py (slot 5)
+    const int sd = sl == 5 ? 1 : 0;
+    int ids[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) ids[f] = id_one;
+    if (c >= W) ids[0] = id_zero;
+    else {
+      int pc = c, iu = -1;                                      // dictionary column and input factor of Px column c
+      if (b.model_type == KP_MODEL_LINEAR) { if (c >= N) { pc = -1; iu = c - N; } }
+      else if (b.model_type == KP_MODEL_BILINEAR) { pc = c % N; iu = c / N - 1; }
+      int nf = 0;
+      if (pc >= 0) {
+        const uint32_t rc = recs[pc];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          const int id = (int)((rc >> (8 * f)) & 255u);
+          if (id != 255 && nf < F) ids[nf++] = id;
+        }
+      }
+      if (iu >= 0) {
+        if (UPRO && nf > 0) ids[0] = id_up + iu * nv * D + ids[0];
+        else if (nf < F) ids[nf++] = id_u + iu;
+      }
+      if (nf == 0) ids[0] = id_mask;                            // the constant column: 1 inside the data, 0 past it
+    }
+#pragma unroll
+    for (int f = 0; f < F; ++f) off[sl][f] = (((sd * E + ids[f]) * TGM_STR) + 4 * wave + kq) * 8;
+  }
+  double accG[4] = {0.0, 0.0, 0.0, 0.0}, accC[4] = {0.0, 0.0, 0.0, 0.0};
+  // Raw values of this thread's (side, pair), TGM_PD tiles ahead: a tile is ~0.6 us of matrix work now, less than a trip to
+  // HBM under load - fetched ONE tile ahead (as kp_traj_gram_kernel does for its 4.7 us tiles) every tile waited for its data.
+  // The stages rotate through register moves (a handful per tile): ONE copy of the tile body - unrolled over the stages the
+  // kernel was 115 KB of code.
+  constexpr int NVL = NVC > 0 ? NVC : TGM_NV;         // variables at compile time (the sweep: 1 or 2), else up to TGM_NV
+  double raw[TGM_PD][NVL], rin[TGM_PD][3];
+  double okq[TGM_PD];
+  // base addresses of this thread's columns (the per-tile part of an address is the row alone)
+  const double* pv[NVL];
+  const double* pu[3];
+#pragma unroll
+  for (int v = 0; v < NVL; ++v)
+    pv[v] = v < nz ? tv.Y + ((size_t)sys * tv.n + v) * tv.rows + side : tv.U + ((size_t)sys * tv.m + (v < nv ? v - nz : 0)) * tv.rows;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) pu[i] = tv.U + ((size_t)sys * tv.m + (i < m ? i : 0)) * tv.rows;
+  auto load_raw = [&](int r0, double (&rw)[NVL], double (&ri)[3]) {
+    const int pair = r0 + p;
+    const bool ok = pair < Ns;
+    const int tr = ok ? (int)(((unsigned long long)pair * tv.div_magic) >> 40) : 0;
+    const int row = ok ? tr + pair : 0;                // = tr T + (pair - tr (T - 1))
+#pragma unroll
+    for (int v = 0; v < NVL; ++v)
+      if (v < nv) rw[v] = pv[v][row];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      if (i < m) ri[i] = pu[i][row];
+    return ok ? 1.0 : 0.0;
+  };
+#pragma unroll
+  for (int st = 0; st < TGM_PD; ++st) okq[st] = load_raw(st * TG_TS, raw[st], rin[st]);
+  int bufsel = 0;
+  for (int rr = 0; rr < Ns; rr += TG_TS, bufsel ^= 1) {
+    // ---- table of this thread's (side, pair): T_1 .. T_D of every variable (the Chebyshev internal basis of the nested
+    // sweep), the inputs, the mask.  Entries of a pair past Ns are 0 (times the mask), so that every product is.
+    const double okf = okq[0];
+    double* my = tab + bufsel * buf_doubles + side * E * TGM_STR + p;
+    double ui[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) ui[i] = i < m ? rin[0][i] * okf : 0.0;
+    {
+#pragma unroll
+      for (int v = 0; v < NVL; ++v)
+        if (v < nv) {
+          const double x = raw[0][v], x2 = x + x;
+          double q = x * okf, qm = okf;                // masked recurrence: T_k(x) okf for every k
+          auto put = [&](int k, double val) {          // entry (v, k) and, for bilinear dictionaries, its products with the inputs
+            my[(v * D + k) * TGM_STR] = val;
+            if constexpr (UPRO) {
+#pragma unroll
+              for (int i = 0; i < 3; ++i)
+                if (i < m) my[(id_up + i * nv * D + v * D + k) * TGM_STR] = val * ui[i];
+            }
+          };
+          if constexpr (DC > 0) {
+#pragma unroll
+            for (int k = 0; k < DC; ++k) {
+              put(k, q);
+              const double qn = x2 * q - qm;
+              qm = q;
+              q = qn;
+            }
+          } else {
+            for (int k = 0; k < D; ++k) {
+              put(k, q);
+              const double qn = x2 * q - qm;
+              qm = q;
+              q = qn;
+            }
+          }
+        }
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+        if (i < m) my[(id_u + i) * TGM_STR] = ui[i];
+      my[id_mask * TGM_STR] = okf;
+    }
+    // rotate the stages, refill the last one
+#pragma unroll
+    for (int st = 0; st + 1 < TGM_PD; ++st) {
+      okq[st] = okq[st + 1];
+#pragma unroll
+      for (int v = 0; v < NVL; ++v) raw[st][v] = raw[st + 1][v];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) rin[st][i] = rin[st + 1][i];
+    }
+    okq[TGM_PD - 1] = load_raw(rr + TGM_PD * TG_TS, raw[TGM_PD - 1], rin[TGM_PD - 1]);
+    __syncthreads();
+    // ---- 8 of the tile's 32 four-pair steps on this wave ----
+    const char* tb = (const char*)(tab + bufsel * buf_doubles);
+    {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        double v6[6];
+#pragma unroll
+        for (int sl = 0; sl < 6; ++sl) {
+          double pr = *reinterpret_cast<const double*>(tb + off[sl][0] + j * 128);
+#pragma unroll
+          for (int f = 1; f < F; ++f) pr *= *reinterpret_cast<const double*>(tb + off[sl][f] + j * 128);
+          v6[sl] = pr;
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          accG[g] = __builtin_amdgcn_mfma_f64_4x4x4f64(v6[g], v6[4], accG[g], 0, 0, 0);
+          accC[g] = __builtin_amdgcn_mfma_f64_4x4x4f64(v6[g], v6[5], accC[g], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // ---- the four waves' partial sums, added in a fixed order; D layout: row 4 g + (lane >> 4), column 4 blk + (lane & 3) ----
+  __syncthreads();
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    Gs[((wave * 2 + 0) * 16 + 4 * g + kq) * 16 + 4 * blk + li] = accG[g];
+    Gs[((wave * 2 + 1) * 16 + 4 * g + kq) * 16 + 4 * blk + li] = accC[g];
+  }
+  __syncthreads();
+  const int gi = tid >> 4, gj = tid & 15;
+  if (gi < W && gj < W) {
+    double sg = 0.0, sc = 0.0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      sg += Gs[((w * 2 + 0) * 16 + gi) * 16 + gj];
+      sc += Gs[((w * 2 + 1) * 16 + gi) * 16 + gj];
+    }
+    Gout[(size_t)sys * W * W + (size_t)gj * W + gi] = sg;
+    Cout[(size_t)sys * W * W + (size_t)gj * W + gi] = sc;
+  }
+}
+
 // =====================================================================================================================
 // All degrees of one model type from ONE pass over the data (evaluate_rand_models.m loops degree by degree, :47-143).
 //  * The degree-j polynomial dictionary is a column subset of the degree-D one: def_polyLift orders the monomials by
@@ -1301,15 +1510,51 @@ extern "C" int kp_sweep_eval_nested(kp_ctx* ctx, const kp_traj* traj, const kp_b
   const int Ns = traj->ntrials * (traj->T - 1) - 1;
   if (!basis->d_recipes || nv > 8) return ctx->fail(KP_ERR_ARG, "kp_sweep_eval_nested: dictionary not supported by the power-table lift");
   const size_t lds = ((size_t)2 * TG_TS * SB_LD + (size_t)2 * nv * Dp * TG_TS + 2 * 16 * SB_LD) * sizeof(double);
-  if (lds > 150 * 1024) return ctx->fail(KP_ERR_ARG, "kp_sweep_eval_nested: dictionary too large for the power-table lift");
-  {
+  // the matrix-pipe form: factors per operand value = monomial factors (+ the input of a bilinear column); two table buffers
+  const int nfac0 = basis->max_factors > 0 ? basis->max_factors : 1;
+  const size_t lds_up = (size_t)2 * 2 * (nv * Dp * (1 + m) + m + 3) * TGM_STR * sizeof(double);
+  const int upro = b.model_type == KP_MODEL_BILINEAR && lds_up <= 78 * 1024;        // input products in the table
+  const int nfac = nfac0 + (b.model_type == KP_MODEL_BILINEAR && !upro ? 1 : 0);
+  const size_t lds_m = std::max(upro ? lds_up : (size_t)2 * 2 * (nv * Dp + m + 3) * TGM_STR * sizeof(double), (size_t)4 * 2 * 256 * sizeof(double));
+  static const bool gram_old = getenv("KP_SWEEP_GRAM_OLD") != nullptr;
+  const bool use_mfma = !gram_old && nfac <= 5 && nv <= TGM_NV && lds_m <= 78 * 1024;      // two workgroups per CU
+  if (!use_mfma && lds > 150 * 1024) return ctx->fail(KP_ERR_ARG, "kp_sweep_eval_nested: dictionary too large for the power-table lift");
+  KP_HIP(ctx, hipMemsetAsync(dS0, 0, (size_t)nb * 4, s));
+  if (use_mfma) {
+#define KP_TGM(F_, DC_, NV_, UP_)                                                                                               \
+    {                                                                                                                             \
+      static KpLdsCache tgm_lds;                                                                                                  \
+      KP_HIP(ctx, kp_ensure_lds(tgm_lds, (const void*)kp_traj_gram_mfma_kernel<F_, DC_, NV_, UP_>, lds_m));                       \
+      KP_HIP(ctx, hipEventRecord(ctx->ev0, s));                                                                                   \
+      hipLaunchKernelGGL((kp_traj_gram_mfma_kernel<F_, DC_, NV_, UP_>), dim3(nb), dim3(256), lds_m, s, b,                         \
+                         (const uint32_t*)basis->d_recipes, Dp, traj_view(traj), Ns, dGc, dCc);                                   \
+    }
+    // the shapes of evaluate_rand_models.m (1-D systems: linear degree 13, bilinear 6, nonlinear 4) with the table depth and
+    // the variable count at compile time; everything else with run-time values
+    if (nfac == 1 && Dp == 13 && nv == 1 && !upro) KP_TGM(1, 13, 1, false)
+    else if (nfac == 1 && Dp == 6 && nv == 1 && upro) KP_TGM(1, 6, 1, true)
+    else if (nfac == 2 && Dp == 4 && nv == 2 && !upro) KP_TGM(2, 4, 2, false)
+    else if (upro) switch (nfac) {
+      case 1: KP_TGM(1, 0, 0, true) break;
+      case 2: KP_TGM(2, 0, 0, true) break;
+      case 3: KP_TGM(3, 0, 0, true) break;
+      default: KP_TGM(4, 0, 0, true) break;
+    }
+    else switch (nfac) {
+      case 1: KP_TGM(1, 0, 0, false) break;
+      case 2: KP_TGM(2, 0, 0, false) break;
+      case 3: KP_TGM(3, 0, 0, false) break;
+      case 4: KP_TGM(4, 0, 0, false) break;
+      default: KP_TGM(5, 0, 0, false) break;
+    }
+#undef KP_TGM
+  } else {
     static KpLdsCache tg_lds;
     KP_HIP(ctx, kp_ensure_lds(tg_lds, (const void*)kp_traj_gram_kernel, lds));
+    KP_HIP(ctx, hipEventRecord(ctx->ev0, s));
+    hipLaunchKernelGGL(kp_traj_gram_kernel, dim3(nb), dim3(256), lds, s, b, (const uint32_t*)basis->d_recipes, Dp, basis->max_factors > 0 ? basis->max_factors : 1,
+                       traj_view(traj), Ns, 1, dGc, dCc);
   }
-  KP_HIP(ctx, hipMemsetAsync(dS0, 0, (size_t)nb * 4, s));
-  KP_HIP(ctx, hipEventRecord(ctx->ev0, s));
-  hipLaunchKernelGGL(kp_traj_gram_kernel, dim3(nb), dim3(256), lds, s, b, (const uint32_t*)basis->d_recipes, Dp, basis->max_factors > 0 ? basis->max_factors : 1,
-                     traj_view(traj), Ns, 1, dGc, dCc);
   KP_HIP(ctx, hipGetLastError());
   KP_HIP(ctx, hipEventRecord(ctx->ev1, s));
   (void)dKc;

@@ -375,3 +375,42 @@ def test_a_system_whose_fit_fails_shows_as_nan_in_the_sweep_table(ctx):
     for mt in degrees:
         assert np.isnan(tab[mt][:, 2]).all(), (mt, tab[mt][:, 2])
         assert np.isfinite(tab[mt][:, [0, 1, 3]]).all()
+
+
+def test_nested_sweep_with_two_states_and_two_inputs(ctx):
+    """The Gram pass of the nested sweep beyond the 1-D systems of evaluate_rand_models.m: 2 states and 2 inputs, so the
+    dictionaries have 2 variables (4 for the nonlinear model: [zeta; u]), monomials with two factors, two input columns
+    (linear) or two input blocks (bilinear).  K of every degree against the oracle's least squares on the same pairs."""
+    from koopman_realizations_amd.device import Traj, Basis
+    rng = np.random.default_rng(12)
+    nb, k, T, n, m = 3, 3, 220, 2, 2
+    systems = []
+    for s_ in range(nb):
+        A = np.array([[0.9, 0.1], [-0.1, 0.85]]) + 0.02 * rng.standard_normal((2, 2))
+        B = 0.1 * rng.standard_normal((2, 2))
+        trials = []
+        for _ in range(k + 1):
+            u = rng.uniform(-1, 1, (T, m)); y = np.zeros((T, n)); y[0] = rng.uniform(-0.5, 0.5, n)
+            for t in range(T - 1):
+                y[t + 1] = A @ y[t] + B @ u[t] + 0.05 * np.tanh(y[t] * u[t, ::-1])
+            trials.append({"t": np.arange(T) * 0.01, "y": y, "u": u})
+        systems.append({"train": trials[:k], "val": trials[k:]})
+    raw = sweep._stack_raw(systems)
+    assert raw is not None
+    traj = Traj(ctx, *raw)
+    for mt, D in (("linear", 3), ("bilinear", 1), ("nonlinear", 2)):
+        nv = n + (m if mt == "nonlinear" else 0)
+        basis = Basis(ctx, mt, n, m, [("poly", kra.poly_exponent_table(nv, D)[nv:])], None)
+        assert basis.W <= 16
+        err, st = traj.sweep_eval_nested(basis, D, np.inf)
+        assert (st == 0).all() and np.isfinite(err).all()
+        for i in range(nb):
+            sd, _ = ko.get_scale(ko.merge_trials(systems[i]["train"]))
+            pairs = ko.snapshot_pairs(sd, 0)
+            for dj in range(D):
+                dic = ko.build_dictionary(mt, n, m, ["poly"], [dj + 1])
+                Kref = ko.get_koopman(dic, pairs)["K"]
+                Kd = traj.nested_K(dj, dic.W)[i]
+                assert np.abs(Kd - Kref).max() <= 1e-9 * np.abs(Kref).max(), (mt, i, dj, np.abs(Kd - Kref).max() / np.abs(Kref).max())
+        basis.close()
+    traj.close()
