@@ -159,7 +159,9 @@ def bench_mpc(ctx, kra, basis, snaps, args):
         z1 = A_ @ z + sum(B_[:, i * N_:(i + 1) * N_] @ z * U[0, i] for i in range(3))
         zc = z1[:6]; uc = U[0]
     dtc = time.perf_counter() - t0
-    Z = basis.lift(F.LIFT_ECON, zeta[:args.mpc_batch])
+    # lifted states in the ABI's layout (one problem's N values contiguous = an N x nb column-major matrix, what a MATLAB caller
+    # holds); kp_lift returns nb x N column-major, and re-laying 2.7 MB out inside every timed call cost 1.4 of its 3.0 ms
+    Z = np.ascontiguousarray(basis.lift(F.LIFT_ECON, zeta[:args.mpc_batch]))
     mpc.step_batch(Z, u_prev[:args.mpc_batch], Yr[:args.mpc_batch])
     dtb = 1e30
     for _ in range(3):       # best of 3: one call is a few ms, so a single wall-clock sample is noisy

@@ -13,3 +13,12 @@ Z = basis.lift(F.LIFT_ECON, zeta)
 for i in range(5):
     t0 = time.perf_counter(); U, st = mpc.step_batch(Z, u_prev, Yr); dt = time.perf_counter() - t0
     print("step_batch wall %.3f ms kernel %.3f ms solved %d" % (dt * 1e3, ctx.timer(2), int((st == 0).sum())))
+# where the wall time goes: the C call alone (ctypes, arrays prepared) against the Python wrapper
+import ctypes as C
+Zc = np.ascontiguousarray(Z); UP = np.ascontiguousarray(u_prev); YR = np.ascontiguousarray(Yr)
+U = np.zeros((nb, mpc.m, mpc.Np)); st = np.zeros(nb, dtype=np.int32)
+for i in range(4):
+    t0 = time.perf_counter()
+    F.lib().kp_mpc_step_batch(mpc.handle, nb, F.dptr(Zc), F.dptr(UP), F.dptr(YR), F.dptr(U), st.ctypes.data_as(F.c_ip))
+    dt = time.perf_counter() - t0
+    print("C call alone %.3f ms, kernel %.3f ms" % (dt * 1e3, ctx.timer(2)))
