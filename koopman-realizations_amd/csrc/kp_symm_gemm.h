@@ -16,12 +16,12 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <math.h>
 
 // kernel choice by output size in (16 rows x 1 column) units, measured with tools/symm_gemm_probe at W = 336 / 136 / 60:
-// up to SG2_SMALL_UNITS the stage-everything kernel wins (latency), up to SG2_MID_UNITS 32 columns per workgroup (more
-// workgroups), above that 64
+// up to SG2_SMALL_UNITS the stage-everything kernel wins (latency); above, the tiled kernel with 32 / 48 / 64 / 96 columns
+// per workgroup, whichever fills the rounds of workgroups best (kp_symm_gemm2)
 #define SG2_SMALL_UNITS 19000
-#define SG2_MID_UNITS 250000
 #define SG2_KB 16        // contraction block
 #define SG2_RS 20        // LDS row stride (doubles): = 4 mod 8 -> the 4-row x 4-k operand reads of the MFMA spread over all banks
 
@@ -289,18 +289,44 @@ static inline hipError_t kp_symm_gemm_small(hipStream_t st, const double* G, con
   return hipGetLastError();
 }
 
-// variant: 0 = by shape; 1 = small-column kernel; 2 / 3 = tiled kernel with 32 / 64 columns per workgroup
+// variant: 0 = by shape; 1 = small-column kernel; 2 / 3 = tiled kernel with 32 / 64 columns per workgroup; 10 + RB = 16 RB columns
 static inline hipError_t kp_symm_gemm2(hipStream_t st, const double* G, const double* X, int W, int nc, double* C, int variant = 0) {
   if (W <= 0 || nc <= 0) return hipSuccess;
   // the tiled kernel addresses X with 32-bit byte offsets from a uniform base (one VGPR per staged row)
   if ((uint64_t)nc * (uint64_t)W * 8u >= (1ull << 32)) variant = 1;
   if (variant == 0) {
     const int64_t cols_rows = (int64_t)nc * ((W + 15) / 16);      // 16-row x 1-column units of output
-    variant = W < 48 || cols_rows <= SG2_SMALL_UNITS ? 1 : cols_rows <= SG2_MID_UNITS ? 2 : 3;
+    if (W < 48 || cols_rows <= SG2_SMALL_UNITS) variant = 1;
+    else {
+      // Columns per workgroup (16 RB) by a two-line cost model fitted to tools/symm_gemm_probe at W = 336 (RA = 7, 21 blocks):
+      // a workgroup takes  nkb (a + b RA RB)  and the launch  floor(r) + {0 | 0.55 | 1}  of those, r = workgroups / (2 per
+      // CU) - a last round that fills at most half of the slots runs one workgroup per CU and is that much shorter.  (The
+      // fixed 32 / 64 columns of before ran 663 workgroups on 512 slots at 14 112 columns, 552 at 11 760: 0.094 -> 0.090 ms
+      // and 0.092 -> 0.071 ms with the widths chosen here.)
+      static int slots = 0;
+      if (!slots) {
+        int dev = 0, cus = 256;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        slots = 2 * cus;
+      }
+      const int ra = sg2_pick_ra(W), nrt = (W + 16 * ra - 1) / (16 * ra), nkb = (W + SG2_KB - 1) / SG2_KB;
+      double best = 1e300;
+      for (int rb : {2, 3, 4, 6}) {
+        const double t_wg = nkb * (6.4e-4 + 8.6e-5 * ra * rb);
+        const double r = (double)nrt * ((nc + 16 * rb - 1) / (16 * rb)) / slots;
+        const double fl = floor(r), fr = r - fl;
+        const double rounds = r <= 1.0 ? 1.0 : fl + (fr < 1e-9 ? 0.0 : fr <= 0.5 ? 0.55 : 1.0);
+        if (t_wg * rounds < best) { best = t_wg * rounds; variant = 10 + rb; }
+      }
+    }
   }
   switch (variant) {
     case 1: return kp_symm_gemm_small(st, G, X, W, nc, C);
-    case 2: return sg2_launch_rb<2>(st, G, X, W, nc, C);
+    case 2: case 12: return sg2_launch_rb<2>(st, G, X, W, nc, C);
+    case 13: return sg2_launch_rb<3>(st, G, X, W, nc, C);
+    case 15: return sg2_launch_rb<5>(st, G, X, W, nc, C);
+    case 16: return sg2_launch_rb<6>(st, G, X, W, nc, C);
     default: return sg2_launch_rb<4>(st, G, X, W, nc, C);
   }
 }
