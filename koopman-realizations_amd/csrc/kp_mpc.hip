@@ -975,6 +975,7 @@ struct MpcArgs {
   const double *A, *B, *P, *S0, *r, *Aq, *bq0, *Anorm;
   EllMat ell;
   int* warm;            // [1 + nvar] active set of the previous single-problem step (nullptr: cold start)
+  int alias;            // batched launches: z | beta | S | e live inside the solver's scratch (dead before it is first written)
   int assemble_only;    // stop after the QP data have been exported (state-bound steps solve with the generic QP kernel)
   const double* U_lin;  // [nb][nvar] or nullptr: re-linearise along the lifted horizon of THESE inputs (pass >= 2 of a
                         // state-bound step, Kmpc.m:890-895) instead of starting from z
@@ -1002,7 +1003,7 @@ __host__ __device__ inline int mpc_lds_doubles(int N, int m, int Np, int nproj, 
 // WARM: single-problem instantiation with the active-set warm start; the batched one carries none of that code
 // (its registers and branches cost the batch 1.8x when they were a run-time option).
 template <bool WARM>
-__global__ __launch_bounds__(256) void kp_mpc_step_kernel(MpcArgs a) {
+__device__ __forceinline__ void mpc_step_body(const MpcArgs& a) {
   extern __shared__ __align__(16) double sm[];
   const int tid = threadIdx.x;
   const int pb = blockIdx.x;
@@ -1023,11 +1024,11 @@ __global__ __launch_bounds__(256) void kp_mpc_step_kernel(MpcArgs a) {
       }
     }
   }
-  double* z = sm;
-  double* beta = z + N;                  // N x m  (Beta(z) = B kron(I,z), Ksysid.m:1288-1289)
-  double* S = beta + N * m;              // [Np][nproj x m]
-  double* ev = S + Np * nproj * m;       // [(Np+1)][nproj]   P_i z - Yr_i
-  double* Hq = ev + (Np + 1) * nproj;    // nv x nv  (= 2H)
+  // a.alias (batched launches, one linearisation pass): the assembly's inputs z | beta | S | e are dead once Hq and f
+  // exist, which is before the solver's scratch is first written - they live in its second n x n block, and a problem
+  // takes 40.7 KB instead of 44.6: FOUR workgroups per CU instead of three.
+  const int n_asm = N + N * m + Np * nproj * m + (Np + 1) * nproj;
+  double* Hq = sm + (a.alias ? 0 : n_asm);   // nv x nv  (= 2H)
   double* f = Hq + nv * nv;
   double* bq = f + nv;
   double* zh = bq + nr;                  // (Np+1) x N   lifted horizon (iters > 1)
@@ -1035,6 +1036,10 @@ __global__ __launch_bounds__(256) void kp_mpc_step_kernel(MpcArgs a) {
   int* st_sh = (int*)(full + (a.has_basis ? a.basis.nfull : 0));   // one slot for the QP status
   double* qpws = (double*)st_sh + 1;
   qpws += (qpws - sm) & 1;                // 16-byte aligned (sm is), by index arithmetic: the pointer stays an LDS pointer
+  double* z = a.alias ? qpws + nv * nv : sm;
+  double* beta = z + N;                  // N x m  (Beta(z) = B kron(I,z), Ksysid.m:1288-1289)
+  double* S = beta + N * m;              // [Np][nproj x m]
+  double* ev = S + Np * nproj * m;       // [(Np+1)][nproj]   P_i z - Yr_i
   const double* Yr = a.Yr + (size_t)pb * nproj * (Np + 1);
   const double* up = a.u_prev + (size_t)pb * m;
   long long* stamps = (a.stamps && pb == 0) ? a.stamps : nullptr;
@@ -1303,6 +1308,16 @@ __global__ __launch_bounds__(256) void kp_mpc_step_kernel(MpcArgs a) {
       __hip_atomic_store(&a.done_flag[0], a.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
+}
+
+// Two entry points over the same body: the single-problem kernel (warm start, workgroup-wide solver) may use every register
+// it likes; the batched one is held to 128 so that FOUR workgroups share a CU (with a.alias their LDS fits).
+template <bool WARM>
+__global__ __launch_bounds__(256) void kp_mpc_step_kernel(MpcArgs a) {
+  mpc_step_body<WARM>(a);
+}
+__global__ __launch_bounds__(256, 4) void kp_mpc_step_batch_kernel(MpcArgs a) {
+  mpc_step_body<false>(a);
 }
 
 // ---- host API ------------------------------------------------------------------------------------
@@ -1693,13 +1708,23 @@ static int mpc_run(kp_mpc* M, const kp_basis* basis, int nb, const double* z, co
     a.done_seq = ++M->step_seq;
   }
   size_t lds = (size_t)mpc_lds_doubles(N, m, Np, nproj, nv, nr, (sb && iters > 1) ? 2 : iters, zeta ? basis->dev.nfull : 0) * 8 + 32;
+  {
+    // batched launches: the assembly's inputs inside the solver's scratch, no exchange words of the workgroup-wide solver
+    const int n_asm = N + N * m + Np * nproj * m + (Np + 1) * nproj;
+    a.alias = (nb > 1 && !a.warm && !sb && iters == 1 && n_asm <= 2 * nv * nv) ? 1 : 0;
+    if (a.alias) lds -= (size_t)(n_asm + 64) * 8;
+  }
   if (lds > 160 * 1024) return ctx->fail(KP_ERR_ARG, "kp_mpc_step: problem too large for LDS");
   static KpLdsCache step_lds[2];
   const int wk = a.warm != nullptr;
-  KP_HIP(ctx, kp_ensure_lds(step_lds[wk], wk ? (const void*)kp_mpc_step_kernel<true> : (const void*)kp_mpc_step_kernel<false>, lds));
+  static KpLdsCache batch_lds;
+  const bool bk = a.alias != 0;                       // the batched entry point
+  if (bk) KP_HIP(ctx, kp_ensure_lds(batch_lds, (const void*)kp_mpc_step_batch_kernel, lds));
+  else KP_HIP(ctx, kp_ensure_lds(step_lds[wk], wk ? (const void*)kp_mpc_step_kernel<true> : (const void*)kp_mpc_step_kernel<false>, lds));
   if (!spin) KP_HIP(ctx, hipEventRecord(ctx->evp[4], ctx->stream));
   if (!sb) {
-    if (wk) hipLaunchKernelGGL(kp_mpc_step_kernel<true>, dim3(nb), dim3(256), lds, ctx->stream, a);
+    if (bk) hipLaunchKernelGGL(kp_mpc_step_batch_kernel, dim3(nb), dim3(256), lds, ctx->stream, a);
+    else if (wk) hipLaunchKernelGGL(kp_mpc_step_kernel<true>, dim3(nb), dim3(256), lds, ctx->stream, a);
     else hipLaunchKernelGGL(kp_mpc_step_kernel<false>, dim3(nb), dim3(256), lds, ctx->stream, a);
     KP_HIP(ctx, hipGetLastError());
   } else {
