@@ -414,3 +414,40 @@ def test_nested_sweep_with_two_states_and_two_inputs(ctx):
                 assert np.abs(Kd - Kref).max() <= 1e-9 * np.abs(Kref).max(), (mt, i, dj, np.abs(Kd - Kref).max() / np.abs(Kref).max())
         basis.close()
     traj.close()
+
+
+def test_nested_sweep_on_short_trials(ctx):
+    """Tile edges of the sweep's Gram pass (128 pairs per tile, raw values fetched four tiles ahead): 131 pairs (a second tile
+    with three of them), 256 pairs (exactly two tiles - from 2 trials of 129 rows), and a system with ONE pair, whose fit is
+    singular: status set, NaN errors, no crash."""
+    from koopman_realizations_amd.device import Traj, Basis
+    rng = np.random.default_rng(3)
+    for (k, T) in ((3, 45), (2, 130)):
+        systems = []
+        for _ in range(2):
+            trials = []
+            for _t in range(k + 1):
+                u = rng.uniform(-1, 1, (T, 1)); y = np.zeros((T, 1)); y[0] = rng.uniform(-0.5, 0.5)
+                for t in range(T - 1):
+                    y[t + 1] = 0.9 * y[t] + 0.2 * u[t] - 0.1 * y[t] ** 3
+                trials.append({"t": np.arange(T) * 0.01, "y": y, "u": u})
+            systems.append({"train": trials[:k], "val": trials[k:]})
+        traj = Traj(ctx, *sweep._stack_raw(systems))
+        basis = Basis(ctx, "linear", 1, 1, [("poly", kra.poly_exponent_table(1, 3)[1:])], None)
+        err, st = traj.sweep_eval_nested(basis, 3, np.inf)
+        assert (st == 0).all()
+        for i in range(2):
+            sd, _ = ko.get_scale(ko.merge_trials(systems[i]["train"]))
+            pairs = ko.snapshot_pairs(sd, 0)
+            assert pairs["alpha"].shape[0] == k * (T - 1) - 1
+            for dj in range(3):
+                dic = ko.build_dictionary("linear", 1, 1, ["poly"], [dj + 1])
+                Kref = ko.get_koopman(dic, pairs)["K"]
+                assert np.abs(traj.nested_K(dj, dic.W)[i] - Kref).max() <= 1e-9 * np.abs(Kref).max()
+        basis.close(); traj.close()
+    Y = rng.uniform(-1, 1, (2, 3, 1)); U = rng.uniform(-1, 1, (2, 3, 1))
+    traj = Traj(ctx, Y, U, 1, rng.uniform(-1, 1, (2, 20, 1)), rng.uniform(-1, 1, (2, 20, 1)))
+    basis = Basis(ctx, "linear", 1, 1, [("poly", kra.poly_exponent_table(1, 2)[1:])], None)
+    err, st = traj.sweep_eval_nested(basis, 2, np.inf)
+    assert (st != 0).all() and np.isnan(err).all()
+    basis.close(); traj.close()
