@@ -418,7 +418,7 @@ def test_nested_sweep_with_two_states_and_two_inputs(ctx):
 
 def test_nested_sweep_on_short_trials(ctx):
     """Tile edges of the sweep's Gram pass (128 pairs per tile, raw values fetched four tiles ahead): 131 pairs (a second tile
-    with three of them), 256 pairs (exactly two tiles - from 2 trials of 129 rows), and a system with ONE pair, whose fit is
+    with three of them), 257 pairs (two full tiles and one pair - 2 trials of 130 rows), and a system with ONE pair, whose fit is
     singular: status set, NaN errors, no crash."""
     from koopman_realizations_amd.device import Traj, Basis
     rng = np.random.default_rng(3)
