@@ -961,8 +961,7 @@ int kp_lasso_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, in
         const int last = nba - 1;
         if (v != last) {
           where[v] = where[last];
-          KP_HIP(ctx, hipMemcpyAsync(st + v, st + last, head, hipMemcpyDeviceToDevice, s));
-          memcpy(&hs(v), &hs(last), head);
+          memcpy(&hs(v), &hs(last), head);                 // (the device copy of the state moves with the slot's arrays below)
           slot_val[v] = slot_val[last];
           last_chg[v] = last_chg[last];
         }
@@ -978,7 +977,15 @@ int kp_lasso_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, in
           for (double* bsrc : mv) cp_mv.push_back({bsrc + (size_t)where[v] * n, bsrc + (size_t)v * n});
         }
       (void)nba0;
-      return flush_copies(cp_mv);
+      rc = flush_copies(cp_mv);
+      if (rc) return rc;
+      // the states of the moved slots: sources are survivors' original slots, destinations retired ones - disjoint sets, one
+      // launch (42 single hipMemcpyAsync of 100 bytes were 0.13 ms of a grid)
+      static_assert(offsetof(LassoState, part) % 8 == 0, "state head is copied as doubles");
+      std::vector<std::pair<const double*, double*>> cp_st;
+      for (int v = 0; v < nba; ++v)
+        if (where[v] != v) cp_st.push_back({(const double*)(st + where[v]), (double*)(st + v)});
+      return lasso_copies(ctx, s, cp_st, (int64_t)(head / 8));
     };
     if (polish) {
       const int rc = polish_round(Kb[kc]);
