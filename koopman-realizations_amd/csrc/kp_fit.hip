@@ -643,8 +643,10 @@ int kp_chol_solve_dev(kp_ctx* ctx, double* G_dev, double* C_dev, int W, int ncol
 // smallest pivot of the factorisation relative to its original diagonal entry, min_i L_ii^2 / G_ii: ~1 / cond(G) - what
 // the normal equations lose against the QR solve of `\` is cond(G) eps, so the caller can tell whether K needs the
 // refinement pass over the data (kp_fit_refine) at all
+// host_out (page-locked, device-mapped words of the context, or nullptr): [0] = the factorisation's info word, [1] = the ratio -
+// written by the kernel itself, so the read-back needs no copy command behind it (4 us of the one-fit latency)
 __global__ __launch_bounds__(256) void kp_pivot_ratio_kernel(const double* __restrict__ Lp, int n, const double* __restrict__ G, int W,
-                                                             double* __restrict__ out) {
+                                                             double* __restrict__ out, const int* __restrict__ info, double* host_out) {
   __shared__ double red[4];
   double r = 1e300;
   for (int i = threadIdx.x; i < W; i += 256) {
@@ -655,7 +657,15 @@ __global__ __launch_bounds__(256) void kp_pivot_ratio_kernel(const double* __res
   for (int o = 32; o > 0; o >>= 1) r = fmin(r, __shfl_xor(r, o, 64));
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = r;
   __syncthreads();
-  if (threadIdx.x == 0) out[0] = fmin(fmin(red[0], red[1]), fmin(red[2], red[3]));
+  if (threadIdx.x == 0) {
+    const double v = fmin(fmin(red[0], red[1]), fmin(red[2], red[3]));
+    out[0] = v;
+    if (host_out) {
+      host_out[1] = v;
+      *reinterpret_cast<int*>(host_out) = info[0];
+      __threadfence_system();
+    }
+  }
 }
 
 static int check_info(kp_ctx* ctx) {
@@ -668,13 +678,15 @@ static int read_chol_info(kp_ctx* ctx, int W, int ncols, int* bad, const double*
   const size_t off = kp_chol_info_offset(W, ncols);
   double* ratio_dev = (double*)((char*)ctx->ws[5] + off + 8);
   if (G_dev) {     // the factor is still in the padded buffer at the head of workspace 5
-    hipLaunchKernelGGL(kp_pivot_ratio_kernel, dim3(1), dim3(256), 0, ctx->stream, (const double*)ctx->ws[5], n, G_dev, W, ratio_dev);
+    hipLaunchKernelGGL(kp_pivot_ratio_kernel, dim3(1), dim3(256), 0, ctx->stream, (const double*)ctx->ws[5], n, G_dev, W, ratio_dev,
+                       (const int*)((char*)ctx->ws[5] + off), ctx->pin_small);
     KP_HIP(ctx, hipGetLastError());
   }
-  // info word (offset `off`) and pivot ratio (off + 8) sit side by side: one 16-byte DMA into page-locked memory instead of two
-  // staged copies into pageable words (25 us of the one-fit latency, tools/fit_timeline.py)
+  // info word (offset `off`) and pivot ratio (off + 8) sit side by side: the ratio kernel stores both into the context's
+  // page-locked words itself; without it (no G) one 16-byte DMA brings them (two staged copies into pageable words were
+  // 25 us of the one-fit latency, tools/fit_timeline.py)
   if (ctx->pin_small) {
-    KP_HIP(ctx, hipMemcpyAsync(ctx->pin_small, (char*)ctx->ws[5] + off, 16, hipMemcpyDeviceToHost, ctx->stream));
+    if (!G_dev) KP_HIP(ctx, hipMemcpyAsync(ctx->pin_small, (char*)ctx->ws[5] + off, 16, hipMemcpyDeviceToHost, ctx->stream));
     KP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     int info = 0;
     memcpy(&info, ctx->pin_small, sizeof(int));
