@@ -476,9 +476,11 @@ __device__ __forceinline__ void tr2_read_b(const double* __restrict__ xs, int j,
 
 // NJ = right-hand sides per workgroup / 4.  One system: NJ = 1 (W / 4 workgroups, the shortest serial chain per step); a batch
 // of systems: NJ = 4 (every workgroup reads all of L: fewer, wider workgroups keep that traffic down).
+// Kout (or nullptr): the solution goes there unpadded (W x ncols, leading dimension W) instead of back into X - the single-
+// system path, which then needs no unpad launch behind it.
 template <int NJ>
 __global__ __launch_bounds__(256) void kp_trsm2_kernel(const double* __restrict__ LU, const double* __restrict__ Dinv, int n, int ncp,
-                                                      double* __restrict__ X) {
+                                                      double* __restrict__ X, double* __restrict__ Kout, int W, int ncols) {
   extern __shared__ __align__(16) double xs[];  // [n][4 NJ] X block, columns in tr2_col order
   constexpr int NC = 4 * NJ;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -579,7 +581,13 @@ __global__ __launch_bounds__(256) void kp_trsm2_kernel(const double* __restrict_
   }
   for (int e = tid; e < n * NC; e += 256) {
     int row = e % n, col = e / n;
-    Xb[(size_t)col * n + row] = xs[row * NC + tr2_col<NJ>(col)];
+    const double v = xs[row * NC + tr2_col<NJ>(col)];
+    if (Kout) {
+      const int gc = cb * NC + col;
+      if (row < W && gc < ncols) Kout[(size_t)gc * W + row] = v;
+    } else {
+      Xb[(size_t)col * n + row] = v;
+    }
   }
 }
 
@@ -621,11 +629,13 @@ int kp_chol_solve_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_de
     KP_HIP(ctx, kp_ensure_lds(trsm_lds, (const void*)kp_trsm_kernel, lds_trsm));
     hipLaunchKernelGGL(kp_trsm_kernel, dim3(ncp / 16, nb), dim3(256), lds_trsm, st, Gp, Dinv, n, Cp);
   } else if (nb == 1) {       // one system: 4 right-hand sides per workgroup - the shortest serial chain per step (LDS <= 16 KB)
-    hipLaunchKernelGGL((kp_trsm2_kernel<1>), dim3(ncp / 4, nb), dim3(256), (size_t)n * 4 * 8, st, Gp, Dinv, n, ncp, Cp);
+    hipLaunchKernelGGL((kp_trsm2_kernel<1>), dim3(ncp / 4, nb), dim3(256), (size_t)n * 4 * 8, st, Gp, Dinv, n, ncp, Cp, K_dev, W, ncols);
+    KP_HIP(ctx, hipGetLastError());
+    return KP_OK;                                           // K written in place: no unpad launch
   } else {                    // a batch: 16 per workgroup, every workgroup reads all of L
     static KpLdsCache trsm2_lds;
     KP_HIP(ctx, kp_ensure_lds(trsm2_lds, (const void*)kp_trsm2_kernel<4>, (size_t)n * 16 * 8));
-    hipLaunchKernelGGL((kp_trsm2_kernel<4>), dim3(ncp / 16, nb), dim3(256), (size_t)n * 16 * 8, st, Gp, Dinv, n, ncp, Cp);
+    hipLaunchKernelGGL((kp_trsm2_kernel<4>), dim3(ncp / 16, nb), dim3(256), (size_t)n * 16 * 8, st, Gp, Dinv, n, ncp, Cp, (double*)nullptr, W, ncols);
   }
   KP_HIP(ctx, hipGetLastError());
   hipLaunchKernelGGL(kp_unpad_kernel, dim3((unsigned)(((int64_t)W * ncols + 255) / 256), nb), dim3(256), 0, st, Cp, n, W, ncols, K_dev, ncp, k_first,
