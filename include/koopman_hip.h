@@ -224,7 +224,9 @@ int kp_fit_batch(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* snaps, 
  *   >= 1e6 or Inf: least squares, else the L1 budget lasso * N of :996, evaluate_rand_models.m:122) + model
  *   extraction (get_model with the M-projection / get_BLmodel / get_NLmodel) + validation rollout (val_model /
  *   val_BLmodel / val_NLmodel) + normalised mean error (evaluate_rand_models.m:69-72).  err_out: nb x n
- *   (system-major); K_out (nb x W x W) and status_out (nb, != 0: singular Gram, err = NaN) may be NULL. */
+ *   (system-major); K_out (nb x W x W) and status_out (nb, != 0: singular Gram, err = NaN) may be NULL.
+ * kp_traj_destroy: before kp_destroy of its context, like every handle (the object's device blocks return to a small pool of
+ *   the context, which the next kp_traj_upload draws from and kp_destroy frees). */
 typedef struct kp_traj kp_traj;
 int kp_traj_upload(kp_ctx* ctx, const double* Y, const double* U, int nb, int ntrials, int T, int n, int m,
                    const double* Yv, const double* Uv, int Tv, kp_traj** traj);

@@ -413,6 +413,7 @@ struct kp_traj {
   kp_ctx* ctx = nullptr;
   int nb = 0, ntrials = 0, T = 0, n = 0, m = 0, Tv = 0;
   double *Y = nullptr, *U = nullptr, *Yv = nullptr, *Uv = nullptr, *sc = nullptr;
+  size_t cap[5] = {0, 0, 0, 0, 0};      // real sizes of the five blocks (they may come from the context's pool)
 };
 
 // min / max per column over the training rows of one system -> offset (max+min)/2, factor (max-min)/2 (1 when the range
@@ -458,6 +459,41 @@ static TrajView traj_view(const kp_traj* t) {
   return TrajView{t->Y, t->U, t->sc, t->ntrials, t->T, t->ntrials * t->T, t->n, t->m, ((1ull << 40) + d - 1) / d};
 }
 
+#define KP_TRAJ_POOL_MAX 10
+// a block of at least `bytes` (and at most twice that) from the context's pool, else a new one; cap = its real size
+static hipError_t traj_alloc(kp_ctx* ctx, double** p, size_t bytes, size_t* cap) {
+  static const bool no_pool = getenv("KP_NO_TRAJ_POOL") != nullptr;
+  if (!no_pool) {
+    int best = -1;
+    for (size_t i = 0; i < ctx->traj_pool.size(); ++i) {
+      const size_t c = ctx->traj_pool[i].second;
+      if (c >= bytes && c <= 2 * bytes + 4096 && (best < 0 || c < ctx->traj_pool[best].second)) best = (int)i;
+    }
+    if (best >= 0) {
+      *p = (double*)ctx->traj_pool[best].first;
+      *cap = ctx->traj_pool[best].second;
+      ctx->traj_pool.erase(ctx->traj_pool.begin() + best);
+      return hipSuccess;
+    }
+  }
+  *cap = bytes;
+  return hipMalloc((void**)p, bytes);
+}
+static void traj_release(kp_ctx* ctx, void* p, size_t cap) {
+  if (!p) return;
+  static const bool no_pool = getenv("KP_NO_TRAJ_POOL") != nullptr;
+  if (no_pool || !ctx) { (void)hipFree(p); return; }
+  ctx->traj_pool.push_back({p, cap});
+  while (ctx->traj_pool.size() > KP_TRAJ_POOL_MAX) {       // the oldest goes
+    (void)hipFree(ctx->traj_pool.front().first);
+    ctx->traj_pool.erase(ctx->traj_pool.begin());
+  }
+}
+void kp_traj_pool_free(kp_ctx* ctx) {
+  for (auto& b : ctx->traj_pool) (void)hipFree(b.first);
+  ctx->traj_pool.clear();
+}
+
 extern "C" int kp_traj_upload(kp_ctx* ctx, const double* Y, const double* U, int nb, int ntrials, int T, int n, int m, const double* Yv,
                               const double* Uv, int Tv, kp_traj** out) {
   if (!ctx || !Y || !U || !Yv || !Uv || !out || nb < 1 || ntrials < 1 || T < 3 || n < 1 || m < 1 || Tv < 2 || (int64_t)ntrials * T >= (1 << 24))
@@ -467,11 +503,11 @@ extern "C" int kp_traj_upload(kp_ctx* ctx, const double* Y, const double* U, int
   t->ctx = ctx; t->nb = nb; t->ntrials = ntrials; t->T = T; t->n = n; t->m = m; t->Tv = Tv;
   const size_t rows = (size_t)ntrials * T;
   const size_t bY = (size_t)nb * rows * n * 8, bU = (size_t)nb * rows * m * 8, bYv = (size_t)nb * Tv * n * 8, bUv = (size_t)nb * Tv * m * 8;
-  hipError_t e = hipMalloc((void**)&t->Y, bY);
-  if (e == hipSuccess) e = hipMalloc((void**)&t->U, bU);
-  if (e == hipSuccess) e = hipMalloc((void**)&t->Yv, bYv);
-  if (e == hipSuccess) e = hipMalloc((void**)&t->Uv, bUv);
-  if (e == hipSuccess) e = hipMalloc((void**)&t->sc, (size_t)nb * 2 * (n + m) * 8);
+  hipError_t e = traj_alloc(ctx, &t->Y, bY, &t->cap[0]);
+  if (e == hipSuccess) e = traj_alloc(ctx, &t->U, bU, &t->cap[1]);
+  if (e == hipSuccess) e = traj_alloc(ctx, &t->Yv, bYv, &t->cap[2]);
+  if (e == hipSuccess) e = traj_alloc(ctx, &t->Uv, bUv, &t->cap[3]);
+  if (e == hipSuccess) e = traj_alloc(ctx, &t->sc, (size_t)nb * 2 * (n + m) * 8, &t->cap[4]);
   hipStream_t s = ctx->stream;
   if (e == hipSuccess) e = hipMemcpyAsync(t->Y, Y, bY, hipMemcpyHostToDevice, s);
   if (e == hipSuccess) e = hipMemcpyAsync(t->U, U, bU, hipMemcpyHostToDevice, s);
@@ -488,6 +524,7 @@ extern "C" int kp_traj_upload(kp_ctx* ctx, const double* Y, const double* U, int
   if (e == hipSuccess) e = hipStreamSynchronize(s);
   if (e != hipSuccess) {
     double* bufs[] = {t->Y, t->U, t->Yv, t->Uv, t->sc};
+    (void)hipStreamSynchronize(s);
     for (double* p : bufs)
       if (p) (void)hipFree(p);
     delete t;
@@ -500,8 +537,9 @@ extern "C" int kp_traj_upload(kp_ctx* ctx, const double* Y, const double* U, int
 extern "C" int kp_traj_destroy(kp_traj* t) {
   if (!t) return KP_OK;
   double* bufs[] = {t->Y, t->U, t->Yv, t->Uv, t->sc};
-  for (double* p : bufs)
-    if (p) (void)hipFree(p);
+  // the blocks go back to the context's pool - once the device is done with them (every entry point that used them has
+  // synchronised its stream before returning)
+  for (int i = 0; i < 5; ++i) traj_release(t->ctx, bufs[i], t->cap[i]);
   delete t;
   return KP_OK;
 }

@@ -99,6 +99,7 @@ extern "C" int kp_destroy(kp_ctx* c) {
   (void)hipEventDestroy(c->ev0);
   (void)hipEventDestroy(c->ev1);
   (void)hipStreamDestroy(c->stream);
+  kp_traj_pool_free(c);
   kp_host_free_all(c);
   delete c;
   return KP_OK;

@@ -5,6 +5,7 @@
 #include <atomic>
 #include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "koopman_hip.h"
@@ -20,6 +21,10 @@ struct kp_ctx {
   int device = 0;
   kp_stage* stage = nullptr;
   std::vector<void*> host_blocks;       // kp_host_alloc: page-locked host buffers handed to the caller
+  // device blocks of destroyed trajectory objects, kept for the next kp_traj_upload (a sweep that uploads chunk after chunk
+  // paid 5 hipMalloc + 5 hipFree per chunk: 1.3 ms of the 16.5 ms of 1024 systems); at most KP_TRAJ_POOL_MAX blocks,
+  // freed by kp_destroy
+  std::vector<std::pair<void*, size_t>> traj_pool;
   std::mutex host_mu;                   // ... a gathering host thread may ask for one while another thread drives the device
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -185,6 +190,7 @@ struct kp_snapshots {
 void* kp_pinned_scratch(kp_ctx* ctx, size_t bytes);
 void kp_stage_destroy(kp_ctx* ctx);
 void kp_host_free_all(kp_ctx* ctx);
+void kp_traj_pool_free(kp_ctx* ctx);
 // Around every launch sequence that reads a snapshot object.  All readers run on ctx->stream, so one wait orders the
 // later ones too.
 inline hipError_t kp_snaps_acquire(const kp_snapshots* s, hipStream_t st) {
