@@ -157,14 +157,15 @@ def rand_models_sweep(systems, comm=None, ctx=None, degrees=None, eval_fn=None, 
     return {mt: np.stack([r[mt][0] for r in allres], axis=1) for mt in ("linear", "bilinear", "nonlinear")}
 
 
-def _stack_raw(systems, ctx=None, slot=""):  # slot: suffix of the buffer names (a caller that keeps two gathers alive)
+def _stack_raw(systems, ctx=None, slot="", overlap=None):  # slot: suffix of the buffer names (a caller that keeps two gathers alive)
     """The systems' trials as stacked raw arrays (no arithmetic): Y (nb, k T, n), U (nb, k T, m), trial count k, and the
     validation trial Yv, Uv - or None unless every system has the same trial layout (equal counts and lengths, time
     restarting at every trial: the generated and shipped rand-systems sets).  With a device context the blocks are
     gathered into its page-locked host arrays (Context.host_array, reused from call to call: no first-touch page faults -
     they were two thirds of this function's time - and the upload that follows is a direct DMA); the returned arrays are
-    then views that stay valid until the next call with the same context and `slot` (a suffix of the buffer names: the
-    pipelined sweep gathers one chunk while the previous one is still being uploaded)."""
+    then views that stay valid until the next call with the same context and `slot`.  `overlap(Y, U, k, Yv, Uv)`, if given,
+    is called as soon as the four blocks exist and BEFORE the seam test of the time vectors (2 ms that read other data): the
+    batched sweep starts its upload there; when the test then fails the caller discards what `overlap` started."""
     try:
         tr = [d["train"] for d in systems]
         k = len(tr[0])
@@ -202,6 +203,10 @@ def _stack_raw(systems, ctx=None, slot=""):  # slot: suffix of the buffer names 
             return out
         Y, U = stacked("y", tr, "Y"), stacked("u", tr, "U")
         T = Y.shape[1] // k
+        va = [[d["val"][0]] for d in systems]
+        Yv, Uv = stacked("y", va, "Yv"), stacked("u", va, "Uv")
+        if overlap is not None:
+            overlap(Y, U, k, Yv, Uv)
         # Ksysid.m:948: seams between trials exactly at the trial joins, nowhere else.  The time vectors are only LOOKED at
         # (threads, no copy: csrc/kp_pygather.c); stacking them and comparing in numpy cost a third of this function
         seams_ok = None
@@ -218,8 +223,6 @@ def _stack_raw(systems, ctx=None, slot=""):  # slot: suffix of the buffer names 
             seams_ok = not (seams.any() or int(np.count_nonzero(good)) != good.size - seams.size)
         if not seams_ok:
             return None
-        va = [[d["val"][0]] for d in systems]
-        Yv, Uv = stacked("y", va, "Yv"), stacked("u", va, "Uv")
     except ValueError:
         return None
     return Y, U, k, Yv, Uv
@@ -236,13 +239,22 @@ def rand_models_sweep_batched(systems, ctx, degrees=None, nested=True):
     from .device import Basis, Traj
     from .ksysid import poly_exponent_table
     degrees = degrees or MAX_DEGREE
-    raw = _stack_raw(systems, ctx)
+    # the upload (3.5 ms per 1024 systems, the DMA engine's) starts in a helper thread as soon as the blocks are gathered and
+    # runs beside the seam test of the time vectors (2 ms of host threads); both calls release the GIL
+    from concurrent.futures import ThreadPoolExecutor
+    from .device import Traj
+    started = []
+    with ThreadPoolExecutor(1) as ex:
+        raw = _stack_raw(systems, ctx, overlap=lambda *blocks: started.append(ex.submit(Traj, ctx, *blocks)))
+        traj = started[0].result() if started else None
     if raw is None:
+        if traj is not None:
+            traj.close()
         return _sweep_batched_host(systems, ctx, degrees)
-    return rand_models_sweep_arrays(*raw, ctx=ctx, degrees=degrees, nested=nested)
+    return rand_models_sweep_arrays(*raw, ctx=ctx, degrees=degrees, nested=nested, traj=traj)
 
 
-def rand_models_sweep_arrays(Y, U, k, Yv, Uv, ctx, degrees=None, nested=True):
+def rand_models_sweep_arrays(Y, U, k, Yv, Uv, ctx, degrees=None, nested=True, traj=None):
     """The batched sweep on already stacked raw trajectories: Y (nb, k T, n), U (nb, k T, m) = the k training trials of
     every system back to back, Yv / Uv (nb, Tv, ·) the validation trial (what `_stack_raw` builds from the reference's
     data4sysid structs; a generator or loader that produces the blocks directly skips that gathering)."""
@@ -250,7 +262,8 @@ def rand_models_sweep_arrays(Y, U, k, Yv, Uv, ctx, degrees=None, nested=True):
     from .ksysid import poly_exponent_table
     degrees = degrees or MAX_DEGREE
     n, m = Y.shape[2], U.shape[2]
-    traj = Traj(ctx, Y, U, k, Yv, Uv)
+    if traj is None:                                   # (else: the caller has uploaded these very blocks already)
+        traj = Traj(ctx, Y, U, k, Yv, Uv)
     out = {}
     try:
         for mt in ("linear", "bilinear", "nonlinear"):
