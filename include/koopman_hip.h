@@ -232,6 +232,15 @@ int kp_traj_upload(kp_ctx* ctx, const double* Y, const double* U, int nb, int nt
                    const double* Yv, const double* Uv, int Tv, kp_traj** traj);
 int kp_traj_destroy(kp_traj* traj);
 int kp_traj_scale(kp_traj* traj, double* sc_out);
+/* kp_traj_upload in three steps, for callers that assemble the four blocks one after the other (the reference hands
+ * evaluate_rand_models.m:45-59 a cell array of data4sysid structs: thousands of small trial arrays to be gathered): every
+ * block is on its way to the device while the next one is prepared.  kp_traj_create: the device blocks; kp_traj_put: block
+ * `which` (0 Y, 1 U, 2 Yv, 3 Uv; layouts as kp_traj_upload) by ONE host-to-device copy enqueued on the context's stream -
+ * asynchronous when `host` is page-locked (kp_host_alloc), which must then stay untouched until kp_traj_finish;
+ * kp_traj_finish: scaling on the device, stream synchronised - only then may the object be used. */
+int kp_traj_create(kp_ctx* ctx, int nb, int ntrials, int T, int n, int m, int Tv, kp_traj** traj);
+int kp_traj_put(kp_traj* traj, int which, const double* host);
+int kp_traj_finish(kp_traj* traj);
 int kp_sweep_eval(kp_ctx* ctx, const kp_traj* traj, const kp_basis* basis, double lasso, double* err_out, double* K_out,
                   int* status_out);
 /* kp_sweep_eval for degrees 1..n_deg of a POLYNOMIAL dictionary from ONE pass over the data (evaluate_rand_models.m

@@ -62,6 +62,9 @@ SIGNATURES = {
     "kp_fit_batch": (C.c_int, [vp, vp, vp, C.c_int, C.c_int64, c_dp, c_dp, c_dp, C.POINTER(C.c_int)]),
     "kp_traj_upload": (C.c_int, [vp, c_dp, c_dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_dp, c_dp, C.c_int, C.POINTER(vp)]),
     "kp_traj_destroy": (C.c_int, [vp]),
+    "kp_traj_create": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
+    "kp_traj_put": (C.c_int, [vp, C.c_int, c_dp]),
+    "kp_traj_finish": (C.c_int, [vp]),
     "kp_traj_scale": (C.c_int, [vp, c_dp]),
     "kp_sweep_eval": (C.c_int, [vp, vp, vp, C.c_double, c_dp, c_dp, c_ip]),
     "kp_sweep_eval_nested": (C.c_int, [vp, vp, vp, C.c_double, C.c_int, c_dp, c_ip]),

@@ -414,6 +414,7 @@ struct kp_traj {
   int nb = 0, ntrials = 0, T = 0, n = 0, m = 0, Tv = 0;
   double *Y = nullptr, *U = nullptr, *Yv = nullptr, *Uv = nullptr, *sc = nullptr;
   size_t cap[5] = {0, 0, 0, 0, 0};      // real sizes of the five blocks (they may come from the context's pool)
+  int have = 0;                         // bit w: block w has been put; 31: scaled (ready)
 };
 
 // min / max per column over the training rows of one system -> offset (max+min)/2, factor (max-min)/2 (1 when the range
@@ -494,9 +495,13 @@ void kp_traj_pool_free(kp_ctx* ctx) {
   ctx->traj_pool.clear();
 }
 
-extern "C" int kp_traj_upload(kp_ctx* ctx, const double* Y, const double* U, int nb, int ntrials, int T, int n, int m, const double* Yv,
-                              const double* Uv, int Tv, kp_traj** out) {
-  if (!ctx || !Y || !U || !Yv || !Uv || !out || nb < 1 || ntrials < 1 || T < 3 || n < 1 || m < 1 || Tv < 2 || (int64_t)ntrials * T >= (1 << 24))
+// The object in three steps, so that a caller that assembles the four blocks one after the other (the host mirror gathers
+// them from thousands of small trial arrays) has each one on its way to the device while it prepares the next:
+//   kp_traj_create (device blocks), kp_traj_put (which = 0 Y, 1 U, 2 Yv, 3 Uv: ONE host-to-device copy enqueued on the
+//   context's stream - asynchronous when `host` is page-locked, e.g. a kp_host_alloc block, which must then stay untouched
+//   until kp_traj_finish), kp_traj_finish (scaling on the device, stream synchronised: the object is ready).
+extern "C" int kp_traj_create(kp_ctx* ctx, int nb, int ntrials, int T, int n, int m, int Tv, kp_traj** out) {
+  if (!ctx || !out || nb < 1 || ntrials < 1 || T < 3 || n < 1 || m < 1 || Tv < 2 || (int64_t)ntrials * T >= (1 << 24))
     return ctx ? ctx->fail(KP_ERR_ARG, "kp_traj_upload: bad argument") : KP_ERR_ARG;
   KP_HIP(ctx, hipSetDevice(ctx->device));
   kp_traj* t = new kp_traj;
@@ -508,27 +513,66 @@ extern "C" int kp_traj_upload(kp_ctx* ctx, const double* Y, const double* U, int
   if (e == hipSuccess) e = traj_alloc(ctx, &t->Yv, bYv, &t->cap[2]);
   if (e == hipSuccess) e = traj_alloc(ctx, &t->Uv, bUv, &t->cap[3]);
   if (e == hipSuccess) e = traj_alloc(ctx, &t->sc, (size_t)nb * 2 * (n + m) * 8, &t->cap[4]);
-  hipStream_t s = ctx->stream;
-  if (e == hipSuccess) e = hipMemcpyAsync(t->Y, Y, bY, hipMemcpyHostToDevice, s);
-  if (e == hipSuccess) e = hipMemcpyAsync(t->U, U, bU, hipMemcpyHostToDevice, s);
-  if (e == hipSuccess) e = hipMemcpyAsync(t->Yv, Yv, bYv, hipMemcpyHostToDevice, s);
-  if (e == hipSuccess) e = hipMemcpyAsync(t->Uv, Uv, bUv, hipMemcpyHostToDevice, s);
-  if (e == hipSuccess) {
-    hipLaunchKernelGGL(kp_traj_scale_kernel, dim3(nb), dim3(256), 0, s, t->Y, t->U, (int)rows, n, m, t->sc);
-    hipLaunchKernelGGL(kp_traj_apply_scale_kernel, dim3(16, nb), dim3(256), 0, s, t->Y, (int)rows, n, n, m, 0, t->sc);
-    hipLaunchKernelGGL(kp_traj_apply_scale_kernel, dim3(16, nb), dim3(256), 0, s, t->U, (int)rows, m, n, m, 1, t->sc);
-    hipLaunchKernelGGL(kp_traj_apply_scale_kernel, dim3(2, nb), dim3(256), 0, s, t->Yv, Tv, n, n, m, 0, t->sc);
-    hipLaunchKernelGGL(kp_traj_apply_scale_kernel, dim3(2, nb), dim3(256), 0, s, t->Uv, Tv, m, n, m, 1, t->sc);
-    e = hipGetLastError();
-  }
-  if (e == hipSuccess) e = hipStreamSynchronize(s);
   if (e != hipSuccess) {
     double* bufs[] = {t->Y, t->U, t->Yv, t->Uv, t->sc};
-    (void)hipStreamSynchronize(s);
     for (double* p : bufs)
       if (p) (void)hipFree(p);
     delete t;
     return ctx->fail(KP_ERR_HIP, std::string("kp_traj_upload: ") + hipGetErrorString(e));
+  }
+  *out = t;
+  return KP_OK;
+}
+
+extern "C" int kp_traj_put(kp_traj* t, int which, const double* host) {
+  if (!t || !host || which < 0 || which > 3) return t ? t->ctx->fail(KP_ERR_ARG, "kp_traj_put: bad argument") : KP_ERR_ARG;
+  kp_ctx* ctx = t->ctx;
+  KP_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t rows = (size_t)t->ntrials * t->T;
+  double* dst[4] = {t->Y, t->U, t->Yv, t->Uv};
+  const size_t bytes[4] = {(size_t)t->nb * rows * t->n * 8, (size_t)t->nb * rows * t->m * 8, (size_t)t->nb * t->Tv * t->n * 8,
+                           (size_t)t->nb * t->Tv * t->m * 8};
+  KP_HIP(ctx, hipMemcpyAsync(dst[which], host, bytes[which], hipMemcpyHostToDevice, ctx->stream));
+  t->have |= 1 << which;
+  return KP_OK;
+}
+
+extern "C" int kp_traj_finish(kp_traj* t) {
+  if (!t) return KP_ERR_ARG;
+  kp_ctx* ctx = t->ctx;
+  if (t->have == 31) return KP_OK;
+  if (t->have != 15) return ctx->fail(KP_ERR_ARG, "kp_traj_finish: a block is missing (kp_traj_put of Y, U, Yv, Uv)");
+  KP_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  const int nb = t->nb, n = t->n, m = t->m, Tv = t->Tv;
+  const size_t rows = (size_t)t->ntrials * t->T;
+  hipLaunchKernelGGL(kp_traj_scale_kernel, dim3(nb), dim3(256), 0, s, t->Y, t->U, (int)rows, n, m, t->sc);
+  hipLaunchKernelGGL(kp_traj_apply_scale_kernel, dim3(16, nb), dim3(256), 0, s, t->Y, (int)rows, n, n, m, 0, t->sc);
+  hipLaunchKernelGGL(kp_traj_apply_scale_kernel, dim3(16, nb), dim3(256), 0, s, t->U, (int)rows, m, n, m, 1, t->sc);
+  hipLaunchKernelGGL(kp_traj_apply_scale_kernel, dim3(2, nb), dim3(256), 0, s, t->Yv, Tv, n, n, m, 0, t->sc);
+  hipLaunchKernelGGL(kp_traj_apply_scale_kernel, dim3(2, nb), dim3(256), 0, s, t->Uv, Tv, m, n, m, 1, t->sc);
+  KP_HIP(ctx, hipGetLastError());
+  KP_HIP(ctx, hipStreamSynchronize(s));
+  t->have = 31;                                       // scaled: a second finish would scale again
+  return KP_OK;
+}
+
+extern "C" int kp_traj_upload(kp_ctx* ctx, const double* Y, const double* U, int nb, int ntrials, int T, int n, int m, const double* Yv,
+                              const double* Uv, int Tv, kp_traj** out) {
+  if (!ctx || !Y || !U || !Yv || !Uv || !out) return ctx ? ctx->fail(KP_ERR_ARG, "kp_traj_upload: bad argument") : KP_ERR_ARG;
+  kp_traj* t = nullptr;
+  int rc = kp_traj_create(ctx, nb, ntrials, T, n, m, Tv, &t);
+  if (rc) return rc;
+  const double* src[4] = {Y, U, Yv, Uv};
+  for (int w = 0; w < 4 && rc == KP_OK; ++w) rc = kp_traj_put(t, w, src[w]);
+  if (rc == KP_OK) rc = kp_traj_finish(t);
+  if (rc) {
+    (void)hipStreamSynchronize(ctx->stream);
+    double* bufs[] = {t->Y, t->U, t->Yv, t->Uv, t->sc};
+    for (double* p : bufs)
+      if (p) (void)hipFree(p);
+    delete t;
+    return rc;
   }
   *out = t;
   return KP_OK;
@@ -547,6 +591,7 @@ extern "C" int kp_traj_destroy(kp_traj* t) {
 extern "C" int kp_traj_scale(kp_traj* t, double* sc_out) {
   if (!t || !sc_out) return KP_ERR_ARG;
   kp_ctx* ctx = t->ctx;
+  if (t->have != 31) return ctx->fail(KP_ERR_ARG, "kp_traj_scale: trajectory object not finished (kp_traj_finish)");
   KP_HIP(ctx, hipMemcpy(sc_out, t->sc, (size_t)t->nb * 2 * (t->n + t->m) * 8, hipMemcpyDeviceToHost));
   return KP_OK;
 }
@@ -669,6 +714,7 @@ __global__ void kp_l1_flag_kernel(const double* __restrict__ K, int W, double t,
 extern "C" int kp_sweep_eval(kp_ctx* ctx, const kp_traj* traj, const kp_basis* basis, double lasso, double* err_out, double* K_out,
                              int* status_out) {
   if (!ctx || !traj || !basis || !err_out) return ctx ? ctx->fail(KP_ERR_ARG, "kp_sweep_eval: bad argument") : KP_ERR_ARG;
+  if (traj->have != 31) return ctx->fail(KP_ERR_ARG, "kp_sweep_eval: trajectory object not finished (kp_traj_finish)");
   const BasisDev& b = basis->dev;
   if (b.nzeta != traj->n || b.m != traj->m) return ctx->fail(KP_ERR_ARG, "kp_sweep_eval: trajectory / dictionary dimension mismatch");
   if (b.W > SB_W || b.k_pcs != 0 || b.N != b.nfull || b.m > 3) return ctx->fail(KP_ERR_ARG, "kp_sweep_eval: needs W <= 16, m <= 3 and no dimension reduction");
@@ -1427,6 +1473,7 @@ static void cheb_table(int dmax, std::vector<std::vector<double>>& s1) {
 extern "C" int kp_sweep_eval_nested(kp_ctx* ctx, const kp_traj* traj, const kp_basis* basis, double lasso, int n_deg, double* err_out,
                                     int* status_out) {
   if (!ctx || !traj || !basis || !err_out || n_deg < 1) return ctx ? ctx->fail(KP_ERR_ARG, "kp_sweep_eval_nested: bad argument") : KP_ERR_ARG;
+  if (traj->have != 31) return ctx->fail(KP_ERR_ARG, "kp_sweep_eval_nested: trajectory object not finished (kp_traj_finish)");
   const BasisDev& b = basis->dev;
   if (b.nzeta != traj->n || b.m != traj->m) return ctx->fail(KP_ERR_ARG, "kp_sweep_eval_nested: trajectory / dictionary dimension mismatch");
   if (b.W > SB_W || b.k_pcs != 0 || b.N != b.nfull || b.m > 3 || !basis->fast || basis->h_recipes.size() != (size_t)b.nfull)

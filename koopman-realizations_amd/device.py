@@ -351,10 +351,46 @@ class Traj:
         self.ntrials, self.T, self.Tv = int(ntrials), rows // int(ntrials), Yv.shape[1]
         if self.T * self.ntrials != rows:
             raise ValueError("Traj: rows must be ntrials * T")
-        tr = lambda a: np.ascontiguousarray(np.transpose(a, (0, 2, 1)))        # each system column-major rows x width
+        tr = Traj._blocks
         self._h = F.vp()
         F.check(F.lib().kp_traj_upload(ctx.handle, F.dptr(tr(Y)), F.dptr(tr(U)), self.nb, self.ntrials, self.T, self.n, self.m,
                                        F.dptr(tr(Yv)), F.dptr(tr(Uv)), self.Tv, C.byref(self._h)), ctx.handle)
+
+    @staticmethod
+    def _blocks(a):
+        """(nb, rows, width) -> each system column-major rows x width (no copy for width 1)."""
+        return np.ascontiguousarray(np.transpose(a, (0, 2, 1)))
+
+    @classmethod
+    def begin(cls, ctx: Context, nb, ntrials, T, n, m, Tv):
+        """kp_traj_create: the object in three steps (begin, put x 4, finish), so that a caller that assembles the blocks one
+        after the other has each on its way to the device while it prepares the next."""
+        self = cls.__new__(cls)
+        self.ctx = ctx
+        ctx._children.add(self)
+        self.nb, self.ntrials, self.T, self.n, self.m, self.Tv = int(nb), int(ntrials), int(T), int(n), int(m), int(Tv)
+        self._h = F.vp()
+        self._keep = []
+        F.check(F.lib().kp_traj_create(ctx.handle, self.nb, self.ntrials, self.T, self.n, self.m, self.Tv, C.byref(self._h)), ctx.handle)
+        return self
+
+    def put(self, which, a):
+        """kp_traj_put: block 'Y' | 'U' | 'Yv' | 'Uv' as (nb, rows, width); asynchronous when `a` lies in page-locked memory
+        (Context.host_array), which must stay untouched until finish()."""
+        w = {"Y": 0, "U": 1, "Yv": 2, "Uv": 3}[which]
+        a = np.asarray(a, dtype=np.float64)
+        want = (self.nb, (self.ntrials * self.T) if w < 2 else self.Tv, self.n if w in (0, 2) else self.m)
+        if a.shape != want:
+            raise ValueError(f"Traj.put: block {which} has shape {a.shape}, expected {want}")
+        blk = Traj._blocks(a)
+        self._keep.append(blk)                                                # alive until the copy has been waited for
+        F.check(F.lib().kp_traj_put(self._h, w, F.dptr(blk)), self.ctx.handle)
+
+    def finish(self):
+        """kp_traj_finish: scaling on the device, stream synchronised - the object is ready."""
+        F.check(F.lib().kp_traj_finish(self._h), self.ctx.handle)
+        self._keep = []
+        return self
 
     @property
     def handle(self):

@@ -157,15 +157,16 @@ def rand_models_sweep(systems, comm=None, ctx=None, degrees=None, eval_fn=None, 
     return {mt: np.stack([r[mt][0] for r in allres], axis=1) for mt in ("linear", "bilinear", "nonlinear")}
 
 
-def _stack_raw(systems, ctx=None, slot="", overlap=None):  # slot: suffix of the buffer names (a caller that keeps two gathers alive)
+def _stack_raw(systems, ctx=None, slot="", on_block=None):  # slot: suffix of the buffer names (a caller that keeps two gathers alive)
     """The systems' trials as stacked raw arrays (no arithmetic): Y (nb, k T, n), U (nb, k T, m), trial count k, and the
     validation trial Yv, Uv - or None unless every system has the same trial layout (equal counts and lengths, time
     restarting at every trial: the generated and shipped rand-systems sets).  With a device context the blocks are
     gathered into its page-locked host arrays (Context.host_array, reused from call to call: no first-touch page faults -
     they were two thirds of this function's time - and the upload that follows is a direct DMA); the returned arrays are
-    then views that stay valid until the next call with the same context and `slot`.  `overlap(Y, U, k, Yv, Uv)`, if given,
-    is called as soon as the four blocks exist and BEFORE the seam test of the time vectors (2 ms that read other data): the
-    batched sweep starts its upload there; when the test then fails the caller discards what `overlap` started."""
+    then views that stay valid until the next call with the same context and `slot`.  `on_block(name, array)`, if given, is
+    called for 'Y', 'U', 'Yv', 'Uv' as soon as each block is gathered - the batched sweep enqueues its upload there, so the
+    DMA of one block runs beside the gather of the next and the seam test of the time vectors; when a later step fails
+    (None is returned) the caller discards what it started."""
     try:
         tr = [d["train"] for d in systems]
         k = len(tr[0])
@@ -201,12 +202,13 @@ def _stack_raw(systems, ctx=None, slot="", overlap=None):  # slot: suffix of the
             flat = out.reshape((-1,) + a0.shape[1:]) if a0.ndim > 1 else out.reshape(-1)
             np.concatenate(arrs, axis=0, out=flat)
             return out
-        Y, U = stacked("y", tr, "Y"), stacked("u", tr, "U")
+        note = on_block if on_block is not None else (lambda name, arr: None)
+        Y = stacked("y", tr, "Y"); note("Y", Y)
+        U = stacked("u", tr, "U"); note("U", U)
         T = Y.shape[1] // k
         va = [[d["val"][0]] for d in systems]
-        Yv, Uv = stacked("y", va, "Yv"), stacked("u", va, "Uv")
-        if overlap is not None:
-            overlap(Y, U, k, Yv, Uv)
+        Yv = stacked("y", va, "Yv"); note("Yv", Yv)
+        Uv = stacked("u", va, "Uv"); note("Uv", Uv)
         # Ksysid.m:948: seams between trials exactly at the trial joins, nowhere else.  The time vectors are only LOOKED at
         # (threads, no copy: csrc/kp_pygather.c); stacking them and comparing in numpy cost a third of this function
         seams_ok = None
@@ -239,18 +241,35 @@ def rand_models_sweep_batched(systems, ctx, degrees=None, nested=True):
     from .device import Basis, Traj
     from .ksysid import poly_exponent_table
     degrees = degrees or MAX_DEGREE
-    # the upload (3.5 ms per 1024 systems, the DMA engine's) starts in a helper thread as soon as the blocks are gathered and
-    # runs beside the seam test of the time vectors (2 ms of host threads); both calls release the GIL
-    from concurrent.futures import ThreadPoolExecutor
+    # every gathered block goes on its way to the device at once (kp_traj_create / kp_traj_put / kp_traj_finish): the DMA of
+    # one block (3.5 ms per 1024 systems in all) runs beside the gather of the next and the seam test of the time vectors
     from .device import Traj
-    started = []
-    with ThreadPoolExecutor(1) as ex:
-        raw = _stack_raw(systems, ctx, overlap=lambda *blocks: started.append(ex.submit(Traj, ctx, *blocks)))
-        traj = started[0].result() if started else None
+    traj = None
+    try:
+        d0 = systems[0]
+        y0, u0, yv0 = np.asarray(d0["train"][0]["y"]), np.asarray(d0["train"][0]["u"]), np.asarray(d0["val"][0]["y"])
+        dims = (len(systems), len(d0["train"]), y0.shape[0], y0.size // max(y0.shape[0], 1), u0.size // max(u0.shape[0], 1), yv0.shape[0])
+        traj = Traj.begin(ctx, *dims)
+    except Exception:                                   # unusual layouts: the blocks decide (Traj(...) below or the host path)
+        traj = None
+
+    def put(name, arr):
+        nonlocal traj
+        if traj is not None:
+            try:
+                traj.put(name, arr)
+            except Exception:
+                ctx.synchronize()
+                traj.close()
+                traj = None
+    raw = _stack_raw(systems, ctx, on_block=put)
     if raw is None:
         if traj is not None:
+            ctx.synchronize()                               # copies out of the gather buffers may still be in flight
             traj.close()
         return _sweep_batched_host(systems, ctx, degrees)
+    if traj is not None:
+        traj.finish()
     return rand_models_sweep_arrays(*raw, ctx=ctx, degrees=degrees, nested=nested, traj=traj)
 
 

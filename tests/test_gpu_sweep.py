@@ -451,3 +451,36 @@ def test_nested_sweep_on_short_trials(ctx):
     err, st = traj.sweep_eval_nested(basis, 2, np.inf)
     assert (st != 0).all() and np.isnan(err).all()
     basis.close(); traj.close()
+
+
+def test_trajectory_object_in_three_steps_equals_the_one_call_upload(ctx):
+    """kp_traj_create / kp_traj_put / kp_traj_finish (each block on its way while the caller prepares the next) against
+    kp_traj_upload: same scaling, same sweep table; an object that is not finished refuses to be used, and finish refuses an
+    object with a block missing."""
+    from koopman_realizations_amd.device import Traj, Basis
+    from koopman_realizations_amd.rsys import Rsys
+    r = Rsys(6, 3, 3, 2, seed=9)
+    systems = Rsys.save_data(r.simulate_systems_fast(4.0, 0.01, 5, np.zeros((1, 1))))
+    Y, U, k, Yv, Uv = sweep._stack_raw(systems)
+    one = Traj(ctx, Y, U, k, Yv, Uv)
+    three = Traj.begin(ctx, Y.shape[0], k, Y.shape[1] // k, 1, 1, Yv.shape[1])
+    basis = Basis(ctx, "linear", 1, 1, [("poly", kra.poly_exponent_table(1, 3)[1:])], None)
+    three.put("Y", Y); three.put("U", U)
+    with pytest.raises(kra.KoopmanHipError):
+        three.sweep_eval_nested(basis, 3, np.inf)                      # not finished
+    with pytest.raises(kra.KoopmanHipError):
+        three.finish()                                                 # Yv, Uv missing
+    with pytest.raises(ValueError):
+        three.put("Yv", Yv[:, :-1])                                    # wrong shape
+    three.put("Yv", Yv); three.put("Uv", Uv)
+    three.finish()
+    assert np.array_equal(one.scale(), three.scale())
+    e1, s1 = one.sweep_eval_nested(basis, 3, np.inf)
+    e3, s3 = three.sweep_eval_nested(basis, 3, np.inf)
+    assert np.array_equal(e1, e3, equal_nan=True) and np.array_equal(s1, s3)
+    basis.close(); one.close(); three.close()
+    # ... and the batched sweep (which uploads block by block) gives the table of the blocks uploaded in one call
+    degrees = {"linear": 3, "bilinear": 2, "nonlinear": 2}
+    a = sweep.rand_models_sweep_batched(systems, ctx, degrees=degrees)
+    b = sweep.rand_models_sweep_arrays(Y, U, k, Yv, Uv, ctx=ctx, degrees=degrees)
+    assert all(np.array_equal(a[mt], b[mt], equal_nan=True) for mt in degrees)
