@@ -948,8 +948,11 @@ __global__ __launch_bounds__(256, 2) void kp_traj_gram_mfma_kernel(BasisDev b, c
   const int D = DC > 0 ? DC : D_rt;                   // DC: the table depth at compile time (the sweep's 13 / 6 / 4): unrolled fill
   // table entries per (side, pair): powers | inputs | mask | 1 | 0 [| u_i x powers, i < m: `upro`, bilinear dictionaries - a
   // column psi_c u_i then costs the lanes no extra factor (6 multiplies per 4 pairs and lane) but the filling thread D]
-  const int E = nv * D + m + 3 + (UPRO ? m * nv * D : 0);
-  const int id_u = nv * D, id_mask = id_u + m, id_one = id_mask + 1, id_zero = id_mask + 2, id_up = id_mask + 3;
+  const int E = nv * D + m + 3 + (UPRO ? m * nv * D : 0);   // powers | inputs | mask | 0 | 1 [| input x powers]
+  // (the 0 entry sits before the 1 entry: the padding columns of a B read use it, and with the sweep's linear dictionary
+  //  - 13 powers, input, mask - it is then entry 15 of a read that spans entries 0 .. 15, one bank pair each; as entry 16 it
+  //  shared a bank pair with entry 0: 20 % of the kernel's LDS cycles were conflicts, rocprofv3 SQ_LDS_BANK_CONFLICT)
+  const int id_u = nv * D, id_mask = id_u + m, id_zero = id_mask + 1, id_one = id_mask + 2, id_up = id_mask + 3;
   const int buf_doubles = 2 * E * TGM_STR;            // one buffer: [side][entry][TGM_STR]
   double* tab = sm;                                   // two buffers
   double* Gs = sm;                                    // [4 waves][2][16][16]: the partial sums, over the table once it is dead
