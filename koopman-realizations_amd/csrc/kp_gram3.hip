@@ -58,6 +58,9 @@
 // entry per (side, gaussian centre) behind the constant; the centres live in LDS where the projection matrix would
 #define GC03 LDS3_DOUBLES
 #define GAUSSMAX3 32                // centres (2 sides x 32 x KT3 values per tile = two items per thread)
+#ifndef KP_PCS_REGS
+#define KP_PCS_REGS 24                 // k-steps of the pcs projection whose matrix operand stays in registers (<= 96 full columns)
+#endif
 #define GNZMAX3 8                   // state variables of a gaussian dictionary
 #define LDS3_GAUSS_DOUBLES (GAUSSMAX3 * GNZMAX3)
 
@@ -300,18 +303,38 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
   // product on the matrix pipe: wave = (side, 4-snapshot group), two 4 x 16 output tiles (32 PCs), contraction over the
   // full columns.  Reads first, barrier, then the PCs overwrite columns nzeta.., the constant moves to column N - 1 and
   // the padding of the last 4-column group is cleared; the Gram MFMAs only touch columns < 4 G4 afterwards.
+  // The projection's matrix operand is the same in every tile: this lane's entries of the FIRST 16 components (one per
+  // k-step, KP_PCS_REGS of them at most) stay in registers for the whole kernel - the shape is bound by the LDS pipe
+  // (DESIGN 6), and of the 3 operand reads per 2 MFMAs of this loop one goes away.  (Both component tiles would be 84
+  // registers: measured, 75 spilled dwords in the <3,3,true> instantiation and 0.21 -> 0.25 ms; half of them: no gain.)
+  constexpr int PREG = PCS ? KP_PCS_REGS : 1;
+  double pcs_r[PREG];
+  if (PCS) {
+    __syncthreads();                                    // the staged matrix is visible
+    const int bbase0 = PCS03 + (lane >> 4) * 16 + 4 * blk + lc;
+#pragma unroll
+    for (int kk = 0; kk < PREG; ++kk) pcs_r[kk] = kk < a.nfull4 / 4 ? sm[bbase0 + kk * 64] : 0.0;
+  }
   auto project = [&](auto buf_c) __attribute__((always_inline)) {
     constexpr int BUF = decltype(buf_c)::value;
     const int side = wave >> 1, rg = wave & 1;
     const int abase = BUF * PSIBUF3 + PSI03 + (4 * rg + lc) * RS3 + side * YOFF3 + (lane >> 4);
     const int bbase = PCS03 + (lane >> 4) * 16 + 4 * blk + lc;
     const int nf4 = a.nfull4;
-    // (measured: a software-pipelined or fully unrolled form of this loop is no faster - the phase is bound by its
-    // two barriers and the dependent MFMA chains, not by address arithmetic)
     double p0 = 0.0, p1 = 0.0;
     const int bb1 = bbase + nf4 * 16;
+    const int nk = nf4 / 4;
+#pragma unroll
+    for (int kk = 0; kk < PREG; ++kk) {
+      if (kk < nk) {                                    // (uniform)
+        const double av = sm[abase + 4 * kk];
+        const double b1 = sm[bb1 + kk * 64];
+        p0 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, pcs_r[kk], p0, 0, 0, 0);
+        p1 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, b1, p1, 0, 0, 0);
+      }
+    }
 #pragma unroll 3
-    for (int kk = 0; kk < nf4 / 4; ++kk) {
+    for (int kk = PREG; kk < nk; ++kk) {                // dictionaries with more than 4 KP_PCS_REGS full columns
       const double av = sm[abase + 4 * kk];
       const double b0 = sm[bbase + kk * 64], b1 = sm[bb1 + kk * 64];
       p0 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, b0, p0, 0, 0, 0);
