@@ -1045,11 +1045,50 @@ __device__ __forceinline__ void mpc_step_body(const MpcArgs& a) {
   long long* stamps = (a.stamps && pb == 0) ? a.stamps : nullptr;
   if (stamps && tid == 0) stamps[0] = wall_clock64();
 
+  // The step's inputs lie in page-locked HOST memory in single-problem launches (zero-copy: no copy command on the latency
+  // path of a closed loop), so every access is a PCIe round trip of ~2 us.  u_prev and Yr are requested HERE, together with
+  // zeta / z below - one round trip instead of three behind each other (dictionary -> right-hand sides -> tracking error) -
+  // and parked in LDS arrays that are written for good only later: u_prev in f, Yr in e (which becomes P z - Yr in place).
+  // zeta (or the lifted state itself) likewise goes to LDS first - into z, which the dictionary evaluation reads and only the
+  // step after it overwrites.  All three requests are in flight before the first of them is waited for.
+  {
+    const double* zin = a.has_basis ? a.zeta + (size_t)pb * a.basis.nzeta : a.z + (size_t)pb * N;
+    const int nzin = a.has_basis ? a.basis.nzeta : N, nyr = (Np + 1) * nproj;
+    const double r_up = tid < m ? up[tid] : 0.0;
+    const double r_yr = tid < nyr ? Yr[tid] : 0.0;
+    const double r_z = tid < nzin ? zin[tid] : 0.0;
+    if (tid < m) f[tid] = r_up;
+    if (tid < nyr) ev[tid] = r_yr;
+    if (tid < nzin) z[tid] = r_z;
+    for (int e = tid + 256; e < nyr; e += 256) ev[e] = Yr[e];
+    for (int c = tid + 256; c < nzin; c += 256) z[c] = zin[c];
+    __syncthreads();
+  }
   // ---- lifted state (Kmpc.m:842) ----
   if (a.has_basis) {
     const BasisDev& b = a.basis;
-    const double* zeta = a.zeta + (size_t)pb * b.nzeta;
-    for (int c = tid; c < b.nfull; c += 256) full[c] = kp_eval_col(b, b.cols[c], zeta, 1);
+    const double* zeta = z;
+    for (int c = tid; c < b.nfull; c += 256) {
+      const ColDesc cd = b.cols[c];
+      double v;
+      if (cd.kind == COL_MONO && b.nvars <= 8) {
+        // all exponent bytes of the column requested at once (kp_eval_col fetches them one by one between branches: a
+        // dependent L2 round trip per variable, 6.7 us for this phase at 6 variables)
+        const uint8_t* e = b.exps + (size_t)cd.arg * b.nvars;
+        int ex[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ex[i] = i < b.nvars ? (int)e[i] : 0;
+        v = 1.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const double x = zeta[i < b.nvars ? i : 0];
+          for (int k = 0; k < ex[i]; ++k) v *= x;
+        }
+      } else {
+        v = kp_eval_col(b, cd, zeta, 1);
+      }
+      full[c] = v;
+    }
     __syncthreads();
     for (int c = tid; c < N; c += 256) {
       double v;
@@ -1065,8 +1104,6 @@ __device__ __forceinline__ void mpc_step_body(const MpcArgs& a) {
         v = 1.0;
       z[c] = v;
     }
-  } else {
-    for (int c = tid; c < N; c += 256) z[c] = a.z[(size_t)pb * N + c];
   }
   __syncthreads();
   if (a.z_out)
@@ -1077,7 +1114,7 @@ __device__ __forceinline__ void mpc_step_body(const MpcArgs& a) {
   for (int e = tid; e < nr; e += 256) {
     double v = a.bq0[e];
     int k = e - (nr - 2 * m);
-    if (k >= 0) v = k < m ? up[k] : -up[k - m];
+    if (k >= 0) v = k < m ? f[k] : -f[k - m];
     bq[e] = v;
   }
   // e_i = P_i z - Yr_i
@@ -1090,7 +1127,7 @@ __device__ __forceinline__ void mpc_step_body(const MpcArgs& a) {
     for (int j = part; j < N; j += 4) s += Pi[p + j * nproj] * z[j];
     s += __shfl_xor(s, 1, 64);
     s += __shfl_xor(s, 2, 64);
-    if (part == 0) ev[e] = s - Yr[e];
+    if (part == 0) ev[e] = s - ev[e];
   }
   int status = 0;
   if (stamps && tid == 0) stamps[1] = wall_clock64();
