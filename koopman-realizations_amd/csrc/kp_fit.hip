@@ -837,7 +837,7 @@ extern "C" int kp_fit_last_rank(const kp_ctx* ctx, int* rank) {
 // Asynchronous pipeline, deferred solves (default): the queued Gram pairs are factored and solved by one batched launch
 // sequence on the Gram stream (Cholesky: one workgroup per fit, all at once; TRSM: W/16 workgroups per fit).
 static int solve_batch_size() {
-  static const int v = [] { const char* e = getenv("KP_SOLVE_BATCH"); return e ? std::max(0, atoi(e)) : 64; }();
+  static const int v = [] { const char* e = getenv("KP_SOLVE_BATCH"); return e ? std::max(0, atoi(e)) : 128; }();   // (128 against 64: 0.4171 against 0.4191 ms per pipelined fit; capped by the result ring)
   return v;
 }
 
