@@ -582,7 +582,12 @@ extern "C" int kp_traj_destroy(kp_traj* t) {
   if (!t) return KP_OK;
   double* bufs[] = {t->Y, t->U, t->Yv, t->Uv, t->sc};
   // the blocks go back to the context's pool - once the device is done with them (every entry point that used them has
-  // synchronised its stream before returning)
+  // synchronised its stream before returning; an object abandoned between kp_traj_put and kp_traj_finish may still have
+  // copies in flight)
+  if (t->have != 0 && t->have != 31 && t->ctx) {
+    (void)hipSetDevice(t->ctx->device);
+    (void)hipStreamSynchronize(t->ctx->stream);
+  }
   for (int i = 0; i < 5; ++i) traj_release(t->ctx, bufs[i], t->cap[i]);
   delete t;
   return KP_OK;
