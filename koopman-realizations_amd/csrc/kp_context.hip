@@ -78,7 +78,7 @@ extern "C" int kp_destroy(kp_ctx* c) {
   kp_stage_destroy(c);
   (void)hipStreamSynchronize(c->stream);
   if (c->stream2) (void)hipStreamSynchronize(c->stream2);
-  for (int i = 0; i < 10; ++i)
+  for (int i = 0; i < 12; ++i)
     if (c->ws[i]) (void)hipFree(c->ws[i]);
   if (c->sticky_info) (void)hipFree(c->sticky_info);
   if (c->pin_small) (void)hipHostFree(c->pin_small);
@@ -360,6 +360,7 @@ extern "C" int kp_basis_destroy(kp_basis* b) {
   kp_gram2_plan_free(b->plan2);
   kp_gram3_plan_free(b->plan3);
   kp_gram5_plan_free(b->plan5);
+  kp_gram3_shadow_free(b);
   delete b;
   return KP_OK;
 }

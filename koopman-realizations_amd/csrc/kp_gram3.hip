@@ -771,3 +771,173 @@ int kp_gram3_launch(kp_ctx* ctx, const kp_basis* basis_c, const kp_snapshots* s,
   ctx->timers[10] = (double)plan.njobs * plan.nq * NWT * 128.0 + (b.k_pcs > 0 ? (double)plan.nsuper * nfull4 * 128.0 : 0.0);
   return KP_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// LINEAR models with dim_red (the first model of the reference's example_sysid.m: poly-3, econ lift [zeta; pcs' psi; 1]).
+// Their row [psi(x), u] is a column subset of the BILINEAR row psi (x) [1; u] of the same dictionary - the last dictionary
+// column is the constant, so u_i = psi_N u_i is column (i + 1) N + N - 1 of it - hence G and C of the linear fit are
+// sub-blocks of the bilinear Grams.  The only kernel that served these dictionaries was the general one (two-stage lift through
+// LDS, v_mfma_f64_16x16x4: 0.55 ms per 1e5 pairs at N = 34); the Kronecker kernel with the in-kernel projection forms the
+// bilinear Grams of the same dictionary in 0.21 ms, and a gather of (N + m)^2 entries makes the linear ones of them.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void kp_gram3_linear_gather_kernel(const double* __restrict__ GCb, int N, int m, int Wb, double* __restrict__ GC) {
+  const int W = N + m;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= 2 * W * W) return;
+  const int which = e / (W * W), r = e - which * W * W, i = r % W, j = r / W;
+  const int bi = i < N ? i : (i - N + 1) * N + N - 1, bj = j < N ? j : (j - N + 1) * N + N - 1;
+  GC[e] = GCb[(size_t)which * Wb * Wb + (size_t)bj * Wb + bi];
+}
+
+static kp_basis* gram3_shadow(const kp_basis* basis_c) {
+  kp_basis* basis = const_cast<kp_basis*>(basis_c);
+  if (!basis->shadow_bil) {
+    kp_basis* sh = new kp_basis(*basis);               // shares every device array (never freed through the shadow)
+    sh->dev.model_type = KP_MODEL_BILINEAR;
+    sh->dev.W = sh->dev.N * (sh->dev.m + 1);
+    sh->plan = nullptr; sh->plan2 = nullptr; sh->plan3 = nullptr; sh->plan5 = nullptr; sh->shadow_bil = nullptr;
+    basis->shadow_bil = sh;
+  }
+  return basis->shadow_bil;
+}
+
+void kp_gram3_shadow_free(kp_basis* basis) {
+  if (!basis) return;
+  if (basis->shadow_bil) {
+    kp_gram3_plan_free(basis->shadow_bil->plan3);
+    delete basis->shadow_bil;
+    basis->shadow_bil = nullptr;
+  }
+  if (basis->shadow_full) {
+    kp_gram_plan_free(basis->shadow_full->plan);
+    kp_gram2_plan_free(basis->shadow_full->plan2);
+    kp_gram5_plan_free(basis->shadow_full->plan5);
+    delete basis->shadow_full;
+    basis->shadow_full = nullptr;
+  }
+}
+
+bool kp_gram3_linear_applicable(const kp_basis* basis) {
+  const BasisDev& b = basis->dev;
+  if (b.model_type != KP_MODEL_LINEAR || b.k_pcs <= 0 || b.m < 1 || getenv("KP_NO_GRAM3_LINEAR")) return false;
+  return kp_gram3_applicable(gram3_shadow(basis));
+}
+
+int kp_gram3_linear_launch(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* s, double* GC_dev) {
+  kp_basis* sh = gram3_shadow(basis);
+  const int N = basis->dev.N, m = basis->dev.m, W = basis->dev.W, Wb = sh->dev.W;
+  double* tmp = (double*)ctx->workspace(10, (size_t)2 * Wb * Wb * 8);
+  if (!tmp) return ctx->fail(KP_ERR_HIP, "kp_fit_gram: out of device memory");
+  // the reduction (and with it the gather) may belong to the solve stream of the asynchronous pipeline
+  hipStream_t rs = ctx->reduce_stream ? ctx->reduce_stream : ctx->stream;
+  int rc = kp_gram3_launch(ctx, sh, s, tmp);
+  if (rc) return rc;
+  hipLaunchKernelGGL(kp_gram3_linear_gather_kernel, dim3((2 * W * W + 255) / 256), dim3(256), 0, rs, tmp, N, m, Wb, GC_dev);
+  KP_HIP(ctx, hipGetLastError());
+  ctx->gram_flops_per_pair = (double)W * (W + 1) + 2.0 * W * W;
+  return KP_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// dim_red dictionaries of LINEAR and NONLINEAR models (the first and third model of the reference's example_sysid.m).  The
+// econ lift [v; pcs' psi_full(v); 1] (Ksysid.m:1594-1618) is a LINEAR map of the full lift - the variables are the first
+// columns of the full dictionary, the constant its last -  psi_econ = T' psi_full,  T = [E_vars | pcs | e_const]  (and the
+// identity on the input columns of a linear row), so
+//     G_econ = T' (Psi_x' Psi_x) T,      C_econ = T' (Psi_x' Psi_y) T :
+// the full dictionary's Grams by the monomial kernels (kp_gram5 / kp_gram2: 0.115 ms linear, 0.34 ms nonlinear poly-3 per 1e5
+// pairs) and two small congruence products, instead of the general kernel's per-pair projection through LDS (0.55 ms and
+// 4.2 ms).  Bilinear dim_red dictionaries keep the Kronecker kernel with the in-kernel projection (0.21 ms against 0.40 ms).
+// ---------------------------------------------------------------------------------------------------------------------
+struct CongT { int nvars, k, nfull, N, W, Wf; const double* pcs; };
+// entry of T: row c of the full row layout (dictionary columns, then the inputs of a linear row), econ column j
+__device__ __forceinline__ int cong_unit(const CongT& t, int j) {        // >= 0: T(:, j) = e_idx; -1: a pcs column
+  if (j < t.nvars) return j;
+  if (j < t.nvars + t.k) return -1;
+  if (j == t.N - 1) return t.nfull - 1;
+  return t.nfull + (j - t.N);                                            // input columns of a linear row
+}
+// R (Wf x W) = M (Wf x Wf) T, for M = G_full and C_full (blockIdx.y)
+__global__ __launch_bounds__(256) void kp_cong_right_kernel(const double* __restrict__ GCf, CongT t, double* __restrict__ R) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= t.Wf * t.W) return;
+  const int i = e % t.Wf, j = e / t.Wf;
+  const double* M = GCf + (size_t)blockIdx.y * t.Wf * t.Wf;
+  const int u = cong_unit(t, j);
+  double v;
+  if (u >= 0) v = M[i + (size_t)u * t.Wf];
+  else {
+    const double* pc = t.pcs + (size_t)(j - t.nvars) * t.nfull;
+    double s0 = 0.0, s1 = 0.0;
+    int c = 0;
+    for (; c + 1 < t.nfull; c += 2) { s0 += M[i + (size_t)c * t.Wf] * pc[c]; s1 += M[i + (size_t)(c + 1) * t.Wf] * pc[c + 1]; }
+    if (c < t.nfull) s0 += M[i + (size_t)c * t.Wf] * pc[c];
+    v = s0 + s1;
+  }
+  R[(size_t)blockIdx.y * t.Wf * t.W + e] = v;
+}
+// out (W x W) = T' R
+__global__ __launch_bounds__(256) void kp_cong_left_kernel(const double* __restrict__ R, CongT t, double* __restrict__ GC) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= t.W * t.W) return;
+  const int i = e % t.W, j = e / t.W;
+  const bool sym = blockIdx.y == 0;                    // G: one triangle is computed and mirrored (exactly symmetric, like the kernels' own G)
+  if (sym && i > j) return;
+  const double* Rj = R + (size_t)blockIdx.y * t.Wf * t.W + (size_t)j * t.Wf;
+  const int u = cong_unit(t, i);
+  double v;
+  if (u >= 0) v = Rj[u];
+  else {
+    const double* pc = t.pcs + (size_t)(i - t.nvars) * t.nfull;
+    double s0 = 0.0, s1 = 0.0;
+    int c = 0;
+    for (; c + 1 < t.nfull; c += 2) { s0 += pc[c] * Rj[c]; s1 += pc[c + 1] * Rj[c + 1]; }
+    if (c < t.nfull) s0 += pc[c] * Rj[c];
+    v = s0 + s1;
+  }
+  GC[(size_t)blockIdx.y * t.W * t.W + e] = v;
+  if (sym && i < j) GC[(size_t)j + (size_t)i * t.W] = v;
+}
+
+static kp_basis* gram_shadow_full(const kp_basis* basis_c) {
+  kp_basis* basis = const_cast<kp_basis*>(basis_c);
+  if (!basis->shadow_full) {
+    kp_basis* sh = new kp_basis(*basis);               // shares every device array (never freed through the shadow)
+    sh->dev.k_pcs = 0;
+    sh->dev.pcs = nullptr;
+    sh->d_pcs = nullptr;
+    sh->dev.N = sh->dev.nfull;
+    sh->dev.W = sh->dev.model_type == KP_MODEL_LINEAR ? sh->dev.nfull + sh->dev.m : sh->dev.nfull;
+    sh->plan = nullptr; sh->plan2 = nullptr; sh->plan3 = nullptr; sh->plan5 = nullptr; sh->shadow_bil = nullptr; sh->shadow_full = nullptr;
+    basis->shadow_full = sh;
+  }
+  return basis->shadow_full;
+}
+
+bool kp_gram_congruence_applicable(const kp_basis* basis) {
+  const BasisDev& b = basis->dev;
+  if ((b.model_type != KP_MODEL_LINEAR && b.model_type != KP_MODEL_NONLINEAR) || b.k_pcs <= 0 || b.N != b.nvars + b.k_pcs + 1 ||
+      getenv("KP_NO_GRAM_CONGRUENCE"))
+    return false;
+  const kp_basis* sh = gram_shadow_full(basis);
+  return kp_gram5_applicable(sh) || kp_gram2_applicable(sh);
+}
+
+int kp_gram_congruence_launch(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* s, double* GC_dev) {
+  kp_basis* sh = gram_shadow_full(basis);
+  const BasisDev& b = basis->dev;
+  const int W = b.W, Wf = sh->dev.W;
+  double* GCf = (double*)ctx->workspace(10, (size_t)2 * Wf * Wf * 8);
+  double* R = (double*)ctx->workspace(11, (size_t)2 * Wf * W * 8);
+  if (!GCf || !R) return ctx->fail(KP_ERR_HIP, "kp_fit_gram: out of device memory");
+  hipStream_t rs = ctx->stream;                       // kp_gram5 / kp_gram2 reduce on the Gram stream
+  int rc = kp_gram5_applicable(sh) ? kp_gram5_launch(ctx, sh, s, GCf) : kp_gram2_launch(ctx, sh, s, GCf);
+  if (rc) return rc;
+  CongT t{b.nvars, b.k_pcs, b.nfull, b.N, W, Wf, b.pcs};
+  hipLaunchKernelGGL(kp_cong_right_kernel, dim3((Wf * W + 255) / 256, 2), dim3(256), 0, rs, GCf, t, R);
+  hipLaunchKernelGGL(kp_cong_left_kernel, dim3((W * W + 255) / 256, 2), dim3(256), 0, rs, R, t, GC_dev);
+  KP_HIP(ctx, hipGetLastError());
+  ctx->gram_flops_per_pair = (double)W * (W + 1) + 2.0 * W * W;
+  return KP_OK;
+}

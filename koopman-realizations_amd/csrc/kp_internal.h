@@ -74,8 +74,8 @@ struct kp_ctx {
   double timers[12] = {0};
   double gram_flops_per_pair = 0;
   // growable device workspaces
-  void* ws[10] = {nullptr};     // slot 8: staging of the collectives, 9: rank-revealing solve
-  size_t ws_bytes[10] = {0};
+  void* ws[12] = {nullptr};     // slot 8: staging of the collectives, 9: rank-revealing solve, 10 / 11: Grams of the shadow dictionary of a dim_red fit, their half-transformed form
+  size_t ws_bytes[12] = {0};
   int last_rank = -1;           // rank found by the most recent solve (W when the Gram matrix was positive definite)
   double last_pivot_ratio = 1.0; // min_i L_ii^2 / G_ii of the most recent synchronous least-squares solve (~1 / cond(G))
   // results of the last kp_fit
@@ -162,6 +162,8 @@ struct kp_basis {
   kp_gram2_plan* plan2 = nullptr;  // plan of the 4x4x4-MFMA Gram kernel (monomial dictionaries)
   kp_gram3_plan* plan3 = nullptr;  // plan of the Kronecker (bilinear) Gram kernel
   kp_gram5_plan* plan5 = nullptr;  // plan of the dense 4x4x4 Gram kernel (linear / nonlinear monomial dictionaries)
+  kp_basis* shadow_bil = nullptr;  // linear dim_red dictionaries: the same dictionary as a BILINEAR one (shares every device array; kp_gram3.hip)
+  kp_basis* shadow_full = nullptr; // linear / nonlinear dim_red dictionaries: the same dictionary WITHOUT the projection (kp_gram3.hip)
   std::vector<uint32_t> h_recipes; // host copy of the recipes (valid if fast)
   // extended recipes of the Kronecker Gram kernel (kp_gram3): besides powers, the per-variable table may hold the
   // harmonics cos / sin(2 pi j x) of fourier blocks (Ksysid.m:694-731) and, behind the per-variable entries, one entry per
@@ -288,6 +290,11 @@ int kp_gram2_launch(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* s, d
 // picks the 4x4x4-MFMA kernel when the dictionary allows it, else the general kernel
 bool kp_gram3_applicable(const kp_basis* basis);
 int kp_gram3_launch(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* s, double* GC_dev);
+bool kp_gram_congruence_applicable(const kp_basis* basis);
+int kp_gram_congruence_launch(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* s, double* GC_dev);
+bool kp_gram3_linear_applicable(const kp_basis* basis);
+int kp_gram3_linear_launch(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* s, double* GC_dev);
+void kp_gram3_shadow_free(kp_basis* basis);
 bool kp_gram5_applicable(const kp_basis* basis);
 int kp_gram5_launch(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* s, double* GC_dev);
 inline int kp_gram_dispatch(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* s, double* GC_dev) {
@@ -296,6 +303,8 @@ inline int kp_gram_dispatch(kp_ctx* ctx, const kp_basis* basis, const kp_snapsho
   ctx->reduce_timed_from = 1;
   KP_HIP(ctx, kp_snaps_acquire(s, ctx->stream));
   const int rc = kp_gram3_applicable(basis)   ? kp_gram3_launch(ctx, basis, s, GC_dev)
+                 : kp_gram_congruence_applicable(basis) ? kp_gram_congruence_launch(ctx, basis, s, GC_dev)
+                 : kp_gram3_linear_applicable(basis) ? kp_gram3_linear_launch(ctx, basis, s, GC_dev)
                  : kp_gram5_applicable(basis) ? kp_gram5_launch(ctx, basis, s, GC_dev)
                  : kp_gram2_applicable(basis) ? kp_gram2_launch(ctx, basis, s, GC_dev)
                                               : kp_gram_launch(ctx, basis, s, GC_dev);

@@ -21,3 +21,21 @@ for mt, deg in (("linear", 3), ("linear", 4), ("nonlinear", 2), ("nonlinear", 3)
     F = W * (W + 1) + 2.0 * W * W
     print(f"{mt:9s} poly-{deg}: N {basis.N:3d} W {W:3d}  gram {ms:.4f} ms  executed {ex * Ns / (ms * 1e-3) / 1e12 / 78.6:.3f} of peak, dense-equivalent {F * Ns / (ms * 1e-3) / 1e12 / 78.6:.3f}")
     basis.close()
+# the reference's own example_sysid.m settings: every model type with dim_red (econ lift [zeta; pcs' psi; 1])
+rng = np.random.default_rng(3)
+for mt, nfull_vars, k in (("linear", 6, 27), ("bilinear", 6, 27), ("nonlinear", 9, 60)):
+    tab = kra.poly_exponent_table(nfull_vars, 3)[nfull_vars:]
+    nfull = nfull_vars + len(tab) + 1
+    pcs = np.linalg.qr(rng.standard_normal((nfull, k)))[0]
+    basis = kra.Basis(ctx, mt, 6, 3, [("poly", tab)], pcs)
+    for Nsx, sn in ((Ns, snaps),):
+        for _ in range(24):
+            kra.fit(ctx, basis, sn, fetch=False)
+        ctx.synchronize()
+        for _ in range(32):
+            kra.fit(ctx, basis, sn, fetch=False)
+        ctx.synchronize()
+        ms = ctx.timer(0)
+        W = basis.W
+        print(f"{mt:9s} poly-3 dim_red: nfull {nfull} k {k} N {basis.N} W {W}  gram {ms:.4f} ms = {Nsx / (ms * 1e-3):.3e} pairs/s")
+    basis.close()
