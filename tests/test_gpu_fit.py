@@ -41,6 +41,8 @@ CASES = [
     ("linear", 6, 3, ["poly"], [3], True),         # example_sysid.m's first model: its Grams are sub-blocks of the bilinear ones
     ("linear", 3, 2, ["poly"], [3], True),
     ("linear", 2, 1, ["poly"], [2], True),
+    ("linear", 10, 2, ["poly"], [3], True),        # 286 full functions (a delay-embedded state): kp_gram2 + congruence; no kernel projects that wide per pair
+    ("nonlinear", 6, 3, ["poly"], [3], True),      # example_sysid.m's third model: 220 full functions on [zeta; u]
     ("bilinear", 3, 2, ["poly"], [3], False),                # two inputs: 6 Kronecker weights
     ("bilinear", 9, 3, ["poly"], [2], False),                # delay-embedded width (nzeta = 9), N = 55
     ("nonlinear", 6, 3, ["poly"], [3], False),               # N = W = 220: dense 16 x 16 tile kernel, 14 tiles per side
