@@ -195,7 +195,9 @@ int kp_fit_refine(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* snaps,
  * kp_fit_gram, kp_fit_solve and kp_destroy synchronise implicitly.
  * The fits issued since the previous kp_synchronize form a BATCH; fit number q of the batch keeps its K in slot
  * q mod n_slots of a device ring, and kp_fit_get_K(ctx, q, W, K) fetches it after the batch (the last n_slots fits are
- * retrievable; n_slots defaults to 64, kp_fit_async_slots changes it - 8 W^2 bytes of HBM per slot).  A fit with
+ * retrievable; n_slots defaults to 128, kp_fit_async_slots changes it - 8 W^2 bytes of HBM per slot; the queued [G | C]
+ * pairs of up to min(128, n_slots) fits are solved by one batched launch sequence, whose padded workspace - about 32 W^2 bytes
+ * per queued fit - is reserved at the first asynchronous fit).  A fit with
  * another dictionary, width or snapshot count than the fits in flight drains the pipeline first (its buffers are
  * shared), which also closes the batch. */
 int kp_synchronize(kp_ctx* ctx);

@@ -465,6 +465,7 @@ static TrajView traj_view(const kp_traj* t) {
 static hipError_t traj_alloc(kp_ctx* ctx, double** p, size_t bytes, size_t* cap) {
   static const bool no_pool = getenv("KP_NO_TRAJ_POOL") != nullptr;
   if (!no_pool) {
+    std::lock_guard<std::mutex> lk(ctx->host_mu);     // the pool is shared with a host thread that builds the next object
     int best = -1;
     for (size_t i = 0; i < ctx->traj_pool.size(); ++i) {
       const size_t c = ctx->traj_pool[i].second;
@@ -484,6 +485,7 @@ static void traj_release(kp_ctx* ctx, void* p, size_t cap) {
   if (!p) return;
   static const bool no_pool = getenv("KP_NO_TRAJ_POOL") != nullptr;
   if (no_pool || !ctx) { (void)hipFree(p); return; }
+  std::lock_guard<std::mutex> lk(ctx->host_mu);
   ctx->traj_pool.push_back({p, cap});
   while (ctx->traj_pool.size() > KP_TRAJ_POOL_MAX) {       // the oldest goes
     (void)hipFree(ctx->traj_pool.front().first);
@@ -491,6 +493,7 @@ static void traj_release(kp_ctx* ctx, void* p, size_t cap) {
   }
 }
 void kp_traj_pool_free(kp_ctx* ctx) {
+  std::lock_guard<std::mutex> lk(ctx->host_mu);
   for (auto& b : ctx->traj_pool) (void)hipFree(b.first);
   ctx->traj_pool.clear();
 }
@@ -527,6 +530,9 @@ extern "C" int kp_traj_create(kp_ctx* ctx, int nb, int ntrials, int T, int n, in
 extern "C" int kp_traj_put(kp_traj* t, int which, const double* host) {
   if (!t || !host || which < 0 || which > 3) return t ? t->ctx->fail(KP_ERR_ARG, "kp_traj_put: bad argument") : KP_ERR_ARG;
   kp_ctx* ctx = t->ctx;
+  // a finished object holds SCALED data: a raw block put behind kp_traj_finish would never be rescaled (finish is a no-op
+  // then) and the sweep would run on a mix of scaled and raw values
+  if (t->have == 31) return ctx->fail(KP_ERR_ARG, "kp_traj_put: the object is finished (scaled); create a new one");
   KP_HIP(ctx, hipSetDevice(ctx->device));
   const size_t rows = (size_t)t->ntrials * t->T;
   double* dst[4] = {t->Y, t->U, t->Yv, t->Uv};

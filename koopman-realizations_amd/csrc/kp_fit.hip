@@ -629,9 +629,12 @@ int kp_chol_solve_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_de
     KP_HIP(ctx, kp_ensure_lds(trsm_lds, (const void*)kp_trsm_kernel, lds_trsm));
     hipLaunchKernelGGL(kp_trsm_kernel, dim3(ncp / 16, nb), dim3(256), lds_trsm, st, Gp, Dinv, n, Cp);
   } else if (nb == 1) {       // one system: 4 right-hand sides per workgroup - the shortest serial chain per step (LDS <= 16 KB)
-    hipLaunchKernelGGL((kp_trsm2_kernel<1>), dim3(ncp / 4, nb), dim3(256), (size_t)n * 4 * 8, st, Gp, Dinv, n, ncp, Cp, K_dev, W, ncols);
+    // K written in place (no unpad launch): the ring offset kp_unpad_kernel would apply is applied here - a lone queued fit
+    // flushed at pend_first % k_cap != 0 must land in ITS slot of the result ring, not in slot 0
+    double* Kdst = K_dev + (k_cap > 0 ? (size_t)(k_first % k_cap) * W * ncols : 0);
+    hipLaunchKernelGGL((kp_trsm2_kernel<1>), dim3(ncp / 4, nb), dim3(256), (size_t)n * 4 * 8, st, Gp, Dinv, n, ncp, Cp, Kdst, W, ncols);
     KP_HIP(ctx, hipGetLastError());
-    return KP_OK;                                           // K written in place: no unpad launch
+    return KP_OK;
   } else {                    // a batch: 16 per workgroup, every workgroup reads all of L
     static KpLdsCache trsm2_lds;
     KP_HIP(ctx, kp_ensure_lds(trsm2_lds, (const void*)kp_trsm2_kernel<4>, (size_t)n * 16 * 8));

@@ -36,7 +36,7 @@ struct kp_ctx {
   int gc_flip = 0;             // asynchronous fits alternate between the two halves of GC
   // results of asynchronous fits: ring of kring_cap slots in Kres; fit number q of the current batch (the fits since
   // the last kp_synchronize) lives in slot q % kring_cap
-  int kring_cap = 64;
+  int kring_cap = 128;   // = the default solve batch (solve_batch_size): a full 128-fit batch needs no kp_fit_async_slots call
   int async_count = 0;         // asynchronous fits issued in the current batch
   bool batch_closed = true;    // kp_synchronize closed the batch: the next asynchronous fit starts a new one
   bool kres_is_ring = false;   // Kres currently holds an asynchronous batch (kp_fit_get_K indexes the ring)

@@ -129,6 +129,34 @@ class KoopData(dict):
     def keys(self):
         return list(dict.keys(self)) + list(self.__dict__.get("_lazy", {}))
 
+    def materialise(self):
+        """Evaluate the pending entries now (the lift closures hold the device dictionary: do this before it is closed)."""
+        for key in list(self.__dict__.get("_lazy", {})):
+            self[key]
+        return self
+
+    # every view that a caller who STORES koopData uses (dict(kd), iteration, copy, pickle, savemat) sees Px / Py:
+    def __iter__(self):
+        self.materialise()
+        return dict.__iter__(self)
+
+    def __len__(self):
+        return dict.__len__(self) + len(self.__dict__.get("_lazy", {}))
+
+    def items(self):
+        self.materialise()
+        return dict.items(self)
+
+    def values(self):
+        self.materialise()
+        return dict.values(self)
+
+    def copy(self):
+        return dict(self.items())
+
+    def __reduce__(self):
+        return (dict, (dict(self.items()),))
+
 
 class Ksysid:
     """Koopman-based system identification (mirror of classdef Ksysid, Ksysid.m:1)."""

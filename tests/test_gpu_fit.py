@@ -288,7 +288,7 @@ def test_async_fit_pipeline_matches_synchronous_result(ctx):
     assert e.value.code == F.KP_ERR_ARG
     for i in (1, 2):
         assert np.abs(ctx.fit_result(i, W) - Ksync[i]).max() <= tol(Ksync[i])
-    ctx.fit_async_slots(64)
+    ctx.fit_async_slots(128)
     # another snapshot count while fits are in flight: the pipeline drains first (shared partial / G|C buffers are
     # sized per call), which closes the batch; the new fit is number 0 of the next one
     kra.fit(ctx, b, snaps[0], fetch=False)
@@ -410,6 +410,45 @@ def test_staged_upload_with_copy_threads_and_small_chunks():
     env = dict(os.environ, KP_COPY_THREADS="4", KP_COPY_CHUNK_KB="64", KP_COPY_POOL_MIN_MB="0")
     r = subprocess.run([sys.executable, "-c", _POOL_SCRIPT, root], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0 and "POOL_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+_LONE_FIT_SCRIPT = r"""
+import sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import numpy as np
+import koopman_realizations_amd as kra
+from conftest import synth_pairs
+from oracle import koopman_oracle as ko
+n_fits, n_slots = int(sys.argv[2]), int(sys.argv[3])
+ctx = kra.Context(0)
+dic = ko.build_dictionary("bilinear", 3, 2, ["poly"], [2])
+b = kra.Basis(ctx, "bilinear", 3, 2, [("poly", dic.basis.blocks[0][1][3:].astype(np.uint8))])
+sets = [synth_pairs(3000, 3, 2, seed=70 + i) for i in range(3)]
+snaps = [kra.Snapshots(ctx, p["alpha"], p["beta"], p["u"]) for p in sets]
+Kref = [kra.fit(ctx, b, s)[0] for s in snaps]
+ctx.fit_async_slots(n_slots)
+for q in range(n_fits):
+    kra.fit(ctx, b, snaps[q % 3], fetch=False)
+ctx.synchronize()
+for q in range(max(0, n_fits - n_slots), n_fits):
+    K = ctx.fit_result(q, b.W)
+    assert np.abs(K - Kref[q % 3]).max() <= 1e-11 * np.abs(Kref[q % 3]).max(), q
+print("LONE_OK")
+"""
+
+
+@pytest.mark.parametrize("n_fits,n_slots,env", [(129, 200, {}), (257, 300, {}), (7, 128, {"KP_SOLVE_BATCH": "1"}), (5, 64, {"KP_SOLVE_BATCH": "3"})])
+def test_a_lone_queued_fit_lands_in_its_own_ring_slot(n_fits, n_slots, env):
+    """A flush of exactly ONE queued fit at a non-zero ring position (129 pipelined fits with a 128-fit solve batch; a solve
+    batch of 1) takes the one-system TRSM, which writes K in place: it must apply the ring offset itself - three distinct
+    snapshot sets in rotation, so a K written to slot 0 (or left stale) is seen."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _LONE_FIT_SCRIPT, root, str(n_fits), str(n_slots)], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, **env))
+    assert r.returncode == 0 and "LONE_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
 
 
 @pytest.mark.parametrize("mt,deg,steps,tol", [("bilinear", 2, 1, 1e-10), ("linear", 2, 1, 1e-10), ("bilinear", 3, 1, 1e-12), ("nonlinear", 2, 2, 1e-10)])
