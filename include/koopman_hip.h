@@ -100,6 +100,8 @@ int kp_basis_destroy(kp_basis* basis);
 /* Nfull = length(basis.full) (Ksysid.m:534); N = params.N after dim_red (:1512-1516);
  * W = width of Px (:1019-1028): N+m linear, N(m+1) bilinear, N nonlinear. */
 int kp_basis_dims(const kp_basis* basis, int* nvars, int* nfull, int* N, int* W);
+/* the same sizes from a descriptor alone (no device, no context): kp_multi_* callers size their outputs with it */
+int kp_basis_desc_dims(const kp_basis_desc* desc, int* nvars, int* nfull, int* N, int* W);
 
 /* Symmetric eigendecomposition S = V diag(lam) V' of an n x n matrix (n <= 1024, column-major, host pointers) on the
  * device (parallel cyclic Jacobi; several workgroups with a grid barrier per round for n > 40): the `pca` step of
@@ -234,6 +236,8 @@ int kp_traj_upload(kp_ctx* ctx, const double* Y, const double* U, int nb, int nt
                    const double* Yv, const double* Uv, int Tv, kp_traj** traj);
 int kp_traj_destroy(kp_traj* traj);
 int kp_traj_scale(kp_traj* traj, double* sc_out);
+/* the layout an object was created with (any pointer may be NULL): a gateway that only keeps the handle sizes its outputs with it */
+int kp_traj_dims(const kp_traj* traj, int* nb, int* ntrials, int* T, int* n, int* m, int* Tv);
 /* kp_traj_upload in three steps, for callers that assemble the four blocks one after the other (the reference hands
  * evaluate_rand_models.m:45-59 a cell array of data4sysid structs: thousands of small trial arrays to be gathered): every
  * block is on its way to the device while the next one is prepared.  kp_traj_create: the device blocks; kp_traj_put: block
@@ -372,6 +376,53 @@ int kp_comm_allgather_fits(kp_ctx* ctx, int first, int count, int W, double* K_a
 int kp_fit_sharded(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* snaps_local, const double* lasso,
                    int n_lasso, double* K_out);
 int kp_fit_gram_sharded(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* snaps_local, double* G, double* C);
+
+/* ---- multi-GPU: ONE caller, several GPUs -----------------------------------------------------------------
+ * The reference's host is one MATLAB interpreter running serial loops (Ksim.m:147, evaluate_rand_models.m:45,
+ * Ksysid.m:1372); without the Parallel Computing Toolbox it cannot start one worker per GPU.  kp_multi_* serve that shape: the
+ * library owns one context and one worker thread per listed device, a call deals its units over them and returns when every
+ * device has written ITS share of the result into the caller's arrays - by direct DMA when they lie in a kp_multi_host_alloc
+ * block (page-locked for every device), staged through pinned scratch otherwise.  No collective; no RCCL.  The same device may
+ * be listed more than once (two contexts): that is how the fan-out is tested on a one-GPU box.
+ *   kp_multi_fit           the lasso grid of train_models (Ksysid.m:1372-1387): value i goes to device i mod n_dev; every
+ *                          device uploads the snapshot pairs, lifts them ONCE and solves its values as one batch (kp_fit);
+ *                          K_out: n_lasso matrices W x W in value order.
+ *   kp_multi_fit_sharded   ONE fit sharded over SNAPSHOTS (rows dealt in contiguous ranges): every device's fused Gram kernel
+ *                          on its rows, its [G | C] (2 W^2 doubles) to device 0 by a peer copy (xGMI), summed there in device
+ *                          order, one solve; lasso may be NULL (least squares).
+ *   kp_multi_traj_upload / kp_multi_sweep_eval_nested   the random-system sweep (evaluate_rand_models.m:45-144): systems dealt
+ *                          in contiguous chunks (layouts as kp_traj_upload / kp_sweep_eval_nested, tables in system order).
+ *   kp_multi_mpc_*         kp_mpc_step_batch with the problems dealt in contiguous chunks (arguments as kp_mpc_create /
+ *                          kp_mpc_set_state_bounds / kp_mpc_step_batch).
+ *   kp_multi_timers        per device [upload, device work, result transfer, whole job] of the most recent call, ms (wall).
+ *   kp_multi_ctx           worker i's context (kp_device_info, kp_timer_get, kp_last_error; not for concurrent use). */
+typedef struct kp_multi kp_multi;
+typedef struct kp_multi_traj kp_multi_traj;
+typedef struct kp_multi_mpc kp_multi_mpc;
+int kp_multi_create(const int* device_ids, int n_dev, kp_multi** mg);
+int kp_multi_destroy(kp_multi* mg);
+int kp_multi_size(const kp_multi* mg, int* n_dev);
+kp_ctx* kp_multi_ctx(kp_multi* mg, int i);
+const char* kp_multi_last_error(const kp_multi* mg);
+int kp_multi_host_alloc(kp_multi* mg, int64_t bytes, void** ptr);
+int kp_multi_host_free(kp_multi* mg, void* ptr);
+int kp_multi_timers(const kp_multi* mg, double* ms);
+int kp_multi_fit(kp_multi* mg, const kp_basis_desc* desc, const double* alpha, const double* beta, const double* u, int64_t Ns,
+                 const double* lasso, int n_lasso, double* K_out);
+int kp_multi_fit_sharded(kp_multi* mg, const kp_basis_desc* desc, const double* alpha, const double* beta, const double* u,
+                         int64_t Ns, const double* lasso, int n_lasso, double* K_out);
+int kp_multi_traj_upload(kp_multi* mg, const double* Y, const double* U, int nb, int ntrials, int T, int n, int m,
+                         const double* Yv, const double* Uv, int Tv, kp_multi_traj** traj);
+int kp_multi_traj_destroy(kp_multi_traj* traj);
+int kp_multi_sweep_eval_nested(kp_multi* mg, const kp_multi_traj* traj, const kp_basis_desc* desc, double lasso, int n_deg,
+                               double* err_out, int* status_out);
+int kp_multi_mpc_create(kp_multi* mg, int model_type, const double* A, const double* B, int N, int m, int Np,
+                        const double* proj, int nproj, double q_run, double q_term, const double* r,
+                        const double* lo, const double* hi, double slope_lim, double smooth_lim, kp_multi_mpc** mpc);
+int kp_multi_mpc_set_state_bounds(kp_multi_mpc* mpc, int n, const double* lo, const double* hi);
+int kp_multi_mpc_destroy(kp_multi_mpc* mpc);
+int kp_multi_mpc_step_batch(kp_multi_mpc* mpc, int nb, const double* z, const double* u_prev, const double* Yr,
+                            double* U_out, int* status);
 
 #ifdef __cplusplus
 }

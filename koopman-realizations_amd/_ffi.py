@@ -43,6 +43,7 @@ SIGNATURES = {
     "kp_basis_create": (C.c_int, [vp, C.POINTER(KpBasisDesc), C.POINTER(vp)]),
     "kp_basis_destroy": (C.c_int, [vp]),
     "kp_basis_dims": (C.c_int, [vp, c_ip, c_ip, c_ip, c_ip]),
+    "kp_basis_desc_dims": (C.c_int, [C.POINTER(KpBasisDesc), c_ip, c_ip, c_ip, c_ip]),
     "kp_lift": (C.c_int, [vp, vp, C.c_int, c_dp, c_dp, C.c_int64, c_dp]),
     "kp_snapshots_upload": (C.c_int, [vp, c_dp, c_dp, c_dp, C.c_int64, C.c_int, C.c_int, C.POINTER(vp)]),
     "kp_snapshots_update": (C.c_int, [vp, vp, c_dp, c_dp, c_dp, C.c_int64]),
@@ -66,6 +67,7 @@ SIGNATURES = {
     "kp_traj_put": (C.c_int, [vp, C.c_int, c_dp]),
     "kp_traj_finish": (C.c_int, [vp]),
     "kp_traj_scale": (C.c_int, [vp, c_dp]),
+    "kp_traj_dims": (C.c_int, [vp, c_ip, c_ip, c_ip, c_ip, c_ip, c_ip]),
     "kp_sweep_eval": (C.c_int, [vp, vp, vp, C.c_double, c_dp, c_dp, c_ip]),
     "kp_sweep_eval_nested": (C.c_int, [vp, vp, vp, C.c_double, C.c_int, c_dp, c_ip]),
     "kp_sweep_nested_get_K": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_dp]),
@@ -97,6 +99,24 @@ SIGNATURES = {
     "kp_comm_allgather_fits": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, c_dp]),
     "kp_fit_sharded": (C.c_int, [vp, vp, vp, c_dp, C.c_int, c_dp]),
     "kp_fit_gram_sharded": (C.c_int, [vp, vp, vp, c_dp, c_dp]),
+    "kp_multi_create": (C.c_int, [c_ip, C.c_int, C.POINTER(vp)]),
+    "kp_multi_destroy": (C.c_int, [vp]),
+    "kp_multi_size": (C.c_int, [vp, c_ip]),
+    "kp_multi_ctx": (vp, [vp, C.c_int]),
+    "kp_multi_last_error": (C.c_char_p, [vp]),
+    "kp_multi_host_alloc": (C.c_int, [vp, C.c_int64, C.POINTER(vp)]),
+    "kp_multi_host_free": (C.c_int, [vp, vp]),
+    "kp_multi_timers": (C.c_int, [vp, c_dp]),
+    "kp_multi_fit": (C.c_int, [vp, C.POINTER(KpBasisDesc), c_dp, c_dp, c_dp, C.c_int64, c_dp, C.c_int, c_dp]),
+    "kp_multi_fit_sharded": (C.c_int, [vp, C.POINTER(KpBasisDesc), c_dp, c_dp, c_dp, C.c_int64, c_dp, C.c_int, c_dp]),
+    "kp_multi_traj_upload": (C.c_int, [vp, c_dp, c_dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_dp, c_dp, C.c_int, C.POINTER(vp)]),
+    "kp_multi_traj_destroy": (C.c_int, [vp]),
+    "kp_multi_sweep_eval_nested": (C.c_int, [vp, vp, C.POINTER(KpBasisDesc), C.c_double, C.c_int, c_dp, c_ip]),
+    "kp_multi_mpc_create": (C.c_int, [vp, C.c_int, c_dp, c_dp, C.c_int, C.c_int, C.c_int, c_dp, C.c_int, C.c_double,
+                                      C.c_double, c_dp, c_dp, c_dp, C.c_double, C.c_double, C.POINTER(vp)]),
+    "kp_multi_mpc_set_state_bounds": (C.c_int, [vp, C.c_int, c_dp, c_dp]),
+    "kp_multi_mpc_destroy": (C.c_int, [vp]),
+    "kp_multi_mpc_step_batch": (C.c_int, [vp, C.c_int, c_dp, c_dp, c_dp, c_dp, c_ip]),
 }
 
 _lib = None

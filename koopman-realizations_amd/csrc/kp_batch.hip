@@ -599,6 +599,17 @@ extern "C" int kp_traj_destroy(kp_traj* t) {
   return KP_OK;
 }
 
+extern "C" int kp_traj_dims(const kp_traj* t, int* nb, int* ntrials, int* T, int* n, int* m, int* Tv) {
+  if (!t) return KP_ERR_ARG;
+  if (nb) *nb = t->nb;
+  if (ntrials) *ntrials = t->ntrials;
+  if (T) *T = t->T;
+  if (n) *n = t->n;
+  if (m) *m = t->m;
+  if (Tv) *Tv = t->Tv;
+  return KP_OK;
+}
+
 extern "C" int kp_traj_scale(kp_traj* t, double* sc_out) {
   if (!t || !sc_out) return KP_ERR_ARG;
   kp_ctx* ctx = t->ctx;

@@ -172,6 +172,32 @@ static int upload(kp_ctx* ctx, void** dst, const void* src, size_t bytes) {
   return KP_OK;
 }
 
+// the sizes kp_basis_create would give this descriptor, without a device (callers of kp_multi_* size their outputs with it)
+extern "C" int kp_basis_desc_dims(const kp_basis_desc* d, int* nvars_out, int* nfull_out, int* N_out, int* W_out) {
+  if (!d || d->nzeta < 1 || d->m < 0 || d->model_type < 0 || d->model_type > 2 || d->n_blocks < 0 ||
+      (d->n_blocks && (!d->block_type || !d->block_count)))
+    return KP_ERR_ARG;
+  const int nvars = d->nzeta + (d->model_type == KP_MODEL_NONLINEAR ? d->m : 0);
+  double nf = nvars + 1.0;
+  for (int b = 0; b < d->n_blocks; ++b) {
+    const int c = d->block_count[b];
+    if (c < 0) return KP_ERR_ARG;
+    switch (d->block_type[b]) {
+      case KP_BLOCK_POLY: case KP_BLOCK_HERMITE: case KP_BLOCK_FOURIER_SPARSER: case KP_BLOCK_GAUSSIAN: nf += c; break;
+      case KP_BLOCK_FOURIER: nf += std::pow((double)(2 * c + 1), (double)nvars) - 1.0; break;
+      default: return KP_ERR_ARG;
+    }
+    if (nf > 1e6) return KP_ERR_ARG;
+  }
+  const int nfull = (int)std::llround(nf);
+  const int N = d->k_pcs > 0 ? d->k_pcs + nvars + 1 : nfull;
+  if (nvars_out) *nvars_out = nvars;
+  if (nfull_out) *nfull_out = nfull;
+  if (N_out) *N_out = N;
+  if (W_out) *W_out = d->model_type == KP_MODEL_BILINEAR ? N * (d->m + 1) : d->model_type == KP_MODEL_LINEAR ? N + d->m : N;
+  return KP_OK;
+}
+
 extern "C" int kp_basis_create(kp_ctx* ctx, const kp_basis_desc* d, kp_basis** out) {
   if (!ctx || !d || !out) return KP_ERR_ARG;
   *out = nullptr;

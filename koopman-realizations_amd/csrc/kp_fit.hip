@@ -766,6 +766,8 @@ static int ensure_kres(kp_ctx* ctx, int W, int n) {
   return KP_OK;
 }
 
+int kp_ensure_gc(kp_ctx* ctx, int W) { return ensure_gc(ctx, W); }
+
 extern "C" int kp_fit_gram(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* snaps, double* G, double* C) {
   if (!ctx || !basis || !snaps) return ctx ? ctx->fail(KP_ERR_ARG, "kp_fit_gram: NULL handle") : KP_ERR_ARG;
   KP_HIP(ctx, hipSetDevice(ctx->device));
@@ -868,7 +870,7 @@ extern "C" int kp_fit(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* sn
       if (lasso && lasso[i] < 1e6) return false;
     return true;
   }();
-  const bool go_async = !K_out && n_lasso == 1 && all_ls && ctx->stream2 && ctx->sticky_info && !ctx->reduce_grams && !getenv("KP_NO_ASYNC");
+  const bool go_async = !K_out && n_lasso == 1 && all_ls && ctx->stream2 && ctx->sticky_info && !ctx->reduce_grams && !ctx->gc_preloaded && !getenv("KP_NO_ASYNC");
   int rc;
   // The [G | C] ring may hold queued Gram pairs that are not solved yet (deferred, batched solves): drain the pipeline
   // BEFORE any buffer of it can be reallocated for another width - ensure_gc frees and reallocates GC when the new W needs
@@ -966,8 +968,10 @@ extern "C" int kp_fit(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* sn
   ctx->reserve_cus = 0;
   ctx->kres_is_ring = false;
   ctx->batch_closed = true;
-  rc = kp_gram_dispatch(ctx, basis, snaps, ctx->GC);  // records ev0/ev1 around gram+reduce
-  if (rc) return rc;
+  if (!ctx->gc_preloaded) {
+    rc = kp_gram_dispatch(ctx, basis, snaps, ctx->GC);  // records ev0/ev1 around gram+reduce
+    if (rc) return rc;
+  }
   if (ctx->reduce_grams) {   // one fit sharded over snapshots: the only exchange is this all-reduce of [G | C]
     rc = kp_comm_allreduce_dev(ctx, ctx->GC, (size_t)2 * W * W, ctx->stream);
     if (rc) return rc;

@@ -50,6 +50,7 @@ struct kp_ctx {
   unsigned ring_skip = 0;
   kp_comm_state* comm = nullptr;      // set by kp_comm_create: rank / world / RCCL communicator
   std::atomic<bool> comm_abandoned{false};   // kp_comm_abandon: a bootstrap still blocked in another thread must not publish `comm`
+  bool gc_preloaded = false;          // kp_multi_fit_sharded: ctx->GC already holds the summed [G | C] of all devices - kp_fit skips its Gram launch
   bool reduce_grams = false;          // kp_fit_sharded: all-reduce [G | C] over the ranks between the Gram kernel and the solve
   // set by the asynchronous kp_fit around kp_gram_dispatch: the split-partial reduction runs on this stream
   // (after an event recorded behind the main Gram kernel) and the partial buffer `part_flip` is used
@@ -319,6 +320,8 @@ int kp_pivchol_solve_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, 
 int kp_comm_allreduce_dev(kp_ctx* ctx, double* buf_dev, size_t count, hipStream_t s);
 // queued (deferred) solves of the asynchronous pipeline are launched; nothing is waited for, no status is consumed (kp_fit.hip)
 int kp_flush_pending(kp_ctx* ctx);
+int kp_snapshots_update_rows(kp_ctx* ctx, kp_snapshots* s, const double* alpha, const double* beta, const double* u, int64_t Ns, int64_t ld);
+int kp_ensure_gc(kp_ctx* ctx, int W);   // the context's [G | C] buffer for width W (kp_fit.hip)
 int kp_lift_dev(kp_ctx* ctx, const kp_basis* basis, int what, const double* dz, const double* du, int64_t rows, double* dout);
 int kp_chol_solve_dev(kp_ctx* ctx, double* G_dev, double* C_dev, int W, int ncols, double* K_dev, hipStream_t st = nullptr,
                       hipEvent_t pad_done = nullptr, int* sticky = nullptr);

@@ -198,7 +198,10 @@ static hipError_t alloc_arrays(kp_snapshots* s, int64_t rows) {
 }
 
 // The staged, chunked copy.  `fresh`: nothing on the device can be reading the object (it was just allocated).
-static int fill(kp_ctx* ctx, kp_snapshots* s, const double* alpha, const double* beta, const double* u, int64_t Ns, bool fresh) {
+// `ld`: rows of the CALLER's column-major arrays (>= Ns; ld > Ns: the object takes Ns consecutive rows of every column -
+// one device's share of a snapshot matrix that kp_multi_fit_sharded deals over several GPUs).
+static int fill(kp_ctx* ctx, kp_snapshots* s, const double* alpha, const double* beta, const double* u, int64_t Ns, bool fresh, int64_t ld = -1) {
+  if (ld < Ns) ld = Ns;
   kp_stage* st = stage_of(ctx);
   if (!st) return ctx->fail(KP_ERR_HIP, "kp_snapshots: could not create the copy stream");
   const size_t bz = (size_t)Ns * s->nzeta * sizeof(double), bu = (size_t)Ns * s->m * sizeof(double);
@@ -243,9 +246,16 @@ static int fill(kp_ctx* ctx, kp_snapshots* s, const double* alpha, const double*
         stage += nb;
       }
     };
-    cut(s->alpha, alpha, bz);
-    cut(s->beta, beta, bz);
-    cut(s->u, u, bu);
+    if (ld == Ns) {
+      cut(s->alpha, alpha, bz);
+      cut(s->beta, beta, bz);
+      cut(s->u, u, bu);
+    } else {                                           // a row range: column by column
+      const size_t bcol = (size_t)Ns * sizeof(double);
+      for (int c = 0; c < s->nzeta; ++c) cut(s->alpha + (size_t)c * Ns, alpha + (size_t)c * ld, bcol);
+      for (int c = 0; c < s->nzeta; ++c) cut(s->beta + (size_t)c * Ns, beta + (size_t)c * ld, bcol);
+      for (int c = 0; c < s->m; ++c) cut(s->u + (size_t)c * Ns, u + (size_t)c * ld, bcol);
+    }
   }
   const int nch = (int)st->chunks.size();
   hipError_t e = hipSuccess;
@@ -292,7 +302,15 @@ extern "C" int kp_snapshots_upload(kp_ctx* ctx, const double* alpha, const doubl
   return KP_OK;
 }
 
+// kp_snapshots_update for a row range of the caller's arrays (internal: kp_multi.hip): rows of length `ld`, the pointers
+// already advanced to the first row of the range
+int kp_snapshots_update_rows(kp_ctx* ctx, kp_snapshots* s, const double* alpha, const double* beta, const double* u, int64_t Ns, int64_t ld);
+
 extern "C" int kp_snapshots_update(kp_ctx* ctx, kp_snapshots* s, const double* alpha, const double* beta, const double* u, int64_t Ns) {
+  return kp_snapshots_update_rows(ctx, s, alpha, beta, u, Ns, Ns);
+}
+
+int kp_snapshots_update_rows(kp_ctx* ctx, kp_snapshots* s, const double* alpha, const double* beta, const double* u, int64_t Ns, int64_t ld) {
   if (!ctx || !s || s->ctx != ctx || Ns < 0 || (Ns > 0 && (!alpha || !beta || (s->m > 0 && !u))))
     return ctx ? ctx->fail(KP_ERR_ARG, "kp_snapshots_update: bad argument") : KP_ERR_ARG;
   KP_HIP(ctx, hipSetDevice(ctx->device));
@@ -317,7 +335,7 @@ extern "C" int kp_snapshots_update(kp_ctx* ctx, kp_snapshots* s, const double* a
     }
     fresh = true;
   }
-  int rc = fill(ctx, s, alpha, beta, u, Ns, fresh);
+  int rc = fill(ctx, s, alpha, beta, u, Ns, fresh, ld);
   if (rc) return rc;
   s->streaming = true;                               // from now on every reader records `ev_read`
   return KP_OK;

@@ -230,6 +230,39 @@ class Context:
         return x, st.value
 
 
+def basis_desc(model_type, nzeta, m, blocks, pcs=None):
+    """kp_basis_desc of a host-side dictionary description (blocks as Basis takes them).  Returns (desc, keep): `keep`
+    holds the arrays the descriptor points into and must outlive every call that is handed the descriptor."""
+    nvars = nzeta + (m if model_type == "nonlinear" else 0)
+    btype, bcount, exps, centres = [], [], [], []
+    for kind, arg in blocks:
+        btype.append(F.BLOCK[kind])
+        if kind in ("poly", "hermite"):
+            e = np.ascontiguousarray(arg, dtype=np.uint8).reshape(-1, nvars)
+            bcount.append(e.shape[0]); exps.append(e)
+        elif kind == "fourier_sparser":
+            e = np.ascontiguousarray(arg, dtype=np.uint8).reshape(-1, 2 * nvars)
+            bcount.append(e.shape[0]); exps.append(e.reshape(-1, nvars))      # two table rows per function
+        elif kind == "fourier":
+            bcount.append(int(arg))
+        else:
+            c = np.asarray(arg, dtype=np.float64).reshape(nvars, -1)
+            bcount.append(c.shape[1]); centres.append(np.ascontiguousarray(c.T))  # centre-major
+    bt = np.array(btype, dtype=np.int32); bc = np.array(bcount, dtype=np.int32)
+    ex = np.ascontiguousarray(np.vstack(exps)) if exps else np.zeros((0, nvars), np.uint8)
+    ce = np.ascontiguousarray(np.vstack(centres)) if centres else np.zeros((0, nvars))
+    pc = None if pcs is None else F.fcol(pcs)
+    d = F.KpBasisDesc()
+    d.model_type, d.nzeta, d.m, d.n_blocks = F.MODEL[model_type], nzeta, m, len(blocks)
+    d.block_type = bt.ctypes.data_as(C.POINTER(C.c_int32))
+    d.block_count = bc.ctypes.data_as(C.POINTER(C.c_int32))
+    d.poly_exps = ex.ctypes.data_as(C.POINTER(C.c_uint8))
+    d.gauss_centres = F.dptr(ce)
+    d.k_pcs = 0 if pcs is None else pc.shape[1]
+    d.pcs = F.dptr(pc)
+    return d, (bt, bc, ex, ce, pc)
+
+
 class Basis:
     """kp_basis built from a host-side dictionary description (see basis.py)."""
 
@@ -238,33 +271,7 @@ class Basis:
         | ('hermite', orders[rows,nvars] uint8) | ('fourier_sparser', multipliers[rows,2*nvars] uint8)."""
         self.ctx = ctx
         ctx._children.add(self)
-        nvars = nzeta + (m if model_type == "nonlinear" else 0)
-        btype, bcount, exps, centres = [], [], [], []
-        for kind, arg in blocks:
-            btype.append(F.BLOCK[kind])
-            if kind in ("poly", "hermite"):
-                e = np.ascontiguousarray(arg, dtype=np.uint8).reshape(-1, nvars)
-                bcount.append(e.shape[0]); exps.append(e)
-            elif kind == "fourier_sparser":
-                e = np.ascontiguousarray(arg, dtype=np.uint8).reshape(-1, 2 * nvars)
-                bcount.append(e.shape[0]); exps.append(e.reshape(-1, nvars))      # two table rows per function
-            elif kind == "fourier":
-                bcount.append(int(arg))
-            else:
-                c = np.asarray(arg, dtype=np.float64).reshape(nvars, -1)
-                bcount.append(c.shape[1]); centres.append(np.ascontiguousarray(c.T))  # centre-major
-        self._bt = np.array(btype, dtype=np.int32); self._bc = np.array(bcount, dtype=np.int32)
-        self._ex = np.ascontiguousarray(np.vstack(exps)) if exps else np.zeros((0, nvars), np.uint8)
-        self._ce = np.ascontiguousarray(np.vstack(centres)) if centres else np.zeros((0, nvars))
-        self._pcs = None if pcs is None else F.fcol(pcs)
-        d = F.KpBasisDesc()
-        d.model_type, d.nzeta, d.m, d.n_blocks = F.MODEL[model_type], nzeta, m, len(blocks)
-        d.block_type = self._bt.ctypes.data_as(C.POINTER(C.c_int32))
-        d.block_count = self._bc.ctypes.data_as(C.POINTER(C.c_int32))
-        d.poly_exps = self._ex.ctypes.data_as(C.POINTER(C.c_uint8))
-        d.gauss_centres = F.dptr(self._ce)
-        d.k_pcs = 0 if pcs is None else self._pcs.shape[1]
-        d.pcs = F.dptr(self._pcs)
+        d, self._keep = basis_desc(model_type, nzeta, m, blocks, pcs)
         self._h = F.vp()
         F.check(F.lib().kp_basis_create(ctx.handle, C.byref(d), C.byref(self._h)), ctx.handle)
         nv, nf, N, W = C.c_int(), C.c_int(), C.c_int(), C.c_int()

@@ -44,6 +44,8 @@ classdef KmpcHip < Kmpc
             % loaded models: A, B already have the loaded sizes N (nw+1) (Ksysid.m:1192-1200, :1251-1259)
             obj.hip.mpc = kp_mex( 'mpc_create' , sysid_class.hip.ctx , mt , obj.model.A , obj.model.B , obj.horizon , ...
                                   obj.projmtx , obj.cost_running , obj.cost_terminal , r , lo , hi , slope , smooth );
+            % released when the last copy of this (value-class) object is gone; the controller points into the context
+            obj.hip.mpc_owner = KpOwner( obj.hip.mpc , 'mpc_destroy' , sysid_class.hip.ctx_owner );
             if ~isempty( obj.state_bounds )              % :313
                 sb = obj.scaledown.y( obj.state_bounds' )';
                 kp_mex( 'mpc_set_state_bounds' , obj.hip.mpc , sb(:,1) , sb(:,2) );
@@ -71,6 +73,16 @@ classdef KmpcHip < Kmpc
                 return;
             end
             [ U , z ] = kp_mex( 'mpc_step_zeta' , obj.hip.mpc , obj.hip.sys.hip.basis , zeta , traj.u(end,:)' , Yr , iters );
+        end
+
+        function [ U , status ] = hip_step_batch( obj , Z , Uprev , refs )
+            % nb independent problems of this controller in one launch (Monte-Carlo closed loops, random-state sweeps;
+            % the reference would call get_mpcInput* nb times, Kmpc.m:329, :750, :817).  Z: N x nb lifted states,
+            % Uprev: m x nb previous inputs, refs: (Np+1) x nproj x nb reference windows (already padded, :354-365).
+            % U: Np x m x nb (row 1 = pinned current input); NaN where the QP failed (status(i) ~= 0)
+            nb = size( Z , 2 );
+            YR = reshape( permute( refs , [ 2 1 3 ] ) , [] , nb );       % Yr = reshape( ref' , [] , 1 ) per problem (:858)
+            [ U , status ] = kp_mex( 'mpc_step_batch' , obj.hip.mpc , Z , Uprev , YR );
         end
 
         function [ U , z ] = get_mpcInput( obj , traj , ref )
@@ -158,9 +170,9 @@ classdef KmpcHip < Kmpc
         end
 
         function delete_hip( obj )
-            % value class: the owning script releases the device problem when it is done (or mexAtExit does at session end)
-            if isfield( obj.hip , 'mpc' )
-                kp_mex( 'mpc_destroy' , obj.hip.mpc );
+            % explicit, early release (the KpOwner member does it when the last copy of the object is gone)
+            if isfield( obj.hip , 'mpc_owner' )
+                obj.hip.mpc_owner.release();
             end
         end
     end
