@@ -43,7 +43,7 @@
  *             q = kp_mex('last_pivot_ratio', h)                                                            kp_fit_last_pivot_ratio
  *             [K, G, C, status] = kp_mex('fit_batch', h, b, s, nb, Ns_each)                                kp_fit_batch
  *             K = kp_mex('fit_sharded', h, b, s, lasso)    [G, C] = kp_mex('fit_gram_sharded', h, b, s)    kp_fit_(gram_)sharded
- * models      [A, B, M] = kp_mex('model_project', h, K, G, C, N, m)                                        kp_model_project
+ * models      [MA, MB, M] = kp_mex('model_project', h, K, G, C, N, m)   the projected M*A, M*B (Ksysid.m:1224-1225) and M   kp_model_project
  *             [A, B, M, status] = kp_mex('model_project_batch', h, K, G, C, N, m)   stacks W x W x nb      kp_model_project_batch
  *             Y = kp_mex('rollout', h, model_type, A, B, z0, U, n_out)       z0 N x batch, U T x m x batch kp_rollout
  *             Z = kp_mex('rollout_nl', h, b, Kf, zeta0, U)                   zeta0 nzeta x batch           kp_rollout_nl

@@ -153,6 +153,8 @@ def test_ksysid_hip_train_models_keeps_the_callers_view_of_the_parent():
     assert "all( obj.lasso >= 1e6 )" in gk                     # the PROPERTY decides the branch (Ksysid.m:1068)
     assert "fit_refine" in gk and "last_pivot_ratio" in gk and "1e-5" in gk
     assert "hip_lasso_delay_rows" in gk and "obj.params.nd >= 1" in gk
+    gm = src[src.index("function [ out , obj ] = get_model"):src.index("function obj = train_models")]
+    assert "out.A = MA;" in gm and "out.B = MB;" in gm and "M * " not in gm      # kp_model_project returns M*A, M*B already (executed check:
     kd = src[src.index("function koopData = hip_koopData"):src.index("function K = hip_lasso_delay_rows")]
     order = [kd.index("koopData.K = "), kd.index("koopData.Px = "), kd.index("koopData.Py = "), kd.index("koopData.u = "), kd.index("koopData.alpha = ")]
     assert order == sorted(order)                              # field order of Ksysid.m:1084-1091

@@ -21,6 +21,14 @@ pytestmark = pytest.mark.gpu
 USED = set()
 
 
+def _f(x):
+    return float(np.asarray(x).reshape(-1)[0])
+
+
+def _i(x):
+    return int(np.asarray(x).reshape(-1)[0])
+
+
 def mex(cmd, *args, nargout=1):
     USED.add(cmd)
     return ms.kp_mex(cmd, *args, nargout=nargout)
@@ -39,7 +47,7 @@ def desc_of(model_type, nzeta, m, deg, pcs=None, extra=()):
 def h():
     hh = mex("create", 0)
     yield hh
-    mex("destroy", hh)
+    mex("destroy", hh, nargout=0)
 
 
 @pytest.fixture(scope="module")
@@ -52,24 +60,24 @@ def small(ctx, h):
     s = mex("snapshots_upload", h, p["alpha"], p["beta"], p["u"])
     sp = kra.Snapshots(ctx, p["alpha"], p["beta"], p["u"])
     yield {"p": p, "d": d, "e": e, "b": b, "bp": bp, "s": s, "sp": sp, "W": bp.W, "N": bp.N}
-    mex("snapshots_destroy", s)
-    mex("basis_destroy", b)
+    mex("snapshots_destroy", s, nargout=0)
+    mex("basis_destroy", b, nargout=0)
 
 
 def test_context_commands(ctx, h):
-    assert int(mex("device_count")) >= 1
+    assert _i(mex("device_count")) >= 1
     name, ncu, hbm = mex("device_info", h, nargout=3)
     info = ctx.info()
-    assert name == info["name"] and int(ncu) == info["num_cu"] and int(hbm) == info["hbm_bytes"]
+    assert name == info["name"] and _i(ncu) == info["num_cu"] and _i(hbm) == info["hbm_bytes"]
     assert isinstance(mex("last_error"), str) and isinstance(mex("last_error", h), str)
-    assert float(mex("timer_get", h, 0)) >= 0.0
+    assert _f(mex("timer_get", h, 0)) >= 0.0
     mex("synchronize", h, nargout=0)
     tab, names = mex("commands", nargout=2)
     assert tab.shape == (len(names.split("\n")), 3)
     h2 = mex("create", 0)                                   # the device's context is shared and reference counted
     assert h2 == h
     mex("destroy", h2, nargout=0)
-    assert int(mex("device_count")) >= 1                    # ... and still alive after one reference was dropped
+    assert _i(mex("device_count")) >= 1                    # ... and still alive after one reference was dropped
     with pytest.raises(ms.MexError) as e:
         mex("create", 99)
     assert e.value.identifier in ("kp:usage", "kp:error")
@@ -88,7 +96,7 @@ def test_dictionary_lift_and_eig(ctx, h, small):
         mex("lift", h, small["b"], 2, z, u[:10])
     S = np.cov(np.random.default_rng(0).standard_normal((40, 12)), rowvar=False)
     V, lam, sweeps = mex("sym_eig", h, S, nargout=3)
-    assert int(sweeps) >= 1 and np.abs(V @ np.diag(lam.ravel()) @ V.T - S).max() <= 1e-12
+    assert _i(sweeps) >= 1 and np.abs(V @ np.diag(lam.ravel()) @ V.T - S).max() <= 1e-12
     lam_p, V_p, _ = ctx.sym_eig(S)
     assert np.allclose(np.sort(lam.ravel())[::-1], lam_p, rtol=0, atol=1e-13)
     # a dictionary with a projection (dim_red): pcs travels as an nfull x k double matrix
@@ -107,8 +115,8 @@ def test_fit_commands(ctx, h, small):
     Kref = kra.fit(ctx, small["bp"], small["sp"])[0]
     K = mex("fit", h, small["b"], small["s"], np.inf)
     assert K.shape == (W, W) and np.array_equal(K, Kref)
-    assert int(mex("last_rank", h)) == W == ctx.last_rank()
-    assert float(mex("last_pivot_ratio", h)) == ctx.last_pivot_ratio()
+    assert _i(mex("last_rank", h)) == W == ctx.last_rank()
+    assert _f(mex("last_pivot_ratio", h)) == ctx.last_pivot_ratio()
     G, Cm = mex("fit_gram", h, small["b"], small["s"], nargout=2)
     Gp, Cp = kra.fit_gram(ctx, small["bp"], small["sp"])
     assert np.array_equal(G, Gp) and np.array_equal(Cm, Cp)
@@ -117,7 +125,7 @@ def test_fit_commands(ctx, h, small):
     t = 0.3 * np.abs(Kref).sum()
     Kl, it = mex("fit_lasso", h, G, Cm, t, nargout=2)
     Klp, itp = ctx.fit_lasso(Gp, Cp, t)
-    assert np.array_equal(Kl, Klp) and int(it) == itp and abs(np.abs(Kl).sum() - t) <= 1e-8 * t
+    assert np.array_equal(Kl, Klp) and _i(it) == itp and abs(np.abs(Kl).sum() - t) <= 1e-8 * t
     tv = np.array([0.5, 0.2, 5.0]) * np.abs(Kref).sum()
     Kb, itb = mex("fit_lasso_batch", h, G, Cm, tv, nargout=2)
     Kbp, itbp = ctx.fit_lasso_batch(Gp, Cp, tv)
@@ -172,9 +180,10 @@ def test_rank_deficient_fit_warns_like_mldivide(h):
     b = mex("basis_create", h, d)
     s = mex("snapshots_upload", h, a, 0.9 * a, u)
     K = mex("fit", h, b, s, np.inf)
-    assert ms.last_warning[0] == "kp:rankDeficient" and "Rank deficient, rank = " in ms.last_warning[1]
-    r = int(mex("last_rank", h))
-    assert r < K.shape[0] and np.isfinite(K).all() and f"rank = {r}" in ms.last_warning[1]
+    warn = ms.last_warning
+    assert warn[0] == "kp:rankDeficient" and "Rank deficient, rank = " in warn[1]
+    r = _i(mex("last_rank", h))
+    assert r < K.shape[0] and np.isfinite(K).all() and f"rank = {r}" in warn[1]
     mex("fit", h, b, s, np.inf)
     mex("snapshots_destroy", s, nargout=0)
     mex("basis_destroy", b, nargout=0)
@@ -245,7 +254,8 @@ def _stacks(nb=12, k=4, T=201, Tv=151, seed=9):
 def test_sweep_commands(ctx, h):
     Y, U, Yv, Uv, k = _stacks()
     nb = Y.shape[2]
-    tp = kra.Traj(ctx, np.transpose(Y, (2, 0, 1)), np.transpose(U, (2, 0, 1)), k, np.transpose(Yv, (2, 0, 1)), np.transpose(Uv, (2, 0, 1)))
+    from koopman_realizations_amd.device import Traj
+    tp = Traj(ctx, np.transpose(Y, (2, 0, 1)), np.transpose(U, (2, 0, 1)), k, np.transpose(Yv, (2, 0, 1)), np.transpose(Uv, (2, 0, 1)))
     t = mex("traj_upload", h, Y, U, Yv, Uv, k)
     assert mex("traj_dims", t).ravel().tolist() == [nb, k, Y.shape[0] // k, 1, 1, Yv.shape[0]]
     assert np.array_equal(mex("traj_scale", t), tp.scale().T)
@@ -267,7 +277,7 @@ def test_sweep_commands(ctx, h):
         errp, stp = tp.sweep_eval_nested(bp, D, las)
         assert err.shape == (1, nb, D) and np.array_equal(np.transpose(err, (2, 1, 0)), errp, equal_nan=True)
         assert np.array_equal(st.T, stp)
-        W2 = int(mex("basis_desc_dims", desc_of(mt, 1, 1, 2)[0])[0, 3])
+        W2 = _i(mex("basis_desc_dims", desc_of(mt, 1, 1, 2)[0])[0, 3])
         Kd = mex("sweep_nested_get_K", h, nb, bp.W, D, 1, W2)
         assert Kd.shape[2] == nb and np.isfinite(Kd).all()
         e1, K1, s1 = mex("sweep_eval", h, t2, b, las, nargout=3)
@@ -310,7 +320,7 @@ def test_mpc_commands(ctx, h, mpc_model):
         Up, zp, stp = mp.step_zeta(mm["bp"], zeta, up, Yr, it)
         assert stp == 0 and np.abs(U - Up).max() <= 1e-10 and np.array_equal(z.ravel(), zp)
         U2, st2 = mex("mpc_step", m_, z, up, Yr, it, nargout=2)
-        assert int(st2) == 0 and np.abs(U2 - Up).max() <= 1e-10
+        assert _i(st2) == 0 and np.abs(U2 - Up).max() <= 1e-10
     Udef = mex("mpc_step_zeta", m_, b, zeta, up, Yr)                      # iters omitted: 1
     assert np.abs(Udef - mp.step_zeta(mm["bp"], zeta, up, Yr, 1)[0]).max() <= 1e-10
     Hq, f, Aq, bq = mex("mpc_last_qp", m_, nargout=4)
@@ -337,7 +347,7 @@ def test_mpc_commands(ctx, h, mpc_model):
     Aqp = np.vstack([np.eye(6), -np.eye(6)]); bqp = np.full(12, 0.3)
     x, stq = mex("qp_solve", h, H, fq, Aqp, bqp, nargout=2)
     xp, stqp = ctx.qp_solve(H, fq, Aqp, bqp)
-    assert int(stq) == stqp == 0 and np.array_equal(x.ravel(), xp)
+    assert _i(stq) == stqp == 0 and np.array_equal(x.ravel(), xp)
     mex("mpc_destroy", m_, nargout=0)
     mex("basis_destroy", b, nargout=0)
     mp.close()
@@ -353,7 +363,7 @@ def test_multi_gpu_commands_with_one_device_listed_twice(ctx, h, small, mpc_mode
     ref = kra.fit(ctx, small["bp"], small["sp"], las)
     for ids in ([0, 0], [0, 0, 0], [0]):
         g = mex("multi_create", np.array(ids, dtype=np.float64))
-        assert int(mex("multi_size", g)) == len(ids)
+        assert _i(mex("multi_size", g)) == len(ids)
         Ks = mex("multi_fit", g, small["d"], p["alpha"], p["beta"], p["u"], las)
         assert Ks.shape == (W, W, 5) and all(np.array_equal(Ks[:, :, i], ref[i]) for i in range(5))
         tm = mex("multi_timers", g)
@@ -478,8 +488,8 @@ def test_flow_of_ksysidhip_get_koopman_and_train_models(ctx, h, golden):
     W = int(dims[3])
     s = mex("snapshots_resident", hc, sp["alpha"], sp["beta"], sp["u"])
     K = mex("fit", hc, b, s, np.inf)
-    assert int(mex("last_rank", hc)) == W
-    ratio = float(mex("last_pivot_ratio", hc))
+    assert _i(mex("last_rank", hc)) == W
+    ratio = _f(mex("last_pivot_ratio", hc))
     if ratio < 1e-5:                                            # KsysidHip.get_Koopman's rule (Ksysid.m:1069: `\` is a QR solve)
         K = mex("fit_refine", hc, b, s, K, 1)
     Kp = ks.koopData["K"]
@@ -487,13 +497,19 @@ def test_flow_of_ksysidhip_get_koopman_and_train_models(ctx, h, golden):
     Px = mex("lift", hc, b, 1, sp["alpha"], None)
     assert np.array_equal(Px, ks.koopData["Px"])
     G, Cm = mex("fit_gram", hc, b, s, nargout=2)
-    A, B, M = mex("model_project", hc, K, G, Cm, ks.params["N"], 3, nargout=3)
-    assert np.abs(M @ A - ks.model["A"]).max() <= 1e-10 * np.abs(ks.model["A"]).max()
-    assert np.abs(M @ B - ks.model["B"]).max() <= 1e-10 * max(1.0, np.abs(ks.model["B"]).max())
+    MA, MB, M = mex("model_project", hc, K, G, Cm, ks.params["N"], 3, nargout=3)     # the projected M*A, M*B (Ksysid.m:1224-1225)
+    assert np.abs(MA - ks.model["A"]).max() <= 1e-10 * np.abs(ks.model["A"]).max()
+    assert np.abs(MB - ks.model["B"]).max() <= 1e-10 * max(1.0, np.abs(ks.model["B"]).max())
+    UT = K.T
+    N_ = ks.params["N"]
+    assert np.abs(M @ UT[:N_, :N_] - MA).max() <= 1e-9 * np.abs(MA).max()            # out.A = M * UT(1:N,1:N), as the parent forms it
     mex("basis_destroy", b, nargout=0)
     # vector branch of train_models (lasso property below 1e6): ONE gateway call, a W x W x n stack, value i = the parent's loop
-    kb = kra.Ksysid(data, ctx=ctx, model_type="bilinear", obs_type=["poly"], obs_degree=[2], snapshots=np.inf, lasso=[1.0], delays=0, dim_red=True)
-    db = dict(d, model_type=np.int32(1), pcs=kb.basis["pcs"])
+    # (poly-3 with dim_red, the dictionary of example_sysid.m: cond(Px) 1.4e3.  The poly-2 one above has cond 1.9e5, i.e. cond(G)
+    #  3.6e10, where the projected-gradient lasso of the library reaches its iteration cap for tight budgets - DESIGN section 5)
+    kb = kra.Ksysid(data, ctx=ctx, model_type="bilinear", obs_type=["poly"], obs_degree=[3], snapshots=np.inf, lasso=[1.0], delays=0, dim_red=True)
+    e3 = kra.poly_exponent_table(nv, 3)[nv:].astype(np.uint8)
+    db = dict(d, model_type=np.int32(1), pcs=kb.basis["pcs"], block_count=np.array([[e3.shape[0]]], dtype=np.int32), poly_exps=np.asfortranarray(e3.T))
     bb = mex("basis_create", hc, db)
     Kls = kra.fit(ctx, kb.basis_dev, kb._resident_snapshots(sp["alpha"], sp["beta"], sp["u"]))[0]
     las = np.array([[2.0, 0.5, 0.1]]) * np.abs(Kls).sum() / kb.params["N"]
