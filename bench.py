@@ -192,7 +192,7 @@ def bench_lasso(ctx, comm, kra, basis, snaps, n_values=64):
     mine = sweep.shard_units(n_values, comm.rank, comm.world)
     per = (n_values + comm.world - 1) // comm.world
     kra.fit(ctx, basis, snaps, [vals[i] for i in mine[:1]], fetch=False)  # warm-up (allocations, RCCL channels)
-    sweep.lasso_sweep_device(ctx, fit_dev, vals, W, comm)                 # ... and every buffer at its final size
+    sweep.lasso_sweep_device(ctx, fit_dev, vals, W, comm, root=0)         # ... and every buffer at its final size
     comm.barrier()
     t0 = time.perf_counter()
     t_g = [0.0]
@@ -203,11 +203,16 @@ def bench_lasso(ctx, comm, kra, basis, snaps, n_values=64):
         return r
     kc.all_gather_fits = timed_gather
     try:
-        Ks = sweep.lasso_sweep_device(ctx, fit_dev, vals, W, comm)
+        # the stack goes to rank 0 ONLY (kp_comm_gather_fits: the other ranks send their share and return) - one host wants
+        # the candidates of train_models, as in the reference (Ksysid.m:1370-1387)
+        Ks = sweep.lasso_sweep_device(ctx, fit_dev, vals, W, comm, root=0)
     finally:
         kc.all_gather_fits = _gather
     comm.barrier()
     dt = kc.max_over_ranks(comm, time.perf_counter() - t0)
+    per_rank = kc.all_gather_array(comm, np.array([ctx.timer(3), t_g[0] * 1e3]))       # device ms (lasso batch), gather ms of every rank
+    if Ks is None:
+        return None
     l1 = np.array([np.abs(K).sum() for K in Ks])
     t = np.array(vals) * basis.N
     active = int((l1 < l1.max() * (1 - 1e-9)).sum())
@@ -215,7 +220,8 @@ def bench_lasso(ctx, comm, kra, basis, snaps, n_values=64):
             "n_gpus": comm.world, "active_constraints": active,
             "budget_met": bool(np.all(l1 <= t * (1 + 1e-9) + 1e-12)),
             "device_ms_rank0": ctx.timer(3), "gather_ms_rank0": t_g[0] * 1e3, "_gemm": (ctx.timer(8), ctx.timer(9)) if ctx.timer(9) > 0 else None,
-            "gather": f"K stack of the shard gathered device to device ({comm.kind}), one DMA of {n_values * W * W * 8 / 1e6:.0f} MB into a page-locked block",
+            "device_ms_per_rank": per_rank[:, 0].tolist(), "gather_ms_per_rank": per_rank[:, 1].tolist(),
+            "gather": f"K stacks of the shards sent to rank 0 only ({comm.kind}; kp_comm_gather_fits), one DMA of {n_values * W * W * 8 / 1e6:.0f} MB into a page-locked block there",
             "workload": "64 lasso values (t/N log-spaced 1e-2..1e2) on the bilinear poly-3 fit, 1e5 pairs, sharded round-robin, "
                         "K stack gathered (BASELINE configs[3])"}
 
@@ -445,6 +451,122 @@ def cpu_baseline_mpc(pack):
             "sample": f"{n} literal Kmpc steps (numpy), N={N}, {dt*1e3:.1f} ms each"}
 
 
+def one_caller_main(args):
+    """ONE process, ONE calling thread, `--gpus` devices through the kp_multi_* entry points (the reference's host shape: a
+    single MATLAB interpreter, Ksim.m:147 / evaluate_rand_models.m:45 - no second process, no RCCL): the lasso grid of
+    configs[3], the random-system sweep of configs[4], a batch of MPC problems and one fit sharded over snapshots.  Prints one
+    JSON object.  KP_ONE_CALLER_IDS=0,0 lists devices explicitly (the same device twice on a one-GPU box)."""
+    ids = [int(x) for x in os.environ["KP_ONE_CALLER_IDS"].split(",")] if os.environ.get("KP_ONE_CALLER_IDS") else list(range(args.gpus))
+    n_gen = 2
+    chunks = gen_rand_systems(list(range(n_gen)))                 # host, before the GPUs are touched
+    import koopman_realizations_amd as kra
+    from koopman_realizations_amd import sweep
+    from koopman_realizations_amd.multi import Multi, MultiMpc
+    res = {"device_ids": ids, "host": "one process, one calling thread; a library-owned worker thread + context per device"}
+    mg = Multi(ids)
+    Ns = args.snapshots
+    a, b, u = (np.asfortranarray(x) for x in synth_pairs(Ns, seed=0))
+    exps = kra.poly_exponent_table(6, 3)[6:]
+    dic = ("bilinear", 6, 3, [("poly", exps)], None)
+    N, W = 84, 336
+
+    def best(fn, reps=3):
+        ts = []
+        for _ in range(reps):
+            t1 = time.perf_counter(); r = fn(); ts.append(time.perf_counter() - t1)
+        return min(ts), r
+    # (a) configs[3]: 64 lasso values on ONE snapshot matrix, value i on device i mod n; K stack into a page-locked block
+    vals = np.geomspace(1e-2, 1e2, 64)
+    out = mg.host_array("Kgrid", (64, W, W))
+    mg.fit(dic, a, b, u, vals, out=out)                           # every buffer at its final size, dictionaries resident
+    dt, Ks = best(lambda: mg.fit(dic, a, b, u, vals, out=out))
+    tm = mg.timers()
+    l1 = np.abs(Ks).sum(axis=(1, 2))
+    res["lasso_grid"] = {"values": 64, "seconds": dt, "values_per_s": 64 / dt, "W": W, "n_devices": len(ids),
+                         "per_device_ms": {"upload": tm[:, 0].tolist(), "device": tm[:, 1].tolist(), "gather": tm[:, 2].tolist(), "job": tm[:, 3].tolist()},
+                         "budget_met": bool(np.all(l1 <= vals * N * (1 + 1e-9) + 1e-12)),
+                         "gather": "each device DMAs its own K matrices into the caller's page-locked stack (no all-gather)",
+                         "note": "includes the upload of the 12 MB snapshot matrix to every device (host data in, K stack on the host out)"}
+    # (b) ONE fit sharded over snapshots: rows dealt over the devices, [G | C] to device 0 by peer copy, one solve
+    sh = {}
+    for Ns_tot in (Ns, 10000000):
+        try:
+            a2, b2, u2 = (a, b, u) if Ns_tot == Ns else (np.asfortranarray(x) for x in synth_pairs(Ns_tot, seed=3))
+            mg.fit_sharded(dic, a2, b2, u2)
+            dts, Ksh = best(lambda: mg.fit_sharded(dic, a2, b2, u2), reps=3 if Ns_tot <= 1000000 else 2)
+            tm = mg.timers()
+            sh[f"Ns{Ns_tot}"] = {"snapshots_total": Ns_tot, "ms_per_fit": dts * 1e3, "pairs_per_s": Ns_tot / dts,
+                                 "per_device_ms": {"upload": tm[:, 0].tolist(), "gram": tm[:, 1].tolist(), "exchange": tm[:, 2].tolist()},
+                                 "note": "host arrays in (PCIe upload of every device's rows inside the time), K on the host out"}
+            if Ns_tot == Ns:
+                Kls = Ksh[0].T
+        except Exception as e:
+            sh[f"Ns{Ns_tot}"] = {"error": repr(e)[:300]}
+    res["snapshot_sharded_fit"] = dict(sh, exchange="peer copy of 2 W^2 doubles per device to device 0 (xGMI), summed in device order", scaling="strong")
+    # (c) configs[4]: 1024 random systems, contiguous chunks per device, three nested passes
+    mine = [s_ for c in sorted(chunks) for s_ in chunks[c]]
+    Y, U, k, Yv, Uv = sweep._stack_raw(mine)
+    rep = max(1, args.rand_systems // Y.shape[0])
+    Y, U, Yv, Uv = (np.ascontiguousarray(np.tile(x, (rep, 1, 1))) for x in (Y, U, Yv, Uv))
+    nsys = Y.shape[0]
+    dicts = {mt: (mt, 1, 1, [("poly", kra.poly_exponent_table(1 + (mt == "nonlinear"), D)[1 + (mt == "nonlinear"):])], None)
+             for mt, D in sweep.MAX_DEGREE.items()}
+
+    def run_sweep():
+        tr = mg.traj_upload(Y, U, k, Yv, Uv)
+        t_up = mg.timers()[:, 0].tolist()
+        errs, t_dev = {}, {}
+        for mt, D in sweep.MAX_DEGREE.items():
+            e, st = tr.sweep_eval_nested(dicts[mt], D, 4.0 if mt == "nonlinear" else np.inf)
+            errs[mt] = np.where(st != 0, np.nan, e[:, :, 0]); t_dev[mt] = mg.timers()[:, 1].tolist()
+        tr.close()
+        return errs, t_up, t_dev
+    run_sweep()
+    dtw, (errs, t_up, t_dev) = best(run_sweep)
+    mean, _ = sweep.sweep_statistics(errs["linear"])
+    res["rand_sweep"] = {"systems": nsys, "distinct_systems": int(n_gen * RAND_CHUNK), "seconds": dtw, "systems_per_s": nsys / dtw, "n_devices": len(ids),
+                         "per_device_ms": {"upload": t_up, "passes": t_dev}, "mean_linear_error_deg1_deg13": [float(mean[0]), float(mean[-1])],
+                         "note": f"{n_gen * RAND_CHUNK} generated systems tiled to {nsys} (the child process generates only two chunks); stacked "
+                                 "raw trials in (host gather of the data4sysid structs excluded), error tables out"}
+    # (d) batched MPC: 4096 problems per device
+    A = np.asfortranarray(Kls[:N, :N].T); B = np.asfortranarray(Kls[N:, :N].T)
+    proj = np.zeros((2, N)); proj[0, 4] = proj[1, 5] = 1.0
+    u_fac = 2.8
+    mm = MultiMpc(mg, "bilinear", A, B, 10, proj, 10.0, 100.0, 0.1 * np.array([3e-2, 2e-2, 1e-2]), np.full(3, -7 * np.pi / 8 / u_fac),
+                  np.full(3, 7 * np.pi / 8 / u_fac), 1e-1 * u_fac)
+    nb = args.mpc_batch * len(ids)
+    zeta, u_prev, Yr = mpc_inputs(nb)
+    ctx0 = kra.Context(ids[0])
+    bs = kra.Basis(ctx0, "bilinear", 6, 3, [("poly", exps)])
+    from koopman_realizations_amd import _ffi as F
+    Z = np.ascontiguousarray(bs.lift(F.LIFT_ECON, zeta))
+    bs.close(); ctx0.close()
+    mm.step_batch(Z, u_prev, Yr)
+    dtb, (Ub, stb) = best(lambda: mm.step_batch(Z, u_prev, Yr))
+    res["mpc_batch"] = {"problems": nb, "seconds": dtb, "problems_per_s": nb / dtb, "solved": int((stb == 0).sum()), "n_devices": len(ids),
+                        "per_device_ms": mg.timers()[:, 1].tolist()}
+    mm.close()
+    mg.close()
+    print(json.dumps(res), flush=True)
+
+
+def run_one_caller(args, n_dev, timeout=240.0):
+    """The one-caller block in a FRESH process (started by rank 0 when its own sections are done): a failure or a hang there
+    costs this block, never the line."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--one-caller", "--gpus", str(n_dev), "--snapshots", str(args.snapshots),
+           "--mpc-batch", str(args.mpc_batch), "--rand-systems", str(args.rand_systems)]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "KP_FORCE_DEVICE")}
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode == 0 and lines:
+            return json.loads(lines[-1])
+        return {"error": f"rc {r.returncode}: " + (r.stderr or r.stdout)[-400:]}
+    except Exception as e:
+        return {"error": repr(e)[:300]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -458,7 +580,12 @@ def main():
     ap.add_argument("--mpc-steps", type=int, default=300)
     ap.add_argument("--mpc-batch", type=int, default=4096)
     ap.add_argument("--rand-systems", type=int, default=1024)
+    ap.add_argument("--one-caller", action="store_true", help="(internal) the single-process multi-GPU block: kp_multi_* over --gpus devices")
+    ap.add_argument("--no-one-caller", action="store_true")
     args = ap.parse_args()
+    if args.one_caller:
+        one_caller_main(args)
+        return
 
     from koopman_realizations_amd import comm as kc
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -705,14 +832,33 @@ def main():
             sweep_res.pop("_gram", None)
         if kern:
             res["kernels"] = kern
+        if extras_on and not args.no_one_caller:
+            # the reference's host shape: ONE process drives all `world` GPUs through kp_multi_* (fresh child process; the
+            # other ranks of this launch idle meanwhile, waiting for the flag file below)
+            res["one_caller"] = run_one_caller(args, world)
         if not args.no_cpu_baseline and world == 1:
-            res["cpu_baseline"] = cpu_baseline(min(Ns, 20000), args.degree)
+            res["cpu_baseline"] = cpu_baseline(Ns, args.degree, seconds=6.0)
             if mpc_res is not None:
                 res["cpu_baseline"]["mpc"] = cpu_baseline_mpc(mpc_res.pop("_setup"))
         if mpc_res is not None:
             mpc_res.pop("_setup", None)
         print(json.dumps(res), flush=True)
+    # ranks other than 0 idle (no collective in flight: an RCCL barrier would spin on their GPUs) until rank 0 is through with
+    # its host-only sections and the one-caller block, which uses every GPU of the launch
+    flag = os.path.join("/tmp", f"kp_bench_done_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}")
+    if world > 1:
+        if rank == 0:
+            open(flag, "w").close()
+        else:
+            t_w = time.perf_counter()
+            while not os.path.exists(flag) and time.perf_counter() - t_w < 600.0:
+                time.sleep(0.05)
     comm.barrier()
+    if world > 1 and rank == 0:
+        try:
+            os.remove(flag)
+        except OSError:
+            pass
     ctx.close()
 
 

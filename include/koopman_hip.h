@@ -373,6 +373,10 @@ int kp_comm_allgather(kp_ctx* ctx, const void* send, int64_t bytes, void* recv);
 int kp_comm_allreduce_sum(kp_ctx* ctx, double* inout, int64_t count);
 int kp_comm_allgather_fit(kp_ctx* ctx, int index, int W, double* K_all);
 int kp_comm_allgather_fits(kp_ctx* ctx, int first, int count, int W, double* K_all);
+/* kp_comm_allgather_fits to ONE rank: every other rank sends its `count` matrices to `root` (ncclSend / ncclRecv, one group)
+ * and returns without a host copy; K_root (world x count matrices, rank-major) is written on the root only and may be NULL
+ * elsewhere.  The reference's caller of train_models is one host (Ksysid.m:1370-1387): one rank wants the candidates. */
+int kp_comm_gather_fits(kp_ctx* ctx, int root, int first, int count, int W, double* K_root);
 int kp_fit_sharded(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* snaps_local, const double* lasso,
                    int n_lasso, double* K_out);
 int kp_fit_gram_sharded(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* snaps_local, double* G, double* C);

@@ -11,9 +11,10 @@ from ._ffi import KoopmanHipError
 from .device import Basis, Context, Snapshots, fit, fit_gram, fit_gram_sharded, fit_refine, fit_sharded
 from .device import Mpc
 from . import comm
+from .multi import Multi, MultiMpc
 from .arm import Arm
 from .kmpc import Kmpc, Ksim, ModelPlant
 from .ksysid import Ksysid, default_context, poly_exponent_table
 
 __all__ = ["Arm", "Basis", "Context", "Snapshots", "fit", "fit_gram", "fit_gram_sharded", "fit_refine", "fit_sharded", "Ksysid", "Kmpc", "Ksim", "ModelPlant", "Mpc", "KoopmanHipError", "default_context",
-           "poly_exponent_table", "_ffi", "comm"]
+           "poly_exponent_table", "_ffi", "comm", "Multi", "MultiMpc"]

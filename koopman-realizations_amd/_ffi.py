@@ -97,6 +97,7 @@ SIGNATURES = {
     "kp_comm_abandon": (C.c_int, [vp]),
     "kp_comm_allgather_fit": (C.c_int, [vp, C.c_int, C.c_int, c_dp]),
     "kp_comm_allgather_fits": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, c_dp]),
+    "kp_comm_gather_fits": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, c_dp]),
     "kp_fit_sharded": (C.c_int, [vp, vp, vp, c_dp, C.c_int, c_dp]),
     "kp_fit_gram_sharded": (C.c_int, [vp, vp, vp, c_dp, c_dp]),
     "kp_multi_create": (C.c_int, [c_ip, C.c_int, C.POINTER(vp)]),

@@ -122,6 +122,16 @@ class RcclComm:
         F.check(F.lib().kp_comm_allgather_fits(self.ctx.handle, int(first), int(count), int(W), F.dptr(out)), self.ctx.handle)
         return out
 
+    def gather_fits(self, root: int, first: int, count: int, W: int):
+        """all_gather_fits to ONE rank (kp_comm_gather_fits: ncclSend / ncclRecv, only the root copies the stack to its host).
+        Returns the (world, count, W, W) block on the root, None elsewhere."""
+        if self.rank == int(root):
+            out = self.ctx.host_array("Kgather", (self.world, int(count), int(W), int(W)))
+            F.check(F.lib().kp_comm_gather_fits(self.ctx.handle, int(root), int(first), int(count), int(W), F.dptr(out)), self.ctx.handle)
+            return out
+        F.check(F.lib().kp_comm_gather_fits(self.ctx.handle, int(root), int(first), int(count), int(W), None), self.ctx.handle)
+        return None
+
     def all_gather_fit(self, index: int, W: int):
         """K of fit `index` (kp_fit_get_K numbering) of every rank, gathered device to device: (world, W, W)."""
         K = np.zeros((self.world, W, W))
@@ -188,14 +198,18 @@ def all_gather_array(comm, a):
     return np.stack([np.frombuffer(p, dtype=np.float64).reshape(a.shape) for p in parts])
 
 
-def all_gather_fits(comm, ctx, first: int, count: int, W: int, have: int | None = None):
+def all_gather_fits(comm, ctx, first: int, count: int, W: int, have: int | None = None, root: int | None = None):
     """K stacks of a sharded sweep, (world, count, W, W) with column-major blocks: fits first .. first + count - 1 of every
     rank's device result buffer (`have` = how many of them this rank really computed; the rest is padding).  RCCL: one
     device-to-device all-gather + one DMA (kp_comm_allgather_fits); one rank: the DMA alone; any other `comm` (file / gloo
-    stand-ins): the rank's stack through a page-locked block, then the stand-in's array gather."""
-    fn = getattr(comm, "all_gather_fits", None)
+    stand-ins): the rank's stack through a page-locked block, then the stand-in's array gather.  `root`: only that rank
+    receives (and returns) the stack, the others return None (RCCL: kp_comm_gather_fits; stand-ins gather everywhere and drop it)."""
+    fn = getattr(comm, "gather_fits" if root is not None else "all_gather_fits", None)
     if fn is not None:
-        return fn(first, count, W)
+        return fn(root, first, count, W) if root is not None else fn(first, count, W)
+    if root is not None and comm is not None and comm.world > 1:
+        out = all_gather_fits(comm, ctx, first, count, W, have)
+        return out if comm.rank == int(root) else None
     have = count if have is None else min(int(have), int(count))
     if comm is None or comm.world == 1:
         out = ctx.host_array("Kgather", (1, int(count), int(W), int(W)))

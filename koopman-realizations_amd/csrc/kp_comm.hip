@@ -8,6 +8,8 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <string>
+#include <vector>
 
 #include "kp_internal.h"
 
@@ -20,7 +22,12 @@ struct RcclApi {
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
-  bool ok = false;
+  // point-to-point (the gather to ONE rank): optional - without them kp_comm_gather_fits runs the all-gather
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  bool ok = false, p2p = false;
 };
 
 RcclApi& rccl() {
@@ -41,6 +48,11 @@ RcclApi& rccl() {
     a.AllGather = (decltype(a.AllGather))dlsym(a.handle, "ncclAllGather");
     a.AllReduce = (decltype(a.AllReduce))dlsym(a.handle, "ncclAllReduce");
     a.GetErrorString = (decltype(a.GetErrorString))dlsym(a.handle, "ncclGetErrorString");
+    a.Send = (decltype(a.Send))dlsym(a.handle, "ncclSend");
+    a.Recv = (decltype(a.Recv))dlsym(a.handle, "ncclRecv");
+    a.GroupStart = (decltype(a.GroupStart))dlsym(a.handle, "ncclGroupStart");
+    a.GroupEnd = (decltype(a.GroupEnd))dlsym(a.handle, "ncclGroupEnd");
+    a.p2p = a.Send && a.Recv && a.GroupStart && a.GroupEnd && !getenv("KP_COMM_NO_P2P");
     a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllGather && a.AllReduce && a.GetErrorString;
     return a;
   }();
@@ -207,6 +219,46 @@ extern "C" int kp_comm_allgather_fit(kp_ctx* ctx, int index, int W, double* K_al
 // last synchronous kp_fit, or the fits of the last asynchronous batch) - of EVERY rank: one ncclAllGather of count W^2
 // doubles straight from the result buffer, one copy out.  K_all = world x count matrices, rank-major.  Ranks whose shard is
 // shorter than `count` (ragged round-robin deal) contribute padding slots of unspecified content.
+// contiguous device source of `count` result slots from `first` on (padding where this rank's shard is shorter); *ws_out: the
+// staging workspace (slot 8) sized for (extra_slots + 1) x count matrices - the source itself when a staging copy was needed
+static int fits_source(kp_ctx* ctx, const char* who, int first, int count, int W, int world, size_t extra_blocks, const double** src_out, double** ws_out) {
+  const size_t cnt = (size_t)W * W;
+  hipStream_t s = ctx->stream;
+  const bool have = ctx->Kres && W == ctx->Kres_W;          // a rank with an EMPTY shard has no results at all: all padding
+  if (!have && world == 1) return ctx->fail(KP_ERR_ARG, std::string(who) + ": no results of that width");
+  int avail = 0;                                             // valid fits from `first` on
+  if (have) {
+    if (ctx->kres_is_ring) {
+      if (first + count > ctx->async_count && world == 1) return ctx->fail(KP_ERR_ARG, std::string(who) + ": range not in the result ring");   // one rank: nobody else to pad for
+      if (first < ctx->async_count - ctx->kring_cap) return ctx->fail(KP_ERR_ARG, std::string(who) + ": range no longer in the result ring");
+      avail = std::max(0, std::min(count, ctx->async_count - first));
+    } else {
+      if (first + count > ctx->Kres_n && world == 1) return ctx->fail(KP_ERR_ARG, std::string(who) + ": index out of range");
+      avail = std::max(0, std::min(count, ctx->Kres_n - first));
+    }
+  }
+  const int slot0 = have && ctx->kres_is_ring ? first % ctx->kring_cap : first;
+  const bool wraps = have && ctx->kres_is_ring && slot0 + avail > ctx->kring_cap;
+  const bool inside = have && !wraps && avail == count;
+  double* ws = nullptr;
+  if (extra_blocks || !inside) {
+    ws = (double*)ctx->workspace(8, cnt * 8 * (size_t)count * (extra_blocks + 1));
+    if (!ws) return ctx->fail(KP_ERR_HIP, std::string(who) + ": out of device memory");
+  }
+  if (inside) {
+    *src_out = ctx->Kres + (size_t)slot0 * cnt;
+  } else {
+    for (int i = 0; i < avail; ++i) {
+      const size_t sl = ctx->kres_is_ring ? (size_t)((first + i) % ctx->kring_cap) : (size_t)(first + i);
+      KP_HIP(ctx, hipMemcpyAsync(ws + (size_t)i * cnt, ctx->Kres + sl * cnt, cnt * 8, hipMemcpyDeviceToDevice, s));
+    }
+    if (avail < count) KP_HIP(ctx, hipMemsetAsync(ws + (size_t)avail * cnt, 0, (size_t)(count - avail) * cnt * 8, s));
+    *src_out = ws;
+  }
+  *ws_out = ws;
+  return KP_OK;
+}
+
 extern "C" int kp_comm_allgather_fits(kp_ctx* ctx, int first, int count, int W, double* K_all) {
   if (!ctx || !K_all || first < 0 || count < 1 || W < 1) return ctx ? ctx->fail(KP_ERR_ARG, "kp_comm_allgather_fits: bad argument") : KP_ERR_ARG;
   KP_HIP(ctx, hipSetDevice(ctx->device));
@@ -215,40 +267,10 @@ extern "C" int kp_comm_allgather_fits(kp_ctx* ctx, int first, int count, int W, 
   const size_t cnt = (size_t)W * W;
   const int world = ctx->comm ? ctx->comm->world : 1;
   hipStream_t s = ctx->stream;
-  const bool have = ctx->Kres && W == ctx->Kres_W;          // a rank with an EMPTY shard has no results at all: all padding
-  if (!have && world == 1) return ctx->fail(KP_ERR_ARG, "kp_comm_allgather_fits: no results of that width");
-  // contiguous source of `count` slots: the result buffer itself when the range is inside it (and does not wrap in the
-  // ring), else a staging copy of what there is
   const double* src = nullptr;
-  int avail = 0;                                             // valid fits from `first` on
-  if (have) {
-    if (ctx->kres_is_ring) {
-      if (first + count > ctx->async_count && world == 1) return ctx->fail(KP_ERR_ARG, "kp_comm_allgather_fits: range not in the result ring");   // one rank: nobody else to pad for
-      if (first < ctx->async_count - ctx->kring_cap) return ctx->fail(KP_ERR_ARG, "kp_comm_allgather_fits: range no longer in the result ring");
-      avail = std::max(0, std::min(count, ctx->async_count - first));
-    } else {
-      if (first + count > ctx->Kres_n && world == 1) return ctx->fail(KP_ERR_ARG, "kp_comm_allgather_fits: index out of range");
-      avail = std::max(0, std::min(count, ctx->Kres_n - first));
-    }
-  }
-  const int slot0 = have && ctx->kres_is_ring ? first % ctx->kring_cap : first;
-  const bool wraps = have && ctx->kres_is_ring && slot0 + avail > ctx->kring_cap;
-  const bool inside = have && !wraps && avail == count;
   double* ws = nullptr;
-  if (ctx->comm || !inside) {
-    ws = (double*)ctx->workspace(8, cnt * 8 * (size_t)count * (size_t)(world + 1));
-    if (!ws) return ctx->fail(KP_ERR_HIP, "kp_comm_allgather_fits: out of device memory");
-  }
-  if (inside) {
-    src = ctx->Kres + (size_t)slot0 * cnt;
-  } else {
-    for (int i = 0; i < avail; ++i) {
-      const size_t sl = ctx->kres_is_ring ? (size_t)((first + i) % ctx->kring_cap) : (size_t)(first + i);
-      KP_HIP(ctx, hipMemcpyAsync(ws + (size_t)i * cnt, ctx->Kres + sl * cnt, cnt * 8, hipMemcpyDeviceToDevice, s));
-    }
-    if (avail < count) KP_HIP(ctx, hipMemsetAsync(ws + (size_t)avail * cnt, 0, (size_t)(count - avail) * cnt * 8, s));
-    src = ws;
-  }
+  rc = fits_source(ctx, "kp_comm_allgather_fits", first, count, W, world, ctx->comm ? (size_t)world : 0, &src, &ws);
+  if (rc) return rc;
   if (!ctx->comm) {                               // no communicator: the gather of one (with one, a one-rank ncclAllGather runs)
     KP_HIP(ctx, hipMemcpyAsync(K_all, src, cnt * 8 * (size_t)count, hipMemcpyDeviceToHost, s));
     KP_HIP(ctx, hipStreamSynchronize(s));
@@ -257,6 +279,50 @@ extern "C" int kp_comm_allgather_fits(kp_ctx* ctx, int first, int count, int W, 
   double* all = ws + (size_t)count * cnt;
   KP_NCCL(ctx, rccl().AllGather(src, all, cnt * (size_t)count, ncclDouble, ctx->comm->comm, s));
   KP_HIP(ctx, hipMemcpyAsync(K_all, all, cnt * 8 * (size_t)count * (size_t)world, hipMemcpyDeviceToHost, s));
+  KP_HIP(ctx, hipStreamSynchronize(s));
+  return KP_OK;
+}
+
+// The same stack gathered to ONE rank: every other rank sends its `count` matrices to `root` (ncclSend / ncclRecv in one
+// group - xGMI is point to point, the root's seven links receive in parallel) and returns without a host copy; only the root
+// pays the device-to-host transfer of world x count matrices.  What the caller of train_models needs: the reference's host
+// is one interpreter (Ksysid.m:1370-1387), so one host wants the candidates - an all-gather hands the 58 MB stack of the
+// 64-value grid to all eight ranks and has each of them copy it out.  K_root: world x count matrices on the root, rank-major;
+// ignored (may be NULL) elsewhere.
+extern "C" int kp_comm_gather_fits(kp_ctx* ctx, int root, int first, int count, int W, double* K_root) {
+  if (!ctx || first < 0 || count < 1 || W < 1 || root < 0) return ctx ? ctx->fail(KP_ERR_ARG, "kp_comm_gather_fits: bad argument") : KP_ERR_ARG;
+  const int world = ctx->comm ? ctx->comm->world : 1, rank = ctx->comm ? ctx->comm->rank : 0;
+  if (root >= world || (rank == root && !K_root)) return ctx->fail(KP_ERR_ARG, "kp_comm_gather_fits: bad root / NULL result on the root");
+  if (!ctx->comm) return kp_comm_allgather_fits(ctx, first, count, W, K_root);
+  if (!rccl().p2p) {                              // no point-to-point entry points in this RCCL: the all-gather, result dropped off the root
+    std::vector<double> tmp;
+    double* dst = K_root;
+    if (rank != root) { tmp.resize((size_t)world * count * W * W); dst = tmp.data(); }
+    return kp_comm_allgather_fits(ctx, first, count, W, dst);
+  }
+  KP_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = kp_synchronize(ctx);
+  if (rc) return rc;
+  const size_t cnt = (size_t)W * W, blk = cnt * (size_t)count;
+  hipStream_t s = ctx->stream;
+  const double* src = nullptr;
+  double* ws = nullptr;
+  rc = fits_source(ctx, "kp_comm_gather_fits", first, count, W, world, rank == root ? (size_t)world : 0, &src, &ws);
+  if (rc) return rc;
+  if (rank != root) {
+    KP_NCCL(ctx, rccl().GroupStart());
+    KP_NCCL(ctx, rccl().Send(src, blk, ncclDouble, root, ctx->comm->comm, s));
+    KP_NCCL(ctx, rccl().GroupEnd());
+    KP_HIP(ctx, hipStreamSynchronize(s));
+    return KP_OK;
+  }
+  double* all = ws + blk;
+  KP_HIP(ctx, hipMemcpyAsync(all + (size_t)root * blk, src, blk * 8, hipMemcpyDeviceToDevice, s));
+  KP_NCCL(ctx, rccl().GroupStart());
+  for (int r = 0; r < world; ++r)
+    if (r != root) KP_NCCL(ctx, rccl().Recv(all + (size_t)r * blk, blk, ncclDouble, r, ctx->comm->comm, s));
+  KP_NCCL(ctx, rccl().GroupEnd());
+  KP_HIP(ctx, hipMemcpyAsync(K_root, all, blk * 8 * (size_t)world, hipMemcpyDeviceToHost, s));
   KP_HIP(ctx, hipStreamSynchronize(s));
   return KP_OK;
 }

@@ -76,18 +76,22 @@ def lasso_sweep(fit_one, lassos, comm=None, shape=None, fit_many=None):
     return gather_results(local, len(lassos), comm)
 
 
-def lasso_sweep_device(ctx, fit_device, lassos, W: int, comm=None):
+def lasso_sweep_device(ctx, fit_device, lassos, W: int, comm=None, root=None):
     """Config 4 with the K stack kept in HBM until the one gather: `fit_device(list of lassos)` runs this rank's shard as ONE
     kp_fit call that leaves its results in the device result buffer (device.fit(..., fetch=False)); the stacks of all ranks
     are gathered device to device (comm.all_gather_fits -> kp_comm_allgather_fits) and land in a page-locked block.
-    Returns the K of every value (views into that block, valid until the context's next gather), ordered like `lassos`."""
+    Returns the K of every value (views into that block, valid until the context's next gather), ordered like `lassos`.
+    `root`: the stack goes to that rank only (kp_comm_gather_fits) - the reference's caller of train_models is ONE host
+    (Ksysid.m:1370-1387) - and the other ranks return None."""
     lassos = list(lassos)
     rank, world = (0, 1) if comm is None else (comm.rank, comm.world)
     mine = shard_units(len(lassos), rank, world)
     per = (len(lassos) + world - 1) // world
     if mine:
         fit_device([lassos[i] for i in mine])
-    out = _comm.all_gather_fits(comm, ctx, 0, per, W, have=len(mine))
+    out = _comm.all_gather_fits(comm, ctx, 0, per, W, have=len(mine), root=root)
+    if out is None:
+        return None
     return [out[uid % world, uid // world].T for uid in range(len(lassos))]
 
 

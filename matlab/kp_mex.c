@@ -66,6 +66,7 @@
  *             A = kp_mex('comm_allgather', h, v)           numel(v) x world        v = kp_mex('comm_allreduce_sum', h, v)
  *             K = kp_mex('comm_allgather_fit', h, index, W)             W x W x world
  *             K = kp_mex('comm_allgather_fits', h, first, count, W)     W x W x count x world
+ *             K = kp_mex('comm_gather_fits', h, root, first, count, W)  the same on rank `root` only, [] elsewhere   kp_comm_gather_fits
  * one caller, several GPUs (no Parallel Computing Toolbox, no second process)
  *             g = kp_mex('multi_create', device_ids)       kp_mex('multi_destroy', g)   n = kp_mex('multi_size', g)
  *             K = kp_mex('multi_fit', g, desc, alpha, beta, u, lasso)           W x W x numel(lasso)       kp_multi_fit
@@ -870,6 +871,22 @@ static void c_comm_allgather_fits(ARGS) {
   plhs[0] = mxCreateNumericArray(4, dims, mxDOUBLE_CLASS, mxREAL);
   check(kp_comm_allgather_fits(c, first, count, W, mxGetPr(plhs[0])), c);
 }
+static void c_comm_gather_fits(ARGS) {
+  UNUSED;
+  kp_ctx* c = CTX(1);
+  int rw[2];
+  comm_rw(c, rw);
+  const int root = int_arg(prhs[2], "root"), first = int_arg(prhs[3], "first"), count = int_arg(prhs[4], "count"), W = int_arg(prhs[5], "W");
+  if (count < 1 || W < 1) mexErrMsgIdAndTxt("kp:usage", "comm_gather_fits: count, W");
+  if (rw[0] != root) {                            /* this rank only sends */
+    plhs[0] = mxCreateDoubleMatrix(0, 0, mxREAL);
+    check(kp_comm_gather_fits(c, root, first, count, W, NULL), c);
+    return;
+  }
+  const mwSize dims[4] = {(mwSize)W, (mwSize)W, (mwSize)count, (mwSize)(rw[1] > 0 ? rw[1] : 1)};
+  plhs[0] = mxCreateNumericArray(4, dims, mxDOUBLE_CLASS, mxREAL);
+  check(kp_comm_gather_fits(c, root, first, count, W, mxGetPr(plhs[0])), c);
+}
 
 /* ---- one caller, several GPUs ---------------------------------------------------------------------------------------------------------------------- */
 static kp_multi* multi_handle(const mxArray* a) {
@@ -1037,7 +1054,7 @@ static const kp_command g_commands[] = {
   {"comm_unique_id", 0, 0, 1, c_comm_unique_id}, {"comm_create", 4, 4, 0, c_comm_create}, {"comm_destroy", 1, 1, 0, c_comm_destroy},
   {"comm_abandon", 1, 1, 0, c_comm_abandon}, {"comm_info", 1, 1, 1, c_comm_info}, {"comm_allgather", 2, 2, 1, c_comm_allgather},
   {"comm_allreduce_sum", 2, 2, 1, c_comm_allreduce_sum}, {"comm_allgather_fit", 3, 3, 1, c_comm_allgather_fit},
-  {"comm_allgather_fits", 4, 4, 1, c_comm_allgather_fits},
+  {"comm_allgather_fits", 4, 4, 1, c_comm_allgather_fits}, {"comm_gather_fits", 5, 5, 1, c_comm_gather_fits},
   {"multi_create", 1, 1, 1, c_multi_create}, {"multi_destroy", 1, 1, 0, c_multi_destroy}, {"multi_size", 1, 1, 1, c_multi_size},
   {"multi_timers", 1, 1, 1, c_multi_timers}, {"multi_fit", 6, 6, 1, c_multi_fit}, {"multi_fit_sharded", 6, 6, 1, c_multi_fit_sharded},
   {"multi_traj_upload", 6, 6, 1, c_multi_traj_upload}, {"multi_traj_destroy", 1, 1, 0, c_multi_traj_destroy},

@@ -1,0 +1,153 @@
+"""GPU tests of the one-caller multi-GPU entry points (kp_multi_*, koopman_realizations_amd.multi) through the C ABI.
+
+One GPU per box here, so the device is listed two or three times: two / three contexts, two / three worker threads - the
+fan-out, the ragged shards, the scatter of the results into the caller's stack (pageable and page-locked destinations) and the
+exchange of the snapshot-sharded fit are the code that runs with distinct devices.  Oracle: the single-context path of the
+same library (itself checked against oracle/ in test_gpu_fit.py, test_gpu_lasso.py, test_gpu_sweep.py)."""
+import numpy as np
+import pytest
+
+import koopman_realizations_amd as kra
+from koopman_realizations_amd.multi import Multi, MultiMpc
+from conftest import synth_pairs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cfg3(ctx):
+    """BASELINE configs[3] at its shape: bilinear poly-3 (W = 336), 1e5 pairs, lasso values t/N log-spaced in [1e-2, 1e2]."""
+    p = synth_pairs(100000, seed=0)
+    exps = kra.poly_exponent_table(6, 3)[6:]
+    b = kra.Basis(ctx, "bilinear", 6, 3, [("poly", exps)])
+    s = kra.Snapshots(ctx, p["alpha"], p["beta"], p["u"])
+    return {"p": p, "dic": ("bilinear", 6, 3, [("poly", exps)], None), "b": b, "s": s}
+
+
+@pytest.mark.parametrize("ids", [[0, 0], [0, 0, 0]])
+def test_lasso_grid_dealt_over_workers_equals_the_single_context_grid(ctx, cfg3, ids):
+    """kp_multi_fit: 13 values (ragged over 2 and 3 workers) of the configs[3] grid, every worker lifting the snapshots once
+    and solving its values as one batch; value i lands at position i of the caller's stack - bit for bit what ONE kp_fit
+    call over the same values of a worker's shard gives."""
+    vals = np.geomspace(1e-2, 1e2, 13)
+    p = cfg3["p"]
+    n = len(ids)
+    ref = {}
+    for r in range(n):                                       # the shard of worker r as ONE kp_fit call of the plain context
+        mine = list(range(r, 13, n))
+        for i, K in zip(mine, kra.fit(ctx, cfg3["b"], cfg3["s"], vals[mine])):
+            ref[i] = K
+    mg = Multi(ids)
+    try:
+        Ks = mg.fit(cfg3["dic"], p["alpha"], p["beta"], p["u"], vals)                       # pageable destination: staged
+        assert Ks.shape == (13, 336, 336)
+        for i in range(13):
+            assert np.array_equal(Ks[i].T, ref[i]), i
+        out = mg.host_array("K", (13, 336, 336))                                            # page-locked for every device: direct DMA
+        out[...] = np.nan
+        Kp = mg.fit(cfg3["dic"], p["alpha"], p["beta"], p["u"], vals, out=out)
+        assert Kp is out and np.array_equal(Kp, Ks)
+        tm = mg.timers()
+        assert tm.shape == (n, 4) and (tm[:, 1] > 0).all() and (tm[:, 3] >= tm[:, 1]).all()
+        # a second dictionary on the same object: the workers replace their resident dictionary
+        e2 = kra.poly_exponent_table(6, 2)[6:]
+        b2 = kra.Basis(ctx, "bilinear", 6, 3, [("poly", e2)])
+        K2 = mg.fit(("bilinear", 6, 3, [("poly", e2)], None), p["alpha"], p["beta"], p["u"], [np.inf])
+        assert np.array_equal(K2[0].T, kra.fit(ctx, b2, cfg3["s"])[0])
+        b2.close()
+        # fewer values than workers: the idle workers take no job
+        K1 = mg.fit(cfg3["dic"], p["alpha"], p["beta"], p["u"], [np.inf])
+        assert np.array_equal(K1[0].T, kra.fit(ctx, cfg3["b"], cfg3["s"])[0])
+    finally:
+        mg.close()
+
+
+@pytest.mark.parametrize("ids", [[0], [0, 0], [0, 0, 0]])
+def test_one_fit_sharded_over_snapshots_sums_the_grams_on_worker_zero(ctx, cfg3, ids):
+    """kp_multi_fit_sharded: rows dealt in contiguous ranges (100 000 over 3 is ragged), each worker's fused Gram kernel on its
+    rows, [G | C] by peer copy to worker 0, summed there in worker order, one solve.  Against the whole-matrix fit: equal to
+    rounding (another summation order of the partial Grams), and reproducible run to run bit for bit."""
+    p = cfg3["p"]
+    Kref = kra.fit(ctx, cfg3["b"], cfg3["s"])[0]
+    mg = Multi(ids)
+    try:
+        K1 = mg.fit_sharded(cfg3["dic"], p["alpha"], p["beta"], p["u"])[0].T.copy()
+        K2 = mg.fit_sharded(cfg3["dic"], p["alpha"], p["beta"], p["u"])[0].T.copy()
+        assert np.array_equal(K1, K2)
+        assert np.abs(K1 - Kref).max() <= 1e-11 * np.abs(Kref).max()
+        if len(ids) == 1:
+            assert np.array_equal(K1, Kref)
+        # property that does not need the reference fit: the sum of the shards' Grams is the Gram of the whole (linearity)
+        lo = 0
+        Gsum = 0.0
+        for r in range(len(ids)):
+            hi = 100000 * (r + 1) // len(ids)
+            sr = kra.Snapshots(ctx, p["alpha"][lo:hi], p["beta"][lo:hi], p["u"][lo:hi])
+            Gsum = Gsum + kra.fit_gram(ctx, cfg3["b"], sr)[0]
+            sr.close()
+            lo = hi
+        G = kra.fit_gram(ctx, cfg3["b"], cfg3["s"])[0]
+        assert np.abs(Gsum - G).max() <= 1e-12 * np.abs(G).max()
+    finally:
+        mg.close()
+
+
+def test_sweep_and_batched_mpc_dealt_in_contiguous_chunks(ctx):
+    from koopman_realizations_amd.device import Traj, Mpc
+    from test_mex_gateway import _stacks
+    Y, U, Yv, Uv, k = _stacks(nb=29, seed=3)                       # rows x 1 x nb stacks -> (nb, rows, 1)
+    Yn, Un, Yvn, Uvn = (np.ascontiguousarray(np.transpose(x, (2, 0, 1))) for x in (Y, U, Yv, Uv))
+    tp = Traj(ctx, Yn, Un, k, Yvn, Uvn)
+    mg = Multi([0, 0, 0])
+    try:
+        mt_ = mg.traj_upload(Yn, Un, k, Yvn, Uvn)
+        for mt, D, las in (("linear", 13, np.inf), ("bilinear", 6, np.inf), ("nonlinear", 4, 4.0)):
+            nv = 1 + (mt == "nonlinear")
+            e = kra.poly_exponent_table(nv, D)[nv:]
+            err, st = mt_.sweep_eval_nested((mt, 1, 1, [("poly", e)], None), D, las)
+            b = kra.Basis(ctx, mt, 1, 1, [("poly", e)])
+            err1, st1 = tp.sweep_eval_nested(b, D, las)
+            assert np.array_equal(err, err1, equal_nan=True) and np.array_equal(st, st1)
+            b.close()
+        mt_.close()
+        # MPC
+        p = synth_pairs(4000, 3, 2, seed=21)
+        e = kra.poly_exponent_table(3, 2)[3:]
+        bp = kra.Basis(ctx, "bilinear", 3, 2, [("poly", e)])
+        K = kra.fit(ctx, bp, kra.Snapshots(ctx, p["alpha"], p["beta"], p["u"]))[0]
+        N = bp.N
+        A = np.asfortranarray(K.T[:N, :N]); B = np.asfortranarray(K.T[:N, N:])
+        proj = np.hstack([np.eye(2), np.zeros((2, N - 2))])
+        args = ("bilinear", A, B, 8, proj, 10.0, 100.0, np.array([3e-3, 2e-3]), np.array([-0.9, -0.9]), np.array([0.9, 0.9]), 0.2, None)
+        mm = MultiMpc(mg, *args)
+        m1 = Mpc(ctx, *args)
+        rng = np.random.default_rng(1)
+        nb = 50
+        Z = bp.lift(1, rng.uniform(-0.5, 0.5, (nb, 3)))
+        UP = rng.uniform(-0.3, 0.3, (nb, 2)); YR = rng.uniform(-0.5, 0.5, (nb, 18))
+        Um, sm = mm.step_batch(Z, UP, YR)
+        U1, s1 = m1.step_batch(Z, UP, YR)
+        assert np.array_equal(Um, U1) and np.array_equal(sm, s1) and (sm == 0).all()
+        mm.close(); m1.close()
+    finally:
+        mg.close()
+        tp.close()
+
+
+def test_multi_errors_name_the_device_and_leave_the_object_usable(ctx, cfg3):
+    p = cfg3["p"]
+    with pytest.raises(kra.KoopmanHipError):
+        Multi([0, 97])                                             # no such device
+    mg = Multi([0, 0])
+    try:
+        z = np.zeros((64, 6)); u = np.random.default_rng(0).uniform(-1, 1, (64, 3))
+        K = mg.fit(cfg3["dic"], z, z, u, [np.inf, np.inf])         # singular Gram: a basic solution, like the plain path (no error)
+        assert np.isfinite(K).all()
+        with pytest.raises(kra.KoopmanHipError) as e:
+            mg.fit(("bilinear", 40, 3, [("poly", np.zeros((1, 40), np.uint8))], None), np.zeros((10, 40)), np.zeros((10, 40)), p["u"][:10], [np.inf])
+        assert e.value.code != 0 and "device 0 (worker" in str(e.value)
+        K2 = mg.fit(cfg3["dic"], p["alpha"], p["beta"], p["u"], [np.inf, np.inf])
+        ref = kra.fit(ctx, cfg3["b"], cfg3["s"])[0]
+        assert np.array_equal(K2[0].T, ref) and np.array_equal(K2[1].T, ref)
+    finally:
+        mg.close()

@@ -442,6 +442,8 @@ Kall = ms.kp_mex('comm_allgather_fit', h, 2, W)
 assert Kall.shape == (W, W) and np.abs(Kall - Kref).max() <= 1e-11 * np.abs(Kref).max()
 Kst = ms.kp_mex('comm_allgather_fits', h, 0, 3, W)
 assert Kst.shape == (W, W, 3) and all(np.abs(Kst[:, :, i] - Kref).max() <= 1e-11 * np.abs(Kref).max() for i in range(3))
+Kg = ms.kp_mex('comm_gather_fits', h, 0, 1, 2, W)
+assert Kg.shape == (W, W, 2) and np.array_equal(Kg, Kst[:, :, 1:])
 assert np.abs(ms.kp_mex('fit_sharded', h, b, s, np.inf) - Kref).max() <= 1e-12 * np.abs(Kref).max()     # all-reduce over one rank
 ms.kp_mex('comm_destroy', h, nargout=0)
 ms.kp_mex('comm_abandon', h, nargout=0)
@@ -458,7 +460,7 @@ def test_comm_commands_with_a_one_rank_communicator():
     env = dict(os.environ, NCCL_SOCKET_IFNAME=os.environ.get("NCCL_SOCKET_IFNAME", "lo"), NCCL_IB_DISABLE=os.environ.get("NCCL_IB_DISABLE", "1"))
     r = subprocess.run([sys.executable, "-c", _COMM_SCRIPT, root], capture_output=True, text=True, timeout=400, env=env)
     for c in ("comm_unique_id", "comm_create", "comm_info", "comm_allgather", "comm_allreduce_sum", "comm_allgather_fit", "comm_allgather_fits",
-              "comm_destroy", "comm_abandon"):
+              "comm_gather_fits", "comm_destroy", "comm_abandon"):
         USED.add(c)
     if "RCCL_INIT_TIMEOUT" in r.stdout:
         pytest.skip("ncclCommInitRank of ONE rank does not return on this box")
