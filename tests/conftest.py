@@ -16,7 +16,7 @@ def pytest_configure(config):
 def golden():
     import numpy as np
     d = os.path.join(ROOT, "tests", "golden")
-    return {k: np.load(os.path.join(d, k + ".npz")) for k in ("arm_data", "arm_blockM", "blockM_ref", "rand_systems", "arm_plant")}
+    return {k: np.load(os.path.join(d, k + ".npz")) for k in ("arm_data", "arm_blockM", "blockM_ref", "rand_systems", "arm_plant", "arm_circle")}
 
 
 @pytest.fixture(scope="session")

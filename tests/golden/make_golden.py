@@ -13,6 +13,9 @@ MAT v5 files); no reference source text is read or stored.
                       res_nonlin: Z width (88)  -> pins scale+pairs+monomial order+pca+econ lift
   blockM_ref.npz      trajectories/files/blockM_c0p45-0p35_0p5x0p5_15sec.mat  ref.y (301x2), Ts
   rand_systems.npz    datafiles/rand-systems_2021-01-10_16-59 (1)/rsys-all_*.mat, first 3 systems
+  arm_circle.npz      systems/.../simulations/circle_c0-0p7_r0p3_15sec/bilinear_..._2020-06-09_16-43.mat  res{1..3}: three more closed
+                      loops of the same N = 34 bilinear model under loads (Y, U, R, Z 300x34, W) - stored MATLAB inputs, slope
+                      constant 1e-2; ..._2020-06-21_23-31.mat  res_loaded{1..3}: Z (300x96 = [1; w] (x) psi, N = 32), What, W
   arm_plant.npz       the plant behind the stored closed loops: train{1}.params (numeric fields),
                       res_bilin.{X,U,Y,err} (X(k+1) = Arm.simulate_Ts(X(k), U(k)), Ksim.m:239-245),
                       train{1}.{x,u,y} rows 1..200
@@ -51,6 +54,19 @@ def main():
         bilin_Y=rb.Y, bilin_U=rb.U, bilin_R=rb.R, bilin_Z=rb.Z, bilin_comp_time=rb.comp_time,
         lin_Y=rl.Y, lin_U=rl.U, lin_Z=rl.Z, lin_comp_time=rl.comp_time,
         nonlin_Zwidth=np.array(rn.Z.shape[1]), nonlin_comp_time=rn.comp_time)
+
+    cbase = ('systems/thesis-arm-markers_noload_3-mods_1-links_20hz/simulations/circle_c0-0p7_r0p3_15sec/')
+    rc = load(cbase + 'bilinear_poly-3_n-6_m-3_del-0_2020-06-09_16-43.mat')['res']
+    rl3 = load(cbase + 'bilinear_poly-3_n-6_m-3_del-0_2020-06-21_23-31.mat')['res_loaded']
+    circ = {}
+    for i in range(3):
+        a = rc[0, i][0, 0]
+        for f in ('Y', 'U', 'R', 'Z', 'W', 'err'):
+            circ[f'run{i}_{f}'] = getattr(a, f)
+        b = rl3[0, i][0, 0]
+        for f in ('Z', 'What', 'W', 'Y', 'U'):
+            circ[f'loaded{i}_{f}'] = getattr(b, f)
+    np.savez_compressed(os.path.join(OUT, 'arm_circle.npz'), **circ)
 
     r = load('trajectories/files/blockM_c0p45-0p35_0p5x0p5_15sec.mat')['ref'][0, 0]
     np.savez_compressed(os.path.join(OUT, 'blockM_ref.npz'), y=r.y, Ts=r.Ts, t=r.t)

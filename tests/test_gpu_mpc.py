@@ -441,3 +441,53 @@ def test_stored_matlab_input_sequences_replayed_teacher_forced_on_device(ctx, go
     assert np.median(d) < 1e-6, np.median(d)
     assert d.max() < max_tol, (d.max(), int(d.argmax()))
     assert (d < 1e-5).sum() >= 245
+
+
+def test_stored_circle_runs_replayed_on_device(ctx, golden):
+    """The three stored circle closed loops (tests/test_oracle_golden.py::test_stored_circle_runs_... has the derivation of
+    their settings: input_slopeConst = 1e-2, reference = R(2:end)) through the product path: device fit -> KmpcHip-shaped
+    controller -> one kp_mpc_step_zeta per stored state, 3 x 289 steps.  Stored Z to 1e-11, device optimum = oracle optimum
+    to 1e-7, stored MATLAB inputs with the oracle replay's tolerances."""
+    g = golden["arm_data"]; c = golden["arm_circle"]
+    lens = g["train_len"]; off = np.concatenate([[0], np.cumsum(lens)])
+    train = [{"t": g["train_t"][a:b], "y": g["train_y"][a:b], "u": g["train_u"][a:b]} for a, b in zip(off[:-1], off[1:])]
+    val = [{"t": g["val_t"], "y": g["val_y"], "u": g["val_u"]}]
+    ks = kra.Ksysid({"train": train, "val": val}, ctx=ctx, model_type="bilinear", obs_type=["poly"], obs_degree=[3],
+                    snapshots=np.inf, lasso=[np.inf], delays=0, dim_red=True).train_models()
+    mpc = kra.Kmpc(ks, horizon=10, input_bounds=[], input_slopeConst=1e-2, input_smoothConst=None, state_bounds=[],
+                   cost_running=10, cost_terminal=100, cost_input=0.1 * np.array([3e-2, 2e-2, 1e-2]), projmtx=ks.model["C"][-2:, :])
+    sc = ks.params["scale"]
+    s = ko.MpcSetup(model_type="bilinear", A=ks.model["A"], B=ks.model["B"], m=3, Np=10, projmtx=ks.model["C"][-2:, :], cost_running=10.0,
+                    cost_terminal=100.0, cost_input=0.1 * np.array([3e-2, 2e-2, 1e-2]), input_bounds=None,
+                    slope_lim=1e-2 * sc["u_factor"].mean(), smooth_lim=None, n=6)
+    for i in range(3):
+        Y, U, R, Z = (c[f"run{i}_{k}"] for k in "YURZ")
+        ref_sc = mpc.scaledown_ref(R[1:])
+        d = np.empty(289); dz = 0.0; dor = 0.0
+        for k in range(289):
+            cur = {"y": ks.scaledown_y(Y[k])[None, :], "u": ks.scaledown_u(U[k])[None, :]}
+            Uk, z = mpc.get_mpcInput_bilinear_iter(cur, ref_sc[k:k + 11], 1)
+            assert not np.isnan(Uk).any()
+            d[k] = np.abs(ks.scaleup_u(Uk[1]) - U[k + 1]).max()
+            dz = max(dz, np.abs(z - Z[k]).max())
+            if k % 10 == 0:
+                Uo, _ = ko.mpc_step(s, z, cur["u"][0], ref_sc[k:k + 11])
+                dor = max(dor, np.abs(Uo - Uk).max())
+        assert dz < 1e-11 and dor < 1e-7, (i, dz, dor)
+        assert np.median(d) < 3e-5 and d.max() < 3e-3 and (d < 1e-3).sum() >= 285, (i, np.median(d), d.max(), (d < 1e-3).sum())
+
+
+def test_stored_loaded_lift_rows_through_the_device_kernel(ctx, golden):
+    """res_loaded{1..3}.Z (300 x 96, MATLAB's lift.econ_full_loaded) through the product's loaded lift: a loaded dictionary is the
+    unloaded one declared bilinear with the load as pseudo-input, its row [psi, w_1 psi, w_2 psi].  The model that
+    produced these rows is not shipped, so psi is fed through the identity dictionary [zeta; 1] on zeta = the stored psi(1:31) -
+    the device kernel's Kronecker row layout is then checked against every stored row, exactly."""
+    c = golden["arm_circle"]
+    b = kra.Basis(ctx, "bilinear", 31, 2, [])                       # psi(zeta) = [zeta; 1]: N = 32; pseudo-input = the two loads
+    assert b.N == 32 and b.W == 96
+    for i in range(3):
+        Z = c[f"loaded{i}_Z"]
+        w = np.stack([Z[:, 63], Z[:, 95]], axis=1)
+        rows = b.lift(F.LIFT_ROW, Z[:, :31], w)
+        assert np.abs(rows - Z).max() < 1e-15, i
+    b.close()

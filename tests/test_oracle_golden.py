@@ -248,3 +248,53 @@ def test_stored_matlab_inputs_are_optimal_for_the_restated_qp(arm, golden, mt, k
         obj = lambda v: 0.5 * v @ Hq @ v + f @ v
         worst = max(worst, (obj(x2) - obj(x)) / abs(obj(x)))
     assert solved >= 295 and worst < 5e-8, (solved, worst)
+
+
+def test_stored_circle_runs_under_load_pin_lift_and_inputs_on_867_more_matlab_steps(arm, golden):
+    """Golden vectors: simulations/circle_c0-0p7_r0p3_15sec/bilinear_..._16-43.mat res{1..3} - three more closed loops of the
+    SAME N = 34 bilinear model (the plant carries loads W = -pi/3, 0, +pi/3; the controller does not know them), each with
+    Y, U, R, Z.  (a) The stored lifted states Z (300 x 34 x 3) are reproduced to 2e-14.  (b) Teacher-forced replay of the stored
+    inputs: the largest stored increment is 0.0789 = 0.01 * mean(u_factor) * u_factor(1), i.e. these runs used
+    input_slopeConst = 1e-2 (everything else example_control.m, no input box: run 3 leaves it); the controller's reference
+    window at step k is ref_sc(k : k+Np) (Ksim.m:198-202) and results.R(j) = ref(j-1) (:252 appends ref_sc(k) AFTER the step),
+    so ref = R(2:end) and the windows are complete for the first 289 steps.  Medians 3.7e-6 / 1.6e-5 / 5.7e-8, maxima
+    1.6e-3 - the flat directions of H again (slope rows bind less than in the block-M runs)."""
+    c = golden["arm_circle"]; sc = arm["scale"]
+    dic, s = _stored_run_setup(arm, "bilinear")
+    s = ko.MpcSetup(**{**s.__dict__, "slope_lim": 1e-2 * sc["u_factor"].mean()})
+    med = []
+    for i in range(3):
+        Y, U, R, Z = (c[f"run{i}_{k}"] for k in "YURZ")
+        assert np.abs(ko.econ_full(dic, ko.scaledown(sc, "y", Y[:300])) - Z).max() < 2e-14
+        assert abs(np.abs(np.diff(U, axis=0)).max() - 1e-2 * sc["u_factor"].mean() * sc["u_factor"][0]) < 1e-7     # quadprog interior point: 2e-9 inside the slope row
+        ref = (R[1:] - sc["y_offset"][-2:]) / sc["y_factor"][-2:]                                   # scaledown_ref, Kmpc.m:135-142
+        d = np.empty(289)
+        for k in range(289):
+            Uo, kkt = ko.mpc_step(s, Z[k], ko.scaledown(sc, "u", U[k]), ref[k:k + 11])
+            assert kkt < 1e-8
+            d[k] = np.abs(ko.scaleup(sc, "u", Uo[1]) - U[k + 1]).max()
+        assert np.median(d) < 3e-5 and d.max() < 3e-3 and (d < 1e-3).sum() >= 285, (i, np.median(d), d.max(), (d < 1e-3).sum())
+        med.append(np.median(d))
+    assert min(med) < 1e-6
+
+
+def test_stored_loaded_lift_has_the_kron_layout_of_econ_full_loaded(golden):
+    """Golden vectors: ..._2020-06-21_23-31.mat res_loaded{1..3}.Z (300 x 96), the only artefact of the reference that touches the
+    LOADED path (its model, N = 32, nw = 2, was trained on a data set that is not shipped).  lift.econ_full_loaded(zeta, w) =
+    kron(eye(nw+1), psi) * [1; w] (Ksysid.m:1606-1612), written by Ksim.m:192-194, :256 with w = scaledown.w(What): the stored
+    rows must be [psi, w_1 psi, w_2 psi] with psi ending in the constant 1 - so column 64 IS w_1, column 96 IS w_2, both are one
+    affine map of the stored What (scaledown.w), and the oracle's loaded_lift(psi, w) rebuilds every stored row exactly."""
+    c = golden["arm_circle"]
+    for i in range(3):
+        Z, What = c[f"loaded{i}_Z"], c[f"loaded{i}_What"]
+        psi = Z[:, :32]
+        assert np.array_equal(psi[:, 31], np.ones(300))                                         # the dictionary's constant
+        w = np.stack([Z[:, 63], Z[:, 95]], axis=1)                                              # w_j * (the constant)
+        assert np.abs(ko.loaded_lift(psi, w) - Z).max() < 1e-15
+        # scaledown.w is affine: w = (What - offset) / factor.  Step k appends its estimate to results.What BEFORE it lifts
+        # (Ksim.m:190-194, then :206-216), so row k of Z goes with row k + 1 of What
+        for j in range(2):
+            A = np.stack([What[1:301, j], np.ones(300)], axis=1)
+            if np.ptp(What[1:301, j]) > 1e-9:
+                coef = np.linalg.lstsq(A, w[:, j], rcond=None)[0]
+                assert np.abs(A @ coef - w[:, j]).max() < 1e-12, (i, j)
