@@ -821,8 +821,9 @@ def main():
         if sweep_res is not None and sweep_res.get("_gram"):
             for mt, (ms_, W_, pairs) in sweep_res.pop("_gram").items():
                 dense = (W_ * (W_ + 1) + 2.0 * W_ * W_) * pairs
-                blk = roofline_block("kp_traj_gram_mfma_kernel", 2.0 * 2 * 16 * 16 * pairs, dense, ms_,
-                                     note="W <= 16: one padded 16 x 16 tile per Gram on the matrix pipe (8 v_mfma_f64_4x4x4_4b per 4 pairs); "
+                blk = roofline_block("kp_traj_gram_cols_kernel", 2.0 * 2 * 16 * 16 * pairs, dense, ms_,
+                                     note="W <= 16: one padded 16 x 16 tile per Gram on the matrix pipe (8 v_mfma_f64_4x4x4_4b per 4 pairs, "
+                                          "6 operand reads of 512 B each: the CU's LDS pipe is as busy as its matrix pipes); "
                                           "24 B per pair, so the pass is also priced against HBM")
                 blk.update({"hbm_GBs": 24.0 * pairs / (ms_ * 1e-3) / 1e9, "hbm_frac": 24.0 * pairs / (ms_ * 1e-3) / 1e9 / PEAK_HBM_GBS})
                 kern.append(dict(blk, point=f"rand sweep {mt} pass, W={W_}, {int(pairs)} pairs"))

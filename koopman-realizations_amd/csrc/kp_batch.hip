@@ -1151,6 +1151,200 @@ __global__ __launch_bounds__(256, 2) void kp_traj_gram_mfma_kernel(BasisDev b, c
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 4: the Gram pass of the sweep's own shapes (1 state, 1 input; linear / bilinear / nonlinear polynomial dictionaries in
+// the order of def_polyLift) with the COLUMNS of the rows in the table.  kp_traj_gram_mfma_kernel above ran at 0.37-0.45 of the
+// f64 matrix rate with 1.3-2.1 VALU instructions beside every MFMA (rocprofv3: SQ_INSTS_VALU / SQ_INSTS_VALU_MFMA_MOPS_F64 =
+// 2.3 | 2.4 | 3.1), and on this chip nothing on the VALU overlaps an f64 MFMA of the same SIMD.  Its ISA says where they came
+// from: (1) the prefetch stages rotated through register moves - and the move out of the newest stage made every tile wait
+// for the load issued one tile earlier (`s_waitcnt vmcnt(0)` at the top of the loop: the "4 tiles ahead" were 1); (2) LDS
+// addresses re-formed per tile for the run-time buffer index and column count; (3) selects on the run-time input count;
+// (4) for the nonlinear dictionary, every LANE multiplied two table entries per operand value, 48 v_mul_f64 per tile.
+// Here: the thread that owns a (side, pair) writes the row's W <= 16 column values themselves (Chebyshev recurrence in
+// registers, mixed monomials multiplied ONCE per pair), every MFMA operand is one ds_read with an immediate offset, the tile
+// loop is unrolled over the four prefetch stages (fixed registers, no moves, loads really 4 tiles ahead; 6 KB of code), the
+// buffer index and the dictionary are compile-time.  Left per tile and wave: the D recurrence steps, <= D products, a 5-
+// instruction row index - against 64 MFMAs.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int MT, int D>
+struct TgcShape {
+  static constexpr int NV = MT == KP_MODEL_NONLINEAR ? 2 : 1;
+  static constexpr int N = MT == KP_MODEL_NONLINEAR ? (D + 1) * (D + 2) / 2 : D + 1;        // dictionary functions, constant included
+  static constexpr int W = MT == KP_MODEL_LINEAR ? N + 1 : MT == KP_MODEL_BILINEAR ? 2 * N : N;
+  static constexpr int E = W < 16 ? W + 1 : W;                                                 // + one zero entry for the padding columns
+};
+
+template <int MT, int D>
+__global__ __launch_bounds__(256, 4) void kp_traj_gram_cols_kernel(TrajView tv, int Ns, double* __restrict__ Gout, double* __restrict__ Cout) {
+  using S = TgcShape<MT, D>;
+  constexpr int W = S::W, E = S::E, N = S::N;
+  static_assert(W <= 16, "one 16 x 16 tile");
+  // ONE table buffer [side][entry][TGM_STR] and NO barrier in the tile loop: a wave owns pairs [32 wave, 32 wave + 32) of every
+  // 128-pair tile - its 64 lanes write exactly the 2 x 32 (side, pair) rows its own eight 4-pair steps read, and the LDS
+  // executes one wave's operations in order.  33 KB per workgroup: four workgroups (16 waves) per CU, the whole sweep resident.
+  extern __shared__ __align__(16) double sm[];
+  double* Gs = sm;                                    // the four waves' partial sums, over the table once it is dead
+  const int tid = threadIdx.x, sys = blockIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int side = lane >> 5, p = 32 * wave + (lane & 31);
+  if (E > W)                                          // the zero entry of both sides
+    for (int e = tid; e < 2 * TGM_STR; e += 256) sm[((e / TGM_STR) * E + W) * TGM_STR + e % TGM_STR] = 0.0;
+  // ---- this lane's six operand addresses (doubles, 4-pair step 0): entry = the column itself ----
+  const int li = lane & 3, kq = lane >> 4, blk = (lane >> 2) & 3;
+  int off[6];
+#pragma unroll
+  for (int sl = 0; sl < 6; ++sl) {
+    const int c = sl < 4 ? 4 * sl + li : 4 * blk + li;         // column of Px (slots 0-4) or of Py (slot 5)
+    off[sl] = ((sl == 5 ? E : 0) + (c < W ? c : W)) * TGM_STR + 32 * wave + kq;
+  }
+  double accG[4] = {0.0, 0.0, 0.0, 0.0}, accC[4] = {0.0, 0.0, 0.0, 0.0};
+  // ---- raw values of this thread's (side, pair), four tiles ahead in FIXED registers (the loop below is unrolled over them) ----
+  const int Tm1 = tv.T - 1;
+  const double* py = tv.Y + (size_t)sys * tv.rows + side;      // side 1 lifts the successor row (Py)
+  const double* pu = tv.U + (size_t)sys * tv.rows;
+  // pair -> row = pair + pair / (T - 1), advanced tile by tile without a division: (trial, offset in trial)
+  int tr = p / Tm1, rem = p - tr * Tm1, pair = p;
+  const int q128 = TG_TS / Tm1, r128 = TG_TS - q128 * Tm1;
+  double ry[TGM_PD], ru[TGM_PD], okq[TGM_PD];
+  auto load_next = [&](double& y, double& u, double& ok) __attribute__((always_inline)) {
+    const bool in = pair < Ns;
+    const int row = in ? pair + tr : 0;
+    y = py[row];
+    u = pu[row];
+    ok = in ? 1.0 : 0.0;
+    pair += TG_TS;
+    tr += q128;
+    rem += r128;
+    if (rem >= Tm1) { rem -= Tm1; ++tr; }
+  };
+#pragma unroll
+  for (int st = 0; st < TGM_PD; ++st) load_next(ry[st], ru[st], okq[st]);
+  __syncthreads();                                     // (the zero entries)
+  double* const my = sm + side * E * TGM_STR + p;
+  auto tile = [&](auto st_c) __attribute__((always_inline)) {
+    constexpr int ST = decltype(st_c)::value;
+    // ---- the row of this (side, pair): Chebyshev internal basis, T_e(x_v) where the monomial has x_v^e; every entry carries
+    // the mask (0 for pairs past Ns), so that every product does ----
+    {
+      const double okf = okq[ST], x = ry[ST], uu = ru[ST] * okf, x2 = x + x;
+      double ty[D];
+      {
+        double q = x * okf, qm = okf;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+          ty[k] = q;
+          const double qn = x2 * q - qm;
+          qm = q;
+          q = qn;
+        }
+      }
+      if constexpr (MT == KP_MODEL_LINEAR) {            // [T_1 .. T_D, 1, u]
+#pragma unroll
+        for (int k = 0; k < D; ++k) my[k * TGM_STR] = ty[k];
+        my[D * TGM_STR] = okf;
+        my[(D + 1) * TGM_STR] = uu;
+      } else if constexpr (MT == KP_MODEL_BILINEAR) {   // [psi, u psi], psi = [T_1 .. T_D, 1]
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+          my[k * TGM_STR] = ty[k];
+          my[(N + k) * TGM_STR] = ty[k] * uu;
+        }
+        my[D * TGM_STR] = okf;
+        my[(N + D) * TGM_STR] = uu;
+      } else {                                          // monomials of [y; u] by total degree, exponent of u ascending inside a degree
+        double tu[D];
+        {
+          const double xu = ru[ST], xu2 = xu + xu;
+          double q = xu * okf, qm = okf;
+#pragma unroll
+          for (int k = 0; k < D; ++k) {
+            tu[k] = q;
+            const double qn = xu2 * q - qm;
+            qm = q;
+            q = qn;
+          }
+        }
+        int c = 0;
+#pragma unroll
+        for (int d = 1; d <= D; ++d)
+#pragma unroll
+          for (int e2 = 0; e2 <= d; ++e2) {
+            const int e1 = d - e2;
+            my[c * TGM_STR] = e2 == 0 ? ty[e1 - 1] : e1 == 0 ? tu[e2 - 1] : ty[e1 - 1] * tu[e2 - 1];
+            ++c;
+          }
+        my[c * TGM_STR] = okf;
+      }
+    }
+    load_next(ry[ST], ru[ST], okq[ST]);                  // this stage's registers are free again: the tile four ahead
+    // ---- this wave's eight 4-pair steps (its own 32 pairs): 6 reads, 8 MFMAs each.  No barrier: the rows were written by
+    // this wave, and a wave's LDS operations complete in order ----
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      double v6[6];
+#pragma unroll
+      for (int sl = 0; sl < 6; ++sl) v6[sl] = sm[off[sl] + j * 4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        accG[g] = __builtin_amdgcn_mfma_f64_4x4x4f64(v6[g], v6[4], accG[g], 0, 0, 0);
+        accC[g] = __builtin_amdgcn_mfma_f64_4x4x4f64(v6[g], v6[5], accC[g], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the reads above precede the next tile's writes of the same rows
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  const int ntiles = (Ns + TG_TS - 1) / TG_TS;
+  for (int t = 0; t < ntiles; t += TGM_PD) {             // tiles past Ns inside the last group of four are all mask: they add zeros
+    tile(std::integral_constant<int, 0>{});
+    tile(std::integral_constant<int, 1>{});
+    tile(std::integral_constant<int, 2>{});
+    tile(std::integral_constant<int, 3>{});
+  }
+  // ---- the four waves' partial sums, added in a fixed order; D layout: row 4 g + (lane >> 4), column 4 blk + (lane & 3) ----
+  __syncthreads();
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    Gs[((wave * 2 + 0) * 16 + 4 * g + kq) * 16 + 4 * blk + li] = accG[g];
+    Gs[((wave * 2 + 1) * 16 + 4 * g + kq) * 16 + 4 * blk + li] = accC[g];
+  }
+  __syncthreads();
+  const int gi = tid >> 4, gj = tid & 15;
+  if (gi < W && gj < W) {
+    double sg = 0.0, sc = 0.0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      sg += Gs[((w * 2 + 0) * 16 + gi) * 16 + gj];
+      sc += Gs[((w * 2 + 1) * 16 + gi) * 16 + gj];
+    }
+    Gout[(size_t)sys * W * W + (size_t)gj * W + gi] = sg;
+    Cout[(size_t)sys * W * W + (size_t)gj * W + gi] = sc;
+  }
+}
+
+// the recipes def_polyLift gives a degree-D dictionary over nv <= 2 variables (what kp_traj_gram_cols_kernel hard-codes)
+static bool tgc_canonical(const kp_basis* basis, int nv, int D) {
+  if (!basis->fast || (int)basis->h_recipes.size() != basis->dev.nfull || basis->pow_depth != D) return false;
+  std::vector<uint32_t> want;
+  for (int d = 1; d <= D; ++d)
+    for (int e2 = 0; e2 <= (nv == 2 ? d : 0); ++e2) {
+      const int e1 = d - e2;
+      uint32_t r = 0xffffffffu;
+      int nf = 0;
+      auto push = [&](int v, int e) { r = (r & ~(0xffu << (8 * nf))) | ((uint32_t)(v * D + e - 1) << (8 * nf)); ++nf; };
+      if (e1 > 0) push(0, e1);
+      if (e2 > 0) push(1, e2);
+      want.push_back(r);
+    }
+  want.push_back(0xffffffffu);                         // the constant
+  if (want.size() != basis->h_recipes.size()) return false;
+  for (size_t i = 0; i < want.size(); ++i)
+    if (want[i] != basis->h_recipes[i]) return false;
+  return true;
+}
+
 // =====================================================================================================================
 // All degrees of one model type from ONE pass over the data (evaluate_rand_models.m loops degree by degree, :47-143).
 //  * The degree-j polynomial dictionary is a column subset of the degree-D one: def_polyLift orders the monomials by
@@ -1630,7 +1824,26 @@ extern "C" int kp_sweep_eval_nested(kp_ctx* ctx, const kp_traj* traj, const kp_b
   const bool use_mfma = !gram_old && nfac <= 5 && nv <= TGM_NV && lds_m <= 78 * 1024;      // two workgroups per CU
   if (!use_mfma && lds > 150 * 1024) return ctx->fail(KP_ERR_ARG, "kp_sweep_eval_nested: dictionary too large for the power-table lift");
   KP_HIP(ctx, hipMemsetAsync(dS0, 0, (size_t)nb * 4, s));
-  if (use_mfma) {
+  // round 4: the sweep's own shapes (1 state, 1 input, canonical polynomial dictionary) with the row's columns in the table
+  static const bool cols_off = getenv("KP_SWEEP_GRAM_V1") != nullptr;
+  bool use_cols = false;
+  if (!cols_off && !gram_old && n == 1 && m == 1 && b.nzeta == 1 && b.k_pcs == 0 && tgc_canonical(basis, nv, Dp)) {
+#define KP_TGC(MT_, D_)                                                                                                           \
+    {                                                                                                                             \
+      static KpLdsCache tgc_lds;                                                                                                  \
+      const size_t lds_c = std::max((size_t)2 * TgcShape<MT_, D_>::E * TGM_STR * sizeof(double), (size_t)4 * 2 * 256 * sizeof(double)); \
+      KP_HIP(ctx, kp_ensure_lds(tgc_lds, (const void*)kp_traj_gram_cols_kernel<MT_, D_>, lds_c));                                 \
+      KP_HIP(ctx, hipEventRecord(ctx->ev0, s));                                                                                   \
+      hipLaunchKernelGGL((kp_traj_gram_cols_kernel<MT_, D_>), dim3(nb), dim3(256), lds_c, s, traj_view(traj), Ns, dGc, dCc);      \
+      use_cols = true;                                                                                                            \
+    }
+    if (b.model_type == KP_MODEL_LINEAR && Dp == 13) KP_TGC(KP_MODEL_LINEAR, 13)
+    else if (b.model_type == KP_MODEL_BILINEAR && Dp == 6) KP_TGC(KP_MODEL_BILINEAR, 6)
+    else if (b.model_type == KP_MODEL_NONLINEAR && Dp == 4) KP_TGC(KP_MODEL_NONLINEAR, 4)
+#undef KP_TGC
+  }
+  if (use_cols) {
+  } else if (use_mfma) {
 #define KP_TGM(F_, DC_, NV_, UP_)                                                                                               \
     {                                                                                                                             \
       static KpLdsCache tgm_lds;                                                                                                  \
