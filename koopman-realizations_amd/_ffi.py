@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkoopman_hip.so")
+LIB_PATH = os.environ.get("KP_LIB_PATH") or os.path.join(_HERE, "libkoopman_hip.so")     # KP_LIB_PATH: an experimental build (tools/)
 
 KP_OK, KP_ERR_ARG, KP_ERR_HIP, KP_ERR_NOT_SPD, KP_ERR_QP_FAIL, KP_ERR_NOT_CONVERGED = 0, -1, -2, -3, -4, -5
 MODEL = {"linear": 0, "bilinear": 1, "nonlinear": 2}

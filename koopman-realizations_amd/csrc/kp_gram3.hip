@@ -64,27 +64,7 @@
 #define GNZMAX3 8                   // state variables of a gaussian dictionary
 #define LDS3_GAUSS_DOUBLES (GAUSSMAX3 * GNZMAX3)
 
-struct Gram3Args {
-  BasisDev b;
-  const double* alpha;   // allocated with >= 64 doubles of zero padding (kp_snapshots_upload): prefetch never leaves the buffer
-  const double* beta;
-  const double* u;
-  int64_t Ns;
-  int G4;               // 4-column groups per side
-  int nsuper;           // workgroups per snapshot split
-  int ktiles_per_split;
-  int D;
-  const uint32_t* recipes;   // [nfull]
-  const uint32_t* desc;      // [njobs][1 + NQ]: a0 | a1 << 8 | qs << 16 (quads < qs use A group a0, the rest a1),
-                             // then per quad 4 packed B group ids (8 bit each)
-  double* part;              // [nsplit][njobs][NQ][NWT][64]
-  int njobs;
-  const double* pcs;         // nfull x k_pcs (column-major) or nullptr: econ lift [zeta | pcs' psi_full | 1] (Ksysid.m:1594-1618)
-  int nfull4;                // nfull rounded up to a multiple of 4
-  // EXT: table entries per variable = Dp powers, then df (cos, sin) pairs (D = Dp + 2 df); ng gaussian centres (nzeta each)
-  int Dp, df, ng;
-  const double* centres;
-};
+#include "kp_gram3_args.h"
 
 // PCS: econ lift through a projection matrix (dim_red dictionaries)
 // EXT: fourier (def_fourierLift, Ksysid.m:694-731) and gaussian (def_gaussianLift, :790-817) blocks through the same table
@@ -531,6 +511,7 @@ __global__ __launch_bounds__(256) void kp_gram3_reduce_kernel(const double* __re
 
 struct kp_gram3_plan {
   int G4 = 0, nq = 0, njobs = 0, nsuper = 0;
+  int wpw = 4;               // waves (jobs) per workgroup: 4 (kp_gram3_kernel) or 8 (kp_gram6_kernel, one workgroup per CU)
   uint32_t* desc = nullptr;  // device
 };
 
@@ -544,8 +525,9 @@ void kp_gram3_plan_free(kp_gram3_plan* p) {
 // (g, g+1, ..., g+floor(G4/2) mod G4; antipodal pairs once) and all G4 groups of psi_y.
 // All quads (A group, 4 B groups) of all rows form one list; a job (one wave) is nq CONSECUTIVE quads,
 // so it spans at most two A groups when nq <= quads per row, and whole workgroups (4 jobs) fill evenly.
-static int make_plan3(kp_ctx* ctx, int N, int nwt, int nq_cap, kp_gram3_plan** out) {
+static int make_plan3(kp_ctx* ctx, int N, int nwt, int nq_cap, kp_gram3_plan** out, int wpw = 4, int nq_force = 0) {
   kp_gram3_plan* p = new kp_gram3_plan();
+  p->wpw = wpw;
   const int G4 = (N + 3) / 4;
   p->G4 = G4;
   const int ZG = 2 * G4;
@@ -582,7 +564,8 @@ static int make_plan3(kp_ctx* ctx, int N, int nwt, int nq_cap, kp_gram3_plan** o
     double cost = (double)waves * (c * nwt * 33.0 + 400.0);
     if (cost < best) { best = cost; nq = c; }
   }
-  if (const char* ov = getenv("KP_GRAM3_NQ")) {   // tuning override
+  if (nq_force > 0) nq = nq_force;
+  else if (const char* ov = getenv("KP_GRAM3_NQ")) {   // tuning override
     int v = atoi(ov);
     if (v >= 1 && v <= std::min(NQMAX, nq_cap) && (size_t)v <= maxq) nq = v;
   }
@@ -590,7 +573,7 @@ static int make_plan3(kp_ctx* ctx, int N, int nwt, int nq_cap, kp_gram3_plan** o
   std::vector<uint32_t> desc;
   int njobs = 0;
   const uint32_t zq = (uint32_t)ZG * 0x01010101u;
-  for (int q0 = 0; q0 < TQ || njobs % 4; q0 += nq) {
+  for (int q0 = 0; q0 < TQ || njobs % wpw; q0 += nq) {
     int a0 = q0 < TQ ? quads[q0].first : 0, a1 = a0, qs = nq;
     for (int q = 0; q < nq; ++q)
       if (q0 + q < TQ && quads[q0 + q].first != a0) { a1 = quads[q0 + q].first; qs = q; break; }
@@ -599,7 +582,7 @@ static int make_plan3(kp_ctx* ctx, int N, int nwt, int nq_cap, kp_gram3_plan** o
     ++njobs;
   }
   p->njobs = njobs;
-  p->nsuper = njobs / 4;
+  p->nsuper = njobs / wpw;
   hipError_t e = hipMalloc((void**)&p->desc, desc.size() * 4);
   if (e == hipSuccess) e = hipMemcpy(p->desc, desc.data(), desc.size() * 4, hipMemcpyHostToDevice);
   if (e != hipSuccess) {
@@ -679,7 +662,11 @@ int kp_gram3_launch(kp_ctx* ctx, const kp_basis* basis_c, const kp_snapshots* s,
     // fourier / gaussian tables: the transcendental code's constants and temporaries cost ~40 registers, so fewer quads
     // (accumulators) per wave or the kernel spills (measured: 4 quads per wave is the fastest cap, tools/gram_shapes_probe.py)
     static const int ext_cap = [] { const char* e = getenv("KP_GRAM3_EXT_NQ"); return e ? atoi(e) : 4; }();
-    int rc = make_plan3(ctx, N, NWT, b.k_pcs > 0 ? 4 : gram3_ext(basis) ? ext_cap : 6, &basis->plan3);
+    // round 4 experiment (KP_GRAM6=1): eight-wave workgroups, the weighted A operands in LDS (kp_gram6.hip)
+    static const bool g6_on = getenv("KP_GRAM6") != nullptr;
+    const bool g6 = g6_on && BM == 3 && b.k_pcs == 0 && !gram3_ext(basis) && kp_gram6_serves(7, (N + 3) / 4);
+    int rc = g6 ? make_plan3(ctx, N, NWT, 7, &basis->plan3, 8, 7)
+                : make_plan3(ctx, N, NWT, b.k_pcs > 0 ? 4 : gram3_ext(basis) ? ext_cap : 6, &basis->plan3);
     if (rc) return rc;
   }
   kp_gram3_plan& plan = *basis->plan3;
@@ -688,7 +675,7 @@ int kp_gram3_launch(kp_ctx* ctx, const kp_basis* basis_c, const kp_snapshots* s,
   const size_t lds = (size_t)(LDS3_DOUBLES + (b.k_pcs > 0 ? 2 * nfull4 * 16 : 0) + (ext ? LDS3_GAUSS_DOUBLES : 0)) * sizeof(double);
   int64_t ktiles = (s->Ns + KT3 - 1) / KT3;
   int ncu = ctx->num_cu > 0 ? ctx->num_cu : 256;
-  int wg_per_cu = 2;                                  // __launch_bounds__(256, 2): two workgroups share a CU
+  int wg_per_cu = plan.wpw == 8 ? 1 : 2;              // __launch_bounds__(256, 2): two workgroups share a CU (kp_gram6: one of eight waves)
   if (const char* ov = getenv("KP_GRAM3_WGPCU")) wg_per_cu = std::max(1, atoi(ov));
   int64_t slots = (int64_t)std::max(8, ncu - ctx->reserve_cus) * wg_per_cu;
   int nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(ktiles, slots / plan.nsuper > 0 ? slots / plan.nsuper : 1));
@@ -742,7 +729,8 @@ int kp_gram3_launch(kp_ctx* ctx, const kp_basis* basis_c, const kp_snapshots* s,
   }
   if (timed) KP_HIP(ctx, hipEventRecord(ev_start, ctx->stream));
   hipError_t e;
-  switch (plan.nq) {
+  if (plan.wpw == 8) e = kp_gram6_launch_kernel(a, plan.nq, grid, ctx->stream);
+  else switch (plan.nq) {
     case 1: e = launch3<1>(a, BM, grid, lds, ctx->stream); break;
     case 2: e = launch3<2>(a, BM, grid, lds, ctx->stream); break;
     case 3: e = launch3<3>(a, BM, grid, lds, ctx->stream); break;

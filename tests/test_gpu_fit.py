@@ -451,6 +451,42 @@ def test_a_lone_queued_fit_lands_in_its_own_ring_slot(n_fits, n_slots, env):
     assert r.returncode == 0 and "LONE_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
 
 
+_GRAM6_SCRIPT = r"""
+import sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import numpy as np
+import koopman_realizations_amd as kra
+from conftest import synth_pairs
+from oracle import koopman_oracle as ko
+ctx = kra.Context(0)
+for Ns in (20001, 37):
+    p = synth_pairs(Ns, seed=3)
+    dic = ko.build_dictionary("bilinear", 6, 3, ["poly"], [3])
+    b = kra.Basis(ctx, "bilinear", 6, 3, [("poly", dic.basis.blocks[0][1][6:].astype(np.uint8))])
+    s = kra.Snapshots(ctx, p["alpha"], p["beta"], p["u"])
+    G, C = kra.fit_gram(ctx, b, s)
+    Px, Py = ko.px_py(dic, p)
+    assert np.abs(G - Px.T @ Px).max() <= 1e-12 * np.abs(G).max() and np.array_equal(G, G.T)
+    assert np.abs(C - Px.T @ Py).max() <= 1e-12 * np.abs(G).max()
+    G2, C2 = kra.fit_gram(ctx, b, s)
+    assert np.array_equal(G, G2) and np.array_equal(C, C2)          # fixed summation order: bitwise reproducible
+print("GRAM6_OK")
+"""
+
+
+def test_eight_wave_kronecker_kernel_experiment_is_exact():
+    """KP_GRAM6=1 selects kp_gram6_kernel (kp_gram6.hip: one 8-wave workgroup per CU, the ten weighted copies of psi_x written
+    to LDS by the lift, no multiply in the MFMA loop) for the W = 336 dictionary.  It is an opt-in experiment - the compiler
+    spills 87 registers of its 7-quad waves and it runs 3.7 x slower than kp_gram3_kernel - but it is exact: G, C
+    against the oracle to 1e-12, symmetric, reproducible, with a ragged tail and with fewer pairs than one tile row."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _GRAM6_SCRIPT, root], capture_output=True, text=True, timeout=300, env=dict(os.environ, KP_GRAM6="1"))
+    assert r.returncode == 0 and "GRAM6_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
 @pytest.mark.parametrize("mt,deg,steps,tol", [("bilinear", 2, 1, 1e-10), ("linear", 2, 1, 1e-10), ("bilinear", 3, 1, 1e-12), ("nonlinear", 2, 2, 1e-10)])
 def test_fit_refine_reaches_qr_accuracy(ctx, arm, mt, deg, steps, tol):
     """kp_fit_refine: K += G^-1 Px'(Py - Px K) with the residual taken from the lifted rows.  On the arm data with
