@@ -819,12 +819,12 @@ def main():
                                             note="first (widest) product G [K_1 .. K_nv] of the lasso grid's FISTA iteration"),
                              point=f"lasso product {W}x{W}x{int(g_cols)}"))
         if sweep_res is not None and sweep_res.get("_gram"):
-            for mt, (ms_, W_, pairs) in sweep_res.pop("_gram").items():
+            for mt, (ms_, W_, pairs, ex_) in sweep_res.pop("_gram").items():
                 dense = (W_ * (W_ + 1) + 2.0 * W_ * W_) * pairs
-                blk = roofline_block("kp_traj_gram_cols_kernel", 2.0 * 2 * 16 * 16 * pairs, dense, ms_,
-                                     note="W <= 16: one padded 16 x 16 tile per Gram on the matrix pipe (8 v_mfma_f64_4x4x4_4b per 4 pairs, "
-                                          "6 operand reads of 512 B each: the CU's LDS pipe is as busy as its matrix pipes); "
-                                          "24 B per pair, so the pass is also priced against HBM")
+                blk = roofline_block("kp_traj_gram_cols_kernel", (ex_ if ex_ > 0 else 1024.0) * pairs, dense, ms_,
+                                     note="W <= 16: the upper triangle of G (10 blocks of 4 x 4) and C (16 blocks) on the matrix pipe, one "
+                                          "v_mfma_f64_4x4x4_4b per block and 16 pairs (its four blocks take four pair groups), 8 operand reads "
+                                          "per 26 MFMAs; 24 B per pair, so the pass is also priced against HBM")
                 blk.update({"hbm_GBs": 24.0 * pairs / (ms_ * 1e-3) / 1e9, "hbm_frac": 24.0 * pairs / (ms_ * 1e-3) / 1e9 / PEAK_HBM_GBS})
                 kern.append(dict(blk, point=f"rand sweep {mt} pass, W={W_}, {int(pairs)} pairs"))
         if lasso_res is not None:

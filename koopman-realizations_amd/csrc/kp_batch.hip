@@ -1188,15 +1188,22 @@ __global__ __launch_bounds__(256, 4) void kp_traj_gram_cols_kernel(TrajView tv, 
   const int side = lane >> 5, p = 32 * wave + (lane & 31);
   if (E > W)                                          // the zero entry of both sides
     for (int e = tid; e < 2 * TGM_STR; e += 256) sm[((e / TGM_STR) * E + W) * TGM_STR + e % TGM_STR] = 0.0;
-  // ---- this lane's six operand addresses (doubles, 4-pair step 0): entry = the column itself ----
+  // ---- MFMA operands.  The four blocks of v_mfma_f64_4x4x4_4b take four different PAIR groups (block = pairs 4 blk .. 4 blk + 3
+  // of a 16-pair step), not four column groups: one instruction then adds 16 pairs to ONE 4 x 4 output block (g, h), its four
+  // blocks being partial sums that meet in the epilogue.  The A fragment of column group g and the B fragment of the same group
+  // are the same register (lane (blk, k, i): psi[pair 4 blk + k][column 4 g + i]), so a 16-pair step reads the four groups of
+  // psi_x and of psi_y ONCE - 8 ds_read_b64 for 26 MFMAs (10 for the upper triangle of G = Px'Px, 16 for C = Px'Py) where the
+  // column-group form read 24 values for 32 MFMAs and kept the CU's LDS pipe as busy as its matrix pipes ----
   const int li = lane & 3, kq = lane >> 4, blk = (lane >> 2) & 3;
-  int off[6];
+  // column groups 0-2 are always inside the row (W >= 12): base + immediate; group 3 may run into the padding (zero entry)
+  const int offa = li * TGM_STR + 32 * wave + 4 * blk + kq;
+  const int off3 = ((12 + li) < W ? 12 + li : W) * TGM_STR + 32 * wave + 4 * blk + kq;
+  static_assert(W >= 12, "column groups 0-2 full");
+  double accG[10], accC[16];
 #pragma unroll
-  for (int sl = 0; sl < 6; ++sl) {
-    const int c = sl < 4 ? 4 * sl + li : 4 * blk + li;         // column of Px (slots 0-4) or of Py (slot 5)
-    off[sl] = ((sl == 5 ? E : 0) + (c < W ? c : W)) * TGM_STR + 32 * wave + kq;
-  }
-  double accG[4] = {0.0, 0.0, 0.0, 0.0}, accC[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int k = 0; k < 10; ++k) accG[k] = 0.0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) accC[k] = 0.0;
   // ---- raw values of this thread's (side, pair), four tiles ahead in FIXED registers (the loop below is unrolled over them) ----
   const int Tm1 = tv.T - 1;
   const double* py = tv.Y + (size_t)sys * tv.rows + side;      // side 1 lifts the successor row (Py)
@@ -1204,20 +1211,20 @@ __global__ __launch_bounds__(256, 4) void kp_traj_gram_cols_kernel(TrajView tv, 
   // pair -> row = pair + pair / (T - 1), advanced tile by tile without a division: (trial, offset in trial)
   int tr = p / Tm1, rem = p - tr * Tm1, pair = p;
   const int q128 = TG_TS / Tm1, r128 = TG_TS - q128 * Tm1;
-  double ry[TGM_PD], ru[TGM_PD], okq[TGM_PD];
-  auto load_next = [&](double& y, double& u, double& ok) __attribute__((always_inline)) {
+  constexpr int PD = 4;                                // tiles of raw values in flight (fixed registers; the mask is re-derived from the pair index)
+  double ry[PD], ru[PD];
+  auto load_next = [&](double& y, double& u) __attribute__((always_inline)) {
     const bool in = pair < Ns;
     const int row = in ? pair + tr : 0;
     y = py[row];
     u = pu[row];
-    ok = in ? 1.0 : 0.0;
     pair += TG_TS;
     tr += q128;
     rem += r128;
     if (rem >= Tm1) { rem -= Tm1; ++tr; }
   };
 #pragma unroll
-  for (int st = 0; st < TGM_PD; ++st) load_next(ry[st], ru[st], okq[st]);
+  for (int st = 0; st < PD; ++st) load_next(ry[st], ru[st]);
   __syncthreads();                                     // (the zero entries)
   double* const my = sm + side * E * TGM_STR + p;
   auto tile = [&](auto st_c) __attribute__((always_inline)) {
@@ -1225,33 +1232,43 @@ __global__ __launch_bounds__(256, 4) void kp_traj_gram_cols_kernel(TrajView tv, 
     // ---- the row of this (side, pair): Chebyshev internal basis, T_e(x_v) where the monomial has x_v^e; every entry carries
     // the mask (0 for pairs past Ns), so that every product does ----
     {
-      const double okf = okq[ST], x = ry[ST], uu = ru[ST] * okf, x2 = x + x;
-      double ty[D];
-      {
+      const double okf = (pair - PD * TG_TS) < Ns ? 1.0 : 0.0;      // `pair` runs PD tiles ahead of the tile being lifted
+      const double x = ry[ST], uu = ru[ST] * okf, x2 = x + x;
+      if constexpr (MT == KP_MODEL_LINEAR) {            // [T_1 .. T_D, 1, u]: written as the recurrence produces them
         double q = x * okf, qm = okf;
 #pragma unroll
         for (int k = 0; k < D; ++k) {
-          ty[k] = q;
+          my[k * TGM_STR] = q;
           const double qn = x2 * q - qm;
           qm = q;
           q = qn;
         }
-      }
-      if constexpr (MT == KP_MODEL_LINEAR) {            // [T_1 .. T_D, 1, u]
-#pragma unroll
-        for (int k = 0; k < D; ++k) my[k * TGM_STR] = ty[k];
         my[D * TGM_STR] = okf;
         my[(D + 1) * TGM_STR] = uu;
       } else if constexpr (MT == KP_MODEL_BILINEAR) {   // [psi, u psi], psi = [T_1 .. T_D, 1]
+        double q = x * okf, qm = okf;
 #pragma unroll
         for (int k = 0; k < D; ++k) {
-          my[k * TGM_STR] = ty[k];
-          my[(N + k) * TGM_STR] = ty[k] * uu;
+          my[k * TGM_STR] = q;
+          my[(N + k) * TGM_STR] = q * uu;
+          const double qn = x2 * q - qm;
+          qm = q;
+          q = qn;
         }
         my[D * TGM_STR] = okf;
         my[(N + D) * TGM_STR] = uu;
       } else {                                          // monomials of [y; u] by total degree, exponent of u ascending inside a degree
-        double tu[D];
+        double ty[D], tu[D];
+        {
+          double q = x * okf, qm = okf;
+#pragma unroll
+          for (int k = 0; k < D; ++k) {
+            ty[k] = q;
+            const double qn = x2 * q - qm;
+            qm = q;
+            q = qn;
+          }
+        }
         {
           const double xu = ru[ST], xu2 = xu + xu;
           double q = xu * okf, qm = okf;
@@ -1275,49 +1292,75 @@ __global__ __launch_bounds__(256, 4) void kp_traj_gram_cols_kernel(TrajView tv, 
         my[c * TGM_STR] = okf;
       }
     }
-    load_next(ry[ST], ru[ST], okq[ST]);                  // this stage's registers are free again: the tile four ahead
+    load_next(ry[ST], ru[ST]);                           // this stage's registers are free again: the tile PD ahead
     // ---- this wave's eight 4-pair steps (its own 32 pairs): 6 reads, 8 MFMAs each.  No barrier: the rows were written by
     // this wave, and a wave's LDS operations complete in order ----
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      double v6[6];
+    for (int jj = 0; jj < 2; ++jj) {                        // this wave's 32 pairs: two 16-pair steps
+      double v[8];
 #pragma unroll
-      for (int sl = 0; sl < 6; ++sl) v6[sl] = sm[off[sl] + j * 4];
+      for (int sl = 0; sl < 8; ++sl)
+        v[sl] = sm[((sl & 3) < 3 ? offa + 4 * (sl & 3) * TGM_STR : off3) + (sl >= 4 ? E * TGM_STR : 0) + jj * 16];
+      int k = 0;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        accG[g] = __builtin_amdgcn_mfma_f64_4x4x4f64(v6[g], v6[4], accG[g], 0, 0, 0);
-        accC[g] = __builtin_amdgcn_mfma_f64_4x4x4f64(v6[g], v6[5], accC[g], 0, 0, 0);
-      }
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int h = g; h < 4; ++h) {
+          accG[k] = __builtin_amdgcn_mfma_f64_4x4x4f64(v[g], v[h], accG[k], 0, 0, 0);
+          ++k;
+        }
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int h = 0; h < 4; ++h) accC[4 * g + h] = __builtin_amdgcn_mfma_f64_4x4x4f64(v[g], v[4 + h], accC[4 * g + h], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);                 // one 16-pair step's operands in registers at a time (128 VGPRs: 4 workgroups per CU)
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the reads above precede the next tile's writes of the same rows
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   };
   const int ntiles = (Ns + TG_TS - 1) / TG_TS;
-  for (int t = 0; t < ntiles; t += TGM_PD) {             // tiles past Ns inside the last group of four are all mask: they add zeros
+  for (int t = 0; t < ntiles; t += PD) {                 // tiles past Ns inside the last group are all mask: they add zeros
     tile(std::integral_constant<int, 0>{});
     tile(std::integral_constant<int, 1>{});
     tile(std::integral_constant<int, 2>{});
     tile(std::integral_constant<int, 3>{});
   }
-  // ---- the four waves' partial sums, added in a fixed order; D layout: row 4 g + (lane >> 4), column 4 blk + (lane & 3) ----
-  __syncthreads();
+  // ---- epilogue: the four blocks of an accumulator (lanes that differ in blk) are partial sums of one 4 x 4 output block -
+  // added first (fixed order: xor 4, then xor 8), then the four waves' sums through LDS, in wave order.  Output block (g, h):
+  // row 4 g + (lane >> 4), column 4 h + (lane & 3); G is mirrored from its upper blocks (exactly symmetric) ----
+  auto blk_sum = [&](double x) __attribute__((always_inline)) {
+    x += __shfl_xor(x, 4, 64);
+    x += __shfl_xor(x, 8, 64);
+    return x;
+  };
+  __syncthreads();                                     // the table is dead: Gs = [wave][26][16] doubles (13 KB)
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    Gs[((wave * 2 + 0) * 16 + 4 * g + kq) * 16 + 4 * blk + li] = accG[g];
-    Gs[((wave * 2 + 1) * 16 + 4 * g + kq) * 16 + 4 * blk + li] = accC[g];
+  for (int k = 0; k < 10; ++k) {
+    const double sg = blk_sum(accG[k]);
+    if (blk == 0) Gs[(wave * 26 + k) * 16 + kq * 4 + li] = sg;
+  }
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const double sc = blk_sum(accC[k]);
+    if (blk == 0) Gs[(wave * 26 + 10 + k) * 16 + kq * 4 + li] = sc;
   }
   __syncthreads();
-  const int gi = tid >> 4, gj = tid & 15;
+  const int gi = tid >> 4, gj = tid & 15;                // output entry (row gi, column gj)
   if (gi < W && gj < W) {
+    const int gq = gi >> 2, hq = gj >> 2;
+    // G: block (g, h) with g <= h is stored; the entry below the block diagonal comes from the transposed block
+    const int ga = gq <= hq ? gq : hq, gb = gq <= hq ? hq : gq;
+    const int ri = gq <= hq ? gi & 3 : gj & 3, rj = gq <= hq ? gj & 3 : gi & 3;
+    const int kg = ga * 4 - ga * (ga - 1) / 2 + (gb - ga);                  // index of (ga, gb) in the order g = 0..3, h = g..3
     double sg = 0.0, sc = 0.0;
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
-      sg += Gs[((w * 2 + 0) * 16 + gi) * 16 + gj];
-      sc += Gs[((w * 2 + 1) * 16 + gi) * 16 + gj];
+      sg += Gs[(w * 26 + kg) * 16 + ri * 4 + rj];
+      sc += Gs[(w * 26 + 10 + 4 * gq + hq) * 16 + (gi & 3) * 4 + (gj & 3)];
     }
     Gout[(size_t)sys * W * W + (size_t)gj * W + gi] = sg;
     Cout[(size_t)sys * W * W + (size_t)gj * W + gi] = sc;
@@ -1831,11 +1874,12 @@ extern "C" int kp_sweep_eval_nested(kp_ctx* ctx, const kp_traj* traj, const kp_b
 #define KP_TGC(MT_, D_)                                                                                                           \
     {                                                                                                                             \
       static KpLdsCache tgc_lds;                                                                                                  \
-      const size_t lds_c = std::max((size_t)2 * TgcShape<MT_, D_>::E * TGM_STR * sizeof(double), (size_t)4 * 2 * 256 * sizeof(double)); \
+      const size_t lds_c = std::max((size_t)2 * TgcShape<MT_, D_>::E * TGM_STR * sizeof(double), (size_t)4 * 26 * 16 * sizeof(double)); \
       KP_HIP(ctx, kp_ensure_lds(tgc_lds, (const void*)kp_traj_gram_cols_kernel<MT_, D_>, lds_c));                                 \
       KP_HIP(ctx, hipEventRecord(ctx->ev0, s));                                                                                   \
       hipLaunchKernelGGL((kp_traj_gram_cols_kernel<MT_, D_>), dim3(nb), dim3(256), lds_c, s, traj_view(traj), Ns, dGc, dCc);      \
       use_cols = true;                                                                                                            \
+      ctx->timers[10] = 26.0 * 512.0 / 16.0;   /* executed on the matrix pipe per pair: 10 + 16 MFMAs per 16 pairs */            \
     }
     if (b.model_type == KP_MODEL_LINEAR && Dp == 13) KP_TGC(KP_MODEL_LINEAR, 13)
     else if (b.model_type == KP_MODEL_BILINEAR && Dp == 6) KP_TGC(KP_MODEL_BILINEAR, 6)
@@ -1844,6 +1888,7 @@ extern "C" int kp_sweep_eval_nested(kp_ctx* ctx, const kp_traj* traj, const kp_b
   }
   if (use_cols) {
   } else if (use_mfma) {
+    ctx->timers[10] = 8.0 * 512.0 / 4.0;         // 8 MFMAs per 4 pairs (one padded 16 x 16 tile for G and for C)
 #define KP_TGM(F_, DC_, NV_, UP_)                                                                                               \
     {                                                                                                                             \
       static KpLdsCache tgm_lds;                                                                                                  \

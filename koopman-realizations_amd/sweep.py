@@ -300,7 +300,7 @@ def rand_models_sweep_arrays(Y, U, k, Yv, Uv, ctx, degrees=None, nested=True, tr
                     # as the reference's own `\` would propagate, instead of whatever the rollout made of it
                     out[mt] = np.where(st != 0, np.nan, err[:, :, 0])
                     # kernel time of this model type's Gram pass (kp_traj_gram_kernel), its width and pair count: bench line
-                    ctx.__dict__.setdefault("_sweep_gram", {})[mt] = (ctx.timer(0), basis.W, Y.shape[0] * (k * (Y.shape[1] // k - 1) - 1))
+                    ctx.__dict__.setdefault("_sweep_gram", {})[mt] = (ctx.timer(0), basis.W, Y.shape[0] * (k * (Y.shape[1] // k - 1) - 1), ctx.timer(10))
                     continue
             finally:
                 basis.close()
