@@ -1196,8 +1196,13 @@ __global__ __launch_bounds__(256, 4) void kp_traj_gram_cols_kernel(TrajView tv, 
   // column-group form read 24 values for 32 MFMAs and kept the CU's LDS pipe as busy as its matrix pipes ----
   const int li = lane & 3, kq = lane >> 4, blk = (lane >> 2) & 3;
   // column groups 0-2 are always inside the row (W >= 12): base + immediate; group 3 may run into the padding (zero entry)
-  const int offa = li * TGM_STR + 32 * wave + 4 * blk + kq;
-  const int off3 = ((12 + li) < W ? 12 + li : W) * TGM_STR + 32 * wave + 4 * blk + kq;
+  // Which of the wave's 32 pairs a (step jj, block, k) slot takes is free (every pair once per tile): position
+  // 16 (kq & 1) + 4 blk + 2 jj + (kq >> 1), so that the 32 lanes of a read pass (kq in {0, 1} or {2, 3}; entry stride = 1 mod 32
+  // bank pairs) hit bank pairs li + 4 blk + 16 (kq & 1) + const - all different.  (With position 4 blk + kq the two k of a
+  // pass overlapped on 15 of 16 bank pairs: rocprofv3 SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.25.)
+  const int ppos = 32 * wave + 16 * (kq & 1) + 4 * blk + (kq >> 1);
+  const int offa = li * TGM_STR + ppos;
+  const int off3 = ((12 + li) < W ? 12 + li : W) * TGM_STR + ppos;
   static_assert(W >= 12, "column groups 0-2 full");
   double accG[10], accC[16];
 #pragma unroll
@@ -1303,7 +1308,7 @@ __global__ __launch_bounds__(256, 4) void kp_traj_gram_cols_kernel(TrajView tv, 
       double v[8];
 #pragma unroll
       for (int sl = 0; sl < 8; ++sl)
-        v[sl] = sm[((sl & 3) < 3 ? offa + 4 * (sl & 3) * TGM_STR : off3) + (sl >= 4 ? E * TGM_STR : 0) + jj * 16];
+        v[sl] = sm[((sl & 3) < 3 ? offa + 4 * (sl & 3) * TGM_STR : off3) + (sl >= 4 ? E * TGM_STR : 0) + jj * 2];
       int k = 0;
 #pragma unroll
       for (int g = 0; g < 4; ++g)
