@@ -160,6 +160,27 @@ def test_ksysid_hip_train_models_keeps_the_callers_view_of_the_parent():
     assert order == sorted(order)                              # field order of Ksysid.m:1084-1091
 
 
+def test_integration_excerpt_is_the_shipped_code():
+    """INTEGRATION.md section 3 shows get_Koopman of matlab/KsysidHip.m: every line of the excerpt (but the `...` that stands for
+    the loaded branch) is a line of the shipped file, in the same order."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    sec = doc[doc.index("## 3. `Ksysid.get_Koopman`"):]
+    block = sec[sec.index("```matlab") + len("```matlab"):]
+    block = block[:block.index("```")]
+    src = [l.strip() for l in open(os.path.join(root, "matlab", "KsysidHip.m")).read().splitlines()]
+    pos = 0
+    n = 0
+    for line in block.splitlines():
+        t = line.strip()
+        if not t or t == "...":
+            continue
+        assert t in src[pos:], t
+        pos = src.index(t, pos) + 1
+        n += 1
+    assert n >= 20
+
+
 def test_matlab_delay_row_indices_equal_the_oracles():
     """KsysidHip.hip_lasso_delay_rows decodes the index formulas of Ksysid.m:1146-1157 with vector expressions; the same
     expressions in numpy give the oracle's literal decoding (oracle.delay_pins) for several (n, m, nd, N)."""
