@@ -78,7 +78,7 @@ extern "C" int kp_destroy(kp_ctx* c) {
   kp_stage_destroy(c);
   (void)hipStreamSynchronize(c->stream);
   if (c->stream2) (void)hipStreamSynchronize(c->stream2);
-  for (int i = 0; i < 12; ++i)
+  for (int i = 0; i < 14; ++i)
     if (c->ws[i]) (void)hipFree(c->ws[i]);
   if (c->sticky_info) (void)hipFree(c->sticky_info);
   if (c->pin_small) (void)hipHostFree(c->pin_small);

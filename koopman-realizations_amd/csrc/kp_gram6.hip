@@ -31,8 +31,11 @@
 
 template <int G4C>
 struct G6Layout {
-  static constexpr int CS = 4 * G4C;                 // columns of one weighted block
-  static constexpr int YO = NWT6 * CS;               // psi_y
+  static constexpr int CS = 4 * G4C;                 // columns per side
+  static constexpr int WS = NWT6;                    // psi_x: [column][weight] - the ten weighted copies of a column are contiguous (80 B:
+                                                     // an A set is five 16-byte reads with immediate offsets; a stride of whole blocks made
+                                                     // the compiler merge pairs into ds_read2_b64 behind a VALU add for every new base)
+  static constexpr int YO = NWT6 * CS;               // psi_y [column]
   static constexpr int ZO = YO + CS;                 // zero group
   static constexpr int RS = ((ZO + 4 - 16 + 31) / 32) * 32 + 16;     // row stride = 16 mod 32: the four k-rows of an operand read hit disjoint banks
   static constexpr int PSIBUF = KT6 * RS;
@@ -43,7 +46,8 @@ struct G6Layout {
 template <int NQ, int G4C>
 __global__ __launch_bounds__(512) void kp_gram6_kernel(Gram3Args a) {
   using L = G6Layout<G4C>;
-  constexpr int CS = L::CS, YO = L::YO, ZO = L::ZO, RS = L::RS, PSIBUF = L::PSIBUF, PSI0 = L::PSI0;
+  constexpr int CS = L::CS, WS = L::WS, YO = L::YO, ZO = L::ZO, RS = L::RS, PSIBUF = L::PSIBUF, PSI0 = L::PSI0;
+  (void)CS;
   extern __shared__ __align__(16) double sm[];
   const BasisDev& b = a.b;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -60,14 +64,14 @@ __global__ __launch_bounds__(512) void kp_gram6_kernel(Gram3Args a) {
   const uint32_t* jd = a.desc + (size_t)job * (1 + NQ);
   const uint32_t jh = jd[0];
   const int lrow = (lane >> 4) * RS, blk = (lane >> 2) & 3, lc = lane & 3;
-  const int ao0 = PSI0 + lrow + 4 * (int)(jh & 255u) + lc;
-  const int ao1 = PSI0 + lrow + 4 * (int)((jh >> 8) & 255u) + lc;
+  const int ao0 = PSI0 + lrow + (4 * (int)(jh & 255u) + lc) * WS;
+  const int ao1 = PSI0 + lrow + (4 * (int)((jh >> 8) & 255u) + lc) * WS;
   const int qs = __builtin_amdgcn_readfirstlane((int)((jh >> 16) & 255u));
   int bo[NQ];
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
     const int g = (int)((jd[1 + q] >> (8 * blk)) & 255u);
-    bo[q] = PSI0 + lrow + (g < a.G4 ? 4 * g : g < 2 * a.G4 ? YO + 4 * (g - a.G4) : ZO) + lc;
+    bo[q] = PSI0 + lrow + (g < a.G4 ? (4 * g + lc) * WS : g < 2 * a.G4 ? YO + 4 * (g - a.G4) + lc : ZO + lc);
   }
   double acc[NQ][NWT6];
 #pragma unroll
@@ -77,37 +81,29 @@ __global__ __launch_bounds__(512) void kp_gram6_kernel(Gram3Args a) {
 
   for (int e = tid; e < L::LDS_DOUBLES; e += 512) sm[e] = 0.0;        // padding columns and the zero group stay zero
 
-  // ---- lift items.  x side: thread t < 4 N = (column, snapshot pair): psi and its nine weighted copies; y side: the other
-  // threads, two (column, snapshot pair) items each ----
+  // ---- lift items: EVERY thread lifts one x item (column, snapshot pair: psi and its nine weighted copies) and one y item,
+  // item = tid mod 4 N - the threads beyond 4 N repeat the first items (identical values to identical addresses), so that the
+  // MFMA loop holds no exec-mask branch (divergent branches cut it into small scheduling regions and cost register copies) ----
   const int nxi = 4 * N;
-  const bool is_x = tid < nxi;
-  const int ny_thr = 512 - nxi;
-  const int yi0 = tid - nxi, yi1 = yi0 + ny_thr;
-  const bool is_y0 = !is_x && yi0 < nxi, is_y1 = !is_x && yi1 < nxi;
-  int it_ch[2], it_col[2];                            // item 0 (x, or first y) and item 1 (second y)
+  const int item = tid % nxi;
+  const int it_ch = item / N, it_col = item - it_ch * N;
+  int fa[2][NF6];                                     // [side][factor]
   {
-    const int i0 = is_x ? tid : (is_y0 ? yi0 : 0), i1 = is_y1 ? yi1 : 0;
-    it_ch[0] = i0 / N; it_col[0] = i0 - it_ch[0] * N;
-    it_ch[1] = i1 / N; it_col[1] = i1 - it_ch[1] * N;
+    const uint32_t r = a.recipes[it_col];
+#pragma unroll
+    for (int sd = 0; sd < 2; ++sd)
+#pragma unroll
+      for (int f = 0; f < NF6; ++f) {
+        const int id = (int)((r >> (8 * f)) & 255u);
+        fa[sd][f] = (id == 255 ? CID : sd * nzm * D + id) * PST6 + 2 * it_ch;
+      }
   }
-  int fa[2][NF6];
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const uint32_t r = a.recipes[it_col[k]];
-    const int side = is_x ? 0 : 1;
-#pragma unroll
-    for (int f = 0; f < NF6; ++f) {
-      const int id = (int)((r >> (8 * f)) & 255u);
-      fa[k][f] = (id == 255 ? CID : side * nzm * D + id) * PST6 + 2 * it_ch[k];
-    }
-  }
-  // destination of item k: row 2 ch (and 2 ch + 1), column: x -> it_col (weight w adds w CS), y -> YO + it_col
-  int wdst[2];
-#pragma unroll
-  for (int k = 0; k < 2; ++k) wdst[k] = PSI0 + (2 * it_ch[k]) * RS + (is_x ? 0 : YO) + it_col[k];
-  // weight w >= 1 of this x item's snapshot pair: table entries CID + 1 + k (one base address, immediate offsets; 16-byte reads
+  // destination: rows 2 ch and 2 ch + 1; x -> column it_col (weight w adds w CS), y -> YO + it_col
+  const int wdst = PSI0 + (2 * it_ch) * RS + it_col * WS;          // x: [column][weight]; y: YO + column (formed below)
+  const int ydst = PSI0 + (2 * it_ch) * RS + YO + it_col;
+  // weight w >= 1 of the item's snapshot pair: table entries CID + 1 + k (one base address, immediate offsets; 16-byte reads
   // of the two snapshots).  k = 0..5: ut_a ut_b, 1 <= a <= b <= 3 in that order; k = 6..8: copies of ut_1..ut_3
-  const int wbase = (CID + 1) * PST6 + 2 * it_ch[0];
+  const int wbase = (CID + 1) * PST6 + 2 * it_ch;
   auto wk = [](int w) constexpr { return w <= 3 ? 5 + w : w - 4; };     // weight index (x <= y order: 1, u1, u2, u3, u1u1, ...) -> k
 
   const int64_t kt0 = (int64_t)split * a.ktiles_per_split;
@@ -116,10 +112,10 @@ __global__ __launch_bounds__(512) void kp_gram6_kernel(Gram3Args a) {
 
   // ---- raw loader: thread t < 2 (nzeta + m) KT6 = (row, snapshot); rows [alpha (nzeta) u (m) | beta (nzeta) u (m)] ----
   struct RawRegs { double v, e0, e1; bool ok; };
-  const bool ld_on = tid < nrawrows * KT6;
+  const bool ld_on = tid < nrawrows * KT6;            // (the others load what thread tid mod (rows KT6) loads and store nothing)
   const int ld_s = tid & (KT6 - 1);
-  const int ld_r = ld_on ? tid / KT6 : 0, ld_rr = ld_r % nzm;
-  const int ld_ua = (ld_on && ld_r < nzm && ld_rr >= b.nzeta) ? ld_rr - b.nzeta : -1;      // input index of an alpha-side input row
+  const int ld_r = (tid % (nrawrows * KT6)) / KT6, ld_rr = ld_r % nzm;
+  const int ld_ua = (ld_r < nzm && ld_rr >= b.nzeta) ? ld_rr - b.nzeta : -1;      // input index of an alpha-side input row
   const double* ld_ptr = (ld_rr < b.nzeta ? ((ld_r < nzm ? a.alpha : a.beta) + (int64_t)ld_rr * a.Ns) : (a.u + (int64_t)(ld_rr - b.nzeta) * a.Ns)) +
                          kt0 * KT6 + ld_s;
   const int ld_e0 = ld_ua >= 0 && ld_ua + 1 < 3 ? (int)a.Ns : 0, ld_e1 = ld_ua >= 0 && ld_ua + 2 < 3 ? 2 * (int)a.Ns : 0;   // the other inputs' columns
@@ -129,12 +125,10 @@ __global__ __launch_bounds__(512) void kp_gram6_kernel(Gram3Args a) {
   auto load_raw = [&]() __attribute__((always_inline)) -> RawRegs {
     RawRegs x;
     x.ok = ld_rem > 0;
-    x.v = 0.0; x.e0 = 0.0; x.e1 = 0.0;
-    if (ld_on) {
-      x.v = *ld_ptr;
-      if (ld_ua >= 0) { x.e0 = ld_ptr[ld_e0]; x.e1 = ld_ptr[ld_e1]; }
-      ld_ptr += KT6;
-    }
+    x.v = *ld_ptr;                                     // branch-free: every thread loads (offsets 0 where there is nothing else to fetch)
+    x.e0 = ld_ptr[ld_e0];
+    x.e1 = ld_ptr[ld_e1];
+    ld_ptr += KT6;
     ld_rem -= KT6;
     return x;
   };
@@ -159,53 +153,40 @@ __global__ __launch_bounds__(512) void kp_gram6_kernel(Gram3Args a) {
     if (tid < KT6) sm[BUF * POWBUF6 + CID * PST6 + tid] = x.ok ? 1.0 : 0.0;
   };
 
-  // ---- the lift in sub-steps, issued between the MFMAs (x items: 0 reads two factors, 1 multiplies them and reads the third,
-  // 2 writes psi and reads weight 1, w + 2 writes weighted copy w and reads weight w + 1; y items: 0-2 the first item, 3-5 the
-  // second).  `psb` = this thread's destination in the Psi buffer being filled (formed once per tile: the two Psi buffers
-  // span 121 KB, beyond the 64 KB an immediate DS offset reaches) ----
-  double2 lfa, lfb, psi, wv;
-  auto lift_sub = [&](int sub, auto buf_c, int psb0, int psb1) __attribute__((always_inline)) {
+  // ---- the lift in sub-steps, issued between the MFMAs: 0 reads two factors of each side, 1 multiplies them and reads the
+  // third, 2 writes psi_x, psi_y and reads weight 1, w + 2 writes weighted copy w of psi_x and reads weight w + 1.  `psb` =
+  // this thread's destination in the Psi buffer being filled (formed once per tile: the two Psi buffers span 121 KB, beyond
+  // the 64 KB an immediate DS offset reaches) ----
+  double2 lxa, lxb, lya, lyb, psi, psy, wv, wlo;
+  auto lift_sub = [&](int sub, auto buf_c, int psb, int ysb) __attribute__((always_inline)) {
     constexpr int BUF = decltype(buf_c)::value;
     const double* pw = sm + BUF * POWBUF6;
     if (sub == 0) {
-      if (is_x || is_y0) {
-        lfa = *reinterpret_cast<const double2*>(&pw[fa[0][0]]);
-        lfb = *reinterpret_cast<const double2*>(&pw[fa[0][1]]);
-      }
+      lxa = *reinterpret_cast<const double2*>(&pw[fa[0][0]]);
+      lxb = *reinterpret_cast<const double2*>(&pw[fa[0][1]]);
+      lya = *reinterpret_cast<const double2*>(&pw[fa[1][0]]);
+      lyb = *reinterpret_cast<const double2*>(&pw[fa[1][1]]);
     } else if (sub == 1) {
-      if (is_x || is_y0) {
-        psi.x = lfa.x * lfb.x;
-        psi.y = lfa.y * lfb.y;
-        lfa = *reinterpret_cast<const double2*>(&pw[fa[0][2]]);
-      }
+      psi.x = lxa.x * lxb.x; psi.y = lxa.y * lxb.y;
+      psy.x = lya.x * lyb.x; psy.y = lya.y * lyb.y;
+      lxa = *reinterpret_cast<const double2*>(&pw[fa[0][2]]);
+      lya = *reinterpret_cast<const double2*>(&pw[fa[1][2]]);
     } else if (sub == 2) {
-      if (is_x || is_y0) {
-        psi.x *= lfa.x;
-        psi.y *= lfa.y;
-        sm[psb0] = psi.x;
-        sm[psb0 + RS] = psi.y;
-      }
-      if (is_x) wv = *reinterpret_cast<const double2*>(&pw[wbase + wk(1) * PST6]);
+      psi.x *= lxa.x; psi.y *= lxa.y;
+      sm[ysb] = psy.x * lya.x;
+      sm[ysb + RS] = psy.y * lya.y;
+      wv = *reinterpret_cast<const double2*>(&pw[wbase + wk(1) * PST6]);
+      wlo = psi;                                        // weight 0 rides with weight 1 (one 16-byte write per snapshot)
     } else if (sub <= NWT6 + 1) {
       const int w = sub - 2;                          // 1 .. 9
-      if (is_x) {
-        sm[psb0 + w * CS] = psi.x * wv.x;
-        sm[psb0 + RS + w * CS] = psi.y * wv.y;
-        if (w + 1 < NWT6) wv = *reinterpret_cast<const double2*>(&pw[wbase + wk(w + 1 < NWT6 ? w + 1 : w) * PST6]);
+      const double2 cur = {psi.x * wv.x, psi.y * wv.y};
+      if (w & 1) {                                      // (w - 1, w): one 16-byte write per snapshot
+        *reinterpret_cast<double2*>(&sm[psb + (w - 1)]) = double2{wlo.x, cur.x};
+        *reinterpret_cast<double2*>(&sm[psb + RS + (w - 1)]) = double2{wlo.y, cur.y};
+      } else {
+        wlo = cur;
       }
-      if (is_y1) {
-        if (sub == 3) {
-          lfa = *reinterpret_cast<const double2*>(&pw[fa[1][0]]);
-          lfb = *reinterpret_cast<const double2*>(&pw[fa[1][1]]);
-        } else if (sub == 4) {
-          psi.x = lfa.x * lfb.x;
-          psi.y = lfa.y * lfb.y;
-          lfa = *reinterpret_cast<const double2*>(&pw[fa[1][2]]);
-        } else if (sub == 5) {
-          sm[psb1] = psi.x * lfa.x;
-          sm[psb1 + RS] = psi.y * lfa.y;
-        }
-      }
+      if (w + 1 < NWT6) wv = *reinterpret_cast<const double2*>(&pw[wbase + wk(w + 1 < NWT6 ? w + 1 : w) * PST6]);
     }
   };
   constexpr int NSUB = NWT6 + 2;
@@ -216,7 +197,7 @@ __global__ __launch_bounds__(512) void kp_gram6_kernel(Gram3Args a) {
   store_raw(B0{}, load_raw());
   __syncthreads();
 #pragma unroll
-  for (int i = 0; i < NSUB; ++i) lift_sub(i, B0{}, wdst[0], wdst[1]);
+  for (int i = 0; i < NSUB; ++i) lift_sub(i, B0{}, wdst, ydst);
   store_raw(B1{}, load_raw());
   __syncthreads();
 
@@ -236,12 +217,12 @@ __global__ __launch_bounds__(512) void kp_gram6_kernel(Gram3Args a) {
     int bq[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) bq[q] = bo[q] + pcur;
-    const int psb0 = wdst[0] + pnxt, psb1 = wdst[1] + pnxt;
+    const int psb = wdst + pnxt, ysb = ydst + pnxt;
     RawRegs rawreg;
     double bvs[NSTEP];
-    double aw[NWT6];
+    double2 aw2[NWT6 / 2];                             // the A set: weights (2 j, 2 j + 1) of this lane's column, 16-byte reads
 #pragma unroll
-    for (int w = 0; w < NWT6; ++w) aw[w] = sm[aA + w * CS];
+    for (int j = 0; j < NWT6 / 2; ++j) aw2[j] = *reinterpret_cast<const double2*>(&sm[aA + 2 * j]);
 #pragma unroll
     for (int i = 0; i < PF; ++i) bvs[i] = sm[(i / NQ) * 4 * RS + bq[i % NQ]];
 #pragma unroll
@@ -255,12 +236,13 @@ __global__ __launch_bounds__(512) void kp_gram6_kernel(Gram3Args a) {
       const bool sw1 = QS < NQ && q == QS - 1;                                   // next: group a1 of this k-step
       const bool sw0 = q == NQ - 1 && kk + 1 < KT6 / 4;                          // next: group a0 of the next k-step
 #pragma unroll
-      for (int w = 0; w < NWT6; ++w) {
-        acc[q][w] = __builtin_amdgcn_mfma_f64_4x4x4f64(aw[w], bv, acc[q][w], 0, 0, 0);
-        if (sw1) aw[w] = sm[kk * 4 * RS + aB + w * CS];
-        else if (sw0) aw[w] = sm[(kk + 1) * 4 * RS + aA + w * CS];
+      for (int j = 0; j < NWT6 / 2; ++j) {
+        acc[q][2 * j] = __builtin_amdgcn_mfma_f64_4x4x4f64(aw2[j].x, bv, acc[q][2 * j], 0, 0, 0);
+        acc[q][2 * j + 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(aw2[j].y, bv, acc[q][2 * j + 1], 0, 0, 0);
+        if (sw1) aw2[j] = *reinterpret_cast<const double2*>(&sm[kk * 4 * RS + aB + 2 * j]);
+        else if (sw0) aw2[j] = *reinterpret_cast<const double2*>(&sm[(kk + 1) * 4 * RS + aA + 2 * j]);
       }
-      if (step < NSUB) lift_sub(step, NXT{}, psb0, psb1);
+      if (step < NSUB) lift_sub(step, NXT{}, psb, ysb);
       __builtin_amdgcn_sched_barrier(0);
     }
     store_raw(cur_c, rawreg);

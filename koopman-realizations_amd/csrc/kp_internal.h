@@ -75,8 +75,8 @@ struct kp_ctx {
   double timers[12] = {0};
   double gram_flops_per_pair = 0;
   // growable device workspaces
-  void* ws[12] = {nullptr};     // slot 8: staging of the collectives, 9: rank-revealing solve, 10 / 11: Grams of the shadow dictionary of a dim_red fit, their half-transformed form
-  size_t ws_bytes[12] = {0};
+  void* ws[14] = {nullptr};     // slot 8: staging of the collectives, 9: rank-revealing solve, 10 / 11: Grams of the shadow dictionary of a dim_red fit, their half-transformed form
+  size_t ws_bytes[14] = {0};   // 12 / 13: column states and results of the lasso homotopy (kp_lasso_path.hip)
   int last_rank = -1;           // rank found by the most recent solve (W when the Gram matrix was positive definite)
   double last_pivot_ratio = 1.0; // min_i L_ii^2 / G_ii of the most recent synchronous least-squares solve (~1 / cond(G))
   // results of the last kp_fit
@@ -344,6 +344,9 @@ struct kp_lasso_prep {
 };
 int kp_lasso_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, int W, int ncols, double t, int max_iter, double tol,
                  double* K_dev, int* iters, kp_lasso_prep* prep = nullptr);
+// the lasso values of one fit by the regularisation-path homotopy (kp_lasso_path.hip); stats: steps, largest support, ms, inverse in memory
+int kp_lasso_path_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, int W, int ncols, const double* t, int nv, double* const* K_dev,
+                            double* stats);
 // all lasso values of one fit at once (one wide G*[K_1..K_nv] product per FISTA iteration, active-set polish)
 int kp_lasso_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, int W, int ncols, const double* t, int nv,
                        int max_iter, double tol, double* const* K_dev, int* iters, kp_lasso_prep* prep = nullptr);

@@ -869,7 +869,33 @@ int kp_lasso_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, in
   static const bool trace = getenv("KP_LASSO_TRACE") != nullptr;
   int gemm_timed_cols = 0;
   const auto t_start = std::chrono::steady_clock::now();
+  // Values still running after `path_after` iterations go to the regularisation-path homotopy (kp_lasso_path.hip): exact in
+  // a bounded number of steps whatever cond(G) is, where this iteration needs O(sqrt(cond)) of them.  KP_LASSO_PATH_AFTER=-1
+  // disables it, 0 sends every active value there at once.
+  static const int path_after = [] { const char* e = getenv("KP_LASSO_PATH_AFTER"); return e ? atoi(e) : 100; }();
+  bool path_tried = false;
+  ctx->timers[11] = 0.0;
   while (it < max_iter && nba > 0) {
+    if (path_after >= 0 && it >= path_after && !path_tried && W <= 384) {
+      path_tried = true;
+      std::vector<double> tv(nba);
+      std::vector<double*> dst(nba);
+      for (int v = 0; v < nba; ++v) { tv[v] = t[slot_val[v]]; dst[v] = K_dev[slot_val[v]]; }
+      double pst[4] = {0, 0, 0, 0};
+      const int prc = kp_lasso_path_batch_dev(ctx, prep->Gw, C_dev, W, ncols, tv.data(), nba, dst.data(), pst);
+      if (trace) fprintf(stderr, "kp_lasso: homotopy for %d values after %d iterations: rc %d, %.0f steps, largest support %.0f, %.3f ms%s\n", nba, it, prc, pst[0],
+                         pst[1], pst[2], pst[3] != 0.0 ? " (inverse in global memory)" : "");
+      if (prc == KP_OK) {
+        for (int v = 0; v < nba; ++v)
+          if (iters) iters[slot_val[v]] = it;
+        ctx->timers[11] = pst[2];
+        nba = 0;
+        break;
+      }
+      hrec = (char*)kp_pinned_scratch(ctx, (size_t)nb * LS_REC + (size_t)nb * 4);      // (the homotopy used the same scratch)
+      if (!hrec) return ctx->fail(KP_ERR_HIP, "kp_fit_lasso: out of page-locked host memory");
+      on_host = (int*)(hrec + (size_t)nb * LS_REC);
+    }
     const dim3 grid(nblk, nba);
     // workgroups per value of the fused projection: all of them resident at once, one per CU
     const int ncu = ctx->num_cu > 0 ? ctx->num_cu : 256;
