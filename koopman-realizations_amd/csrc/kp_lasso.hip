@@ -874,6 +874,7 @@ int kp_lasso_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, in
   // disables it, 0 sends every active value there at once.
   static const int path_after = [] { const char* e = getenv("KP_LASSO_PATH_AFTER"); return e ? atoi(e) : 100; }();
   bool path_tried = false;
+  std::string path_err;
   ctx->timers[11] = 0.0;
   while (it < max_iter && nba > 0) {
     if (path_after >= 0 && it >= path_after && !path_tried && W <= 384) {
@@ -892,6 +893,7 @@ int kp_lasso_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, in
         nba = 0;
         break;
       }
+      path_err = ctx->err;
       hrec = (char*)kp_pinned_scratch(ctx, (size_t)nb * LS_REC + (size_t)nb * 4);      // (the homotopy used the same scratch)
       if (!hrec) return ctx->fail(KP_ERR_HIP, "kp_fit_lasso: out of page-locked host memory");
       on_host = (int*)(hrec + (size_t)nb * LS_REC);
@@ -1090,7 +1092,7 @@ int kp_lasso_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, in
       KP_HIP(ctx, hipMemcpyAsync(K_dev[slot_val[v]], Kb[kc] + (size_t)v * n, bK, hipMemcpyDeviceToDevice, s));
       if (iters) iters[slot_val[v]] = it;
     }
-    return ctx->fail(KP_ERR_NOT_CONVERGED, "kp_fit_lasso: iteration cap reached");
+    return ctx->fail(KP_ERR_NOT_CONVERGED, path_err.empty() ? std::string("kp_fit_lasso: iteration cap reached") : "kp_fit_lasso: iteration cap reached (" + path_err + ")");
   }
   return KP_OK;
 }

@@ -139,7 +139,7 @@ __device__ __forceinline__ Cand cmin(Cand a, Cand b) { return (b.dl < a.dl || (b
 
 template <bool MG>
 __global__ __launch_bounds__(PT) void kp_lasso_path_kernel(const double* __restrict__ G, const double* __restrict__ C, PathLayout L, char* __restrict__ arena,
-                                                           double theta_stop, double theta_from, int max_steps, int init, int record, int adjust, double* __restrict__ Kout) {
+                                                           double theta_stop, double theta_from, int max_steps, int init, int record, int adjust, int polish, double* __restrict__ Kout) {
   extern __shared__ double sm[];
   const int W = L.W, ld = L.ldm, tid = threadIdx.x, col = blockIdx.x, lane = tid & 63, wave = tid >> 6;
   char* base = arena + (size_t)col * L.stride;
@@ -215,28 +215,31 @@ __global__ __launch_bounds__(PT) void kp_lasso_path_kernel(const double* __restr
     __syncthreads();
   }
 
-  // adjust: ONE move to theta_stop (above or below theta) along the current segment, no event - the caller knows it is tiny
+  // r = c - G k from scratch, k_S corrected so that r_S = theta s_S (one Newton step with the inverse at hand), r again
+  auto resync = [&]() {
+    for (int pass = 0; pass < 2; ++pass) {
+      for (int t = tid; t < cnt; t += PT) u[t] = k[idx[t]];
+      __syncthreads();
+      mv_gather(G, W, nullptr, W, idx, cnt, u, a);
+      for (int i = tid; i < W; i += PT) r[i] = c[i] - a[i];
+      __syncthreads();
+      if (pass == 1) break;
+      for (int t = tid; t < cnt; t += PT) e[t] = r[idx[t]] - theta * sg[idx[t]];
+      __syncthreads();
+      mv_sym(M, ld, cnt, e, g, red);
+      for (int t = tid; t < cnt; t += PT) k[idx[t]] += g[t];
+      __syncthreads();
+    }
+  };
+  // adjust: ONE move to theta_stop (above or below theta) along the current segment, no event - the caller knows it is tiny (an
+  // entry pushed past zero by it, at the 1e-12 level, leaves in the next step of the walk)
   bool adjusted = false;
   while (status == PATH_OK && (adjust ? (!adjusted && cnt > 0 && theta == theta_from && theta_stop != theta) : theta > theta_stop)) {
     if (steps >= max_steps) { status = PATH_STEPS; break; }
     ++steps;
     adjusted = true;
     // ---- every P_RESYNC steps: r = c - G k from scratch, k_S corrected so that r_S = theta s_S, r again
-    if (steps % P_RESYNC == 0 && cnt > 0 && !adjust) {
-      for (int pass = 0; pass < 2; ++pass) {
-        for (int t = tid; t < cnt; t += PT) u[t] = k[idx[t]];
-        __syncthreads();
-        mv_gather(G, W, nullptr, W, idx, cnt, u, a);
-        for (int i = tid; i < W; i += PT) r[i] = c[i] - a[i];
-        __syncthreads();
-        if (pass == 1) break;
-        for (int t = tid; t < cnt; t += PT) e[t] = r[idx[t]] - theta * sg[idx[t]];
-        __syncthreads();
-        mv_sym(M, ld, cnt, e, g, red);
-        for (int t = tid; t < cnt; t += PT) k[idx[t]] += g[t];
-        __syncthreads();
-      }
-    }
+    if (steps % P_RESYNC == 0 && cnt > 0 && !adjust) resync();
     // ---- direction on the support, its image off the support
     for (int t = tid; t < cnt; t += PT) sS[t] = sg[idx[t]];
     if (tid < 8) sc_i[tid] = 0;
@@ -298,7 +301,6 @@ __global__ __launch_bounds__(PT) void kp_lasso_path_kernel(const double* __restr
     for (int t = tid; t < cnt; t += PT) {
       const int i = idx[t];
       const double kn = k[i] + dl * d[t];
-      if (adjust && kn * sS[t] < 0.0) sc_i[6] = 1;
       k[i] = kn;
       r[i] = theta_new * sS[t];
       part += fabs(kn);
@@ -309,7 +311,6 @@ __global__ __launch_bounds__(PT) void kp_lasso_path_kernel(const double* __restr
     __syncthreads();
     l1 = sc_d[8] + sc_d[9] + sc_d[10] + sc_d[11];
     theta = theta_new;
-    if (adjust && sc_i[6]) status = PATH_ADJUST;
     if (!adjust) { last_add = -1; last_del = -1; last_del_sgn = 0.0; }
     __syncthreads();
     if (!capped) {
@@ -392,6 +393,16 @@ __global__ __launch_bounds__(PT) void kp_lasso_path_kernel(const double* __restr
   __syncthreads();
   double slope = 0.0;
   if (status == PATH_OK && cnt > 0) {
+    if (polish) {                                     // an answer leaves from here: at the rounding level of r_S = theta s_S
+      resync();
+      double part = 0.0;
+      for (int t = tid; t < cnt; t += PT) part += fabs(k[idx[t]]);
+      part = wsum(part);
+      if (lane == 0) sc_d[8 + wave] = part;
+      __syncthreads();
+      l1 = sc_d[8] + sc_d[9] + sc_d[10] + sc_d[11];
+      __syncthreads();
+    }
     for (int t = tid; t < cnt; t += PT) sS[t] = sg[idx[t]];
     __syncthreads();
     mv_sym(M, ld, cnt, sS, d, red);
@@ -514,12 +525,12 @@ int kp_lasso_path_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_de
     char* arena = (char*)ctx->workspace(12, L.stride * (size_t)ncols);
     if (!arena) return ctx->fail(KP_ERR_HIP, "kp_fit_lasso: out of device memory");
     const size_t lds = ((mglobal ? 0 : (size_t)L.ldm * L.ldm) + 4 * (size_t)W + 5 * (size_t)L.ldm + 512) * 8 + ((size_t)L.ldm + 2 + W + 2 + 8) * 4 + 16 * 8;
-    auto launch = [&](double stop, int init, int record, double* Kout, int adjust = 0, double from = 0.0) -> int {
+    auto launch = [&](double stop, int init, int record, double* Kout, int adjust = 0, double from = 0.0, int polish = 0) -> int {
       if (mglobal) {
-        hipLaunchKernelGGL(kp_lasso_path_kernel<true>, dim3(ncols), dim3(PT), lds, s, G_dev, C_dev, L, arena, stop, from, cap, init, record, adjust, Kout);
+        hipLaunchKernelGGL(kp_lasso_path_kernel<true>, dim3(ncols), dim3(PT), lds, s, G_dev, C_dev, L, arena, stop, from, cap, init, record, adjust, polish, Kout);
       } else {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kp_lasso_path_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL(kp_lasso_path_kernel<false>, dim3(ncols), dim3(PT), lds, s, G_dev, C_dev, L, arena, stop, from, cap, init, record, adjust, Kout);
+        hipLaunchKernelGGL(kp_lasso_path_kernel<false>, dim3(ncols), dim3(PT), lds, s, G_dev, C_dev, L, arena, stop, from, cap, init, record, adjust, polish, Kout);
       }
       KP_HIP(ctx, hipGetLastError());
       return KP_OK;
@@ -577,20 +588,25 @@ int kp_lasso_path_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_de
     for (int q = 0; q < nv; ++q) {
       const int v = order[q];
       double cur = theta[v];
-      rc = launch(cur, q == 0 ? 1 : 0, 0, K_dev[v]);
+      rc = launch(cur, q == 0 ? 1 : 0, 0, K_dev[v], 0, 0.0, 1);
       if (rc) return rc;
       if (h_th[v] < 0.0) continue;                   // inactive constraint: K(0)
-      for (int corr = 0; corr < 6; ++corr) {
+      for (int corr = 0; corr < 8; ++corr) {
         rc = summary(res, hres);
         if (rc) return rc;
         if ((int)hres[2] != PATH_OK) return ctx->fail(KP_ERR_NOT_CONVERGED, "kp_fit_lasso: homotopy failed in its second pass");
         const double gap = t[v] - hres[0], slope = hres[6];
-        if (fabs(gap) <= 1e-12 * t[v] || !(slope > 0.0)) break;
-        if (corr == 5 && fabs(gap) <= 1e-9 * t[v]) break;
-        if (corr == 5 || fabs(gap) > 1e-3 * t[v]) return ctx->fail(KP_ERR_NOT_CONVERGED, "kp_fit_lasso: homotopy passes disagree on |K|_1");
+        if (fabs(gap) <= 1e-13 * t[v] || !(slope > 0.0)) break;
+        if (corr == 7) {
+          if (fabs(gap) <= 1e-9 * t[v]) break;
+          return ctx->fail(KP_ERR_NOT_CONVERGED, "kp_fit_lasso: homotopy passes disagree on |K|_1");
+        }
         const double next = cur - gap / slope;
         if (!(next > 0.0) || next == cur) break;
-        rc = gap > 0.0 ? launch(next, 0, 0, K_dev[v]) : launch(next, 0, 0, K_dev[v], 1, cur);
+        // small gaps: a move inside the segment (either direction; exact in |K|_1); larger ones forwards by walking on, with events
+        if (fabs(gap) <= 1e-6 * t[v]) rc = launch(next, 0, 0, K_dev[v], 1, cur, 0);
+        else if (gap > 0.0) rc = launch(next, 0, 0, K_dev[v], 0, 0.0, 1);
+        else return ctx->fail(KP_ERR_NOT_CONVERGED, "kp_fit_lasso: homotopy passes disagree on |K|_1");
         if (rc) return rc;
         cur = next;
       }

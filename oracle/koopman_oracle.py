@@ -384,6 +384,104 @@ def koopman_lasso(G, C, t, iters=200000, tol=1e-13):
     return K
 
 
+def _lasso_column_path(G, c, theta_stop, max_steps):
+    """Regularisation path of ONE column of the QP of Ksysid.m:1126-1137 in its multiplier form
+    k(theta) = argmin 1/2 k'Gk - c'k + theta |k|_1, from theta = max|c| (k = 0) down to theta_stop, by the homotopy (LARS with
+    drops): between breakpoints the support S and signs s are fixed and dk_S/d(-theta) = G_SS^-1 s_S (a dense solve per step here -
+    the device keeps the inverse by rank-1 updates instead).  Returns breakpoints [(theta, |k|_1)] and k(theta_stop)."""
+    W = G.shape[0]
+    k = np.zeros(W); sgn = np.zeros(W); r = c.astype(float).copy()
+    j0 = int(np.argmax(np.abs(r))); theta = abs(r[j0])
+    bps = [(theta, 0.0)]
+    if theta <= theta_stop or theta == 0.0:
+        return bps, k
+    S = [j0]; sgn[j0] = np.sign(r[j0])
+    last_add, last_del, last_del_sgn = j0, -1, 0.0
+    for _ in range(max_steps):
+        if theta <= theta_stop:
+            break
+        Sa = np.array(S)
+        d = np.linalg.solve(G[np.ix_(Sa, Sa)], sgn[Sa])
+        a = G[:, Sa] @ d
+        best, ev = theta - theta_stop, None
+        off = np.ones(W, bool); off[Sa] = False
+        io = np.flatnonzero(off)
+        for s in (1.0, -1.0):                          # entry i enters with sign s when s (r_i - delta a_i) = theta - delta
+            den = s * a[io] - 1.0; num = s * r[io] - theta
+            with np.errstate(divide="ignore", invalid="ignore"):
+                dl = num / den
+            ok = (den != 0) & (dl > 1e-14 * theta) & ~((io == last_del) & (s == last_del_sgn))
+            if ok.any():
+                j = int(np.argmin(np.where(ok, dl, np.inf)))
+                if dl[j] < best:
+                    best, ev = dl[j], ("add", int(io[j]), s)
+        mov = (d * sgn[Sa] < 0) & (Sa != last_add)     # entry on the support reaches zero
+        if mov.any():
+            dl = np.where(mov, -k[Sa] / np.where(mov, d, 1.0), np.inf)
+            j = int(np.argmin(dl))
+            if max(dl[j], 0.0) < best:
+                best, ev = max(dl[j], 0.0), ("del", int(Sa[j]), 0.0)
+        k[Sa] += best * d; r = r - best * a; theta = theta - best if ev is not None else theta_stop
+        last_add, last_del, last_del_sgn = -1, -1, 0.0
+        if ev is not None:
+            if ev[0] == "add":
+                S.append(ev[1]); sgn[ev[1]] = ev[2]; last_add = ev[1]
+            else:
+                last_del, last_del_sgn = ev[1], sgn[ev[1]]
+                S.remove(ev[1]); sgn[ev[1]] = 0.0; k[ev[1]] = 0.0
+        bps.append((theta, np.abs(k).sum()))
+    return bps, k
+
+
+def koopman_lasso_path(G, C, t, max_steps_per_w=64):
+    """solve_KoopmanQP (Ksysid.m:1126-1137, delays = 0) by the regularisation path: with the multiplier theta of the L1 row the
+    columns of K separate, |K(theta)|_1 is piecewise linear and decreasing, and theta* with |K(theta*)|_1 = t is found on the
+    breakpoints of the column paths; then every column is walked to theta*.  Exact (active-set) optimum whatever cond(G) is -
+    the checker of the device's homotopy on the ill-conditioned arm Grams, where koopman_lasso's first-order iteration stalls.
+    Returns K and theta*.  The PSD guard of :1117-1120 is applied first."""
+    G = (G + G.T) / 2
+    if np.linalg.eigvalsh(G).min() < 0:               # :1117-1120
+        G = G + 1e-6 * np.eye(G.shape[0])
+    W, nc = C.shape
+    cap = max_steps_per_w * W + 512
+    paths = [_lasso_column_path(G, C[:, j], 0.0, cap)[0] for j in range(nc)]
+
+    def total(theta):
+        s = 0.0
+        for bp in paths:
+            th = np.array([b[0] for b in bp]); l1 = np.array([b[1] for b in bp])
+            s += 0.0 if theta >= th[0] else np.interp(-theta, -th, l1)
+        return s
+    if total(0.0) <= t:                               # inactive L1 row: the least-squares solution
+        return np.column_stack([_lasso_column_path(G, C[:, j], 0.0, cap)[1] for j in range(nc)]), 0.0
+    lo, hi = 0.0, max(bp[0][0] for bp in paths)
+    for _ in range(300):
+        mid = math.sqrt(lo * hi) if lo > 0 else hi * 2.0 ** -24
+        if not (lo < mid < hi):
+            break
+        if total(mid) >= t:
+            lo = mid
+        else:
+            hi = mid
+    K = np.column_stack([_lasso_column_path(G, C[:, j], lo, cap)[1] for j in range(nc)])
+    return K, lo
+
+
+def lasso_kkt(G, C, K, t):
+    """Optimality conditions of min 1/2<K,GK> - <C,K> s.t. |K|_1 <= t at K (PSD guard of Ksysid.m:1117-1120 applied): returns
+    (theta, on, off, feas): the multiplier estimated on the support (median of -g_i sign k_i), max |g_i + theta sign k_i| on the
+    support, max |g_i| / theta off it, and |K|_1 / t."""
+    G = (G + G.T) / 2
+    if np.linalg.eigvalsh(G).min() < 0:
+        G = G + 1e-6 * np.eye(G.shape[0])
+    g = G @ K - C
+    on = K != 0
+    theta = float(np.median(-(g * np.sign(K))[on])) if on.any() else float(np.abs(g).max())
+    res_on = float(np.abs(g + theta * np.sign(K))[on].max()) if on.any() else 0.0
+    off = float(np.abs(g[~on]).max() / theta) if (~on).any() and theta > 0 else 0.0
+    return theta, res_on, off, float(np.abs(K).sum() / t)
+
+
 def delay_pins(n, m, nd, N):
     """Equality rows of solve_KoopmanQP for LINEAR models with delays (Ksysid.m:1139-1164): the columns of K that
     produce the delayed part of zeta (columns n .. n(nd+1)+m nd - 1, i.e. vec rows n*Nm+1 : Nm*(n(nd+1)+mnd))

@@ -1,0 +1,148 @@
+"""GPU tests of the regularisation-path homotopy behind kp_fit_lasso (kp_lasso_path.hip; solve_KoopmanQP, Ksysid.m:1095-1176) on the
+Grams the projected-gradient iteration cannot finish: the monomial dictionaries of the reference's own arm data (cond(G) 5e9 ...
+3e10, and rank-deficient ones under the 1e-6 PSD guard of :1117-1120) with budgets within a decade of |K_LS|_1, where the multiplier
+of the L1 row is tiny and the answer dense.  Until round 4 these calls ended with "iteration cap reached" after 0.6 s.
+
+Oracle: the optimality conditions of the QP (oracle.lasso_kkt: multiplier theta from the support, |g_i + theta sign k_i| on it,
+|g_i| <= theta off it, |K|_1 = t) - size-independent - and, where numpy finishes in seconds, the oracle's own homotopy
+(koopman_lasso_path: dense solves, no shared code with the device).  Tolerances: budget met to 1e-11 relative; off-support
+|g| <= theta (1 + 1e-6) + the rounding of g itself (256 eps |G||K| - at cond 1e10 the multiplier of an almost-inactive constraint is
+below that rounding, and no solver in f64 can certify more); K against the oracle 1e-5 max|K| (cond * eps), objective 1e-12."""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+import koopman_realizations_amd as kra
+from oracle import koopman_oracle as ko
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _arm(golden):
+    g = golden["arm_data"]
+    lens = g["train_len"]; off = np.concatenate([[0], np.cumsum(lens)])
+    train = [{"t": g["train_t"][a:b], "y": g["train_y"][a:b], "u": g["train_u"][a:b]} for a, b in zip(off[:-1], off[1:])]
+    return {"train": train, "val": [{"t": g["val_t"], "y": g["val_y"], "u": g["val_u"]}]}
+
+
+def _grams(ctx, golden, model_type, degree, dim_red):
+    ks = kra.Ksysid(_arm(golden), ctx=ctx, model_type=model_type, obs_type=["poly"], obs_degree=[degree], snapshots=np.inf, lasso=[1.0], delays=0,
+                    dim_red=dim_red)
+    sp = ks.snapshotPairs
+    s = ks._resident_snapshots(sp["alpha"], sp["beta"], sp["u"])
+    G, C = kra.fit_gram(ctx, ks.basis_dev, s)
+    Kls = kra.fit(ctx, ks.basis_dev, s)[0]
+    return ks, s, G, C, Kls
+
+
+def _check_kkt(G, C, K, t, label):
+    theta, res_on, off, feas = ko.lasso_kkt(G, C, K, t)
+    noise = 256 * np.finfo(float).eps * (np.abs(G) @ np.abs(K)).max()           # rounding of g = G K - C itself (sums of W terms)
+    assert abs(feas - 1.0) <= 1e-11, (label, feas)
+    assert theta > -noise, (label, theta)
+    assert res_on <= 1e-9 * max(theta, 0.0) + noise, (label, res_on, theta, noise)
+    g = (G + G.T) / 2 @ K - C if np.linalg.eigvalsh((G + G.T) / 2).min() >= 0 else ((G + G.T) / 2 + 1e-6 * np.eye(len(G))) @ K - C
+    assert np.abs(g[K == 0]).max(initial=0.0) <= max(theta, 0.0) * (1 + 1e-6) + noise, (label, off)
+    return theta
+
+
+@pytest.mark.parametrize("model_type,degree,dim_red", [("bilinear", 2, True), ("linear", 2, True), ("linear", 3, False)],
+                         ids=["bilinear_poly2_dimred_W92", "linear_poly2_dimred_W26", "linear_poly3_W87_rank_deficient"])
+def test_lasso_on_the_arm_dictionaries_ends_in_the_homotopy_and_is_optimal(ctx, golden, model_type, degree, dim_red):
+    """kp_fit with lasso values 0.5 and 0.1 |K_LS|_1 / N on the arm data: the iteration hands over after 100 steps (timer 11 = the
+    homotopy's milliseconds), both values come from ONE path, and both satisfy the optimality conditions of the QP."""
+    ks, s, G, C, Kls = _grams(ctx, golden, model_type, degree, dim_red)
+    N = ks.params["N"]
+    l1 = float(np.abs(Kls).sum())
+    las = [0.5 * l1 / N, 0.1 * l1 / N]
+    Ks = kra.fit(ctx, ks.basis_dev, s, las)
+    assert ctx.timer(11) > 0.0                                                   # the homotopy ran
+    assert ctx.timer(11) < 200.0                                                 # milliseconds (was: 600 + ms and an error)
+    fs = []
+    for lv, K in zip(las, Ks):
+        _check_kkt(G, C, K, lv * N, (model_type, degree, lv))
+        fs.append(0.5 * (K * (G @ K)).sum() - (C * K).sum())
+    assert fs[0] < fs[1]                                                         # the larger budget fits better
+    assert (Ks[0] != 0).sum() >= (Ks[1] != 0).sum()
+
+
+def test_homotopy_against_the_numpy_homotopy_on_the_arm_gram(ctx, golden):
+    """linear poly-2 dim_red dictionary (W = 26, cond 5e9): the device's answer (inverse kept by rank-1 updates in LDS) against the
+    oracle's (a dense solve per step): same multiplier, same support, K to cond * eps, objective to 1e-12."""
+    ks, s, G, C, Kls = _grams(ctx, golden, "linear", 2, True)
+    l1 = float(np.abs(Kls).sum())
+    ts = [0.5 * l1, 0.1 * l1]
+    Ks, iters = ctx.fit_lasso_batch(G, C, ts)
+    assert ctx.timer(11) > 0.0
+    for t, K in zip(ts, Ks):
+        Ko, th = ko.koopman_lasso_path(G, C, t)
+        theta = _check_kkt(G, C, K, t, t)
+        assert abs(theta - th) <= 1e-5 * th
+        assert np.abs(K - Ko).max() <= 1e-5 * np.abs(Ko).max()
+        assert ((K != 0) == (Ko != 0)).mean() >= 0.995
+        f = lambda X: 0.5 * (X * (G @ X)).sum() - (C * X).sum()
+        assert abs(f(K) - f(Ko)) <= 1e-12 * abs(f(Ko))
+
+
+_SCRIPT = ("import sys, numpy as np; sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + '/tests')\n"
+           "import koopman_realizations_amd as kra\n"
+           "d = np.load(sys.argv[2]); c = kra.Context(0)\n"
+           "K, it = c.fit_lasso_batch(d['G'], d['C'], d['t'])\n"
+           "np.savez(sys.argv[3], K=np.stack(K), it=it, ms=c.timer(11))\n")
+
+
+def _in_fresh_process(G, C, t, env):
+    with tempfile.TemporaryDirectory() as td:
+        np.savez(os.path.join(td, "in.npz"), G=G, C=C, t=np.asarray(t, dtype=float))
+        r = subprocess.run([sys.executable, "-c", _SCRIPT, ROOT, os.path.join(td, "in.npz"), os.path.join(td, "out.npz")], env=dict(os.environ, **env),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        o = np.load(os.path.join(td, "out.npz"))
+        return o["K"], o["it"], float(o["ms"])
+
+
+@pytest.mark.parametrize("global_inverse", [False, True], ids=["inverse_in_lds", "inverse_in_memory"])
+def test_homotopy_alone_equals_the_projected_gradient_optimum(ctx, global_inverse):
+    """KP_LASSO_PATH_AFTER=0 (read once per process: a fresh interpreter) sends every active value straight to the homotopy: on a
+    well-conditioned synthetic problem (bilinear poly-2 on 4 states, W = 60, six budgets incl. an inactive one) its answers equal
+    the projected-gradient + active-set answers of the default path to 1e-8 - two algorithms, one optimum.  Both placements of
+    the inverse (LDS; global memory, KP_LASSO_PATH_GLOBAL=1 - the path supports beyond 128 entries take)."""
+    from conftest import synth_pairs
+    p = synth_pairs(5000, 4, 2, seed=3)
+    dic = ko.build_dictionary("bilinear", 4, 2, ["poly"], [2])
+    Px, Py = ko.px_py(dic, p)
+    G, C = ko.gram(Px, Py)
+    l1 = np.abs(np.linalg.solve(G, C)).sum()
+    ts = np.array([1.2, 0.9, 0.6, 0.3, 0.05, 0.005]) * l1
+    Kd, itd = ctx.fit_lasso_batch(G, C, ts, tol=1e-12)
+    assert ctx.timer(11) == 0.0                                                  # the default path needed no homotopy here
+    env = {"KP_LASSO_PATH_AFTER": "0"}
+    if global_inverse:
+        env["KP_LASSO_PATH_GLOBAL"] = "1"
+    Kh, ith, ms = _in_fresh_process(G, C, ts, env)
+    assert ms > 0.0 and ith[0] == 0 and (ith[1:] == 0).all()                     # no projected-gradient iteration at all
+    for v in range(len(ts)):
+        assert np.abs(Kh[v] - Kd[v]).max() <= 1e-8 * np.abs(Kd[v]).max(), v
+        if v > 0:
+            assert abs(np.abs(Kh[v]).sum() - ts[v]) <= 1e-11 * ts[v]
+    Ko = ko.koopman_lasso(G, C, ts[3])
+    assert np.abs(Kh[3] - Ko).max() <= 1e-8 * np.abs(Ko).max()
+
+
+def test_one_path_serves_the_whole_lasso_vector(ctx, golden):
+    """Values solved as one batch (one phase-1 walk, stops in decreasing theta) equal the values solved one call at a time - the
+    train_models loop of Ksysid.m:1372-1387 against its batched form - to the accuracy of the path (1e-6 max|K| at cond 3e10)."""
+    ks, s, G, C, Kls = _grams(ctx, golden, "bilinear", 2, True)
+    l1 = float(np.abs(Kls).sum())
+    ts = [0.7 * l1, 0.4 * l1, 0.2 * l1, 0.02 * l1]
+    Kb, _ = ctx.fit_lasso_batch(G, C, ts)
+    assert ctx.timer(11) > 0.0
+    for t, K in zip(ts, Kb):
+        K1, _ = ctx.fit_lasso(G, C, t)
+        assert np.abs(K1 - K).max() <= 1e-6 * np.abs(K).max()
+        _check_kkt(G, C, K, t, t)

@@ -1,0 +1,48 @@
+"""CPU tests of the oracle's regularisation-path solver of solve_KoopmanQP (oracle/koopman_oracle.py: koopman_lasso_path), the checker of
+the device's homotopy: pinned to the oracle's projected-gradient solver (itself the checker of the round 1-3 lasso tests) where that one
+converges, and to the optimality conditions of the QP of Ksysid.m:1126-1137 on an ill-conditioned monomial Gram where it does not."""
+import numpy as np
+
+from oracle import koopman_oracle as ko
+from conftest import synth_pairs
+
+
+def test_path_solver_equals_projected_gradient_on_a_well_conditioned_problem():
+    p = synth_pairs(3000, 3, 2, seed=5)
+    dic = ko.build_dictionary("bilinear", 3, 2, ["poly"], [2])
+    Px, Py = ko.px_py(dic, p)
+    G, C = ko.gram(Px, Py)
+    l1 = np.abs(np.linalg.solve(G, C)).sum()
+    for f in (0.9, 0.4, 0.03):
+        K1 = ko.koopman_lasso(G, C, f * l1)
+        K2, theta = ko.koopman_lasso_path(G, C, f * l1)
+        assert np.abs(K1 - K2).max() <= 1e-10 * np.abs(K1).max()
+        th, res_on, off, feas = ko.lasso_kkt(G, C, K2, f * l1)
+        assert abs(th - theta) <= 1e-9 * theta and res_on <= 1e-9 * theta and off <= 1 + 1e-9 and abs(feas - 1) <= 1e-12
+    K3, theta = ko.koopman_lasso_path(G, C, 1.5 * l1)                            # inactive L1 row: the least-squares solution
+    assert theta == 0.0 and np.abs(K3 - np.linalg.solve(G, C)).max() <= 1e-9 * np.abs(K3).max()
+
+
+def test_path_solver_is_optimal_on_an_ill_conditioned_monomial_gram():
+    """Degree-5 monomials of two strongly correlated smooth signals: cond(G) ~ 1e12.  The first-order oracle does not get there in
+    2e5 iterations (its answer keeps a larger objective); the path solver satisfies the optimality conditions."""
+    rng = np.random.default_rng(0)
+    ts = np.linspace(0, 6, 1500)
+    x = np.stack([np.sin(ts) + 0.01 * rng.standard_normal(ts.size), np.sin(ts + 0.05) + 0.01 * rng.standard_normal(ts.size)], 1)
+    cols = [x[:, 0] ** a * x[:, 1] ** b for a in range(6) for b in range(6 - a)]
+    Px = np.stack(cols, 1)[:-1]; Py = np.stack(cols, 1)[1:]
+    G, C = Px.T @ Px, Px.T @ Py
+    assert np.linalg.cond(G) > 1e9
+    Gq = (G + G.T) / 2
+    if np.linalg.eigvalsh(Gq).min() < 0:                                         # the PSD guard of Ksysid.m:1117-1120, as the solver applies it
+        Gq = Gq + 1e-6 * np.eye(len(Gq))
+    t = 0.5 * np.abs(np.linalg.solve(Gq, C)).sum()
+    K, theta = ko.koopman_lasso_path(G, C, t)
+    th, res_on, off, feas = ko.lasso_kkt(G, C, K, t)
+    noise = 64 * np.finfo(float).eps * (np.abs(G) @ np.abs(K)).max()
+    assert abs(feas - 1) <= 1e-10
+    assert res_on <= 1e-9 * theta + noise
+    assert off <= 1 + 1e-6 + noise / theta
+    f = lambda X: 0.5 * (X * (G @ X)).sum() - (C * X).sum()
+    Kpg = ko.koopman_lasso(G, C, t, iters=20000)
+    assert f(K) <= f(Kpg) + 1e-9 * abs(f(Kpg))
