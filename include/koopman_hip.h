@@ -51,7 +51,9 @@ int kp_device_info(const kp_ctx* ctx, char* name, int name_len, int* num_cu, int
  * After a run of pipelined fits (kp_fit with K_out == NULL) timer 0 is the MEAN duration of the last (up to 64) Gram
  * launches and which = 7 the number of launches in that mean.  which = 8: the first (widest) product G [K_1 ... K_nv] of the
  * most recent lasso batch, 9: its number of columns (kp_symm_gemm2_kernel: the FISTA iteration's product); 10: flop per snapshot pair the most recent
- * fused lift+Gram launch EXECUTES on the matrix pipe (padding and, for dim_red dictionaries, the projection included). */
+ * fused lift+Gram launch EXECUTES on the matrix pipe (padding and, for dim_red dictionaries, the projection included); 11: host
+ * milliseconds the most recent lasso batch spent in the regularisation-path homotopy (0: the projected-gradient iteration
+ * finished every value; kp_fit_lasso below). */
 int kp_timer_get(const kp_ctx* ctx, int which, double* ms);
 /* Device pointer + byte size of the library stream's raw handle, for profilers/benchmarks
  * that want to bracket work with their own HIP events: returns hipStream_t as void*. */
@@ -179,7 +181,10 @@ int kp_fit_lasso(kp_ctx* ctx, const double* G, const double* C, int W, int ncols
  * t: nv budgets; K: nv matrices W x ncols back to back; iters: nv counts (may be NULL; 0 = constraint inactive).
  * Each value ends either by convergence of the projected-gradient iteration (relative change <= tol) or, earlier, when
  * the active-set candidate built from its current support satisfies every optimality condition of the QP of
- * Ksysid.m:1126-1137 (then K is that QP's optimum to rounding).  KP_ERR_NOT_CONVERGED: iteration cap (K still written). */
+ * Ksysid.m:1126-1137 (then K is that QP's optimum to rounding), or - values still running after 100 iterations, W <= 384: the
+ * ill-conditioned Grams of monomial dictionaries on real data - by the regularisation-path homotopy (ONE LARS-with-drops path
+ * per column of K serves all of them; exact active-set optimum, |K|_1 = t to 1e-13; kp_timer_get(11) tells).
+ * KP_ERR_NOT_CONVERGED: iteration cap (K still written). */
 int kp_fit_lasso_batch(kp_ctx* ctx, const double* G, const double* C, int W, int ncols, const double* t, int nv,
                        int max_iter, double tol, double* K, int* iters);
 int kp_fit(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* snaps, const double* lasso,
