@@ -406,7 +406,7 @@ int kp_fit_gram_sharded(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* 
  *   kp_multi_timers        per device [upload, device work, result transfer, whole job] of the most recent call, ms (wall).
  *   kp_multi_ctx           worker i's context (kp_device_info, kp_timer_get, kp_last_error; not for concurrent use).
  * Lifetime: kp_multi_traj and kp_multi_mpc objects point into the workers' contexts - destroy them BEFORE kp_multi_destroy.  One
- * call at a time per kp_multi (calls from several threads are serialised by the object). */
+ * call at a time per kp_multi object: calls from several threads are serialised by it. */
 typedef struct kp_multi kp_multi;
 typedef struct kp_multi_traj kp_multi_traj;
 typedef struct kp_multi_mpc kp_multi_mpc;
