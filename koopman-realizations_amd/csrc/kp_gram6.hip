@@ -5,7 +5,7 @@
 // w_ab psi_x itself: 9 v_mul_f64 per (A group, k-step), 18-36 per wave and 8-snapshot tile beside 120 MFMAs - and on gfx950
 // nothing on the VALU overlaps the f64 MFMA stream of its SIMD (profiles/r01_coissue.txt).  A timing-only build without those
 // multiplies (KP_ABL3=7) runs the 1e5-pair, W = 336 launch in 0.360 instead of 0.395 ms.  Here the LIFT writes the weighted
-// columns: a Psi row is [psi_x w_0 | psi_x w_1 | ... | psi_x w_9 | psi_y | zero group], 11 x 84 + 4 doubles, so that every
+// columns: a Psi row is [ten weighted copies of psi_x, column by column | psi_y | zero group], 11 x 84 + 4 doubles, so that every
 // MFMA operand - A as well as B - is one ds_read_b64 with an immediate offset and the MFMA loop holds no multiply at all.  That
 // row is 7.4 KB; two buffers of eight rows are 121 KB, which leaves room for ONE workgroup per CU - so it has eight waves
 // (two per SIMD, as before), and three workgroups instead of seven serve a snapshot split: the tile is lifted 3 times instead
@@ -14,6 +14,9 @@
 // entries, the six quadratic ones are written by the raw-loader threads of the input rows (which fetch the other inputs of
 // their snapshot as well).  Per wave and tile that leaves ~20 multiplies of the lift, the power table and a handful of
 // address updates against 140 MFMAs.
+//
+// Status: OPT-IN (KP_GRAM6=1), exact, 0.565 ms against kp_gram3's 0.395 ms for the 1e5-pair launch: the compiler spills 66 dwords of
+// the 7-quad waves at 256 registers and surrounds the reads with ~100 v_mov_b64 / ~125 v_add_u32 per three tiles.
 //
 // Same partial layout, plan format and reduction as kp_gram3 ([split][job][quad][weight][lane]; kp_gram3_reduce_kernel), same
 // tail mask (the table's entries are 0 past Ns), bitwise reproducible.  Replaces the per-row lift loop of
