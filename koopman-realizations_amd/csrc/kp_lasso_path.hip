@@ -18,11 +18,12 @@
 // (tools/lasso_homotopy_probe2.py: without it the adds break down, with it the KKT conditions hold to 1e-10 after 450 steps).
 // M lives in LDS while the support is at most 128 entries (any W <= 384), else in global memory (template flag).
 //
-//   phase 1  all columns walk the path in rounds (theta targets theta_max / 16^r) and record (theta, |k|_1) at every breakpoint;
-//            after each round the host reads sum_j |k_j|_1 and stops once it covers the largest budget
+//   walk     all columns walk the path in rounds (theta targets theta_max / 16^r) and record (theta, |k|_1) at every breakpoint;
+//            after each round the host reads sum_j |k_j|_1: the values whose budget it now covers are bracketed by the round
 //   theta    sum_j |k_j(theta)|_1 is piecewise linear and decreasing: theta_v with sum = t_v by bisection on the recorded
-//            breakpoints, one workgroup per lasso value
-//   phase 2  the same walk again with stops at the theta_v in decreasing order; k_j(theta_v) is written at each stop
+//            breakpoints, one workgroup per bracketed value
+//   answers  from a copy of the state at the round's START the walk is repeated with stops at the theta_v in decreasing order
+//            and k_j(theta_v) written at each stop (only the bracketing round is walked twice); the walk then goes on
 #include "kp_internal.h"
 #include <algorithm>
 #include <chrono>
@@ -522,98 +523,116 @@ int kp_lasso_path_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_de
   if (!res || !hres) return ctx->fail(KP_ERR_HIP, "kp_fit_lasso: out of memory");
   for (int attempt = 0; attempt < 2; ++attempt) {
     const PathLayout L = make_layout(W, mglobal, cap + 2);
-    char* arena = (char*)ctx->workspace(12, L.stride * (size_t)ncols);
+    // two copies of the column states: the walk itself (with the breakpoint store) and the state at the start of the current round,
+    // from which the answers of the values that round brackets are walked
+    char* arena = (char*)ctx->workspace(12, 2 * L.stride * (size_t)ncols);
     if (!arena) return ctx->fail(KP_ERR_HIP, "kp_fit_lasso: out of device memory");
+    char* snap = arena + L.stride * (size_t)ncols;
     const size_t lds = ((mglobal ? 0 : (size_t)L.ldm * L.ldm) + 4 * (size_t)W + 5 * (size_t)L.ldm + 512) * 8 + ((size_t)L.ldm + 2 + W + 2 + 8) * 4 + 16 * 8;
-    auto launch = [&](double stop, int init, int record, double* Kout, int adjust = 0, double from = 0.0, int polish = 0) -> int {
+    auto launch = [&](char* ar, double stop, int init, int record, double* Kout, int adjust = 0, double from = 0.0, int polish = 0) -> int {
       if (mglobal) {
-        hipLaunchKernelGGL(kp_lasso_path_kernel<true>, dim3(ncols), dim3(PT), lds, s, G_dev, C_dev, L, arena, stop, from, cap, init, record, adjust, polish, Kout);
+        hipLaunchKernelGGL(kp_lasso_path_kernel<true>, dim3(ncols), dim3(PT), lds, s, G_dev, C_dev, L, ar, stop, from, cap, init, record, adjust, polish, Kout);
       } else {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kp_lasso_path_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL(kp_lasso_path_kernel<false>, dim3(ncols), dim3(PT), lds, s, G_dev, C_dev, L, arena, stop, from, cap, init, record, adjust, polish, Kout);
+        hipLaunchKernelGGL(kp_lasso_path_kernel<false>, dim3(ncols), dim3(PT), lds, s, G_dev, C_dev, L, ar, stop, from, cap, init, record, adjust, polish, Kout);
       }
       KP_HIP(ctx, hipGetLastError());
       return KP_OK;
     };
-    auto summary = [&](double* dst_dev, double* dst_host) -> int {
-      hipLaunchKernelGGL(kp_lasso_path_sum_kernel, dim3(1), dim3(256), 0, s, arena, L.stride, ncols, dst_dev);
-      KP_HIP(ctx, hipMemcpyAsync(dst_host, dst_dev, 7 * 8, hipMemcpyDeviceToHost, s));
+    auto summary = [&](const char* ar) -> int {      // -> hres[0..6]
+      hipLaunchKernelGGL(kp_lasso_path_sum_kernel, dim3(1), dim3(256), 0, s, ar, L.stride, ncols, res);
+      KP_HIP(ctx, hipMemcpyAsync(hres, res, 7 * 8, hipMemcpyDeviceToHost, s));
       KP_HIP(ctx, hipStreamSynchronize(s));
       return KP_OK;
     };
-    // ---- phase 1
-    int rc = launch(INFINITY, 1, 1, nullptr);       // initialisation only: theta_stop above every start
+    int rc = launch(arena, INFINITY, 1, 1, nullptr);      // initialisation only: theta_stop above every start
     if (rc) return rc;
-    rc = summary(res, hres);
+    rc = summary(arena);
     if (rc) return rc;
     const double theta_max = hres[1];
+    if (!(theta_max > 0.0)) {                        // C = 0: K = 0 for every budget
+      for (int v = 0; v < nv; ++v) KP_HIP(ctx, hipMemsetAsync(K_dev[v], 0, (size_t)W * ncols * 8, s));
+      if (stats) { stats[0] = 0; stats[1] = 0; stats[2] = 0; stats[3] = mglobal ? 1.0 : 0.0; }
+      return KP_OK;
+    }
+    double* t_dev = res + 8;
+    double* th_dev = res + 8 + nv;
+    double* h_t = hres + 8;
+    double* h_th = hres + 8 + nv;
+    std::vector<char> finished(nv, 0);
+    int nfin = 0;
     double stop = theta_max, steps1 = 0, maxcnt = 0;
-    bool overflow = false, done = false;
-    int status = 0;
-    if (!(theta_max > 0.0)) done = true;            // C = 0: K = 0
-    while (!done) {
+    bool overflow = false;
+    int status = PATH_OK;
+    while (nfin < nv) {
+      // the state (not the breakpoint store) at the start of the round
+      KP_HIP(ctx, hipMemcpy2DAsync(snap, L.stride, arena, L.stride, L.off_bpt, (size_t)ncols, hipMemcpyDeviceToDevice, s));
       stop = stop > theta_max * 1e-18 ? stop * (1.0 / 16.0) : 0.0;
-      rc = launch(stop, 0, 1, nullptr);
+      rc = launch(arena, stop, 0, 1, nullptr);
       if (rc) return rc;
-      rc = summary(res, hres);
+      rc = summary(arena);
       if (rc) return rc;
-      status = (int)hres[2]; steps1 = hres[3]; maxcnt = hres[5];
+      status = (int)hres[2]; steps1 = hres[3]; maxcnt = std::max(maxcnt, hres[5]);
       if (status == PATH_OVERFLOW) { overflow = true; break; }
       if (status != PATH_OK) break;
-      if (hres[0] >= tmax || stop == 0.0) done = true;
+      const double l1_end = hres[0];
+      // values whose budget this round reaches (all that are left once theta = 0 is reached: their constraint is inactive)
+      std::vector<int> br;
+      for (int v = 0; v < nv; ++v)
+        if (!finished[v] && (t[v] <= l1_end || stop == 0.0)) br.push_back(v);
+      if (br.empty()) continue;
+      const int nb = (int)br.size();
+      for (int q = 0; q < nb; ++q) h_t[q] = t[br[q]];
+      KP_HIP(ctx, hipMemcpyAsync(t_dev, h_t, (size_t)nb * 8, hipMemcpyHostToDevice, s));
+      hipLaunchKernelGGL(kp_lasso_path_theta_kernel, dim3(nb), dim3(256), 0, s, arena, L, ncols, t_dev, stop, theta_max, th_dev);
+      KP_HIP(ctx, hipMemcpyAsync(h_th, th_dev, (size_t)nb * 8, hipMemcpyDeviceToHost, s));
+      KP_HIP(ctx, hipStreamSynchronize(s));
+      std::vector<double> theta(nb);
+      std::vector<char> active(nb);
+      for (int q = 0; q < nb; ++q) { active[q] = h_th[q] >= 0.0; theta[q] = active[q] ? h_th[q] : 0.0; }      // budget not reached at theta = 0: K(0)
+      std::vector<int> order(nb);
+      std::iota(order.begin(), order.end(), 0);
+      std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return theta[x] > theta[y]; });
+      // the answers: from the round's start to every theta_v in decreasing order.  At cond 1e10 two walks with different stops agree
+      // on |K|_1 to ~1e-7 only, so the budget is met by Newton steps on the actual sums: along a segment |K(theta)|_1 is linear with
+      // slope sum_j s_j'G_SS^-1 s_j - a small gap (or one backwards) by a move inside the segment, a larger one forwards by walking on
+      for (int qq = 0; qq < nb; ++qq) {
+        const int q = order[qq], v = br[q];
+        double cur = theta[q];
+        rc = launch(snap, cur, 0, 0, K_dev[v], 0, 0.0, 1);
+        if (rc) return rc;
+        for (int corr = 0; active[q] && corr < 16; ++corr) {
+          rc = summary(snap);
+          if (rc) return rc;
+          if ((int)hres[2] != PATH_OK) return ctx->fail(KP_ERR_NOT_CONVERGED, "kp_fit_lasso: homotopy failed in its second pass");
+          const double gap = t[v] - hres[0], slope = hres[6];
+          if (fabs(gap) <= 1e-13 * t[v] || !(slope > 0.0)) break;
+          if (corr == 15) {
+            if (fabs(gap) <= 1e-9 * t[v]) break;
+            return ctx->fail(KP_ERR_NOT_CONVERGED, "kp_fit_lasso: homotopy passes disagree on |K|_1");
+          }
+          const double next = cur - gap / slope;
+          if (!(next > 0.0) || next == cur) break;
+          // (|K(theta)|_1 is convex in theta: a Newton step forwards over breakpoints lands past the budget; backwards there is only
+          // the move inside the segment - past the segment's start it leaves the path by O(gap), the accuracy of the walk itself)
+          if (fabs(gap) > 1e-3 * t[v]) return ctx->fail(KP_ERR_NOT_CONVERGED, "kp_fit_lasso: homotopy passes disagree on |K|_1");
+          if (fabs(gap) <= 1e-6 * t[v] || gap < 0.0) rc = launch(snap, next, 0, 0, K_dev[v], 1, cur, 0);
+          else rc = launch(snap, next, 0, 0, K_dev[v], 0, 0.0, 1);
+          if (rc) return rc;
+          cur = next;
+        }
+        finished[v] = 1;
+        ++nfin;
+      }
+      rc = summary(snap);
+      if (rc) return rc;
+      if ((int)hres[2] != PATH_OK) return ctx->fail(KP_ERR_NOT_CONVERGED, "kp_fit_lasso: homotopy failed in its second pass");
     }
     if (overflow && !mglobal) { mglobal = true; continue; }      // supports beyond the LDS-resident inverse: again with M in memory
     if (status != PATH_OK)
       return ctx->fail(KP_ERR_NOT_CONVERGED, status == PATH_STEPS ? "kp_fit_lasso: homotopy step cap reached"
                                              : status == PATH_BP ? "kp_fit_lasso: homotopy breakpoint store full"
                                                                  : "kp_fit_lasso: homotopy met a singular support (dependent dictionary columns)");
-    // ---- theta of every value
-    double* t_dev = res + 8;
-    double* th_dev = res + 8 + nv;
-    double* h_t = hres + 8;
-    double* h_th = hres + 8 + nv;
-    for (int v = 0; v < nv; ++v) h_t[v] = t[v];
-    KP_HIP(ctx, hipMemcpyAsync(t_dev, h_t, (size_t)nv * 8, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(kp_lasso_path_theta_kernel, dim3(nv), dim3(256), 0, s, arena, L, ncols, t_dev, stop, theta_max > 0.0 ? theta_max : 1.0, th_dev);
-    KP_HIP(ctx, hipMemcpyAsync(h_th, th_dev, (size_t)nv * 8, hipMemcpyDeviceToHost, s));
-    KP_HIP(ctx, hipStreamSynchronize(s));
-    std::vector<double> theta(nv);
-    for (int v = 0; v < nv; ++v) theta[v] = h_th[v] < 0.0 ? 0.0 : h_th[v];      // budget not reached at theta = 0: the constraint is inactive, K(0)
-    std::vector<int> order(nv);
-    std::iota(order.begin(), order.end(), 0);
-    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return theta[x] > theta[y]; });
-    // ---- phase 2: the walk again, a stop per value.  At cond 1e10 two walks with different stops agree on |K|_1 to ~1e-7 only, so
-    // the budget is met by Newton steps on the actual sums: along a segment |K(theta)|_1 is linear with slope sum_j s_j'G_SS^-1 s_j,
-    // forwards by walking on (events are handled), backwards (overshoot) by a move inside the current segment
-    for (int q = 0; q < nv; ++q) {
-      const int v = order[q];
-      double cur = theta[v];
-      rc = launch(cur, q == 0 ? 1 : 0, 0, K_dev[v], 0, 0.0, 1);
-      if (rc) return rc;
-      if (h_th[v] < 0.0) continue;                   // inactive constraint: K(0)
-      for (int corr = 0; corr < 8; ++corr) {
-        rc = summary(res, hres);
-        if (rc) return rc;
-        if ((int)hres[2] != PATH_OK) return ctx->fail(KP_ERR_NOT_CONVERGED, "kp_fit_lasso: homotopy failed in its second pass");
-        const double gap = t[v] - hres[0], slope = hres[6];
-        if (fabs(gap) <= 1e-13 * t[v] || !(slope > 0.0)) break;
-        if (corr == 7) {
-          if (fabs(gap) <= 1e-9 * t[v]) break;
-          return ctx->fail(KP_ERR_NOT_CONVERGED, "kp_fit_lasso: homotopy passes disagree on |K|_1");
-        }
-        const double next = cur - gap / slope;
-        if (!(next > 0.0) || next == cur) break;
-        // small gaps: a move inside the segment (either direction; exact in |K|_1); larger ones forwards by walking on, with events
-        if (fabs(gap) <= 1e-6 * t[v]) rc = launch(next, 0, 0, K_dev[v], 1, cur, 0);
-        else if (gap > 0.0) rc = launch(next, 0, 0, K_dev[v], 0, 0.0, 1);
-        else return ctx->fail(KP_ERR_NOT_CONVERGED, "kp_fit_lasso: homotopy passes disagree on |K|_1");
-        if (rc) return rc;
-        cur = next;
-      }
-    }
-    rc = summary(res, hres);
-    if (rc) return rc;
-    if ((int)hres[2] != PATH_OK) return ctx->fail(KP_ERR_NOT_CONVERGED, "kp_fit_lasso: homotopy failed in its second pass");
     if (stats) {
       stats[0] = steps1; stats[1] = maxcnt;
       stats[2] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
