@@ -31,7 +31,8 @@
 #include <vector>
 
 namespace {
-constexpr int PT = 256;             // threads per column
+constexpr int P_TPB_LDS = 256;      // threads per column, inverse in LDS
+constexpr int P_TPB_GLOBAL = 1024;  // ... inverse in global memory (supports beyond 128: the products are long)
 constexpr int P_LDS_CAP = 128;      // support entries the LDS-resident inverse holds
 constexpr int P_WMAX = 384;         // widest dictionary (the W-length vectors live in LDS)
 constexpr int P_RESYNC = 16;        // steps between re-synchronisations of r = c - G k and of r_S = theta s_S
@@ -72,29 +73,43 @@ __device__ __forceinline__ double wsum(double v) {
   return v;
 }
 
-// y[t] = sum_{q < n} M[q * ld + t] x[q], t < n  (M symmetric: column q read with consecutive t).  Rows are split over
-// P = PT / TP column ranges (TP = 64, 128 or 256 threads of rows), partial sums combined in a fixed order through `red`.
-template <class MP>
-__device__ __forceinline__ void mv_sym(const MP M, int ld, int n, const double* __restrict__ x, double* __restrict__ y, double* __restrict__ red) {
+// y[t] = sum_{q < n} M[q * ld + t] x[q], t < n  (M symmetric: column q read with consecutive t).  TP = 64 ... TPB threads of rows
+// times P = TPB / TP column ranges, partial sums combined in a fixed order through `red` (TPB doubles).
+template <int TPB>
+__device__ __forceinline__ void mv_sym(const double* M, int ld, int n, const double* __restrict__ x, double* __restrict__ y, double* __restrict__ red) {
   const int tid = threadIdx.x;
   if (n <= 0) { __syncthreads(); return; }
-  const int TP = n <= 64 ? 64 : n <= 128 ? 128 : 256;
-  const int P = PT / TP;
-  if (TP == 256) {                                  // rows beyond 256: every thread owns rows tid, tid + 256
-    for (int t = tid; t < n; t += PT) {
-      double acc = 0.0;
-      for (int q = 0; q < n; ++q) acc += M[(size_t)q * ld + t] * x[q];
-      y[t] = acc;
+  int TP = 64;
+  while (TP < n && TP < TPB) TP *= 2;
+  const int P = TPB / TP;
+  if (P == 1) {                                     // every thread owns rows tid, tid + TPB, ... over all columns
+    for (int t = tid; t < n; t += TPB) {
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+      int q = 0;
+      for (; q + 3 < n; q += 4) {
+        a0 += M[(size_t)q * ld + t] * x[q];
+        a1 += M[(size_t)(q + 1) * ld + t] * x[q + 1];
+        a2 += M[(size_t)(q + 2) * ld + t] * x[q + 2];
+        a3 += M[(size_t)(q + 3) * ld + t] * x[q + 3];
+      }
+      for (; q < n; ++q) a0 += M[(size_t)q * ld + t] * x[q];
+      y[t] = (a0 + a1) + (a2 + a3);
     }
     __syncthreads();
     return;
   }
   const int t = tid & (TP - 1), p = tid / TP;
   const int q0 = (int)((long)n * p / P), q1 = (int)((long)n * (p + 1) / P);
-  double acc = 0.0;
-  if (t < n)
-    for (int q = q0; q < q1; ++q) acc += M[(size_t)q * ld + t] * x[q];
-  red[p * TP + t] = acc;
+  double a0 = 0.0, a1 = 0.0;
+  if (t < n) {
+    int q = q0;
+    for (; q + 1 < q1; q += 2) {
+      a0 += M[(size_t)q * ld + t] * x[q];
+      a1 += M[(size_t)(q + 1) * ld + t] * x[q + 1];
+    }
+    if (q < q1) a0 += M[(size_t)q * ld + t] * x[q];
+  }
+  red[p * TP + t] = a0 + a1;
   __syncthreads();
   if (p == 0 && t < n) {
     double s = red[t];
@@ -104,15 +119,29 @@ __device__ __forceinline__ void mv_sym(const MP M, int ld, int n, const double* 
   __syncthreads();
 }
 
+// M[q * ld + t] += sign * (u[t] u[q]) * inv for t, q < n: the bordering / deletion update (symmetric bit for bit)
+template <int TPB>
+__device__ __forceinline__ void rank1(double* M, int ld, int n, const double* __restrict__ u, double sinv) {
+  const int tid = threadIdx.x;
+  int TP = 64;
+  while (TP < n && TP < TPB) TP *= 2;
+  const int P = TPB / TP, t0 = tid & (TP - 1), pp = tid / TP;
+  for (int t = t0; t < n; t += TP) {
+    const double ut = u[t];
+    for (int q = pp; q < n; q += P) M[(size_t)q * ld + t] += (ut * u[q]) * sinv;
+  }
+}
+
 // y[r] = sum_{q < n} G[rows[r] + idx[q] * W] x[q], r < nr  (rows == nullptr: rows[r] = r).  A row is shared by PW adjacent lanes
-// (PW a power of two, 256 threads cover 256 / PW rows per pass) so that many independent L2 loads are in flight whatever nr is.
+// (PW a power of two, TPB threads cover TPB / PW rows per pass) so that many independent L2 loads are in flight whatever nr is.
+template <int TPB>
 __device__ __forceinline__ void mv_gather(const double* __restrict__ G, int W, const int* __restrict__ rows, int nr, const int* __restrict__ idx, int n,
                                           const double* __restrict__ x, double* __restrict__ y) {
   const int tid = threadIdx.x;
   int PW = 1;
-  while (PW < 64 && nr * PW * 2 <= PT) PW *= 2;
-  if (PW > 1 && n < PW) { while (PW > 1 && n < PW) PW >>= 1; }
-  const int part = tid & (PW - 1), rslot = tid / PW, rpp = PT / PW;
+  while (PW < 64 && nr * PW * 2 <= TPB) PW *= 2;
+  while (PW > 1 && n < PW) PW >>= 1;
+  const int part = tid & (PW - 1), rslot = tid / PW, rpp = TPB / PW;
   for (int r0 = 0; r0 < nr; r0 += rpp) {
     const int r = r0 + rslot;
     double acc = 0.0;
@@ -138,11 +167,12 @@ __device__ __forceinline__ void mv_gather(const double* __restrict__ G, int W, c
 struct Cand { double dl; int key; };                 // key = 2 * index + (sign < 0) for an entry, 2 * index | 0x40000000 for a leave
 __device__ __forceinline__ Cand cmin(Cand a, Cand b) { return (b.dl < a.dl || (b.dl == a.dl && b.key < a.key)) ? b : a; }
 
-template <bool MG>
-__global__ __launch_bounds__(PT) void kp_lasso_path_kernel(const double* __restrict__ G, const double* __restrict__ C, PathLayout L, char* __restrict__ arena,
+template <bool MG, int TPB>
+__global__ __launch_bounds__(TPB) void kp_lasso_path_kernel(const double* __restrict__ G, const double* __restrict__ C, PathLayout L, char* __restrict__ arena,
                                                            double theta_stop, double theta_from, int max_steps, int init, int record, int adjust, int polish, double* __restrict__ Kout) {
   extern __shared__ double sm[];
   const int W = L.W, ld = L.ldm, tid = threadIdx.x, col = blockIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int PT = TPB, NW = TPB / 64;
   char* base = arena + (size_t)col * L.stride;
   PathHdr* hdr = reinterpret_cast<PathHdr*>(base);
   double* gk = reinterpret_cast<double*>(base + L.off_k);
@@ -165,11 +195,14 @@ __global__ __launch_bounds__(PT) void kp_lasso_path_kernel(const double* __restr
   double* u = p; p += ld;
   double* g = p; p += ld;
   double* e = p; p += ld;
-  double* red = p; p += 512;
+  double* red = p; p += TPB;
   int* idx = reinterpret_cast<int*>(p);
   int* offl = idx + ld + (ld & 1);
-  int* sc_i = offl + W + (W & 1);                    // [0] noff, [1..4] per-wave counts
-  double* sc_d = reinterpret_cast<double*>(sc_i + 8);   // [0..3] wave minima dl, [4..7] keys as doubles, [8..11] wave sums
+  int* sc_i = offl + W + (W & 1);                    // [0] noff, [1..16] per-wave counts, [17] position of the leaving entry
+  double* sc_d = reinterpret_cast<double*>(sc_i + 24);  // [0..15] wave minima dl, [16..23] their keys (ints), [24..39] wave sums
+  int* sc_k = reinterpret_cast<int*>(sc_d + 16);
+  double* sc_s = sc_d + 24;
+  auto sum_waves = [&]() { double v = sc_s[0]; for (int w = 1; w < NW; ++w) v += sc_s[w]; return v; };
   double* const M = MG ? gM : Ml;                    // the inverse on the support: global memory or LDS
 
   double theta, l1, last_del_sgn;
@@ -185,10 +218,10 @@ __global__ __launch_bounds__(PT) void kp_lasso_path_kernel(const double* __restr
       Cand b{__shfl_xor(best.dl, o, 64), __shfl_xor(best.key, o, 64)};
       if (b.dl > best.dl || (b.dl == best.dl && b.key < best.key)) best = b;
     }
-    if (lane == 0) { sc_d[wave] = best.dl; sc_d[4 + wave] = (double)best.key; }
+    if (lane == 0) { sc_d[wave] = best.dl; sc_k[wave] = best.key; }
     __syncthreads();
-    best = Cand{sc_d[0], (int)sc_d[4]};
-    for (int w = 1; w < 4; ++w) { const Cand b{sc_d[w], (int)sc_d[4 + w]}; if (b.dl > best.dl || (b.dl == best.dl && b.key < best.key)) best = b; }
+    best = Cand{sc_d[0], sc_k[0]};
+    for (int w = 1; w < NW; ++w) { const Cand b{sc_d[w], sc_k[w]}; if (b.dl > best.dl || (b.dl == best.dl && b.key < best.key)) best = b; }
     __syncthreads();
     theta = best.dl; l1 = 0.0; last_del_sgn = 0.0; steps = 0; cnt = 0; last_add = -1; last_del = -1; status = PATH_OK; nbp = 0;
     const int j0 = best.key;
@@ -221,13 +254,13 @@ __global__ __launch_bounds__(PT) void kp_lasso_path_kernel(const double* __restr
     for (int pass = 0; pass < 2; ++pass) {
       for (int t = tid; t < cnt; t += PT) u[t] = k[idx[t]];
       __syncthreads();
-      mv_gather(G, W, nullptr, W, idx, cnt, u, a);
+      mv_gather<TPB>(G, W, nullptr, W, idx, cnt, u, a);
       for (int i = tid; i < W; i += PT) r[i] = c[i] - a[i];
       __syncthreads();
       if (pass == 1) break;
       for (int t = tid; t < cnt; t += PT) e[t] = r[idx[t]] - theta * sg[idx[t]];
       __syncthreads();
-      mv_sym(M, ld, cnt, e, g, red);
+      mv_sym<TPB>(M, ld, cnt, e, g, red);
       for (int t = tid; t < cnt; t += PT) k[idx[t]] += g[t];
       __syncthreads();
     }
@@ -243,9 +276,9 @@ __global__ __launch_bounds__(PT) void kp_lasso_path_kernel(const double* __restr
     if (steps % P_RESYNC == 0 && cnt > 0 && !adjust) resync();
     // ---- direction on the support, its image off the support
     for (int t = tid; t < cnt; t += PT) sS[t] = sg[idx[t]];
-    if (tid < 8) sc_i[tid] = 0;
+    if (tid < 24) sc_i[tid] = 0;
     __syncthreads();
-    mv_sym(M, ld, cnt, sS, d, red);
+    mv_sym<TPB>(M, ld, cnt, sS, d, red);
     // compact list of the rows off the support (order: by index)
     {
       int noff = 0;
@@ -257,7 +290,8 @@ __global__ __launch_bounds__(PT) void kp_lasso_path_kernel(const double* __restr
         __syncthreads();
         int before = noff;
         for (int w = 0; w < wave; ++w) before += sc_i[1 + w];
-        const int tot = sc_i[1] + sc_i[2] + sc_i[3] + sc_i[4];
+        int tot = 0;
+        for (int w = 0; w < NW; ++w) tot += sc_i[1 + w];
         if (off) offl[before + __popcll(mk & ((1ull << lane) - 1ull))] = i;
         noff += tot;
         __syncthreads();
@@ -266,7 +300,7 @@ __global__ __launch_bounds__(PT) void kp_lasso_path_kernel(const double* __restr
       __syncthreads();
     }
     const int noff = sc_i[0];
-    mv_gather(G, W, offl, noff, idx, cnt, d, a);     // a[rr] = (G d)_i for i = offl[rr]   (on the support (G d)_i = s_i)
+    mv_gather<TPB>(G, W, offl, noff, idx, cnt, d, a);     // a[rr] = (G d)_i for i = offl[rr]   (on the support (G d)_i = s_i)
     // ---- the first event
     Cand best{theta - theta_stop, 0x7fffffff};
     if (!adjust)
@@ -290,10 +324,10 @@ __global__ __launch_bounds__(PT) void kp_lasso_path_kernel(const double* __restr
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) best = cmin(best, Cand{__shfl_xor(best.dl, o, 64), __shfl_xor(best.key, o, 64)});
-    if (lane == 0) { sc_d[wave] = best.dl; reinterpret_cast<int*>(sc_d + 4)[wave] = best.key; }
+    if (lane == 0) { sc_d[wave] = best.dl; sc_k[wave] = best.key; }
     __syncthreads();
-    best = Cand{sc_d[0], reinterpret_cast<int*>(sc_d + 4)[0]};
-    for (int w = 1; w < 4; ++w) best = cmin(best, Cand{sc_d[w], reinterpret_cast<int*>(sc_d + 4)[w]});
+    best = Cand{sc_d[0], sc_k[0]};
+    for (int w = 1; w < NW; ++w) best = cmin(best, Cand{sc_d[w], sc_k[w]});
     const bool capped = best.key == 0x7fffffff;
     const double dl = best.dl;
     const double theta_new = capped ? theta_stop : theta - dl;
@@ -308,9 +342,9 @@ __global__ __launch_bounds__(PT) void kp_lasso_path_kernel(const double* __restr
     }
     for (int rr = tid; rr < noff; rr += PT) { const int i = offl[rr]; r[i] -= dl * a[rr]; }
     part = wsum(part);
-    if (lane == 0) sc_d[8 + wave] = part;
+    if (lane == 0) sc_s[wave] = part;
     __syncthreads();
-    l1 = sc_d[8] + sc_d[9] + sc_d[10] + sc_d[11];
+    l1 = sum_waves();
     theta = theta_new;
     if (!adjust) { last_add = -1; last_del = -1; last_del_sgn = 0.0; }
     __syncthreads();
@@ -319,20 +353,15 @@ __global__ __launch_bounds__(PT) void kp_lasso_path_kernel(const double* __restr
       if (best.key & 0x40000000) {
         // ---- entry ei leaves: M <- M - m m' / m_q on the rest, the last position moves into the hole
         int qd = 0;
-        for (int t = tid; t < cnt; t += PT) if (idx[t] == ei) sc_i[5] = t;
+        for (int t = tid; t < cnt; t += PT) if (idx[t] == ei) sc_i[17] = t;
         __syncthreads();
-        qd = sc_i[5];
+        qd = sc_i[17];
         for (int t = tid; t < cnt; t += PT) u[t] = M[(size_t)qd * ld + t];
         __syncthreads();
         const double inv = 1.0 / u[qd];
         l1 -= fabs(k[ei]);
         last_del = ei; last_del_sgn = sg[ei];
-        {
-          const int TP = cnt <= 64 ? 64 : cnt <= 128 ? 128 : 256;
-          const int P = PT / TP, t0 = tid & (TP - 1), pp = tid / TP;
-          for (int t = t0; t < cnt; t += TP)
-            for (int q = pp; q < cnt; q += P) M[(size_t)q * ld + t] -= (u[t] * u[q]) * inv;
-        }
+        rank1<TPB>(M, ld, cnt, u, -inv);
         __syncthreads();
         const int last = cnt - 1;
         if (qd != last) {
@@ -351,27 +380,22 @@ __global__ __launch_bounds__(PT) void kp_lasso_path_kernel(const double* __restr
         else {
           for (int t = tid; t < cnt; t += PT) g[t] = G[(size_t)ei * W + idx[t]];
           __syncthreads();
-          mv_sym(M, ld, cnt, g, u, red);
-          mv_gather(G, W, idx, cnt, idx, cnt, u, e);                   // e = G_SS u
+          mv_sym<TPB>(M, ld, cnt, g, u, red);
+          mv_gather<TPB>(G, W, idx, cnt, idx, cnt, u, e);                   // e = G_SS u
           for (int t = tid; t < cnt; t += PT) e[t] = g[t] - e[t];
           __syncthreads();
-          mv_sym(M, ld, cnt, e, d, red);                                // (d is free here: rebuilt every step)
+          mv_sym<TPB>(M, ld, cnt, e, d, red);                                // (d is free here: rebuilt every step)
           double dot = 0.0;
           for (int t = tid; t < cnt; t += PT) { const double ut = u[t] + d[t]; u[t] = ut; dot += g[t] * ut; }
           dot = wsum(dot);
-          if (lane == 0) sc_d[8 + wave] = dot;
+          if (lane == 0) sc_s[wave] = dot;
           __syncthreads();
           const double gpp = G[(size_t)ei * W + ei];
-          const double alpha = gpp - (sc_d[8] + sc_d[9] + sc_d[10] + sc_d[11]);
+          const double alpha = gpp - (sum_waves());
           if (!(alpha > 1e-15 * gpp)) { status = PATH_SINGULAR; }
           else {
             const double inv = 1.0 / alpha;
-            {
-              const int TP = cnt <= 64 ? 64 : cnt <= 128 ? 128 : 256;
-              const int P = PT / TP, t0 = tid & (TP - 1), pp = tid / TP;
-              for (int t = t0; t < cnt; t += TP)
-                for (int q = pp; q < cnt; q += P) M[(size_t)q * ld + t] += (u[t] * u[q]) * inv;
-            }
+            rank1<TPB>(M, ld, cnt, u, inv);
             for (int t = tid; t < cnt; t += PT) { const double v = -u[t] * inv; M[(size_t)cnt * ld + t] = v; M[(size_t)t * ld + cnt] = v; }
             if (tid == 0) { M[(size_t)cnt * ld + cnt] = inv; idx[cnt] = ei; sg[ei] = s; }
             cnt += 1;
@@ -399,20 +423,20 @@ __global__ __launch_bounds__(PT) void kp_lasso_path_kernel(const double* __restr
       double part = 0.0;
       for (int t = tid; t < cnt; t += PT) part += fabs(k[idx[t]]);
       part = wsum(part);
-      if (lane == 0) sc_d[8 + wave] = part;
+      if (lane == 0) sc_s[wave] = part;
       __syncthreads();
-      l1 = sc_d[8] + sc_d[9] + sc_d[10] + sc_d[11];
+      l1 = sum_waves();
       __syncthreads();
     }
     for (int t = tid; t < cnt; t += PT) sS[t] = sg[idx[t]];
     __syncthreads();
-    mv_sym(M, ld, cnt, sS, d, red);
+    mv_sym<TPB>(M, ld, cnt, sS, d, red);
     double part = 0.0;
     for (int t = tid; t < cnt; t += PT) part += sS[t] * d[t];
     part = wsum(part);
-    if (lane == 0) sc_d[8 + wave] = part;
+    if (lane == 0) sc_s[wave] = part;
     __syncthreads();
-    slope = sc_d[8] + sc_d[9] + sc_d[10] + sc_d[11];
+    slope = sum_waves();
   }
   for (int i = tid; i < W; i += PT) { gk[i] = k[i]; gr[i] = r[i]; gs[i] = sg[i]; }
   for (int t = tid; t < cnt; t += PT) gidx[t] = idx[t];
@@ -528,13 +552,14 @@ int kp_lasso_path_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_de
     char* arena = (char*)ctx->workspace(12, 2 * L.stride * (size_t)ncols);
     if (!arena) return ctx->fail(KP_ERR_HIP, "kp_fit_lasso: out of device memory");
     char* snap = arena + L.stride * (size_t)ncols;
-    const size_t lds = ((mglobal ? 0 : (size_t)L.ldm * L.ldm) + 4 * (size_t)W + 5 * (size_t)L.ldm + 512) * 8 + ((size_t)L.ldm + 2 + W + 2 + 8) * 4 + 16 * 8;
+    const int tpb = mglobal ? P_TPB_GLOBAL : P_TPB_LDS;
+    const size_t lds = ((mglobal ? 0 : (size_t)L.ldm * L.ldm) + 4 * (size_t)W + 5 * (size_t)L.ldm + tpb) * 8 + ((size_t)L.ldm + 2 + W + 2 + 24) * 4 + 40 * 8;
     auto launch = [&](char* ar, double stop, int init, int record, double* Kout, int adjust = 0, double from = 0.0, int polish = 0) -> int {
       if (mglobal) {
-        hipLaunchKernelGGL(kp_lasso_path_kernel<true>, dim3(ncols), dim3(PT), lds, s, G_dev, C_dev, L, ar, stop, from, cap, init, record, adjust, polish, Kout);
+        hipLaunchKernelGGL((kp_lasso_path_kernel<true, P_TPB_GLOBAL>), dim3(ncols), dim3(P_TPB_GLOBAL), lds, s, G_dev, C_dev, L, ar, stop, from, cap, init, record, adjust, polish, Kout);
       } else {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kp_lasso_path_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL(kp_lasso_path_kernel<false>, dim3(ncols), dim3(PT), lds, s, G_dev, C_dev, L, ar, stop, from, cap, init, record, adjust, polish, Kout);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kp_lasso_path_kernel<false, P_TPB_LDS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL((kp_lasso_path_kernel<false, P_TPB_LDS>), dim3(ncols), dim3(P_TPB_LDS), lds, s, G_dev, C_dev, L, ar, stop, from, cap, init, record, adjust, polish, Kout);
       }
       KP_HIP(ctx, hipGetLastError());
       return KP_OK;
