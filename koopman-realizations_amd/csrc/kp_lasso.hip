@@ -773,6 +773,20 @@ int kp_lasso_prepare(kp_ctx* ctx, const double* G_dev, const double* C_dev, int 
   KP_HIP(ctx, hipStreamSynchronize(s));
   p->L = dst[0]; p->l1_ls = dst[3]; p->bad = dst[4] != 0.0;
   if (!(p->L > 0.0)) return ctx->fail(KP_ERR_ARG, "kp_fit_lasso: Gram matrix is zero");
+  if (p->bad) {
+    // The factorisation broke down and Gw now carries the 1e-6 guard: the QP the reference solves from here on (Ksysid.m:1117-1137) is
+    // the one of the GUARDED matrix, which is positive definite - its least-squares solution decides which budgets are inactive
+    // (they get exactly that solution) and starts the others.  (L was computed on the guarded matrix already.)
+    rc = kp_chol_solve_dev(ctx, p->Gw, const_cast<double*>(C_dev), W, ncols, p->Kls);
+    if (rc) return rc;
+    hipLaunchKernelGGL(kp_reduce_partial_kernel<false>, dim3(KP_RED_PARTS), dim3(256), 0, s, p->Kls, n, part);
+    hipLaunchKernelGGL(kp_reduce_final_kernel, dim3(1), dim3(64), 0, s, part, scal);
+    hipLaunchKernelGGL(kp_lasso_prep_pack_kernel, dim3(1), dim3(1), 0, s, info_dev, scal, scal + 3);
+    KP_HIP(ctx, hipGetLastError());
+    KP_HIP(ctx, hipMemcpyAsync(dst, scal, sizeof(back), hipMemcpyDeviceToHost, s));
+    KP_HIP(ctx, hipStreamSynchronize(s));
+    if (dst[4] == 0.0) { p->l1_ls = dst[3]; p->bad = 0; }
+  }
   p->ready = true;
   return KP_OK;
 }
@@ -871,8 +885,10 @@ int kp_lasso_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, in
   const auto t_start = std::chrono::steady_clock::now();
   // Values still running after `path_after` iterations go to the regularisation-path homotopy (kp_lasso_path.hip): exact in
   // a bounded number of steps whatever cond(G) is, where this iteration needs O(sqrt(cond)) of them.  KP_LASSO_PATH_AFTER=-1
-  // disables it, 0 sends every active value there at once.
-  static const int path_after = [] { const char* e = getenv("KP_LASSO_PATH_AFTER"); return e ? atoi(e) : 100; }();
+  // disables it, 0 sends every active value there at once
+  static const int path_env = [] { const char* e = getenv("KP_LASSO_PATH_AFTER"); return e ? atoi(e) : -2; }();
+  // (default: 24 iterations - the first three checks - while the inverse fits LDS and the path costs 3 - 13 ms, 100 beyond)
+  const int path_after = path_env != -2 ? path_env : (W <= 128 ? 24 : 100);
   bool path_tried = false;
   std::string path_err;
   ctx->timers[11] = 0.0;

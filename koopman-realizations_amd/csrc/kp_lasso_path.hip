@@ -47,7 +47,7 @@ static_assert(sizeof(PathHdr) == 64, "header size");
 
 struct PathLayout {
   int W, ldm, cap;                  // width, leading dimension / capacity of M and of the support vectors, breakpoints per column
-  size_t off_k, off_r, off_sgn, off_idx, off_M, off_bpt, off_bpl, stride;
+  size_t off_k, off_r, off_sgn, off_idx, off_M, off_bpt, off_bpl, off_bpe, stride;
 };
 
 static PathLayout make_layout(int W, bool mglobal, int cap) {
@@ -63,6 +63,7 @@ static PathLayout make_layout(int W, bool mglobal, int cap) {
   L.off_M = o; o += (size_t)L.ldm * L.ldm * 8;
   L.off_bpt = o; o += (size_t)cap * 8;
   L.off_bpl = o; o += (size_t)cap * 8;
+  L.off_bpe = o; o += (((size_t)cap * 4 + 7) & ~(size_t)7);      // the event behind every breakpoint (debugging aid: KP_LASSO_PATH_DEBUG)
   L.stride = (o + 255) & ~(size_t)255;
   return L;
 }
@@ -182,6 +183,7 @@ __global__ __launch_bounds__(TPB) void kp_lasso_path_kernel(const double* __rest
   double* gM = reinterpret_cast<double*>(base + L.off_M);
   double* bpt = reinterpret_cast<double*>(base + L.off_bpt);
   double* bpl = reinterpret_cast<double*>(base + L.off_bpl);
+  int* bpe = reinterpret_cast<int*>(base + L.off_bpe);
   const double* c = C + (size_t)col * W;
   // LDS: [M (LDS mode)] k r sgn a (W each) | sS d u g e (ld each) | red (512) | idx (ld) offl (W) ints | scalars
   double* p = sm;
@@ -311,10 +313,11 @@ __global__ __launch_bounds__(TPB) void kp_lasso_path_kernel(const double* __rest
       for (int sgi = 0; sgi < 2; ++sgi) {
         const double s = sgi ? -1.0 : 1.0;
         const double den = s * ai - 1.0, num = s * ri - theta;
-        if (den != 0.0) {
+        if (den != 0.0 && !(i == last_del && s == last_del_sgn)) {
           const double dl = num / den;
-          if (dl > 1e-14 * theta && !(i == last_del && s == last_del_sgn)) best = cmin(best, Cand{dl, 2 * i + sgi});
-        }
+          if (dl > 1e-14 * theta) best = cmin(best, Cand{dl, 2 * i + sgi});
+          else if (num >= 0.0 && den < 0.0) best = cmin(best, Cand{0.0, 2 * i + sgi});     // on the boundary and moving out (a tie with the
+        }                                                                                  // event just taken: duplicate columns): enters now
       }
     }
     if (!adjust)
@@ -408,7 +411,7 @@ __global__ __launch_bounds__(TPB) void kp_lasso_path_kernel(const double* __rest
     if (record) {
       if (nbp >= L.cap) { status = PATH_BP; }
       else {
-        if (tid == 0) { bpt[nbp] = theta; bpl[nbp] = l1; }
+        if (tid == 0) { bpt[nbp] = theta; bpl[nbp] = l1; bpe[nbp] = capped ? -1 : best.key; }
         ++nbp;
       }
     }
@@ -652,6 +655,25 @@ int kp_lasso_path_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_de
       rc = summary(snap);
       if (rc) return rc;
       if ((int)hres[2] != PATH_OK) return ctx->fail(KP_ERR_NOT_CONVERGED, "kp_fit_lasso: homotopy failed in its second pass");
+    }
+    static const bool debug = getenv("KP_LASSO_PATH_DEBUG") != nullptr;
+    if (debug) {                                     // the tail of the recorded breakpoints of the first columns
+      KP_HIP(ctx, hipStreamSynchronize(s));
+      for (int j = 0; j < std::min(ncols, 3); ++j) {
+        PathHdr h;
+        KP_HIP(ctx, hipMemcpy(&h, arena + (size_t)j * L.stride, sizeof(h), hipMemcpyDeviceToHost));
+        const int nb_ = std::min(h.nbp, 64);
+        std::vector<double> bt(nb_), bl(nb_);
+        KP_HIP(ctx, hipMemcpy(bt.data(), arena + (size_t)j * L.stride + L.off_bpt + (size_t)(h.nbp - nb_) * 8, (size_t)nb_ * 8, hipMemcpyDeviceToHost));
+        KP_HIP(ctx, hipMemcpy(bl.data(), arena + (size_t)j * L.stride + L.off_bpl + (size_t)(h.nbp - nb_) * 8, (size_t)nb_ * 8, hipMemcpyDeviceToHost));
+        fprintf(stderr, "kp_lasso_path: column %d: theta0 %.4e theta %.4e |k|_1 %.8f steps %d support %d status %d breakpoints %d; tail:", j, h.theta0, h.theta, h.l1,
+                h.steps, h.cnt, h.status, h.nbp);
+        std::vector<int> be(nb_);
+        KP_HIP(ctx, hipMemcpy(be.data(), arena + (size_t)j * L.stride + L.off_bpe + (size_t)(h.nbp - nb_) * 4, (size_t)nb_ * 4, hipMemcpyDeviceToHost));
+        for (int i = 0; i < nb_; ++i)
+          fprintf(stderr, " (%.6e %.8f %s%d)", bt[i], bl[i], be[i] < 0 ? "stop" : (be[i] & 0x40000000) ? "del " : (be[i] & 1) ? "add- " : "add+ ", be[i] < 0 ? 0 : (be[i] & 0x3fffffff) >> 1);
+        fprintf(stderr, "\n");
+      }
     }
     if (overflow && !mglobal) { mglobal = true; continue; }      // supports beyond the LDS-resident inverse: again with M in memory
     if (status != PATH_OK)

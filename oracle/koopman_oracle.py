@@ -410,7 +410,10 @@ def _lasso_column_path(G, c, theta_stop, max_steps):
             den = s * a[io] - 1.0; num = s * r[io] - theta
             with np.errstate(divide="ignore", invalid="ignore"):
                 dl = num / den
-            ok = (den != 0) & (dl > 1e-14 * theta) & ~((io == last_del) & (s == last_del_sgn))
+            allowed = (den != 0) & ~((io == last_del) & (s == last_del_sgn))
+            ok = allowed & (dl > 1e-14 * theta)
+            now = allowed & ~ok & (num >= 0) & (den < 0)       # on the boundary and moving out (a tie with the event just taken): enters now
+            dl = np.where(now, 0.0, dl); ok = ok | now
             if ok.any():
                 j = int(np.argmin(np.where(ok, dl, np.inf)))
                 if dl[j] < best:

@@ -46,3 +46,27 @@ def test_path_solver_is_optimal_on_an_ill_conditioned_monomial_gram():
     f = lambda X: 0.5 * (X * (G @ X)).sum() - (C * X).sum()
     Kpg = ko.koopman_lasso(G, C, t, iters=20000)
     assert f(K) <= f(Kpg) + 1e-9 * abs(f(Kpg))
+
+
+def test_path_solver_takes_tied_entries_together():
+    """Two identical dictionary columns under the 1e-6 PSD guard (Ksysid.m:1117-1120): their correlations tie at every event, the second
+    one sits ON the boundary and moves out - it has to enter in the same breath, and the strictly convex guarded problem splits the
+    weight equally between the twins (what the projected-gradient oracle finds)."""
+    rng = np.random.default_rng(1)
+    P = rng.standard_normal((300, 6)); P[:, 4] = P[:, 1]
+    Y = P @ rng.standard_normal((6, 6))
+    G, C = P.T @ P, P.T @ Y
+    Gg = (G + G.T) / 2
+    if np.linalg.eigvalsh(Gg).min() >= 0:
+        G = G - 1e-9 * np.eye(6)                                                  # make sure the guard applies, as on the device after a failed factorisation
+        Gg = (G + G.T) / 2
+    Gg = Gg + 1e-6 * np.eye(6)
+    Kg = np.linalg.solve(Gg, C)
+    for f in (0.7, 0.2):
+        t = f * np.abs(Kg).sum()
+        K, theta = ko.koopman_lasso_path(G, C, t)
+        assert np.abs(K[1] - K[4]).max() <= 1e-6 * np.abs(K).max()
+        K1 = ko.koopman_lasso(G, C, t)
+        assert np.abs(K - K1).max() <= 1e-6 * np.abs(K1).max()
+    K0, th0 = ko.koopman_lasso_path(G, C, 2.0 * np.abs(Kg).sum())
+    assert th0 == 0.0 and np.abs(K0 - Kg).max() <= 1e-6 * np.abs(Kg).max()

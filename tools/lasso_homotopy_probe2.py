@@ -70,7 +70,10 @@ class Path:
                 den = s * a[io] - 1.0; num = s * self.r[io] - th
                 with np.errstate(divide="ignore", invalid="ignore"):
                     dl = num / den
-                ok = (den != 0) & (dl > 1e-14 * th) & ~((io == self.last_del) & (s == self.last_del_sgn))
+                allowed = (den != 0) & ~((io == self.last_del) & (s == self.last_del_sgn))
+                ok = allowed & (dl > 1e-14 * th)
+                now = allowed & ~ok & (num >= 0) & (den < 0)
+                dl = np.where(now, 0.0, dl); ok = ok | now
                 if ok.any():
                     j = np.argmin(np.where(ok, dl, np.inf))
                     if dl[j] < best: best = dl[j]; ev = ("add", int(io[j]), s)
