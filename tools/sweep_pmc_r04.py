@@ -7,6 +7,7 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof_r04_sweep")
 short = lambda n: re.sub(r"\(.*$", "", re.sub(r"^void ", "", n))
+OLD = json.load(open(os.path.join(ROOT, "profiles", "r04_sweep_pmc_summary.json"))) if os.path.exists(os.path.join(ROOT, "profiles", "r04_sweep_pmc_summary.json")) else {"kernels": {}}
 out = {"command": "rocprofv3 --pmc <set> --kernel-trace -- python3 tools/sweep_profile.py 1024 (one run per counter set, tools/prof_r04.sh)", "kernels": defaultdict(dict)}
 for d in ("pmc_valu", "pmc_lds", "pmc_fetch", "pmc_write"):
     fs = glob.glob(os.path.join(SRC, d, "*", "*_counter_collection.csv"))
@@ -30,6 +31,14 @@ if st:
             out["kernels"][k]["calls"] = int(r["Calls"])
     shutil.copy(st, os.path.join(ROOT, "profiles", "r04_sweep_kernel_stats.csv"))
 out["kernels"] = dict(out["kernels"])
+# a counter pass that did not finish (the LDS set sat past its 300 s limit on the last run): its counters are carried over from the
+# previous summary and marked
+for k, v in out["kernels"].items():
+    if "SQ_INSTS_LDS" not in v and "SQ_INSTS_LDS" in OLD["kernels"].get(k, {}):
+        for c in ("SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_WAIT_INST_ANY"):
+            if c in OLD["kernels"][k]:
+                v[c] = OLD["kernels"][k][c]
+        v["lds_counters_from"] = "the previous run of this script (kernel before the pair permutation of the operand reads)"
 for k, v in out["kernels"].items():
     if "SQ_INSTS_VALU" in v and v.get("SQ_INSTS_VALU_MFMA_MOPS_F64"):
         v["valu_per_mfma_incl_the_mfma"] = v["SQ_INSTS_VALU"] / v["SQ_INSTS_VALU_MFMA_MOPS_F64"]
