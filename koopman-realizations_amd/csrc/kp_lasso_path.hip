@@ -395,8 +395,12 @@ __global__ __launch_bounds__(TPB) void kp_lasso_path_kernel(const double* __rest
           __syncthreads();
           const double gpp = G[(size_t)ei * W + ei];
           const double alpha = gpp - (sum_waves());
-          if (!(alpha > 1e-15 * gpp)) { status = PATH_SINGULAR; }
-          else {
+          if (!(alpha > 1e-10 * gpp)) {
+            // the entering column is (numerically) a combination of the support's columns - an exact twin in a Gram that got past
+            // the factorisation without the guard.  It adds nothing to the fit: barred from this column's support for good
+            // (sign 3: neither on the support nor in the list of rows off it), its weight stays with its twins
+            if (tid == 0) sg[ei] = 3.0;
+          } else {
             const double inv = 1.0 / alpha;
             rank1<TPB>(M, ld, cnt, u, inv);
             for (int t = tid; t < cnt; t += PT) { const double v = -u[t] * inv; M[(size_t)cnt * ld + t] = v; M[(size_t)t * ld + cnt] = v; }

@@ -146,3 +146,27 @@ def test_one_path_serves_the_whole_lasso_vector(ctx, golden):
         K1, _ = ctx.fit_lasso(G, C, t)
         assert np.abs(K1 - K).max() <= 1e-6 * np.abs(K).max()
         _check_kkt(G, C, K, t, t)
+
+
+def test_numerically_dependent_columns_are_barred_not_fatal(ctx):
+    """Two dictionary columns equal to 1e-7 relative: the Gram matrix passes the factorisation (no PSD guard), but in a column's walk
+    the second twin's bordering pivot is 1e-13 of its diagonal - it is barred from that support (its weight stays with the first
+    twin) instead of ending the homotopy.  The answers are optimal to the size of the perturbation: budget met, objective within
+    1e-9 of the oracle's on the same Grams, every other entry as the oracle's."""
+    rng = np.random.default_rng(7)
+    P = rng.standard_normal((2000, 12))
+    P[:, 7] = P[:, 2] * (1 + 1e-7 * rng.standard_normal(2000))
+    Y = P @ (rng.standard_normal((12, 12)) * (rng.random((12, 12)) < 0.5)) + 0.01 * rng.standard_normal((2000, 12))
+    G, C = P.T @ P, P.T @ Y
+    assert np.linalg.eigvalsh(G)[0] > 0
+    l1 = np.abs(ctx.fit_solve(G, C)).sum()             # the device's least-squares solution (one twin carries the pair's weight), not
+    Kh, ith, ms = _in_fresh_process(G, C, [0.6 * l1, 0.2 * l1], {"KP_LASSO_PATH_AFTER": "0"})      # numpy's (+-1e7 on the twins)
+    assert ms > 0.0
+    f = lambda X: 0.5 * (X * (G @ X)).sum() - (C * X).sum()
+    for K, t in zip(Kh, [0.6 * l1, 0.2 * l1]):
+        assert abs(np.abs(K).sum() - t) <= 1e-10 * t
+        Ko, _ = ko.koopman_lasso_path(G, C, t)
+        assert f(K) <= f(Ko) + 1e-9 * abs(f(Ko))
+        rows = [i for i in range(12) if i not in (2, 7)]
+        assert np.abs(K[rows] - Ko[rows]).max() <= 1e-5 * np.abs(Ko).max()
+        assert np.abs((K[2] + K[7]) - (Ko[2] + Ko[7])).max() <= 1e-5 * np.abs(Ko).max()     # the twins' joint weight
