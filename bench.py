@@ -226,6 +226,39 @@ def bench_lasso(ctx, comm, kra, basis, snaps, n_values=64):
                         "K stack gathered (BASELINE configs[3])"}
 
 
+def bench_lasso_ill_conditioned(ctx, kra):
+    """The lasso on a Gram matrix like those of the reference's own arm data (monomial dictionary on strongly correlated
+    states: cond(G) ~ 1e11): bilinear poly-2 dictionary on 6 states that are noisy mixtures of two latent signals, m = 3
+    (W = 112), 12 000 pairs, budgets 0.5 and 0.1 |K_LS|_1 (solve_KoopmanQP, Ksysid.m:1095-1176).  The projected-gradient
+    iteration cannot finish these (rounds 1-3: KP_ERR_NOT_CONVERGED after 0.6 s); kp_fit hands them to the regularisation-path
+    homotopy (csrc/kp_lasso_path.hip).  Reported: wall time of the kp_fit call, the homotopy's share, budget met."""
+    rng = np.random.default_rng(11)
+    Ns = 12000
+    ts = np.linspace(0.0, 60.0, Ns + 1)
+    lat = np.stack([np.sin(0.9 * ts), np.cos(0.37 * ts + 0.4)], 1)
+    Y = 0.8 * lat @ rng.uniform(-1, 1, (2, 6)) + 3e-3 * rng.standard_normal((Ns + 1, 6))
+    u = rng.uniform(-1, 1, (Ns, 3))
+    exps = kra.poly_exponent_table(6, 2)[6:]
+    b = kra.Basis(ctx, "bilinear", 6, 3, [("poly", exps)])
+    s_ = kra.Snapshots(ctx, np.ascontiguousarray(Y[:-1]), np.ascontiguousarray(Y[1:]), u)
+    G, C = kra.fit_gram(ctx, b, s_)
+    ev = np.linalg.eigvalsh((G + G.T) / 2)
+    Kls = kra.fit(ctx, b, s_)[0]
+    l1 = float(np.abs(Kls).sum())
+    las = [0.5 * l1 / b.N, 0.1 * l1 / b.N]
+    kra.fit(ctx, b, s_, las)                                                  # warm-up (allocations)
+    t0 = time.perf_counter()
+    Ks = kra.fit(ctx, b, s_, las)
+    dt = time.perf_counter() - t0
+    res = {"W": b.W, "pairs": Ns, "cond_G": float(ev[-1] / (ev[0] if ev[0] > 0 else 1e-6)), "budgets": "0.5 and 0.1 |K_LS|_1",
+           "ms": dt * 1e3, "homotopy_ms": ctx.timer(11),
+           "budget_met": bool(all(abs(np.abs(K).sum() - lv * b.N) <= 1e-9 * lv * b.N for K, lv in zip(Ks, las))),
+           "nnz": [int((K != 0).sum()) for K in Ks],
+           "workload": "synthetic arm-like data: 6 states = mixtures of 2 latent signals + 3e-3 noise, bilinear poly-2 dictionary"}
+    s_.close(); b.close()
+    return res
+
+
 RAND_CHUNK = 128
 
 
@@ -735,6 +768,11 @@ def main():
             a0, b0, u0 = synth_pairs(Ns, seed=0)
             snaps_l = kra.Snapshots(ctx, a0, b0, u0)
         lasso_res = bench_lasso(ctx, comm, kra, basis, snaps_l)
+        if lasso_res is not None and comm.rank == 0:
+            try:
+                lasso_res["ill_conditioned"] = bench_lasso_ill_conditioned(ctx, kra)
+            except Exception as e:                                                    # a secondary point never takes the line down
+                lasso_res["ill_conditioned"] = {"error": str(e)}
         sweep_res = bench_rand_sweep(ctx, comm, kra, chunks, n_chunks * RAND_CHUNK)
 
     if rank == 0:

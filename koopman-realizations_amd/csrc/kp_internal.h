@@ -346,7 +346,7 @@ int kp_lasso_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, int W, i
                  double* K_dev, int* iters, kp_lasso_prep* prep = nullptr);
 // the lasso values of one fit by the regularisation-path homotopy (kp_lasso_path.hip); stats: steps, largest support, ms, inverse in memory
 int kp_lasso_path_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, int W, int ncols, const double* t, int nv, double* const* K_dev,
-                            double* stats);
+                            double* stats, bool known_active = false);
 // all lasso values of one fit at once (one wide G*[K_1..K_nv] product per FISTA iteration, active-set polish)
 int kp_lasso_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, int W, int ncols, const double* t, int nv,
                        int max_iter, double tol, double* const* K_dev, int* iters, kp_lasso_prep* prep = nullptr);

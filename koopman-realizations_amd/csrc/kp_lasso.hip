@@ -899,7 +899,7 @@ int kp_lasso_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, in
       std::vector<double*> dst(nba);
       for (int v = 0; v < nba; ++v) { tv[v] = t[slot_val[v]]; dst[v] = K_dev[slot_val[v]]; }
       double pst[4] = {0, 0, 0, 0};
-      const int prc = kp_lasso_path_batch_dev(ctx, prep->Gw, C_dev, W, ncols, tv.data(), nba, dst.data(), pst);
+      const int prc = kp_lasso_path_batch_dev(ctx, prep->Gw, C_dev, W, ncols, tv.data(), nba, dst.data(), pst, !prep->bad);
       if (trace) fprintf(stderr, "kp_lasso: homotopy for %d values after %d iterations: rc %d, %.0f steps, largest support %.0f, %.3f ms%s\n", nba, it, prc, pst[0],
                          pst[1], pst[2], pst[3] != 0.0 ? " (inverse in global memory)" : "");
       if (prc == KP_OK) {

@@ -538,9 +538,9 @@ __global__ __launch_bounds__(256) void kp_lasso_path_theta_kernel(const char* __
 
 // The lasso values t[0..nv) of one fit by the homotopy: K_dev[v] (W x ncols, device) <- K(theta_v).  G_dev: the Gram matrix as the
 // QP uses it (PSD guard applied), C_dev: W x ncols.  stats (may be NULL): [0] steps of phase 1 over all columns, [1] largest support,
-// [2] milliseconds, [3] 1 when the inverse lived in global memory.
+// [2] milliseconds, [3] 1 when the inverse lived in global memory.  known_active: the caller's least-squares solution exceeds every budget.
 int kp_lasso_path_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, int W, int ncols, const double* t, int nv, double* const* K_dev,
-                            double* stats) {
+                            double* stats, bool known_active) {
   if (W > P_WMAX) return ctx->fail(KP_ERR_ARG, "kp_fit_lasso: the homotopy serves W <= 384");
   if (nv <= 0) return KP_OK;
   hipStream_t s = ctx->stream;
@@ -622,6 +622,10 @@ int kp_lasso_path_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_de
       std::vector<double> theta(nb);
       std::vector<char> active(nb);
       for (int q = 0; q < nb; ++q) { active[q] = h_th[q] >= 0.0; theta[q] = active[q] ? h_th[q] : 0.0; }      // budget not reached at theta = 0: K(0)
+      // the caller's least-squares solution exceeds these budgets, the walk's end does not reach them: at cond(G) ~ 1e13 the inverse
+      // kept by rank-1 updates has lost the directions that carry the difference - no answer rather than a wrong one
+      if (known_active && std::find(active.begin(), active.end(), (char)0) != active.end())
+        return ctx->fail(KP_ERR_NOT_CONVERGED, "kp_fit_lasso: homotopy lost accuracy (cond(G) beyond ~1e12)");
       std::vector<int> order(nb);
       std::iota(order.begin(), order.end(), 0);
       std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return theta[x] > theta[y]; });
