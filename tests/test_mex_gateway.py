@@ -507,8 +507,7 @@ def test_flow_of_ksysidhip_get_koopman_and_train_models(ctx, h, golden):
     assert np.abs(M @ UT[:N_, :N_] - MA).max() <= 1e-9 * np.abs(MA).max()            # out.A = M * UT(1:N,1:N), as the parent forms it
     mex("basis_destroy", b, nargout=0)
     # vector branch of train_models (lasso property below 1e6): ONE gateway call, a W x W x n stack, value i = the parent's loop
-    # (poly-3 with dim_red, the dictionary of example_sysid.m: cond(Px) 1.4e3.  The poly-2 one above has cond 1.9e5, i.e. cond(G)
-    #  3.6e10, where the projected-gradient lasso of the library reaches its iteration cap for tight budgets - DESIGN section 5)
+    # (poly-3 with dim_red, the dictionary of example_sysid.m: cond(Px) 1.4e3)
     kb = kra.Ksysid(data, ctx=ctx, model_type="bilinear", obs_type=["poly"], obs_degree=[3], snapshots=np.inf, lasso=[1.0], delays=0, dim_red=True)
     e3 = kra.poly_exponent_table(nv, 3)[nv:].astype(np.uint8)
     db = dict(d, model_type=np.int32(1), pcs=kb.basis["pcs"], block_count=np.array([[e3.shape[0]]], dtype=np.int32), poly_exps=np.asfortranarray(e3.T))
@@ -523,6 +522,20 @@ def test_flow_of_ksysidhip_get_koopman_and_train_models(ctx, h, golden):
         Ki = kb.koopData[i]["K"]
         assert np.abs(Ks[:, :, i] - Ki).max() <= 1e-9 * np.abs(Ki).max()
     mex("basis_destroy", bb, nargout=0)
+    # ... and on the poly-2 dictionary (cond(G) 3.5e10), where rounds 1-3 ended with "iteration cap reached": the values that the
+    # projected-gradient iteration cannot finish come from the regularisation-path homotopy (kp_lasso_path.hip), budget met exactly
+    kb2 = kra.Ksysid(data, ctx=ctx, model_type="bilinear", obs_type=["poly"], obs_degree=[2], snapshots=np.inf, lasso=[1.0], delays=0, dim_red=True)
+    db2 = dict(d, model_type=np.int32(1), pcs=kb2.basis["pcs"])
+    bb2 = mex("basis_create", hc, db2)
+    Kls2 = kra.fit(ctx, kb2.basis_dev, kb2._resident_snapshots(sp["alpha"], sp["beta"], sp["u"]))[0]
+    las2 = np.array([[0.5, 0.1]]) * np.abs(Kls2).sum() / kb2.params["N"]
+    Ks2 = mex("fit", hc, bb2, s, las2)
+    kb2.train_models(las2.ravel())
+    for i in range(2):
+        Ki = kb2.koopData[i]["K"]
+        assert np.abs(Ks2[:, :, i] - Ki).max() <= 1e-9 * np.abs(Ki).max()
+        assert abs(np.abs(Ks2[:, :, i]).sum() - las2[0, i] * kb2.params["N"]) <= 1e-11 * las2[0, i] * kb2.params["N"]
+    mex("basis_destroy", bb2, nargout=0)
     mex("destroy", hc, nargout=0)
 
 
