@@ -78,7 +78,7 @@ extern "C" int kp_destroy(kp_ctx* c) {
   kp_stage_destroy(c);
   (void)hipStreamSynchronize(c->stream);
   if (c->stream2) (void)hipStreamSynchronize(c->stream2);
-  for (int i = 0; i < 14; ++i)
+  for (int i = 0; i < 15; ++i)
     if (c->ws[i]) (void)hipFree(c->ws[i]);
   if (c->sticky_info) (void)hipFree(c->sticky_info);
   if (c->pin_small) (void)hipHostFree(c->pin_small);
@@ -381,6 +381,7 @@ extern "C" int kp_basis_destroy(kp_basis* b) {
   if (b->d_centres) (void)hipFree(b->d_centres);
   if (b->d_pcs) (void)hipFree(b->d_pcs);
   if (b->d_recipes) (void)hipFree(b->d_recipes);
+  if (b->d_pcsT) (void)hipFree(b->d_pcsT);
   if (b->d_recipes_ext) (void)hipFree(b->d_recipes_ext);
   kp_gram_plan_free(b->plan);
   kp_gram2_plan_free(b->plan2);

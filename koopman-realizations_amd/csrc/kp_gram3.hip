@@ -68,7 +68,7 @@
 
 // PCS: econ lift through a projection matrix (dim_red dictionaries)
 // EXT: fourier (def_fourierLift, Ksysid.m:694-731) and gaussian (def_gaussianLift, :790-817) blocks through the same table
-template <int NQ, int BM, bool PCS, bool EXT = false>
+template <int NQ, int BM, bool PCS, bool EXT = false, bool PRE = false>
 __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
   constexpr int NWT = (BM + 1) * (BM + 2) / 2;
   extern __shared__ __align__(16) double sm[];
@@ -258,6 +258,42 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
     if (tid < KT3) sm[BUF * POWBUF3 + CID * PST3 + tid] = x.ok ? 1.0 : 0.0;
   };
 
+  // ---- PRE: the tile comes lifted from memory (kp_gram3_prelift_kernel): entries [psi_x | psi_y | weights] x KT3 snapshots, two 16-byte pieces per thread ----
+  struct PreRegs { double2 v[2]; };
+  const int pre_n2 = PRE ? KT3 * a.pre_rl / 2 : 0;   // 16-byte pieces per tile (<= 512)
+  const double2* pre_ptr = PRE ? reinterpret_cast<const double2*>(a.pre + kt0 * KT3 * a.pre_rl) + tid : nullptr;
+  int pre_left = nkt;
+  bool pre_on[2] = {false, false};
+  int pre_dst[2] = {0, 0};
+  if (PRE) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int e = tid + j * 256;
+      pre_on[j] = e < pre_n2;
+      const int d0 = pre_on[j] ? 2 * e : 0;             // tile layout [row entry c][snapshot]: a piece = snapshots (s, s + 1) of entry c
+      const int c = d0 / KT3, srow = d0 - c * KT3;
+      const int off = c < 4 * a.G4 ? c : c < 8 * a.G4 ? YOFF3 + (c - 4 * a.G4) : WOFF3 + (c - 8 * a.G4);
+      pre_dst[j] = PSI03 + srow * RS3 + off;
+    }
+  }
+  auto load_pre = [&]() __attribute__((always_inline)) -> PreRegs {
+    PreRegs x;
+    x.v[0] = make_double2(0.0, 0.0);
+    x.v[1] = make_double2(0.0, 0.0);
+    if (pre_left > 0) {
+      if (pre_on[0]) x.v[0] = pre_ptr[0];
+      if (pre_on[1]) x.v[1] = pre_ptr[256];
+      pre_ptr += pre_n2;
+    }
+    --pre_left;
+    return x;
+  };
+  auto store_pre = [&](auto buf_c, const PreRegs& x) __attribute__((always_inline)) {
+    constexpr int BUF = decltype(buf_c)::value;
+    if (pre_on[0]) { sm[BUF * PSIBUF3 + pre_dst[0]] = x.v[0].x; sm[BUF * PSIBUF3 + pre_dst[0] + RS3] = x.v[0].y; }
+    if (pre_on[1]) { sm[BUF * PSIBUF3 + pre_dst[1]] = x.v[1].x; sm[BUF * PSIBUF3 + pre_dst[1] + RS3] = x.v[1].y; }
+  };
+
   // ---- lift of a snapshot tile: power-table buffer B -> Psi buffer B, in pipelined chunks ----
   constexpr int NCH = KT3 / 2;                       // chunks: snapshot pairs
   double2 lf[NF3];
@@ -339,17 +375,22 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
   };
 
   __syncthreads();
-  store_raw(B0{}, load_raw());
-  __syncthreads();
-  lift_begin(B0{});
+  if constexpr (PRE) {
+    store_pre(B0{}, load_pre());
+    __syncthreads();
+  } else {
+    store_raw(B0{}, load_raw());
+    __syncthreads();
+    lift_begin(B0{});
 #pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    lift_read(i, B0{});
-    lift_write(i, B0{});
+    for (int i = 0; i < NCH; ++i) {
+      lift_read(i, B0{});
+      lift_write(i, B0{});
+    }
+    store_raw(B1{}, load_raw());
+    __syncthreads();
+    if (PCS) project(B0{});
   }
-  store_raw(B1{}, load_raw());
-  __syncthreads();
-  if (PCS) project(B0{});
 
   constexpr int NSTEP = (KT3 / 4) * NQ;                 // quad steps (NWT MFMAs each) per snapshot tile
   constexpr int SP = NSTEP / NCH > 0 ? NSTEP / NCH : 1;
@@ -367,7 +408,8 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
     // compiler has spilled are reloaded at the top of the tile, and a scratch reload behind a global load waits for that
     // load too (vmcnt counts in order) - with the load up here every wave sat out its HBM latency at the start of every tile.
     RawRegs rawreg;
-    lift_begin(NXT{});
+    PreRegs prereg;
+    if constexpr (!PRE) lift_begin(NXT{});
     double bvs[NSTEP];
     double aw[NWT];
     double wt[NWT];
@@ -400,7 +442,10 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
 #pragma unroll
     for (int step = 0; step < NSTEP; ++step) {
       const int kk = step / NQ, q = step % NQ;
-      if (step == (NSTEP > KP_RAW_STEP ? KP_RAW_STEP : 0)) rawreg = load_raw();
+      if (step == (NSTEP > KP_RAW_STEP ? KP_RAW_STEP : 0)) {
+        if constexpr (PRE) prereg = load_pre();        // the NEXT tile, lifted; stored behind the MFMA loop
+        else rawreg = load_raw();
+      }
       if (q == 0) {
         weigh(avn0);
         if (QS < NQ) av1 = avn1;
@@ -423,19 +468,24 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
       for (int w = 0; w < NWT; ++w) acc[q][w] = __builtin_amdgcn_mfma_f64_4x4x4f64(aw[w], bv, acc[q][w], 0, 0, 0);
 #if KP_ABL3 != 1 && KP_ABL3 != 6
       // one register set for the chunk in flight: the write of chunk i precedes the read of chunk i+1
-      if (step >= LAG && (step - LAG) % SP == 0 && (step - LAG) / SP < NCH) lift_write((step - LAG) / SP, NXT{});
-      if (step % SP == 0 && step / SP < NCH) lift_read(step / SP, NXT{});
+      if constexpr (!PRE) {
+        if (step >= LAG && (step - LAG) % SP == 0 && (step - LAG) / SP < NCH) lift_write((step - LAG) / SP, NXT{});
+        if (step % SP == 0 && step / SP < NCH) lift_read(step / SP, NXT{});
+      }
 #endif
       __builtin_amdgcn_sched_barrier(0);   // keep the hand-made software pipeline: no hoisting of later steps' LDS reads
     }
 #if KP_ABL3 != 1 && KP_ABL3 != 6
+    if constexpr (!PRE) {
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      if (i * SP >= NSTEP) lift_read(i, NXT{});
-      if (i * SP + LAG >= NSTEP) lift_write(i, NXT{});
+      for (int i = 0; i < NCH; ++i) {
+        if (i * SP >= NSTEP) lift_read(i, NXT{});
+        if (i * SP + LAG >= NSTEP) lift_write(i, NXT{});
+      }
     }
 #endif
-    store_raw(cur_c, rawreg);
+    if constexpr (PRE) store_pre(NXT{}, prereg);
+    else store_raw(cur_c, rawreg);
     __syncthreads();
     if (PCS) project(NXT{});
   };
@@ -593,20 +643,27 @@ static int make_plan3(kp_ctx* ctx, int N, int nwt, int nq_cap, kp_gram3_plan** o
   return KP_OK;
 }
 
-template <int NQ, int BM, bool PCS, bool EXT = false>
+template <int NQ, int BM, bool PCS, bool EXT = false, bool PRE = false>
 static hipError_t launch3b(const Gram3Args& a, int grid, size_t lds, hipStream_t st) {
   static KpLdsCache lds_cache;
   {
     const size_t lds_max = (size_t)(LDS3_DOUBLES + (PCS ? LDS3_PCS_DOUBLES : 0) + (EXT ? LDS3_GAUSS_DOUBLES : 0)) * sizeof(double);
-    hipError_t e = kp_ensure_lds(lds_cache, (const void*)kp_gram3_kernel<NQ, BM, PCS, EXT>, lds_max);
+    hipError_t e = kp_ensure_lds(lds_cache, (const void*)kp_gram3_kernel<NQ, BM, PCS, EXT, PRE>, lds_max);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL((kp_gram3_kernel<NQ, BM, PCS, EXT>), dim3(grid), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((kp_gram3_kernel<NQ, BM, PCS, EXT, PRE>), dim3(grid), dim3(256), lds, st, a);
   return hipGetLastError();
 }
 
 template <int NQ>
 static hipError_t launch3(const Gram3Args& a, int bm, int grid, size_t lds, hipStream_t st) {
+  if (a.pre) {                           // dim_red dictionary, econ lift done by kp_gram3_prelift_kernel
+    switch (bm) {
+      case 1: return launch3b<NQ, 1, false, false, true>(a, grid, lds, st);
+      case 2: return launch3b<NQ, 2, false, false, true>(a, grid, lds, st);
+      default: return launch3b<NQ, 3, false, false, true>(a, grid, lds, st);
+    }
+  }
   if (a.pcs) {
     if constexpr (NQ <= 4) {             // more quads per wave spill once the projection is inlined (plans of dim_red dictionaries stay below)
       switch (bm) {
@@ -639,6 +696,13 @@ static bool gram3_ext(const kp_basis* basis) {
          (basis->ext_ng == 0 || b.nzeta <= GNZMAX3) && !getenv("KP_NO_GRAM3_EXT");
 }
 
+// dim_red dictionaries: econ lift by kp_gram3_prelift_kernel (its power table: nzeta * depth entries x 256 threads of LDS)
+static bool gram3_prelift(const kp_basis* basis) {
+  static const bool off = getenv("KP_GRAM3_NO_PRELIFT") != nullptr;
+  const BasisDev& b = basis->dev;
+  return !off && b.k_pcs > 0 && b.k_pcs <= 32 && basis->fast && b.nzeta * basis->pow_depth <= 24;      // (2 x 24 entries x 256 threads: 96 KB of LDS)
+}
+
 bool kp_gram3_applicable(const kp_basis* basis) {
   const BasisDev& b = basis->dev;
   if (getenv("KP_NO_GRAM3")) return false;
@@ -666,13 +730,13 @@ int kp_gram3_launch(kp_ctx* ctx, const kp_basis* basis_c, const kp_snapshots* s,
     static const bool g6_on = getenv("KP_GRAM6") != nullptr;
     const bool g6 = g6_on && BM == 3 && b.k_pcs == 0 && !gram3_ext(basis) && kp_gram6_serves(7, (N + 3) / 4);
     int rc = g6 ? make_plan3(ctx, N, NWT, 7, &basis->plan3, 8, 7)
-                : make_plan3(ctx, N, NWT, b.k_pcs > 0 ? 4 : gram3_ext(basis) ? ext_cap : 6, &basis->plan3);
+                : make_plan3(ctx, N, NWT, b.k_pcs > 0 && !gram3_prelift(basis) ? 4 : gram3_ext(basis) ? ext_cap : 6, &basis->plan3);
     if (rc) return rc;
   }
   kp_gram3_plan& plan = *basis->plan3;
   const int nfull4 = (b.nfull + 3) / 4 * 4;
   const bool ext = gram3_ext(basis);
-  const size_t lds = (size_t)(LDS3_DOUBLES + (b.k_pcs > 0 ? 2 * nfull4 * 16 : 0) + (ext ? LDS3_GAUSS_DOUBLES : 0)) * sizeof(double);
+  const size_t lds = (size_t)(LDS3_DOUBLES + (b.k_pcs > 0 && !gram3_prelift(basis) ? 2 * nfull4 * 16 : 0) + (ext ? LDS3_GAUSS_DOUBLES : 0)) * sizeof(double);
   int64_t ktiles = (s->Ns + KT3 - 1) / KT3;
   int ncu = ctx->num_cu > 0 ? ctx->num_cu : 256;
   int wg_per_cu = plan.wpw == 8 ? 1 : 2;              // __launch_bounds__(256, 2): two workgroups share a CU (kp_gram6: one of eight waves)
@@ -692,6 +756,19 @@ int kp_gram3_launch(kp_ctx* ctx, const kp_basis* basis_c, const kp_snapshots* s,
   if (!part_base) return ctx->fail(KP_ERR_HIP, "kp_fit_gram: out of device memory");
   double* part = (double*)(part_base + (ctx->reduce_stream ? (size_t)ctx->part_flip * part_bytes : 0));
 
+  // dim_red dictionaries: the econ lift once per snapshot into a row buffer (kp_gram3_prelift_kernel), the Gram kernel loads tiles of it
+  const bool pre = gram3_prelift(basis);
+  const int pre_rl = 8 * plan.G4 + 12;
+  double* pre_buf = nullptr;
+  if (pre) {
+    if (!basis->d_pcsT) {
+      if (hipMalloc(&basis->d_pcsT, (size_t)b.nfull * 32 * 8) != hipSuccess) return ctx->fail(KP_ERR_HIP, "kp_fit_gram: out of device memory");
+      KP_HIP(ctx, kp_gram3_pcs_transpose_launch(b.pcs, b.nfull, b.k_pcs, (double*)basis->d_pcsT, ctx->stream));
+    }
+    pre_buf = (double*)ctx->workspace(14, (size_t)ktiles * KT3 * pre_rl * 8);
+    if (!pre_buf) return ctx->fail(KP_ERR_HIP, "kp_fit_gram: out of device memory");
+  }
+
   Gram3Args a;
   a.b = b;
   a.alpha = s->alpha;
@@ -710,8 +787,10 @@ int kp_gram3_launch(kp_ctx* ctx, const kp_basis* basis_c, const kp_snapshots* s,
   a.desc = plan.desc;
   a.part = part;
   a.njobs = plan.njobs;
-  a.pcs = b.k_pcs > 0 ? b.pcs : nullptr;
+  a.pcs = b.k_pcs > 0 && !pre ? b.pcs : nullptr;
   a.nfull4 = nfull4;
+  a.pre = pre_buf;
+  a.pre_rl = pre_rl;
   const int grid = plan.nsuper * nsplit;
   // every event record is a barrier packet the command processor works through between two Gram kernels: the
   // pipelined path keeps two (kernel start / end; the end also releases the reduction on the solve stream)
@@ -729,6 +808,9 @@ int kp_gram3_launch(kp_ctx* ctx, const kp_basis* basis_c, const kp_snapshots* s,
   }
   if (timed) KP_HIP(ctx, hipEventRecord(ev_start, ctx->stream));
   hipError_t e;
+  if (pre)
+    KP_HIP(ctx, kp_gram3_prelift_launch(BM, s->alpha, s->beta, s->u, s->Ns, ktiles * KT3, b.nzeta, basis->pow_depth, b.nfull, b.k_pcs, N, plan.G4,
+                                        (const uint32_t*)basis->d_recipes, (const double*)basis->d_pcsT, pre_buf, pre_rl, ctx->stream));
   if (plan.wpw == 8) e = kp_gram6_launch_kernel(a, plan.nq, grid, ctx->stream);
   else switch (plan.nq) {
     case 1: e = launch3<1>(a, BM, grid, lds, ctx->stream); break;
@@ -756,7 +838,7 @@ int kp_gram3_launch(kp_ctx* ctx, const kp_basis* basis_c, const kp_snapshots* s,
   ctx->gram_flops_per_pair = (double)W * (W + 1) + 2.0 * W * W;
   // executed on the matrix pipe per pair (timer 10): jobs (padding included) x quads x weights MFMAs per 4 snapshots, 512 flop
   // each; dim_red: + the projection pcs' psi of every workgroup of a split (2 x nfull4 / 4 MFMAs per wave and tile)
-  ctx->timers[10] = (double)plan.njobs * plan.nq * NWT * 128.0 + (b.k_pcs > 0 ? (double)plan.nsuper * nfull4 * 128.0 : 0.0);
+  ctx->timers[10] = (double)plan.njobs * plan.nq * NWT * 128.0 + (b.k_pcs > 0 && !pre ? (double)plan.nsuper * nfull4 * 128.0 : 0.0);
   return KP_OK;
 }
 
@@ -785,6 +867,7 @@ static kp_basis* gram3_shadow(const kp_basis* basis_c) {
     sh->dev.model_type = KP_MODEL_BILINEAR;
     sh->dev.W = sh->dev.N * (sh->dev.m + 1);
     sh->plan = nullptr; sh->plan2 = nullptr; sh->plan3 = nullptr; sh->plan5 = nullptr; sh->shadow_bil = nullptr;
+    sh->d_pcsT = nullptr;                              // (its own transposed projection matrix, built on first use)
     basis->shadow_bil = sh;
   }
   return basis->shadow_bil;
@@ -794,6 +877,7 @@ void kp_gram3_shadow_free(kp_basis* basis) {
   if (!basis) return;
   if (basis->shadow_bil) {
     kp_gram3_plan_free(basis->shadow_bil->plan3);
+    if (basis->shadow_bil->d_pcsT) (void)hipFree(basis->shadow_bil->d_pcsT);
     delete basis->shadow_bil;
     basis->shadow_bil = nullptr;
   }
@@ -898,6 +982,7 @@ static kp_basis* gram_shadow_full(const kp_basis* basis_c) {
     sh->dev.N = sh->dev.nfull;
     sh->dev.W = sh->dev.model_type == KP_MODEL_LINEAR ? sh->dev.nfull + sh->dev.m : sh->dev.nfull;
     sh->plan = nullptr; sh->plan2 = nullptr; sh->plan3 = nullptr; sh->plan5 = nullptr; sh->shadow_bil = nullptr; sh->shadow_full = nullptr;
+    sh->d_pcsT = nullptr;
     basis->shadow_full = sh;
   }
   return basis->shadow_full;

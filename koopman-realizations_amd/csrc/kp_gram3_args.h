@@ -23,8 +23,18 @@ struct Gram3Args {
   // EXT: table entries per variable = Dp powers, then df (cos, sin) pairs (D = Dp + 2 df); ng gaussian centres (nzeta each)
   int Dp, df, ng;
   const double* centres;
+  // PRE (dim_red dictionaries, kp_gram3_prelift_kernel): per tile of 8 snapshots the entries [psi_x (4 G4) | psi_y (4 G4) | 9 weights + 3
+  // zeros] of the econ lift as [entry][snapshot], zeros past Ns; pre_rl = entries per snapshot
+  const double* pre = nullptr;
+  int pre_rl = 0;
 };
 
 // one job per wave: kp_gram6_kernel<NQ, G4C> (kp_gram6.hip); hipErrorInvalidValue when no instantiation serves (nq, G4)
 bool kp_gram6_serves(int nq, int G4);
 hipError_t kp_gram6_launch_kernel(const Gram3Args& a, int nq, int grid, hipStream_t st);
+
+// kp_gram3_prelift.hip: the projection matrix as [full column][32 components] (zero padded), and the econ lift of every snapshot in the
+// tile layout of Gram3Args::pre
+hipError_t kp_gram3_pcs_transpose_launch(const double* pcs, int nfull, int k, double* pcsT, hipStream_t st);
+hipError_t kp_gram3_prelift_launch(int BM, const double* alpha, const double* beta, const double* u, int64_t Ns, int64_t Ns_pad, int nzeta, int D, int nfull, int k_pcs,
+                                   int N, int G4, const uint32_t* recipes, const double* pcsT, double* out, int rl, hipStream_t st);

@@ -75,8 +75,8 @@ struct kp_ctx {
   double timers[12] = {0};
   double gram_flops_per_pair = 0;
   // growable device workspaces
-  void* ws[14] = {nullptr};     // slot 8: staging of the collectives, 9: rank-revealing solve, 10 / 11: Grams of the shadow dictionary of a dim_red fit, their half-transformed form
-  size_t ws_bytes[14] = {0};   // 12 / 13: column states and results of the lasso homotopy (kp_lasso_path.hip)
+  void* ws[15] = {nullptr};     // slot 8: staging of the collectives, 9: rank-revealing solve, 10 / 11: Grams of the shadow dictionary of a dim_red fit, their half-transformed form
+  size_t ws_bytes[15] = {0};   // 12 / 13: column states and results of the lasso homotopy (kp_lasso_path.hip); 14: econ-lifted rows of a dim_red fit (kp_gram3.hip)
   int last_rank = -1;           // rank found by the most recent solve (W when the Gram matrix was positive definite)
   double last_pivot_ratio = 1.0; // min_i L_ii^2 / G_ii of the most recent synchronous least-squares solve (~1 / cond(G))
   // results of the last kp_fit
@@ -155,6 +155,7 @@ struct kp_basis {
   void* d_centres = nullptr;
   void* d_pcs = nullptr;
   void* d_recipes = nullptr;   // [nfull] uint32: 4 x 8-bit power-table ids (255 = 1.0)
+  void* d_pcsT = nullptr;      // dim_red: pcs as [full column][32 components], zero padded (kp_gram3_prelift_kernel; built on first use)
   int max_degree = 0;
   int pow_depth = 1;           // largest single-variable exponent
   bool fast = false;           // every column is a product of <= 4 single-variable powers

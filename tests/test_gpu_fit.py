@@ -535,3 +535,44 @@ def test_large_snapshot_counts_by_size_independent_properties(ctx, mt, Ns):
     K = kra.fit(ctx, b, sA)[0]
     assert np.abs(K[:, :6] - Kt).max() < 1e-9
     sA.close()
+
+
+_PRELIFT_SCRIPT = """
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + '/tests')
+import koopman_realizations_amd as kra
+from conftest import synth_pairs
+ctx = kra.Context(0)
+pcs = np.linalg.qr(np.random.default_rng(0).standard_normal((84, 27)))[0]
+out = {}
+for Ns in (100000, 4099, 5):
+    p = synth_pairs(Ns, seed=2)
+    b = kra.Basis(ctx, "bilinear", 6, 3, [("poly", kra.poly_exponent_table(6, 3)[6:])], pcs)
+    s = kra.Snapshots(ctx, p["alpha"], p["beta"], p["u"])
+    G, C = kra.fit_gram(ctx, b, s)
+    out["G%d" % Ns] = G; out["C%d" % Ns] = C
+np.savez(sys.argv[2], **out)
+"""
+
+
+def test_econ_lift_once_per_snapshot_equals_the_in_kernel_projection():
+    """dim_red bilinear dictionary (N = 34, W = 136, the shape of example_sysid.m): by default the econ lift [zeta; pcs' psi; 1]
+    (Ksysid.m:1594-1618) is formed once per snapshot by kp_gram3_prelift_kernel and the Kronecker kernel loads lifted tiles;
+    KP_GRAM3_NO_PRELIFT=1 (read once per process) keeps the projection inside every workgroup of the Gram kernel.  Same G, C to
+    rounding, at 1e5 pairs, with a ragged tail (4099) and with fewer pairs than one tile (5)."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    with tempfile.TemporaryDirectory() as td:
+        for name, env in (("pre", {}), ("proj", {"KP_GRAM3_NO_PRELIFT": "1"})):
+            f = os.path.join(td, name + ".npz")
+            r = subprocess.run([sys.executable, "-c", _PRELIFT_SCRIPT, root, f], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+            assert r.returncode == 0, r.stderr[-1500:]
+            res[name] = dict(np.load(f))
+    for k in res["pre"]:
+        a, b = res["pre"][k], res["proj"][k]
+        assert np.isfinite(a).all()
+        assert np.abs(a - b).max() <= 1e-12 * np.abs(b).max(), k
