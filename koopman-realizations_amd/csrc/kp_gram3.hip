@@ -696,11 +696,14 @@ static bool gram3_ext(const kp_basis* basis) {
          (basis->ext_ng == 0 || b.nzeta <= GNZMAX3) && !getenv("KP_NO_GRAM3_EXT");
 }
 
-// dim_red dictionaries: econ lift by kp_gram3_prelift_kernel (its power table: nzeta * depth entries x 256 threads of LDS)
+// dim_red dictionaries: econ lift by kp_gram3_prelift_kernel (its power table: 2 x nzeta * depth entries x 256 threads of LDS);
+// fourier / gaussian dictionaries: their table entries once per snapshot by kp_gram3_prelift_ext_kernel (kp_gram3_prelift.hip)
 static bool gram3_prelift(const kp_basis* basis) {
   static const bool off = getenv("KP_GRAM3_NO_PRELIFT") != nullptr;
   const BasisDev& b = basis->dev;
-  return !off && b.k_pcs > 0 && b.k_pcs <= 32 && basis->fast && b.nzeta * basis->pow_depth <= 24;      // (2 x 24 entries x 256 threads: 96 KB of LDS)
+  if (off) return false;
+  if (b.k_pcs > 0) return b.k_pcs <= 32 && basis->fast && b.nzeta * basis->pow_depth <= 24;      // (2 x 24 entries x 256 threads: 96 KB of LDS)
+  return gram3_ext(basis) && b.nzeta <= 16 && b.nzeta * (basis->ext_Dp + 2 * basis->ext_df) + basis->ext_ng + 1 <= 64;
 }
 
 bool kp_gram3_applicable(const kp_basis* basis) {
@@ -730,13 +733,13 @@ int kp_gram3_launch(kp_ctx* ctx, const kp_basis* basis_c, const kp_snapshots* s,
     static const bool g6_on = getenv("KP_GRAM6") != nullptr;
     const bool g6 = g6_on && BM == 3 && b.k_pcs == 0 && !gram3_ext(basis) && kp_gram6_serves(7, (N + 3) / 4);
     int rc = g6 ? make_plan3(ctx, N, NWT, 7, &basis->plan3, 8, 7)
-                : make_plan3(ctx, N, NWT, b.k_pcs > 0 && !gram3_prelift(basis) ? 4 : gram3_ext(basis) ? ext_cap : 6, &basis->plan3);
+                : make_plan3(ctx, N, NWT, gram3_prelift(basis) ? 6 : b.k_pcs > 0 ? 4 : gram3_ext(basis) ? ext_cap : 6, &basis->plan3);
     if (rc) return rc;
   }
   kp_gram3_plan& plan = *basis->plan3;
   const int nfull4 = (b.nfull + 3) / 4 * 4;
   const bool ext = gram3_ext(basis);
-  const size_t lds = (size_t)(LDS3_DOUBLES + (b.k_pcs > 0 && !gram3_prelift(basis) ? 2 * nfull4 * 16 : 0) + (ext ? LDS3_GAUSS_DOUBLES : 0)) * sizeof(double);
+  const size_t lds = (size_t)(LDS3_DOUBLES + (b.k_pcs > 0 && !gram3_prelift(basis) ? 2 * nfull4 * 16 : 0) + (ext && !gram3_prelift(basis) ? LDS3_GAUSS_DOUBLES : 0)) * sizeof(double);
   int64_t ktiles = (s->Ns + KT3 - 1) / KT3;
   int ncu = ctx->num_cu > 0 ? ctx->num_cu : 256;
   int wg_per_cu = plan.wpw == 8 ? 1 : 2;              // __launch_bounds__(256, 2): two workgroups share a CU (kp_gram6: one of eight waves)
@@ -761,7 +764,7 @@ int kp_gram3_launch(kp_ctx* ctx, const kp_basis* basis_c, const kp_snapshots* s,
   const int pre_rl = 8 * plan.G4 + 12;
   double* pre_buf = nullptr;
   if (pre) {
-    if (!basis->d_pcsT) {
+    if (!ext && !basis->d_pcsT) {
       if (hipMalloc(&basis->d_pcsT, (size_t)b.nfull * 32 * 8) != hipSuccess) return ctx->fail(KP_ERR_HIP, "kp_fit_gram: out of device memory");
       KP_HIP(ctx, kp_gram3_pcs_transpose_launch(b.pcs, b.nfull, b.k_pcs, (double*)basis->d_pcsT, ctx->stream));
     }
@@ -808,7 +811,10 @@ int kp_gram3_launch(kp_ctx* ctx, const kp_basis* basis_c, const kp_snapshots* s,
   }
   if (timed) KP_HIP(ctx, hipEventRecord(ev_start, ctx->stream));
   hipError_t e;
-  if (pre)
+  if (pre && ext)
+    KP_HIP(ctx, kp_gram3_prelift_ext_launch(BM, s->alpha, s->beta, s->u, s->Ns, ktiles * KT3, b.nzeta, basis->ext_Dp, basis->ext_df, basis->ext_ng, b.nfull, plan.G4,
+                                            (const uint32_t*)basis->d_recipes_ext, b.centres, pre_buf, pre_rl, ctx->stream));
+  else if (pre)
     KP_HIP(ctx, kp_gram3_prelift_launch(BM, s->alpha, s->beta, s->u, s->Ns, ktiles * KT3, b.nzeta, basis->pow_depth, b.nfull, b.k_pcs, N, plan.G4,
                                         (const uint32_t*)basis->d_recipes, (const double*)basis->d_pcsT, pre_buf, pre_rl, ctx->stream));
   if (plan.wpw == 8) e = kp_gram6_launch_kernel(a, plan.nq, grid, ctx->stream);

@@ -38,3 +38,6 @@ hipError_t kp_gram6_launch_kernel(const Gram3Args& a, int nq, int grid, hipStrea
 hipError_t kp_gram3_pcs_transpose_launch(const double* pcs, int nfull, int k, double* pcsT, hipStream_t st);
 hipError_t kp_gram3_prelift_launch(int BM, const double* alpha, const double* beta, const double* u, int64_t Ns, int64_t Ns_pad, int nzeta, int D, int nfull, int k_pcs,
                                    int N, int G4, const uint32_t* recipes, const double* pcsT, double* out, int rl, hipStream_t st);
+// ... of a dictionary with fourier / gaussian blocks (EXT recipes, no projection); at most 64 KB of LDS: nzeta (Dp + 2 df) + ng + 1 <= 64 entries, nzeta <= 16
+hipError_t kp_gram3_prelift_ext_launch(int BM, const double* alpha, const double* beta, const double* u, int64_t Ns, int64_t Ns_pad, int nzeta, int Dp, int df, int ng,
+                                       int nfull, int G4, const uint32_t* recipes, const double* centres, double* out, int rl, hipStream_t st);

@@ -120,3 +120,115 @@ hipError_t kp_gram3_prelift_launch(int BM, const double* alpha, const double* be
 #undef KP_PRELIFT
   return hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same row buffer for dictionaries with fourier / gaussian blocks and no projection (def_fourierLift Ksysid.m:694-731,
+// def_gaussianLift :790-817; the EXT recipes of kp_context.hip).  kp_gram3_kernel<.,.,false,true> builds their table entries -
+// sincospi, exp(-|zeta - c|^2) with the centres in LDS - in every workgroup of a snapshot split and next to the MFMA loop, which
+// costs it 40 registers (plans capped at 4 quads per wave).  Here: one thread per snapshot, both sides; table entries per side
+// [variable v: x^1..x^Dp, cos / sin(2 pi j x) j = 1..df][gaussian centre c], a column = product of <= 3 entries (id < 128:
+// variable entry, 128 + c: gaussian, 255: none), written straight to the tile layout.
+// ---------------------------------------------------------------------------------------------------------------------
+#define PREX_T 128
+template <int BM>
+__global__ __launch_bounds__(PREX_T) void kp_gram3_prelift_ext_kernel(const double* __restrict__ alpha, const double* __restrict__ beta, const double* __restrict__ u,
+                                                                      int64_t Ns, int64_t Ns_pad, int nzeta, int Dp, int df, int ng, int nfull, int G4,
+                                                                      const uint32_t* __restrict__ recipes, const double* __restrict__ centres,
+                                                                      double* __restrict__ out, int rl) {
+  extern __shared__ double tab[];                       // [nzeta * D + ng][PREX_T], then one entry of ones
+  const int tid = threadIdx.x;
+  const int64_t snap = (int64_t)blockIdx.x * PREX_T + tid;
+  if (snap >= Ns_pad) return;
+  const bool valid = snap < Ns;
+  const int D = Dp + 2 * df, nv = nzeta * D, ne = nv + ng;
+  // raw values of both sides first (all loads in flight together), then the entries from registers
+  constexpr int NZMAX = 16;
+  double xa[NZMAX], xb[NZMAX];
+#pragma unroll
+  for (int v = 0; v < NZMAX; ++v) {
+    xa[v] = (valid && v < nzeta) ? alpha[(int64_t)v * Ns + snap] : 0.0;
+    xb[v] = (valid && v < nzeta) ? beta[(int64_t)v * Ns + snap] : 0.0;
+  }
+  // one side at a time through ONE table (27 entries x 128 threads = 27 KB for 20 gaussians on 6 states: five workgroups per CU;
+  // a table per side left two)
+  double* t0 = tab + tid;
+  double* ox = out + (snap / KT3) * (int64_t)(KT3 * rl) + (snap % KT3);
+  double* oy = ox + (int64_t)4 * G4 * KT3;
+#pragma unroll
+  for (int side = 0; side < 2; ++side) {
+    const double* xs = side ? xb : xa;
+#pragma unroll
+    for (int v = 0; v < NZMAX; ++v) {
+      if (v < nzeta) {
+        double pw = xs[v];
+        for (int e = 0; e < Dp; ++e) {
+          t0[(v * D + e) * PREX_T] = pw;
+          pw *= xs[v];
+        }
+        if (df > 0) {                                   // harmonics by the angle-addition recurrence, as kp_gram3_kernel's loader
+          double s1, c1;
+          sincospi(2.0 * xs[v], &s1, &c1);
+          double cj = c1, sj = s1, cm = 1.0, sm1 = 0.0;
+          for (int h = 0; h < df; ++h) {
+            t0[(v * D + Dp + 2 * h) * PREX_T] = cj;
+            t0[(v * D + Dp + 2 * h + 1) * PREX_T] = sj;
+            const double cn = 2.0 * c1 * cj - cm, sn = 2.0 * c1 * sj - sm1;
+            cm = cj; sm1 = sj; cj = cn; sj = sn;
+          }
+        }
+      }
+    }
+    for (int c = 0; c < ng; ++c) {                      // exp(-|zeta - centre|^2), the centres through wave-uniform addresses
+      double r2 = 0.0;
+#pragma unroll
+      for (int i = 0; i < NZMAX; ++i)
+        if (i < nzeta) {
+          const double dlt = xs[i] - centres[c * nzeta + i];
+          r2 = fma(dlt, dlt, r2);
+        }
+      t0[(nv + c) * PREX_T] = exp(-r2);
+    }
+    t0[(size_t)ne * PREX_T] = 1.0;
+    double* o = side ? oy : ox;
+#pragma unroll 2
+    for (int c = 0; c < nfull; ++c) {
+      const uint32_t r = recipes[c];
+      double ps = 1.0;
+#pragma unroll
+      for (int f = 0; f < NF3; ++f) {
+        const int id = (int)((r >> (8 * f)) & 255u);
+        ps *= t0[(id == 255 ? ne : id >= 128 ? nv + (id - 128) : id) * PREX_T];
+      }
+      o[c * KT3] = valid ? ps : 0.0;
+    }
+  }
+  for (int j = nfull; j < 4 * G4; ++j) { ox[j * KT3] = 0.0; oy[j * KT3] = 0.0; }
+  {
+    double ut[BM + 1];
+    ut[0] = 1.0;
+#pragma unroll
+    for (int i = 0; i < BM; ++i) ut[1 + i] = valid ? u[(int64_t)i * Ns + snap] : 0.0;
+    double* w = ox + (int64_t)8 * G4 * KT3;
+    int cnt = 0;
+#pragma unroll
+    for (int x = 0; x <= BM; ++x)
+#pragma unroll
+      for (int y = x; y <= BM; ++y) {
+        if (cnt > 0) w[(cnt - 1) * KT3] = valid ? ut[x] * ut[y] : 0.0;
+        ++cnt;
+      }
+    for (int j = cnt - 1; j < 12; ++j) w[j * KT3] = 0.0;
+  }
+}
+
+hipError_t kp_gram3_prelift_ext_launch(int BM, const double* alpha, const double* beta, const double* u, int64_t Ns, int64_t Ns_pad, int nzeta, int Dp, int df, int ng,
+                                       int nfull, int G4, const uint32_t* recipes, const double* centres, double* out, int rl, hipStream_t st) {
+  const size_t plds = ((size_t)(nzeta * (Dp + 2 * df) + ng) + 1) * PREX_T * 8;
+  const dim3 pg((unsigned)((Ns_pad + PREX_T - 1) / PREX_T));
+#define KP_PRELIFTX(M) hipLaunchKernelGGL(kp_gram3_prelift_ext_kernel<M>, pg, dim3(PREX_T), plds, st, alpha, beta, u, Ns, Ns_pad, nzeta, Dp, df, ng, nfull, G4, recipes, centres, out, rl)
+  if (BM == 1) KP_PRELIFTX(1);
+  else if (BM == 2) KP_PRELIFTX(2);
+  else KP_PRELIFTX(3);
+#undef KP_PRELIFTX
+  return hipGetLastError();
+}
