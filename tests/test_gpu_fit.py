@@ -551,6 +551,15 @@ for Ns in (100000, 4099, 5):
     s = kra.Snapshots(ctx, p["alpha"], p["beta"], p["u"])
     G, C = kra.fit_gram(ctx, b, s)
     out["G%d" % Ns] = G; out["C%d" % Ns] = C
+    # fourier / gaussian blocks: their table entries once per snapshot (kp_gram3_prelift_ext_kernel) or inside the Gram kernel
+    bg = kra.Basis(ctx, "bilinear", 6, 3, [("gaussian", np.random.default_rng(3).uniform(-1, 1, (6, 20)))])
+    G, C = kra.fit_gram(ctx, bg, s)
+    out["Gg%d" % Ns] = G; out["Cg%d" % Ns] = C
+    p3 = synth_pairs(Ns, 3, 2, seed=4)
+    s3 = kra.Snapshots(ctx, p3["alpha"], p3["beta"], p3["u"])
+    bf = kra.Basis(ctx, "bilinear", 3, 2, [("fourier", 1), ("poly", kra.poly_exponent_table(3, 2)[3:])])
+    G, C = kra.fit_gram(ctx, bf, s3)
+    out["Gf%d" % Ns] = G; out["Cf%d" % Ns] = C
 np.savez(sys.argv[2], **out)
 """
 
@@ -559,7 +568,9 @@ def test_econ_lift_once_per_snapshot_equals_the_in_kernel_projection():
     """dim_red bilinear dictionary (N = 34, W = 136, the shape of example_sysid.m): by default the econ lift [zeta; pcs' psi; 1]
     (Ksysid.m:1594-1618) is formed once per snapshot by kp_gram3_prelift_kernel and the Kronecker kernel loads lifted tiles;
     KP_GRAM3_NO_PRELIFT=1 (read once per process) keeps the projection inside every workgroup of the Gram kernel.  Same G, C to
-    rounding, at 1e5 pairs, with a ragged tail (4099) and with fewer pairs than one tile (5)."""
+    rounding, at 1e5 pairs, with a ragged tail (4099) and with fewer pairs than one tile (5).  The same for a gaussian dictionary
+    (20 centres on 6 states, m = 3) and a fourier + poly-2 one (3 states, m = 2), whose table entries - sincospi, exp - move out of
+    the Gram kernel the same way (kp_gram3_prelift_ext_kernel)."""
     import os
     import subprocess
     import sys
