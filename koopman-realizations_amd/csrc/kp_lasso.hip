@@ -887,8 +887,8 @@ int kp_lasso_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, in
   // a bounded number of steps whatever cond(G) is, where this iteration needs O(sqrt(cond)) of them.  KP_LASSO_PATH_AFTER=-1
   // disables it, 0 sends every active value there at once
   static const int path_env = [] { const char* e = getenv("KP_LASSO_PATH_AFTER"); return e ? atoi(e) : -2; }();
-  // (default: 24 iterations - the first three checks - while the inverse fits LDS and the path costs 3 - 13 ms, 100 beyond)
-  const int path_after = path_env != -2 ? path_env : (W <= 128 ? 24 : 100);
+  // (default: 24 iterations - the first three checks - while every support fits the LDS-resident inverse and the path costs 3 - 13 ms, 100 beyond)
+  const int path_after = path_env != -2 ? path_env : (W <= 136 ? 24 : 100);
   bool path_tried = false;
   std::string path_err;
   ctx->timers[11] = 0.0;

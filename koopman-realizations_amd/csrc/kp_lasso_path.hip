@@ -16,7 +16,8 @@
 // parallel pass, no triangular solves - a dependent chain of |S| steps per solve would cost more than everything else), with
 // one step of iterative refinement of the bordering vector against G itself, which is what keeps M accurate at cond 1e10
 // (tools/lasso_homotopy_probe2.py: without it the adds break down, with it the KKT conditions hold to 1e-10 after 450 steps).
-// M lives in LDS while the support is at most 128 entries (any W <= 384), else in global memory (template flag).
+// M lives in LDS while the support fits beside the vectors (136 entries at W = 136, 128 at W = 384), else in global memory
+// (template flag).
 //
 //   walk     all columns walk the path in rounds (theta targets theta_max / 16^r) and record (theta, |k|_1) at every breakpoint;
 //            after each round the host reads sum_j |k_j|_1: the values whose budget it now covers are bracketed by the round
@@ -33,7 +34,7 @@
 namespace {
 constexpr int P_TPB_LDS = 256;      // threads per column, inverse in LDS
 constexpr int P_TPB_GLOBAL = 1024;  // ... inverse in global memory (supports beyond 128: the products are long)
-constexpr int P_LDS_CAP = 128;      // support entries the LDS-resident inverse holds
+constexpr int P_LDS_BYTES = 160 * 1024;   // LDS of a CU: the inverse takes what the vectors leave (128 entries at W = 384, 136 at W = 136)
 constexpr int P_WMAX = 384;         // widest dictionary (the W-length vectors live in LDS)
 constexpr int P_RESYNC = 16;        // steps between re-synchronisations of r = c - G k and of r_S = theta s_S
 enum { PATH_OK = 0, PATH_OVERFLOW = 1, PATH_STEPS = 2, PATH_SINGULAR = 3, PATH_BP = 4, PATH_ADJUST = 5 };
@@ -50,10 +51,18 @@ struct PathLayout {
   size_t off_k, off_r, off_sgn, off_idx, off_M, off_bpt, off_bpl, off_bpe, stride;
 };
 
+// dynamic LDS of kp_lasso_path_kernel: [M] + 4 W-vectors + 5 support vectors + the reduction scratch, then the index lists and scalars
+static size_t path_lds_bytes(int W, int ldm, bool mglobal, int tpb) {
+  return ((mglobal ? 0 : (size_t)ldm * ldm) + 4 * (size_t)W + 5 * (size_t)ldm + tpb) * 8 + ((size_t)ldm + 2 + W + 2 + 24) * 4 + 40 * 8;
+}
+
 static PathLayout make_layout(int W, bool mglobal, int cap) {
   PathLayout L;
   L.W = W;
-  L.ldm = mglobal ? W : std::min(W, P_LDS_CAP);
+  L.ldm = W;
+  if (!mglobal) {                                    // largest support whose inverse fits LDS beside the vectors (path_lds_bytes)
+    while (L.ldm > 8 && path_lds_bytes(W, L.ldm, false, P_TPB_LDS) > (size_t)P_LDS_BYTES) --L.ldm;
+  }
   L.cap = cap;
   size_t o = sizeof(PathHdr);
   L.off_k = o; o += (size_t)W * 8;
@@ -560,7 +569,7 @@ int kp_lasso_path_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_de
     if (!arena) return ctx->fail(KP_ERR_HIP, "kp_fit_lasso: out of device memory");
     char* snap = arena + L.stride * (size_t)ncols;
     const int tpb = mglobal ? P_TPB_GLOBAL : P_TPB_LDS;
-    const size_t lds = ((mglobal ? 0 : (size_t)L.ldm * L.ldm) + 4 * (size_t)W + 5 * (size_t)L.ldm + tpb) * 8 + ((size_t)L.ldm + 2 + W + 2 + 24) * 4 + 40 * 8;
+    const size_t lds = path_lds_bytes(W, L.ldm, mglobal, tpb);
     auto launch = [&](char* ar, double stop, int init, int record, double* Kout, int adjust = 0, double from = 0.0, int polish = 0) -> int {
       if (mglobal) {
         hipLaunchKernelGGL((kp_lasso_path_kernel<true, P_TPB_GLOBAL>), dim3(ncols), dim3(P_TPB_GLOBAL), lds, s, G_dev, C_dev, L, ar, stop, from, cap, init, record, adjust, polish, Kout);
