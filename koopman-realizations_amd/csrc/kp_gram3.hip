@@ -914,6 +914,9 @@ int kp_gram3_linear_launch(kp_ctx* ctx, const kp_basis* basis, const kp_snapshot
   hipLaunchKernelGGL(kp_gram3_linear_gather_kernel, dim3((2 * W * W + 255) / 256), dim3(256), 0, rs, tmp, N, m, Wb, GC_dev);
   KP_HIP(ctx, hipGetLastError());
   ctx->gram_flops_per_pair = (double)W * (W + 1) + 2.0 * W * W;
+  // timer 10 (flop EXECUTED on the matrix pipe per pair) stays what the inner launch set: the work added here - the gather, the
+  // congruence products 2 (Wf^2 W + Wf W^2) flop - is per FIT and runs on the vector pipe, so it is in the kernel time of the
+  // bench's roofline block but, rightly, not in its matrix-pipe flop
   return KP_OK;
 }
 
@@ -1018,5 +1021,8 @@ int kp_gram_congruence_launch(kp_ctx* ctx, const kp_basis* basis, const kp_snaps
   hipLaunchKernelGGL(kp_cong_left_kernel, dim3((W * W + 255) / 256, 2), dim3(256), 0, rs, R, t, GC_dev);
   KP_HIP(ctx, hipGetLastError());
   ctx->gram_flops_per_pair = (double)W * (W + 1) + 2.0 * W * W;
+  // timer 10 (flop EXECUTED on the matrix pipe per pair) stays what the inner launch set: the work added here - the gather, the
+  // congruence products 2 (Wf^2 W + Wf W^2) flop - is per FIT and runs on the vector pipe, so it is in the kernel time of the
+  // bench's roofline block but, rightly, not in its matrix-pipe flop
   return KP_OK;
 }

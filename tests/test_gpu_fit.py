@@ -587,3 +587,46 @@ def test_econ_lift_once_per_snapshot_equals_the_in_kernel_projection():
         a, b = res["pre"][k], res["proj"][k]
         assert np.isfinite(a).all()
         assert np.abs(a - b).max() <= 1e-12 * np.abs(b).max(), k
+
+
+_CONG_SCRIPT = """
+import sys, os, numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + '/tests')
+import koopman_realizations_amd as kra
+g = np.load(os.path.join(sys.argv[1], 'tests', 'golden', 'arm_data.npz'))
+lens = g['train_len']; off = np.concatenate([[0], np.cumsum(lens)])
+train = [{'t': g['train_t'][a:b], 'y': g['train_y'][a:b], 'u': g['train_u'][a:b]} for a, b in zip(off[:-1], off[1:])]
+data = {'train': train, 'val': [{'t': g['val_t'], 'y': g['val_y'], 'u': g['val_u']}]}
+ctx = kra.Context(0)
+out = {}
+for mt in ('linear', 'nonlinear'):
+    ks = kra.Ksysid(data, ctx=ctx, model_type=mt, obs_type=['poly'], obs_degree=[3], snapshots=np.inf, lasso=[np.inf], delays=0, dim_red=True)
+    sp = ks.snapshotPairs
+    s = ks._resident_snapshots(sp['alpha'], sp['beta'], sp['u'])
+    G, C = kra.fit_gram(ctx, ks.basis_dev, s)
+    out['G_' + mt] = G; out['C_' + mt] = C
+np.savez(sys.argv[2], **out)
+"""
+
+
+def test_congruence_grams_of_dim_red_dictionaries_equal_the_per_pair_projection_on_the_arm_data():
+    """Linear and nonlinear dim_red dictionaries take their Grams as T'(Psi_full' Psi_full) T from the monomial kernels (DESIGN 3.1);
+    KP_NO_GRAM_CONGRUENCE=1 (read per process) keeps the general kernel, which projects every lifted pair.  The two summation orders
+    are compared where they differ most: the arm data, whose FULL poly-3 dictionaries are rank-deficient (rank 252 of 336 for the
+    bilinear row) - G, C agree to 1e-11 max|G| (the congruence forms differences of O(max|G_full|) terms)."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    with tempfile.TemporaryDirectory() as td:
+        for name, env in (("cong", {}), ("general", {"KP_NO_GRAM_CONGRUENCE": "1"})):
+            f = os.path.join(td, name + ".npz")
+            r = subprocess.run([sys.executable, "-c", _CONG_SCRIPT, root, f], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+            assert r.returncode == 0, r.stderr[-1500:]
+            res[name] = dict(np.load(f))
+    for mt in ("linear", "nonlinear"):
+        scale = np.abs(res["general"]["G_" + mt]).max()
+        for k in ("G_" + mt, "C_" + mt):
+            assert np.abs(res["cong"][k] - res["general"][k]).max() <= 1e-11 * scale, k
