@@ -702,6 +702,7 @@ static bool gram3_prelift(const kp_basis* basis) {
   static const bool off = getenv("KP_GRAM3_NO_PRELIFT") != nullptr;
   const BasisDev& b = basis->dev;
   if (off) return false;
+  if ((b.N + 3) / 4 > 14) return false;               // the tile loader of the PRE kernel moves two 16-byte pieces per thread: 4 (8 G4 + 12) <= 512
   if (b.k_pcs > 0) return b.k_pcs <= 32 && basis->fast && b.nzeta * basis->pow_depth <= 24;      // (2 x 24 entries x 256 threads: 96 KB of LDS)
   return gram3_ext(basis) && b.nzeta <= 16 && b.nzeta * (basis->ext_Dp + 2 * basis->ext_df) + basis->ext_ng + 1 <= 64;
 }

@@ -560,6 +560,13 @@ for Ns in (100000, 4099, 5):
     bf = kra.Basis(ctx, "bilinear", 3, 2, [("fourier", 1), ("poly", kra.poly_exponent_table(3, 2)[3:])])
     G, C = kra.fit_gram(ctx, bf, s3)
     out["Gf%d" % Ns] = G; out["Cf%d" % Ns] = C
+    # the widest rows the lifted-tile loader takes (N = 55: 14 column groups, 496 of its 512 pieces) and the first that it does not (N = 59)
+    p4 = synth_pairs(Ns, 4, 2, seed=6)
+    s4 = kra.Snapshots(ctx, p4["alpha"], p4["beta"], p4["u"])
+    for ng in (20, 24):
+        bw = kra.Basis(ctx, "bilinear", 4, 2, [("poly", kra.poly_exponent_table(4, 3)[4:]), ("gaussian", np.random.default_rng(ng).uniform(-1, 1, (4, ng)))])
+        G, C = kra.fit_gram(ctx, bw, s4)
+        out["Gw%d_%d" % (ng, Ns)] = G; out["Cw%d_%d" % (ng, Ns)] = C
 np.savez(sys.argv[2], **out)
 """
 
