@@ -170,3 +170,50 @@ def test_numerically_dependent_columns_are_barred_not_fatal(ctx):
         rows = [i for i in range(12) if i not in (2, 7)]
         assert np.abs(K[rows] - Ko[rows]).max() <= 1e-5 * np.abs(Ko).max()
         assert np.abs((K[2] + K[7]) - (Ko[2] + Ko[7])).max() <= 1e-5 * np.abs(Ko).max()     # the twins' joint weight
+
+
+_RANDOM_SCRIPT = ("import sys, numpy as np; sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + '/tests')\n"
+                  "import koopman_realizations_amd as kra\n"
+                  "d = np.load(sys.argv[2]); c = kra.Context(0)\n"
+                  "out = {}\n"
+                  "for i in range(int(d['n'])):\n"
+                  "    K, it = c.fit_lasso_batch(d['G%d' % i], d['C%d' % i], d['t%d' % i])\n"
+                  "    out['K%d' % i] = np.stack(K); out['ms%d' % i] = c.timer(11)\n"
+                  "np.savez(sys.argv[3], **out)\n")
+
+
+def test_homotopy_on_random_problems_against_the_oracle_path():
+    """Forty random problems (W = 5 ... 24, 1 ... W columns, condition numbers 1e1 ... 1e8, sparse and dense truths, three budgets each
+    incl. one above |K_LS|_1) through the homotopy alone (KP_LASSO_PATH_AFTER=0, fresh interpreter): every answer equals the
+    oracle's path solver to 1e-7 max|K| (cond * eps) and meets its budget to 1e-11; an inactive budget returns the least-squares
+    solution.  The event handling (entries, drops, ties, re-entries) has no other test as broad."""
+    rng = np.random.default_rng(2024)
+    probs = {}
+    n = 40
+    for i in range(n):
+        W = int(rng.integers(5, 25)); nc = int(rng.integers(1, W + 1)); Ns = 40 * W
+        sv = np.geomspace(1.0, 10.0 ** -rng.uniform(0.5, 4.0), W)
+        Q1 = np.linalg.qr(rng.standard_normal((Ns, W)))[0]; Q2 = np.linalg.qr(rng.standard_normal((W, W)))[0]
+        P = (Q1 * sv) @ Q2.T * np.sqrt(Ns)
+        Kt = rng.standard_normal((W, nc)) * (rng.random((W, nc)) < rng.uniform(0.2, 1.0))
+        Y = P @ Kt + 0.05 * rng.standard_normal((Ns, nc))
+        G, C = P.T @ P, P.T @ Y
+        l1 = np.abs(np.linalg.solve(G, C)).sum()
+        probs["G%d" % i] = G; probs["C%d" % i] = C; probs["t%d" % i] = np.array([1.3, rng.uniform(0.3, 0.95), rng.uniform(0.01, 0.3)]) * l1
+    probs["n"] = n
+    with tempfile.TemporaryDirectory() as td:
+        np.savez(os.path.join(td, "in.npz"), **probs)
+        r = subprocess.run([sys.executable, "-c", _RANDOM_SCRIPT, ROOT, os.path.join(td, "in.npz"), os.path.join(td, "out.npz")],
+                           env=dict(os.environ, KP_LASSO_PATH_AFTER="0"), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        o = dict(np.load(os.path.join(td, "out.npz")))
+    for i in range(n):
+        G, C, ts = probs["G%d" % i], probs["C%d" % i], probs["t%d" % i]
+        K = o["K%d" % i]
+        assert o["ms%d" % i] > 0.0
+        Kls = np.linalg.solve(G, C)
+        assert np.abs(np.asfortranarray(K[0]) - Kls).max() <= 1e-8 * np.abs(Kls).max(), i           # inactive budget
+        for v in (1, 2):
+            Ko, th = ko.koopman_lasso_path(G, C, ts[v])
+            assert np.abs(K[v] - Ko).max() <= 1e-7 * np.abs(Ko).max(), (i, v, np.linalg.cond(G))
+            assert abs(np.abs(K[v]).sum() - ts[v]) <= 1e-11 * ts[v], (i, v)
