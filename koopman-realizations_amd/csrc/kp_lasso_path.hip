@@ -96,6 +96,12 @@ __device__ __forceinline__ void mv_sym(const double* M, int ld, int n, const dou
     for (int t = tid; t < n; t += TPB) {
       double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
       int q = 0;
+      for (; q + 7 < n; q += 8) {
+        const double m0 = M[(size_t)q * ld + t], m1 = M[(size_t)(q + 1) * ld + t], m2 = M[(size_t)(q + 2) * ld + t], m3 = M[(size_t)(q + 3) * ld + t];
+        const double m4 = M[(size_t)(q + 4) * ld + t], m5 = M[(size_t)(q + 5) * ld + t], m6 = M[(size_t)(q + 6) * ld + t], m7 = M[(size_t)(q + 7) * ld + t];
+        a0 += m0 * x[q]; a1 += m1 * x[q + 1]; a2 += m2 * x[q + 2]; a3 += m3 * x[q + 3];
+        a0 += m4 * x[q + 4]; a1 += m5 * x[q + 5]; a2 += m6 * x[q + 6]; a3 += m7 * x[q + 7];
+      }
       for (; q + 3 < n; q += 4) {
         a0 += M[(size_t)q * ld + t] * x[q];
         a1 += M[(size_t)(q + 1) * ld + t] * x[q + 1];
@@ -113,11 +119,13 @@ __device__ __forceinline__ void mv_sym(const double* M, int ld, int n, const dou
   double a0 = 0.0, a1 = 0.0;
   if (t < n) {
     int q = q0;
-    for (; q + 1 < q1; q += 2) {
-      a0 += M[(size_t)q * ld + t] * x[q];
-      a1 += M[(size_t)(q + 1) * ld + t] * x[q + 1];
+    for (; q + 7 < q1; q += 8) {                      // eight loads of M in flight (the loop is bound by their latency, not by the FMAs)
+      const double m0 = M[(size_t)q * ld + t], m1 = M[(size_t)(q + 1) * ld + t], m2 = M[(size_t)(q + 2) * ld + t], m3 = M[(size_t)(q + 3) * ld + t];
+      const double m4 = M[(size_t)(q + 4) * ld + t], m5 = M[(size_t)(q + 5) * ld + t], m6 = M[(size_t)(q + 6) * ld + t], m7 = M[(size_t)(q + 7) * ld + t];
+      a0 += m0 * x[q]; a1 += m1 * x[q + 1]; a0 += m2 * x[q + 2]; a1 += m3 * x[q + 3];
+      a0 += m4 * x[q + 4]; a1 += m5 * x[q + 5]; a0 += m6 * x[q + 6]; a1 += m7 * x[q + 7];
     }
-    if (q < q1) a0 += M[(size_t)q * ld + t] * x[q];
+    for (; q < q1; ++q) a0 += M[(size_t)q * ld + t] * x[q];
   }
   red[p * TP + t] = a0 + a1;
   __syncthreads();
@@ -138,7 +146,15 @@ __device__ __forceinline__ void rank1(double* M, int ld, int n, const double* __
   const int P = TPB / TP, t0 = tid & (TP - 1), pp = tid / TP;
   for (int t = t0; t < n; t += TP) {
     const double ut = u[t];
-    for (int q = pp; q < n; q += P) M[(size_t)q * ld + t] += (ut * u[q]) * sinv;
+    int q = pp;
+    for (; q + 3 * P < n; q += 4 * P) {               // four read-modify-writes in flight
+      const double m0 = M[(size_t)q * ld + t], m1 = M[(size_t)(q + P) * ld + t], m2 = M[(size_t)(q + 2 * P) * ld + t], m3 = M[(size_t)(q + 3 * P) * ld + t];
+      M[(size_t)q * ld + t] = m0 + (ut * u[q]) * sinv;
+      M[(size_t)(q + P) * ld + t] = m1 + (ut * u[q + P]) * sinv;
+      M[(size_t)(q + 2 * P) * ld + t] = m2 + (ut * u[q + 2 * P]) * sinv;
+      M[(size_t)(q + 3 * P) * ld + t] = m3 + (ut * u[q + 3 * P]) * sinv;
+    }
+    for (; q < n; q += P) M[(size_t)q * ld + t] += (ut * u[q]) * sinv;
   }
 }
 
@@ -177,8 +193,8 @@ __device__ __forceinline__ void mv_gather(const double* __restrict__ G, int W, c
 struct Cand { double dl; int key; };                 // key = 2 * index + (sign < 0) for an entry, 2 * index | 0x40000000 for a leave
 __device__ __forceinline__ Cand cmin(Cand a, Cand b) { return (b.dl < a.dl || (b.dl == a.dl && b.key < a.key)) ? b : a; }
 
-template <bool MG, int TPB>
-__global__ __launch_bounds__(TPB) void kp_lasso_path_kernel(const double* __restrict__ G, const double* __restrict__ C, PathLayout L, char* __restrict__ arena,
+template <bool MG, int TPB, bool GL>
+__global__ __launch_bounds__(TPB) void kp_lasso_path_kernel(const double* __restrict__ Gg, const double* __restrict__ C, PathLayout L, char* __restrict__ arena,
                                                            double theta_stop, double theta_from, int max_steps, int init, int record, int adjust, int polish, double* __restrict__ Kout) {
   extern __shared__ double sm[];
   const int W = L.W, ld = L.ldm, tid = threadIdx.x, col = blockIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -197,6 +213,7 @@ __global__ __launch_bounds__(TPB) void kp_lasso_path_kernel(const double* __rest
   // LDS: [M (LDS mode)] k r sgn a (W each) | sS d u g e (ld each) | red (512) | idx (ld) offl (W) ints | scalars
   double* p = sm;
   double* Ml = p; if (!MG) p += (size_t)ld * ld;
+  double* Gl = p; if (GL) p += (size_t)W * W;       // G itself, when it fits beside the inverse (W <= 96): its gathers stay out of L2
   double* k = p; p += W;
   double* r = p; p += W;
   double* sg = p; p += W;
@@ -215,6 +232,11 @@ __global__ __launch_bounds__(TPB) void kp_lasso_path_kernel(const double* __rest
   double* sc_s = sc_d + 24;
   auto sum_waves = [&]() { double v = sc_s[0]; for (int w = 1; w < NW; ++w) v += sc_s[w]; return v; };
   double* const M = MG ? gM : Ml;                    // the inverse on the support: global memory or LDS
+  const double* const G = GL ? Gl : Gg;
+  if (GL) {
+    for (int e2 = tid; e2 < W * W; e2 += PT) Gl[e2] = Gg[e2];
+    __syncthreads();
+  }
 
   double theta, l1, last_del_sgn;
   int steps, cnt, last_add, last_del, status, nbp;
@@ -569,13 +591,19 @@ int kp_lasso_path_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_de
     if (!arena) return ctx->fail(KP_ERR_HIP, "kp_fit_lasso: out of device memory");
     char* snap = arena + L.stride * (size_t)ncols;
     const int tpb = mglobal ? P_TPB_GLOBAL : P_TPB_LDS;
-    const size_t lds = path_lds_bytes(W, L.ldm, mglobal, tpb);
+    // G in LDS as well when it fits beside the whole inverse (W <= 96)
+    static const bool no_gl = getenv("KP_LASSO_PATH_NO_GLDS") != nullptr;
+    const bool gl = !mglobal && !no_gl && L.ldm == W && path_lds_bytes(W, L.ldm, false, tpb) + (size_t)W * W * 8 <= (size_t)P_LDS_BYTES;
+    const size_t lds = path_lds_bytes(W, L.ldm, mglobal, tpb) + (gl ? (size_t)W * W * 8 : 0);
     auto launch = [&](char* ar, double stop, int init, int record, double* Kout, int adjust = 0, double from = 0.0, int polish = 0) -> int {
       if (mglobal) {
-        hipLaunchKernelGGL((kp_lasso_path_kernel<true, P_TPB_GLOBAL>), dim3(ncols), dim3(P_TPB_GLOBAL), lds, s, G_dev, C_dev, L, ar, stop, from, cap, init, record, adjust, polish, Kout);
+        hipLaunchKernelGGL((kp_lasso_path_kernel<true, P_TPB_GLOBAL, false>), dim3(ncols), dim3(P_TPB_GLOBAL), lds, s, G_dev, C_dev, L, ar, stop, from, cap, init, record, adjust, polish, Kout);
+      } else if (gl) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kp_lasso_path_kernel<false, P_TPB_LDS, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL((kp_lasso_path_kernel<false, P_TPB_LDS, true>), dim3(ncols), dim3(P_TPB_LDS), lds, s, G_dev, C_dev, L, ar, stop, from, cap, init, record, adjust, polish, Kout);
       } else {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kp_lasso_path_kernel<false, P_TPB_LDS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL((kp_lasso_path_kernel<false, P_TPB_LDS>), dim3(ncols), dim3(P_TPB_LDS), lds, s, G_dev, C_dev, L, ar, stop, from, cap, init, record, adjust, polish, Kout);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kp_lasso_path_kernel<false, P_TPB_LDS, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL((kp_lasso_path_kernel<false, P_TPB_LDS, false>), dim3(ncols), dim3(P_TPB_LDS), lds, s, G_dev, C_dev, L, ar, stop, from, cap, init, record, adjust, polish, Kout);
       }
       KP_HIP(ctx, hipGetLastError());
       return KP_OK;
