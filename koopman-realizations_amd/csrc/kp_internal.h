@@ -340,6 +340,7 @@ struct kp_lasso_prep {
   bool ready = false;
   double L = 0.0, l1_ls = 0.0;
   int bad = 0;
+  bool guarded = false;    // the 1e-6 PSD guard of Ksysid.m:1117-1120 was applied (cond(Gw) >= lambda_max / 1e-6)
   double* Kls = nullptr;   // device, W x ncols
   double* Gw = nullptr;    // device copy of G (with the PSD guard applied when needed)
 };

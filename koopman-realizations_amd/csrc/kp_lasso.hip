@@ -774,6 +774,7 @@ int kp_lasso_prepare(kp_ctx* ctx, const double* G_dev, const double* C_dev, int 
   p->L = dst[0]; p->l1_ls = dst[3]; p->bad = dst[4] != 0.0;
   if (!(p->L > 0.0)) return ctx->fail(KP_ERR_ARG, "kp_fit_lasso: Gram matrix is zero");
   if (p->bad) {
+    p->guarded = true;
     // The factorisation broke down and Gw now carries the 1e-6 guard: the QP the reference solves from here on (Ksysid.m:1117-1137) is
     // the one of the GUARDED matrix, which is positive definite - its least-squares solution decides which budgets are inactive
     // (they get exactly that solution) and starts the others.  (L was computed on the guarded matrix already.)
@@ -888,7 +889,7 @@ int kp_lasso_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, in
   // disables it, 0 sends every active value there at once
   static const int path_env = [] { const char* e = getenv("KP_LASSO_PATH_AFTER"); return e ? atoi(e) : -2; }();
   // (default: 24 iterations - the first three checks - while every support fits the LDS-resident inverse and the path costs 3 - 13 ms, 100 beyond)
-  const int path_after = path_env != -2 ? path_env : (W <= 136 ? 24 : 100);
+  const int path_after = path_env != -2 ? path_env : ((W <= 136 || prep->guarded) ? 24 : 100);     // (a guarded Gram is at cond 1e10: no point in waiting)
   bool path_tried = false;
   std::string path_err;
   ctx->timers[11] = 0.0;
