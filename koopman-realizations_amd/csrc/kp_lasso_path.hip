@@ -210,7 +210,7 @@ __global__ __launch_bounds__(TPB) void kp_lasso_path_kernel(const double* __rest
   double* bpl = reinterpret_cast<double*>(base + L.off_bpl);
   int* bpe = reinterpret_cast<int*>(base + L.off_bpe);
   const double* c = C + (size_t)col * W;
-  // LDS: [M (LDS mode)] k r sgn a (W each) | sS d u g e (ld each) | red (512) | idx (ld) offl (W) ints | scalars
+  // LDS: [M (LDS mode)] [G (W <= 96)] k r sgn a (W each) | sS d u g e (ld each) | red (TPB) | idx (ld) offl (W) ints | scalars
   double* p = sm;
   double* Ml = p; if (!MG) p += (size_t)ld * ld;
   double* Gl = p; if (GL) p += (size_t)W * W;       // G itself, when it fits beside the inverse (W <= 96): its gathers stay out of L2

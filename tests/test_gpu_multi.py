@@ -151,3 +151,28 @@ def test_multi_errors_name_the_device_and_leave_the_object_usable(ctx, cfg3):
         assert np.array_equal(K2[0].T, ref) and np.array_equal(K2[1].T, ref)
     finally:
         mg.close()
+
+
+def test_lasso_values_that_need_the_homotopy_through_the_worker_threads(ctx, golden):
+    """kp_multi_fit on the arm data's bilinear poly-2 dim_red dictionary (cond(G) 3.5e10): every worker's values end in the
+    regularisation-path homotopy (kp_lasso_path.hip) inside its own thread and context - the same matrices as the plain context's
+    kp_fit, value by value, to the accuracy of a path at that conditioning (the workers' batches stop at other thetas: 1e-5 max|K|;
+    the budgets are met exactly either way)."""
+    from test_gpu_lasso_path import _arm
+    ks = kra.Ksysid(_arm(golden), ctx=ctx, model_type="bilinear", obs_type=["poly"], obs_degree=[2], snapshots=np.inf, lasso=[1.0], delays=0, dim_red=True)
+    sp = ks.snapshotPairs
+    s = ks._resident_snapshots(sp["alpha"], sp["beta"], sp["u"])
+    Kls = kra.fit(ctx, ks.basis_dev, s)[0]
+    N = ks.params["N"]
+    las = np.array([0.6, 0.3, 0.05]) * np.abs(Kls).sum() / N
+    ref = kra.fit(ctx, ks.basis_dev, s, las)
+    assert ctx.timer(11) > 0.0
+    exps = kra.poly_exponent_table(6, 2)[6:]
+    mg = Multi([0, 0])
+    try:
+        Ks = mg.fit(("bilinear", 6, 3, [("poly", exps)], ks.basis["pcs"]), sp["alpha"], sp["beta"], sp["u"], las)
+        for i in range(3):
+            assert np.abs(Ks[i].T - ref[i]).max() <= 1e-5 * np.abs(ref[i]).max(), i
+            assert abs(np.abs(Ks[i]).sum() - las[i] * N) <= 1e-11 * las[i] * N
+    finally:
+        mg.close()
