@@ -734,13 +734,13 @@ int kp_gram3_launch(kp_ctx* ctx, const kp_basis* basis_c, const kp_snapshots* s,
     static const bool g6_on = getenv("KP_GRAM6") != nullptr;
     const bool g6 = g6_on && BM == 3 && b.k_pcs == 0 && !gram3_ext(basis) && kp_gram6_serves(7, (N + 3) / 4);
     int rc = g6 ? make_plan3(ctx, N, NWT, 7, &basis->plan3, 8, 7)
-                : make_plan3(ctx, N, NWT, gram3_prelift(basis) ? 6 : b.k_pcs > 0 ? 4 : gram3_ext(basis) ? ext_cap : 6, &basis->plan3);
+                : make_plan3(ctx, N, NWT, b.k_pcs > 0 ? 4 : gram3_ext(basis) ? ext_cap : 6, &basis->plan3);     // (one plan serves both forms of a dim_red / fourier / gaussian fit)
     if (rc) return rc;
   }
   kp_gram3_plan& plan = *basis->plan3;
   const int nfull4 = (b.nfull + 3) / 4 * 4;
   const bool ext = gram3_ext(basis);
-  const size_t lds = (size_t)(LDS3_DOUBLES + (b.k_pcs > 0 && !gram3_prelift(basis) ? 2 * nfull4 * 16 : 0) + (ext && !gram3_prelift(basis) ? LDS3_GAUSS_DOUBLES : 0)) * sizeof(double);
+  
   int64_t ktiles = (s->Ns + KT3 - 1) / KT3;
   int ncu = ctx->num_cu > 0 ? ctx->num_cu : 256;
   int wg_per_cu = plan.wpw == 8 ? 1 : 2;              // __launch_bounds__(256, 2): two workgroups share a CU (kp_gram6: one of eight waves)
@@ -761,7 +761,13 @@ int kp_gram3_launch(kp_ctx* ctx, const kp_basis* basis_c, const kp_snapshots* s,
   double* part = (double*)(part_base + (ctx->reduce_stream ? (size_t)ctx->part_flip * part_bytes : 0));
 
   // dim_red dictionaries: the econ lift once per snapshot into a row buffer (kp_gram3_prelift_kernel), the Gram kernel loads tiles of it
-  const bool pre = gram3_prelift(basis);
+  // ... when there are enough snapshots to fill the chip with one thread each: the prelift kernel walks its 84 columns in ~40 us
+  // however few threads run, so at the arm data's 11 999 pairs the in-kernel projection is faster (0.049 against 0.088 ms of
+  // kernels, tools/arm_shape_latency.py), the two forms cross near 45 000 pairs (gaussian dictionaries: the same), and at 1e5 pairs it is
+  // slower (0.207 against 0.161)
+  static const int64_t pre_min_ns = [] { const char* e = getenv("KP_GRAM3_PRELIFT_MIN_NS"); return e ? (int64_t)atoll(e) : (int64_t)48000; }();
+  const bool pre = gram3_prelift(basis) && s->Ns >= pre_min_ns;
+  const size_t lds = (size_t)(LDS3_DOUBLES + (b.k_pcs > 0 && !pre ? 2 * nfull4 * 16 : 0) + (ext && !pre ? LDS3_GAUSS_DOUBLES : 0)) * sizeof(double);
   const int pre_rl = 8 * plan.G4 + 12;
   double* pre_buf = nullptr;
   if (pre) {

@@ -585,7 +585,7 @@ def test_econ_lift_once_per_snapshot_equals_the_in_kernel_projection():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
     with tempfile.TemporaryDirectory() as td:
-        for name, env in (("pre", {}), ("proj", {"KP_GRAM3_NO_PRELIFT": "1"})):
+        for name, env in (("pre", {"KP_GRAM3_PRELIFT_MIN_NS": "0"}), ("proj", {"KP_GRAM3_NO_PRELIFT": "1"})):
             f = os.path.join(td, name + ".npz")
             r = subprocess.run([sys.executable, "-c", _PRELIFT_SCRIPT, root, f], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
             assert r.returncode == 0, r.stderr[-1500:]
