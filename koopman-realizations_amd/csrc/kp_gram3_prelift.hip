@@ -18,7 +18,11 @@
 // the next column run under the 64 multiply-adds of this one.  Timing-only builds: without the multiply-adds 25 us, with ONE
 // matrix row for every column (scalar-cache hits) 43 us - the 21 KB matrix streams through a 16 KB scalar cache; two passes of
 // 16 components (10.5 KB each) were slower (117 us: the factors are read twice).  The multiply-adds alone are 14 us at the f64
-// vector peak.
+// vector peak.  Counters (profiles/r04_new_kernels_pmc_summary.json): 6 650 VALU instructions per wave in 138 k cycles, 1.5 waves per
+// SIMD (1e5 snapshots are only 1 564 waves) - latency-bound.  Tried on top and no better: only the raw values in LDS, powers formed
+// where they are used (25 instead of 74 KB per workgroup: 64 us - there are not enough workgroups for the occupancy to matter); a
+// quarter of the components per thread, four times the waves (80 us: the factors are formed four times); the matrix through the
+// vector L1 instead of scalar loads (all lanes one address: 88 us).
 // ---------------------------------------------------------------------------------------------------------------------
 #define PRE_T 256
 __global__ __launch_bounds__(PRE_T) void kp_gram3_pcs_transpose_kernel(const double* __restrict__ pcs, int nfull, int k, double* __restrict__ pcsT) {
