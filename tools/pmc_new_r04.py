@@ -6,7 +6,7 @@ import csv, glob, json, os, re
 from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof_r04_new")
-short = lambda n: re.sub(r"\(.*$", "", re.sub(r"^void ", "", n)).replace("(anonymous namespace)::", "")
+short = lambda n: re.sub(r"\(.*$", "", re.sub(r"^void ", "", n.replace("(anonymous namespace)::", "")))
 out = {"command": "rocprofv3 --pmc <set> --kernel-trace -- python3 tools/{lasso_illcond_probe.py 2 1 bilinear | prelift_time.py | prelift_ext_time.py} (tools/prof_r04_new_kernels.sh)", "kernels": {}}
 want = ("kp_lasso_path_kernel", "kp_gram3_prelift_kernel", "kp_gram3_prelift_ext_kernel", "kp_gram3_kernel<3, 3, false, false, true>")
 for d in sorted(glob.glob(os.path.join(SRC, "*_*"))):
