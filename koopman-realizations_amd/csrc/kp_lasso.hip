@@ -894,7 +894,7 @@ int kp_lasso_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, in
   std::string path_err;
   ctx->timers[11] = 0.0;
   while (it < max_iter && nba > 0) {
-    if (path_after >= 0 && it >= path_after && !path_tried && W <= 384) {
+    if (path_after >= 0 && it >= path_after && !path_tried && W <= 512) {
       path_tried = true;
       std::vector<double> tv(nba);
       std::vector<double*> dst(nba);

@@ -35,7 +35,7 @@ namespace {
 constexpr int P_TPB_LDS = 256;      // threads per column, inverse in LDS
 constexpr int P_TPB_GLOBAL = 1024;  // ... inverse in global memory (supports beyond 128: the products are long)
 constexpr int P_LDS_BYTES = 160 * 1024;   // LDS of a CU: the inverse takes what the vectors leave (128 entries at W = 384, 136 at W = 136)
-constexpr int P_WMAX = 384;         // widest dictionary (the W-length vectors live in LDS)
+constexpr int P_WMAX = 512;         // widest dictionary (the library's own limit; the W-length vectors live in LDS)
 constexpr int P_RESYNC = 16;        // steps between re-synchronisations of r = c - G k and of r_S = theta s_S
 enum { PATH_OK = 0, PATH_OVERFLOW = 1, PATH_STEPS = 2, PATH_SINGULAR = 3, PATH_BP = 4, PATH_ADJUST = 5 };
 
@@ -572,7 +572,7 @@ __global__ __launch_bounds__(256) void kp_lasso_path_theta_kernel(const char* __
 // [2] milliseconds, [3] 1 when the inverse lived in global memory.  known_active: the caller's least-squares solution exceeds every budget.
 int kp_lasso_path_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, int W, int ncols, const double* t, int nv, double* const* K_dev,
                             double* stats, bool known_active) {
-  if (W > P_WMAX) return ctx->fail(KP_ERR_ARG, "kp_fit_lasso: the homotopy serves W <= 384");
+  if (W > P_WMAX) return ctx->fail(KP_ERR_ARG, "kp_fit_lasso: the homotopy serves W <= 512");
   if (nv <= 0) return KP_OK;
   hipStream_t s = ctx->stream;
   const auto t_start = std::chrono::steady_clock::now();

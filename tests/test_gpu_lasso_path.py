@@ -217,3 +217,20 @@ def test_homotopy_on_random_problems_against_the_oracle_path():
             Ko, th = ko.koopman_lasso_path(G, C, ts[v])
             assert np.abs(K[v] - Ko).max() <= 1e-7 * np.abs(Ko).max(), (i, v, np.linalg.cond(G))
             assert abs(np.abs(K[v]).sum() - ts[v]) <= 1e-11 * ts[v], (i, v)
+
+
+def test_homotopy_at_the_widest_dictionary_the_library_takes(ctx):
+    """W = 500 (the library's limit is 512), 24 columns, cond(G) 1e8, budgets 0.5 and 0.05 |K_LS|_1: the walk runs with the inverse in
+    global memory once a support outgrows LDS; answers meet their budgets and the optimality conditions."""
+    rng = np.random.default_rng(5)
+    W, nc, Ns = 500, 24, 4000
+    sv = np.geomspace(1.0, 1e-4, W)
+    P = (np.linalg.qr(rng.standard_normal((Ns, W)))[0] * sv) @ np.linalg.qr(rng.standard_normal((W, W)))[0].T * np.sqrt(Ns)
+    Y = P @ (rng.standard_normal((W, nc)) * (rng.random((W, nc)) < 0.3)) + 0.05 * rng.standard_normal((Ns, nc))
+    G, C = P.T @ P, P.T @ Y
+    l1 = np.abs(np.linalg.solve(G, C)).sum()
+    ts = [0.5 * l1, 0.05 * l1]
+    Kh, ith, ms = _in_fresh_process(G, C, ts, {"KP_LASSO_PATH_AFTER": "0"})
+    assert ms > 0.0
+    for K, t in zip(Kh, ts):
+        _check_kkt(G, C, K, t, t)
