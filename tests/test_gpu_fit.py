@@ -637,3 +637,60 @@ def test_congruence_grams_of_dim_red_dictionaries_equal_the_per_pair_projection_
         scale = np.abs(res["general"]["G_" + mt]).max()
         for k in ("G_" + mt, "C_" + mt):
             assert np.abs(res["cong"][k] - res["general"][k]).max() <= 1e-11 * scale, k
+
+
+_PRELIFT_RANDOM_SCRIPT = """
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + '/tests')
+import koopman_realizations_amd as kra
+from conftest import synth_pairs
+ctx = kra.Context(0)
+rng = np.random.default_rng(77)
+out = {}
+for i in range(24):
+    nz = int(rng.integers(2, 7)); m = int(rng.integers(1, 4)); deg = int(rng.integers(2, 4)); Ns = int(rng.choice([3, 8, 9, 257, 4099, 20011]))
+    tab = kra.poly_exponent_table(nz, deg)
+    nfull = len(tab) + 1
+    if nfull > 96:
+        continue
+    p = synth_pairs(Ns, nz, m, seed=100 + i)
+    s = kra.Snapshots(ctx, p["alpha"], p["beta"], p["u"])
+    if i % 3 == 0:                                     # gaussian block beside the monomials
+        ng = int(rng.integers(1, 12))
+        if nz + (len(tab) - nz) + ng + 1 > 56:
+            ng = max(1, 56 - len(tab) - 1)
+        b = kra.Basis(ctx, "bilinear", nz, m, [("poly", tab[nz:]), ("gaussian", rng.uniform(-1, 1, (nz, ng)))])
+    else:                                              # dim_red
+        k = int(rng.integers(1, min(32, nfull - 1) + 1))
+        pcs = np.linalg.qr(rng.standard_normal((nfull, nfull)))[0][:, :k].copy()
+        b = kra.Basis(ctx, "bilinear", nz, m, [("poly", tab[nz:])], pcs)
+    G, C = kra.fit_gram(ctx, b, s)
+    out["G%d" % i] = G; out["C%d" % i] = C; out["d%d" % i] = np.array([nz, m, deg, Ns, b.N, b.W])
+np.savez(sys.argv[2], **out)
+"""
+
+
+def test_lifted_tiles_on_random_dictionaries_equal_the_in_kernel_lift():
+    """Two dozen random bilinear dictionaries - 2 ... 6 states, 1 ... 3 inputs, degree 2 / 3, dim_red with 1 ... 32 components or a
+    gaussian block, 3 ... 20 011 pairs (fewer than a tile, ragged tails) - through the lifted-tile form at every size
+    (KP_GRAM3_PRELIFT_MIN_NS=0) and through the in-kernel lift (KP_GRAM3_NO_PRELIFT=1): the same G, C to 1e-12 max|G|."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    with tempfile.TemporaryDirectory() as td:
+        for name, env in (("pre", {"KP_GRAM3_PRELIFT_MIN_NS": "0"}), ("proj", {"KP_GRAM3_NO_PRELIFT": "1"})):
+            f = os.path.join(td, name + ".npz")
+            r = subprocess.run([sys.executable, "-c", _PRELIFT_RANDOM_SCRIPT, root, f], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+            assert r.returncode == 0, r.stderr[-1500:]
+            res[name] = dict(np.load(f))
+    n = 0
+    for k in res["pre"]:
+        if k[0] in "GC":
+            a, b = res["pre"][k], res["proj"][k]
+            assert np.isfinite(a).all()
+            assert np.abs(a - b).max() <= 1e-12 * max(np.abs(res["proj"]["G" + k[1:]]).max(), 1e-300), (k, res["pre"]["d" + k[1:]])
+            n += 1
+    assert n >= 30
