@@ -570,8 +570,25 @@ __global__ __launch_bounds__(256) void kp_lasso_path_theta_kernel(const char* __
 // The lasso values t[0..nv) of one fit by the homotopy: K_dev[v] (W x ncols, device) <- K(theta_v).  G_dev: the Gram matrix as the
 // QP uses it (PSD guard applied), C_dev: W x ncols.  stats (may be NULL): [0] steps of phase 1 over all columns, [1] largest support,
 // [2] milliseconds, [3] 1 when the inverse lived in global memory.  known_active: the caller's least-squares solution exceeds every budget.
+static int path_batch(kp_ctx* ctx, const double* G_dev, const double* C_dev, int W, int ncols, const double* t, int nv, double* const* K_dev,
+                      double* stats, bool known_active);
+
 int kp_lasso_path_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, int W, int ncols, const double* t, int nv, double* const* K_dev,
                             double* stats, bool known_active) {
+  const int rc = path_batch(ctx, G_dev, C_dev, W, ncols, t, nv, K_dev, stats, known_active);
+  // the column states of a wide dictionary with the inverse in memory are gigabytes (W = 336: 0.9 GB, W = 512: 2.7 GB): not kept
+  // between calls (the answers have left them: they were written to K_dev by the kernels)
+  if (ctx->ws[12] && ctx->ws_bytes[12] > ((size_t)256 << 20)) {
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(ctx->ws[12]);
+    ctx->ws[12] = nullptr;
+    ctx->ws_bytes[12] = 0;
+  }
+  return rc;
+}
+
+static int path_batch(kp_ctx* ctx, const double* G_dev, const double* C_dev, int W, int ncols, const double* t, int nv, double* const* K_dev,
+                      double* stats, bool known_active) {
   if (W > P_WMAX) return ctx->fail(KP_ERR_ARG, "kp_fit_lasso: the homotopy serves W <= 512");
   if (nv <= 0) return KP_OK;
   hipStream_t s = ctx->stream;
