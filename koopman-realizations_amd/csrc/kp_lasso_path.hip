@@ -576,9 +576,9 @@ static int path_batch(kp_ctx* ctx, const double* G_dev, const double* C_dev, int
 int kp_lasso_path_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, int W, int ncols, const double* t, int nv, double* const* K_dev,
                             double* stats, bool known_active) {
   const int rc = path_batch(ctx, G_dev, C_dev, W, ncols, t, nv, K_dev, stats, known_active);
-  // the column states of a wide dictionary with the inverse in memory are gigabytes (W = 336: 0.9 GB, W = 512: 2.7 GB): not kept
+  // the column states of the widest dictionaries with the inverse in memory are gigabytes (W = 336: 0.9 GB - kept; W = 512: 2.7 GB): above 1.5 GB not kept
   // between calls (the answers have left them: they were written to K_dev by the kernels)
-  if (ctx->ws[12] && ctx->ws_bytes[12] > ((size_t)256 << 20)) {
+  if (ctx->ws[12] && ctx->ws_bytes[12] > ((size_t)1536 << 20)) {
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(ctx->ws[12]);
     ctx->ws[12] = nullptr;
