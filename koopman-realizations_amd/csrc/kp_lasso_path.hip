@@ -565,6 +565,40 @@ __global__ __launch_bounds__(256) void kp_lasso_path_theta_kernel(const char* __
   th = fmin(fmax(th, lo), hi);
   if (threadIdx.x == 0) theta_out[blockIdx.x] = th;
 }
+
+// The column states of an arena in the LDS layout (inverse with leading dimension Ls.ldm) copied into the layout of the
+// global-memory kernel (leading dimension W): a support has outgrown the LDS-resident inverse and the walk goes on where it is.
+// blockIdx.y: 0 = the walk's arena (with its breakpoint store), 1 = the state at the start of the round.
+__global__ __launch_bounds__(256) void kp_lasso_path_relayout_kernel(const char* __restrict__ src0, const char* __restrict__ src1, PathLayout Ls, char* __restrict__ dst0,
+                                                                    char* __restrict__ dst1, PathLayout Ld) {
+  const int col = blockIdx.x, tid = threadIdx.x, W = Ls.W;
+  const char* sb = (blockIdx.y ? src1 : src0) + (size_t)col * Ls.stride;
+  char* db = (blockIdx.y ? dst1 : dst0) + (size_t)col * Ld.stride;
+  const PathHdr h = *reinterpret_cast<const PathHdr*>(sb);
+  if (tid == 0) {
+    PathHdr o = h;
+    if (o.status == PATH_OVERFLOW) o.status = PATH_OK;
+    *reinterpret_cast<PathHdr*>(db) = o;
+  }
+  for (int i = tid; i < W; i += 256) {
+    reinterpret_cast<double*>(db + Ld.off_k)[i] = reinterpret_cast<const double*>(sb + Ls.off_k)[i];
+    reinterpret_cast<double*>(db + Ld.off_r)[i] = reinterpret_cast<const double*>(sb + Ls.off_r)[i];
+    reinterpret_cast<double*>(db + Ld.off_sgn)[i] = reinterpret_cast<const double*>(sb + Ls.off_sgn)[i];
+    reinterpret_cast<int*>(db + Ld.off_idx)[i] = reinterpret_cast<const int*>(sb + Ls.off_idx)[i];
+  }
+  const double* Ms = reinterpret_cast<const double*>(sb + Ls.off_M);
+  double* Md = reinterpret_cast<double*>(db + Ld.off_M);
+  for (int e = tid; e < h.cnt * h.cnt; e += 256) {
+    const int q = e / h.cnt, t = e - q * h.cnt;
+    Md[(size_t)q * Ld.ldm + t] = Ms[(size_t)q * Ls.ldm + t];
+  }
+  if (blockIdx.y == 0)
+    for (int i = tid; i < h.nbp; i += 256) {
+      reinterpret_cast<double*>(db + Ld.off_bpt)[i] = reinterpret_cast<const double*>(sb + Ls.off_bpt)[i];
+      reinterpret_cast<double*>(db + Ld.off_bpl)[i] = reinterpret_cast<const double*>(sb + Ls.off_bpl)[i];
+      reinterpret_cast<int*>(db + Ld.off_bpe)[i] = reinterpret_cast<const int*>(sb + Ls.off_bpe)[i];
+    }
+}
 }  // namespace
 
 // The lasso values t[0..nv) of one fit by the homotopy: K_dev[v] (W x ncols, device) <- K(theta_v).  G_dev: the Gram matrix as the
@@ -601,17 +635,21 @@ static int path_batch(kp_ctx* ctx, const double* G_dev, const double* C_dev, int
   double* hres = (double*)kp_pinned_scratch(ctx, (size_t)(8 + nv * 2 + nv * 8) * 8);
   if (!res || !hres) return ctx->fail(KP_ERR_HIP, "kp_fit_lasso: out of memory");
   for (int attempt = 0; attempt < 2; ++attempt) {
-    const PathLayout L = make_layout(W, mglobal, cap + 2);
+    PathLayout L = make_layout(W, mglobal, cap + 2);
     // two copies of the column states: the walk itself (with the breakpoint store) and the state at the start of the current round,
-    // from which the answers of the values that round brackets are walked
-    char* arena = (char*)ctx->workspace(12, 2 * L.stride * (size_t)ncols);
+    // from which the answers of the values that round brackets are walked.  Behind them, when a support can outgrow the LDS-resident
+    // inverse (ldm < W), room for the same two in the layout of the global-memory kernel: the walk MOVES there when it happens
+    const PathLayout Lg = make_layout(W, true, cap + 2);
+    const bool may_move = !mglobal && L.ldm < W;
+    char* arena = (char*)ctx->workspace(12, 2 * L.stride * (size_t)ncols + (may_move ? 2 * Lg.stride * (size_t)ncols : 0));
     if (!arena) return ctx->fail(KP_ERR_HIP, "kp_fit_lasso: out of device memory");
     char* snap = arena + L.stride * (size_t)ncols;
-    const int tpb = mglobal ? P_TPB_GLOBAL : P_TPB_LDS;
+    char* const arena_g = snap + L.stride * (size_t)ncols;
+    int tpb = mglobal ? P_TPB_GLOBAL : P_TPB_LDS;
     // G in LDS as well when it fits beside the whole inverse (W <= 96)
     static const bool no_gl = getenv("KP_LASSO_PATH_NO_GLDS") != nullptr;
-    const bool gl = !mglobal && !no_gl && L.ldm == W && path_lds_bytes(W, L.ldm, false, tpb) + (size_t)W * W * 8 <= (size_t)P_LDS_BYTES;
-    const size_t lds = path_lds_bytes(W, L.ldm, mglobal, tpb) + (gl ? (size_t)W * W * 8 : 0);
+    bool gl = !mglobal && !no_gl && L.ldm == W && path_lds_bytes(W, L.ldm, false, tpb) + (size_t)W * W * 8 <= (size_t)P_LDS_BYTES;
+    size_t lds = path_lds_bytes(W, L.ldm, mglobal, tpb) + (gl ? (size_t)W * W * 8 : 0);
     auto launch = [&](char* ar, double stop, int init, int record, double* Kout, int adjust = 0, double from = 0.0, int polish = 0) -> int {
       if (mglobal) {
         hipLaunchKernelGGL((kp_lasso_path_kernel<true, P_TPB_GLOBAL, false>), dim3(ncols), dim3(P_TPB_GLOBAL), lds, s, G_dev, C_dev, L, ar, stop, from, cap, init, record, adjust, polish, Kout);
@@ -659,6 +697,22 @@ static int path_batch(kp_ctx* ctx, const double* G_dev, const double* C_dev, int
       rc = summary(arena);
       if (rc) return rc;
       status = (int)hres[2]; steps1 = hres[3]; maxcnt = std::max(maxcnt, hres[5]);
+      if (status == PATH_OVERFLOW && may_move && !mglobal) {
+        // a support has outgrown the LDS-resident inverse: both state copies into the layout of the global-memory kernel, and on
+        // from where every column stands (the entry that did not fit sits on the boundary: the next step takes it)
+        hipLaunchKernelGGL(kp_lasso_path_relayout_kernel, dim3(ncols, 2), dim3(256), 0, s, arena, snap, L, arena_g, arena_g + Lg.stride * (size_t)ncols, Lg);
+        KP_HIP(ctx, hipGetLastError());
+        arena = arena_g;
+        snap = arena_g + Lg.stride * (size_t)ncols;
+        L = Lg;
+        mglobal = true; gl = false; tpb = P_TPB_GLOBAL;
+        lds = path_lds_bytes(W, L.ldm, true, tpb);
+        rc = launch(arena, stop, 0, 1, nullptr);
+        if (rc) return rc;
+        rc = summary(arena);
+        if (rc) return rc;
+        status = (int)hres[2]; steps1 = hres[3]; maxcnt = std::max(maxcnt, hres[5]);
+      }
       if (status == PATH_OVERFLOW) { overflow = true; break; }
       if (status != PATH_OK) break;
       const double l1_end = hres[0];
