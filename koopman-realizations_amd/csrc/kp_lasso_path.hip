@@ -16,8 +16,8 @@
 // parallel pass, no triangular solves - a dependent chain of |S| steps per solve would cost more than everything else), with
 // one step of iterative refinement of the bordering vector against G itself, which is what keeps M accurate at cond 1e10
 // (tools/lasso_homotopy_probe2.py: without it the adds break down, with it the KKT conditions hold to 1e-10 after 450 steps).
-// M lives in LDS while the support fits beside the vectors (136 entries at W = 136, 128 at W = 384), else in global memory
-// (template flag).
+// M lives in LDS while the support fits beside the vectors (136 entries at W = 136, 128 at W = 384); when a support outgrows it the
+// column states are copied into the layout of the global-memory form of the kernel (template flag) and the walk goes on there.
 //
 //   walk     all columns walk the path in rounds (theta targets theta_max / 16^r) and record (theta, |k|_1) at every breakpoint;
 //            after each round the host reads sum_j |k_j|_1: the values whose budget it now covers are bracketed by the round
