@@ -181,7 +181,7 @@ int kp_fit_lasso(kp_ctx* ctx, const double* G, const double* C, int W, int ncols
  * t: nv budgets; K: nv matrices W x ncols back to back; iters: nv counts (may be NULL; 0 = constraint inactive).
  * Each value ends either by convergence of the projected-gradient iteration (relative change <= tol) or, earlier, when
  * the active-set candidate built from its current support satisfies every optimality condition of the QP of
- * Ksysid.m:1126-1137 (then K is that QP's optimum to rounding), or - values still running after 24 (W <= 136 or a guarded Gram) or 100 iterations: the
+ * Ksysid.m:1126-1137 (then K is that QP's optimum to rounding), or - values still running after 24 iterations when W <= 136 or cond(G) > 1e7 (1 000 otherwise): the
  * ill-conditioned Grams of monomial dictionaries on real data - by the regularisation-path homotopy (ONE LARS-with-drops path
  * per column of K serves all of them; exact active-set optimum, |K|_1 = t to 1e-13; kp_timer_get(11) tells).
  * KP_ERR_NOT_CONVERGED: iteration cap (K still written). */

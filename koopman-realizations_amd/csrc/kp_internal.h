@@ -341,6 +341,7 @@ struct kp_lasso_prep {
   double L = 0.0, l1_ls = 0.0;
   int bad = 0;
   bool guarded = false;    // the 1e-6 PSD guard of Ksysid.m:1117-1120 was applied (cond(Gw) >= lambda_max / 1e-6)
+  double pivot_ratio = 1.0; // min_i L_ii^2 / G_ii of the least-squares factorisation (~1 / cond(G))
   double* Kls = nullptr;   // device, W x ncols
   double* Gw = nullptr;    // device copy of G (with the PSD guard applied when needed)
 };

@@ -710,6 +710,10 @@ static int lasso_copies(kp_ctx* ctx, hipStream_t s, std::vector<std::pair<const 
   return KP_OK;
 }
 
+// (kp_fit.hip) smallest pivot of the factorisation at the head of workspace 5 relative to its diagonal entry: ~1 / cond(G)
+__global__ void kp_pivot_ratio_kernel(const double* __restrict__ Lp, int n, const double* __restrict__ G, int W, double* __restrict__ out,
+                                      const int* __restrict__ info, double* host_out);
+
 // Least-squares solution + its L1 norm, PSD guard and Lipschitz constant: shared by all lasso values of one fit.
 int kp_lasso_prepare(kp_ctx* ctx, const double* G_dev, const double* C_dev, int W, int ncols, kp_lasso_prep* p) {
   const int64_t n = (int64_t)W * ncols;
@@ -734,6 +738,8 @@ int kp_lasso_prepare(kp_ctx* ctx, const double* G_dev, const double* C_dev, int 
   hipLaunchKernelGGL(kp_reduce_final_kernel, dim3(1), dim3(64), 0, s, part, scal);
   const int* info_dev = (const int*)((char*)ctx->ws[5] + kp_chol_info_offset(W, ncols));
   hipLaunchKernelGGL(kp_lasso_prep_pack_kernel, dim3(1), dim3(1), 0, s, info_dev, scal, scal + 3);   // scal[3] = |K_LS|_1, scal[4] = info
+  // scal[5] = min_i L_ii^2 / G_ii ~ 1 / cond(G): tells the batch whether the projected-gradient iteration (O(sqrt(cond)) steps) has a chance
+  hipLaunchKernelGGL(kp_pivot_ratio_kernel, dim3(1), dim3(256), 0, s, (const double*)ctx->ws[5], (W + 15) / 16 * 16, G_dev, W, scal + 5, info_dev, (double*)nullptr);
   // PSD guard of Ksysid.m:1117-1120: a non-PD Gram gets 1e-6 on the diagonal (decided on the device: no host round trip here)
   hipLaunchKernelGGL(kp_add_diag_if_kernel, dim3((W + 255) / 256), dim3(256), 0, s, p->Gw, W, 1e-6, info_dev);
   // Lipschitz constant of the gradient = lambda_max(G).  Round 2: 60 power iterations (120 launches, 0.7 ms) whose estimate
@@ -767,11 +773,11 @@ int kp_lasso_prepare(kp_ctx* ctx, const double* G_dev, const double* C_dev, int 
   }
   KP_HIP(ctx, hipGetLastError());
   // L, -, -, |K_LS|_1, info: one DMA (into the context's page-locked words when it has them), one synchronisation
-  double back[5];
+  double back[6];
   double* dst = ctx->pin_small ? ctx->pin_small : back;
   KP_HIP(ctx, hipMemcpyAsync(dst, scal, sizeof(back), hipMemcpyDeviceToHost, s));
   KP_HIP(ctx, hipStreamSynchronize(s));
-  p->L = dst[0]; p->l1_ls = dst[3]; p->bad = dst[4] != 0.0;
+  p->L = dst[0]; p->l1_ls = dst[3]; p->bad = dst[4] != 0.0; p->pivot_ratio = dst[5];
   if (!(p->L > 0.0)) return ctx->fail(KP_ERR_ARG, "kp_fit_lasso: Gram matrix is zero");
   if (p->bad) {
     p->guarded = true;
@@ -889,7 +895,11 @@ int kp_lasso_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, in
   // disables it, 0 sends every active value there at once
   static const int path_env = [] { const char* e = getenv("KP_LASSO_PATH_AFTER"); return e ? atoi(e) : -2; }();
   // (default: 24 iterations - the first three checks - while every support fits the LDS-resident inverse and the path costs 3 - 13 ms, 100 beyond)
-  const int path_after = path_env != -2 ? path_env : ((W <= 136 || prep->guarded) ? 24 : 100);     // (a guarded Gram is at cond 1e10: no point in waiting)
+  // wider dictionaries: at once when the Gram is guarded or its factorisation's pivot ratio says cond(G) > 1e7 (no point in waiting:
+  // O(sqrt(cond)) iterations), otherwise only as a late safety net - on a WELL-conditioned W = 336 problem a dense-support value
+  // (budget 0.99 |K_LS|_1) converges in 284 iterations = 13 ms, and its path takes 57 ms (tools/lasso_dense_wellcond_probe.py)
+  const bool ill = prep->guarded || prep->pivot_ratio < 1e-7;
+  const int path_after = path_env != -2 ? path_env : ((W <= 136 || ill) ? 24 : 1000);
   bool path_tried = false;
   std::string path_err;
   ctx->timers[11] = 0.0;
