@@ -70,3 +70,39 @@ def test_path_solver_takes_tied_entries_together():
         assert np.abs(K - K1).max() <= 1e-6 * np.abs(K1).max()
     K0, th0 = ko.koopman_lasso_path(G, C, 2.0 * np.abs(Kg).sum())
     assert th0 == 0.0 and np.abs(K0 - Kg).max() <= 1e-6 * np.abs(Kg).max()
+
+
+def test_both_oracle_solvers_solve_the_literal_qp_of_the_reference():
+    """The QP exactly as solve_KoopmanQP writes it (Ksysid.m:1112-1137): x = [K+; K-] >= 0, M = [I, -I], H = M'(I (x) Px'Px)M,
+    f = -M'vec(Px'Py), rows Aq = [-I; 1'], bq = [0; t] - solved here by a general-purpose solver (scipy, exact gradient and Hessian) on a
+    5 x 5 problem (trust-constr, an interior-point method like quadprog's default).  vec(K) = M x from that solver, the oracle's projected-gradient solver and its path solver agree (1e-5: the general solver's
+    stopping tolerance), and all three reach the same objective - the restatement `min 1/2|Px K - Py|^2 s.t. |vec K|_1 <= t` that the
+    oracle and the device work on IS the reference's QP."""
+    from scipy.optimize import minimize, LinearConstraint
+    rng = np.random.default_rng(12)
+    Nm = 5
+    Px = rng.standard_normal((60, Nm)); Py = Px @ (rng.standard_normal((Nm, Nm)) * (rng.random((Nm, Nm)) < 0.6)) + 0.1 * rng.standard_normal((60, Nm))
+    PxTPx = Px.T @ Px                                                       # :1114
+    PxTPy = Px.T @ Py                                                       # :1125
+    M = np.hstack([np.eye(Nm * Nm), -np.eye(Nm * Nm)])                      # :1112
+    ATA = np.kron(np.eye(Nm), PxTPx)                                        # :1126
+    ATb = PxTPy.reshape(Nm * Nm, 1, order="F")                              # :1127 (MATLAB reshape: column-major)
+    H = M.T @ (ATA @ M)                                                     # :1130-1131
+    f = (-M.T @ ATb).ravel()                                                # :1132
+    Kls = np.linalg.solve(PxTPx, PxTPy)
+    for frac in (0.7, 0.25):
+        t = frac * np.abs(Kls).sum()
+        Aq = np.vstack([-np.eye(2 * Nm * Nm), np.ones((1, 2 * Nm * Nm))])   # :1136
+        bq = np.concatenate([np.zeros(2 * Nm * Nm), [t]])                   # :1137
+        res = minimize(lambda x: 0.5 * x @ H @ x + f @ x, np.full(2 * Nm * Nm, t / (4 * Nm * Nm)), jac=lambda x: H @ x + f, hess=lambda x: H,
+                       method="trust-constr", constraints=[LinearConstraint(Aq, -np.inf, bq)],
+                       options={"gtol": 1e-11, "xtol": 1e-13, "barrier_tol": 1e-12, "maxiter": 5000})
+        assert res.constr_violation <= 1e-9, res.message
+        Kq = (M @ res.x).reshape(Nm, Nm, order="F")                         # :1172 xout = M x; reshaped by the caller (:1076)
+        K1 = ko.koopman_lasso(PxTPx, PxTPy, t)
+        K2, _ = ko.koopman_lasso_path(PxTPx, PxTPy, t)
+        obj = lambda K: 0.5 * np.linalg.norm(Px @ K - Py) ** 2
+        assert np.abs(K1 - K2).max() <= 1e-10 * np.abs(K1).max()
+        assert np.abs(Kq - K2).max() <= 1e-5 * np.abs(K2).max(), np.abs(Kq - K2).max()
+        assert abs(obj(Kq) - obj(K2)) <= 1e-8 * obj(K2)                          # (the interior-point answer stops just inside: no exact zeros, as quadprog's)
+        assert np.abs(Kq).sum() <= t * (1 + 1e-9)
