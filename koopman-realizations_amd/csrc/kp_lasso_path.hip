@@ -301,17 +301,22 @@ __global__ __launch_bounds__(TPB) void kp_lasso_path_kernel(const double* __rest
   // adjust: ONE move to theta_stop (above or below theta) along the current segment, no event - the caller knows it is tiny (an
   // entry pushed past zero by it, at the 1e-12 level, leaves in the next step of the walk)
   bool adjusted = false;
+  bool d_fresh = true;
   while (status == PATH_OK && (adjust ? (!adjusted && cnt > 0 && theta == theta_from && theta_stop != theta) : theta > theta_stop)) {
     if (steps >= max_steps) { status = PATH_STEPS; break; }
     ++steps;
     adjusted = true;
     // ---- every P_RESYNC steps: r = c - G k from scratch, k_S corrected so that r_S = theta s_S, r again
-    if (steps % P_RESYNC == 0 && cnt > 0 && !adjust) resync();
-    // ---- direction on the support, its image off the support
+    if (steps % P_RESYNC == 0 && cnt > 0 && !adjust) { resync(); d_fresh = true; }
+    // ---- direction on the support (d = M s_S: formed afresh at the start of a launch and after a re-synchronisation, otherwise
+    // carried through the bordering / deletion of M in O(|S|) - one pass over M less per step), its image off the support
     for (int t = tid; t < cnt; t += PT) sS[t] = sg[idx[t]];
     if (tid < 24) sc_i[tid] = 0;
     __syncthreads();
-    mv_sym<TPB>(M, ld, cnt, sS, d, red);
+    if (d_fresh) {
+      mv_sym<TPB>(M, ld, cnt, sS, d, red);
+      d_fresh = false;
+    }
     // compact list of the rows off the support (order: by index)
     {
       int noff = 0;
@@ -396,6 +401,11 @@ __global__ __launch_bounds__(TPB) void kp_lasso_path_kernel(const double* __rest
         l1 -= fabs(k[ei]);
         last_del = ei; last_del_sgn = sg[ei];
         rank1<TPB>(M, ld, cnt, u, -inv);
+        {                                               // d of the remaining support: d - m d_q / m_q
+          const double dq = d[qd] * inv;
+          __syncthreads();
+          for (int t = tid; t < cnt; t += PT) d[t] -= u[t] * dq;
+        }
         __syncthreads();
         const int last = cnt - 1;
         if (qd != last) {
@@ -404,7 +414,7 @@ __global__ __launch_bounds__(TPB) void kp_lasso_path_kernel(const double* __rest
           if (tid == 0) { M[(size_t)qd * ld + qd] = M[(size_t)last * ld + last]; }
         }
         __syncthreads();
-        if (tid == 0) { if (qd != last) idx[qd] = idx[last]; sg[ei] = 0.0; k[ei] = 0.0; }
+        if (tid == 0) { if (qd != last) { idx[qd] = idx[last]; d[qd] = d[last]; } sg[ei] = 0.0; k[ei] = 0.0; }
         cnt = last;
         __syncthreads();
       } else {
@@ -418,14 +428,17 @@ __global__ __launch_bounds__(TPB) void kp_lasso_path_kernel(const double* __rest
           mv_gather<TPB>(G, W, idx, cnt, idx, cnt, u, e);                   // e = G_SS u
           for (int t = tid; t < cnt; t += PT) e[t] = g[t] - e[t];
           __syncthreads();
-          mv_sym<TPB>(M, ld, cnt, e, d, red);                                // (d is free here: rebuilt every step)
-          double dot = 0.0;
-          for (int t = tid; t < cnt; t += PT) { const double ut = u[t] + d[t]; u[t] = ut; dot += g[t] * ut; }
+          mv_sym<TPB>(M, ld, cnt, e, a, red);                                // (a is free here: rebuilt every step)
+          double dot = 0.0, us = 0.0;
+          for (int t = tid; t < cnt; t += PT) { const double ut = u[t] + a[t]; u[t] = ut; dot += g[t] * ut; us += ut * sS[t]; }
           dot = wsum(dot);
-          if (lane == 0) sc_s[wave] = dot;
+          us = wsum(us);
+          if (lane == 0) { sc_s[wave] = dot; sc_d[wave] = us; }
           __syncthreads();
           const double gpp = G[(size_t)ei * W + ei];
           const double alpha = gpp - (sum_waves());
+          double us_all = sc_d[0];
+          for (int w = 1; w < NW; ++w) us_all += sc_d[w];
           if (!(alpha > 1e-10 * gpp)) {
             // the entering column is (numerically) a combination of the support's columns - an exact twin in a Gram that got past
             // the factorisation without the guard.  It adds nothing to the fit: barred from this column's support for good
@@ -435,7 +448,10 @@ __global__ __launch_bounds__(TPB) void kp_lasso_path_kernel(const double* __rest
             const double inv = 1.0 / alpha;
             rank1<TPB>(M, ld, cnt, u, inv);
             for (int t = tid; t < cnt; t += PT) { const double v = -u[t] * inv; M[(size_t)cnt * ld + t] = v; M[(size_t)t * ld + cnt] = v; }
-            if (tid == 0) { M[(size_t)cnt * ld + cnt] = inv; idx[cnt] = ei; sg[ei] = s; }
+            // d of the bordered support: [d + u (u's - s_p) / alpha ; (s_p - u's) / alpha]
+            const double coef = (us_all - s) * inv;
+            for (int t = tid; t < cnt; t += PT) d[t] += u[t] * coef;
+            if (tid == 0) { M[(size_t)cnt * ld + cnt] = inv; idx[cnt] = ei; sg[ei] = s; d[cnt] = -coef; }
             cnt += 1;
             last_add = ei;
           }
