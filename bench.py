@@ -416,8 +416,8 @@ def bench_width_points(ctx, kra, Ns):
     centres = rng.uniform(-1, 1, (6, 20))
     shapes = [("W200", kra.Basis(ctx, "bilinear", 6, 3, [("poly", tab[6:49])]), snaps, "kp_gram3_kernel<6,3,false>"),
               ("W136_pcs", kra.Basis(ctx, "bilinear", 6, 3, [("poly", tab[6:])], pcs), snaps, "kp_gram3_prelift_kernel + kp_gram3_kernel<.,3,false,false,true>"),
-              ("fourier1_nzeta3", kra.Basis(ctx, "bilinear", 3, 3, [("fourier", 1)]), snaps3, None),
-              ("gaussian20", kra.Basis(ctx, "bilinear", 6, 3, [("gaussian", centres)]), snaps, None)]
+              ("fourier1_nzeta3", kra.Basis(ctx, "bilinear", 3, 3, [("fourier", 1)]), snaps3, "kp_gram3_prelift_ext_kernel + kp_gram3_kernel<.,3,false,false,true>"),
+              ("gaussian20", kra.Basis(ctx, "bilinear", 6, 3, [("gaussian", centres)]), snaps, "kp_gram3_prelift_ext_kernel + kp_gram3_kernel<.,3,false,false,true>")]
     if os.environ.get("KP_BENCH_MORE_WIDTHS"):    # same width without the projection: what the econ lift costs
         shapes.append(("W136_plain", kra.Basis(ctx, "bilinear", 6, 3, [("poly", tab[6:33])]), snaps, "kp_gram3_kernel"))
     for name, basis, sn, kern in shapes:
