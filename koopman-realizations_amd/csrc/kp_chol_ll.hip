@@ -317,8 +317,10 @@ __device__ __forceinline__ void ll_stage_rows(const double* __restrict__ A, int 
 
 }  // namespace
 
+// thr (or nullptr): pivot thresholds of the n rows supplied by the caller - the blocked factorisation of wide systems hands
+// down the thresholds of the ORIGINAL diagonal, which a trailing-updated diagonal block no longer shows (single systems only)
 __global__ __launch_bounds__(LL_NT) void kp_chol_ll_kernel(double* __restrict__ A, int n, int* __restrict__ info, int* __restrict__ sticky,
-                                                           int prof) {
+                                                           int prof, const double* __restrict__ thr) {
   long long tph[6] = {0, 0, 0, 0, 0, 0}, tlast = 0;   // KP_CHOL_PROF=1: cycles per phase (wave 0)
 #define LL_TICK(i) do { if (prof) { long long tnow = clock64(); tph[i] += tnow - tlast; tlast = tnow; } } while (0)
   extern __shared__ __align__(16) double sm[];
@@ -335,7 +337,7 @@ __global__ __launch_bounds__(LL_NT) void kp_chol_ll_kernel(double* __restrict__ 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: loop bounds and tile counts live in SGPRs
   A += blockIdx.y * (size_t)n * n; info += blockIdx.y;   // system of a batch
   if (tid == 0) bad = 0;
-  for (int i = tid; i < n; i += LL_NT) odiag[i] = fmax(A[(size_t)i * n + i], 0.0) * ((double)n * 8.0 * 2.220446049250313e-16);
+  for (int i = tid; i < n; i += LL_NT) odiag[i] = thr ? thr[i] : fmax(A[(size_t)i * n + i], 0.0) * ((double)n * 8.0 * 2.220446049250313e-16);
   // panel 0: S = A(:, 0:16); panel 1 of A into its buffer
   for (int e = tid; e < 16 * n; e += LL_NT) {
     const int c = e / n, x = e - c * n;
@@ -478,12 +480,12 @@ bool kp_chol_ll_applicable(int n) {
 
 static size_t kp_chol_ll_lds_bytes(int n) { return (size_t)3 * 16 * (n + 4) * sizeof(double); }
 
-hipError_t kp_chol_ll_launch(double* Gp, int n, int nb, int* info, int* sticky, int prof, hipStream_t st) {
+hipError_t kp_chol_ll_launch(double* Gp, int n, int nb, int* info, int* sticky, int prof, hipStream_t st, const double* thr) {
   static KpLdsCache lds_cache;
   const size_t lds = kp_chol_ll_lds_bytes(n);
   hipError_t e = kp_ensure_lds(lds_cache, (const void*)kp_chol_ll_kernel, kp_chol_ll_lds_bytes(LL_NMAX));
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kp_chol_ll_kernel, dim3(1, nb), dim3(LL_NT), lds, st, Gp, n, info, sticky, prof);
+  hipLaunchKernelGGL(kp_chol_ll_kernel, dim3(1, nb), dim3(LL_NT), lds, st, Gp, n, info, sticky, prof, thr);
   e = hipGetLastError();
   if (prof && e == hipSuccess) {                  // diagnostic only: synchronous
     long long t[16];

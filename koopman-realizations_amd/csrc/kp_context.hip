@@ -78,7 +78,7 @@ extern "C" int kp_destroy(kp_ctx* c) {
   kp_stage_destroy(c);
   (void)hipStreamSynchronize(c->stream);
   if (c->stream2) (void)hipStreamSynchronize(c->stream2);
-  for (int i = 0; i < 15; ++i)
+  for (int i = 0; i < 20; ++i)
     if (c->ws[i]) (void)hipFree(c->ws[i]);
   if (c->sticky_info) (void)hipFree(c->sticky_info);
   if (c->pin_small) (void)hipHostFree(c->pin_small);
@@ -414,10 +414,12 @@ extern "C" int kp_basis_dims(const kp_basis* b, int* nvars, int* nfull, int* N, 
 // wave writes 64 consecutive rows of one column (coalesced).
 // ------------------------------------------------------------------------------------
 
-#define LT 64
-
+// LT points per workgroup (64; 16 when the full lift of a projected dictionary would not fit the LDS at 64).  ldi / ldo: leading
+// dimensions of the input columns and of the output (the wide Gram path, kp_wide.hip, lifts a row range of the snapshot arrays
+// into a panel of its own).
+template <int LT>
 __global__ __launch_bounds__(256) void kp_lift_kernel(BasisDev b, int what, const double* __restrict__ zeta,
-                                                      const double* __restrict__ u, int64_t rows,
+                                                      const double* __restrict__ u, int64_t rows, int64_t ldi, int64_t ldo,
                                                       double* __restrict__ out) {
   extern __shared__ double sm[];
   // layout: vars[nvars][LT] | um[m][LT] | full[nfull][LT] (only when k_pcs)
@@ -432,11 +434,11 @@ __global__ __launch_bounds__(256) void kp_lift_kernel(BasisDev b, int what, cons
     double x = 0.0;
     if (p < nl) {
       if (v < b.nzeta)
-        x = zeta[(int64_t)v * rows + r0 + p];
+        x = zeta[(int64_t)v * ldi + r0 + p];
       else if (v < b.nvars)  // nonlinear: u appended to zeta
-        x = u[(int64_t)(v - b.nzeta) * rows + r0 + p];
+        x = u[(int64_t)(v - b.nzeta) * ldi + r0 + p];
       else if (u)
-        x = u[(int64_t)(v - b.nvars) * rows + r0 + p];
+        x = u[(int64_t)(v - b.nvars) * ldi + r0 + p];
     }
     if (v < b.nvars)
       vars[v * LT + p] = x;
@@ -453,10 +455,10 @@ __global__ __launch_bounds__(256) void kp_lift_kernel(BasisDev b, int what, cons
       double val = kp_eval_col(b, b.cols[c], vars + p, LT);
       int64_t r = r0 + p;
       if (what == KP_LIFT_ROW && b.model_type == KP_MODEL_BILINEAR) {
-        out[(int64_t)c * rows + r] = val;
-        for (int i = 0; i < b.m; ++i) out[(int64_t)((i + 1) * b.N + c) * rows + r] = val * um[i * LT + p];
+        out[(int64_t)c * ldo + r] = val;
+        for (int i = 0; i < b.m; ++i) out[(int64_t)((i + 1) * b.N + c) * ldo + r] = val * um[i * LT + p];
       } else {
-        out[(int64_t)c * rows + r] = val;
+        out[(int64_t)c * ldo + r] = val;
       }
     }
   } else {
@@ -479,30 +481,43 @@ __global__ __launch_bounds__(256) void kp_lift_kernel(BasisDev b, int what, cons
       } else
         val = 1.0;
       int64_t r = r0 + p;
-      out[(int64_t)c * rows + r] = val;
+      out[(int64_t)c * ldo + r] = val;
       if (what == KP_LIFT_ROW && b.model_type == KP_MODEL_BILINEAR)
-        for (int i = 0; i < b.m; ++i) out[(int64_t)((i + 1) * b.N + c) * rows + r] = val * um[i * LT + p];
+        for (int i = 0; i < b.m; ++i) out[(int64_t)((i + 1) * b.N + c) * ldo + r] = val * um[i * LT + p];
     }
   }
   if (what == KP_LIFT_ROW && b.model_type == KP_MODEL_LINEAR) {  // [psi , u]  Ksysid.m:1062
     for (int e = tid; e < b.m * LT; e += 256) {
       int i = e / LT, p = e % LT;
-      if (p < nl) out[(int64_t)(b.N + i) * rows + r0 + p] = um[i * LT + p];
+      if (p < nl) out[(int64_t)(b.N + i) * ldo + r0 + p] = um[i * LT + p];
     }
   }
 }
 
-// device-to-device lift (used by kp_lift and kp_fit_refine): zeta, u, out are device pointers
-int kp_lift_dev(kp_ctx* ctx, const kp_basis* basis, int what, const double* dz, const double* du, int64_t rows, double* dout) {
+// device-to-device lift (used by kp_lift, kp_fit_refine and the wide Gram path): zeta, u, out are device pointers; ldi / ldo as
+// in the kernel
+int kp_lift_dev_ld(kp_ctx* ctx, const kp_basis* basis, int what, const double* dz, const double* du, int64_t rows, int64_t ldi, double* dout,
+                   int64_t ldo) {
   const BasisDev& b = basis->dev;
-  size_t lds = (size_t)(b.nvars + (b.m > 0 ? b.m : 1) + (b.k_pcs ? b.nfull : 0)) * LT * 8;
+  const size_t per_point = (size_t)(b.nvars + (b.m > 0 ? b.m : 1) + (b.k_pcs ? b.nfull : 0)) * 8;
+  const int lt = per_point * 64 <= 160 * 1024 ? 64 : 16;
+  const size_t lds = per_point * lt;
   if (lds > 160 * 1024) return ctx->fail(KP_ERR_ARG, "kp_lift: dictionary too large for the LDS staging of the pcs projection");
-  if (lds > 64 * 1024)
-    KP_HIP(ctx, hipFuncSetAttribute((const void*)kp_lift_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  int64_t nblk = (rows + LT - 1) / LT;
-  hipLaunchKernelGGL(kp_lift_kernel, dim3((unsigned)nblk), dim3(256), lds, ctx->stream, b, what, dz, du, rows, dout);
+  static KpLdsCache c64, c16;
+  const int64_t nblk = (rows + lt - 1) / lt;
+  if (lt == 64) {
+    KP_HIP(ctx, kp_ensure_lds(c64, (const void*)kp_lift_kernel<64>, lds));
+    hipLaunchKernelGGL(kp_lift_kernel<64>, dim3((unsigned)nblk), dim3(256), lds, ctx->stream, b, what, dz, du, rows, ldi, ldo, dout);
+  } else {
+    KP_HIP(ctx, kp_ensure_lds(c16, (const void*)kp_lift_kernel<16>, lds));
+    hipLaunchKernelGGL(kp_lift_kernel<16>, dim3((unsigned)nblk), dim3(256), lds, ctx->stream, b, what, dz, du, rows, ldi, ldo, dout);
+  }
   KP_HIP(ctx, hipGetLastError());
   return KP_OK;
+}
+
+int kp_lift_dev(kp_ctx* ctx, const kp_basis* basis, int what, const double* dz, const double* du, int64_t rows, double* dout) {
+  return kp_lift_dev_ld(ctx, basis, what, dz, du, rows, rows, dout, rows);
 }
 
 extern "C" int kp_lift(kp_ctx* ctx, const kp_basis* basis, int what, const double* zeta, const double* u, int64_t rows,
@@ -522,14 +537,9 @@ extern "C" int kp_lift(kp_ctx* ctx, const kp_basis* basis, int what, const doubl
   if (!dz || !du || !dout) return ctx->fail(KP_ERR_HIP, "kp_lift: out of device memory");
   KP_HIP(ctx, hipMemcpyAsync(dz, zeta, bz, hipMemcpyHostToDevice, ctx->stream));
   if (u && bu) KP_HIP(ctx, hipMemcpyAsync(du, u, bu, hipMemcpyHostToDevice, ctx->stream));
-  size_t lds = (size_t)(b.nvars + (b.m > 0 ? b.m : 1) + (b.k_pcs ? b.nfull : 0)) * LT * 8;
-  if (lds > 160 * 1024) return ctx->fail(KP_ERR_ARG, "kp_lift: dictionary too large for the LDS staging of the pcs projection");
-  if (lds > 64 * 1024)
-    KP_HIP(ctx, hipFuncSetAttribute((const void*)kp_lift_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  int64_t nblk = (rows + LT - 1) / LT;
   KP_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-  hipLaunchKernelGGL(kp_lift_kernel, dim3((unsigned)nblk), dim3(256), lds, ctx->stream, b, what, dz, (u && bu) ? du : nullptr, rows, dout);
-  KP_HIP(ctx, hipGetLastError());
+  int rc = kp_lift_dev_ld(ctx, basis, what, dz, (u && bu) ? du : nullptr, rows, rows, dout, rows);
+  if (rc) return rc;
   KP_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   KP_HIP(ctx, hipMemcpyAsync(out, dout, bo, hipMemcpyDeviceToHost, ctx->stream));
   KP_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -400,7 +400,7 @@ __device__ __forceinline__ int tr2_col(int c) { return (c & 3) * NJ + (c >> 2); 
 
 // an[q][K] = -(A operand of tile (row(q), column block jc)): rows 4 blk + jj of the tile, column 4 K + kq
 template <int CNT>
-__device__ __forceinline__ void tr2_load(double (&an)[TR2_MAXR][4], const double* __restrict__ LU, int n, int jc, const int (&rowof)[TR2_MAXR], int kq,
+__device__ __forceinline__ void tr2_load(double (&an)[TR2_MAXR][4], const double* __restrict__ LU, int64_t n, int jc, const int (&rowof)[TR2_MAXR], int kq,
                                          int blk, int jj) {
 #pragma unroll
   for (int q = 0; q < CNT; ++q)
@@ -478,9 +478,13 @@ __device__ __forceinline__ void tr2_read_b(const double* __restrict__ xs, int j,
 // of systems: NJ = 4 (every workgroup reads all of L: fewer, wider workgroups keep that traffic down).
 // Kout (or nullptr): the solution goes there unpadded (W x ncols, leading dimension W) instead of back into X - the single-
 // system path, which then needs no unpad launch behind it.
+// ldl / ldx: leading dimensions of LU and X (the blocked factorisation of wide systems, kp_wide.hip, substitutes against a
+// diagonal block that sits inside a larger matrix and right-hand sides that are rows of one); dirs: 1 = forward only,
+// 2 = backward only, 3 = both.
 template <int NJ>
 __global__ __launch_bounds__(256) void kp_trsm2_kernel(const double* __restrict__ LU, const double* __restrict__ Dinv, int n, int ncp,
-                                                      double* __restrict__ X, double* __restrict__ Kout, int W, int ncols) {
+                                                      double* __restrict__ X, double* __restrict__ Kout, int W, int ncols, int64_t ldl, int64_t ldx,
+                                                      int dirs) {
   extern __shared__ __align__(16) double xs[];  // [n][4 NJ] X block, columns in tr2_col order
   constexpr int NC = 4 * NJ;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -488,15 +492,16 @@ __global__ __launch_bounds__(256) void kp_trsm2_kernel(const double* __restrict_
   const int cb = blockIdx.x;
   const int nt = n / 16;
   const int kq = lane >> 4, blk = (lane >> 2) & 3, jj = lane & 3;
-  LU += blockIdx.y * (size_t)n * n; Dinv += blockIdx.y * (size_t)nt * 256; X += blockIdx.y * (size_t)n * ncp;   // system of a batch
-  double* Xb = X + (size_t)cb * NC * n;
+  LU += blockIdx.y * (size_t)n * n; Dinv += blockIdx.y * (size_t)nt * 256; X += blockIdx.y * (size_t)ldx * ncp;   // system of a batch
+  double* Xb = X + (size_t)cb * NC * ldx;
   for (int e = tid; e < n * NC; e += 256) {
     int row = e % n, col = e / n;
-    xs[row * NC + tr2_col<NJ>(col)] = Xb[(size_t)col * n + row];       // C block -> LDS (overwritten by Y, then K)
+    xs[row * NC + tr2_col<NJ>(col)] = Xb[(size_t)col * ldx + row];       // C block -> LDS (overwritten by Y, then K)
   }
   __syncthreads();
   const int nown = wave < nt ? (nt - wave + 3) / 4 : 0;    // row blocks wave, wave + 4, ... < nt
   for (int dir = 0; dir < 2; ++dir) {                      // 0: L Y = C (forward), 1: L' K = Y (backward)
+    if (!((dirs >> dir) & 1)) continue;
     // slot q <-> row block, the rows that retire LAST first, so that the rows a step still reaches are always the slots
     // [0, cnt) and the row that retires next is slot cnt - 1: forward rows retire ascending (slot 0 = the largest row),
     // backward descending (slot 0 = the smallest)
@@ -572,7 +577,7 @@ __global__ __launch_bounds__(256) void kp_trsm2_kernel(const double* __restrict_
       }
       // tiles of column j for the rows beyond it: requested now, used after the barrier
       cnt = beyond(j);
-      TR2_SWITCH((tr2_load<C_>(an, LU, n, j, rowof, kq, blk, jj)));
+      TR2_SWITCH((tr2_load<C_>(an, LU, ldl, j, rowof, kq, blk, jj)));
       // LDS-only barrier: the tile loads just issued stay in flight across it (a __syncthreads would wait for them)
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       tr2_read_b<NJ>(xs, j, kq, jj, bv);
@@ -586,9 +591,99 @@ __global__ __launch_bounds__(256) void kp_trsm2_kernel(const double* __restrict_
       const int gc = cb * NC + col;
       if (row < W && gc < ncols) Kout[(size_t)gc * W + row] = v;
     } else {
-      Xb[(size_t)col * n + row] = v;
+      Xb[(size_t)col * ldx + row] = v;
     }
   }
+}
+
+// ---- systems beyond one workgroup's reach (n > 512): blocked right-looking factorisation over MANY workgroups ------------------
+// The reference solves `K = Px \ Py` (Ksysid.m:1069) for whatever dictionary the user configured; its fourier dictionary on the
+// arm's six states has 738 (linear) / 2 940 (bilinear) columns (Ksysid.m:694-731).  Structure (block = KP_WIDE_BS columns, 256):
+//   for each diagonal block k:  D = A_kk (gathered from the upper triangle)  ->  kp_chol_ll_kernel (the one-workgroup
+//   factorisation of the narrow path, with the pivot thresholds of the ORIGINAL diagonal)  ->  kp_chol_finish_kernel (L' and the
+//   inverses of the 16 x 16 diagonal blocks)  ->  back into A;   U_12 = L_kk^-1 A_12: kp_trsm2_kernel<4>, forward sweep only, the
+//   right-hand sides are the COLUMNS of the upper block row (contiguous along the contraction index of what follows);
+//   A_22 -= U_12' U_12: kp_tn_gemm (upper tiles only, every CU).
+// Only the upper triangle is ever updated; it is mirrored once at the end (the backward sweep reads L = U').  The solve is the
+// same three kernels: per block a forward (then backward) substitution against the diagonal block and one TN product that
+// takes the block's solution out of all remaining rows.  The one-workgroup chain (~0.5 us per column) is then only the
+// diagonal blocks; everything O(n^3) runs on all CUs.
+__global__ __launch_bounds__(256) void kp_wide_thresh_kernel(const double* __restrict__ A, int n, double* __restrict__ thr) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) thr[i] = fmax(A[(size_t)i * n + i], 0.0) * ((double)n * 8.0 * 2.220446049250313e-16);
+}
+
+// D (b x b) = symmetric block of A at (k0, k0), read from the UPPER triangle;  back: both triangles of the factored block
+__global__ __launch_bounds__(256) void kp_wide_diag_kernel(double* __restrict__ A, int n, int k0, int b, double* __restrict__ D, int back) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= b * b) return;
+  const int i = e % b, j = e / b;
+  if (back) A[(size_t)(k0 + j) * n + k0 + i] = D[e];
+  else D[e] = A[(size_t)(k0 + max(i, j)) * n + k0 + min(i, j)];
+}
+
+static int wide_block() {               // (read per call: the tests vary it)
+  const char* e = getenv("KP_WIDE_BS");
+  const int b = e ? atoi(e) : 256;
+  return std::max(16, std::min(352, b)) / 16 * 16;
+}
+
+#include "kp_tn_gemm.h"
+
+// Gp (n x n, padded, identity beyond W), Cp (n x ncp): factor Gp in place (L below, L' above the diagonal, as the narrow path
+// leaves it), Dinv = inverses of the 16 x 16 diagonal blocks, Cp := Gp^-1 Cp.  *info is set when a pivot falls below its threshold.
+static int chol_solve_wide(kp_ctx* ctx, double* Gp, double* Cp, double* Dinv, int n, int ncp, int* info, int* sticky, hipStream_t st) {
+  const int bs = wide_block();
+  double* scr = (double*)ctx->workspace(18, ((size_t)bs * bs + n) * 8 + 64);
+  if (!scr) return ctx->fail(KP_ERR_HIP, "kp_fit_solve: out of device memory");
+  double* D = scr;
+  double* thr = scr + (size_t)bs * bs;
+  int* dummy = (int*)(thr + n);
+  static KpLdsCache trsm_lds;
+  KP_HIP(ctx, kp_ensure_lds(trsm_lds, (const void*)kp_trsm2_kernel<4>, (size_t)352 * 16 * 8));
+  KP_HIP(ctx, hipMemsetAsync(info, 0, sizeof(int), st));
+  hipLaunchKernelGGL(kp_wide_thresh_kernel, dim3((n + 255) / 256), dim3(256), 0, st, Gp, n, thr);
+  for (int k0 = 0; k0 < n; k0 += bs) {
+    const int b = std::min(bs, n - k0), R = n - k0 - b;
+    double* Akk = Gp + (size_t)k0 * n + k0;
+    double* A12 = Gp + (size_t)(k0 + b) * n + k0;
+    hipLaunchKernelGGL(kp_wide_diag_kernel, dim3((b * b + 255) / 256), dim3(256), 0, st, Gp, n, k0, b, D, 0);
+    KP_HIP(ctx, kp_chol_ll_launch(D, b, 1, dummy, info, 0, st, thr + k0));
+    {
+      const int nbk = b / 16, npair = nbk * (nbk - 1) / 2;
+      hipLaunchKernelGGL(kp_chol_finish_kernel, dim3(npair + nbk, 1), dim3(256), 0, st, D, b, npair, Dinv + (size_t)(k0 / 16) * 256);
+    }
+    hipLaunchKernelGGL(kp_wide_diag_kernel, dim3((b * b + 255) / 256), dim3(256), 0, st, Gp, n, k0, b, D, 1);
+    KP_HIP(ctx, hipGetLastError());
+    if (R > 0) {
+      hipLaunchKernelGGL((kp_trsm2_kernel<4>), dim3(R / 16, 1), dim3(256), (size_t)b * 16 * 8, st, Akk, Dinv + (size_t)(k0 / 16) * 256, b, R, A12, (double*)nullptr, 0, 0,
+                         (int64_t)n, (int64_t)n, 1);
+      KP_HIP(ctx, hipGetLastError());
+      KP_HIP(ctx, kp_tn_gemm(st, A12, n, A12, n, R, R, b, Gp + (size_t)(k0 + b) * n + k0 + b, n, -1.0, 1.0, 1, 1, nullptr));
+    }
+  }
+  hipLaunchKernelGGL(kp_mirror_upper_kernel, dim3(n / 16, n / 16), dim3(256), 0, st, Gp, n, (int64_t)n);
+  KP_HIP(ctx, hipGetLastError());
+  if (sticky) {   // (the deferred pipeline's word; wide fits run synchronously, so this is only for symmetry with the narrow path)
+    KP_HIP(ctx, hipMemcpyAsync(sticky, info, sizeof(int), hipMemcpyDeviceToDevice, st));
+  }
+  // forward: L Y = C, block rows ascending; the block's Y leaves all later rows by one product
+  for (int k0 = 0; k0 < n; k0 += bs) {
+    const int b = std::min(bs, n - k0), R = n - k0 - b;
+    hipLaunchKernelGGL((kp_trsm2_kernel<4>), dim3(ncp / 16, 1), dim3(256), (size_t)b * 16 * 8, st, Gp + (size_t)k0 * n + k0, Dinv + (size_t)(k0 / 16) * 256, b, ncp,
+                       Cp + k0, (double*)nullptr, 0, 0, (int64_t)n, (int64_t)n, 1);
+    KP_HIP(ctx, hipGetLastError());
+    if (R > 0) KP_HIP(ctx, kp_tn_gemm(st, Gp + (size_t)(k0 + b) * n + k0, n, Cp + k0, n, R, ncp, b, Cp + k0 + b, n, -1.0, 1.0, 0, 1, nullptr));
+  }
+  // backward: L' K = Y, block rows descending; K_k leaves the rows above through L (the mirrored lower triangle)
+  for (int k0 = (n - 1) / bs * bs; k0 >= 0; k0 -= bs) {
+    const int b = std::min(bs, n - k0);
+    hipLaunchKernelGGL((kp_trsm2_kernel<4>), dim3(ncp / 16, 1), dim3(256), (size_t)b * 16 * 8, st, Gp + (size_t)k0 * n + k0, Dinv + (size_t)(k0 / 16) * 256, b, ncp,
+                       Cp + k0, (double*)nullptr, 0, 0, (int64_t)n, (int64_t)n, 2);
+    KP_HIP(ctx, hipGetLastError());
+    if (k0 > 0) KP_HIP(ctx, kp_tn_gemm(st, Gp + k0, n, Cp + k0, n, k0, ncp, b, Cp, n, -1.0, 1.0, 0, 1, nullptr));
+  }
+  return KP_OK;
 }
 
 // nb systems [G | C] gc_stride doubles apart (W x W each; ncols = W when nb > 1); system y's K goes to
@@ -606,11 +701,21 @@ int kp_chol_solve_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_de
   int* info = (int*)(ws + (size_t)nb * (bG + bC + bD));   // nb = 1: kp_chol_info_offset(W, ncols), the readers' formula
   size_t lds_chol = (size_t)2 * 16 * n * 8;
   size_t lds_trsm = ((size_t)n * 16 + 1024) * 8;
-  if (lds_chol > 160 * 1024 - 8192 || lds_trsm > 160 * 1024 || n > 16 * 4 * TR_MAXJ) return ctx->fail(KP_ERR_ARG, "kp_fit_solve: W too large (max 512)");
+  const bool wide = n > 16 * 4 * TR_MAXJ;
+  if (wide && nb != 1) return ctx->fail(KP_ERR_ARG, "kp_fit_solve: systems wider than 512 are solved one at a time");
+  if (!wide && (lds_chol > 160 * 1024 - 8192 || lds_trsm > 160 * 1024)) return ctx->fail(KP_ERR_ARG, "kp_fit_solve: W too large");
   int64_t tot = (int64_t)n * n + (int64_t)n * ncp;
   hipLaunchKernelGGL(kp_pad_kernel, dim3((unsigned)((tot + 255) / 256), nb), dim3(256), 0, st, G_dev, C_dev, W, ncols, n, ncp, Gp, Cp, gc_stride);
   KP_HIP(ctx, hipGetLastError());
   if (pad_done) KP_HIP(ctx, hipEventRecord(pad_done, st));
+  if (wide) {      // blocked factorisation and substitution over all CUs
+    int rc = chol_solve_wide(ctx, Gp, Cp, Dinv, n, ncp, info, sticky, st);
+    if (rc) return rc;
+    double* Kdst = K_dev + (k_cap > 0 ? (size_t)(k_first % k_cap) * W * ncols : 0);
+    hipLaunchKernelGGL(kp_unpad_kernel, dim3((unsigned)(((int64_t)W * ncols + 255) / 256), 1), dim3(256), 0, st, Cp, n, W, ncols, Kdst, ncp, 0, 0);
+    KP_HIP(ctx, hipGetLastError());
+    return KP_OK;
+  }
   static KpLdsCache chol_lds, trsm_lds;
   static const int chol_prof = getenv("KP_CHOL_PROF") ? atoi(getenv("KP_CHOL_PROF")) : 0;
   if (kp_chol_ll_applicable(n)) {                 // n <= 352: left-looking factorisation on the matrix pipe (kp_chol_ll.hip)
@@ -632,13 +737,15 @@ int kp_chol_solve_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_de
     // K written in place (no unpad launch): the ring offset kp_unpad_kernel would apply is applied here - a lone queued fit
     // flushed at pend_first % k_cap != 0 must land in ITS slot of the result ring, not in slot 0
     double* Kdst = K_dev + (k_cap > 0 ? (size_t)(k_first % k_cap) * W * ncols : 0);
-    hipLaunchKernelGGL((kp_trsm2_kernel<1>), dim3(ncp / 4, nb), dim3(256), (size_t)n * 4 * 8, st, Gp, Dinv, n, ncp, Cp, Kdst, W, ncols);
+    hipLaunchKernelGGL((kp_trsm2_kernel<1>), dim3(ncp / 4, nb), dim3(256), (size_t)n * 4 * 8, st, Gp, Dinv, n, ncp, Cp, Kdst, W, ncols, (int64_t)n,
+                       (int64_t)n, 3);
     KP_HIP(ctx, hipGetLastError());
     return KP_OK;
   } else {                    // a batch: 16 per workgroup, every workgroup reads all of L
     static KpLdsCache trsm2_lds;
     KP_HIP(ctx, kp_ensure_lds(trsm2_lds, (const void*)kp_trsm2_kernel<4>, (size_t)n * 16 * 8));
-    hipLaunchKernelGGL((kp_trsm2_kernel<4>), dim3(ncp / 16, nb), dim3(256), (size_t)n * 16 * 8, st, Gp, Dinv, n, ncp, Cp, (double*)nullptr, W, ncols);
+    hipLaunchKernelGGL((kp_trsm2_kernel<4>), dim3(ncp / 16, nb), dim3(256), (size_t)n * 16 * 8, st, Gp, Dinv, n, ncp, Cp, (double*)nullptr, W, ncols,
+                       (int64_t)n, (int64_t)n, 3);
   }
   KP_HIP(ctx, hipGetLastError());
   hipLaunchKernelGGL(kp_unpad_kernel, dim3((unsigned)(((int64_t)W * ncols + 255) / 256), nb), dim3(256), 0, st, Cp, n, W, ncols, K_dev, ncp, k_first,
@@ -870,7 +977,8 @@ extern "C" int kp_fit(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* sn
       if (lasso && lasso[i] < 1e6) return false;
     return true;
   }();
-  const bool go_async = !K_out && n_lasso == 1 && all_ls && ctx->stream2 && ctx->sticky_info && !ctx->reduce_grams && !ctx->gc_preloaded && !getenv("KP_NO_ASYNC");
+  // (wide dictionaries, W > 512, take the synchronous path: a ring of 128 [G | C] pairs of that size would be tens of GB)
+  const bool go_async = !K_out && n_lasso == 1 && all_ls && ctx->stream2 && ctx->sticky_info && !ctx->reduce_grams && !ctx->gc_preloaded && W <= 512 && !getenv("KP_NO_ASYNC");
   int rc;
   // The [G | C] ring may hold queued Gram pairs that are not solved yet (deferred, batched solves): drain the pipeline
   // BEFORE any buffer of it can be reallocated for another width - ensure_gc frees and reallocates GC when the new W needs

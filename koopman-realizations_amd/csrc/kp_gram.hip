@@ -400,13 +400,13 @@ int kp_gram_launch(kp_ctx* ctx, const kp_basis* basis_c, const kp_snapshots* s, 
     if (rc) return rc;
   }
   kp_gram_plan& plan = *basis->plan;
-  if ((uint32_t)(2 * KT * plan.Wp) > 65535u) return ctx->fail(KP_ERR_ARG, "kp_fit_gram: dictionary too wide");
+  if ((uint32_t)(2 * KT * plan.Wp) > 65535u) return kp_gram_wide_launch(ctx, basis, s, GC_dev);
   const bool fast = basis->fast;
   const int D = fast ? basis->pow_depth : 1;
   const int pcs_in_lds = (b.k_pcs > 0 && (size_t)b.k_pcs * b.nfull * 8 <= 40 * 1024) ? 1 : 0;
   GramLds L = gram_lds(b, plan.Wp, D, pcs_in_lds);
   size_t lds = (size_t)L.total * sizeof(double);
-  if (lds > 160 * 1024) return ctx->fail(KP_ERR_ARG, "kp_fit_gram: dictionary too wide for the LDS-staged tile (W > ~580)");
+  if (lds > 160 * 1024) return kp_gram_wide_launch(ctx, basis, s, GC_dev);   // W > ~580: lifted panels in HBM + TN products (kp_wide.hip)
   if (2 * (b.nzeta + b.m) * KT > 3 * 256) return ctx->fail(KP_ERR_ARG, "kp_fit_gram: too many raw columns");
   int64_t ktiles = (s->Ns + KT - 1) / KT;
   int ncu = ctx->num_cu > 0 ? ctx->num_cu : 256;

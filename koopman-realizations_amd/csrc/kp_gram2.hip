@@ -433,7 +433,7 @@ int kp_gram2_launch(kp_ctx* ctx, const kp_basis* basis_c, const kp_snapshots* s,
   size_t lds = ((size_t)2 * (nraw * D + 1) * KT + (size_t)2 * 2 * KT * plan.Wp + plan.Wp) * sizeof(double);
   const int bm = b.model_type == KP_MODEL_BILINEAR ? b.m : 0;
   if (lds > 160 * 1024 || (uint32_t)(2 * KT * plan.Wp) > 65535u)
-    return ctx->fail(KP_ERR_ARG, "kp_fit_gram: dictionary too wide for the LDS-staged tile (W > ~580)");
+    return kp_gram_wide_launch(ctx, basis, s, GC_dev);   // W > ~580: lifted panels in HBM + TN products (kp_wide.hip)
   int64_t ktiles = (s->Ns + KT - 1) / KT;
   int ncu = std::max(8, (ctx->num_cu > 0 ? ctx->num_cu : 256) - ctx->reserve_cus);
   int nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(ktiles, ncu / plan.nsuper > 0 ? ncu / plan.nsuper : 1));

@@ -75,8 +75,9 @@ struct kp_ctx {
   double timers[12] = {0};
   double gram_flops_per_pair = 0;
   // growable device workspaces
-  void* ws[15] = {nullptr};     // slot 8: staging of the collectives, 9: rank-revealing solve, 10 / 11: Grams of the shadow dictionary of a dim_red fit, their half-transformed form
-  size_t ws_bytes[15] = {0};   // 12 / 13: column states and results of the lasso homotopy (kp_lasso_path.hip); 14: econ-lifted rows of a dim_red fit (kp_gram3.hip)
+  void* ws[20] = {nullptr};     // slot 8: staging of the collectives, 9: rank-revealing solve, 10 / 11: Grams of the shadow dictionary of a dim_red fit, their half-transformed form
+  size_t ws_bytes[20] = {0};   // 12 / 13: column states and results of the lasso homotopy (kp_lasso_path.hip); 14: econ-lifted rows of a dim_red fit (kp_gram3.hip)
+                                // 15 / 16: lifted snapshot panels of a wide dictionary, 17: split partials of its products, 18: scratch of the blocked factorisation (kp_wide.hip, kp_fit.hip)
   int last_rank = -1;           // rank found by the most recent solve (W when the Gram matrix was positive definite)
   double last_pivot_ratio = 1.0; // min_i L_ii^2 / G_ii of the most recent synchronous least-squares solve (~1 / cond(G))
   // results of the last kp_fit
@@ -316,7 +317,7 @@ inline int kp_gram_dispatch(kp_ctx* ctx, const kp_basis* basis, const kp_snapsho
 }
 // kp_chol_ll.hip: left-looking single-workgroup Cholesky for n <= 352 (in place, lower triangle; `info` as kp_chol_kernel)
 bool kp_chol_ll_applicable(int n);
-hipError_t kp_chol_ll_launch(double* Gp, int n, int nb, int* info, int* sticky, int prof, hipStream_t st);
+hipError_t kp_chol_ll_launch(double* Gp, int n, int nb, int* info, int* sticky, int prof, hipStream_t st, const double* thr = nullptr);
 int kp_pivchol_solve_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, int W, int ncols, double* K_dev, int* rank);
 int kp_comm_allreduce_dev(kp_ctx* ctx, double* buf_dev, size_t count, hipStream_t s);
 // queued (deferred) solves of the asynchronous pipeline are launched; nothing is waited for, no status is consumed (kp_fit.hip)
@@ -324,6 +325,10 @@ int kp_flush_pending(kp_ctx* ctx);
 int kp_snapshots_update_rows(kp_ctx* ctx, kp_snapshots* s, const double* alpha, const double* beta, const double* u, int64_t Ns, int64_t ld);
 int kp_ensure_gc(kp_ctx* ctx, int W);   // the context's [G | C] buffer for width W (kp_fit.hip)
 int kp_lift_dev(kp_ctx* ctx, const kp_basis* basis, int what, const double* dz, const double* du, int64_t rows, double* dout);
+// the same with leading dimensions: `rows` rows of input columns ldi apart into output columns ldo apart
+int kp_lift_dev_ld(kp_ctx* ctx, const kp_basis* basis, int what, const double* dz, const double* du, int64_t rows, int64_t ldi, double* dout, int64_t ldo);
+// dictionaries too wide for the LDS-staged Gram kernels: lifted panels in HBM + TN products on the matrix pipe (kp_wide.hip)
+int kp_gram_wide_launch(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* s, double* GC_dev);
 int kp_chol_solve_dev(kp_ctx* ctx, double* G_dev, double* C_dev, int W, int ncols, double* K_dev, hipStream_t st = nullptr,
                       hipEvent_t pad_done = nullptr, int* sticky = nullptr);
 // Where kp_chol_solve_dev leaves its info word (non-zero: a non-positive pivot) in workspace 5, behind the padded copies of

@@ -1,0 +1,249 @@
+// C (M x N) = beta C + alpha A' B,  A: K x M, B: K x N, all column-major f64 with leading dimensions lda / ldb / ldc - the
+// "TN" product, BOTH operands contiguous along the contraction index.  It is the one product every stage of the WIDE
+// path needs (dictionaries beyond the LDS-staged Gram kernels and the one-workgroup factorisation, W > 512: the reference's
+// fourier dictionary on the arm's six states has 728 functions, Ksysid.m:694-731):
+//   * Gram matrices of a lifted snapshot panel, G += Px' Px (upper tiles only, `tri`), C += Px' Py  (Ksysid.m:1114, 1125);
+//   * trailing update of the blocked Cholesky factorisation, A22 -= U12' U12 (upper tiles only);
+//   * block substitution, C_rest -= U12' Y_k  and  Y_rest -= L21' K_k  (kp_wide.hip).
+// Same skeleton as kp_symm_gemm2_kernel (kp_symm_gemm.h): 4-wave workgroup, output tile 16 RA x 16 RB, wave w owns 4 RA rows as
+// RA x RB accumulators of v_mfma_f64_4x4x4_4b, contraction in blocks of 16 double-buffered in LDS ([row][k], row stride 20
+// doubles), one barrier per block, operand addresses base + immediate, result tile through LDS so that the stores run along
+// the columns of C, XCD-aware workgroup order.  New here: general leading dimensions (64-bit tile bases + 32-bit offsets),
+// a contraction RANGE per workgroup (split-K over blockIdx.y into partial buffers, summed in split order by
+// kp_tn_gemm_reduce_kernel: bitwise reproducible), the alpha / beta epilogue and the triangular tile skip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define TNG_KB 16
+#define TNG_RS 20
+
+template <int RA, int RB>
+struct TngCfg {
+  static constexpr int TM = 16 * RA, TN = 16 * RB;
+  static constexpr int BUF = (TM + TN) * TNG_RS;
+  static constexpr int OS = TM + 4;
+  static constexpr int ECH = RB < 4 ? RB : 4;
+  static constexpr int LDS_DOUBLES = (2 * BUF > 16 * ECH * OS) ? 2 * BUF : 16 * ECH * OS;
+  static constexpr size_t LDS_BYTES = (size_t)LDS_DOUBLES * 8;
+};
+
+struct TngArgs {
+  const double* A; const double* B; double* C;
+  double* P;                 // split-K partials [split][N][M] (nsplit > 1)
+  int64_t lda, ldb, ldc;
+  int M, N, K;
+  int kper;                  // contraction range of a split (multiple of TNG_KB)
+  int nsplit, nrt, nct, tri;
+  double alpha, beta;
+};
+
+template <int RA, int RB>
+__global__ __launch_bounds__(256, 2) void kp_tn_gemm_kernel(TngArgs g) {
+  using Cfg = TngCfg<RA, RB>;
+  constexpr int TM = Cfg::TM, TN = Cfg::TN, BUF = Cfg::BUF, OS = Cfg::OS, RS = TNG_RS, KB = TNG_KB, ECH = Cfg::ECH;
+  extern __shared__ double sm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int ct = (slot / g.nrt) * 8 + xcd, rt = slot % g.nrt;
+  if (ct >= g.nct) return;
+  const int r0 = rt * TM, c0 = ct * TN;
+  if (g.tri && r0 > c0 + TN - 1) return;            // tile strictly below the diagonal: nobody reads it
+  const int split = blockIdx.y;
+  const int k_lo = split * g.kper, k_hi = min(g.K, k_lo + g.kper);
+  const int klen = max(0, k_hi - k_lo);
+
+  const int sk = tid & 15, sr = tid >> 4;
+  unsigned go[RA], xo[RB];
+#pragma unroll
+  for (int p = 0; p < RA; ++p) {
+    const int row = sr + 16 * p;
+    go[p] = (unsigned)(((int64_t)(r0 + row < g.M ? row : 0) * g.lda + sk) * 8);
+  }
+#pragma unroll
+  for (int p = 0; p < RB; ++p) {
+    const int col = sr + 16 * p;
+    xo[p] = (unsigned)(((int64_t)(c0 + col < g.N ? col : 0) * g.ldb + sk) * 8);
+  }
+  const char* Ab = (const char*)(g.A + (int64_t)r0 * g.lda + k_lo);
+  const char* Bb = (const char*)(g.B + (int64_t)c0 * g.ldb + k_lo);
+  const int so = sr * RS + sk;
+  double sg[RA], sx[RB];
+  const int nkb = (klen + KB - 1) / KB, nkb_full = klen / KB;
+  auto stage_load = [&](int kb) {
+    if (kb < nkb_full) {
+      const unsigned ko = (unsigned)kb * (KB * 8u);
+#pragma unroll
+      for (int p = 0; p < RA; ++p) sg[p] = *(const double*)(Ab + (go[p] + ko));
+#pragma unroll
+      for (int p = 0; p < RB; ++p) sx[p] = *(const double*)(Bb + (xo[p] + ko));
+    } else {
+      const int k = kb * KB + sk;
+      const bool kok = k < klen;
+      const unsigned ko = (unsigned)((kok ? k : klen - 1) - sk) * 8u;
+#pragma unroll
+      for (int p = 0; p < RA; ++p) { const double v = *(const double*)(Ab + (go[p] + ko)); sg[p] = kok ? v : 0.0; }
+#pragma unroll
+      for (int p = 0; p < RB; ++p) { const double v = *(const double*)(Bb + (xo[p] + ko)); sx[p] = kok ? v : 0.0; }
+    }
+  };
+  auto stage_store = [&](int buf) {
+    double* d = sm + buf * BUF + so;
+#pragma unroll
+    for (int p = 0; p < RA; ++p) d[16 * p * RS] = sg[p];
+#pragma unroll
+    for (int p = 0; p < RB; ++p) d[(TM + 16 * p) * RS] = sx[p];
+  };
+
+  const int lc = lane & 3, blk = (lane >> 2) & 3, lk = lane >> 4;
+  const int ab = (wave * 4 * RA + lc) * RS + lk;
+  const int bb = (TM + 4 * blk + lc) * RS + lk;
+  double acc[RA][RB];
+#pragma unroll
+  for (int ra = 0; ra < RA; ++ra)
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) acc[ra][rb] = 0.0;
+
+  auto compute = [&](const double* s) {
+    double a[2][RA], b[2][RB];
+#pragma unroll
+    for (int ra = 0; ra < RA; ++ra) a[0][ra] = s[ab + 4 * ra * RS];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) b[0][rb] = s[bb + 16 * rb * RS];
+#pragma unroll
+    for (int kk = 0; kk < KB / 4; ++kk) {
+      const int cur = kk & 1, nxt = cur ^ 1;
+      if (kk + 1 < KB / 4) {
+#pragma unroll
+        for (int ra = 0; ra < RA; ++ra) a[nxt][ra] = s[ab + 4 * ra * RS + 4 * (kk + 1)];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) b[nxt][rb] = s[bb + 16 * rb * RS + 4 * (kk + 1)];
+      }
+#pragma unroll
+      for (int ra = 0; ra < RA; ++ra)
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) acc[ra][rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[cur][ra], b[cur][rb], acc[ra][rb], 0, 0, 0);
+    }
+  };
+
+  if (nkb > 0) {
+    stage_load(0);
+    stage_store(0);
+  }
+  __syncthreads();
+  for (int kb = 0; kb < nkb; kb += 2) {
+    if (kb + 1 < nkb) stage_load(kb + 1);
+    compute(sm);
+    if (kb + 1 < nkb) stage_store(1);
+    __syncthreads();
+    if (kb + 1 >= nkb) break;
+    if (kb + 2 < nkb) stage_load(kb + 2);
+    compute(sm + BUF);
+    if (kb + 2 < nkb) stage_store(0);
+    __syncthreads();
+  }
+  // result tile through LDS, 16 ECH columns at a time
+  double* Pp = g.nsplit > 1 ? g.P + (size_t)split * g.M * g.N : nullptr;
+#pragma unroll
+  for (int ch = 0; ch < RB; ch += ECH) {
+    if (ch) __syncthreads();
+#pragma unroll
+    for (int ra = 0; ra < RA; ++ra)
+#pragma unroll
+      for (int rb = 0; rb < ECH; ++rb)
+        if (ch + rb < RB) sm[(16 * rb + 4 * blk + lc) * OS + wave * 4 * RA + 4 * ra + lk] = acc[ra][ch + rb];
+    __syncthreads();
+    for (int e = tid; e < TM * 16 * ECH; e += 256) {
+      const int j = e / TM, i = e - j * TM, jc = c0 + 16 * ch + j;
+      if (r0 + i < g.M && jc < g.N && 16 * ch + j < TN) {
+        const double v = sm[j * OS + i];
+        if (Pp) Pp[(size_t)jc * g.M + r0 + i] = v;
+        else {
+          double* dst = g.C + (int64_t)jc * g.ldc + r0 + i;
+          *dst = g.beta != 0.0 ? g.beta * *dst + g.alpha * v : g.alpha * v;
+        }
+      }
+    }
+  }
+}
+
+// C = beta C + alpha sum_s P[s], splits in order; the tiles the product skipped (`tri`) are skipped here too
+static __global__ __launch_bounds__(256) void kp_tn_gemm_reduce_kernel(const double* __restrict__ P, int nsplit, int M, int N, double* __restrict__ C, int64_t ldc,
+                                                                double alpha, double beta, int tri, int TM, int TN) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (int64_t)M * N) return;
+  const int i = (int)(e % M), j = (int)(e / M);
+  if (tri && (i / TM) * TM > (j / TN) * TN + TN - 1) return;
+  double s = 0.0;
+  for (int p = 0; p < nsplit; ++p) s += P[(size_t)p * M * N + e];
+  double* dst = C + (int64_t)j * ldc + i;
+  *dst = beta != 0.0 ? beta * *dst + alpha * s : alpha * s;
+}
+
+// lower triangle := transpose of the upper one (n x n, leading dimension ld)
+static __global__ __launch_bounds__(256) void kp_mirror_upper_kernel(double* __restrict__ A, int n, int64_t ld) {
+  __shared__ double T[16][17];
+  const int bi = blockIdx.x, bj = blockIdx.y;          // block (rows bi, columns bj) of the UPPER triangle: bi <= bj
+  if (bi > bj) return;
+  const int ti = threadIdx.x & 15, tj = threadIdx.x >> 4;
+  const int i = 16 * bi + ti, j = 16 * bj + tj;
+  T[tj][ti] = (i < n && j < n) ? A[(int64_t)j * ld + i] : 0.0;
+  __syncthreads();
+  // element (row 16 bj + ti, column 16 bi + tj) of the lower triangle = upper (16 bi + tj, 16 bj + ti)
+  const int r = 16 * bj + ti, c = 16 * bi + tj;
+  if (r < n && c < n && r > c) A[(int64_t)c * ld + r] = T[ti][tj];
+}
+
+template <int RA, int RB>
+static hipError_t tng_launch_cfg(hipStream_t st, TngArgs g) {
+  using Cfg = TngCfg<RA, RB>;
+  static bool attr_set[32] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 32 || !attr_set[dev]) {
+    hipError_t e = hipFuncSetAttribute((const void*)kp_tn_gemm_kernel<RA, RB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 32) attr_set[dev] = true;
+  }
+  g.nrt = (g.M + Cfg::TM - 1) / Cfg::TM;
+  g.nct = (g.N + Cfg::TN - 1) / Cfg::TN;
+  const int nblk = 8 * ((g.nct + 7) / 8) * g.nrt;
+  hipLaunchKernelGGL((kp_tn_gemm_kernel<RA, RB>), dim3(nblk, g.nsplit), dim3(256), Cfg::LDS_BYTES, st, g);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess || g.nsplit <= 1) return e;
+  hipLaunchKernelGGL(kp_tn_gemm_reduce_kernel, dim3((unsigned)(((int64_t)g.M * g.N + 255) / 256)), dim3(256), 0, st, g.P, g.nsplit, g.M, g.N, g.C, g.ldc,
+                     g.alpha, g.beta, g.tri, Cfg::TM, Cfg::TN);
+  return hipGetLastError();
+}
+
+// Number of contraction splits that fills the device: `slots` workgroup slots (2 per CU), `tiles` output tiles.
+static inline int tng_pick_splits(int M, int N, int K, int tri, int slots) {
+  const int64_t tiles = (int64_t)((M + 127) / 128) * ((N + 63) / 64) / (tri ? 2 : 1) + 1;
+  int ns = (int)((slots + tiles - 1) / tiles);
+  const int max_by_k = (K + 16 * TNG_KB - 1) / (16 * TNG_KB);      // at least 16 contraction blocks per split
+  if (ns > max_by_k) ns = max_by_k;
+  if (ns > 64) ns = 64;
+  return ns < 1 ? 1 : ns;
+}
+
+// P (or nullptr): room for nsplit * M * N doubles when nsplit > 1.
+static inline hipError_t kp_tn_gemm(hipStream_t st, const double* A, int64_t lda, const double* B, int64_t ldb, int M, int N, int K, double* C, int64_t ldc,
+                                    double alpha, double beta, int tri, int nsplit, double* P) {
+  if (M <= 0 || N <= 0) return hipSuccess;
+  // tile rows are addressed by 32-bit byte offsets from the tile's base
+  if ((uint64_t)128 * (uint64_t)(lda > ldb ? lda : ldb) * 8u + (uint64_t)K * 8u >= (1ull << 32)) return hipErrorInvalidValue;
+  TngArgs g;
+  g.A = A; g.B = B; g.C = C; g.P = P;
+  g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+  g.M = M; g.N = N; g.K = K;
+  g.nsplit = (nsplit > 1 && P) ? nsplit : 1;
+  g.kper = ((K + g.nsplit - 1) / g.nsplit + TNG_KB - 1) / TNG_KB * TNG_KB;
+  if (g.kper < TNG_KB) g.kper = TNG_KB;
+  g.nsplit = g.nsplit > 1 ? (K + g.kper - 1) / g.kper : 1;
+  if (g.nsplit < 1) g.nsplit = 1;
+  g.nrt = g.nct = 0;
+  g.tri = tri;
+  g.alpha = alpha; g.beta = beta;
+  if (M <= 64) return tng_launch_cfg<4, 4>(st, g);
+  return tng_launch_cfg<8, 4>(st, g);
+}

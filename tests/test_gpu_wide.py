@@ -1,0 +1,113 @@
+"""GPU parity tests of the WIDE path (W > 512): dictionaries the reference accepts as they come - `def_fourierLift` on the
+arm's six states gives 728 functions (Ksysid.m:694-731; linear row 738 columns, bilinear row 2 940), poly-3 on a
+delay-embedded state 816 (Ksysid.m:868-907) - and `K = Px \\ Py` on them (Ksysid.m:1069).  Device side: lifted panels in HBM +
+TN products on the matrix pipe (csrc/kp_wide.hip, kp_tn_gemm.h), blocked Cholesky / substitution over all CUs
+(csrc/kp_fit.hip `chol_solve_wide`).  Oracle: oracle/koopman_oracle.py on the same inputs.  Tolerances (f64):
+  G, C   1e-12 relative to max|G|
+  K      max(1e-9, 50 cond(Px)^2 eps) relative to max|K| against the SVD least-squares oracle (normal equations)
+  solve  residual |G K - C| <= 1e-11 |G| |K| against a dense numpy solve on random SPD systems
+"""
+import os
+
+import numpy as np
+import pytest
+
+import koopman_realizations_amd as kra
+from koopman_realizations_amd import _ffi as F
+from oracle import koopman_oracle as ko
+from conftest import synth_pairs
+from test_gpu_fit import make_basis
+
+pytestmark = pytest.mark.gpu
+
+EPS = 2.220446049250313e-16
+
+WIDE_CASES = [
+    ("linear", 6, 3, ["fourier"], [1], False),        # SURVEY row a7 at the size it names: 728 functions, W = 738
+    ("bilinear", 6, 3, ["fourier"], [1], False),      # the same dictionary in a bilinear row: W = 2 940
+    ("linear", 15, 3, ["poly"], [3], False),          # poly-3 on a delay-embedded arm state (nzeta = 15): 816 functions
+    ("bilinear", 6, 3, ["poly"], [4], False),         # N = 210, W = 840: beyond the Kronecker kernel's 96 columns
+]
+
+
+@pytest.mark.parametrize("mt,nz,m,types,degs,dim_red", WIDE_CASES)
+def test_wide_lift_and_gram_parity(ctx, mt, nz, m, types, degs, dim_red):
+    Ns = 1003
+    pairs = synth_pairs(Ns, nz, m, seed=7)
+    dic = ko.build_dictionary(mt, nz, m, types, degs, pairs, dim_red)
+    b = make_basis(ctx, dic)
+    assert (b.nfull, b.N, b.W) == (dic.basis.nfull, dic.N, dic.W)
+    assert b.W > 512
+    Px, Py = ko.px_py(dic, pairs)
+    np.testing.assert_allclose(b.lift(F.LIFT_ROW, pairs["alpha"], pairs["u"]), Px, atol=1e-13, rtol=0)
+    snaps = kra.Snapshots(ctx, pairs["alpha"], pairs["beta"], pairs["u"])
+    G, C = kra.fit_gram(ctx, b, snaps)
+    Gr, Cr = ko.gram(Px, Py)
+    scale = np.abs(Gr).max()
+    assert np.abs(G - Gr).max() <= 1e-12 * scale
+    assert np.abs(C - Cr).max() <= 1e-12 * scale
+    assert (G == G.T).all()
+    G2, C2 = kra.fit_gram(ctx, b, snaps)
+    assert (G2 == G).all() and (C2 == C).all()          # fixed split / panel order: bitwise reproducible
+
+
+def test_wide_gram_accumulates_over_panels(ctx):
+    """The lifted panel is bounded (KP_WIDE_PANEL_MB); a snapshot matrix longer than one panel is accumulated panel by
+    panel, ragged last panel included: same Grams as one panel to rounding."""
+    pairs = synth_pairs(3001, 6, 3, seed=12)
+    dic = ko.build_dictionary("linear", 6, 3, ["fourier"], [1])
+    b = make_basis(ctx, dic)
+    snaps = kra.Snapshots(ctx, pairs["alpha"], pairs["beta"], pairs["u"])
+    G1, C1 = kra.fit_gram(ctx, b, snaps)
+    os.environ["KP_WIDE_PANEL_MB"] = "1"                 # -> 1024-row panels: 3 panels, the last one 953 rows
+    try:
+        G3, C3 = kra.fit_gram(ctx, b, snaps)
+    finally:
+        del os.environ["KP_WIDE_PANEL_MB"]
+    s = np.abs(G1).max()
+    assert np.abs(G3 - G1).max() <= 1e-13 * s and np.abs(C3 - C1).max() <= 1e-13 * s
+    assert (G3 == G3.T).all()
+    Px, Py = ko.px_py(dic, pairs)
+    Gr, Cr = ko.gram(Px, Py)
+    assert np.abs(G3 - Gr).max() <= 1e-12 * s and np.abs(C3 - Cr).max() <= 1e-12 * s
+
+
+@pytest.mark.parametrize("W,nc,bs", [(513, 513, None), (600, 7, None), (777, 777, 128), (1000, 1000, None), (1000, 33, 352), (2940, 64, None)])
+def test_wide_solve_random_spd(ctx, W, nc, bs):
+    """kp_fit_solve beyond one workgroup's reach: blocked factorisation + substitution, ragged sizes, few and many
+    right-hand sides, several block sizes."""
+    rng = np.random.default_rng(W + nc)
+    A = rng.standard_normal((W + 50, W))
+    G = A.T @ A / W + 0.1 * np.eye(W)
+    Cm = rng.standard_normal((W, nc))
+    if bs:
+        os.environ["KP_WIDE_BS"] = str(bs)
+    try:
+        K = ctx.fit_solve(G, Cm)
+    finally:
+        os.environ.pop("KP_WIDE_BS", None)
+    Kr = np.linalg.solve(G, Cm)
+    assert np.abs(K - Kr).max() <= 1e-10 * np.abs(Kr).max()
+    assert np.abs(G @ K - Cm).max() <= 1e-11 * np.abs(G).sum(axis=1).max() * np.abs(K).max()
+
+
+@pytest.mark.parametrize("mt,Ns", [("linear", 4000), ("bilinear", 7000)])
+def test_wide_fit_fourier_on_six_states(ctx, mt, Ns):
+    """SURVEY row a7 end to end: the 728-function fourier dictionary of `def_fourierLift` on six states, K = Px \\ Py."""
+    pairs = synth_pairs(Ns, 6, 3, seed=5)
+    dic = ko.build_dictionary(mt, 6, 3, ["fourier"], [1])
+    b = make_basis(ctx, dic)
+    assert b.W == (738 if mt == "linear" else 2940)
+    snaps = kra.Snapshots(ctx, pairs["alpha"], pairs["beta"], pairs["u"])
+    K = kra.fit(ctx, b, snaps)[0]
+    assert ctx.last_rank() == b.W
+    Px, Py = ko.px_py(dic, pairs)
+    sv = np.linalg.svd(Px, compute_uv=False)
+    cond = sv[0] / sv[-1]
+    Kr = ko.koopman_ls(Px, Py)
+    tol = max(1e-9, 50 * cond ** 2 * EPS)
+    assert np.abs(K - Kr).max() <= tol * np.abs(Kr).max(), (cond, np.abs(K - Kr).max() / np.abs(Kr).max())
+    # the pipelined entry (K_out == NULL) serves wide dictionaries synchronously: same K through kp_fit_get_K
+    kra.fit(ctx, b, snaps, fetch=False)
+    K2 = ctx.fit_result(0, b.W)
+    assert (K2 == K).all()
