@@ -630,6 +630,32 @@ static int wide_block() {               // (read per call: the tests vary it)
 
 #include "kp_tn_gemm.h"
 
+// Cp := (L L')^-1 Cp for a factor as chol_solve_wide leaves it (L below, L' above the diagonal, Dinv = inverses of the 16 x 16
+// diagonal blocks): per block a forward (then backward) substitution against the diagonal block and one TN product that takes
+// the block's solution out of all remaining rows.
+static int wide_substitute(kp_ctx* ctx, double* Gp, double* Cp, double* Dinv, int n, int ncp, hipStream_t st) {
+  const int bs = wide_block();
+  static KpLdsCache trsm_lds;
+  KP_HIP(ctx, kp_ensure_lds(trsm_lds, (const void*)kp_trsm2_kernel<4>, (size_t)352 * 16 * 8));
+  // forward: L Y = C, block rows ascending; the block's Y leaves all later rows by one product
+  for (int k0 = 0; k0 < n; k0 += bs) {
+    const int b = std::min(bs, n - k0), R = n - k0 - b;
+    hipLaunchKernelGGL((kp_trsm2_kernel<4>), dim3(ncp / 16, 1), dim3(256), (size_t)b * 16 * 8, st, Gp + (size_t)k0 * n + k0, Dinv + (size_t)(k0 / 16) * 256, b, ncp,
+                       Cp + k0, (double*)nullptr, 0, 0, (int64_t)n, (int64_t)n, 1);
+    KP_HIP(ctx, hipGetLastError());
+    if (R > 0) KP_HIP(ctx, kp_tn_gemm(st, Gp + (size_t)(k0 + b) * n + k0, n, Cp + k0, n, R, ncp, b, Cp + k0 + b, n, -1.0, 1.0, 0, 1, nullptr));
+  }
+  // backward: L' K = Y, block rows descending; K_k leaves the rows above through L (the mirrored lower triangle)
+  for (int k0 = (n - 1) / bs * bs; k0 >= 0; k0 -= bs) {
+    const int b = std::min(bs, n - k0);
+    hipLaunchKernelGGL((kp_trsm2_kernel<4>), dim3(ncp / 16, 1), dim3(256), (size_t)b * 16 * 8, st, Gp + (size_t)k0 * n + k0, Dinv + (size_t)(k0 / 16) * 256, b, ncp,
+                       Cp + k0, (double*)nullptr, 0, 0, (int64_t)n, (int64_t)n, 2);
+    KP_HIP(ctx, hipGetLastError());
+    if (k0 > 0) KP_HIP(ctx, kp_tn_gemm(st, Gp + k0, n, Cp + k0, n, k0, ncp, b, Cp, n, -1.0, 1.0, 0, 1, nullptr));
+  }
+  return KP_OK;
+}
+
 // Gp (n x n, padded, identity beyond W), Cp (n x ncp): factor Gp in place (L below, L' above the diagonal, as the narrow path
 // leaves it), Dinv = inverses of the 16 x 16 diagonal blocks, Cp := Gp^-1 Cp.  *info is set when a pivot falls below its threshold.
 static int chol_solve_wide(kp_ctx* ctx, double* Gp, double* Cp, double* Dinv, int n, int ncp, int* info, int* sticky, hipStream_t st) {
@@ -667,22 +693,24 @@ static int chol_solve_wide(kp_ctx* ctx, double* Gp, double* Cp, double* Dinv, in
   if (sticky) {   // (the deferred pipeline's word; wide fits run synchronously, so this is only for symmetry with the narrow path)
     KP_HIP(ctx, hipMemcpyAsync(sticky, info, sizeof(int), hipMemcpyDeviceToDevice, st));
   }
-  // forward: L Y = C, block rows ascending; the block's Y leaves all later rows by one product
-  for (int k0 = 0; k0 < n; k0 += bs) {
-    const int b = std::min(bs, n - k0), R = n - k0 - b;
-    hipLaunchKernelGGL((kp_trsm2_kernel<4>), dim3(ncp / 16, 1), dim3(256), (size_t)b * 16 * 8, st, Gp + (size_t)k0 * n + k0, Dinv + (size_t)(k0 / 16) * 256, b, ncp,
-                       Cp + k0, (double*)nullptr, 0, 0, (int64_t)n, (int64_t)n, 1);
-    KP_HIP(ctx, hipGetLastError());
-    if (R > 0) KP_HIP(ctx, kp_tn_gemm(st, Gp + (size_t)(k0 + b) * n + k0, n, Cp + k0, n, R, ncp, b, Cp + k0 + b, n, -1.0, 1.0, 0, 1, nullptr));
-  }
-  // backward: L' K = Y, block rows descending; K_k leaves the rows above through L (the mirrored lower triangle)
-  for (int k0 = (n - 1) / bs * bs; k0 >= 0; k0 -= bs) {
-    const int b = std::min(bs, n - k0);
-    hipLaunchKernelGGL((kp_trsm2_kernel<4>), dim3(ncp / 16, 1), dim3(256), (size_t)b * 16 * 8, st, Gp + (size_t)k0 * n + k0, Dinv + (size_t)(k0 / 16) * 256, b, ncp,
-                       Cp + k0, (double*)nullptr, 0, 0, (int64_t)n, (int64_t)n, 2);
-    KP_HIP(ctx, hipGetLastError());
-    if (k0 > 0) KP_HIP(ctx, kp_tn_gemm(st, Gp + k0, n, Cp + k0, n, k0, ncp, b, Cp, n, -1.0, 1.0, 0, 1, nullptr));
-  }
+  return wide_substitute(ctx, Gp, Cp, Dinv, n, ncp, st);
+}
+
+// For a caller that already holds a Cholesky factor (the rank-revealing solve, kp_pivchol.hip): Lp = n x n (n a multiple of
+// 16), L in the lower triangle; Cp (n x ncp, ncp a multiple of 16) := (L L')^-1 Cp.  Dinv: room for (n / 16) * 256 doubles.
+int kp_factor_substitute_dev(kp_ctx* ctx, double* Lp, int n, double* Cp, int ncp, double* Dinv, hipStream_t st) {
+  if (!st) st = ctx->stream;
+  const int nbk = n / 16, npair = nbk * (nbk - 1) / 2;
+  hipLaunchKernelGGL(kp_chol_finish_kernel, dim3(npair + nbk, 1), dim3(256), 0, st, Lp, n, npair, Dinv);
+  KP_HIP(ctx, hipGetLastError());
+  if (n > 16 * 4 * TR_MAXJ) return wide_substitute(ctx, Lp, Cp, Dinv, n, ncp, st);
+  static KpLdsCache trsm2_lds;
+  KP_HIP(ctx, kp_ensure_lds(trsm2_lds, (const void*)kp_trsm2_kernel<4>, (size_t)352 * 16 * 8 > (size_t)n * 16 * 8 ? (size_t)352 * 16 * 8 : (size_t)n * 16 * 8));
+  if (ncp <= 512)
+    hipLaunchKernelGGL((kp_trsm2_kernel<1>), dim3(ncp / 4, 1), dim3(256), (size_t)n * 4 * 8, st, Lp, Dinv, n, ncp, Cp, (double*)nullptr, 0, 0, (int64_t)n, (int64_t)n, 3);
+  else
+    hipLaunchKernelGGL((kp_trsm2_kernel<4>), dim3(ncp / 16, 1), dim3(256), (size_t)n * 16 * 8, st, Lp, Dinv, n, ncp, Cp, (double*)nullptr, 0, 0, (int64_t)n, (int64_t)n, 3);
+  KP_HIP(ctx, hipGetLastError());
   return KP_OK;
 }
 

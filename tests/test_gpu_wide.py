@@ -111,3 +111,24 @@ def test_wide_fit_fourier_on_six_states(ctx, mt, Ns):
     kra.fit(ctx, b, snaps, fetch=False)
     K2 = ctx.fit_result(0, b.W)
     assert (K2 == K).all()
+
+
+def test_wide_rank_deficient_fit_returns_a_basic_solution_and_the_rank(ctx):
+    """MATLAB's `\\` on a rank-deficient wide Px (Ksysid.m:1069): a repeated state makes products of its harmonics coincide
+    (cos a sin b = sin a cos b, cos^2 + sin^2 = 1); the blocked pivoted Cholesky over many workgroups selects the column
+    subset: same rank and residual as LAPACK's pivoted QR."""
+    from test_gpu_fit import _pivoted_qr_basic_solution
+    pairs = synth_pairs(3000, 6, 3, seed=3)
+    pairs["alpha"][:, 5] = pairs["alpha"][:, 4]
+    pairs["beta"][:, 5] = pairs["beta"][:, 4]
+    dic = ko.build_dictionary("linear", 6, 3, ["fourier"], [1])
+    b = make_basis(ctx, dic)
+    snaps = kra.Snapshots(ctx, pairs["alpha"], pairs["beta"], pairs["u"])
+    K = kra.fit(ctx, b, snaps)[0]
+    Px, Py = ko.px_py(dic, pairs)
+    Kq, r = _pivoted_qr_basic_solution(Px, Py)
+    assert r < dic.W
+    assert ctx.last_rank() == r
+    assert (np.abs(K).sum(axis=1) == 0).sum() == dic.W - r
+    res, resq = Px @ K - Py, Px @ Kq - Py
+    assert np.abs(res - resq).max() < 1e-8 * max(1.0, np.abs(Py).max())
