@@ -349,6 +349,9 @@ __global__ __launch_bounds__(LL_NT) void kp_chol_ll_kernel(double* __restrict__ 
   const int nt = n / 16;
   double acc[LL_TMAX][4];
   for (int kb = 0; kb < nt; ++kb) {
+    // a pivot below its threshold: the caller goes to the rank-revealing solve, nothing of this factor is used - stop here
+    // (`bad` was last written before the barrier that ended the previous panel: uniform)
+    if (bad) break;
     const int k0 = kb * 16, k1 = k0 + 16;
     // lane coordinates, opaque to the optimiser once per panel: otherwise every per-lane address of every phase and variant is
     // hoisted out of this loop and kept live across it (the kernel then spills; recomputing them is a few VALU ops per phase)

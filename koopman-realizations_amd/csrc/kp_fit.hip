@@ -484,7 +484,10 @@ __device__ __forceinline__ void tr2_read_b(const double* __restrict__ xs, int j,
 template <int NJ>
 __global__ __launch_bounds__(256) void kp_trsm2_kernel(const double* __restrict__ LU, const double* __restrict__ Dinv, int n, int ncp,
                                                       double* __restrict__ X, double* __restrict__ Kout, int W, int ncols, int64_t ldl, int64_t ldx,
-                                                      int dirs) {
+                                                      int dirs, const int* __restrict__ info) {
+  // (info: the factorisation's status word(s), or nullptr - a factor that hit a non-positive pivot is not substituted with:
+  // the caller reads the same word and takes the rank-revealing path)
+  if (info && info[blockIdx.y]) return;
   extern __shared__ __align__(16) double xs[];  // [n][4 NJ] X block, columns in tr2_col order
   constexpr int NC = 4 * NJ;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -641,7 +644,7 @@ static int wide_substitute(kp_ctx* ctx, double* Gp, double* Cp, double* Dinv, in
   for (int k0 = 0; k0 < n; k0 += bs) {
     const int b = std::min(bs, n - k0), R = n - k0 - b;
     hipLaunchKernelGGL((kp_trsm2_kernel<4>), dim3(ncp / 16, 1), dim3(256), (size_t)b * 16 * 8, st, Gp + (size_t)k0 * n + k0, Dinv + (size_t)(k0 / 16) * 256, b, ncp,
-                       Cp + k0, (double*)nullptr, 0, 0, (int64_t)n, (int64_t)n, 1);
+                       Cp + k0, (double*)nullptr, 0, 0, (int64_t)n, (int64_t)n, 1, (const int*)nullptr);
     KP_HIP(ctx, hipGetLastError());
     if (R > 0) KP_HIP(ctx, kp_tn_gemm(st, Gp + (size_t)(k0 + b) * n + k0, n, Cp + k0, n, R, ncp, b, Cp + k0 + b, n, -1.0, 1.0, 0, 1, nullptr));
   }
@@ -649,7 +652,7 @@ static int wide_substitute(kp_ctx* ctx, double* Gp, double* Cp, double* Dinv, in
   for (int k0 = (n - 1) / bs * bs; k0 >= 0; k0 -= bs) {
     const int b = std::min(bs, n - k0);
     hipLaunchKernelGGL((kp_trsm2_kernel<4>), dim3(ncp / 16, 1), dim3(256), (size_t)b * 16 * 8, st, Gp + (size_t)k0 * n + k0, Dinv + (size_t)(k0 / 16) * 256, b, ncp,
-                       Cp + k0, (double*)nullptr, 0, 0, (int64_t)n, (int64_t)n, 2);
+                       Cp + k0, (double*)nullptr, 0, 0, (int64_t)n, (int64_t)n, 2, (const int*)nullptr);
     KP_HIP(ctx, hipGetLastError());
     if (k0 > 0) KP_HIP(ctx, kp_tn_gemm(st, Gp + k0, n, Cp + k0, n, k0, ncp, b, Cp, n, -1.0, 1.0, 0, 1, nullptr));
   }
@@ -683,7 +686,7 @@ static int chol_solve_wide(kp_ctx* ctx, double* Gp, double* Cp, double* Dinv, in
     KP_HIP(ctx, hipGetLastError());
     if (R > 0) {
       hipLaunchKernelGGL((kp_trsm2_kernel<4>), dim3(R / 16, 1), dim3(256), (size_t)b * 16 * 8, st, Akk, Dinv + (size_t)(k0 / 16) * 256, b, R, A12, (double*)nullptr, 0, 0,
-                         (int64_t)n, (int64_t)n, 1);
+                         (int64_t)n, (int64_t)n, 1, (const int*)nullptr);
       KP_HIP(ctx, hipGetLastError());
       KP_HIP(ctx, kp_tn_gemm(st, A12, n, A12, n, R, R, b, Gp + (size_t)(k0 + b) * n + k0 + b, n, -1.0, 1.0, 1, 1, nullptr));
     }
@@ -707,9 +710,9 @@ int kp_factor_substitute_dev(kp_ctx* ctx, double* Lp, int n, double* Cp, int ncp
   static KpLdsCache trsm2_lds;
   KP_HIP(ctx, kp_ensure_lds(trsm2_lds, (const void*)kp_trsm2_kernel<4>, (size_t)352 * 16 * 8 > (size_t)n * 16 * 8 ? (size_t)352 * 16 * 8 : (size_t)n * 16 * 8));
   if (ncp <= 512)
-    hipLaunchKernelGGL((kp_trsm2_kernel<1>), dim3(ncp / 4, 1), dim3(256), (size_t)n * 4 * 8, st, Lp, Dinv, n, ncp, Cp, (double*)nullptr, 0, 0, (int64_t)n, (int64_t)n, 3);
+    hipLaunchKernelGGL((kp_trsm2_kernel<1>), dim3(ncp / 4, 1), dim3(256), (size_t)n * 4 * 8, st, Lp, Dinv, n, ncp, Cp, (double*)nullptr, 0, 0, (int64_t)n, (int64_t)n, 3, (const int*)nullptr);
   else
-    hipLaunchKernelGGL((kp_trsm2_kernel<4>), dim3(ncp / 16, 1), dim3(256), (size_t)n * 16 * 8, st, Lp, Dinv, n, ncp, Cp, (double*)nullptr, 0, 0, (int64_t)n, (int64_t)n, 3);
+    hipLaunchKernelGGL((kp_trsm2_kernel<4>), dim3(ncp / 16, 1), dim3(256), (size_t)n * 16 * 8, st, Lp, Dinv, n, ncp, Cp, (double*)nullptr, 0, 0, (int64_t)n, (int64_t)n, 3, (const int*)nullptr);
   KP_HIP(ctx, hipGetLastError());
   return KP_OK;
 }
@@ -766,14 +769,14 @@ int kp_chol_solve_batch_dev(kp_ctx* ctx, const double* G_dev, const double* C_de
     // flushed at pend_first % k_cap != 0 must land in ITS slot of the result ring, not in slot 0
     double* Kdst = K_dev + (k_cap > 0 ? (size_t)(k_first % k_cap) * W * ncols : 0);
     hipLaunchKernelGGL((kp_trsm2_kernel<1>), dim3(ncp / 4, nb), dim3(256), (size_t)n * 4 * 8, st, Gp, Dinv, n, ncp, Cp, Kdst, W, ncols, (int64_t)n,
-                       (int64_t)n, 3);
+                       (int64_t)n, 3, (const int*)info);
     KP_HIP(ctx, hipGetLastError());
     return KP_OK;
   } else {                    // a batch: 16 per workgroup, every workgroup reads all of L
     static KpLdsCache trsm2_lds;
     KP_HIP(ctx, kp_ensure_lds(trsm2_lds, (const void*)kp_trsm2_kernel<4>, (size_t)n * 16 * 8));
     hipLaunchKernelGGL((kp_trsm2_kernel<4>), dim3(ncp / 16, nb), dim3(256), (size_t)n * 16 * 8, st, Gp, Dinv, n, ncp, Cp, (double*)nullptr, W, ncols,
-                       (int64_t)n, (int64_t)n, 3);
+                       (int64_t)n, (int64_t)n, 3, (const int*)info);
   }
   KP_HIP(ctx, hipGetLastError());
   hipLaunchKernelGGL(kp_unpad_kernel, dim3((unsigned)(((int64_t)W * ncols + 255) / 256), nb), dim3(256), 0, st, Cp, n, W, ncols, K_dev, ncp, k_first,
