@@ -270,8 +270,12 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
     for (int j = 0; j < 2; ++j) {
       const int e = tid + j * 256;
       pre_on[j] = e < pre_n2;
-      const int d0 = pre_on[j] ? 2 * e : 0;             // tile layout [row entry c][snapshot]: a piece = snapshots (s, s + 1) of entry c
-      const int c = d0 / KT3, srow = d0 - c * KT3;
+      // tile layout [snapshot pair][row entry c][2]: a piece = snapshots (s, s + 1) of entry c; consecutive lanes = consecutive
+      // entries of one pair, so the 16 lanes of a store group write 16 different columns of two Psi rows (the round-4 layout
+      // [entry][8 snapshots] put the four pairs of one entry on neighbouring lanes: rows 240 doubles apart, the same bank - 32 %
+      // of this kernel's LDS cycles were conflicts)
+      const int e1 = pre_on[j] ? e : 0;
+      const int sp = e1 / a.pre_rl, c = e1 - sp * a.pre_rl, srow = 2 * sp;
       const int off = c < 4 * a.G4 ? c : c < 8 * a.G4 ? YOFF3 + (c - 4 * a.G4) : WOFF3 + (c - 8 * a.G4);
       pre_dst[j] = PSI03 + srow * RS3 + off;
     }

@@ -1,7 +1,11 @@
 // kp_gram3_prelift.hip - econ lift of a dim_red dictionary, once per snapshot, for the Kronecker Gram kernel (kp_gram3.hip, PRE mode).
+#include <algorithm>
+#include <cstdlib>
+
 #include "kp_gram3_args.h"
 
 #define KT3 8     // snapshots per tile of kp_gram3_kernel
+#define PES 2     // doubles between two entries of a snapshot in the tile layout [snapshot pair][entry][2]
 #define NF3 3     // single-variable powers per column
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -33,78 +37,312 @@ __global__ __launch_bounds__(PRE_T) void kp_gram3_pcs_transpose_kernel(const dou
   }
 }
 
-template <int BM>
-__global__ __launch_bounds__(PRE_T) void kp_gram3_prelift_kernel(const double* __restrict__ alpha, const double* __restrict__ beta, const double* __restrict__ u,
-                                                                  int64_t Ns, int64_t Ns_pad, int nzeta, int D, int nfull, int k_pcs, int N, int G4,
-                                                                  const uint32_t* __restrict__ recipes, const double* __restrict__ pcsT,
-                                                                  double* __restrict__ out, int rl) {
-  extern __shared__ double tab[];                       // [2 sides][nzeta * D][PRE_T], then one entry of ones
-  const int tid = threadIdx.x;
-  const int64_t snap = (int64_t)blockIdx.x * PRE_T + tid;
-  if (snap >= Ns_pad) return;
-  const bool valid = snap < Ns;
+// Round 5: the projection on the MATRIX pipe, by workgroups of FOUR PRODUCER AND FOUR CONSUMER WAVES.  The round-4 kernel (one
+// thread per snapshot, the matrix as scalar operands of 64 multiply-adds per column) was latency-bound: 1e5 snapshots are 1 564
+// waves, 1.5 per SIMD, each walking 84 columns one after the other, and the 21 KB matrix streamed through a 16 KB scalar cache -
+// 65 us where its multiply-adds are 14.  Now a tile of 8 snapshots (both sides) is prepared by a producer wave and projected by
+// a consumer wave, 12 500 tiles per 1e5 pairs dealt to persistent workgroups, four tiles per workgroup and round:
+//   producer (tile of the NEXT round, into the other LDS buffer):
+//     1. power table x_v^e of both sides ([entry][side][8 snapshots], 20 doubles per entry: entries 8 dwords apart modulo the banks);
+//     2. the FULL lift into the Psi tile [column][side][8 snapshots] (18 doubles per column): a lane takes a (column, side) item -
+//        its three factors' table offsets sit in registers, 16-byte reads and writes (two snapshots each), 168 items in 3 rounds;
+//     3. the entries that are no components (zeta, the constant, padding, the 9 weights) straight to memory;
+//   consumer (tile of THIS round):
+//     4. pcs' psi by v_mfma_f64_4x4x4_4b, the four blocks = four groups of four COMPONENTS: the A operand (4 snapshots x 4 full
+//        columns) is ONE ds_read_b64 at `lane base + immediate` (affine in the k-step, the side and the snapshot group: nothing on
+//        the vector ALU between the MFMAs), the B operand pcs[4 kk + k][16 t + 4 blk + j] differs per lane - the whole 84 x 32
+//        matrix is 42 registers per lane, loaded once; two MFMAs (component tiles t = 0, 1) share an A operand;
+//     5. a D register (snapshot = lane >> 4, component = 4 blk + j) stores 256 contiguous bytes per snapshot pair of the tile
+//        layout [snapshot pair][entry][2] - whose consecutive entries the Gram kernel's loader writes into its Psi rows without
+//        the 4-way bank conflict of the round-4 layout [entry][8 snapshots];
+//   ONE LDS-only barrier per round (__syncthreads() would also drain the memory counter: the loads just requested for the round
+//   after next, the stores just issued).
+// Measured (1e5 pairs, 84 -> 27 components; tools/prelift_abl5.sh = timing-only builds through KP_PM_ABL, tools/prelift_phase_probe.py
+// = in-kernel cycle counters): 40 us against round 4's 65.  The MFMAs alone are 17 us (168 per tile at 16.5 cycles: the floor of
+// this instruction), the 67 MB of output another ~17 us of HBM writes that overlap them.  The way here: every wave doing all
+// steps in turn - one wave per tile (two waves per SIMD) or a pair of waves sharing a tile (three) - took 38 - 45 us however the
+// steps were tuned (62 us with a branch per k-step: no operand prefetch; 45 us with the lane forming psi[s][c] itself in front of
+// every MFMA pair; 41 us with the Psi tile staged as here; 38 us once a tile's loads were consumed BEFORE its stores - the memory
+// counter retires in order), and the time was the SUM of the steps' times: identical waves fall into step - all in the MFMA
+// phase, then all in the latency-bound phases (counters: every phase twice its instruction time, matrix pipe 41 % busy).  With
+// fixed roles the consumer's round is 3 400 cycles of MFMAs + 500 of stores, but a producer's round is 5 000: while a
+// consumer streams f64 MFMAs on its SIMD, the other waves' vector instructions wait (the power table - a dozen dependent
+// instructions - 1 400 - 2 000 cycles per tile, the lift 1 500; without the MFMAs 700 and 1 400), whichever wave has priority
+// (`s_setprio` on the producers: 41.5 -> 40.1 us) and however few they are (one producer per SIDE instead of one per tile: no
+// change).  What is left to try is the consumer lifting its own next tile BETWEEN its MFMAs (a vector instruction of the MFMA wave
+// itself costs the stream ~5 cycles): a hand-interleaved loop, not built.
+#define PM_T 768
+#define PM_NS 4       // tiles (producer / consumer pairs) per workgroup
+#define PM_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define PM_ES 20      // doubles per power-table entry: [side 0: 8 snapshots][side 1: 8][4 of padding]
+#define PM_CS 18      // doubles per Psi-tile column: [side 0: 8][side 1: 8][2 of padding]: 16-byte writes of consecutive columns and the
+                      // operand reads of two neighbouring columns both spread over the banks
+template <int BM, int NK, int NRAW>
+__global__ __launch_bounds__(PM_T, 1) void kp_gram3_prelift_mfma_kernel(const double* __restrict__ alpha, const double* __restrict__ beta, const double* __restrict__ u,
+                                                                        int64_t Ns, int64_t ktiles, int nzeta, int D, int nfull, int k_pcs, int N, int G4,
+                                                                        const uint32_t* __restrict__ recipes, const double* __restrict__ pcsT,
+                                                                        double* __restrict__ out, int rl, int abl) {
+  extern __shared__ double sm[];                        // per slot: tab[nid + 1][PM_ES] | utab[BM + 1][8] | psi[2 buffers][4 NK][PM_CS]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int slot = wave & (PM_NS - 1);
+  const bool producer = wave >= PM_NS;
+  const int pside = (wave >> 2) - 1;                    // producer of side 0 (alpha; also the inputs and the weights) / side 1 (beta)
   const int nid = nzeta * D;
-  for (int v = 0; v < nzeta; ++v) {
-    const double xa = valid ? alpha[(int64_t)v * Ns + snap] : 0.0, xb = valid ? beta[(int64_t)v * Ns + snap] : 0.0;
-    double pa = xa, pb = xb;
-    for (int e = 0; e < D; ++e) {
-      tab[(v * D + e) * PRE_T + tid] = pa;
-      tab[(nid + v * D + e) * PRE_T + tid] = pb;
-      pa *= xa;
-      pb *= xb;
-    }
-  }
-  tab[2 * nid * PRE_T + tid] = 1.0;                     // "no factor"
-  // both sides of the snapshot in one thread: every scalar operand of the projection serves two multiply-adds.  The factors of a
-  // column come from the table without a branch (id 255, "no factor", reads the entry of ones behind the powers), so that the
-  // loads of the next column run under the multiply-adds of this one
-  double ax[32], ay[32];
+  const int tab_d = ((nid + 1) * PM_ES + (BM + 1) * 8 + 1) & ~1;
+  const int psi_d = 4 * NK * PM_CS;
+  double* wsm = sm + slot * (tab_d + 2 * psi_d);
+  double* utab = wsm + (nid + 1) * PM_ES;
+  double* psi = wsm + tab_d;
+  const unsigned wbase = (unsigned)(uintptr_t)wsm, pbase = (unsigned)(uintptr_t)psi;   // (low 32 bits of a generic LDS address = the LDS byte address)
+  const int64_t tstep = (int64_t)gridDim.x * PM_NS;
+  const int64_t tile0 = (int64_t)blockIdx.x * PM_NS + slot;
+  typedef double dbl2 __attribute__((ext_vector_type(2)));
+  typedef const __attribute__((address_space(3))) dbl2* lds_d2;
+  typedef __attribute__((address_space(3))) dbl2* lds_d2w;
+  typedef const __attribute__((address_space(3))) double* lds_d;
+  if (producer) {
+    // ================================================ producer ================================================
+    // The consumer's f64 MFMA stream occupies the SIMD's vector issue: left at equal priority a producer's vector instruction
+    // waits ~100 cycles when it depends on the previous one (in-kernel counters: the power table alone 2 000 - 2 700 cycles per
+    // tile).  At raised priority the producer's few instructions go first; each costs the MFMA stream ~5 cycles.
+    if (!(abl & 64)) __builtin_amdgcn_s_setprio(3);
+    // lift items of this lane: columns lane + 64 r of this wave's side; byte offsets of their three factors in the power table
+    constexpr int NIT = (4 * NK + 63) / 64;
+    unsigned foff[NIT][NF3], poff[NIT];
+    bool ion[NIT];
 #pragma unroll
-  for (int p = 0; p < 32; ++p) { ax[p] = 0.0; ay[p] = 0.0; }
-#pragma unroll 4
-  for (int c = 0; c < nfull; ++c) {
-    const uint32_t r = recipes[c];
-    double px = 1.0, py = 1.0;
+    for (int r = 0; r < NIT; ++r) {
+      const int c = lane + 64 * r;
+      ion[r] = c < nfull;
+      const uint32_t rc = ion[r] ? recipes[c] : 0xffffffffu;
 #pragma unroll
-    for (int f = 0; f < NF3; ++f) {
-      int id = (int)((r >> (8 * f)) & 255u);
-      id = id == 255 ? 2 * nid : id;
-      px *= tab[id * PRE_T + tid];
-      py *= tab[(id == 2 * nid ? id : nid + id) * PRE_T + tid];
-    }
-    const double* __restrict__ row = pcsT + (size_t)c * 32;
-#pragma unroll
-    for (int p = 0; p < 32; ++p) { const double w = row[p]; ax[p] = fma(px, w, ax[p]); ay[p] = fma(py, w, ay[p]); }
-  }
-  // tile layout [entry][KT3 snapshots]: the 8 lanes of a tile write one full 64-byte sector per entry (a row-per-snapshot layout
-  // scattered 8-byte stores over 67 MB: the kernel took 109 us instead of 80)
-  double* ox = out + (snap / KT3) * (int64_t)(KT3 * rl) + (snap % KT3);
-  double* oy = ox + (int64_t)4 * G4 * KT3;
-  for (int j = 0; j < nzeta; ++j) {
-    ox[j * KT3] = tab[(j * D) * PRE_T + tid];           // (zero past Ns: the table holds zeros there)
-    oy[j * KT3] = tab[(nid + j * D) * PRE_T + tid];
-  }
-#pragma unroll
-  for (int p = 0; p < 32; ++p)
-    if (p < k_pcs) { ox[(nzeta + p) * KT3] = valid ? ax[p] : 0.0; oy[(nzeta + p) * KT3] = valid ? ay[p] : 0.0; }
-  ox[(N - 1) * KT3] = valid ? 1.0 : 0.0;
-  oy[(N - 1) * KT3] = valid ? 1.0 : 0.0;
-  for (int j = N; j < 4 * G4; ++j) { ox[j * KT3] = 0.0; oy[j * KT3] = 0.0; }
-  {                                                     // the weights ut_x ut_y, (x <= y) order without (0, 0); ut = [1, u]
-    double ut[BM + 1];
-    ut[0] = 1.0;
-#pragma unroll
-    for (int i = 0; i < BM; ++i) ut[1 + i] = valid ? u[(int64_t)i * Ns + snap] : 0.0;
-    double* w = ox + (int64_t)8 * G4 * KT3;
-    int cnt = 0;
-#pragma unroll
-    for (int x = 0; x <= BM; ++x)
-#pragma unroll
-      for (int y = x; y <= BM; ++y) {
-        if (cnt > 0) w[(cnt - 1) * KT3] = valid ? ut[x] * ut[y] : 0.0;
-        ++cnt;
+      for (int f = 0; f < NF3; ++f) {
+        int id = (int)((rc >> (8 * f)) & 255u);
+        id = id == 255 ? nid : id;
+        foff[r][f] = wbase + (unsigned)(id * PM_ES + pside * 8) * 8u;
       }
-    for (int j = cnt - 1; j < 12; ++j) w[j * KT3] = 0.0;
+      poff[r] = pbase + (unsigned)((ion[r] ? c : 0) * PM_CS + pside * 8) * 8u;
+    }
+    if (pside == 0) {
+      for (int e = nfull * PM_CS + lane; e < psi_d; e += 64) { psi[e] = 0.0; psi[psi_d + e] = 0.0; }    // columns beyond the dictionary, both buffers
+      if (lane < 8) utab[BM * 8 + lane] = 1.0;                                                             // ut_0 = 1
+    }
+    // (snapshot, eighth) roles for loads, tables and the entries that are not components
+    const int ls = lane & 7, lq = lane >> 3;
+    const int nsv = nzeta + (pside == 0 ? BM : 0);      // raw columns this wave reads: alpha | u, or beta
+    auto raw_ptr = [&](int sv) -> const double* {
+      return pside ? beta + (int64_t)sv * Ns : sv < nzeta ? alpha + (int64_t)sv * Ns : u + (int64_t)(sv - nzeta) * Ns;
+    };
+    double raw[NRAW];                                   // NRAW = ceil((nzeta + BM) / 8) (2 or 4)
+    auto load_raw = [&](int64_t tile) {
+      const int64_t snap = tile * KT3 + ls;
+#pragma unroll
+      for (int m = 0; m < NRAW; ++m) {
+        const int sv = lq + 8 * m;
+        raw[m] = (sv < nsv && snap < Ns && tile < ktiles) ? raw_ptr(sv)[snap] : 0.0;
+      }
+    };
+    // entries that are not components, fixed per lane: zeta (one per raw value), then up to NOTH of this side's [constant |
+    // padding of the last column group] and (side 0) the 12 weight slots; a weight = product of two utab entries (ut = [1, u];
+    // slots beyond the (BM + 1)(BM + 2) / 2 - 1 pairs are zero)
+    constexpr int NOTH = 4;                             // npad + 12 <= 32 entries over 8 lane groups
+    const int npad = 4 * G4 - N + 1;                    // constant + padding entries per side
+    int oth_ent[NOTH], oth_kind[NOTH];                  // kind 0: nothing, 1: zero, 2: tail mask (the constant), 3: weight
+    unsigned oth_a[NOTH], oth_b[NOTH];
+    const unsigned ubase = (unsigned)(uintptr_t)utab;
+#pragma unroll
+    for (int t = 0; t < NOTH; ++t) {
+      const int e = lq + 8 * t;
+      oth_kind[t] = 0; oth_ent[t] = 0; oth_a[t] = oth_b[t] = ubase;
+      if (e < npad) {
+        oth_ent[t] = pside * 4 * G4 + N - 1 + e;
+        oth_kind[t] = e == 0 ? 2 : 1;
+      } else if (pside == 0 && e < npad + 12) {
+        const int w = e - npad;
+        oth_ent[t] = 8 * G4 + w;
+        oth_kind[t] = 1;
+        int cnt = 0;
+#pragma unroll
+        for (int x = 0; x <= BM; ++x)
+#pragma unroll
+          for (int y = x; y <= BM; ++y) {
+            if (cnt == w + 1) {
+              oth_kind[t] = 3;
+              oth_a[t] = ubase + (unsigned)((x == 0 ? BM : x - 1) * 8 + ls) * 8u;
+              oth_b[t] = ubase + (unsigned)((y - 1) * 8 + ls) * 8u;
+            }
+            ++cnt;
+          }
+      }
+    }
+    const int o_off = (ls >> 1) * 2 * rl + (ls & 1);
+    // prepare(tile, buffer): steps 1 - 2 with the raw values in xs, the values of step 3 into oth_v; finish(tile): step 3's stores
+    double xs[NRAW], zs[NRAW], oth_v[NOTH];
+    long long sph[4] = {0, 0, 0, 0};
+    auto prepare = [&](int64_t tile, int buf) {
+      long long s0 = (abl & 32) ? clock64() : 0;
+      const bool valid = tile * KT3 + ls < Ns;
+#pragma unroll
+      for (int m = 0; m < NRAW; ++m) {
+        const int sv = lq + 8 * m;
+        zs[m] = xs[m];
+        if (sv < nzeta) {
+          // (no loop over the depth: a dependent multiply per power waits out the consumer's MFMA stream every time - in-kernel
+          // counters had this table at 2 000 - 2 700 cycles per tile)
+          const double x1 = xs[m], x2 = x1 * x1, x3 = x2 * x1, x4 = x2 * x2;
+          double* t = wsm + (sv * D) * PM_ES + pside * 8 + ls;
+          t[0] = x1;
+          if (D > 1) t[PM_ES] = x2;
+          if (D > 2) t[2 * PM_ES] = x3;
+          if (D > 3) t[3 * PM_ES] = x4;
+          if (D > 4) {
+            double pw = x4 * x1;
+            for (int e = 4; e < D; ++e) {
+              t[e * PM_ES] = pw;
+              pw *= x1;
+            }
+          }
+        } else if (sv < nsv) {
+          utab[(sv - nzeta) * 8 + ls] = xs[m];
+        }
+      }
+      if (lq == 0) wsm[nid * PM_ES + pside * 8 + ls] = valid ? 1.0 : 0.0;   // "no factor" = the tail mask (the full dictionary's constant column is all of it)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const unsigned pb = (unsigned)buf * (unsigned)(psi_d * 8);
+      if (abl & 32) { const long long s1 = clock64(); sph[0] += s1 - s0; s0 = s1; }
+#pragma unroll
+      for (int r = 0; r < NIT; ++r) {
+        if (ion[r] && !(abl & 2)) {
+          dbl2 f0[4], f1[4], f2[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            f0[q] = *reinterpret_cast<lds_d2>((uintptr_t)(foff[r][0] + 16u * q));
+            f1[q] = *reinterpret_cast<lds_d2>((uintptr_t)(foff[r][1] + 16u * q));
+            f2[q] = *reinterpret_cast<lds_d2>((uintptr_t)(foff[r][2] + 16u * q));
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) *reinterpret_cast<lds_d2w>((uintptr_t)(poff[r] + pb + 16u * q)) = (f0[q] * f1[q]) * f2[q];
+        }
+      }
+      if (abl & 32) { const long long s1 = clock64(); sph[1] += s1 - s0; s0 = s1; }
+#pragma unroll
+      for (int t = 0; t < NOTH; ++t) {
+        const double wa = *reinterpret_cast<lds_d>((uintptr_t)oth_a[t]), wb = *reinterpret_cast<lds_d>((uintptr_t)oth_b[t]);
+        oth_v[t] = oth_kind[t] == 3 ? wa * wb : (oth_kind[t] == 2 && valid) ? 1.0 : 0.0;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (the next prepare's table overwrites what was just read)
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (abl & 32) { const long long s1 = clock64(); sph[2] += s1 - s0; s0 = s1; }
+    };
+    auto finish = [&](int64_t tile) {
+      if (tile < ktiles && !(abl & 8)) {
+        double* ot = out + tile * (int64_t)(KT3 * rl);
+#pragma unroll
+        for (int m = 0; m < NRAW; ++m) {
+          const int sv = lq + 8 * m;
+          if (sv < nzeta) ot[o_off + (pside * 4 * G4 + sv) * PES] = zs[m];
+        }
+#pragma unroll
+        for (int t = 0; t < NOTH; ++t)
+          if (oth_kind[t]) ot[o_off + oth_ent[t] * PES] = oth_v[t];
+      }
+    };
+    // Order of a round: prepare (LDS only) -> take the raw values requested a round ago -> this tile's stores -> request the values
+    // of the round after next.  The memory counter retires in order, and a wait for loads also waits for every store issued in
+    // front of them: in this order both are a whole round old when the wait comes (with the stores last - just issued when the
+    // next round asked for its values - every round ended in a full memory round trip, 1.5 us of a 3.4 us round).
+    load_raw(tile0);
+#pragma unroll
+    for (int m = 0; m < NRAW; ++m) xs[m] = raw[m];
+    prepare(tile0, 0);
+    finish(tile0);
+    load_raw(tile0 + tstep);
+#pragma unroll
+    for (int m = 0; m < NRAW; ++m) xs[m] = raw[m];      // (values of the first round's tile: waited for here, once)
+    load_raw(tile0 + 2 * tstep);
+    PM_LDS_BARRIER();
+    int it = 0;
+    long long tph[4] = {0, 0, 0, 0}, tlast = (abl & 32) ? clock64() : 0;
+#define PM_TICK(i) do { if (abl & 32) { const long long tn = clock64(); tph[i] += tn - tlast; tlast = tn; } } while (0)
+    for (int64_t tb = (int64_t)blockIdx.x * PM_NS; tb < ktiles; tb += tstep, ++it) {      // (uniform trip count over the workgroup)
+      const int64_t tnext = tile0 + (int64_t)(it + 1) * tstep;
+      const bool more = tb + tstep < ktiles;
+      if (more) prepare(tnext, (it + 1) & 1);
+      PM_TICK(0);
+#pragma unroll
+      for (int m = 0; m < NRAW; ++m) {
+        asm volatile("" : "+v"(raw[m]));                // (a use: the compiler's wait for the loads lands here)
+        xs[m] = raw[m];
+      }
+      PM_TICK(1);
+      if (more) finish(tnext);
+      load_raw(tnext + 2 * tstep);
+      PM_TICK(2);
+      PM_LDS_BARRIER();
+      PM_TICK(3);
+    }
+    if ((abl & 32) && lane == 0 && (blockIdx.x == 0 || blockIdx.x == 200) && slot < 1)
+      printf("producer (%d, %d): prepare %lld (table %lld lift %lld oth %lld)  raw wait %lld  stores+loads %lld  barrier %lld cycles, %d rounds\n", (int)blockIdx.x, slot, tph[0], sph[0], sph[1], sph[2], tph[1], tph[2], tph[3], it);
+  } else {
+    // ================================================ consumer ================================================
+    const int li = lane & 3, blk = (lane >> 2) & 3, kq = lane >> 4;
+    double b0[NK], b1[NK];                              // zero beyond the dictionary
+#pragma unroll
+    for (int kk = 0; kk < NK; ++kk) {
+      const int c = 4 * kk + kq;
+      const bool on = c < nfull;
+      b0[kk] = on ? pcsT[(size_t)c * 32 + 4 * blk + li] : 0.0;
+      b1[kk] = on ? pcsT[(size_t)c * 32 + 16 + 4 * blk + li] : 0.0;
+    }
+    const unsigned abase0 = pbase + (unsigned)(kq * PM_CS + li) * 8u;                   // A operand: column 4 kk + kq, snapshot 4 g + li
+    const int pc = 4 * blk + li;
+    const int d_off = (kq >> 1) * 2 * rl + (kq & 1) + (nzeta + pc) * PES;             // + g * 4 rl + side * 4 G4 PES (+ 16 PES)
+    PM_LDS_BARRIER();                                   // tile 0 is prepared
+    int it = 0;
+    long long tph[4] = {0, 0, 0, 0}, tlast = (abl & 32) ? clock64() : 0;
+    for (int64_t tb = (int64_t)blockIdx.x * PM_NS; tb < ktiles; tb += tstep, ++it) {
+      const int64_t tile = tile0 + (int64_t)it * tstep;
+      const unsigned abase = abase0 + (unsigned)(it & 1) * (unsigned)(psi_d * 8);
+      double acc[2][2][2];
+#pragma unroll
+      for (int side = 0; side < 2; ++side) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          double acc0 = 0.0, acc1 = 0.0;
+          if (!(abl & 1))
+#pragma unroll
+          for (int kk = 0; kk < NK; ++kk) {
+            const double av = *reinterpret_cast<lds_d>((uintptr_t)(abase + (unsigned)(kk * 4 * PM_CS * 8 + side * 64 + g * 32)));
+            acc0 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, b0[kk], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, b1[kk], acc1, 0, 0, 0);
+          }
+          acc[side][g][0] = acc0;
+          acc[side][g][1] = acc1;
+        }
+      }
+      PM_TICK(0);
+      if (tile < ktiles && !(abl & 4)) {
+        double* ot = out + tile * (int64_t)(KT3 * rl);
+#pragma unroll
+        for (int side = 0; side < 2; ++side)
+#pragma unroll
+          for (int g = 0; g < 2; ++g) {
+            double* og = ot + (g * 4 * rl + side * 4 * G4 * PES);
+            if (pc < k_pcs) og[d_off] = acc[side][g][0];
+            if (pc + 16 < k_pcs) og[d_off + 16 * PES] = acc[side][g][1];
+          }
+      }
+      PM_TICK(1);
+      PM_LDS_BARRIER();
+      PM_TICK(2);
+    }
+    if ((abl & 32) && lane == 0 && (blockIdx.x == 0 || blockIdx.x == 200) && slot < 2)
+      printf("consumer (%d, %d): mfma %lld  stores %lld  barrier %lld cycles, %d rounds\n", (int)blockIdx.x, slot, tph[0], tph[1], tph[2], it);
+#undef PM_TICK
   }
 }
 
@@ -113,16 +351,45 @@ hipError_t kp_gram3_pcs_transpose_launch(const double* pcs, int nfull, int k, do
   return hipGetLastError();
 }
 
+template <int BM, int NK, int NRAW>
+static hipError_t prelift_mfma_launch(const double* alpha, const double* beta, const double* u, int64_t Ns, int64_t ktiles, int nzeta, int D, int nfull, int k_pcs, int N,
+                                      int G4, const uint32_t* recipes, const double* pcsT, double* out, int rl, hipStream_t st) {
+  const size_t lds = (size_t)PM_NS * ((size_t)((((nzeta * D + 1) * PM_ES + (BM + 1) * 8 + 1) & ~1) + 2 * 4 * NK * PM_CS)) * 8;
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  static KpLdsCache cache;
+  hipError_t e = kp_ensure_lds(cache, (const void*)kp_gram3_prelift_mfma_kernel<BM, NK, NRAW>, lds);
+  if (e != hipSuccess) return e;
+  int dev = 0, cus = 256;
+  (void)hipGetDevice(&dev);
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  const int64_t grid = std::max<int64_t>(1, std::min<int64_t>((ktiles + PM_NS - 1) / PM_NS, (int64_t)cus));
+  hipLaunchKernelGGL((kp_gram3_prelift_mfma_kernel<BM, NK, NRAW>), dim3((unsigned)grid), dim3(PM_T), lds, st, alpha, beta, u, Ns, ktiles, nzeta, D, nfull, k_pcs, N, G4,
+                     recipes, pcsT, out, rl, getenv("KP_PM_ABL") ? atoi(getenv("KP_PM_ABL")) : 0);
+  return hipGetLastError();
+}
+
+template <int BM>
+static hipError_t prelift_mfma_launch_nk(int nk, const double* alpha, const double* beta, const double* u, int64_t Ns, int64_t ktiles, int nzeta, int D, int nfull, int k_pcs,
+                                         int N, int G4, const uint32_t* recipes, const double* pcsT, double* out, int rl, hipStream_t st) {
+  const bool few = nzeta + BM <= 16;
+#define KP_PM(NKT) (few ? prelift_mfma_launch<BM, NKT, 2>(alpha, beta, u, Ns, ktiles, nzeta, D, nfull, k_pcs, N, G4, recipes, pcsT, out, rl, st) \
+                        : prelift_mfma_launch<BM, NKT, 4>(alpha, beta, u, Ns, ktiles, nzeta, D, nfull, k_pcs, N, G4, recipes, pcsT, out, rl, st))
+  if (nk <= 8) return KP_PM(8);
+  if (nk <= 14) return KP_PM(14);
+  if (nk <= 21) return KP_PM(21);
+  return KP_PM(24);
+#undef KP_PM
+}
+
+// Ns_pad = ktiles * KT3 (the row buffer holds whole tiles).  Needs nfull <= 96, 2 nzeta + BM <= 32 (kp_gram3_applicable's own limits).
 hipError_t kp_gram3_prelift_launch(int BM, const double* alpha, const double* beta, const double* u, int64_t Ns, int64_t Ns_pad, int nzeta, int D, int nfull, int k_pcs,
                                    int N, int G4, const uint32_t* recipes, const double* pcsT, double* out, int rl, hipStream_t st) {
-  const size_t plds = (size_t)(2 * nzeta * D + 1) * PRE_T * 8;
-  const dim3 pg((unsigned)((Ns_pad + PRE_T - 1) / PRE_T));
-#define KP_PRELIFT(M) hipLaunchKernelGGL(kp_gram3_prelift_kernel<M>, pg, dim3(PRE_T), plds, st, alpha, beta, u, Ns, Ns_pad, nzeta, D, nfull, k_pcs, N, G4, recipes, pcsT, out, rl)
-  if (BM == 1) KP_PRELIFT(1);
-  else if (BM == 2) KP_PRELIFT(2);
-  else KP_PRELIFT(3);
-#undef KP_PRELIFT
-  return hipGetLastError();
+  const int nk = (nfull + 3) / 4;
+  const int64_t ktiles = Ns_pad / KT3;
+  if (nk > 24 || nzeta + BM > 32 || (4 * G4 - N + 1) + 12 > 32) return hipErrorInvalidValue;
+  if (BM == 1) return prelift_mfma_launch_nk<1>(nk, alpha, beta, u, Ns, ktiles, nzeta, D, nfull, k_pcs, N, G4, recipes, pcsT, out, rl, st);
+  if (BM == 2) return prelift_mfma_launch_nk<2>(nk, alpha, beta, u, Ns, ktiles, nzeta, D, nfull, k_pcs, N, G4, recipes, pcsT, out, rl, st);
+  return prelift_mfma_launch_nk<3>(nk, alpha, beta, u, Ns, ktiles, nzeta, D, nfull, k_pcs, N, G4, recipes, pcsT, out, rl, st);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -156,8 +423,8 @@ __global__ __launch_bounds__(PREX_T) void kp_gram3_prelift_ext_kernel(const doub
   // one side at a time through ONE table (27 entries x 128 threads = 27 KB for 20 gaussians on 6 states: five workgroups per CU;
   // a table per side left two)
   double* t0 = tab + tid;
-  double* ox = out + (snap / KT3) * (int64_t)(KT3 * rl) + (snap % KT3);
-  double* oy = ox + (int64_t)4 * G4 * KT3;
+  double* ox = out + (snap / KT3) * (int64_t)(KT3 * rl) + ((snap % KT3) >> 1) * (int64_t)(2 * rl) + (snap & 1);   // tile layout [snapshot pair][entry][2]
+  double* oy = ox + (int64_t)4 * G4 * PES;
 #pragma unroll
   for (int side = 0; side < 2; ++side) {
     const double* xs = side ? xb : xa;
@@ -203,25 +470,25 @@ __global__ __launch_bounds__(PREX_T) void kp_gram3_prelift_ext_kernel(const doub
         const int id = (int)((r >> (8 * f)) & 255u);
         ps *= t0[(id == 255 ? ne : id >= 128 ? nv + (id - 128) : id) * PREX_T];
       }
-      o[c * KT3] = valid ? ps : 0.0;
+      o[c * PES] = valid ? ps : 0.0;
     }
   }
-  for (int j = nfull; j < 4 * G4; ++j) { ox[j * KT3] = 0.0; oy[j * KT3] = 0.0; }
+  for (int j = nfull; j < 4 * G4; ++j) { ox[j * PES] = 0.0; oy[j * PES] = 0.0; }
   {
     double ut[BM + 1];
     ut[0] = 1.0;
 #pragma unroll
     for (int i = 0; i < BM; ++i) ut[1 + i] = valid ? u[(int64_t)i * Ns + snap] : 0.0;
-    double* w = ox + (int64_t)8 * G4 * KT3;
+    double* w = ox + (int64_t)8 * G4 * PES;
     int cnt = 0;
 #pragma unroll
     for (int x = 0; x <= BM; ++x)
 #pragma unroll
       for (int y = x; y <= BM; ++y) {
-        if (cnt > 0) w[(cnt - 1) * KT3] = valid ? ut[x] * ut[y] : 0.0;
+        if (cnt > 0) w[(cnt - 1) * PES] = valid ? ut[x] * ut[y] : 0.0;
         ++cnt;
       }
-    for (int j = cnt - 1; j < 12; ++j) w[j * KT3] = 0.0;
+    for (int j = cnt - 1; j < 12; ++j) w[j * PES] = 0.0;
   }
 }
 
