@@ -8,6 +8,7 @@ only - no arithmetic here."""
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -26,6 +27,11 @@ class Multi:
         self.n_dev = len(ids)
         self.device_ids = [int(i) for i in ids]
         self._blocks = {}
+        self._retired = []                   # page-locked blocks a host_array() call outgrew: kept until close() (views of them may live on)
+        # trajectory / controller objects created from this one: kp_multi_destroy tears down the contexts they point into, so
+        # close() releases them FIRST (include/koopman_hip.h: "destroy the objects before the kp_multi"), and their own
+        # close() / __del__ afterwards is a no-op
+        self._children = weakref.WeakSet()
 
     def _check(self, rc):
         if rc != F.KP_OK:
@@ -49,7 +55,8 @@ class Multi:
         ent = self._blocks.get(name)
         if ent is None or ent[1] < n:
             if ent is not None:
-                self._check(F.lib().kp_multi_host_free(self._h, ent[0]))
+                # arrays handed out earlier are views of the old block: it stays allocated until close()
+                self._retired.append(ent[0])
             p = F.vp()
             cap = n + n // 8 + 512
             self._check(F.lib().kp_multi_host_alloc(self._h, cap * 8, C.byref(p)))
@@ -90,6 +97,11 @@ class Multi:
 
     def close(self):
         if self._h:
+            for child in list(self._children):
+                child.close()
+            for p in self._retired:
+                F.lib().kp_multi_host_free(self._h, p)
+            self._retired = []
             F.lib().kp_multi_destroy(self._h)
             self._h = F.vp()
             self._blocks = {}
@@ -111,6 +123,7 @@ class MultiTraj:
         self.ntrials, self.T, self.Tv = int(ntrials), rows // int(ntrials), Yv.shape[1]
         tr = Traj._blocks
         self._h = F.vp()
+        mg._children.add(self)
         mg._check(F.lib().kp_multi_traj_upload(mg.handle, F.dptr(tr(Y)), F.dptr(tr(U)), self.nb, self.ntrials, self.T, self.n, self.m,
                                                F.dptr(tr(Yv)), F.dptr(tr(Uv)), self.Tv, C.byref(self._h)))
 
@@ -126,9 +139,9 @@ class MultiTraj:
         return err, st
 
     def close(self):
-        if self._h:
+        if self._h and self.mg._h:           # (a closed parent has released this object already)
             F.lib().kp_multi_traj_destroy(self._h)
-            self._h = F.vp()
+        self._h = F.vp()
 
     def __del__(self):
         try:
@@ -149,6 +162,7 @@ class MultiMpc:
         hi_ = None if hi is None else np.ascontiguousarray(hi, dtype=np.float64)
         nan = float("nan")
         self._h = F.vp()
+        mg._children.add(self)
         mg._check(F.lib().kp_multi_mpc_create(mg.handle, F.MODEL[model_type], F.dptr(A), F.dptr(B), self.N, self.m, self.Np, F.dptr(proj),
                                               self.nproj, float(q_run), float(q_term), F.dptr(r), F.dptr(lo_), F.dptr(hi_),
                                               nan if slope_lim is None else float(slope_lim),
@@ -172,9 +186,9 @@ class MultiMpc:
         return np.transpose(U, (0, 2, 1)), st
 
     def close(self):
-        if self._h:
+        if self._h and self.mg._h:           # (a closed parent has released this object already)
             F.lib().kp_multi_mpc_destroy(self._h)
-            self._h = F.vp()
+        self._h = F.vp()
 
     def __del__(self):
         try:

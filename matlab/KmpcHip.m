@@ -176,4 +176,17 @@ classdef KmpcHip < Kmpc
             end
         end
     end
+
+    methods ( Static )
+        function obj = loadobj( s )
+            % a loaded controller carries no device handle (KpOwner's handles are Transient): it is rebuilt on first use by
+            % constructing the controller again from its sysid class, KmpcHip( sysid_class , ... ) - the MPC problem on the
+            % device is a function of the model AND of this session's context, which a MAT file cannot hold.  Until then the
+            % device calls of this object fail with kp_mex's "unknown or stale handle" error instead of touching freed memory.
+            obj = s;
+            if isa( obj , 'KmpcHip' ) && isstruct( obj.hip )
+                obj.hip.mpc = uint64( 0 );
+            end
+        end
+    end
 end

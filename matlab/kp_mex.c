@@ -103,10 +103,13 @@ static int g_snaps_nz[MAXDEV], g_snaps_m[MAXDEV];
 #define MAXMULTI 8
 static kp_multi* g_multi[MAXMULTI];
 
+static void reg_del(void* p);
+static void reg_clear(void);
 static void release_slot(int i) {
   if (!g_ctx[i]) return;
-  if (g_snaps[i]) kp_snapshots_destroy(g_snaps[i]);
+  if (g_snaps[i]) { reg_del(g_snaps[i]); kp_snapshots_destroy(g_snaps[i]); }
   g_snaps[i] = NULL;
+  reg_del(g_ctx[i]);
   kp_destroy(g_ctx[i]);
   g_ctx[i] = NULL;
   g_refs[i] = 0;
@@ -117,7 +120,10 @@ static void at_exit(void) {
     if (g_multi[i]) kp_multi_destroy(g_multi[i]);
     g_multi[i] = NULL;
   }
+  /* (whatever basis / MPC / trajectory handles the scripts never released go with their contexts' device memory at process
+   * exit; the registry only forgets them) */
   for (int i = 0; i < MAXDEV; ++i) release_slot(i);
+  reg_clear();
 }
 
 static int slot_of(const kp_ctx* c) {
@@ -126,14 +132,56 @@ static int slot_of(const kp_ctx* c) {
   return -1;
 }
 
+/* ---- registry of live handles -------------------------------------------------------------------------------------------
+ * A handle is a raw pointer in a uint64.  MATLAB objects that carry one can be saved and loaded (Ksysid.save_class, Ksysid.m:
+ * 436-448), copied into another session, or outlive `clear kp_mex`: the value then names memory that was freed, or never was
+ * ours.  Every handle handed out is recorded here, every command that takes one checks it, and a *_destroy command on an
+ * unknown value is an error MATLAB can catch - not a free() of a stale pointer. */
+static void** g_live;
+static size_t g_nlive, g_caplive;
+static void reg_add(void* p) {
+  if (!p) return;
+  if (g_nlive == g_caplive) {
+    const size_t cap = g_caplive ? 2 * g_caplive : 64;
+    void** q = (void**)realloc(g_live, cap * sizeof *q);
+    if (!q) mexErrMsgIdAndTxt("kp:memory", "out of host memory");
+    g_live = q;
+    g_caplive = cap;
+  }
+  g_live[g_nlive++] = p;
+}
+static int reg_find(const void* p) {
+  for (size_t i = 0; i < g_nlive; ++i)
+    if (g_live[i] == p) return (int)i;
+  return -1;
+}
+static void reg_del(void* p) {
+  const int i = reg_find(p);
+  if (i >= 0) g_live[i] = g_live[--g_nlive];
+}
+static void reg_clear(void) {
+  free(g_live);
+  g_live = NULL;
+  g_nlive = g_caplive = 0;
+}
+
 /* ---- argument helpers ------------------------------------------------------------------------------------------------ */
 static void* get_handle(const mxArray* a) {
   if (!mxIsUint64(a) || mxGetNumberOfElements(a) != 1) mexErrMsgIdAndTxt("kp:handle", "handle must be a uint64 scalar");
   void* p = (void*)(uintptr_t)(*(uint64_t*)mxGetData(a));
   if (!p) mexErrMsgIdAndTxt("kp:handle", "null handle");
+  if (reg_find(p) < 0)
+    mexErrMsgIdAndTxt("kp:handle", "unknown or stale handle (released already, loaded from a MAT file, or from before `clear kp_mex`)");
+  return p;
+}
+/* a *_destroy command: the handle leaves the registry before its memory goes */
+static void* take_handle(const mxArray* a) {
+  void* p = get_handle(a);
+  reg_del(p);
   return p;
 }
 static mxArray* put_handle(void* p) {
+  if (reg_find(p) < 0) reg_add(p);                      /* (the shared context and the resident snapshot object are handed out repeatedly) */
   mxArray* a = mxCreateNumericMatrix(1, 1, mxUINT64_CLASS, mxREAL);
   *(uint64_t*)mxGetData(a) = (uint64_t)(uintptr_t)p;
   return a;
@@ -301,9 +349,9 @@ static void c_basis_desc_dims(ARGS) {
   check(kp_basis_desc_dims(&desc, &v[0], &v[1], &v[2], &v[3]), NULL);
   dims4(plhs, v);
 }
-static void c_basis_destroy(ARGS) { UNUSED; kp_basis_destroy((kp_basis*)get_handle(prhs[1])); }
-static void c_snapshots_destroy(ARGS) { UNUSED; kp_snapshots_destroy((kp_snapshots*)get_handle(prhs[1])); }
-static void c_mpc_destroy(ARGS) { UNUSED; kp_mpc_destroy((kp_mpc*)get_handle(prhs[1])); }
+static void c_basis_destroy(ARGS) { UNUSED; kp_basis_destroy((kp_basis*)take_handle(prhs[1])); }
+static void c_snapshots_destroy(ARGS) { UNUSED; kp_snapshots_destroy((kp_snapshots*)take_handle(prhs[1])); }
+static void c_mpc_destroy(ARGS) { UNUSED; kp_mpc_destroy((kp_mpc*)take_handle(prhs[1])); }
 static void c_sym_eig(ARGS) {
   UNUSED;
   kp_ctx* c = CTX(1);
@@ -356,6 +404,7 @@ static void c_snapshots_resident(ARGS) {
   const int slot = slot_of(c);
   if (slot < 0) mexErrMsgIdAndTxt("kp:handle", "snapshots_resident: unknown context");
   if (g_snaps[slot] && (g_snaps_nz[slot] != nz || g_snaps_m[slot] != m_)) {
+    reg_del(g_snaps[slot]);
     kp_snapshots_destroy(g_snaps[slot]);
     g_snaps[slot] = NULL;
   }
@@ -623,7 +672,7 @@ static void c_traj_put(ARGS) {
   check(kp_traj_put(t, which, blk), NULL);
 }
 static void c_traj_finish(ARGS) { UNUSED; check(kp_traj_finish((kp_traj*)get_handle(prhs[1])), NULL); }
-static void c_traj_destroy(ARGS) { UNUSED; kp_traj_destroy((kp_traj*)get_handle(prhs[1])); }
+static void c_traj_destroy(ARGS) { UNUSED; kp_traj_destroy((kp_traj*)take_handle(prhs[1])); }
 static void c_traj_dims(ARGS) {
   UNUSED;
   int d[6];
@@ -914,6 +963,7 @@ static void c_multi_destroy(ARGS) {
   kp_multi* g = multi_handle(prhs[1]);
   for (int i = 0; i < MAXMULTI; ++i)
     if (g_multi[i] == g) g_multi[i] = NULL;
+  reg_del(g);
   kp_multi_destroy(g);
 }
 static void c_multi_size(ARGS) {
@@ -965,7 +1015,7 @@ static void c_multi_traj_upload(ARGS) {
 }
 static void c_multi_traj_destroy(ARGS) {
   UNUSED;
-  mtraj_rec* r = (mtraj_rec*)get_handle(prhs[1]);
+  mtraj_rec* r = (mtraj_rec*)take_handle(prhs[1]);
   kp_multi_traj_destroy(r->t);
   free(r);
 }
@@ -1007,7 +1057,7 @@ static void c_multi_mpc_set_state_bounds(ARGS) {
 }
 static void c_multi_mpc_destroy(ARGS) {
   UNUSED;
-  mmpc_rec* r = (mmpc_rec*)get_handle(prhs[1]);
+  mmpc_rec* r = (mmpc_rec*)take_handle(prhs[1]);
   kp_multi_mpc_destroy(r->p);
   free(r);
 }

@@ -176,3 +176,26 @@ def test_lasso_values_that_need_the_homotopy_through_the_worker_threads(ctx, gol
             assert abs(np.abs(Ks[i]).sum() - las[i] * N) <= 1e-11 * las[i] * N
     finally:
         mg.close()
+
+
+def test_closing_the_multi_object_first_releases_its_children_and_keeps_old_host_views_valid():
+    """kp_multi_destroy tears down the contexts its trajectory / controller objects point into (include/koopman_hip.h: destroy
+    the objects first).  The Python owner enforces the order: Multi.close() releases the children it created, their own close()
+    / __del__ afterwards is a no-op (round-4 advisor: a use-after-free at interpreter shutdown).  And a named page-locked block
+    that has to grow leaves the arrays handed out before usable until close()."""
+    from test_mex_gateway import _stacks
+    Y, U, Yv, Uv, k = _stacks(nb=6, seed=5)
+    Yn, Un, Yvn, Uvn = (np.ascontiguousarray(np.transpose(x, (2, 0, 1))) for x in (Y, U, Yv, Uv))
+    mg = Multi([0, 0])
+    tr = mg.traj_upload(Yn, Un, k, Yvn, Uvn)
+    A = np.array([[0.9, 0.1], [0.0, 0.8]]); B = np.array([[0.0], [1.0]])
+    mm = MultiMpc(mg, "linear", A, B, 4, np.array([[1.0, 0.0]]), 1.0, 1.0, np.array([0.1]))
+    first = mg.host_array("K", (4, 8, 8))
+    first[:] = 3.0
+    second = mg.host_array("K", (64, 8, 8))                          # grows: a new block
+    second[:] = 5.0
+    assert (first == 3.0).all()                                      # the old view still points at live memory
+    mg.close()                                                       # children first, then the retired blocks, then the contexts
+    tr.close(); mm.close()                                           # no-ops: nothing is released twice
+    tr.close(); mm.close()
+    del tr, mm, mg

@@ -83,6 +83,26 @@ def test_context_commands(ctx, h):
     assert e.value.identifier in ("kp:usage", "kp:error")
 
 
+def test_stale_and_foreign_handles_are_rejected(ctx, h):
+    """A handle is a raw pointer in a uint64; MATLAB objects that carry one can be saved, loaded and outlive `clear kp_mex`
+    (Ksysid.save_class, Ksysid.m:436-448).  The gateway keeps a registry of the handles it handed out: releasing one twice,
+    using one after its release, or presenting a value it never produced is an ERROR MATLAB can catch - never a free() of a
+    stale pointer (round-4 advisor finding on matlab/KpOwner.m)."""
+    d, _ = desc_of("bilinear", 2, 1, 2)
+    b = mex("basis_create", h, d)
+    assert mex("basis_dims", b).ravel().tolist()[0] == 2
+    mex("basis_destroy", b, nargout=0)
+    for cmd, args in (("basis_destroy", (b,)), ("basis_dims", (b,)), ("mpc_destroy", (b,)), ("traj_destroy", (ms.Handle(0x7f0000001000),)),
+                      ("snapshots_destroy", (ms.Handle(int(b) + 8),)), ("lift", (h, b, 1, np.zeros((3, 2)))), ("destroy", (ms.Handle(12345678),))):
+        with pytest.raises(ms.MexError) as e:
+            mex(cmd, *args, nargout=0)
+        assert e.value.identifier == "kp:handle", (cmd, e.value.identifier)
+    # the context is still usable, and a handle of one kind released through its own command still works afterwards
+    b2 = mex("basis_create", h, d)
+    assert mex("basis_dims", b2).ravel().tolist()[0] == 2
+    mex("basis_destroy", b2, nargout=0)
+
+
 def test_dictionary_lift_and_eig(ctx, h, small):
     assert mex("basis_dims", small["b"]).ravel().tolist() == [small["bp"].nvars, small["bp"].nfull, small["N"], small["W"]]
     assert mex("basis_desc_dims", small["d"]).ravel().tolist() == [small["bp"].nvars, small["bp"].nfull, small["N"], small["W"]]
