@@ -1000,7 +1000,8 @@ int kp_flush_pending(kp_ctx* ctx) { return flush_solves(ctx); }
 
 extern "C" int kp_fit(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* snaps, const double* lasso, int n_lasso,
                       double* K_out) {
-  if (!ctx || !basis || !snaps || n_lasso < 1) return ctx ? ctx->fail(KP_ERR_ARG, "kp_fit: bad argument") : KP_ERR_ARG;
+  // (a context whose [G | C] was handed in - kp_multi_fit's peers - needs no snapshot object)
+  if (!ctx || !basis || (!snaps && !ctx->gc_preloaded) || n_lasso < 1) return ctx ? ctx->fail(KP_ERR_ARG, "kp_fit: bad argument") : KP_ERR_ARG;
   KP_HIP(ctx, hipSetDevice(ctx->device));
   const int W = basis->dev.W, N = basis->dev.N;
   const bool all_ls = [&] {

@@ -764,24 +764,33 @@ int kp_gram3_launch(kp_ctx* ctx, const kp_basis* basis_c, const kp_snapshots* s,
   if (!part_base) return ctx->fail(KP_ERR_HIP, "kp_fit_gram: out of device memory");
   double* part = (double*)(part_base + (ctx->reduce_stream ? (size_t)ctx->part_flip * part_bytes : 0));
 
-  // dim_red dictionaries: the econ lift once per snapshot into a row buffer (kp_gram3_prelift_kernel), the Gram kernel loads tiles of it
-  // ... when there are enough snapshots to fill the chip with one thread each: the prelift kernel walks its 84 columns in ~40 us
-  // however few threads run, so at the arm data's 11 999 pairs the in-kernel projection is faster (0.049 against 0.088 ms of
-  // kernels, tools/arm_shape_latency.py), the two forms cross near 45 000 pairs (gaussian dictionaries: the same), and at 1e5 pairs it is
-  // slower (0.207 against 0.161)
-  static const int64_t pre_min_ns = [] { const char* e = getenv("KP_GRAM3_PRELIFT_MIN_NS"); return e ? (int64_t)atoll(e) : (int64_t)48000; }();
-  const bool pre = gram3_prelift(basis) && s->Ns >= pre_min_ns;
-  const size_t lds = (size_t)(LDS3_DOUBLES + (b.k_pcs > 0 && !pre ? 2 * nfull4 * 16 : 0) + (ext && !pre ? LDS3_GAUSS_DOUBLES : 0)) * sizeof(double);
+  // dim_red dictionaries: the econ lift once per snapshot into a row buffer (kp_gram3_prelift.hip), the Gram kernel loads tiles of it.
+  // Round 4's prelift kernel walked its 84 columns in ~40 us however few threads ran, so the in-kernel projection won below
+  // ~45 000 pairs; round 5's works tile by tile: at the arm data's 11 999 pairs 0.040 against 0.053 ms of kernels
+  // (tools/arm_shape_latency.py with KP_GRAM3_PRELIFT_MIN_NS=0).  Below a few thousand pairs the second launch is not worth it.
+  static const int64_t pre_min_ns = [] { const char* e = getenv("KP_GRAM3_PRELIFT_MIN_NS"); return e ? (int64_t)atoll(e) : (int64_t)6000; }();
+  bool pre = gram3_prelift(basis) && s->Ns >= pre_min_ns;
   const int pre_rl = 8 * plan.G4 + 12;
   double* pre_buf = nullptr;
   if (pre) {
-    if (!ext && !basis->d_pcsT) {
-      if (hipMalloc(&basis->d_pcsT, (size_t)b.nfull * 32 * 8) != hipSuccess) return ctx->fail(KP_ERR_HIP, "kp_fit_gram: out of device memory");
-      KP_HIP(ctx, kp_gram3_pcs_transpose_launch(b.pcs, b.nfull, b.k_pcs, (double*)basis->d_pcsT, ctx->stream));
+    // the row buffer is ~0.7 - 1 KB per snapshot (7 - 10 GB at 1e7 pairs), in one piece: when it is more than a quarter of the
+    // device's memory, or cannot be had (a busy device, several contexts of a kp_multi on one GPU), the fit runs with the
+    // in-kernel lift instead of failing - same Grams, no buffer
+    const size_t pre_bytes = (size_t)ktiles * KT3 * pre_rl * 8;
+    if (ctx->hbm_bytes > 0 && pre_bytes > (size_t)ctx->hbm_bytes / 4) pre = false;
+    if (pre) {
+      pre_buf = (double*)ctx->workspace(14, pre_bytes);
+      if (!pre_buf) {
+        (void)hipGetLastError();
+        pre = false;
+      }
     }
-    pre_buf = (double*)ctx->workspace(14, (size_t)ktiles * KT3 * pre_rl * 8);
-    if (!pre_buf) return ctx->fail(KP_ERR_HIP, "kp_fit_gram: out of device memory");
   }
+  if (pre && !ext && !basis->d_pcsT) {
+    if (hipMalloc(&basis->d_pcsT, (size_t)b.nfull * 32 * 8) != hipSuccess) return ctx->fail(KP_ERR_HIP, "kp_fit_gram: out of device memory");
+    KP_HIP(ctx, kp_gram3_pcs_transpose_launch(b.pcs, b.nfull, b.k_pcs, (double*)basis->d_pcsT, ctx->stream));
+  }
+  const size_t lds = (size_t)(LDS3_DOUBLES + (b.k_pcs > 0 && !pre ? 2 * nfull4 * 16 : 0) + (ext && !pre ? LDS3_GAUSS_DOUBLES : 0)) * sizeof(double);
 
   Gram3Args a;
   a.b = b;

@@ -222,6 +222,8 @@ extern "C" int kp_multi_create(const int* device_ids, int n_dev, kp_multi** out)
   }
   // peer access between the devices (the exchange of kp_multi_fit_sharded is a peer copy); refusals are not errors: the
   // copy then goes through the host
+  int dev_before = -1;                                    // the caller's current device is left as it was
+  if (hipGetDevice(&dev_before) != hipSuccess) dev_before = -1;
   for (int a = 0; a < n_dev; ++a)
     for (int b = 0; b < n_dev; ++b) {
       const int da = device_ids[a], db = device_ids[b];
@@ -230,6 +232,7 @@ extern "C" int kp_multi_create(const int* device_ids, int n_dev, kp_multi** out)
       if (hipSetDevice(da) == hipSuccess) (void)hipDeviceEnablePeerAccess(db, 0);
       (void)hipGetLastError();
     }
+  if (dev_before >= 0) (void)hipSetDevice(dev_before);
   for (auto& w : mg->w) w->th = std::thread(worker_main, w.get());
   *out = mg.release();
   return KP_OK;
@@ -270,8 +273,11 @@ extern "C" int kp_multi_host_alloc(kp_multi* mg, int64_t bytes, void** ptr) {
   if (!mg || !ptr || bytes < 1) return mg ? mg->fail(KP_ERR_ARG, "kp_multi_host_alloc: bad argument") : KP_ERR_ARG;
   *ptr = nullptr;
   void* p = nullptr;
+  int dev_before = -1;                                    // the caller's current device is left as it was
+  if (hipGetDevice(&dev_before) != hipSuccess) dev_before = -1;
   (void)hipSetDevice(mg->w[0]->device);
   hipError_t e = hipHostMalloc(&p, (size_t)bytes, hipHostMallocPortable);      // page-locked for EVERY device of the process
+  if (dev_before >= 0) (void)hipSetDevice(dev_before);
   if (e != hipSuccess) return mg->fail(KP_ERR_HIP, std::string("kp_multi_host_alloc: ") + hipGetErrorString(e));
   std::lock_guard<std::mutex> lk(mg->mu);
   mg->host_blocks.push_back({(char*)p, (size_t)bytes});
@@ -325,45 +331,101 @@ static int scatter_results(kp_multi* mg, Worker* w, int W, const std::vector<int
   return KP_OK;
 }
 
+// The lasso grid of train_models (Ksysid.m:1372-1387): value i on device i mod n.  The Grams do not depend on the value:
+// device 0 uploads the snapshot matrix and runs the fused lift + Gram kernel ONCE, every other device receives [G | C]
+// (2 W^2 doubles, 1.8 MB at W = 336) by a peer copy over xGMI and only factorises and solves its own values.  (Round 4 uploaded
+// the 12 MB of snapshots to EVERY device and repeated the 0.40 ms Gram kernel there: 0.7 ms per device that bought nothing.)
 extern "C" int kp_multi_fit(kp_multi* mg, const kp_basis_desc* desc, const double* alpha, const double* beta, const double* u, int64_t Ns,
                             const double* lasso, int n_lasso, double* K_out) {
   if (!mg || !desc || !alpha || !beta || Ns < 1 || n_lasso < 1 || !lasso || !K_out || (desc->m > 0 && !u))
     return mg ? mg->fail(KP_ERR_ARG, "kp_multi_fit: bad argument") : KP_ERR_ARG;
   std::lock_guard<std::mutex> call(mg->mu);
+  mg->err.clear();
+  const double t_call = now_ms();
   std::vector<uint8_t> key;
   if (desc_key(desc, &key)) return mg->fail(KP_ERR_ARG, "kp_multi_fit: bad dictionary descriptor");
   const int n = (int)mg->w.size();
+  const int nw = std::min(n, n_lasso);                      // workers with at least one value
+  Worker* w0 = mg->w[0].get();
+  // phase 0: every worker's dictionary and [G | C] buffer; worker 0 also uploads the snapshots and forms the Grams
   std::vector<std::function<int()>> jobs(n);
-  for (int r = 0; r < n && r < n_lasso; ++r) {
+  for (int r = 0; r < nw; ++r) {
     Worker* w = mg->w[r].get();
     jobs[r] = [=, &key]() -> int {
-      std::vector<int> idx;                       // value i belongs to worker i mod n (as the one-process-per-GPU path deals them)
-      std::vector<double> lv;
-      for (int i = r; i < n_lasso; i += n) { idx.push_back(i); lv.push_back(lasso[i]); }
-      double t0 = now_ms();
+      w->ms[0] = w->ms[1] = w->ms[2] = 0.0;
       int rc = worker_basis(w, desc, key);
       if (rc) return rc;
+      if (w->ctx->async_pending) { rc = kp_synchronize(w->ctx); if (rc) return rc; }
+      rc = kp_ensure_gc(w->ctx, w->basis->dev.W);
+      if (rc || r != 0) return rc;
+      double t0 = now_ms();
       rc = worker_snapshots(w, alpha, beta, u, Ns, 0, Ns, desc->nzeta, desc->m);
       if (rc) return rc;
       w->ms[0] = now_ms() - t0;
       t0 = now_ms();
-      std::vector<double> one;
-      double* direct_out = nullptr;
-      if (lv.size() == 1) {                       // kp_fit with K_out == NULL and ONE value is the asynchronous pipeline: keep this synchronous
-        one.resize((size_t)w->basis->dev.W * w->basis->dev.W);
-        direct_out = one.data();
-      }
-      rc = kp_fit(w->ctx, w->basis, w->snaps, lv.data(), (int)lv.size(), direct_out);
-      if (rc) return rc;
-      KP_HIP(w->ctx, hipStreamSynchronize(w->ctx->stream));
+      rc = kp_fit_gram(w->ctx, w->basis, w->snaps, nullptr, nullptr);       // leaves [G | C] in the context's buffer
       w->ms[1] = now_ms() - t0;
-      t0 = now_ms();
-      rc = scatter_results(mg, w, w->basis->dev.W, idx, K_out);
-      w->ms[2] = now_ms() - t0;
       return rc;
     };
   }
-  return run_all(mg, jobs);
+  int rc = run_all(mg, jobs);
+  if (rc) return rc;
+  const int W = w0->basis->dev.W;
+  const size_t cnt = (size_t)2 * W * W;
+  // phase 1: [G | C] to the peers (issued by worker 0 on its stream; the same device listed twice: a device-to-device copy)
+  if (nw > 1) {
+    std::vector<std::function<int()>> j1(n);
+    j1[0] = [&]() -> int {
+      const double t0 = now_ms();
+      for (int r = 1; r < nw; ++r) {
+        Worker* w = mg->w[r].get();
+        KP_HIP(w0->ctx, hipMemcpyPeerAsync(w->ctx->GC, w->device, w0->ctx->GC, w0->device, cnt * 8, w0->ctx->stream));
+      }
+      KP_HIP(w0->ctx, hipStreamSynchronize(w0->ctx->stream));
+      w0->ms[2] = now_ms() - t0;
+      return KP_OK;
+    };
+    rc = run_all(mg, j1);
+    if (rc) return rc;
+  }
+  // phase 2: every worker factorises once and solves its values as one batch, its results straight into the caller's stack
+  std::vector<int> ranks(nw, W);
+  for (int r = 0; r < nw; ++r) {
+    Worker* w = mg->w[r].get();
+    jobs[r] = [=, &ranks]() -> int {
+      std::vector<int> idx;                       // value i belongs to worker i mod n (as the one-process-per-GPU path deals them)
+      std::vector<double> lv;
+      for (int i = r; i < n_lasso; i += n) { idx.push_back(i); lv.push_back(lasso[i]); }
+      double t0 = now_ms();
+      std::vector<double> one;
+      double* direct_out = nullptr;
+      if (lv.size() == 1) {                       // kp_fit with K_out == NULL and ONE value is the asynchronous pipeline: keep this synchronous
+        one.resize((size_t)W * W);
+        direct_out = one.data();
+      }
+      w->ctx->gc_preloaded = true;                // the context's [G | C] is final: kp_fit skips its Gram launch (and needs no snapshots)
+      int rc2 = kp_fit(w->ctx, w->basis, w0->snaps, lv.data(), (int)lv.size(), direct_out);
+      w->ctx->gc_preloaded = false;
+      if (rc2) return rc2;
+      KP_HIP(w->ctx, hipStreamSynchronize(w->ctx->stream));
+      ranks[r] = w->ctx->last_rank;
+      w->ms[1] += now_ms() - t0;
+      t0 = now_ms();
+      rc2 = scatter_results(mg, w, W, idx, K_out);
+      w->ms[2] += now_ms() - t0;
+      return rc2;
+    };
+  }
+  rc = run_all(mg, jobs);
+  if (rc) return rc;
+  for (int r = 0; r < nw; ++r) mg->w[r]->ms[3] = now_ms() - t_call;      // (the call had three rounds of jobs: the whole of it)
+  // MATLAB's `\` warns on a rank-deficient Px and goes on (Ksysid.m:1069); the workers' warnings reach the caller here
+  for (int r = 0; r < nw; ++r)
+    if (ranks[r] >= 0 && ranks[r] < W) {
+      mg->err = "warning: Gram matrix is rank deficient (rank " + std::to_string(ranks[r]) + " of " + std::to_string(W) + "); basic solution returned";
+      break;
+    }
+  return KP_OK;
 }
 
 extern "C" int kp_multi_fit_sharded(kp_multi* mg, const kp_basis_desc* desc, const double* alpha, const double* beta, const double* u,

@@ -199,3 +199,33 @@ def test_closing_the_multi_object_first_releases_its_children_and_keeps_old_host
     tr.close(); mm.close()                                           # no-ops: nothing is released twice
     tr.close(); mm.close()
     del tr, mm, mg
+
+
+def test_distinct_devices_when_the_box_has_them(ctx, cfg3):
+    """The one-caller path over DISTINCT devices (peer access, hipMemcpyPeerAsync between two GPUs, one worker thread per
+    device): skipped on a one-GPU box, run by whoever first has several - the lasso grid (one Gram + peer broadcast of
+    [G | C]) and the snapshot-sharded fit against the single-context results."""
+    import ctypes as C
+    from koopman_realizations_amd import _ffi as F
+    n = C.c_int()
+    F.check(F.lib().kp_device_count(C.byref(n)))
+    if n.value < 2:
+        pytest.skip("one visible device: the distinct-device branch needs two")
+    ids = list(range(n.value))
+    p, dic = cfg3["p"], cfg3["dic"]
+    N = cfg3["b"].N
+    lasso = list(np.logspace(-2, 2, 2 * n.value + 1))
+    ref = kra.fit(ctx, cfg3["b"], cfg3["s"], lasso)
+    mg = Multi(ids)
+    try:
+        K = mg.fit(dic, p["alpha"], p["beta"], p["u"], lasso)
+        for i in range(len(lasso)):
+            assert np.array_equal(K[i].T, ref[i]), i
+        tm = mg.timers()
+        assert tm[0, 0] > 0.0 and (tm[1:, 0] == 0.0).all()          # only device 0 uploads the snapshots
+        Ks = mg.fit_sharded(dic, p["alpha"], p["beta"], p["u"])
+        Kls = kra.fit(ctx, cfg3["b"], cfg3["s"])[0]
+        assert np.abs(Ks[0].T - Kls).max() <= 1e-10 * np.abs(Kls).max()
+    finally:
+        mg.close()
+    del N
