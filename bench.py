@@ -415,7 +415,7 @@ def bench_width_points(ctx, kra, Ns):
     pcs = np.linalg.qr(rng.standard_normal((84, 27)))[0]
     centres = rng.uniform(-1, 1, (6, 20))
     shapes = [("W200", kra.Basis(ctx, "bilinear", 6, 3, [("poly", tab[6:49])]), snaps, "kp_gram3_kernel<6,3,false>"),
-              ("W136_pcs", kra.Basis(ctx, "bilinear", 6, 3, [("poly", tab[6:])], pcs), snaps, "kp_gram3_prelift_kernel + kp_gram3_kernel<.,3,false,false,true>"),
+              ("W136_pcs", kra.Basis(ctx, "bilinear", 6, 3, [("poly", tab[6:])], pcs), snaps, "kp_gram3_prelift_mfma_kernel + kp_gram3_kernel<.,3,false,false,true>"),
               ("fourier1_nzeta3", kra.Basis(ctx, "bilinear", 3, 3, [("fourier", 1)]), snaps3, "kp_gram3_prelift_ext_kernel + kp_gram3_kernel<.,3,false,false,true>"),
               ("gaussian20", kra.Basis(ctx, "bilinear", 6, 3, [("gaussian", centres)]), snaps, "kp_gram3_prelift_ext_kernel + kp_gram3_kernel<.,3,false,false,true>")]
     if os.environ.get("KP_BENCH_MORE_WIDTHS"):    # same width without the projection: what the econ lift costs
@@ -434,6 +434,63 @@ def bench_width_points(ctx, kra, Ns):
                      "roofline": roofline_block(kern or "fused lift+Gram (see DESIGN 3.1 for the variant)", ex * Ns, F_ * Ns, ms)}
         basis.close()
     snaps.close(); snaps3.close()
+    return out
+
+
+def bench_wide_points(ctx, kra):
+    """Dictionaries beyond one workgroup's reach (round 5): `def_fourierLift` with degree 1 on the arm's six
+    states (Ksysid.m:694-731: 728 functions; linear row W = 738, bilinear row W = 2 940) at the shipped data set's 11 999 pairs
+    and at 1e5.  Grams: lifted panels in HBM + TN products on the matrix pipe (csrc/kp_wide.hip); K = Px \\ Py: blocked Cholesky /
+    substitution over all CUs (csrc/kp_fit.hip).  Synchronous fits (the pipelined queue serves W <= 512)."""
+    out = {}
+    for mt in ("linear", "bilinear"):
+        basis = kra.Basis(ctx, mt, 6, 3, [("fourier", 1)])
+        W = basis.W
+        F_ = W * (W + 1) + 2.0 * W * W
+        for Ns in (11999, 100000):
+            a, b, u = synth_pairs(Ns, seed=11)
+            sn = kra.Snapshots(ctx, a, b, u)
+            kra.fit(ctx, basis, sn, fetch=False)
+            reps = 3
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                kra.fit(ctx, basis, sn, fetch=False)
+            dt = (time.perf_counter() - t0) / reps
+            gram_ms, solve_ms, ex = ctx.timer(0), ctx.timer(1), ctx.timer(10)
+            out[f"{mt}_W{W}_Ns{Ns}"] = {"W": W, "snapshots": Ns, "ms_per_fit": dt * 1e3, "pairs_per_s": Ns / dt, "gram_ms": gram_ms, "solve_ms": solve_ms,
+                                        "rank": ctx.last_rank(),
+                                        "roofline": roofline_block("kp_lift_kernel + kp_tn_gemm_kernel<8,4> (Px'Px upper tiles, Px'Py)", ex * Ns, F_ * Ns, gram_ms,
+                                                                   note="gram_ms includes the lift of the panel (fourier: 6 sincos per function and snapshot)"),
+                                        "solve_flop": W ** 3 / 3.0 + 2.0 * W ** 3, "solve_tflops": (W ** 3 / 3.0 + 2.0 * W ** 3) / (solve_ms * 1e-3) / 1e12}
+            sn.close()
+        basis.close()
+    return out
+
+
+def bench_rank_deficient(ctx, kra):
+    """MATLAB's `\\` on the arm data WITHOUT dim_red (Ksysid.m:1069; bilinear poly-3: rank 252 of 336): the plain
+    factorisation stops at its first rounding-level pivot, the blocked pivoted Cholesky over many workgroups selects the
+    column subset, its factor serves the substitution.  One synchronous fit on the shipped data set (tests/golden)."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "arm_data.npz"))
+    lens = g["train_len"]; off = np.concatenate([[0], np.cumsum(lens)])
+    train = [{"t": g["train_t"][a:b], "y": g["train_y"][a:b], "u": g["train_u"][a:b]} for a, b in zip(off[:-1], off[1:])]
+    data = {"train": train, "val": [{"t": g["val_t"], "y": g["val_y"], "u": g["val_u"]}]}
+    import warnings
+    out = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for mt, deg in (("bilinear", 3), ("linear", 3)):
+            ks = kra.Ksysid(data, ctx=ctx, model_type=mt, obs_type=["poly"], obs_degree=[deg], snapshots=np.inf, lasso=[np.inf], delays=0, dim_red=False)
+            sp = ks.snapshotPairs
+            sn = ks._resident_snapshots(sp["alpha"], sp["beta"], sp["u"])
+            for _ in range(5):
+                kra.fit(ctx, ks.basis_dev, sn)
+            t0 = time.perf_counter()
+            for _ in range(30):
+                kra.fit(ctx, ks.basis_dev, sn)
+            dt = (time.perf_counter() - t0) / 30
+            out[f"{mt}_poly{deg}"] = {"W": ks.basis_dev.W, "rank": ctx.last_rank(), "snapshots": int(sp["alpha"].shape[0]), "ms_per_fit": dt * 1e3,
+                                      "gram_ms": ctx.timer(0)}
     return out
 
 
@@ -490,7 +547,7 @@ def one_caller_main(args):
     configs[3], the random-system sweep of configs[4], a batch of MPC problems and one fit sharded over snapshots.  Prints one
     JSON object.  KP_ONE_CALLER_IDS=0,0 lists devices explicitly (the same device twice on a one-GPU box)."""
     ids = [int(x) for x in os.environ["KP_ONE_CALLER_IDS"].split(",")] if os.environ.get("KP_ONE_CALLER_IDS") else list(range(args.gpus))
-    n_gen = 2
+    n_gen = max(1, args.rand_systems // RAND_CHUNK)               # the SAME distinct systems as the per-process block (seeded per chunk)
     chunks = gen_rand_systems(list(range(n_gen)))                 # host, before the GPUs are touched
     import koopman_realizations_amd as kra
     from koopman_realizations_amd import sweep
@@ -519,7 +576,8 @@ def one_caller_main(args):
                          "per_device_ms": {"upload": tm[:, 0].tolist(), "device": tm[:, 1].tolist(), "gather": tm[:, 2].tolist(), "job": tm[:, 3].tolist()},
                          "budget_met": bool(np.all(l1 <= vals * N * (1 + 1e-9) + 1e-12)),
                          "gather": "each device DMAs its own K matrices into the caller's page-locked stack (no all-gather)",
-                         "note": "includes the upload of the 12 MB snapshot matrix to every device (host data in, K stack on the host out)"}
+                         "note": "host data in, K stack on the host out; device 0 uploads the 12 MB snapshot matrix and forms the Grams once, "
+                                 "the other devices receive [G | C] (1.8 MB) by a peer copy and only factorise / solve their values"}
     # (b) ONE fit sharded over snapshots: rows dealt over the devices, [G | C] to device 0 by peer copy, one solve
     sh = {}
     for Ns_tot in (Ns, 10000000):
@@ -539,8 +597,7 @@ def one_caller_main(args):
     # (c) configs[4]: 1024 random systems, contiguous chunks per device, three nested passes
     mine = [s_ for c in sorted(chunks) for s_ in chunks[c]]
     Y, U, k, Yv, Uv = sweep._stack_raw(mine)
-    rep = max(1, args.rand_systems // Y.shape[0])
-    Y, U, Yv, Uv = (np.ascontiguousarray(np.tile(x, (rep, 1, 1))) for x in (Y, U, Yv, Uv))
+    Y, U, Yv, Uv = (np.ascontiguousarray(x) for x in (Y, U, Yv, Uv))
     nsys = Y.shape[0]
     dicts = {mt: (mt, 1, 1, [("poly", kra.poly_exponent_table(1 + (mt == "nonlinear"), D)[1 + (mt == "nonlinear"):])], None)
              for mt, D in sweep.MAX_DEGREE.items()}
@@ -559,8 +616,8 @@ def one_caller_main(args):
     mean, _ = sweep.sweep_statistics(errs["linear"])
     res["rand_sweep"] = {"systems": nsys, "distinct_systems": int(n_gen * RAND_CHUNK), "seconds": dtw, "systems_per_s": nsys / dtw, "n_devices": len(ids),
                          "per_device_ms": {"upload": t_up, "passes": t_dev}, "mean_linear_error_deg1_deg13": [float(mean[0]), float(mean[-1])],
-                         "note": f"{n_gen * RAND_CHUNK} generated systems tiled to {nsys} (the child process generates only two chunks); stacked "
-                                 "raw trials in (host gather of the data4sysid structs excluded), error tables out"}
+                         "note": f"{nsys} distinct generated systems (the population of the per-process block); stacked raw trials in (host "
+                                 "gather of the data4sysid structs excluded), error tables out"}
     # (d) batched MPC: 4096 problems per device
     A = np.asfortranarray(Kls[:N, :N].T); B = np.asfortranarray(Kls[N:, :N].T)
     proj = np.zeros((2, N)); proj[0, 4] = proj[1, 5] = 1.0
@@ -725,7 +782,7 @@ def main():
             streamed_ms = (time.perf_counter() - t1) / n_st * 1e3
         ring2[1].close()
 
-    mpc_res = arm_res = widths = ns_pts = None
+    mpc_res = arm_res = widths = ns_pts = wide_pts = rankdef = None
     if rank == 0 and not args.no_mpc and world == 1:     # latency-bound sections only in the single-GPU run
         mpc_res = bench_mpc(ctx, kra, basis, snaps, args)
         arm_res = bench_arm_closed_loop(ctx, kra)
@@ -734,6 +791,8 @@ def main():
         widths = bench_width_points(ctx, kra, Ns)
         ns_pts = bench_ns_points(ctx, kra, basis) if (Ns == 100000 and args.degree == 3) else None
         gk_res = bench_get_koopman(ctx, kra, Ns)
+        wide_pts = bench_wide_points(ctx, kra)
+        rankdef = bench_rank_deficient(ctx, kra)
     lasso_res = sweep_res = shard_res = None
     if extras_on and world > 1:
         # SURVEY 8(e) pattern 2: ONE fit whose snapshots are sharded over the ranks (strong scaling: the total is fixed) - local
@@ -837,6 +896,10 @@ def main():
             res["snapshot_count_points"] = ns_pts
         if gk_res is not None:
             res["get_koopman"] = gk_res
+        if wide_pts is not None:
+            res["wide_dictionaries"] = wide_pts
+        if rankdef is not None:
+            res["rank_deficient_fit"] = rankdef
         if shard_res is not None:
             res["snapshot_sharded_fit"] = dict(shard_res, scaling="strong")
         if lasso_res is not None:

@@ -208,7 +208,7 @@ extern "C" int kp_basis_create(kp_ctx* ctx, const kp_basis_desc* d, kp_basis** o
   if (nvars > KP_MAX_VARS) return ctx->fail(KP_ERR_ARG, "kp_basis_create: too many variables (max 32)");
   std::vector<ColDesc> cols;
   for (int i = 0; i < nvars; ++i) cols.push_back({COL_VAR, i, 0, 0});
-  int n_mono = 0, n_gauss = 0, max_deg = 1;
+  int n_mono = 0, n_gauss = 0, max_deg = 1, fourier_deg = 0;
   for (int b = 0; b < d->n_blocks; ++b) {
     int cnt = d->block_count[b];
     if (cnt < 0) return ctx->fail(KP_ERR_ARG, "kp_basis_create: negative block count");
@@ -229,6 +229,7 @@ extern "C" int kp_basis_create(kp_ctx* ctx, const kp_basis_desc* d, kp_basis** o
         if (nf > 1e6) return ctx->fail(KP_ERR_ARG, "kp_basis_create: fourier block too large");
         int total = (int)std::llround(nf);
         for (int i = 1; i < total; ++i) cols.push_back({COL_FOURIER, i, cnt, 0});
+        fourier_deg = fourier_deg == 0 ? cnt : (fourier_deg == cnt ? cnt : -1);   // (blocks of different degrees: generic evaluation)
         break;
       }
       case KP_BLOCK_HERMITE:
@@ -254,6 +255,7 @@ extern "C" int kp_basis_create(kp_ctx* ctx, const kp_basis_desc* d, kp_basis** o
   kp_basis* b = new kp_basis();
   b->ctx = ctx;
   b->max_degree = max_deg;
+  b->fourier_degree = (fourier_deg > 0 && fourier_deg <= 8) ? fourier_deg : 0;
   // recipes of the fused Gram kernel's fast lift: column = product of <= 4 entries x_v^e of a
   // power table, id = v*D + (e-1), 255 = the constant 1
   {
@@ -417,15 +419,33 @@ extern "C" int kp_basis_dims(const kp_basis* b, int* nvars, int* nfull, int* N, 
 // LT points per workgroup (64; 16 when the full lift of a projected dictionary would not fit the LDS at 64).  ldi / ldo: leading
 // dimensions of the input columns and of the output (the wide Gram path, kp_wide.hip, lifts a row range of the snapshot arrays
 // into a panel of its own).
+// fdeg > 0: the dictionary has a fourier block of that degree (def_fourierLift, Ksysid.m:694-731): cos / sin(2 pi j x_v), j = 1..fdeg,
+// are formed ONCE per (point, variable) into `trig` and a function is a product of table entries - the generic column
+// evaluation called sin / cos once per non-trivial factor of every function, 3 000 of them per point for 728 functions on six
+// states (the lift was half of the wide Gram pass at W = 738).
+template <int LT>
+__device__ __forceinline__ double kp_lift_fourier_col(const BasisDev& b, const ColDesc c, const double* trig, int fdeg, int p) {
+  const int radix = 2 * c.aux + 1;
+  int idx = c.arg;
+  double v = 1.0;
+  for (int i = b.nvars - 1; i >= 0; --i) {
+    const int d = idx % radix;
+    idx /= radix;
+    if (d) v *= trig[(i * 2 * fdeg + (d - 1)) * LT + p];       // digit 2j - 1: cos(2 pi j x), 2j: sin(2 pi j x)
+  }
+  return v;
+}
+
 template <int LT>
 __global__ __launch_bounds__(256) void kp_lift_kernel(BasisDev b, int what, const double* __restrict__ zeta,
                                                       const double* __restrict__ u, int64_t rows, int64_t ldi, int64_t ldo,
-                                                      double* __restrict__ out) {
+                                                      double* __restrict__ out, int fdeg) {
   extern __shared__ double sm[];
-  // layout: vars[nvars][LT] | um[m][LT] | full[nfull][LT] (only when k_pcs)
+  // layout: vars[nvars][LT] | um[m][LT] | trig[nvars][2 fdeg][LT] (fourier blocks) | full[nfull][LT] (only when k_pcs)
   double* vars = sm;
   double* um = vars + b.nvars * LT;
-  double* full = um + (b.m > 0 ? b.m : 1) * LT;
+  double* trig = um + (b.m > 0 ? b.m : 1) * LT;
+  double* full = trig + b.nvars * 2 * fdeg * LT;
   const int64_t r0 = (int64_t)blockIdx.x * LT;
   const int tid = threadIdx.x;
   const int nl = (int)min((int64_t)LT, rows - r0);
@@ -446,13 +466,24 @@ __global__ __launch_bounds__(256) void kp_lift_kernel(BasisDev b, int what, cons
       um[(v - b.nvars) * LT + p] = x;
   }
   __syncthreads();
+  if (fdeg > 0) {
+    for (int e = tid; e < b.nvars * fdeg * LT; e += 256) {
+      const int p = e % LT, vj = e / LT, v = vj / fdeg, j = vj % fdeg + 1;
+      double sn, cs;
+      sincos(2.0 * 3.14159265358979323846 * (double)j * vars[v * LT + p], &sn, &cs);
+      trig[(v * 2 * fdeg + 2 * j - 2) * LT + p] = cs;
+      trig[(v * 2 * fdeg + 2 * j - 1) * LT + p] = sn;
+    }
+    __syncthreads();
+  }
   const bool econ = (b.k_pcs > 0) && what != KP_LIFT_FULL;
   if (!econ) {
     // column c of the full basis is also column c of psi
     for (int e = tid; e < b.nfull * LT; e += 256) {
       int c = e / LT, p = e % LT;
       if (p >= nl) continue;
-      double val = kp_eval_col(b, b.cols[c], vars + p, LT);
+      const ColDesc cd = b.cols[c];
+      double val = (fdeg > 0 && cd.kind == COL_FOURIER && cd.aux == fdeg) ? kp_lift_fourier_col<LT>(b, cd, trig, fdeg, p) : kp_eval_col(b, cd, vars + p, LT);
       int64_t r = r0 + p;
       if (what == KP_LIFT_ROW && b.model_type == KP_MODEL_BILINEAR) {
         out[(int64_t)c * ldo + r] = val;
@@ -464,7 +495,9 @@ __global__ __launch_bounds__(256) void kp_lift_kernel(BasisDev b, int what, cons
   } else {
     for (int e = tid; e < b.nfull * LT; e += 256) {
       int c = e / LT, p = e % LT;
-      full[c * LT + p] = p < nl ? kp_eval_col(b, b.cols[c], vars + p, LT) : 0.0;
+      const ColDesc cd = b.cols[c];
+      full[c * LT + p] = p >= nl ? 0.0
+                         : (fdeg > 0 && cd.kind == COL_FOURIER && cd.aux == fdeg) ? kp_lift_fourier_col<LT>(b, cd, trig, fdeg, p) : kp_eval_col(b, cd, vars + p, LT);
     }
     __syncthreads();
     // econ = [ v ; pcs' * full ; 1 ]   (Ksysid.m:1615-1618)
@@ -499,7 +532,8 @@ __global__ __launch_bounds__(256) void kp_lift_kernel(BasisDev b, int what, cons
 int kp_lift_dev_ld(kp_ctx* ctx, const kp_basis* basis, int what, const double* dz, const double* du, int64_t rows, int64_t ldi, double* dout,
                    int64_t ldo) {
   const BasisDev& b = basis->dev;
-  const size_t per_point = (size_t)(b.nvars + (b.m > 0 ? b.m : 1) + (b.k_pcs ? b.nfull : 0)) * 8;
+  const int fdeg = basis->fourier_degree;
+  const size_t per_point = (size_t)(b.nvars + (b.m > 0 ? b.m : 1) + b.nvars * 2 * fdeg + (b.k_pcs ? b.nfull : 0)) * 8;
   const int lt = per_point * 64 <= 160 * 1024 ? 64 : 16;
   const size_t lds = per_point * lt;
   if (lds > 160 * 1024) return ctx->fail(KP_ERR_ARG, "kp_lift: dictionary too large for the LDS staging of the pcs projection");
@@ -507,10 +541,10 @@ int kp_lift_dev_ld(kp_ctx* ctx, const kp_basis* basis, int what, const double* d
   const int64_t nblk = (rows + lt - 1) / lt;
   if (lt == 64) {
     KP_HIP(ctx, kp_ensure_lds(c64, (const void*)kp_lift_kernel<64>, lds));
-    hipLaunchKernelGGL(kp_lift_kernel<64>, dim3((unsigned)nblk), dim3(256), lds, ctx->stream, b, what, dz, du, rows, ldi, ldo, dout);
+    hipLaunchKernelGGL(kp_lift_kernel<64>, dim3((unsigned)nblk), dim3(256), lds, ctx->stream, b, what, dz, du, rows, ldi, ldo, dout, fdeg);
   } else {
     KP_HIP(ctx, kp_ensure_lds(c16, (const void*)kp_lift_kernel<16>, lds));
-    hipLaunchKernelGGL(kp_lift_kernel<16>, dim3((unsigned)nblk), dim3(256), lds, ctx->stream, b, what, dz, du, rows, ldi, ldo, dout);
+    hipLaunchKernelGGL(kp_lift_kernel<16>, dim3((unsigned)nblk), dim3(256), lds, ctx->stream, b, what, dz, du, rows, ldi, ldo, dout, fdeg);
   }
   KP_HIP(ctx, hipGetLastError());
   return KP_OK;

@@ -158,6 +158,7 @@ struct kp_basis {
   void* d_recipes = nullptr;   // [nfull] uint32: 4 x 8-bit power-table ids (255 = 1.0)
   void* d_pcsT = nullptr;      // dim_red: pcs as [full column][32 components], zero padded (kp_gram3_prelift_kernel; built on first use)
   int max_degree = 0;
+  int fourier_degree = 0;      // degree of the dictionary's fourier block (0: none, or blocks of different degrees): kp_lift_kernel's harmonic table
   int pow_depth = 1;           // largest single-variable exponent
   bool fast = false;           // every column is a product of <= 4 single-variable powers
   int max_factors = 1;         // largest number of single-variable powers in one column (valid if fast)
