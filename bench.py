@@ -842,7 +842,7 @@ def main():
         # HBM traffic of the dominant kernel: PMC counters are collected in separate rocprofv3 passes of this
         # same command (tools/prof_round.sh) and committed under profiles/; null when the workload differs
         traffic, prof_note = None, None
-        for pj in ("r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
+        for pj in ("r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
             pj = os.path.join(ROOT, "profiles", pj)
             if os.path.exists(pj) and Ns == 100000 and args.degree == 3:
                 try:

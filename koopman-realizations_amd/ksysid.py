@@ -210,9 +210,11 @@ class Ksysid:
         self.traindata = self.get_scale(merged)                            # :122
         self.valdata = [self.scale_data(v) for v in data4sysid["val"]]    # :123-126
         self.snapshotPairs = self.get_snapshotPairs(self.traindata, self.snapshots)   # :134
-        # pca of dictionaries wider than the fused Gram kernel takes (covariance width nfull + m > 560, e.g. poly-3 on a delayed
-        # arm state: 816 functions): lift on the device, SVD of the lifted matrix on the host - as the reference's `pca` does
-        wide = self.basis_dev.nfull + self.params["m"] > 560
+        # pca (Ksysid.m:1498): covariance of the lifted snapshots from the device Grams at any width (round 5: dictionaries beyond
+        # the LDS-staged kernels - poly-3 on a delayed arm state has 816 functions, fourier on six states 728 - go through lifted
+        # panels + TN products, csrc/kp_wide.hip), eigenvectors by kp_sym_eig up to its 1024 columns; beyond that the lift on the
+        # device and the SVD of the lifted matrix on the host, as the reference's `pca` does
+        wide = self.basis_dev.nfull + self.params["m"] > 1024
         Px = self.lift_snapshots(self.snapshotPairs) if (self.dim_red and (self._pca_host or wide)) else None   # :137-141
         self.get_econ_observables(Px)                                      # :142
         if self.loaded and not self._host_only:

@@ -132,3 +132,39 @@ def test_wide_rank_deficient_fit_returns_a_basic_solution_and_the_rank(ctx):
     assert (np.abs(K).sum(axis=1) == 0).sum() == dic.W - r
     res, resq = Px @ K - Py, Px @ Kq - Py
     assert np.abs(res - resq).max() < 1e-8 * max(1.0, np.abs(Py).max())
+
+
+def test_mirror_with_a_delay_embedded_state_and_dim_red(ctx, golden):
+    """Ksysid_setup.m lets the user pick delays = 1 with poly-3 and dim_red: nzeta = 15, 816 functions.  Rounds 1-4 took the
+    `pca` of that dictionary on the host (too wide for the Gram kernels) and refused the BILINEAR model on it.  Now the
+    covariance comes from the wide Gram path on the device (same principal axes as the host SVD of the lifted matrix), and
+    the bilinear fit runs: its projected row goes through the lift kernel's 16-point form (the full lift of 64 points would
+    not fit the LDS) and the wide Gram path - checked against the Grams of the device's own lifted rows formed on the host."""
+    import warnings
+    g = golden["arm_data"]
+    lens = g["train_len"]; off = np.concatenate([[0], np.cumsum(lens)])
+    train = [{"t": g["train_t"][a:b], "y": g["train_y"][a:b], "u": g["train_u"][a:b]} for a, b in zip(off[:-1], off[1:])]
+    data = {"train": train, "val": [{"t": g["val_t"], "y": g["val_y"], "u": g["val_u"]}]}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        kd = kra.Ksysid(data, ctx=ctx, model_type="linear", obs_type=["poly"], obs_degree=[3], snapshots=3000, lasso=[np.inf], delays=1, dim_red=True)
+        kh = kra.Ksysid(data, ctx=ctx, model_type="linear", obs_type=["poly"], obs_degree=[3], snapshots=3000, lasso=[np.inf], delays=1, dim_red=True,
+                        _pca_host=True)
+    assert kd.basis_dev.nfull == 816 and kd.params["nzeta"] == 15
+    assert kd.params["N"] == kh.params["N"]
+    pd_, ph = kd.basis["pcs"], kh.basis["pcs"]
+    # the leading principal axes agree (the trailing ones of the 99 % cut belong to nearly equal eigenvalues: compare the subspaces)
+    k = min(10, pd_.shape[1])
+    assert np.abs(np.abs(np.sum(pd_[:, :k] * ph[:, :k], axis=0)) - 1.0).max() < 1e-6
+    sv = np.linalg.svd(pd_.T @ ph, compute_uv=False)
+    assert sv.min() > 1 - 1e-6
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        kb = kra.Ksysid(data, ctx=ctx, model_type="bilinear", obs_type=["poly"], obs_degree=[3], snapshots=3000, lasso=[np.inf], delays=1, dim_red=True)
+    sp = kb.snapshotPairs
+    snaps = kra.Snapshots(ctx, sp["alpha"], sp["beta"], sp["u"])
+    G, C = kra.fit_gram(ctx, kb.basis_dev, snaps)
+    Px = kb.basis_dev.lift(F.LIFT_ROW, sp["alpha"], sp["u"]); Py = kb.basis_dev.lift(F.LIFT_ROW, sp["beta"], sp["u"])
+    s = np.abs(Px.T @ Px).max()
+    assert np.abs(G - Px.T @ Px).max() <= 1e-11 * s and np.abs(C - Px.T @ Py).max() <= 1e-11 * s
+    snaps.close()
