@@ -1,6 +1,8 @@
 // kp_gram3_prelift.hip - econ lift of a dim_red dictionary, once per snapshot, for the Kronecker Gram kernel (kp_gram3.hip, PRE mode).
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
+#include <utility>
 
 #include "kp_gram3_args.h"
 
@@ -37,64 +39,78 @@ __global__ __launch_bounds__(PRE_T) void kp_gram3_pcs_transpose_kernel(const dou
   }
 }
 
-// Round 5: the projection on the MATRIX pipe, by workgroups of FOUR PRODUCER AND FOUR CONSUMER WAVES.  The round-4 kernel (one
+// Round 5: the projection on the MATRIX pipe, by workgroups of four CONSUMER and four PRODUCER waves.  The round-4 kernel (one
 // thread per snapshot, the matrix as scalar operands of 64 multiply-adds per column) was latency-bound: 1e5 snapshots are 1 564
 // waves, 1.5 per SIMD, each walking 84 columns one after the other, and the 21 KB matrix streamed through a 16 KB scalar cache -
-// 65 us where its multiply-adds are 14.  Now a tile of 8 snapshots (both sides) is prepared by a producer wave and projected by
-// a consumer wave, 12 500 tiles per 1e5 pairs dealt to persistent workgroups, four tiles per workgroup and round:
-//   producer (tile of the NEXT round, into the other LDS buffer):
-//     1. power table x_v^e of both sides ([entry][side][8 snapshots], 20 doubles per entry: entries 8 dwords apart modulo the banks);
-//     2. the FULL lift into the Psi tile [column][side][8 snapshots] (18 doubles per column): a lane takes a (column, side) item -
-//        its three factors' table offsets sit in registers, 16-byte reads and writes (two snapshots each), 168 items in 3 rounds;
-//     3. the entries that are no components (zeta, the constant, padding, the 9 weights) straight to memory;
-//   consumer (tile of THIS round):
-//     4. pcs' psi by v_mfma_f64_4x4x4_4b, the four blocks = four groups of four COMPONENTS: the A operand (4 snapshots x 4 full
-//        columns) is ONE ds_read_b64 at `lane base + immediate` (affine in the k-step, the side and the snapshot group: nothing on
-//        the vector ALU between the MFMAs), the B operand pcs[4 kk + k][16 t + 4 blk + j] differs per lane - the whole 84 x 32
-//        matrix is 42 registers per lane, loaded once; two MFMAs (component tiles t = 0, 1) share an A operand;
-//     5. a D register (snapshot = lane >> 4, component = 4 blk + j) stores 256 contiguous bytes per snapshot pair of the tile
-//        layout [snapshot pair][entry][2] - whose consecutive entries the Gram kernel's loader writes into its Psi rows without
-//        the 4-way bank conflict of the round-4 layout [entry][8 snapshots];
-//   ONE LDS-only barrier per round (__syncthreads() would also drain the memory counter: the loads just requested for the round
-//   after next, the stores just issued).
+// 65 us where its multiply-adds are 14.  Now a tile of 8 snapshots (both sides) is the unit, 12 500 per 1e5 pairs dealt to
+// persistent workgroups, four tiles per workgroup and round; per slot:
+//   producer wave (two rounds ahead): raw loads; power table x_v^e of both sides ([entry][side][8 snapshots], 20 doubles per entry:
+//     entries 8 dwords apart modulo the banks), double-buffered; the entries that are no components (zeta, the constant,
+//     padding, the 9 weights) straight to memory;
+//   consumer wave: pcs' psi of THIS round's tile by v_mfma_f64_4x4x4_4b - the four blocks = four groups of four COMPONENTS: the
+//     A operand (4 snapshots x 4 full columns of the Psi tile [column][side][8 snapshots], 18 doubles per column) is ONE
+//     ds_read_b64 at `lane base + immediate`, requested four steps ahead IN THE SOURCE; the B operand pcs[4 kk + k][16 t + 4 blk
+//     + j] differs per lane - the whole 84 x 32 matrix is 42 registers per lane, loaded once; two MFMAs (component tiles t = 0, 1)
+//     share an A operand - and, one micro-operation behind each MFMA pair, the FULL lift of the NEXT round's tile into the other
+//     Psi buffer: a lane takes a (column, side) item, three 16-byte table reads at register offsets, two pairs of multiplies, a
+//     16-byte store per two snapshots (168 items in 3 rounds of 24 micro-operations, branch free: idle lanes work on a spare
+//     column).  A D register (snapshot = lane >> 4, component = 4 blk + j) stores 256 contiguous bytes per snapshot pair of the
+//     tile layout [snapshot pair][entry][2] - whose consecutive entries the Gram kernel's loader writes into its Psi rows
+//     without the 4-way bank conflict of the round-4 layout [entry][8 snapshots];
+//   ONE LDS-only barrier per round (__syncthreads() would also drain the memory counter: the loads just requested, the stores
+//   just issued).
 // Measured (1e5 pairs, 84 -> 27 components; tools/prelift_abl5.sh = timing-only builds through KP_PM_ABL, tools/prelift_phase_probe.py
-// = in-kernel cycle counters): 40 us against round 4's 65.  The MFMAs alone are 17 us (168 per tile at 16.5 cycles: the floor of
-// this instruction), the 67 MB of output another ~17 us of HBM writes that overlap them.  The way here: every wave doing all
-// steps in turn - one wave per tile (two waves per SIMD) or a pair of waves sharing a tile (three) - took 38 - 45 us however the
-// steps were tuned (62 us with a branch per k-step: no operand prefetch; 45 us with the lane forming psi[s][c] itself in front of
-// every MFMA pair; 41 us with the Psi tile staged as here; 38 us once a tile's loads were consumed BEFORE its stores - the memory
-// counter retires in order), and the time was the SUM of the steps' times: identical waves fall into step - all in the MFMA
-// phase, then all in the latency-bound phases (counters: every phase twice its instruction time, matrix pipe 41 % busy).  With
-// fixed roles the consumer's round is 3 400 cycles of MFMAs + 500 of stores, but a producer's round is 5 000: while a
-// consumer streams f64 MFMAs on its SIMD, the other waves' vector instructions wait (the power table - a dozen dependent
-// instructions - 1 400 - 2 000 cycles per tile, the lift 1 500; without the MFMAs 700 and 1 400), whichever wave has priority
-// (`s_setprio` on the producers: 41.5 -> 40.1 us) and however few they are (one producer per SIDE instead of one per tile: no
-// change).  What is left to try is the consumer lifting its own next tile BETWEEN its MFMAs (a vector instruction of the MFMA wave
-// itself costs the stream ~5 cycles): a hand-interleaved loop, not built.
-#define PM_T 768
+// = in-kernel cycle counters, KP_PM_ABL=32): **38 us against round 4's 65.**  The MFMAs alone are 17 us (168 per tile at 16.5
+// cycles: the floor of this instruction), the 67 MB of output another ~17 us of HBM writes beside them.  The way here, each
+// step measured:
+//   * every wave doing all steps in turn - one wave per tile (two waves per SIMD) or a pair of waves sharing a tile (three) -
+//     took 38 - 45 us however the steps were tuned (62 us with a branch per k-step: no operand prefetch; 45 us with the lane
+//     forming psi[s][c] itself in front of every MFMA pair; 41 us with the Psi tile staged in LDS; 38 us once a tile's loads
+//     were consumed BEFORE its stores - the memory counter retires in order, a wait for loads issued behind stores waits for the
+//     stores' acknowledgements), and the time was the SUM of the steps' times: identical waves fall into step - all in the
+//     MFMA phase, then all in the latency-bound phases (every phase twice its instruction time, matrix pipe 41 % busy);
+//   * fixed roles with the LIFT on the producer (one producer per tile, or one per side): the consumer's round is 3 400 cycles
+//     of MFMAs + 500 of stores, the producer's 5 000 - while a wave streams f64 MFMAs on a SIMD, the other waves' vector
+//     instructions wait ~100 cycles each when they depend on one another (power table 1 400 - 2 000 cycles per tile, 700
+//     without the MFMAs), whichever wave has priority (`s_setprio`: 41.5 -> 40.1 us): 40 - 42 us;
+//   * the shipped form - the lift inside the consumer's own instruction stream (a vector instruction of the MFMA wave costs the
+//     stream ~5 cycles): 50 us as first written (the lift's stores and the A-operand reads are integer LDS addresses to hipcc: it
+//     will not move a read above an earlier store, so every MFMA pair waited for a read issued just in front of it), 39 us with
+//     the A operands requested four steps ahead in the source, 38 us with a scheduling barrier per step (the scheduler sank the
+//     table reads to their uses).  Consumer round now 4 300 cycles (3 000 of instructions) + 500 of stores, producer 5 000.
+// What would be next: two producers per slot (table per side) to take the producer off the critical path, and a second look at
+// what the consumer's 1 300 extra cycles per round are.
+#define PM_T 512
 #define PM_NS 4       // tiles (producer / consumer pairs) per workgroup
 #define PM_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define PM_ES 20      // doubles per power-table entry: [side 0: 8 snapshots][side 1: 8][4 of padding]
 #define PM_CS 18      // doubles per Psi-tile column: [side 0: 8][side 1: 8][2 of padding]: 16-byte writes of consecutive columns and the
                       // operand reads of two neighbouring columns both spread over the banks
+// Round 5, last form: the CONSUMER lifts its own next tile between its MFMAs (a vector instruction of the MFMA wave itself costs
+// the stream ~5 cycles; the same instruction from another wave of the SIMD waits ~100 when it depends on its predecessor), one
+// micro-operation of the lift - a 16-byte table read, a pair of multiplies, a 16-byte store - behind each pair of MFMAs, branch
+// free (idle lanes of the last round work on a spare column).  The producer wave of the slot is left with what has no vector
+// work to speak of: raw loads, the power table of the tile after next, the entries that are no components.
 template <int BM, int NK, int NRAW>
 __global__ __launch_bounds__(PM_T, 1) void kp_gram3_prelift_mfma_kernel(const double* __restrict__ alpha, const double* __restrict__ beta, const double* __restrict__ u,
                                                                         int64_t Ns, int64_t ktiles, int nzeta, int D, int nfull, int k_pcs, int N, int G4,
                                                                         const uint32_t* __restrict__ recipes, const double* __restrict__ pcsT,
                                                                         double* __restrict__ out, int rl, int abl) {
-  extern __shared__ double sm[];                        // per slot: tab[nid + 1][PM_ES] | utab[BM + 1][8] | psi[2 buffers][4 NK][PM_CS]
+  extern __shared__ double sm[];                        // per slot: tab[2][nid + 1][PM_ES] | utab[BM + 1][8] | psi[2][4 NK + 1][PM_CS]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int slot = wave & (PM_NS - 1);
   const bool producer = wave >= PM_NS;
-  const int pside = (wave >> 2) - 1;                    // producer of side 0 (alpha; also the inputs and the weights) / side 1 (beta)
   const int nid = nzeta * D;
-  const int tab_d = ((nid + 1) * PM_ES + (BM + 1) * 8 + 1) & ~1;
-  const int psi_d = 4 * NK * PM_CS;
-  double* wsm = sm + slot * (tab_d + 2 * psi_d);
-  double* utab = wsm + (nid + 1) * PM_ES;
-  double* psi = wsm + tab_d;
+  const int tab_d = ((nid + 1) * PM_ES + 1) & ~1;       // one power table
+  const int utab_d = ((BM + 1) * 8 + 1) & ~1;
+  constexpr int PSI_D = (4 * NK + 1) * PM_CS;           // one Psi tile (+ a spare column for idle lanes)
+  double* wsm = sm + slot * (2 * tab_d + utab_d + 2 * PSI_D);
+  double* utab = wsm + 2 * tab_d;
+  double* psi = utab + utab_d;
   const unsigned wbase = (unsigned)(uintptr_t)wsm, pbase = (unsigned)(uintptr_t)psi;   // (low 32 bits of a generic LDS address = the LDS byte address)
+  const unsigned TABB = (unsigned)tab_d * 8u;
+  constexpr unsigned PSIB = (unsigned)PSI_D * 8u;
   const int64_t tstep = (int64_t)gridDim.x * PM_NS;
   const int64_t tile0 = (int64_t)blockIdx.x * PM_NS + slot;
   typedef double dbl2 __attribute__((ext_vector_type(2)));
@@ -103,38 +119,17 @@ __global__ __launch_bounds__(PM_T, 1) void kp_gram3_prelift_mfma_kernel(const do
   typedef const __attribute__((address_space(3))) double* lds_d;
   if (producer) {
     // ================================================ producer ================================================
-    // The consumer's f64 MFMA stream occupies the SIMD's vector issue: left at equal priority a producer's vector instruction
-    // waits ~100 cycles when it depends on the previous one (in-kernel counters: the power table alone 2 000 - 2 700 cycles per
-    // tile).  At raised priority the producer's few instructions go first; each costs the MFMA stream ~5 cycles.
-    if (!(abl & 64)) __builtin_amdgcn_s_setprio(3);
-    // lift items of this lane: columns lane + 64 r of this wave's side; byte offsets of their three factors in the power table
-    constexpr int NIT = (4 * NK + 63) / 64;
-    unsigned foff[NIT][NF3], poff[NIT];
-    bool ion[NIT];
-#pragma unroll
-    for (int r = 0; r < NIT; ++r) {
-      const int c = lane + 64 * r;
-      ion[r] = c < nfull;
-      const uint32_t rc = ion[r] ? recipes[c] : 0xffffffffu;
-#pragma unroll
-      for (int f = 0; f < NF3; ++f) {
-        int id = (int)((rc >> (8 * f)) & 255u);
-        id = id == 255 ? nid : id;
-        foff[r][f] = wbase + (unsigned)(id * PM_ES + pside * 8) * 8u;
-      }
-      poff[r] = pbase + (unsigned)((ion[r] ? c : 0) * PM_CS + pside * 8) * 8u;
-    }
-    if (pside == 0) {
-      for (int e = nfull * PM_CS + lane; e < psi_d; e += 64) { psi[e] = 0.0; psi[psi_d + e] = 0.0; }    // columns beyond the dictionary, both buffers
-      if (lane < 8) utab[BM * 8 + lane] = 1.0;                                                             // ut_0 = 1
+    if (lane < 8) utab[BM * 8 + lane] = 1.0;            // ut_0 = 1
+    for (int e = lane; e < 2 * PM_CS; e += 64) {        // columns beyond the dictionary (zero operands) stay zero: cleared once, both buffers
+      for (int c = nfull; c < 4 * NK; ++c) { if (e < PM_CS) psi[c * PM_CS + e] = 0.0; else psi[PSI_D + c * PM_CS + e - PM_CS] = 0.0; }
     }
     // (snapshot, eighth) roles for loads, tables and the entries that are not components
     const int ls = lane & 7, lq = lane >> 3;
-    const int nsv = nzeta + (pside == 0 ? BM : 0);      // raw columns this wave reads: alpha | u, or beta
+    const int nsv = 2 * nzeta + BM;                     // raw columns of a snapshot: alpha | beta | u
     auto raw_ptr = [&](int sv) -> const double* {
-      return pside ? beta + (int64_t)sv * Ns : sv < nzeta ? alpha + (int64_t)sv * Ns : u + (int64_t)(sv - nzeta) * Ns;
+      return sv < nzeta ? alpha + (int64_t)sv * Ns : sv < 2 * nzeta ? beta + (int64_t)(sv - nzeta) * Ns : u + (int64_t)(sv - 2 * nzeta) * Ns;
     };
-    double raw[NRAW];                                   // NRAW = ceil((nzeta + BM) / 8) (2 or 4)
+    double raw[NRAW];                                   // NRAW = ceil((2 nzeta + BM) / 8) (2 or 4)
     auto load_raw = [&](int64_t tile) {
       const int64_t snap = tile * KT3 + ls;
 #pragma unroll
@@ -143,10 +138,10 @@ __global__ __launch_bounds__(PM_T, 1) void kp_gram3_prelift_mfma_kernel(const do
         raw[m] = (sv < nsv && snap < Ns && tile < ktiles) ? raw_ptr(sv)[snap] : 0.0;
       }
     };
-    // entries that are not components, fixed per lane: zeta (one per raw value), then up to NOTH of this side's [constant |
-    // padding of the last column group] and (side 0) the 12 weight slots; a weight = product of two utab entries (ut = [1, u];
-    // slots beyond the (BM + 1)(BM + 2) / 2 - 1 pairs are zero)
-    constexpr int NOTH = 4;                             // npad + 12 <= 32 entries over 8 lane groups
+    // entries that are not components, fixed per lane: zeta (one per raw value), then up to NOTH of [constant | padding of the
+    // last column group] x 2 sides and the 12 weight slots; a weight = product of two utab entries (ut = [1, u]; slots beyond
+    // the (BM + 1)(BM + 2) / 2 - 1 pairs are zero)
+    constexpr int NOTH = 4;                             // 2 npad + 12 <= 32 entries over 8 lane groups
     const int npad = 4 * G4 - N + 1;                    // constant + padding entries per side
     int oth_ent[NOTH], oth_kind[NOTH];                  // kind 0: nothing, 1: zero, 2: tail mask (the constant), 3: weight
     unsigned oth_a[NOTH], oth_b[NOTH];
@@ -155,11 +150,12 @@ __global__ __launch_bounds__(PM_T, 1) void kp_gram3_prelift_mfma_kernel(const do
     for (int t = 0; t < NOTH; ++t) {
       const int e = lq + 8 * t;
       oth_kind[t] = 0; oth_ent[t] = 0; oth_a[t] = oth_b[t] = ubase;
-      if (e < npad) {
-        oth_ent[t] = pside * 4 * G4 + N - 1 + e;
-        oth_kind[t] = e == 0 ? 2 : 1;
-      } else if (pside == 0 && e < npad + 12) {
-        const int w = e - npad;
+      if (e < 2 * npad) {
+        const int side = e >= npad, j = side ? e - npad : e;
+        oth_ent[t] = side * 4 * G4 + N - 1 + j;
+        oth_kind[t] = j == 0 ? 2 : 1;
+      } else if (e < 2 * npad + 12) {
+        const int w = e - 2 * npad;
         oth_ent[t] = 8 * G4 + w;
         oth_kind[t] = 1;
         int cnt = 0;
@@ -177,21 +173,23 @@ __global__ __launch_bounds__(PM_T, 1) void kp_gram3_prelift_mfma_kernel(const do
       }
     }
     const int o_off = (ls >> 1) * 2 * rl + (ls & 1);
-    // prepare(tile, buffer): steps 1 - 2 with the raw values in xs, the values of step 3 into oth_v; finish(tile): step 3's stores
-    double xs[NRAW], zs[NRAW], oth_v[NOTH];
-    long long sph[4] = {0, 0, 0, 0};
-    auto prepare = [&](int64_t tile, int buf) {
-      long long s0 = (abl & 32) ? clock64() : 0;
+    // table(tile, buffer): power table of both sides + inputs from the raw values just consumed; then the tile's other entries
+    auto table_and_entries = [&](int64_t tile, int buf) {
       const bool valid = tile * KT3 + ls < Ns;
+      double* tb = wsm + buf * tab_d;
+      double xs[NRAW];
+#pragma unroll
+      for (int m = 0; m < NRAW; ++m) {
+        asm volatile("" : "+v"(raw[m]));                // (a use: the compiler's wait for the loads lands here - behind it only
+        xs[m] = raw[m];                                 //  stores and loads that are a round old)
+      }
 #pragma unroll
       for (int m = 0; m < NRAW; ++m) {
         const int sv = lq + 8 * m;
-        zs[m] = xs[m];
-        if (sv < nzeta) {
-          // (no loop over the depth: a dependent multiply per power waits out the consumer's MFMA stream every time - in-kernel
-          // counters had this table at 2 000 - 2 700 cycles per tile)
+        if (sv < 2 * nzeta) {
+          const int side = sv >= nzeta, v = side ? sv - nzeta : sv;
           const double x1 = xs[m], x2 = x1 * x1, x3 = x2 * x1, x4 = x2 * x2;
-          double* t = wsm + (sv * D) * PM_ES + pside * 8 + ls;
+          double* t = tb + (v * D) * PM_ES + side * 8 + ls;
           t[0] = x1;
           if (D > 1) t[PM_ES] = x2;
           if (D > 2) t[2 * PM_ES] = x3;
@@ -204,89 +202,55 @@ __global__ __launch_bounds__(PM_T, 1) void kp_gram3_prelift_mfma_kernel(const do
             }
           }
         } else if (sv < nsv) {
-          utab[(sv - nzeta) * 8 + ls] = xs[m];
+          utab[(sv - 2 * nzeta) * 8 + ls] = xs[m];
         }
       }
-      if (lq == 0) wsm[nid * PM_ES + pside * 8 + ls] = valid ? 1.0 : 0.0;   // "no factor" = the tail mask (the full dictionary's constant column is all of it)
+      if (lq < 2) tb[nid * PM_ES + lq * 8 + ls] = valid ? 1.0 : 0.0;    // "no factor" = the tail mask (the full dictionary's constant column is all of it)
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      const unsigned pb = (unsigned)buf * (unsigned)(psi_d * 8);
-      if (abl & 32) { const long long s1 = clock64(); sph[0] += s1 - s0; s0 = s1; }
-#pragma unroll
-      for (int r = 0; r < NIT; ++r) {
-        if (ion[r] && !(abl & 2)) {
-          dbl2 f0[4], f1[4], f2[4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            f0[q] = *reinterpret_cast<lds_d2>((uintptr_t)(foff[r][0] + 16u * q));
-            f1[q] = *reinterpret_cast<lds_d2>((uintptr_t)(foff[r][1] + 16u * q));
-            f2[q] = *reinterpret_cast<lds_d2>((uintptr_t)(foff[r][2] + 16u * q));
-          }
-#pragma unroll
-          for (int q = 0; q < 4; ++q) *reinterpret_cast<lds_d2w>((uintptr_t)(poff[r] + pb + 16u * q)) = (f0[q] * f1[q]) * f2[q];
-        }
-      }
-      if (abl & 32) { const long long s1 = clock64(); sph[1] += s1 - s0; s0 = s1; }
+      double oth_v[NOTH];
 #pragma unroll
       for (int t = 0; t < NOTH; ++t) {
         const double wa = *reinterpret_cast<lds_d>((uintptr_t)oth_a[t]), wb = *reinterpret_cast<lds_d>((uintptr_t)oth_b[t]);
         oth_v[t] = oth_kind[t] == 3 ? wa * wb : (oth_kind[t] == 2 && valid) ? 1.0 : 0.0;
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (the next prepare's table overwrites what was just read)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (the next call's inputs overwrite utab)
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      if (abl & 32) { const long long s1 = clock64(); sph[2] += s1 - s0; s0 = s1; }
-    };
-    auto finish = [&](int64_t tile) {
       if (tile < ktiles && !(abl & 8)) {
         double* ot = out + tile * (int64_t)(KT3 * rl);
 #pragma unroll
         for (int m = 0; m < NRAW; ++m) {
           const int sv = lq + 8 * m;
-          if (sv < nzeta) ot[o_off + (pside * 4 * G4 + sv) * PES] = zs[m];
+          if (sv < 2 * nzeta) ot[o_off + (sv < nzeta ? sv : 4 * G4 + sv - nzeta) * PES] = xs[m];
         }
 #pragma unroll
         for (int t = 0; t < NOTH; ++t)
           if (oth_kind[t]) ot[o_off + oth_ent[t] * PES] = oth_v[t];
       }
     };
-    // Order of a round: prepare (LDS only) -> take the raw values requested a round ago -> this tile's stores -> request the values
-    // of the round after next.  The memory counter retires in order, and a wait for loads also waits for every store issued in
-    // front of them: in this order both are a whole round old when the wait comes (with the stores last - just issued when the
-    // next round asked for its values - every round ended in a full memory round trip, 1.5 us of a 3.4 us round).
+    // Order inside a call and across rounds: take the raw values requested a round ago -> tables -> this tile's stores -> request
+    // the next tile's values.  The memory counter retires in order and a wait for loads also waits for every store issued in
+    // front of them: in this order both are a whole round old when the wait comes.
     load_raw(tile0);
-#pragma unroll
-    for (int m = 0; m < NRAW; ++m) xs[m] = raw[m];
-    prepare(tile0, 0);
-    finish(tile0);
+    table_and_entries(tile0, 0);
     load_raw(tile0 + tstep);
-#pragma unroll
-    for (int m = 0; m < NRAW; ++m) xs[m] = raw[m];      // (values of the first round's tile: waited for here, once)
+    PM_LDS_BARRIER();                                   // P0: table(0) is there; the consumer lifts tile 0
+    table_and_entries(tile0 + tstep, 1);
     load_raw(tile0 + 2 * tstep);
-    PM_LDS_BARRIER();
+    PM_LDS_BARRIER();                                   // P1: Psi(0) and table(1) are there
     int it = 0;
-    long long tph[4] = {0, 0, 0, 0}, tlast = (abl & 32) ? clock64() : 0;
-#define PM_TICK(i) do { if (abl & 32) { const long long tn = clock64(); tph[i] += tn - tlast; tlast = tn; } } while (0)
-    for (int64_t tb = (int64_t)blockIdx.x * PM_NS; tb < ktiles; tb += tstep, ++it) {      // (uniform trip count over the workgroup)
-      const int64_t tnext = tile0 + (int64_t)(it + 1) * tstep;
-      const bool more = tb + tstep < ktiles;
-      if (more) prepare(tnext, (it + 1) & 1);
-      PM_TICK(0);
-#pragma unroll
-      for (int m = 0; m < NRAW; ++m) {
-        asm volatile("" : "+v"(raw[m]));                // (a use: the compiler's wait for the loads lands here)
-        xs[m] = raw[m];
-      }
-      PM_TICK(1);
-      if (more) finish(tnext);
-      load_raw(tnext + 2 * tstep);
-      PM_TICK(2);
+    long long pph[2] = {0, 0}, plast = (abl & 32) ? clock64() : 0;
+    for (int64_t tb0 = (int64_t)blockIdx.x * PM_NS; tb0 < ktiles; tb0 += tstep, ++it) {   // (uniform trip count over the workgroup)
+      table_and_entries(tile0 + (int64_t)(it + 2) * tstep, it & 1);      // table(it + 2) where table(it) was: lift(it) read it a round ago
+      load_raw(tile0 + (int64_t)(it + 3) * tstep);
+      if (abl & 32) { const long long tn_ = clock64(); pph[0] += tn_ - plast; plast = tn_; }
       PM_LDS_BARRIER();
-      PM_TICK(3);
+      if (abl & 32) { const long long tn_ = clock64(); pph[1] += tn_ - plast; plast = tn_; }
     }
-    if ((abl & 32) && lane == 0 && (blockIdx.x == 0 || blockIdx.x == 200) && slot < 1)
-      printf("producer (%d, %d): prepare %lld (table %lld lift %lld oth %lld)  raw wait %lld  stores+loads %lld  barrier %lld cycles, %d rounds\n", (int)blockIdx.x, slot, tph[0], sph[0], sph[1], sph[2], tph[1], tph[2], tph[3], it);
+    if ((abl & 32) && lane == 0 && (blockIdx.x == 0 || blockIdx.x == 200) && slot < 2)
+      printf("producer (%d, %d): table+entries+loads %lld  barrier %lld cycles, %d rounds\n", (int)blockIdx.x, slot, pph[0], pph[1], it);
   } else {
     // ================================================ consumer ================================================
     const int li = lane & 3, blk = (lane >> 2) & 3, kq = lane >> 4;
@@ -298,33 +262,89 @@ __global__ __launch_bounds__(PM_T, 1) void kp_gram3_prelift_mfma_kernel(const do
       b0[kk] = on ? pcsT[(size_t)c * 32 + 4 * blk + li] : 0.0;
       b1[kk] = on ? pcsT[(size_t)c * 32 + 16 + 4 * blk + li] : 0.0;
     }
+    // lift items of this lane: item = lane + 64 r -> (column, side); byte offsets of its three factors in power table 0 and of its
+    // Psi column in buffer 0 (idle lanes of the last round: the entry of ones, the spare column)
+    constexpr int NIT = (2 * 4 * NK + 63) / 64;
+    // (one offset register per (round, factor, TABLE): the table's size is a run-time number, and an address add in front of
+    // every table read is a vector instruction in the MFMA stream)
+    unsigned foff[2][NIT][NF3], poff[NIT];
+#pragma unroll
+    for (int r = 0; r < NIT; ++r) {
+      const int item = lane + 64 * r;
+      const int side = item >= nfull, c = side ? item - nfull : item;
+      const bool on = item < 2 * nfull;
+      const uint32_t rc = on ? recipes[c] : 0xffffffffu;
+#pragma unroll
+      for (int f = 0; f < NF3; ++f) {
+        int id = (int)((rc >> (8 * f)) & 255u);
+        id = id == 255 ? nid : id;
+        foff[0][r][f] = wbase + (unsigned)(id * PM_ES + (on ? side : 0) * 8) * 8u;
+        foff[1][r][f] = foff[0][r][f] + TABB;
+      }
+      poff[r] = pbase + (unsigned)((on ? c : 4 * NK) * PM_CS + (on ? side : 0) * 8) * 8u;
+    }
     const unsigned abase0 = pbase + (unsigned)(kq * PM_CS + li) * 8u;                   // A operand: column 4 kk + kq, snapshot 4 g + li
     const int pc = 4 * blk + li;
     const int d_off = (kq >> 1) * 2 * rl + (kq & 1) + (nzeta + pc) * PES;             // + g * 4 rl + side * 4 G4 PES (+ 16 PES)
-    PM_LDS_BARRIER();                                   // tile 0 is prepared
-    int it = 0;
-    long long tph[4] = {0, 0, 0, 0}, tlast = (abl & 32) ? clock64() : 0;
-    for (int64_t tb = (int64_t)blockIdx.x * PM_NS; tb < ktiles; tb += tstep, ++it) {
-      const int64_t tile = tile0 + (int64_t)it * tstep;
-      const unsigned abase = abase0 + (unsigned)(it & 1) * (unsigned)(psi_d * 8);
-      double acc[2][2][2];
-#pragma unroll
-      for (int side = 0; side < 2; ++side) {
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-          double acc0 = 0.0, acc1 = 0.0;
-          if (!(abl & 1))
-#pragma unroll
-          for (int kk = 0; kk < NK; ++kk) {
-            const double av = *reinterpret_cast<lds_d>((uintptr_t)(abase + (unsigned)(kk * 4 * PM_CS * 8 + side * 64 + g * 32)));
-            acc0 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, b0[kk], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, b1[kk], acc1, 0, 0, 0);
-          }
-          acc[side][g][0] = acc0;
-          acc[side][g][1] = acc1;
+    dbl2 f0[4], f1[4], f2[4];
+    long long tph[3] = {0, 0, 0}, tlast = 0;
+    // one micro-operation of the lift of the NEXT tile (table tn, Psi buffer pn): 24 per round of 64 items -
+    // 12 reads, 4 + 4 pairs of multiplies, 4 stores
+    auto lift_op = [&](auto slot_c, auto tn_c, auto pn_c) __attribute__((always_inline)) {
+      constexpr int S = decltype(slot_c)::value;
+      constexpr int TN = decltype(tn_c)::value;         // table of the next tile (0 / 1)
+      constexpr unsigned pn = decltype(pn_c)::value;    // byte offset of its Psi buffer
+      constexpr int r = S / 24, o = S % 24;
+      if constexpr (r < NIT) {
+        if constexpr (o < 12) {
+          constexpr int f = o / 4, q = o % 4;
+          const dbl2 v = *reinterpret_cast<lds_d2>((uintptr_t)(foff[TN][r][f] + 16u * q));
+          if constexpr (f == 0) f0[q] = v; else if constexpr (f == 1) f1[q] = v; else f2[q] = v;
+        } else if constexpr (o < 16) {
+          f0[o - 12] = f0[o - 12] * f1[o - 12];
+        } else if constexpr (o < 20) {
+          f0[o - 16] = f0[o - 16] * f2[o - 16];
+        } else {
+          *reinterpret_cast<lds_d2w>((uintptr_t)(poff[r] + pn + 16u * (o - 20))) = f0[o - 20];
         }
       }
-      PM_TICK(0);
+    };
+    PM_LDS_BARRIER();                                   // P0: table(0) is there
+    {                                                   // lift of tile 0, not interleaved with anything
+      [&]<int... S>(std::integer_sequence<int, S...>) {
+        (lift_op(std::integral_constant<int, S>{}, std::integral_constant<int, 0>{}, std::integral_constant<unsigned, 0u>{}), ...);
+      }(std::make_integer_sequence<int, 24 * NIT>{});
+    }
+    PM_LDS_BARRIER();                                   // P1: Psi(0) and table(1) are there
+    if (abl & 32) tlast = clock64();
+    // one round with the parity of the CURRENT tile as a constant (buffer offsets are immediates)
+    auto round = [&](auto par_c, int64_t tile) __attribute__((always_inline)) {
+      constexpr unsigned P = decltype(par_c)::value;
+      const unsigned abase = abase0 + P * PSIB;
+      using TNc = std::integral_constant<int, 1 - (int)P>;                            // next tile: the other table,
+      using PNc = std::integral_constant<unsigned, (1u - P) * PSIB>;                  // the other Psi buffer
+      double acc[2][2][2];
+      // The A operands are requested PF steps ahead IN THE SOURCE: the lift's stores go to the other Psi buffer, but both are
+      // integer LDS addresses to the compiler - it will not move an operand read above an earlier store, so left to itself every
+      // MFMA pair waited for a read issued just in front of it (measured: 50 us).
+      constexpr int PF = 4, NJ = 4 * NK;
+      auto a_addr = [&](int j) -> unsigned { return abase + (unsigned)((j % NK) * 4 * PM_CS * 8 + (j / (2 * NK)) * 64 + ((j / NK) % 2) * 32); };
+      double av[PF];
+#pragma unroll
+      for (int j = 0; j < PF; ++j) av[j] = *reinterpret_cast<lds_d>((uintptr_t)a_addr(j));
+      [&]<int... J>(std::integer_sequence<int, J...>) {
+        ([&] {
+          constexpr int side = J / (2 * NK), g = (J / NK) % 2, kk = J % NK;
+          if constexpr (kk == 0) { acc[side][g][0] = 0.0; acc[side][g][1] = 0.0; }
+          const double a_now = av[J % PF];
+          if constexpr (J + PF < NJ) av[J % PF] = *reinterpret_cast<lds_d>((uintptr_t)a_addr(J + PF));
+          acc[side][g][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a_now, b0[kk], acc[side][g][0], 0, 0, 0);
+          acc[side][g][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a_now, b1[kk], acc[side][g][1], 0, 0, 0);
+          lift_op(std::integral_constant<int, J>{}, TNc{}, PNc{});
+          __builtin_amdgcn_sched_barrier(0);            // (the scheduler sinks the table reads to their uses otherwise: each then waits out its LDS latency)
+        }(), ...);
+      }(std::make_integer_sequence<int, 4 * NK>{});
+      if (abl & 32) { const long long tn_ = clock64(); tph[0] += tn_ - tlast; tlast = tn_; }
       if (tile < ktiles && !(abl & 4)) {
         double* ot = out + tile * (int64_t)(KT3 * rl);
 #pragma unroll
@@ -336,13 +356,18 @@ __global__ __launch_bounds__(PM_T, 1) void kp_gram3_prelift_mfma_kernel(const do
             if (pc + 16 < k_pcs) og[d_off + 16 * PES] = acc[side][g][1];
           }
       }
-      PM_TICK(1);
+      if (abl & 32) { const long long tn_ = clock64(); tph[1] += tn_ - tlast; tlast = tn_; }
       PM_LDS_BARRIER();
-      PM_TICK(2);
+      if (abl & 32) { const long long tn_ = clock64(); tph[2] += tn_ - tlast; tlast = tn_; }
+    };
+    int it = 0;
+    for (int64_t tb0 = (int64_t)blockIdx.x * PM_NS; tb0 < ktiles; tb0 += tstep, ++it) {
+      const int64_t tile = tile0 + (int64_t)it * tstep;
+      if (it & 1) round(std::integral_constant<unsigned, 1>{}, tile);
+      else round(std::integral_constant<unsigned, 0>{}, tile);
     }
     if ((abl & 32) && lane == 0 && (blockIdx.x == 0 || blockIdx.x == 200) && slot < 2)
-      printf("consumer (%d, %d): mfma %lld  stores %lld  barrier %lld cycles, %d rounds\n", (int)blockIdx.x, slot, tph[0], tph[1], tph[2], it);
-#undef PM_TICK
+      printf("consumer (%d, %d): mfma+lift %lld  stores %lld  barrier %lld cycles, %d rounds\n", (int)blockIdx.x, slot, tph[0], tph[1], tph[2], it);
   }
 }
 
@@ -354,7 +379,7 @@ hipError_t kp_gram3_pcs_transpose_launch(const double* pcs, int nfull, int k, do
 template <int BM, int NK, int NRAW>
 static hipError_t prelift_mfma_launch(const double* alpha, const double* beta, const double* u, int64_t Ns, int64_t ktiles, int nzeta, int D, int nfull, int k_pcs, int N,
                                       int G4, const uint32_t* recipes, const double* pcsT, double* out, int rl, hipStream_t st) {
-  const size_t lds = (size_t)PM_NS * ((size_t)((((nzeta * D + 1) * PM_ES + (BM + 1) * 8 + 1) & ~1) + 2 * 4 * NK * PM_CS)) * 8;
+  const size_t lds = (size_t)PM_NS * ((size_t)(2 * ((((nzeta * D + 1) * PM_ES) + 1) & ~1) + ((((BM + 1) * 8) + 1) & ~1) + 2 * (4 * NK + 1) * PM_CS)) * 8;
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   static KpLdsCache cache;
   hipError_t e = kp_ensure_lds(cache, (const void*)kp_gram3_prelift_mfma_kernel<BM, NK, NRAW>, lds);
@@ -371,7 +396,7 @@ static hipError_t prelift_mfma_launch(const double* alpha, const double* beta, c
 template <int BM>
 static hipError_t prelift_mfma_launch_nk(int nk, const double* alpha, const double* beta, const double* u, int64_t Ns, int64_t ktiles, int nzeta, int D, int nfull, int k_pcs,
                                          int N, int G4, const uint32_t* recipes, const double* pcsT, double* out, int rl, hipStream_t st) {
-  const bool few = nzeta + BM <= 16;
+  const bool few = 2 * nzeta + BM <= 16;
 #define KP_PM(NKT) (few ? prelift_mfma_launch<BM, NKT, 2>(alpha, beta, u, Ns, ktiles, nzeta, D, nfull, k_pcs, N, G4, recipes, pcsT, out, rl, st) \
                         : prelift_mfma_launch<BM, NKT, 4>(alpha, beta, u, Ns, ktiles, nzeta, D, nfull, k_pcs, N, G4, recipes, pcsT, out, rl, st))
   if (nk <= 8) return KP_PM(8);
@@ -386,7 +411,7 @@ hipError_t kp_gram3_prelift_launch(int BM, const double* alpha, const double* be
                                    int N, int G4, const uint32_t* recipes, const double* pcsT, double* out, int rl, hipStream_t st) {
   const int nk = (nfull + 3) / 4;
   const int64_t ktiles = Ns_pad / KT3;
-  if (nk > 24 || nzeta + BM > 32 || (4 * G4 - N + 1) + 12 > 32) return hipErrorInvalidValue;
+  if (nk > 24 || 2 * nzeta + BM > 32 || 2 * (4 * G4 - N + 1) + 12 > 32) return hipErrorInvalidValue;
   if (BM == 1) return prelift_mfma_launch_nk<1>(nk, alpha, beta, u, Ns, ktiles, nzeta, D, nfull, k_pcs, N, G4, recipes, pcsT, out, rl, st);
   if (BM == 2) return prelift_mfma_launch_nk<2>(nk, alpha, beta, u, Ns, ktiles, nzeta, D, nfull, k_pcs, N, G4, recipes, pcsT, out, rl, st);
   return prelift_mfma_launch_nk<3>(nk, alpha, beta, u, Ns, ktiles, nzeta, D, nfull, k_pcs, N, G4, recipes, pcsT, out, rl, st);
