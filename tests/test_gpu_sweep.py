@@ -490,3 +490,41 @@ def test_trajectory_object_in_three_steps_equals_the_one_call_upload(ctx):
     a = sweep.rand_models_sweep_batched(systems, ctx, degrees=degrees)
     b = sweep.rand_models_sweep_arrays(Y, U, k, Yv, Uv, ctx=ctx, degrees=degrees)
     assert all(np.array_equal(a[mt], b[mt], equal_nan=True) for mt in degrees)
+
+
+def test_config5_at_its_full_size_through_property_checks(ctx):
+    """BASELINE configs[4] at its shape - evaluate_rand_models.m on 1024 DISTINCT generated systems (the population bench.py
+    times), 23 fits + validation rollouts each - through size-independent properties: the nested form (one data pass per model
+    type) equals the flat form (one kp_sweep_eval per degree) on every system; the same stacked trials dealt over the workers of a
+    kp_multi object (the device listed three times: ragged chunks of 342 / 341 / 341 systems) give the single context's tables
+    bit for bit; no status word is set; and the statistics of evaluate_rand_models.m:149-171 are finite."""
+    import bench
+    from koopman_realizations_amd.multi import Multi
+    chunks = bench.gen_rand_systems(list(range(1024 // bench.RAND_CHUNK)))
+    systems = [s_ for c in sorted(chunks) for s_ in chunks[c]]
+    assert len(systems) == 1024
+    degrees = dict(sweep.MAX_DEGREE)
+    nested = sweep.rand_models_sweep_batched(systems, ctx, degrees=degrees)
+    flat = sweep.rand_models_sweep_batched(systems, ctx, degrees=degrees, nested=False)
+    for mt in nested:
+        assert nested[mt].shape == (degrees[mt], 1024)
+        ok = np.isfinite(flat[mt]) & np.isfinite(nested[mt])
+        assert ok.mean() > 0.99
+        # (the flat form solves the normal equations in the monomial basis, the nested one in the Chebyshev basis: cond up to 3e5 at
+        # linear degree 13, SURVEY appendix B)
+        assert np.all(np.abs(nested[mt][ok] - flat[mt][ok]) <= 1e-3 * np.maximum(1.0, np.abs(flat[mt][ok]))), mt
+    mean, _ = sweep.sweep_statistics(nested["linear"])
+    assert np.isfinite(mean).all()
+    Y, U, k, Yv, Uv = sweep._stack_raw(systems)
+    mg = Multi([0, 0, 0])
+    try:
+        tr = mg.traj_upload(Y, U, k, Yv, Uv)
+        for mt, D in degrees.items():
+            nv = 1 + (mt == "nonlinear")
+            e = kra.poly_exponent_table(nv, D)[nv:]
+            err, st = tr.sweep_eval_nested((mt, 1, 1, [("poly", e)], None), D, 4.0 if mt == "nonlinear" else np.inf)
+            assert (st == 0).all()
+            assert np.array_equal(err[:, :, 0], nested[mt], equal_nan=True), mt
+        tr.close()
+    finally:
+        mg.close()
