@@ -168,3 +168,29 @@ def test_mirror_with_a_delay_embedded_state_and_dim_red(ctx, golden):
     s = np.abs(Px.T @ Px).max()
     assert np.abs(G - Px.T @ Px).max() <= 1e-11 * s and np.abs(C - Px.T @ Py).max() <= 1e-11 * s
     snaps.close()
+
+
+def test_lasso_on_a_wide_dictionary_meets_the_optimality_conditions(ctx):
+    """solve_KoopmanQP (Ksysid.m:1095-1176) on the 728-function fourier dictionary (W = 738): the L1-constrained fit through the
+    batched projected-gradient solver (the homotopy serves W <= 512).  Checked by the conditions of the convex QP: budget met,
+    |G K - C| equal to one multiplier theta on the support and below it elsewhere."""
+    p = synth_pairs(4000, 6, 3, seed=5)
+    dic = ko.build_dictionary("linear", 6, 3, ["fourier"], [1])
+    b = make_basis(ctx, dic)
+    s = kra.Snapshots(ctx, p["alpha"], p["beta"], p["u"])
+    Kls = kra.fit(ctx, b, s)[0]
+    G, C = kra.fit_gram(ctx, b, s)
+    l1 = np.abs(Kls).sum()
+    for frac in (0.5, 0.1):
+        t = frac * l1 / b.N
+        K = kra.fit(ctx, b, s, lasso=[t])[0]
+        assert abs(np.abs(K).sum() - t * b.N) <= 1e-9 * t * b.N
+        g = G @ K - C
+        supp = K != 0
+        theta = np.abs(g[supp]).mean()
+        assert np.abs(np.abs(g[supp]) - theta).max() <= 1e-5 * theta
+        assert np.abs(g[~supp]).max() <= theta * (1 + 1e-6)
+        assert (np.sign(K[supp]) == -np.sign(g[supp])).all()
+    # an inactive budget returns the least-squares solution
+    K = kra.fit(ctx, b, s, lasso=[2.0 * l1 / b.N])[0]
+    assert np.array_equal(K, Kls)
