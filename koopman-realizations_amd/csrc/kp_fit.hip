@@ -633,6 +633,19 @@ static int wide_block() {               // (read per call: the tests vary it)
 
 #include "kp_tn_gemm.h"
 
+// one direction of the block substitution against a diagonal block (b x b at Akk, leading dimension n) for `nrhs` right-hand sides
+// at X (leading dimension n): 4 right-hand sides per workgroup (the shortest serial chain) while that gives at most ~2 rounds of
+// workgroups, 16 beyond (every workgroup reads the whole block)
+static hipError_t wide_trsm(hipStream_t st, const double* Akk, const double* Dinv_k, int b, int nrhs, double* X, int n, int dirs) {
+  if (nrhs <= 4096)
+    hipLaunchKernelGGL((kp_trsm2_kernel<1>), dim3(nrhs / 4, 1), dim3(256), (size_t)b * 4 * 8, st, Akk, Dinv_k, b, nrhs, X, (double*)nullptr, 0, 0, (int64_t)n, (int64_t)n,
+                       dirs, (const int*)nullptr);
+  else
+    hipLaunchKernelGGL((kp_trsm2_kernel<4>), dim3(nrhs / 16, 1), dim3(256), (size_t)b * 16 * 8, st, Akk, Dinv_k, b, nrhs, X, (double*)nullptr, 0, 0, (int64_t)n, (int64_t)n,
+                       dirs, (const int*)nullptr);
+  return hipGetLastError();
+}
+
 // Cp := (L L')^-1 Cp for a factor as chol_solve_wide leaves it (L below, L' above the diagonal, Dinv = inverses of the 16 x 16
 // diagonal blocks): per block a forward (then backward) substitution against the diagonal block and one TN product that takes
 // the block's solution out of all remaining rows.
@@ -643,17 +656,13 @@ static int wide_substitute(kp_ctx* ctx, double* Gp, double* Cp, double* Dinv, in
   // forward: L Y = C, block rows ascending; the block's Y leaves all later rows by one product
   for (int k0 = 0; k0 < n; k0 += bs) {
     const int b = std::min(bs, n - k0), R = n - k0 - b;
-    hipLaunchKernelGGL((kp_trsm2_kernel<4>), dim3(ncp / 16, 1), dim3(256), (size_t)b * 16 * 8, st, Gp + (size_t)k0 * n + k0, Dinv + (size_t)(k0 / 16) * 256, b, ncp,
-                       Cp + k0, (double*)nullptr, 0, 0, (int64_t)n, (int64_t)n, 1, (const int*)nullptr);
-    KP_HIP(ctx, hipGetLastError());
+    KP_HIP(ctx, wide_trsm(st, Gp + (size_t)k0 * n + k0, Dinv + (size_t)(k0 / 16) * 256, b, ncp, Cp + k0, n, 1));
     if (R > 0) KP_HIP(ctx, kp_tn_gemm(st, Gp + (size_t)(k0 + b) * n + k0, n, Cp + k0, n, R, ncp, b, Cp + k0 + b, n, -1.0, 1.0, 0, 1, nullptr));
   }
   // backward: L' K = Y, block rows descending; K_k leaves the rows above through L (the mirrored lower triangle)
   for (int k0 = (n - 1) / bs * bs; k0 >= 0; k0 -= bs) {
     const int b = std::min(bs, n - k0);
-    hipLaunchKernelGGL((kp_trsm2_kernel<4>), dim3(ncp / 16, 1), dim3(256), (size_t)b * 16 * 8, st, Gp + (size_t)k0 * n + k0, Dinv + (size_t)(k0 / 16) * 256, b, ncp,
-                       Cp + k0, (double*)nullptr, 0, 0, (int64_t)n, (int64_t)n, 2, (const int*)nullptr);
-    KP_HIP(ctx, hipGetLastError());
+    KP_HIP(ctx, wide_trsm(st, Gp + (size_t)k0 * n + k0, Dinv + (size_t)(k0 / 16) * 256, b, ncp, Cp + k0, n, 2));
     if (k0 > 0) KP_HIP(ctx, kp_tn_gemm(st, Gp + k0, n, Cp + k0, n, k0, ncp, b, Cp, n, -1.0, 1.0, 0, 1, nullptr));
   }
   return KP_OK;
@@ -685,9 +694,7 @@ static int chol_solve_wide(kp_ctx* ctx, double* Gp, double* Cp, double* Dinv, in
     hipLaunchKernelGGL(kp_wide_diag_kernel, dim3((b * b + 255) / 256), dim3(256), 0, st, Gp, n, k0, b, D, 1);
     KP_HIP(ctx, hipGetLastError());
     if (R > 0) {
-      hipLaunchKernelGGL((kp_trsm2_kernel<4>), dim3(R / 16, 1), dim3(256), (size_t)b * 16 * 8, st, Akk, Dinv + (size_t)(k0 / 16) * 256, b, R, A12, (double*)nullptr, 0, 0,
-                         (int64_t)n, (int64_t)n, 1, (const int*)nullptr);
-      KP_HIP(ctx, hipGetLastError());
+      KP_HIP(ctx, wide_trsm(st, Akk, Dinv + (size_t)(k0 / 16) * 256, b, R, A12, n, 1));
       KP_HIP(ctx, kp_tn_gemm(st, A12, n, A12, n, R, R, b, Gp + (size_t)(k0 + b) * n + k0 + b, n, -1.0, 1.0, 1, 1, nullptr));
     }
   }
