@@ -4,6 +4,8 @@
 #include <type_traits>
 #include <utility>
 
+#pragma clang diagnostic ignored "-Wc++20-extensions"      // lambdas with explicit template parameters (the hand-unrolled MFMA / lift schedule)
+
 #include "kp_gram3_args.h"
 
 #define KT3 8     // snapshots per tile of kp_gram3_kernel
