@@ -18,6 +18,7 @@
 // factor of the selected r x r system, so the solve needs no second factorisation: gather, kp_factor_substitute_dev.
 // Any width the library fits (the panel shrinks with W: 32 pivots per block up to W = 560, 6 at W = 2 940).
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 #include <vector>
 
@@ -184,16 +185,18 @@ __global__ __launch_bounds__(NT) void kp_pivchol_panel_kernel(const double* __re
 //    entry), all independent, and run under the pivot column's global load;
 //  * the cross-wave stage of the pivot search is a second DPP reduction - every 16-lane row holds all NT / 64 wave
 //    candidates (lane l reads candidate l mod NW) - instead of a serial scan over them;
-//  * the pivot column comes from the trailing matrix in memory, which the update kernels of other XCDs wrote: ~1 us from the
-//    fabric-side cache on the chain of every step, the largest single piece left.  (Fetching the columns of the runner-up
-//    candidates ahead would hide it - the runner-up of step j is the pivot of step j + 1 in 192 of 251 steps on the arm
-//    data's W = 336 Gram, one of the next two in 237 - but not from plain C++: hipcc waits for every outstanding load before
-//    the first use of any and before it reuses a destination register, and it copies the destination of a hand-issued load
-//    before the data has landed.  It needs LDS-DMA loads with hand-counted waits; not built.)
+//  * the pivot column comes from the trailing matrix in memory (one coalesced load, issued as soon as the pivot is known).
+// What a step costs (0.93 us at W = 336: 34 us per launch of 32): NOT that load - a timing-only build without it
+// (KP_PIV_ABL=1) takes the same time - but the step's own dependent instruction chain: two DPP reductions with their
+// v_readlane / ballot tails, 1 / sqrt with two Newton steps, the products, at ~7 cycles per dependent vector instruction
+// (tools/clock_probe).  (Fetching the columns of the runner-up candidates ahead was built on the assumption that the load
+// bounds the step - the runner-up of step j is the pivot of step j + 1 in 192 of 251 steps on the arm data's W = 336 Gram -
+// and taught two things about hipcc: it waits for EVERY outstanding load before the first use of any and before it reuses a
+// destination register, and it copies the destination of a hand-issued load before the data has landed.)
 template <int NT>
 __global__ __launch_bounds__(NT) void kp_pivchol_panel32_kernel(const double* __restrict__ A, int W, int k0, int nb, double rel_tol, double* __restrict__ L,
                                                                 double* __restrict__ dg, int* __restrict__ ipos, int* __restrict__ perm,
-                                                                PivState* __restrict__ stt) {
+                                                                PivState* __restrict__ stt, int abl) {
   extern __shared__ double Pn[];         // [32][W]
   __shared__ double red_v[2][NT / 64];
   __shared__ int red_i[2][NT / 64];
@@ -214,7 +217,9 @@ __global__ __launch_bounds__(NT) void kp_pivchol_panel32_kernel(const double* __
     int vi = tid;
     pc_wave_argmax(v, vi);
     if ((tid & 63) == 0) { red_v[j & 1][tid >> 6] = v; red_i[j & 1][tid >> 6] = vi; }
-    __syncthreads();
+    // LDS-only barrier: __syncthreads() also drains the memory counter - every step would wait for the acknowledgement of the
+    // previous step's stores of L (nobody in this kernel reads them back)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     // best of the waves' candidates: a DPP reduction inside the 16-lane rows (each holds all of them), the first lane that
     // holds the maximum names the row (lowest wave = lowest index on ties)
     constexpr int NW = NT / 64;
@@ -228,7 +233,7 @@ __global__ __launch_bounds__(NT) void kp_pivchol_panel32_kernel(const double* __
     const int p = __builtin_amdgcn_readlane(ci, __ffsll((long long)mk) - 1);
     if (k == 0) d1 = pv;
     if (!(pv > rel_tol * d1) || !(pv > 0.0)) { stop = 1; return true; }
-    const double a = A[irow + (size_t)p * W];              // in flight across the products below
+    const double a = (abl & 1) ? (tid == p ? pv : 0.0) : A[irow + (size_t)p * W];   // in flight across the products below (abl: timing only)
     double rinv = __builtin_amdgcn_rsq(pv);
     rinv = rinv * (1.5 - 0.5 * pv * rinv * rinv);
     rinv = rinv * (1.5 - 0.5 * pv * rinv * rinv);
@@ -365,12 +370,13 @@ int kp_pivchol_solve_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, 
               : rpt == 1 ? kp_ensure_lds(lds1024, (const void*)kp_pivchol_panel_kernel<1024, 1>, lds)
                          : kp_ensure_lds(lds4096, (const void*)kp_pivchol_panel_kernel<1024, PC_RPT_MAX>, lds));
   const dim3 ugrid((W + 63) / 64, (W + 63) / 64);
+  static const int piv_abl = getenv("KP_PIV_ABL") ? atoi(getenv("KP_PIV_ABL")) : 0;      // timing-only ablations (bit 0: no pivot-column load)
   for (int k0 = 0; k0 < W; k0 += nb) {
     const int nbk = std::min(nb, W - k0);
     if (fast32 && nt == 512)
-      hipLaunchKernelGGL((kp_pivchol_panel32_kernel<512>), dim3(1), dim3(512), lds, s, (const double*)A, W, k0, nbk, rel_tol, L, dg, ipos, perm, stt);
+      hipLaunchKernelGGL((kp_pivchol_panel32_kernel<512>), dim3(1), dim3(512), lds, s, (const double*)A, W, k0, nbk, rel_tol, L, dg, ipos, perm, stt, piv_abl);
     else if (fast32)
-      hipLaunchKernelGGL((kp_pivchol_panel32_kernel<1024>), dim3(1), dim3(1024), lds, s, (const double*)A, W, k0, nbk, rel_tol, L, dg, ipos, perm, stt);
+      hipLaunchKernelGGL((kp_pivchol_panel32_kernel<1024>), dim3(1), dim3(1024), lds, s, (const double*)A, W, k0, nbk, rel_tol, L, dg, ipos, perm, stt, piv_abl);
     else if (nt == 512)
       hipLaunchKernelGGL((kp_pivchol_panel_kernel<512, 1>), dim3(1), dim3(512), lds, s, (const double*)A, W, k0, nbk, rel_tol, L, dg, ipos, perm, stt);
     else if (rpt == 1)
