@@ -14,6 +14,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #define TNG_KB 16
 #define TNG_RS 20
@@ -226,6 +227,13 @@ static inline int tng_pick_splits(int M, int N, int K, int tri, int slots) {
   return ns < 1 ? 1 : ns;
 }
 
+// Columns per workgroup of the 128-row form: 96 (192 MFMAs per wave between two barriers instead of 128: the bilinear W = 2 940
+// Gram pass 70.5 -> 64.4 ms per 1e5 pairs) when that still fills the chip's 512 workgroup slots, else 64.  KP_TNG_RB=4 keeps 64.
+static inline int tng_tile_cols(int M, int N, int nsplit, int tri) {
+  static const int wide_cols = [] { const char* e = getenv("KP_TNG_RB"); return e ? atoi(e) : 6; }();
+  return (wide_cols == 6 && (int64_t)((M + 127) / 128) * ((N + 95) / 96) * (nsplit > 1 ? nsplit : 1) / (tri ? 2 : 1) >= 512) ? 96 : 64;
+}
+
 // P (or nullptr): room for nsplit * M * N doubles when nsplit > 1.
 static inline hipError_t kp_tn_gemm(hipStream_t st, const double* A, int64_t lda, const double* B, int64_t ldb, int M, int N, int K, double* C, int64_t ldc,
                                     double alpha, double beta, int tri, int nsplit, double* P) {
@@ -245,5 +253,6 @@ static inline hipError_t kp_tn_gemm(hipStream_t st, const double* A, int64_t lda
   g.tri = tri;
   g.alpha = alpha; g.beta = beta;
   if (M <= 64) return tng_launch_cfg<4, 4>(st, g);
+  if (tng_tile_cols(M, N, g.nsplit, tri) == 96) return tng_launch_cfg<8, 6>(st, g);
   return tng_launch_cfg<8, 4>(st, g);
 }

@@ -64,11 +64,14 @@ int kp_gram_wide_launch(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* 
   KP_HIP(ctx, hipEventRecord(ctx->ev1, st));
   KP_HIP(ctx, hipEventRecord(ctx->evp[2], st));
   ctx->gram_flops_per_pair = (double)W * (W + 1) + 2.0 * W * W;
-  // executed on the matrix pipe per pair: the 128 x 64 tiles that meet the upper triangle of G, and all of C
-  const double tm = 128.0, tn = 64.0, nrt = std::ceil(W / tm), nct = std::ceil(W / tn);
-  double gt = 0;
-  for (int r = 0; r < (int)nrt; ++r)
-    for (int c = 0; c < (int)nct; ++c) gt += (r * tm <= c * tn + tn - 1) ? 1 : 0;
-  ctx->timers[10] = 2.0 * tm * tn * (gt + nrt * nct);
+  // executed on the matrix pipe per pair: the output tiles (128 rows x 64 or 96 columns) that meet the upper triangle of G, and all of C
+  auto tiles = [&](int tri, int nsplit) {
+    const double tm = 128.0, tn = (double)tng_tile_cols(W, W, nsplit, tri), nrt = std::ceil(W / tm), nct = std::ceil(W / tn);
+    double cnt = 0;
+    for (int r = 0; r < (int)nrt; ++r)
+      for (int c = 0; c < (int)nct; ++c) cnt += (!tri || r * tm <= c * tn + tn - 1) ? 1 : 0;
+    return 2.0 * tm * tn * cnt;
+  };
+  ctx->timers[10] = tiles(1, nsplit_g) + tiles(0, nsplit_c);
   return KP_OK;
 }
