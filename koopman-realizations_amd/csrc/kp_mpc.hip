@@ -34,6 +34,7 @@ struct kp_mpc {
   double* B = nullptr;     // N x mb
   double* P = nullptr;     // (Np+1) x [nproj x N]  (P_k column-major nproj x N)
   double* S0 = nullptr;    // linear model: Np x [nproj x m]
+  double* PB = nullptr;    // bilinear model: [Np * m * nproj][N]  rows of P_k B_i (S_k = P_k Beta(z) = these rows times z)
   double* r = nullptr;     // m
   double* Aq = nullptr;    // nrows x nvar column-major (constant: L = F, tack rows)
   double* bq0 = nullptr;   // nrows (c and zeros for the tack rows)
@@ -941,7 +942,8 @@ extern "C" int kp_qp_solve(kp_ctx* ctx, const double* H, const double* f, const 
 // linear model: S_k = P_k B.
 __global__ __launch_bounds__(256) void kp_mpc_setup_kernel(const double* __restrict__ A, const double* __restrict__ B,
                                                            const double* __restrict__ proj, int N, int m, int Np, int nproj,
-                                                           int linear, double* __restrict__ P, double* __restrict__ S0) {
+                                                           int linear, double* __restrict__ P, double* __restrict__ S0,
+                                                           double* __restrict__ PB) {
   const int tid = threadIdx.x;
   for (int e = tid; e < nproj * N; e += 256) P[e] = proj[e];
   __syncthreads();
@@ -964,6 +966,19 @@ __global__ __launch_bounds__(256) void kp_mpc_setup_kernel(const double* __restr
       for (int j = 0; j < N; ++j) s += Pk[p + j * nproj] * B[j + (size_t)a * N];
       S0[e] = s;
     }
+  } else {
+    // bilinear: S_k = P_k Beta(z) with Beta(z) = [B_1 z ... B_m z] (Kmpc.m:578-585), i.e. entry (p, i) of S_k is row p of
+    // P_k B_i times z.  Those rows are constants of the model: Np m nproj N doubles (40 KB for the bench's N = 84) instead of
+    // the N x N m of B (169 KB) that a step would otherwise stream through its one CU to form Beta(z) first.
+    for (int e = tid; e < Np * nproj * m * N; e += 256) {
+      const int j = e % N, row = e / N;
+      const int k = row / (nproj * m), rem = row % (nproj * m), p = rem % nproj, i = rem / nproj;
+      const double* Pk = P + (size_t)k * nproj * N;
+      const double* Bi = B + (size_t)i * N * N + (size_t)j * N;
+      double s = 0.0;
+      for (int c = 0; c < N; ++c) s += Pk[p + c * nproj] * Bi[c];
+      PB[e] = s;
+    }
   }
 }
 
@@ -972,7 +987,7 @@ struct MpcArgs {
   BasisDev basis;   // used when zeta != nullptr (fused lift)
   int model_type, N, m, Np, nproj, nvar, nrows, iters, has_basis;
   double q_run, q_term;
-  const double *A, *B, *P, *S0, *r, *Aq, *bq0, *Anorm;
+  const double *A, *B, *P, *S0, *PB, *r, *Aq, *bq0, *Anorm;
   EllMat ell;
   int* warm;            // [1 + nvar] active set of the previous single-problem step (nullptr: cold start)
   int alias;            // batched launches: z | beta | S | e live inside the solver's scratch (dead before it is first written)
@@ -1051,12 +1066,24 @@ __device__ __forceinline__ void mpc_step_body(const MpcArgs& a) {
   // and parked in LDS arrays that are written for good only later: u_prev in f, Yr in e (which becomes P z - Yr in place).
   // zeta (or the lifted state itself) likewise goes to LDS first - into z, which the dictionary evaluation reads and only the
   // step after it overwrites.  All three requests are in flight before the first of them is waited for.
+  // The descriptor of this thread's first dictionary column and its exponent bytes do not depend on the state: they are
+  // requested FIRST (two dependent L2 round trips), the host words behind them, and everything is waited for once.
+  const double r_diag = tid < nv ? a.r[tid % m] : 0.0;      // diagonal of R for the Hessian (element tid of its first round)
+  ColDesc cd0 = {};
+  int ex0[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const bool pre0 = a.has_basis && tid < a.basis.nfull;
+  if (pre0) cd0 = a.basis.cols[tid];
   {
     const double* zin = a.has_basis ? a.zeta + (size_t)pb * a.basis.nzeta : a.z + (size_t)pb * N;
     const int nzin = a.has_basis ? a.basis.nzeta : N, nyr = (Np + 1) * nproj;
     const double r_up = tid < m ? up[tid] : 0.0;
     const double r_yr = tid < nyr ? Yr[tid] : 0.0;
     const double r_z = tid < nzin ? zin[tid] : 0.0;
+    if (pre0 && cd0.kind == COL_MONO && a.basis.nvars <= 8) {
+      const uint8_t* e = a.basis.exps + (size_t)cd0.arg * a.basis.nvars;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) ex0[i] = i < a.basis.nvars ? (int)e[i] : 0;
+    }
     if (tid < m) f[tid] = r_up;
     if (tid < nyr) ev[tid] = r_yr;
     if (tid < nzin) z[tid] = r_z;
@@ -1069,15 +1096,20 @@ __device__ __forceinline__ void mpc_step_body(const MpcArgs& a) {
     const BasisDev& b = a.basis;
     const double* zeta = z;
     for (int c = tid; c < b.nfull; c += 256) {
-      const ColDesc cd = b.cols[c];
+      const ColDesc cd = c == tid ? cd0 : b.cols[c];
       double v;
       if (cd.kind == COL_MONO && b.nvars <= 8) {
         // all exponent bytes of the column requested at once (kp_eval_col fetches them one by one between branches: a
         // dependent L2 round trip per variable, 6.7 us for this phase at 6 variables)
-        const uint8_t* e = b.exps + (size_t)cd.arg * b.nvars;
         int ex[8];
+        if (c == tid) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) ex[i] = i < b.nvars ? (int)e[i] : 0;
+          for (int i = 0; i < 8; ++i) ex[i] = ex0[i];
+        } else {
+          const uint8_t* e = b.exps + (size_t)cd.arg * b.nvars;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) ex[i] = i < b.nvars ? (int)e[i] : 0;
+        }
         v = 1.0;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -1165,28 +1197,17 @@ __device__ __forceinline__ void mpc_step_body(const MpcArgs& a) {
     if (a.model_type == KP_MODEL_BILINEAR) {
       for (int k = 0; k < Np; ++k) {
         const double* zk = iter == 0 ? z : zh + (size_t)k * N;
-        if (iter == 0 && k > 0) break;   // same z for every block: compute Beta once
-        __syncthreads();
-        for (int e = tid; e < N * m; e += 256) {
-          int rr = e % N, i = e / N;
-          const double* Bi = a.B + (size_t)i * N * N;
-          double s = 0.0;
-#pragma unroll 8
-          for (int c = 0; c < N; ++c) s += Bi[rr + (size_t)c * N] * zk[c];
-          beta[e] = s;
-        }
-        __syncthreads();
+        if (iter == 0 && k > 0) break;   // same z for every block: one pass over all of them
         int k0 = k, k1 = iter == 0 ? Np : k + 1;
         for (int e4 = tid; e4 < (k1 - k0) * nproj * m * 4; e4 += 256) {
-          int e = e4 >> 2, part = e4 & 3;
-          int kk = k0 + e / (nproj * m), rem = e % (nproj * m), p = rem % nproj, i = rem / nproj;
-          const double* Pk = a.P + (size_t)kk * nproj * N;
+          const int e = k0 * nproj * m + (e4 >> 2), part = e4 & 3;
+          const double* row = a.PB + (size_t)e * N;        // row p of P_k B_i, contiguous: four lanes share a dot product
           double s = 0.0;
-#pragma unroll 4
-          for (int j = part; j < N; j += 4) s += Pk[p + j * nproj] * beta[j + i * N];
+#pragma unroll 8
+          for (int j = part; j < N; j += 4) s += row[j] * zk[j];
           s += __shfl_xor(s, 1, 64);
           s += __shfl_xor(s, 2, 64);
-          if (part == 0) S[kk * nproj * m + rem] = s;
+          if (part == 0) S[e] = s;
         }
       }
     } else {
@@ -1195,20 +1216,40 @@ __device__ __forceinline__ void mpc_step_body(const MpcArgs& a) {
     __syncthreads();
     if (stamps && tid == 0) stamps[2] = wall_clock64();
     // ---- Hq = 2 (CB'Q CB + R),  f = 2 CB'Q e   (Kmpc.m:604,879,883) ----
-    for (int e = tid; e < nv * nv; e += 256) {
-      int r1 = e % nv, r2 = e / nv;
-      int j1 = r1 / m, a1 = r1 % m, j2 = r2 / m, a2 = r2 % m;
-      double s = 0.0;
-      for (int i = max(j1, j2) + 1; i <= Np; ++i) {
-        double qi = i == Np ? a.q_term : a.q_run;
-        const double* S1 = S + (i - j1 - 1) * nproj * m + a1 * nproj;
-        const double* S2 = S + (i - j2 - 1) * nproj * m + a2 * nproj;
-        double t = 0.0;
-        for (int p = 0; p < nproj; ++p) t += S1[p] * S2[p];
-        s += qi * t;
+    // H is symmetric: the pairs {r, (r + d) mod nv}, d = 0 .. nv / 2, cover its upper triangle (the last d twice when nv is
+    // even: the same value stored twice), 480 sums instead of 900 at nv = 30 - two rounds of the workgroup instead of four;
+    // small quotients by a float reciprocal with one correction (a 32-bit integer division is ~35 instructions, six of them
+    // per element were more than the sum itself)
+    {
+      const float rnv = 1.0f / (float)nv, rmf = 1.0f / (float)m;
+      auto divmod = [](int x, int d, float rd, int& q, int& r) {
+        q = (int)((float)x * rd);
+        r = x - q * d;
+        if (r < 0) { r += d; --q; }
+        if (r >= d) { r -= d; ++q; }
+      };
+      for (int e = tid; e < nv * (nv / 2 + 1); e += 256) {
+        int d, i0;
+        divmod(e, nv, rnv, d, i0);
+        int jx = i0 + d;
+        if (jx >= nv) jx -= nv;
+        const int r1 = min(i0, jx), r2 = max(i0, jx);
+        int j1, a1, j2, a2;
+        divmod(r1, m, rmf, j1, a1);
+        divmod(r2, m, rmf, j2, a2);
+        double s = 0.0;
+        for (int i = j2 + 1; i <= Np; ++i) {               // j2 >= j1
+          double qi = i == Np ? a.q_term : a.q_run;
+          const double* S1 = S + (i - j1 - 1) * nproj * m + a1 * nproj;
+          const double* S2 = S + (i - j2 - 1) * nproj * m + a2 * nproj;
+          double t = 0.0;
+          for (int p = 0; p < nproj; ++p) t += S1[p] * S2[p];
+          s += qi * t;
+        }
+        if (r1 == r2) s += (e == tid && tid < nv) ? r_diag : a.r[a1];
+        Hq[r1 + r2 * nv] = 2.0 * s;
+        Hq[r2 + r1 * nv] = 2.0 * s;
       }
-      if (r1 == r2) s += a.r[a1];
-      Hq[e] = 2.0 * s;
     }
     for (int e = tid; e < nv; e += 256) {
       int j = e / m, a1 = e % m;
@@ -1238,9 +1279,7 @@ __device__ __forceinline__ void mpc_step_body(const MpcArgs& a) {
     // ping-pong inverse.
     // (the solver's own single-wave inverse, have_hinv = false, measured 63 us against 38 us for the first workgroup
     //  version, 27 us for the two-barrier in-place one and 10 us for this one, nv = 30)
-    for (int e = tid; e < nv * nv; e += 256) qpws[e] = Hq[e];
-    __syncthreads();
-    const int hbad = wg_spd_inverse_pp(qpws, Hq, nv, nv);
+    const int hbad = wg_spd_inverse_pp(qpws, Hq, nv, nv, true);       // (the pair sweep reads Hq where it lies)
     const bool have_hinv = true;
     // warm start from the previous step's active set (closed loops change it by a few rows per step): the whole
     // workgroup forms HN = H^-1 N' and S = N H^-1 N' and inverts S; wave 0 then only has to release rows whose
@@ -1370,7 +1409,7 @@ static int dev_alloc_copy(kp_ctx* ctx, double** dst, const double* src, size_t n
 extern "C" int kp_mpc_destroy(kp_mpc* M) {
   if (!M) return KP_OK;
   (void)hipSetDevice(M->ctx->device);
-  double* ptrs[] = {M->A, M->B, M->P, M->S0, M->r, M->Aq, M->bq0, M->Anorm, M->work, M->d_in, M->d_out};
+  double* ptrs[] = {M->A, M->B, M->P, M->S0, M->PB, M->r, M->Aq, M->bq0, M->Anorm, M->work, M->d_in, M->d_out};
   for (double* p : ptrs)
     if (p) (void)hipFree(p);
   if (M->h_in) (void)hipHostFree(M->h_in);
@@ -1462,6 +1501,7 @@ extern "C" int kp_mpc_create(kp_ctx* ctx, int model_type, const double* A, const
   if (!rc) rc = dev_alloc_copy(ctx, &M->B, B, (size_t)N * M->mb);
   if (!rc) rc = dev_alloc_copy(ctx, &M->P, nullptr, (size_t)(Np + 1) * nproj * N);
   if (!rc) rc = dev_alloc_copy(ctx, &M->S0, nullptr, (size_t)Np * nproj * m);
+  if (!rc && model_type == KP_MODEL_BILINEAR) rc = dev_alloc_copy(ctx, &M->PB, nullptr, (size_t)Np * nproj * m * N);
   if (!rc) rc = dev_alloc_copy(ctx, &M->r, r, m);
   if (!rc) rc = dev_alloc_copy(ctx, &M->Aq, Aq.data(), Aq.size());
   if (!rc) rc = dev_alloc_copy(ctx, &M->bq0, bq.data(), nrows);
@@ -1483,7 +1523,7 @@ extern "C" int kp_mpc_create(kp_ctx* ctx, int model_type, const double* A, const
     return rc;
   }
   hipLaunchKernelGGL(kp_mpc_setup_kernel, dim3(1), dim3(256), 0, ctx->stream, M->A, M->B, dproj, N, m, Np, nproj,
-                     model_type == KP_MODEL_LINEAR ? 1 : 0, M->P, M->S0);
+                     model_type == KP_MODEL_LINEAR ? 1 : 0, M->P, M->S0, M->PB);
   hipError_t e = hipStreamSynchronize(ctx->stream);
   (void)hipFree(dproj);
   if (e != hipSuccess) {
@@ -1691,7 +1731,7 @@ static int mpc_run(kp_mpc* M, const kp_basis* basis, int nb, const double* z, co
   a.has_basis = zeta ? 1 : 0;
   a.model_type = M->model_type; a.N = N; a.m = m; a.Np = Np; a.nproj = nproj; a.nvar = nv; a.nrows = nr; a.iters = iters;
   a.q_run = M->q_run; a.q_term = M->q_term;
-  a.A = M->A; a.B = M->B; a.P = M->P; a.S0 = M->S0; a.r = M->r; a.Aq = M->Aq; a.bq0 = M->bq0; a.Anorm = M->Anorm;
+  a.A = M->A; a.B = M->B; a.P = M->P; a.S0 = M->S0; a.PB = M->PB; a.r = M->r; a.Aq = M->Aq; a.bq0 = M->bq0; a.Anorm = M->Anorm;
   a.ell = EllMat{M->ellv, M->ellc, M->Anorm, M->ellK};
   a.z = zeta ? nullptr : d_z;
   a.zeta = zeta ? d_z : nullptr;

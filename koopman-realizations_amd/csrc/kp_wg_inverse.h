@@ -78,6 +78,77 @@ __device__ __forceinline__ int wg_spd_inverse_tiles(double* X, double* Y, int n,
   return bad;
 }
 
+// Pair version (n even, n <= 32): TWO pivots per barrier with the 2 x 2 tiles held in registers.  A pivot step of the tile
+// version is a barrier, an LDS round trip for nine operands, the reciprocal chain and four stores (~770 cycles, most of it
+// latency: the workgroup has one wave per SIMD and nothing to overlap with).  Here a thread keeps its tile in registers for
+// the whole sweep and only the two pivot rows and columns of the next pair go through LDS (written by the 2 nt - 1 threads
+// that own them, into the other buffer: one barrier per pair).  Pivot k + 1 is applied from values every thread forms itself
+// with the arithmetic the owner uses - Y[i][k+1], Y[k+1][j] and Y[k+1][k+1] of the intermediate matrix - so every element
+// sees exactly the two scalar updates of the one-pivot sweep, in the same order and with the same roundings (tools/inv_probe
+// compares the two bit by bit): this is NOT elimination with an inverted 2 x 2 pivot block.
+// The matrix is read from R0 (X itself, or Y when the caller's copy lies there: both buffers are exchange space from the first
+// pair on); the inverse is written to X.
+__device__ __forceinline__ int wg_spd_inverse_pairs(double* X, double* Y, int n, int ld, double thr, double* R0) {
+  const int tid = threadIdx.x;
+  const int nt = n >> 1;
+  const int ti = tid % nt, tj = tid / nt;
+  const bool valid = tj < nt;
+  const int r2 = 2 * ti, c2 = valid ? 2 * tj : 0;
+  double o00 = R0[r2 + c2 * ld], o10 = R0[r2 + 1 + c2 * ld], o01 = R0[r2 + c2 * ld + ld], o11 = R0[r2 + 1 + c2 * ld + ld];
+  int bad = 0;
+  double* R = R0;
+  double* Wn = R0 == X ? Y : X;
+  for (int kt = 0; kt < nt; ++kt) {
+    const int k = 2 * kt;
+    const double* Rk = R + k * ld;
+    const double pa = Rk[k], pc = Rk[k + 1], pb = Rk[k + ld], pd = Rk[k + 1 + ld];      // pivot block [pa pb; pc pd]
+    const double ck0 = Rk[r2], ck1 = Rk[r2 + 1], cl0 = Rk[r2 + ld], cl1 = Rk[r2 + 1 + ld];  // my rows in columns k, k + 1
+    const double rk0 = R[k + c2 * ld], rl0 = R[k + 1 + c2 * ld], rk1 = R[k + c2 * ld + ld], rl1 = R[k + 1 + c2 * ld + ld];
+    const bool inrow = ti == kt, incol = valid && tj == kt;
+    // ---- pivot k ----
+    if (!(pa > thr)) bad = 1;
+    const double ip1 = wg_recip(pa);
+    const double a0 = inrow ? -1.0 : ck0, a1 = ck1;
+    const double b0 = (incol ? 1.0 : rk0) * ip1, b1 = rk1 * ip1, bb = pb * ip1;
+    const double p2 = pd - pc * bb;
+    const double y00 = ((inrow || incol) ? 0.0 : o00) - a0 * b0;
+    const double y10 = (incol ? 0.0 : o10) - a1 * b0;
+    const double y01 = (inrow ? 0.0 : o01) - a0 * b1;
+    const double y11 = o11 - a1 * b1;
+    const double yl0 = (inrow ? 0.0 : cl0) - a0 * bb, yl1 = cl1 - a1 * bb;       // column k + 1 of the intermediate matrix, my rows
+    const double yr0 = (incol ? 0.0 : rl0) - pc * b0, yr1 = rl1 - pc * b1;       // row k + 1, my columns
+    // ---- pivot k + 1 ----
+    if (!(p2 > thr)) bad = 1;
+    const double ip2 = wg_recip(p2);
+    const double e0 = yl0, e1 = inrow ? -1.0 : yl1;
+    const double f0 = yr0 * ip2, f1 = (incol ? 1.0 : yr1) * ip2;
+    o00 = y00 - e0 * f0;
+    o10 = (inrow ? 0.0 : y10) - e1 * f0;
+    o01 = (incol ? 0.0 : y01) - e0 * f1;
+    o11 = ((inrow || incol) ? 0.0 : y11) - e1 * f1;
+    if (valid && kt + 1 < nt && (ti == kt + 1 || tj == kt + 1)) {      // the next pair's rows and columns
+      double* Wo = Wn + r2 + c2 * ld;
+      Wo[0] = o00;
+      Wo[1] = o10;
+      Wo[ld] = o01;
+      Wo[ld + 1] = o11;
+    }
+    __syncthreads();
+    double* T_ = R;
+    R = Wn;
+    Wn = T_;
+  }
+  if (valid) {
+    double* Xo = X + r2 + c2 * ld;
+    Xo[0] = o00;
+    Xo[1] = o10;
+    Xo[ld] = o01;
+    Xo[ld + 1] = o11;
+  }
+  __syncthreads();
+  return bad;
+}
+
 // Per-element version for odd n without room for a padding row (ld == n).  Thread tid owns elements e = tid + 256 t;
 // their (row, column) pairs advance by (256 % n, 256 / n) with one carry: no integer division in the pivot loop and no
 // per-thread index table (a fully unrolled 16-entry table cost 248 VGPRs and halved the occupancy of the batched kernel).
@@ -128,8 +199,15 @@ __device__ __forceinline__ int wg_spd_inverse_elems(double* X, double* Y, int n,
 // shape (contents destroyed).  All 256 threads must call; returns non-zero if a pivot is not positive.
 // Odd n with ld > n: the matrix is bordered by a unit row and column (inverse of diag(S, 1) = diag(S^-1, 1)), so the tile
 // version applies and row / column n of X are overwritten.
-__device__ __forceinline__ int wg_spd_inverse_pp(double* X, double* Y, int n, int ld) {
+// in_Y: the matrix lies in Y instead of X (saves the caller a copy when its matrix is dead afterwards anyway).
+__device__ __forceinline__ int wg_spd_inverse_pp(double* X, double* Y, int n, int ld, bool in_Y = false) {
   const int tid = threadIdx.x;
+  if (in_Y && ((n & 1) || n > 32)) {               // only the pair sweep reads its matrix from either buffer
+    for (int e = tid; e < n * ld; e += 256) X[e] = Y[e];
+    __syncthreads();
+    in_Y = false;
+  }
+  const double* D = in_Y ? Y : X;
   // "not positive definite" means a pivot (a diagonal entry of a Schur complement, >= lambda_min) that is not above
   // 1e-13 of the largest diagonal entry: a matrix of condition > 1e13 has no meaningful inverse in doubles.  A bare
   // `pivot > 0` lets the rounding decide for numerically singular matrices (the inverse Schur complement of an active
@@ -140,7 +218,7 @@ __device__ __forceinline__ int wg_spd_inverse_pp(double* X, double* Y, int n, in
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int kk = min(k + j, n - 1);
-      d[j] = X[kk + kk * ld];
+      d[j] = D[kk + kk * ld];
     }
     dmax = fmax(dmax, fmax(fmax(fmax(d[0], d[1]), fmax(d[2], d[3])), fmax(fmax(d[4], d[5]), fmax(d[6], d[7]))));
   }
@@ -159,6 +237,6 @@ __device__ __forceinline__ int wg_spd_inverse_pp(double* X, double* Y, int n, in
     __syncthreads();
     ++n;
   }
-  if (n <= 32) return wg_spd_inverse_tiles<false>(X, Y, n, ld, thr);
+  if (n <= 32) return wg_spd_inverse_pairs(X, Y, n, ld, thr, in_Y ? Y : X);
   return wg_spd_inverse_tiles<true>(X, Y, n, ld, thr);
 }

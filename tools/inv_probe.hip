@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <vector>
 #include <cmath>
+#include <cstring>
 template <int MODE>
 __global__ __launch_bounds__(256) void inv_kernel(const double* H, double* out, long long* ticks, int n, int ld, int reps) {
   extern __shared__ __align__(16) double sm[];
@@ -23,6 +24,7 @@ __global__ __launch_bounds__(256) void inv_kernel(const double* H, double* out, 
     long long t0 = wall_clock64();
     if (MODE == 0) wg_spd_inverse_pp(X, Y, n, ld);
     else if (MODE == 1) wg_spd_inverse_fast(X, Y, Cm, n, ld);
+    else if (MODE == 3) wg_spd_inverse_tiles<false>(X, Y, n, ld, 0.0);      // the one-pivot-per-barrier sweep (n even, <= 32)
     else {
       if (n <= 16) wg_spd_inverse_mfma<1>(X, Y, n, ld);
       else if (n <= 32) wg_spd_inverse_mfma<2>(X, Y, n, ld);
@@ -55,14 +57,22 @@ int main(int argc, char** argv) {
   hipMalloc(&dH, n * n * 8); hipMalloc(&dO, n * n * 8); hipMalloc(&dT, 8);
   hipMemcpy(dH, H.data(), n * n * 8, hipMemcpyHostToDevice);
   const int reps = 200;
-  for (int mode = 0; mode < 3; ++mode) {
+  std::vector<double> O0(n * n);
+  for (int mode = 0; mode < ((n & 1) || n > 32 ? 3 : 4); ++mode) {
     for (int it = 0; it < 2; ++it) {
       if (mode == 0) inv_kernel<0><<<1, 256, 3 * ld * ld * 8>>>(dH, dO, dT, n, ld, reps);
       else if (mode == 1) inv_kernel<1><<<1, 256, 3 * ld * ld * 8>>>(dH, dO, dT, n, ld, reps);
-      else inv_kernel<2><<<1, 256, 3 * ld * ld * 8>>>(dH, dO, dT, n, ld, reps);
+      else if (mode == 2) inv_kernel<2><<<1, 256, 3 * ld * ld * 8>>>(dH, dO, dT, n, ld, reps);
+      else inv_kernel<3><<<1, 256, 3 * ld * ld * 8>>>(dH, dO, dT, n, ld, reps);
     }
     std::vector<double> O(n * n); long long t;
     hipMemcpy(O.data(), dO, n * n * 8, hipMemcpyDeviceToHost); hipMemcpy(&t, dT, 8, hipMemcpyDeviceToHost);
+    if (mode == 0) O0 = O;
+    if (mode == 3) {
+      int ndiff = 0;
+      for (int e = 0; e < n * n; ++e) ndiff += memcmp(&O[e], &O0[e], 8) != 0;
+      printf("elements of the pair sweep that differ from the one-pivot sweep in any bit: %d of %d\n", ndiff, n * n);
+    }
     double err = 0, asym = 0;
     for (int i = 0; i < n; ++i)
       for (int j = 0; j < n; ++j) {
@@ -72,7 +82,7 @@ int main(int argc, char** argv) {
         asym = fmax(asym, fabs(O[i + j * n] - O[j + i * n]));
       }
     printf("%s n %d ld %d: %.2f us per inverse (%.0f ns per scalar pivot), |H Hinv - I| = %.2e, asymmetry %.1e\n",
-           mode == 0 ? "scalar sweep" : mode == 1 ? "blocked + check" : "blocked alone", n, ld, t * 0.01 / reps, t * 10.0 / reps / n, err, asym);
+           mode == 0 ? "scalar sweep (pairs)" : mode == 1 ? "blocked + check" : mode == 2 ? "blocked alone" : "scalar sweep (one pivot per barrier)", n, ld, t * 0.01 / reps, t * 10.0 / reps / n, err, asym);
   }
   return 0;
 }
