@@ -343,6 +343,10 @@ int kp_mpc_last_qp(kp_mpc* mpc, double* Hq, double* f, double* Aq, double* bq);
  * [2] H and f, [3] H^-1, [4] active-set iterations, [5] whole kernel; counts[0] solver
  * iterations, counts[1] active constraints at the optimum. */
 int kp_mpc_last_profile(kp_mpc* mpc, double* us, int* counts);
+/* All 16 device-side stamps of that step relative to its first one, in microseconds ([8], [9]: the two counts):
+ * [1] tracking error formed, [2] S_k, [3] H and f, [4] solver entered, [5] solved, [10] inputs landed,
+ * [11] lifted state, [6] iteration loop entered, [12] H^-1, [13] warm-start products, [14] inverse of the warm set's Schur complement. */
+int kp_mpc_last_stamps(kp_mpc* mpc, double* us16);
 int kp_qp_solve(kp_ctx* ctx, const double* H, const double* f, const double* A, const double* b, int n,
                 int mrows, double* x, int* status);
 

@@ -87,6 +87,7 @@ SIGNATURES = {
     "kp_mpc_step_batch": (C.c_int, [vp, C.c_int, c_dp, c_dp, c_dp, c_dp, c_ip]),
     "kp_mpc_last_qp": (C.c_int, [vp, c_dp, c_dp, c_dp, c_dp]),
     "kp_mpc_last_profile": (C.c_int, [vp, c_dp, c_ip]),
+    "kp_mpc_last_stamps": (C.c_int, [vp, c_dp]),
     "kp_qp_solve": (C.c_int, [vp, c_dp, c_dp, c_dp, c_dp, C.c_int, C.c_int, c_dp, c_ip]),
     "kp_comm_unique_id": (C.c_int, [vp]),
     "kp_comm_create": (C.c_int, [vp, vp, C.c_int, C.c_int]),

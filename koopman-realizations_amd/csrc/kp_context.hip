@@ -219,7 +219,12 @@ extern "C" int kp_basis_create(kp_ctx* ctx, const kp_basis_desc* d, kp_basis** o
           int deg = 0;
           for (int v = 0; v < nvars; ++v) deg += d->poly_exps[(size_t)(n_mono + i) * nvars + v];
           if (deg > max_deg) max_deg = deg;
-          cols.push_back({COL_MONO, n_mono + i, 0, 0});
+          // up to 8 variables: the exponent bytes ride in the descriptor itself (aux = variables 0-3, pad = 4-7), so the
+          // fused lift of an MPC step needs one load per column instead of two dependent ones
+          uint32_t pk[2] = {0, 0};
+          if (nvars <= 8)
+            for (int v = 0; v < nvars; ++v) pk[v >> 2] |= (uint32_t)d->poly_exps[(size_t)(n_mono + i) * nvars + v] << (8 * (v & 3));
+          cols.push_back({COL_MONO, n_mono + i, (int32_t)pk[0], (int32_t)pk[1]});
         }
         n_mono += cnt;
         break;

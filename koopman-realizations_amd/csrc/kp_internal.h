@@ -111,8 +111,8 @@ struct ColDesc {
   int32_t kind;
   int32_t arg;  // VAR: variable index; MONO/HERMITE: row in exps; FSPARSE: first of two rows in exps (sin, cos
                 // multipliers); FOURIER: mixed-radix index (>=1); GAUSS: centre
-  int32_t aux;  // FOURIER: degree
-  int32_t pad;
+  int32_t aux;  // FOURIER: degree; MONO with <= 8 variables (kp_basis_create): exponent bytes of variables 0-3
+  int32_t pad;  // MONO with <= 8 variables: exponent bytes of variables 4-7
 };
 
 // Device view of a dictionary, passed by value to kernels.

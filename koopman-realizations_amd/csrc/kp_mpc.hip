@@ -34,7 +34,8 @@ struct kp_mpc {
   double* B = nullptr;     // N x mb
   double* P = nullptr;     // (Np+1) x [nproj x N]  (P_k column-major nproj x N)
   double* S0 = nullptr;    // linear model: Np x [nproj x m]
-  double* PB = nullptr;    // bilinear model: [Np * m * nproj][N]  rows of P_k B_i (S_k = P_k Beta(z) = these rows times z)
+  double* PB = nullptr;    // bilinear model: [Np * m * nproj][N]  rows of P_k B_i (S_k = P_k Beta(z) = these rows times z); inside P's allocation
+  int stage_doubles = 0;   // size of that allocation
   double* r = nullptr;     // m
   double* Aq = nullptr;    // nrows x nvar column-major (constant: L = F, tack rows)
   double* bq0 = nullptr;   // nrows (c and zeros for the tack rows)
@@ -1006,6 +1007,8 @@ struct MpcArgs {
   unsigned long long* done_flag;   // pinned host word: the kernel stores done_seq there when its outputs are visible (or nullptr)
   unsigned long long done_seq;
   int qp_wg;            // active-set iteration by the whole workgroup (qp_gi_wg) when the problem qualifies
+  int stage_off;        // single-problem launches: P | PB are copied to LDS at this offset (doubles) at kernel start; 0: read from L2
+  int stage_doubles;    // multiple of 512 (every wave issues the same number of 1 KB LDS-DMA loads)
 };
 
 // LDS (doubles): z N | beta N*m | S Np*nproj*m | e (Np+1)*nproj | Hq nvar^2 | f nvar | b nrows | zh (Np+1)*N (iters>1)
@@ -1066,11 +1069,11 @@ __device__ __forceinline__ void mpc_step_body(const MpcArgs& a) {
   // and parked in LDS arrays that are written for good only later: u_prev in f, Yr in e (which becomes P z - Yr in place).
   // zeta (or the lifted state itself) likewise goes to LDS first - into z, which the dictionary evaluation reads and only the
   // step after it overwrites.  All three requests are in flight before the first of them is waited for.
-  // The descriptor of this thread's first dictionary column and its exponent bytes do not depend on the state: they are
-  // requested FIRST (two dependent L2 round trips), the host words behind them, and everything is waited for once.
+  // The descriptor of this thread's first dictionary column does not depend on the state (and carries a monomial's exponent
+  // bytes, kp_basis_create): requested FIRST, the host words behind it, and everything is waited for once.
   const double r_diag = tid < nv ? a.r[tid % m] : 0.0;      // diagonal of R for the Hessian (element tid of its first round)
+  const double r_bq0 = tid < nr ? a.bq0[tid] : 0.0;         // constant right-hand sides (first round of the loop below)
   ColDesc cd0 = {};
-  int ex0[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const bool pre0 = a.has_basis && tid < a.basis.nfull;
   if (pre0) cd0 = a.basis.cols[tid];
   {
@@ -1079,10 +1082,16 @@ __device__ __forceinline__ void mpc_step_body(const MpcArgs& a) {
     const double r_up = tid < m ? up[tid] : 0.0;
     const double r_yr = tid < nyr ? Yr[tid] : 0.0;
     const double r_z = tid < nzin ? zin[tid] : 0.0;
-    if (pre0 && cd0.kind == COL_MONO && a.basis.nvars <= 8) {
-      const uint8_t* e = a.basis.exps + (size_t)cd0.arg * a.basis.nvars;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) ex0[i] = i < a.basis.nvars ? (int)e[i] : 0;
+    // P | PB (constants of the model that every step reads once, 55 KB at N = 84) go to LDS by LDS-DMA while the host words
+    // are on their way: no registers, nothing to wait for before the barrier below (hipcc drains vmcnt there)
+    if (a.stage_off) {
+      typedef __attribute__((address_space(3))) char lds_char;
+      typedef __attribute__((address_space(1))) const char glb_char;
+      lds_char* dst = (lds_char*)(sm + a.stage_off);
+      glb_char* src = (glb_char*)a.P;
+      const int wbase = (tid & ~63) * 16, lane16 = (tid & 63) * 16;
+      for (int o = wbase; o < a.stage_doubles * 8; o += 256 * 16)       // wave-uniform LDS base; each lane its own 16 source bytes
+        __builtin_amdgcn_global_load_lds(src + o + lane16, dst + o, 16, 0, 0);
     }
     if (tid < m) f[tid] = r_up;
     if (tid < nyr) ev[tid] = r_yr;
@@ -1090,6 +1099,7 @@ __device__ __forceinline__ void mpc_step_body(const MpcArgs& a) {
     for (int e = tid + 256; e < nyr; e += 256) ev[e] = Yr[e];
     for (int c = tid + 256; c < nzin; c += 256) z[c] = zin[c];
     __syncthreads();
+    if (stamps && tid == 0) stamps[10] = wall_clock64();      // host words and staged constants have landed
   }
   // ---- lifted state (Kmpc.m:842) ----
   if (a.has_basis) {
@@ -1099,17 +1109,11 @@ __device__ __forceinline__ void mpc_step_body(const MpcArgs& a) {
       const ColDesc cd = c == tid ? cd0 : b.cols[c];
       double v;
       if (cd.kind == COL_MONO && b.nvars <= 8) {
-        // all exponent bytes of the column requested at once (kp_eval_col fetches them one by one between branches: a
-        // dependent L2 round trip per variable, 6.7 us for this phase at 6 variables)
+        // the exponent bytes come with the descriptor (kp_eval_col fetches them one by one between branches: a dependent L2
+        // round trip per variable, 6.7 us for this phase at 6 variables)
         int ex[8];
-        if (c == tid) {
 #pragma unroll
-          for (int i = 0; i < 8; ++i) ex[i] = ex0[i];
-        } else {
-          const uint8_t* e = b.exps + (size_t)cd.arg * b.nvars;
-#pragma unroll
-          for (int i = 0; i < 8; ++i) ex[i] = i < b.nvars ? (int)e[i] : 0;
-        }
+        for (int i = 0; i < 8; ++i) ex[i] = ((uint32_t)(i < 4 ? cd.aux : cd.pad) >> (8 * (i & 3))) & 0xff;
         v = 1.0;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -1138,29 +1142,34 @@ __device__ __forceinline__ void mpc_step_body(const MpcArgs& a) {
     }
   }
   __syncthreads();
+  if (stamps && tid == 0) stamps[11] = wall_clock64();        // lifted state
   if (a.z_out)
     for (int c = tid; c < N; c += 256) a.z_out[(size_t)pb * N + c] = z[c];
 
   // constraint right-hand side: b = c (E = 0 without state bounds, Kmpc.m:862) and the
   // "memory" rows +-u_0 <= +-u_prev (Kmpc.m:865-870)
   for (int e = tid; e < nr; e += 256) {
-    double v = a.bq0[e];
+    double v = e == tid ? r_bq0 : a.bq0[e];
     int k = e - (nr - 2 * m);
     if (k >= 0) v = k < m ? f[k] : -f[k - m];
     bq[e] = v;
   }
   // e_i = P_i z - Yr_i
-  for (int e4 = tid; e4 < (Np + 1) * nproj * 4; e4 += 256) {   // each dot product split over 4 lanes
-    int e = e4 >> 2, part = e4 & 3;
-    int i = e / nproj, p = e % nproj;
-    const double* Pi = a.P + (size_t)i * nproj * N;
-    double s = 0.0;
+  auto track_err = [&](auto Pp) {          // (Pp: P in global memory or its LDS copy - two instantiations, no generic pointer)
+    for (int e4 = tid; e4 < (Np + 1) * nproj * 4; e4 += 256) {   // each dot product split over 4 lanes
+      int e = e4 >> 2, part = e4 & 3;
+      int i = e / nproj, p = e % nproj;
+      auto Pi = Pp + (size_t)i * nproj * N;
+      double s = 0.0;
 #pragma unroll 4
-    for (int j = part; j < N; j += 4) s += Pi[p + j * nproj] * z[j];
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
-    if (part == 0) ev[e] = s - ev[e];
-  }
+      for (int j = part; j < N; j += 4) s += Pi[p + j * nproj] * z[j];
+      s += __shfl_xor(s, 1, 64);
+      s += __shfl_xor(s, 2, 64);
+      if (part == 0) ev[e] = s - ev[e];
+    }
+  };
+  if (a.stage_off) track_err(sm + a.stage_off);
+  else track_err(a.P);
   int status = 0;
   if (stamps && tid == 0) stamps[1] = wall_clock64();
   // lifted horizon along an input sequence x = [u_0; u_1; ...] (Kmpc.m:891-895)
@@ -1194,21 +1203,26 @@ __device__ __forceinline__ void mpc_step_body(const MpcArgs& a) {
   for (int iter = iter0; iter < iter0 + a.iters; ++iter) {
     // ---- S_k = P_k * Beta(z_k)  (get_costB_bilinear, Kmpc.m:578-585: block i uses z(i,:) when a
     // horizon of lifted states is given, else z) ----
+    if (stamps && tid == 0) stamps[6] = wall_clock64();        // (what precedes is the loop's hoisted address arithmetic)
     if (a.model_type == KP_MODEL_BILINEAR) {
       for (int k = 0; k < Np; ++k) {
         const double* zk = iter == 0 ? z : zh + (size_t)k * N;
         if (iter == 0 && k > 0) break;   // same z for every block: one pass over all of them
         int k0 = k, k1 = iter == 0 ? Np : k + 1;
-        for (int e4 = tid; e4 < (k1 - k0) * nproj * m * 4; e4 += 256) {
-          const int e = k0 * nproj * m + (e4 >> 2), part = e4 & 3;
-          const double* row = a.PB + (size_t)e * N;        // row p of P_k B_i, contiguous: four lanes share a dot product
-          double s = 0.0;
+        auto s_rows = [&](auto PBp) {
+          for (int e4 = tid; e4 < (k1 - k0) * nproj * m * 4; e4 += 256) {
+            const int e = k0 * nproj * m + (e4 >> 2), part = e4 & 3;
+            auto row = PBp + (size_t)e * N;        // row p of P_k B_i, contiguous: four lanes share a dot product
+            double s = 0.0;
 #pragma unroll 8
-          for (int j = part; j < N; j += 4) s += row[j] * zk[j];
-          s += __shfl_xor(s, 1, 64);
-          s += __shfl_xor(s, 2, 64);
-          if (part == 0) S[e] = s;
-        }
+            for (int j = part; j < N; j += 4) s += row[j] * zk[j];
+            s += __shfl_xor(s, 1, 64);
+            s += __shfl_xor(s, 2, 64);
+            if (part == 0) S[e] = s;
+          }
+        };
+        if (a.stage_off) s_rows(sm + a.stage_off + (a.PB - a.P));
+        else s_rows(a.PB);
       }
     } else {
       for (int e = tid; e < Np * nproj * m; e += 256) S[e] = a.S0[e];
@@ -1280,6 +1294,7 @@ __device__ __forceinline__ void mpc_step_body(const MpcArgs& a) {
     // (the solver's own single-wave inverse, have_hinv = false, measured 63 us against 38 us for the first workgroup
     //  version, 27 us for the two-barrier in-place one and 10 us for this one, nv = 30)
     const int hbad = wg_spd_inverse_pp(qpws, Hq, nv, nv, true);       // (the pair sweep reads Hq where it lies)
+    if (stamps && tid == 0) stamps[12] = wall_clock64();      // H^-1
     const bool have_hinv = true;
     // warm start from the previous step's active set (closed loops change it by a few rows per step): the whole
     // workgroup forms HN = H^-1 N' and S = N H^-1 N' and inverts S; wave 0 then only has to release rows whose
@@ -1350,7 +1365,9 @@ __device__ __forceinline__ void mpc_step_body(const MpcArgs& a) {
           }
           __syncthreads();
         }
+        if (stamps && tid == 0) stamps[13] = wall_clock64();  // H^-1 N', N H^-1 N'
         if (wg_spd_inverse_pp(Sw, Hq, wq, nv)) wq = 0;   // dependent rows: cold start
+        if (stamps && tid == 0) stamps[14] = wall_clock64();  // its inverse
       }
     }
     // single-problem launches: the iteration by all four waves (12 % faster cold solves; in the batched kernel it would
@@ -1409,7 +1426,7 @@ static int dev_alloc_copy(kp_ctx* ctx, double** dst, const double* src, size_t n
 extern "C" int kp_mpc_destroy(kp_mpc* M) {
   if (!M) return KP_OK;
   (void)hipSetDevice(M->ctx->device);
-  double* ptrs[] = {M->A, M->B, M->P, M->S0, M->PB, M->r, M->Aq, M->bq0, M->Anorm, M->work, M->d_in, M->d_out};
+  double* ptrs[] = {M->A, M->B, M->P, M->S0, M->r, M->Aq, M->bq0, M->Anorm, M->work, M->d_in, M->d_out};
   for (double* p : ptrs)
     if (p) (void)hipFree(p);
   if (M->h_in) (void)hipHostFree(M->h_in);
@@ -1499,9 +1516,14 @@ extern "C" int kp_mpc_create(kp_ctx* ctx, int model_type, const double* A, const
   M->q_run = q_run; M->q_term = q_term;
   int rc = dev_alloc_copy(ctx, &M->A, A, (size_t)N * N);
   if (!rc) rc = dev_alloc_copy(ctx, &M->B, B, (size_t)N * M->mb);
-  if (!rc) rc = dev_alloc_copy(ctx, &M->P, nullptr, (size_t)(Np + 1) * nproj * N);
+  // P | PB in ONE allocation (PB at an even offset), padded to a multiple of 4 KB: a single-problem step copies the block
+  // to LDS with 1 KB loads per wave
+  const size_t nP = ((size_t)(Np + 1) * nproj * N + 1) & ~(size_t)1;
+  const size_t nPB = model_type == KP_MODEL_BILINEAR ? (size_t)Np * nproj * m * N : 0;
+  M->stage_doubles = (int)((nP + nPB + 511) & ~(size_t)511);
+  if (!rc) rc = dev_alloc_copy(ctx, &M->P, nullptr, (size_t)M->stage_doubles);
+  if (!rc && nPB) M->PB = M->P + nP;
   if (!rc) rc = dev_alloc_copy(ctx, &M->S0, nullptr, (size_t)Np * nproj * m);
-  if (!rc && model_type == KP_MODEL_BILINEAR) rc = dev_alloc_copy(ctx, &M->PB, nullptr, (size_t)Np * nproj * m * N);
   if (!rc) rc = dev_alloc_copy(ctx, &M->r, r, m);
   if (!rc) rc = dev_alloc_copy(ctx, &M->Aq, Aq.data(), Aq.size());
   if (!rc) rc = dev_alloc_copy(ctx, &M->bq0, bq.data(), nrows);
@@ -1792,6 +1814,15 @@ static int mpc_run(kp_mpc* M, const kp_basis* basis, int nb, const double* z, co
     if (a.alias) lds -= (size_t)(n_asm + 64) * 8;
   }
   if (lds > 160 * 1024) return ctx->fail(KP_ERR_ARG, "kp_mpc_step: problem too large for LDS");
+  // single-problem launches: the model's P | PB block behind everything else in LDS when it fits (a batch reads it from L2,
+  // shared by its workgroups, and needs its LDS for occupancy)
+  static const bool no_stage = getenv("KP_MPC_NO_STAGE") != nullptr;
+  a.stage_off = 0;
+  a.stage_doubles = M->stage_doubles;
+  if (nb == 1 && !no_stage && lds + 16 + (size_t)M->stage_doubles * 8 <= 160 * 1024) {
+    a.stage_off = (int)((lds / 8 + 1) & ~(size_t)1);
+    lds = (size_t)(a.stage_off + M->stage_doubles) * 8;
+  }
   static KpLdsCache step_lds[2];
   const int wk = a.warm != nullptr;
   static KpLdsCache batch_lds;
@@ -1898,6 +1929,20 @@ extern "C" int kp_mpc_last_qp(kp_mpc* M, double* Hq, double* f, double* Aq, doub
 // Diagnostics: phase times (microseconds) of the most recent single-problem step:
 // [0] lift + e, [1] Beta/S, [2] H/f, [3] Hinv (Gauss-Jordan), [4] active-set iterations,
 // [5] total kernel; counts[0] = solver iterations, counts[1] = active constraints at the optimum.
+// every stamp of the most recent single step relative to its first, in microseconds (slots a step did not reach hold stale or
+// negative values): [1] tracking error, [2] S_k, [3] H and f, [4] solver entered, [5] solved, [10] inputs landed, [11] lifted
+// state, [6] iteration loop entered, [12] H^-1, [13] warm-start products, [14] inverse of the warm set's Schur complement
+extern "C" int kp_mpc_last_stamps(kp_mpc* M, double* us16) {
+  if (!M || !M->work || !us16) return KP_ERR_ARG;
+  kp_ctx* ctx = M->ctx;
+  KP_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t n_ex = (size_t)M->nvar * M->nvar + M->nvar + M->nrows;
+  long long st[16];
+  KP_HIP(ctx, hipMemcpy(st, M->work + n_ex, sizeof(st), hipMemcpyDeviceToHost));
+  for (int i = 0; i < 16; ++i) us16[i] = (i == 8 || i == 9) ? (double)st[i] : (st[i] - st[0]) * 0.01;
+  return KP_OK;
+}
+
 extern "C" int kp_mpc_last_profile(kp_mpc* M, double* us, int* counts) {
   if (!M || !M->work || !us) return KP_ERR_ARG;
   kp_ctx* ctx = M->ctx;
