@@ -59,6 +59,7 @@
  *             U = kp_mex('mpc_step', m, z, u_prev, Yr [, iters])                                           kp_mpc_step
  *             [U, status] = kp_mex('mpc_step_batch', m, Z, Uprev, YR)    Z N x nb, ..., U Np x m x nb      kp_mpc_step_batch
  *             [Hq, f, Aq, bq] = kp_mex('mpc_last_qp', m)     [us, counts] = kp_mex('mpc_last_profile', m)
+ *             us16 = kp_mex('mpc_last_stamps', m)
  *             x = kp_mex('qp_solve', h, H, f, A, b)        signature of quadprog_gurobi.m:1                kp_qp_solve
  * comm        id = kp_mex('comm_unique_id')                uint8 1 x 128                                   kp_comm_unique_id
  *             kp_mex('comm_create', h, id, rank, world)    kp_mex('comm_destroy', h)    kp_mex('comm_abandon', h)
@@ -847,6 +848,11 @@ static void c_mpc_last_profile(ARGS) {
   check(kp_mpc_last_profile((kp_mpc*)get_handle(prhs[1]), mxGetPr(plhs[0]), counts), NULL);
   set_or_drop(nlhs, plhs, 1, ints_out(counts, 2, 1, 2));
 }
+static void c_mpc_last_stamps(ARGS) {
+  UNUSED;
+  plhs[0] = mxCreateDoubleMatrix(1, 16, mxREAL);
+  check(kp_mpc_last_stamps((kp_mpc*)get_handle(prhs[1]), mxGetPr(plhs[0])), NULL);
+}
 static void c_qp_solve(ARGS) {
   UNUSED;
   kp_ctx* c = CTX(1);
@@ -1100,6 +1106,7 @@ static const kp_command g_commands[] = {
   {"mpc_create", 13, 13, 1, c_mpc_create}, {"mpc_set_state_bounds", 3, 3, 0, c_mpc_set_state_bounds}, {"mpc_destroy", 1, 1, 0, c_mpc_destroy},
   {"mpc_dims", 1, 1, 1, c_mpc_dims}, {"mpc_step_zeta", 5, 6, 2, c_mpc_step_zeta}, {"mpc_step", 4, 5, 2, c_mpc_step},
   {"mpc_step_batch", 4, 4, 2, c_mpc_step_batch}, {"mpc_last_qp", 1, 1, 4, c_mpc_last_qp}, {"mpc_last_profile", 1, 1, 2, c_mpc_last_profile},
+  {"mpc_last_stamps", 1, 1, 1, c_mpc_last_stamps},
   {"qp_solve", 5, 5, 2, c_qp_solve},
   {"comm_unique_id", 0, 0, 1, c_comm_unique_id}, {"comm_create", 4, 4, 0, c_comm_create}, {"comm_destroy", 1, 1, 0, c_comm_destroy},
   {"comm_abandon", 1, 1, 0, c_comm_abandon}, {"comm_info", 1, 1, 1, c_comm_info}, {"comm_allgather", 2, 2, 1, c_comm_allgather},

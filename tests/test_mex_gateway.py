@@ -348,6 +348,8 @@ def test_mpc_commands(ctx, h, mpc_model):
     assert Hq.shape == Hp.shape and np.allclose(Hq, Hp, rtol=0, atol=1e-12) and Aq.shape == Ap.shape and bq.shape[0] == bp_.shape[0]
     us, counts = mex("mpc_last_profile", m_, nargout=2)
     assert us.shape == (1, 6) and us[0, 5] > 0 and counts.shape == (1, 2)
+    us16 = mex("mpc_last_stamps", m_)
+    assert us16.shape == (1, 16) and us16[0, 0] == 0 and abs(us16[0, 5] - us[0, 5]) < 1e-9 and 0 < us16[0, 10] < us16[0, 11] < us16[0, 5]
     # batch: columns = problems
     nb = 37
     Z = np.asfortranarray(mm["bp"].lift(1, rng.uniform(-0.5, 0.5, (nb, 3))).T)
