@@ -20,6 +20,7 @@
 
 #include "kp_internal.h"
 #include "kp_wg_inverse.h"
+#include <type_traits>
 
 #define QP_MAXN 64       // variables (one wave handles <= 64)
 #define QP_MAXIT 2000
@@ -1125,7 +1126,7 @@ __device__ __forceinline__ void mpc_step_body(const MpcArgs& a) {
       }
       full[c] = v;
     }
-    __syncthreads();
+    wg_lds_barrier();
     for (int c = tid; c < N; c += 256) {
       double v;
       if (b.k_pcs == 0)
@@ -1141,7 +1142,7 @@ __device__ __forceinline__ void mpc_step_body(const MpcArgs& a) {
       z[c] = v;
     }
   }
-  __syncthreads();
+  wg_lds_barrier();
   if (stamps && tid == 0) stamps[11] = wall_clock64();        // lifted state
   if (a.z_out)
     for (int c = tid; c < N; c += 256) a.z_out[(size_t)pb * N + c] = z[c];
@@ -1227,13 +1228,18 @@ __device__ __forceinline__ void mpc_step_body(const MpcArgs& a) {
     } else {
       for (int e = tid; e < Np * nproj * m; e += 256) S[e] = a.S0[e];
     }
-    __syncthreads();
+    wg_lds_barrier();
     if (stamps && tid == 0) stamps[2] = wall_clock64();
     // ---- Hq = 2 (CB'Q CB + R),  f = 2 CB'Q e   (Kmpc.m:604,879,883) ----
-    // H is symmetric: the pairs {r, (r + d) mod nv}, d = 0 .. nv / 2, cover its upper triangle (the last d twice when nv is
-    // even: the same value stored twice), 480 sums instead of 900 at nv = 30 - two rounds of the workgroup instead of four;
-    // small quotients by a float reciprocal with one correction (a 32-bit integer division is ~35 instructions, six of them
-    // per element were more than the sum itself)
+    // With Sall = [S_0 S_1 ... S_{Np-1}] (nproj x nv: block k, input a is column k m + a) the blocks of CB_i are columns of Sall,
+    // so every term of H is an entry of the Gram matrix T = Sall' Sall, and H(r1, r2) walks down one diagonal of it:
+    //   H(j1 m + a1, j2 m + a2) = 2 sum_{t < Np - j2} q_{j2 + 1 + t} T((j2 - j1 + t) m + a1, t m + a2)        (j2 >= j1).
+    // Stage 1 forms T once (nv (nv / 2 + 1) short dot products, into the solver's scratch, which is free until H^-1), stage 2
+    // is one LDS read and one multiply-add per term - the direct form recomputed every T entry up to Np times inside a
+    // doubly nested loop of dependent LDS round trips (4.5 us of a 34 us step).  Same terms in the same order: same bits.
+    // Both stages use symmetry: the pairs {r, (r + d) mod nv}, d = 0 .. nv / 2, cover the upper triangle (the last d twice
+    // when nv is even: the same value stored twice); small quotients by a float reciprocal with one correction (a 32-bit
+    // integer division is ~35 instructions).
     {
       const float rnv = 1.0f / (float)nv, rmf = 1.0f / (float)m;
       auto divmod = [](int x, int d, float rd, int& q, int& r) {
@@ -1242,6 +1248,80 @@ __device__ __forceinline__ void mpc_step_body(const MpcArgs& a) {
         if (r < 0) { r += d; --q; }
         if (r >= d) { r -= d; ++q; }
       };
+      double* Tm = qpws;
+      // The loops below fetch the operands of FOUR terms (and of all nproj products of a term) before they use the first: a
+      // loop that reads, waits, adds and branches per term is a chain of LDS round trips (~130 cycles each, ten per element).
+      // Indices past the end are clamped (the reads stay inside the arrays), the sums take only the valid terms, in order.
+      auto stage1 = [&](auto NPc) {
+        constexpr int NP = decltype(NPc)::value;          // nproj (0: any)
+        for (int e = tid; e < nv * (nv / 2 + 1); e += 256) {
+          int d, i0;
+          divmod(e, nv, rnv, d, i0);
+          int jx = i0 + d;
+          if (jx >= nv) jx -= nv;
+          const int c1 = min(i0, jx), c2 = max(i0, jx);
+          const double* S1 = S + c1 * nproj;
+          const double* S2 = S + c2 * nproj;
+          double t = 0.0;
+          if constexpr (NP > 0) {
+            double x1[NP], x2[NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) { x1[p] = S1[p]; x2[p] = S2[p]; }
+#pragma unroll
+            for (int p = 0; p < NP; ++p) t += x1[p] * x2[p];
+          } else {
+            for (int p = 0; p < nproj; ++p) t += S1[p] * S2[p];
+          }
+          Tm[c1 + c2 * nv] = t;
+          Tm[c2 + c1 * nv] = t;
+        }
+        // f = 2 CB'Q e by the LAST threads (they have the fewest elements of the two H rounds)
+        for (int e = 255 - tid; e < nv; e += 256) {
+          int j, a1;
+          divmod(e, m, rmf, j, a1);
+          double s = 0.0;
+          if constexpr (NP > 0) {
+            const int cnt = Np - j, last = cnt - 1;
+            const double* S0 = S + a1 * nproj;               // column a1 of S_0; term t uses S_t and e_{j + 1 + t}
+            const double* e0 = ev + (j + 1) * nproj;
+            for (int t0 = 0; t0 < cnt; t0 += 4) {
+              double xs[4][NP], xe[4][NP];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                const int tt = min(t0 + u, last);
+#pragma unroll
+                for (int p = 0; p < NP; ++p) { xs[u][p] = S0[tt * nproj * m + p]; xe[u][p] = e0[tt * nproj + p]; }
+              }
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                double t = 0.0;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) t += xs[u][p] * xe[u][p];
+                if (t0 + u < last) s += a.q_run * t;
+                else if (t0 + u == last) s += a.q_term * t;
+              }
+            }
+          } else {
+            for (int i = j + 1; i <= Np; ++i) {
+              double qi = i == Np ? a.q_term : a.q_run;
+              const double* S1 = S + (i - j - 1) * nproj * m + a1 * nproj;
+              double t = 0.0;
+              for (int p = 0; p < nproj; ++p) t += S1[p] * ev[i * nproj + p];
+              s += qi * t;
+            }
+          }
+          f[e] = 2.0 * s;
+        }
+      };
+      switch (nproj) {
+        case 1: stage1(std::integral_constant<int, 1>()); break;
+        case 2: stage1(std::integral_constant<int, 2>()); break;
+        case 3: stage1(std::integral_constant<int, 3>()); break;
+        case 4: stage1(std::integral_constant<int, 4>()); break;
+        default: stage1(std::integral_constant<int, 0>()); break;
+      }
+      wg_lds_barrier();
+      const int dstride = m * (nv + 1);
       for (int e = tid; e < nv * (nv / 2 + 1); e += 256) {
         int d, i0;
         divmod(e, nv, rnv, d, i0);
@@ -1251,33 +1331,25 @@ __device__ __forceinline__ void mpc_step_body(const MpcArgs& a) {
         int j1, a1, j2, a2;
         divmod(r1, m, rmf, j1, a1);
         divmod(r2, m, rmf, j2, a2);
+        const double* tp = Tm + ((j2 - j1) * m + a1) + a2 * nv;      // T(S_{i-j1-1} column a1, S_{i-j2-1} column a2) at i = j2 + 1
+        const int cnt = Np - j2, last = cnt - 1;
         double s = 0.0;
-        for (int i = j2 + 1; i <= Np; ++i) {               // j2 >= j1
-          double qi = i == Np ? a.q_term : a.q_run;
-          const double* S1 = S + (i - j1 - 1) * nproj * m + a1 * nproj;
-          const double* S2 = S + (i - j2 - 1) * nproj * m + a2 * nproj;
-          double t = 0.0;
-          for (int p = 0; p < nproj; ++p) t += S1[p] * S2[p];
-          s += qi * t;
+        for (int t0 = 0; t0 < cnt; t0 += 4) {
+          double v[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) v[u] = tp[min(t0 + u, last) * dstride];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (t0 + u < last) s += a.q_run * v[u];
+            else if (t0 + u == last) s += a.q_term * v[u];
+          }
         }
         if (r1 == r2) s += (e == tid && tid < nv) ? r_diag : a.r[a1];
         Hq[r1 + r2 * nv] = 2.0 * s;
         Hq[r2 + r1 * nv] = 2.0 * s;
       }
     }
-    for (int e = tid; e < nv; e += 256) {
-      int j = e / m, a1 = e % m;
-      double s = 0.0;
-      for (int i = j + 1; i <= Np; ++i) {
-        double qi = i == Np ? a.q_term : a.q_run;
-        const double* S1 = S + (i - j - 1) * nproj * m + a1 * nproj;
-        double t = 0.0;
-        for (int p = 0; p < nproj; ++p) t += S1[p] * ev[i * nproj + p];
-        s += qi * t;
-      }
-      f[e] = 2.0 * s;
-    }
-    __syncthreads();
+    wg_lds_barrier();
     if (a.qp_export) {
       double* ex = a.qp_export + (size_t)pb * (nv * nv + nv + nr);
       for (int e = tid; e < nv * nv; e += 256) ex[e] = Hq[e];
@@ -1331,22 +1403,48 @@ __device__ __forceinline__ void mpc_step_body(const MpcArgs& a) {
               sc[tid * QP_KLDS + k] = warm_col[k];
             }
           }
-          __syncthreads();
-          const int li_ = tid & 63, w4 = tid >> 6;
-          if (li_ < nv)
-            for (int c = w4; c < wq; c += 4) {
+          wg_lds_barrier();
+          // lane = row of the result, groups of 32 (nv <= 32) or 64 lanes stride the columns; always QP_KLDS terms (the
+          // entries behind a row's last one are 0 * column 0), so the reads of a sum do not wait for each other and
+          // two columns are in flight per thread - the loops over a run-time K were chains of dependent LDS round trips
+          const int RL = nv <= 32 ? 32 : 64, NG = 256 / RL;
+          const int li_ = tid & (RL - 1), cg = tid / RL;
+          if (li_ < nv) {
+#pragma unroll 2
+            for (int c = cg; c < wq; c += NG) {
+              double v4[QP_KLDS], h4[QP_KLDS];
+#pragma unroll
+              for (int k = 0; k < QP_KLDS; ++k) {
+                v4[k] = sv[c * QP_KLDS + k];
+                h4[k] = qpws[li_ + sc[c * QP_KLDS + k] * nv];
+              }
               double sacc = 0.0;
-              for (int k = 0; k < K; ++k) sacc += sv[c * QP_KLDS + k] * qpws[li_ + sc[c * QP_KLDS + k] * nv];
+#pragma unroll
+              for (int k = 0; k < QP_KLDS; ++k) sacc += v4[k] * h4[k];
               HNw[li_ + c * nv] = sacc;
             }
-          __syncthreads();
-          if (li_ < wq)
-            for (int c2 = w4; c2 < wq; c2 += 4) {
+          }
+          wg_lds_barrier();
+          if (li_ < wq) {
+            double v4[QP_KLDS];
+            int c4[QP_KLDS];
+#pragma unroll
+            for (int k = 0; k < QP_KLDS; ++k) {
+              v4[k] = sv[li_ * QP_KLDS + k];
+              c4[k] = sc[li_ * QP_KLDS + k];
+            }
+#pragma unroll 2
+            for (int c2 = cg; c2 < wq; c2 += NG) {
+              double h4[QP_KLDS];
+#pragma unroll
+              for (int k = 0; k < QP_KLDS; ++k) h4[k] = HNw[c4[k] + c2 * nv];
               double sacc = 0.0;
-              for (int k = 0; k < K; ++k) sacc += sv[li_ * QP_KLDS + k] * HNw[sc[li_ * QP_KLDS + k] + c2 * nv];
+#pragma unroll
+              for (int k = 0; k < QP_KLDS; ++k) sacc += v4[k] * h4[k];
               Sw[li_ + c2 * nv] = sacc;
             }
-          __syncthreads();
+          }
+          wg_lds_barrier();
         } else {
           for (int c = tid; c < wq; c += 256) actw[c] = a.warm[1 + c];
           __syncthreads();

@@ -2,6 +2,13 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+// Barrier between phases that exchange data through LDS only.  __syncthreads() also waits for every global store of the wave
+// to be acknowledged (s_waitcnt vmcnt(0)); in a single-workgroup kernel that has just written results, exports or time stamps
+// - some of them into host memory - that is microseconds of waiting for nothing.
+__device__ __forceinline__ void wg_lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // 1/p: v_rcp_f64 and two Newton steps (the IEEE division sequence is ~3x longer and sits on every pivot's critical path)
 __device__ __forceinline__ double wg_recip(double p) {
   double ip = __builtin_amdgcn_rcp(p);
@@ -70,7 +77,7 @@ __device__ __forceinline__ int wg_spd_inverse_tiles(double* X, double* Y, int n,
         }
       }
     }
-    __syncthreads();
+    wg_lds_barrier();
     double* T_ = X;
     X = Y;
     Y = T_;
@@ -133,7 +140,7 @@ __device__ __forceinline__ int wg_spd_inverse_pairs(double* X, double* Y, int n,
       Wo[ld] = o01;
       Wo[ld + 1] = o11;
     }
-    __syncthreads();
+    wg_lds_barrier();
     double* T_ = R;
     R = Wn;
     Wn = T_;
@@ -145,7 +152,7 @@ __device__ __forceinline__ int wg_spd_inverse_pairs(double* X, double* Y, int n,
     Xo[ld] = o01;
     Xo[ld + 1] = o11;
   }
-  __syncthreads();
+  wg_lds_barrier();
   return bad;
 }
 
@@ -187,7 +194,7 @@ __device__ __forceinline__ int wg_spd_inverse_elems(double* X, double* Y, int n,
       for (int u = 0; u < 4; ++u)
         if (ix[u] >= 0) Y[ix[u]] = v[u];
     }
-    __syncthreads();
+    wg_lds_barrier();
     double* T_ = X;
     X = Y;
     Y = T_;
@@ -204,7 +211,7 @@ __device__ __forceinline__ int wg_spd_inverse_pp(double* X, double* Y, int n, in
   const int tid = threadIdx.x;
   if (in_Y && ((n & 1) || n > 32)) {               // only the pair sweep reads its matrix from either buffer
     for (int e = tid; e < n * ld; e += 256) X[e] = Y[e];
-    __syncthreads();
+    wg_lds_barrier();
     in_Y = false;
   }
   const double* D = in_Y ? Y : X;
@@ -226,7 +233,7 @@ __device__ __forceinline__ int wg_spd_inverse_pp(double* X, double* Y, int n, in
   if ((n & 1) && ld == n) {
     const int bad = wg_spd_inverse_elems(X, Y, n, ld, thr);     // odd number of steps: the result is in Y
     for (int e = tid; e < n * n; e += 256) X[e] = Y[e];
-    __syncthreads();
+    wg_lds_barrier();
     return bad;
   }
   if (n & 1) {
@@ -234,7 +241,7 @@ __device__ __forceinline__ int wg_spd_inverse_pp(double* X, double* Y, int n, in
       X[e + n * ld] = e == n ? 1.0 : 0.0;
       X[n + e * ld] = e == n ? 1.0 : 0.0;
     }
-    __syncthreads();
+    wg_lds_barrier();
     ++n;
   }
   if (n <= 32) return wg_spd_inverse_pairs(X, Y, n, ld, thr, in_Y ? Y : X);
