@@ -1027,22 +1027,6 @@ __device__ __forceinline__ void mpc_step_body(const MpcArgs& a) {
   const int tid = threadIdx.x;
   const int pb = blockIdx.x;
   const int N = a.N, m = a.m, Np = a.Np, nproj = a.nproj, nv = a.nvar, nr = a.nrows;
-  // warm start: the previous step's active rows and their (sparse) constraint entries are fetched NOW, so that their three
-  // dependent global loads (set size -> row ids -> entries, ~0.5 us each from L2) hide behind the lift and the assembly
-  int warm_q0 = 0, warm_row = 0;
-  double warm_val[QP_KLDS];
-  int warm_col[QP_KLDS];
-  if (WARM && a.warm) {
-    warm_q0 = a.warm[0];
-    if (tid < nv) warm_row = a.warm[1 + tid];
-    if (a.ell.K <= QP_KLDS) {
-#pragma unroll
-      for (int k = 0; k < QP_KLDS; ++k) {
-        warm_val[k] = (tid < nv && k < a.ell.K) ? a.ell.val[k * nr + warm_row] : 0.0;
-        warm_col[k] = (tid < nv && k < a.ell.K) ? a.ell.col[k * nr + warm_row] : 0;
-      }
-    }
-  }
   // a.alias (batched launches, one linearisation pass): the assembly's inputs z | beta | S | e are dead once Hq and f
   // exist, which is before the solver's scratch is first written - they live in its second n x n block, and a problem
   // takes 40.7 KB instead of 44.6: FOUR workgroups per CU instead of three.
@@ -1065,24 +1049,43 @@ __device__ __forceinline__ void mpc_step_body(const MpcArgs& a) {
   if (stamps && tid == 0) stamps[0] = wall_clock64();
 
   // The step's inputs lie in page-locked HOST memory in single-problem launches (zero-copy: no copy command on the latency
-  // path of a closed loop), so every access is a PCIe round trip of ~2 us.  u_prev and Yr are requested HERE, together with
-  // zeta / z below - one round trip instead of three behind each other (dictionary -> right-hand sides -> tracking error) -
-  // and parked in LDS arrays that are written for good only later: u_prev in f, Yr in e (which becomes P z - Yr in place).
-  // zeta (or the lifted state itself) likewise goes to LDS first - into z, which the dictionary evaluation reads and only the
-  // step after it overwrites.  All three requests are in flight before the first of them is waited for.
-  // The descriptor of this thread's first dictionary column does not depend on the state (and carries a monomial's exponent
-  // bytes, kp_basis_create): requested FIRST, the host words behind it, and everything is waited for once.
+  // path of a closed loop), so every access is a PCIe round trip of ~2.3 us.  u_prev, Yr and zeta / z are requested HERE,
+  // before anything else that has to be waited for - one round trip instead of three behind each other (dictionary ->
+  // right-hand sides -> tracking error) - and go straight to the LDS arrays that are written for good only later: u_prev
+  // to f, Yr to e (which becomes P z - Yr in place), zeta (or the lifted state itself) to z, which the dictionary evaluation
+  // reads and only the step after it overwrites.  By LDS-DMA (4-byte pieces: any alignment of the caller's block), one array
+  // per wave: no register waits for them.  (Measured and undone: everything that consumes them moved into the first pass of
+  // the linearisation loop, so that the loop's hoisted address arithmetic - ~2 us of scalar instructions after the tracking
+  // error - would run while the words are in flight: the hoisted block grew to ~1 500 instructions, longer than the round
+  // trip it was to hide behind, 32.6 against 31.7 us.)
+  const double* zin = a.has_basis ? a.zeta + (size_t)pb * a.basis.nzeta : a.z + (size_t)pb * N;
+  const int nzin = a.has_basis ? a.basis.nzeta : N, nyr = (Np + 1) * nproj;
+  {
+    typedef __attribute__((address_space(3))) char lds_char;
+    typedef __attribute__((address_space(1))) const char glb_char;
+    const int w_ = tid >> 6, l4 = (tid & 63) * 4;
+    const double* src = w_ == 0 ? zin : w_ == 1 ? Yr : up;
+    double* dst = w_ == 0 ? z : w_ == 1 ? ev : f;
+    const int bytes = w_ == 0 ? nzin * 8 : w_ == 1 ? nyr * 8 : w_ == 2 ? m * 8 : 0;
+    for (int o = 0; o < bytes; o += 256)
+      if (o + l4 < bytes) __builtin_amdgcn_global_load_lds((glb_char*)src + o + l4, (lds_char*)dst + o, 4, 0, 0);
+  }
   const double r_diag = tid < nv ? a.r[tid % m] : 0.0;      // diagonal of R for the Hessian (element tid of its first round)
   const double r_bq0 = tid < nr ? a.bq0[tid] : 0.0;         // constant right-hand sides (first round of the loop below)
   ColDesc cd0 = {};
   const bool pre0 = a.has_basis && tid < a.basis.nfull;
   if (pre0) cd0 = a.basis.cols[tid];
+  // warm start: the previous step's active set - its size and row ids are requested here, the rows' (sparse) entries, whose
+  // addresses need the ids, behind the barrier that publishes the host words (the ids have arrived by then): both round trips hide behind
+  // the host words and the lift, and no wait for an ordinary load stands between the LDS-DMA requests and that barrier (hipcc
+  // drains the whole vector-memory counter at such a wait while an LDS-DMA is in flight)
+  int warm_q0 = 0, warm_row = 0;
+  double warm_val[QP_KLDS];
+  int warm_col[QP_KLDS];
+#pragma unroll
+  for (int k = 0; k < QP_KLDS; ++k) { warm_val[k] = 0.0; warm_col[k] = 0; }
+  if (WARM && a.warm && tid < nv) warm_row = a.warm[1 + tid];      // (the set's size is wave-uniform: the compiler would wait for it at once)
   {
-    const double* zin = a.has_basis ? a.zeta + (size_t)pb * a.basis.nzeta : a.z + (size_t)pb * N;
-    const int nzin = a.has_basis ? a.basis.nzeta : N, nyr = (Np + 1) * nproj;
-    const double r_up = tid < m ? up[tid] : 0.0;
-    const double r_yr = tid < nyr ? Yr[tid] : 0.0;
-    const double r_z = tid < nzin ? zin[tid] : 0.0;
     // P | PB (constants of the model that every step reads once, 55 KB at N = 84) go to LDS by LDS-DMA while the host words
     // are on their way: no registers, nothing to wait for before the barrier below (hipcc drains vmcnt there)
     if (a.stage_off) {
@@ -1094,14 +1097,40 @@ __device__ __forceinline__ void mpc_step_body(const MpcArgs& a) {
       for (int o = wbase; o < a.stage_doubles * 8; o += 256 * 16)       // wave-uniform LDS base; each lane its own 16 source bytes
         __builtin_amdgcn_global_load_lds(src + o + lane16, dst + o, 16, 0, 0);
     }
-    if (tid < m) f[tid] = r_up;
-    if (tid < nyr) ev[tid] = r_yr;
-    if (tid < nzin) z[tid] = r_z;
-    for (int e = tid + 256; e < nyr; e += 256) ev[e] = Yr[e];
-    for (int c = tid + 256; c < nzin; c += 256) z[c] = zin[c];
-    __syncthreads();
-    if (stamps && tid == 0) stamps[10] = wall_clock64();      // host words and staged constants have landed
   }
+  int status = 0;
+  // lifted horizon along an input sequence x = [u_0; u_1; ...] (Kmpc.m:891-895)
+  auto lifted_horizon = [&](const double* x) {
+    if (tid < 64) {
+      for (int c = tid; c < N; c += 64) zh[c] = z[c];
+    }
+    __syncthreads();
+    for (int j = 0; j < Np; ++j) {
+      const double* zj = zh + (size_t)j * N;
+      for (int e = tid; e < N; e += 256) {
+        double s = 0.0;
+        for (int c = 0; c < N; ++c) s += a.A[e + (size_t)c * N] * zj[c];
+        for (int i = 0; i < m; ++i) {
+          const double* Bi = a.B + (size_t)i * N * N;
+          double t = 0.0;
+          for (int c = 0; c < N; ++c) t += Bi[e + (size_t)c * N] * zj[c];
+          s += t * x[j * m + i];
+        }
+        zh[(size_t)(j + 1) * N + e] = s;
+      }
+      __syncthreads();
+    }
+  };
+    __syncthreads();                                          // (with vmcnt(0): every LDS-DMA above has landed)
+    if (WARM && a.warm) warm_q0 = a.warm[0];
+    if (WARM && a.warm && a.ell.K <= QP_KLDS) {
+#pragma unroll
+      for (int k = 0; k < QP_KLDS; ++k) {
+        warm_val[k] = (tid < nv && k < a.ell.K) ? a.ell.val[k * nr + warm_row] : 0.0;
+        warm_col[k] = (tid < nv && k < a.ell.K) ? a.ell.col[k * nr + warm_row] : 0;
+      }
+    }
+    if (stamps && tid == 0) stamps[10] = wall_clock64();      // host words and staged constants have landed
   // ---- lifted state (Kmpc.m:842) ----
   if (a.has_basis) {
     const BasisDev& b = a.basis;
@@ -1171,30 +1200,7 @@ __device__ __forceinline__ void mpc_step_body(const MpcArgs& a) {
   };
   if (a.stage_off) track_err(sm + a.stage_off);
   else track_err(a.P);
-  int status = 0;
   if (stamps && tid == 0) stamps[1] = wall_clock64();
-  // lifted horizon along an input sequence x = [u_0; u_1; ...] (Kmpc.m:891-895)
-  auto lifted_horizon = [&](const double* x) {
-    if (tid < 64) {
-      for (int c = tid; c < N; c += 64) zh[c] = z[c];
-    }
-    __syncthreads();
-    for (int j = 0; j < Np; ++j) {
-      const double* zj = zh + (size_t)j * N;
-      for (int e = tid; e < N; e += 256) {
-        double s = 0.0;
-        for (int c = 0; c < N; ++c) s += a.A[e + (size_t)c * N] * zj[c];
-        for (int i = 0; i < m; ++i) {
-          const double* Bi = a.B + (size_t)i * N * N;
-          double t = 0.0;
-          for (int c = 0; c < N; ++c) t += Bi[e + (size_t)c * N] * zj[c];
-          s += t * x[j * m + i];
-        }
-        zh[(size_t)(j + 1) * N + e] = s;
-      }
-      __syncthreads();
-    }
-  };
   int iter0 = 0;
   if (a.U_lin) {                         // (uniform) a later pass of a state-bound step: linearise along the previous solution
     __syncthreads();
