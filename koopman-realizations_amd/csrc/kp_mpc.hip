@@ -1396,7 +1396,7 @@ __device__ __forceinline__ void mpc_step_body(const MpcArgs& a) {
       int* actw = (int*)(qpws + 3 * nv * nv + 9 * nv) + nv + (nv & 1);     // the solver's act[] (behind apv and apc)
       if (wq > 0) {
         const int K = a.ell.K;
-        if (K <= QP_KLDS) {
+        if (K <= QP_KLDS && 3 * QP_KLDS <= 2 * nv) {          // (the staged rows take 1.5 QP_KLDS nv doubles of Hq's nv^2)
           // rows staged in LDS (Hq is free between the two inverses): val [wq][4] | col [wq][4]; no global access and
           // no integer division in the two products (lane = row of the result, waves stride the columns)
           double* sv = Hq;

@@ -491,3 +491,36 @@ def test_stored_loaded_lift_rows_through_the_device_kernel(ctx, golden):
         rows = b.lift(F.LIFT_ROW, Z[:, :31], w)
         assert np.abs(rows - Z).max() < 1e-15, i
     b.close()
+
+
+@pytest.mark.parametrize("mt,N,m,Np,nproj", [("bilinear", 7, 1, 5, 3), ("bilinear", 12, 2, 7, 5), ("linear", 9, 3, 4, 4), ("bilinear", 40, 2, 6, 1),
+                                             ("bilinear", 120, 3, 10, 2), ("bilinear", 200, 3, 10, 2), ("linear", 30, 1, 9, 2)])
+def test_assembly_and_solve_on_random_models_of_other_shapes(ctx, mt, N, m, Np, nproj):
+    """Shapes the arm models do not have: 1 - 5 tracked outputs (the Hessian assembly is specialised for nproj <= 4 and generic
+    beyond), one input (odd variable counts: the bordered pair sweep of the workgroup inverse), models whose constant blocks
+    P | P_k B_i fit the step kernel's LDS staging (N = 120) and models where they do not (N = 200), linear models (no P_k B_i).
+    QP data against the literal assembly of Kmpc.m:861-883, the optimum against the exact active-set solve, single steps
+    (warm-started from the step before, staged constants) against the batched launch (cold, constants from L2)."""
+    rng = np.random.default_rng(1000 * N + 10 * Np + nproj)
+    A = 0.9 * np.linalg.qr(rng.standard_normal((N, N)))[0] + 0.02 * rng.standard_normal((N, N))
+    B = 0.5 * rng.standard_normal((N, m)) if mt == "linear" else 0.5 / np.sqrt(N) * rng.standard_normal((N, N * m))
+    proj = rng.standard_normal((nproj, N)) / np.sqrt(N)
+    s = ko.MpcSetup(model_type=mt, A=A, B=B, m=m, Np=Np, projmtx=proj, cost_running=2.0, cost_terminal=7.0,
+                    cost_input=0.05 + 0.01 * np.arange(m), input_bounds=np.tile([-0.6, 0.7], (m, 1)), slope_lim=0.25, smooth_lim=None, n=min(N, 3))
+    mpc = make_mpc(ctx, s)
+    Z, UP, YR, Us = [], [], [], []
+    for trial in range(6):
+        z = 0.3 * rng.standard_normal(N); z[-1] = 1.0
+        u_prev = rng.uniform(-0.5, 0.5, m)
+        ref = 0.6 * rng.standard_normal((Np + 1, nproj))
+        U, st = mpc.step(z, u_prev, ko.pad_ref(ref, Np))
+        Hd, fd, Ad, bd = mpc.last_qp()
+        Hr, fr, Ar, br = ko.mpc_qp(s, z, u_prev, ref)
+        assert np.abs(Hd - Hr).max() <= 1e-11 * np.abs(Hr).max() and np.abs(fd - fr).max() <= 1e-11 * max(1.0, np.abs(fr).max())
+        assert np.array_equal(Hd, Hd.T)                                # (assembled from the upper triangle)
+        assert np.abs(Ad - Ar).max() == 0 and np.abs(bd - br).max() <= 1e-14
+        x, lam, ok = ko.qp_solve(Hr, fr, Ar, br)
+        assert ok and st == 0 and np.abs(U - x.reshape(Np, m)).max() < 1e-8
+        Z.append(z); UP.append(u_prev); YR.append(ko.pad_ref(ref, Np)); Us.append(U)
+    Ub, stb = mpc.step_batch(np.array(Z), np.array(UP), np.array(YR))
+    assert (stb == 0).all() and np.abs(Ub - np.array(Us)).max() < 1e-9
