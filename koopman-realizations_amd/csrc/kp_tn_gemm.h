@@ -10,11 +10,13 @@
 // doubles), one barrier per block, operand addresses base + immediate, result tile through LDS so that the stores run along
 // the columns of C, XCD-aware workgroup order.  New here: general leading dimensions (64-bit tile bases + 32-bit offsets),
 // a contraction RANGE per workgroup (split-K over blockIdx.y into partial buffers, summed in split order by
-// kp_tn_gemm_reduce_kernel: bitwise reproducible), the alpha / beta epilogue and the triangular tile skip.
+// kp_tn_gemm_reduce_kernel: bitwise reproducible), the alpha / beta epilogue, the triangular tile skip, and optional weights
+// of the contraction index (the Kronecker form of bilinear Gram matrices, kp_wide.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <algorithm>
 
 #define TNG_KB 16
 #define TNG_RS 20
@@ -36,7 +38,9 @@ struct TngArgs {
   int M, N, K;
   int kper;                  // contraction range of a split (multiple of TNG_KB)
   int nsplit, nrt, nct, tri;
+  int per_xcd;               // tri: active tiles per XCD (launcher)
   double alpha, beta;
+  const double *wa, *wb;     // optional row weights (length K each, nullptr = 1): C += alpha sum_k wa[k] wb[k] A[k,:]' B[k,:]
 };
 
 template <int RA, int RB>
@@ -46,10 +50,28 @@ __global__ __launch_bounds__(256, 2) void kp_tn_gemm_kernel(TngArgs g) {
   extern __shared__ double sm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int ct = (slot / g.nrt) * 8 + xcd, rt = slot % g.nrt;
-  if (ct >= g.nct) return;
+  int ct, rt;
+  if (!g.tri) {
+    ct = (slot / g.nrt) * 8 + xcd;
+    rt = slot % g.nrt;
+    if (ct >= g.nct) return;
+  } else {
+    // upper tiles only (a tile strictly below the diagonal is read by nobody): the ACTIVE tiles, listed column by column, are
+    // dealt to the XCDs in contiguous runs of g.per_xcd.  (Dealing whole tile columns ct = xcd mod 8 as above left XCD 0 with
+    // one tile and XCD 7 with six of a 6 x 8 grid: two rounds of workgroups on one XCD while others idled - the weighted
+    // 735-wide products of the Kronecker form took 3.2 ms with half the tiles of the 2.8 ms full products.)
+    int t = xcd * g.per_xcd + slot;
+    if (slot >= g.per_xcd) return;
+    ct = 0;
+    for (; ct < g.nct; ++ct) {
+      const int cnt = min(g.nrt, (ct * TN + TN - 1) / TM + 1);
+      if (t < cnt) break;
+      t -= cnt;
+    }
+    if (ct >= g.nct) return;
+    rt = t;
+  }
   const int r0 = rt * TM, c0 = ct * TN;
-  if (g.tri && r0 > c0 + TN - 1) return;            // tile strictly below the diagonal: nobody reads it
   const int split = blockIdx.y;
   const int k_lo = split * g.kper, k_hi = min(g.K, k_lo + g.kper);
   const int klen = max(0, k_hi - k_lo);
@@ -69,8 +91,9 @@ __global__ __launch_bounds__(256, 2) void kp_tn_gemm_kernel(TngArgs g) {
   const char* Ab = (const char*)(g.A + (int64_t)r0 * g.lda + k_lo);
   const char* Bb = (const char*)(g.B + (int64_t)c0 * g.ldb + k_lo);
   const int so = sr * RS + sk;
-  double sg[RA], sx[RB];
+  double sg[RA], sx[RB], swa = 1.0, swb = 1.0;
   const int nkb = (klen + KB - 1) / KB, nkb_full = klen / KB;
+  const bool weighted = g.wa != nullptr || g.wb != nullptr;
   auto stage_load = [&](int kb) {
     if (kb < nkb_full) {
       const unsigned ko = (unsigned)kb * (KB * 8u);
@@ -78,6 +101,11 @@ __global__ __launch_bounds__(256, 2) void kp_tn_gemm_kernel(TngArgs g) {
       for (int p = 0; p < RA; ++p) sg[p] = *(const double*)(Ab + (go[p] + ko));
 #pragma unroll
       for (int p = 0; p < RB; ++p) sx[p] = *(const double*)(Bb + (xo[p] + ko));
+      if (weighted) {                     // (uniform) the weight of contraction index k rides on the A operand; it is applied
+        const int k = k_lo + kb * KB + sk;     // in stage_store: a product here would wait for the loads before the MFMAs they hide behind
+        swa = g.wa ? g.wa[k] : 1.0;
+        swb = g.wb ? g.wb[k] : 1.0;
+      }
     } else {
       const int k = kb * KB + sk;
       const bool kok = k < klen;
@@ -86,10 +114,20 @@ __global__ __launch_bounds__(256, 2) void kp_tn_gemm_kernel(TngArgs g) {
       for (int p = 0; p < RA; ++p) { const double v = *(const double*)(Ab + (go[p] + ko)); sg[p] = kok ? v : 0.0; }
 #pragma unroll
       for (int p = 0; p < RB; ++p) { const double v = *(const double*)(Bb + (xo[p] + ko)); sx[p] = kok ? v : 0.0; }
+      if (weighted) {
+        const int kc = k_lo + (kok ? k : klen - 1);
+        swa = g.wa ? g.wa[kc] : 1.0;
+        swb = g.wb ? g.wb[kc] : 1.0;
+      }
     }
   };
   auto stage_store = [&](int buf) {
     double* d = sm + buf * BUF + so;
+    if (weighted) {
+      const double w = swa * swb;
+#pragma unroll
+      for (int p = 0; p < RA; ++p) sg[p] *= w;
+    }
 #pragma unroll
     for (int p = 0; p < RA; ++p) d[16 * p * RS] = sg[p];
 #pragma unroll
@@ -195,6 +233,15 @@ static __global__ __launch_bounds__(256) void kp_mirror_upper_kernel(double* __r
   if (r < n && c < n && r > c) A[(int64_t)c * ld + r] = T[ti][tj];
 }
 
+// output tiles (tm x tn) that a product runs: all of them, or those that meet the upper triangle
+static inline int64_t tng_count_tiles(int M, int N, int tm, int tn, int tri) {
+  const int nrt = (M + tm - 1) / tm, nct = (N + tn - 1) / tn;
+  if (!tri) return (int64_t)nrt * nct;
+  int64_t cnt = 0;
+  for (int r = 0; r < nrt; ++r)
+    for (int c = 0; c < nct; ++c) cnt += r * tm <= c * tn + tn - 1 ? 1 : 0;
+  return cnt;
+}
 template <int RA, int RB>
 static hipError_t tng_launch_cfg(hipStream_t st, TngArgs g) {
   using Cfg = TngCfg<RA, RB>;
@@ -208,7 +255,13 @@ static hipError_t tng_launch_cfg(hipStream_t st, TngArgs g) {
   }
   g.nrt = (g.M + Cfg::TM - 1) / Cfg::TM;
   g.nct = (g.N + Cfg::TN - 1) / Cfg::TN;
-  const int nblk = 8 * ((g.nct + 7) / 8) * g.nrt;
+  int nblk = 8 * ((g.nct + 7) / 8) * g.nrt;
+  g.per_xcd = 0;
+  if (g.tri) {
+    const int64_t act = tng_count_tiles(g.M, g.N, Cfg::TM, Cfg::TN, 1);
+    g.per_xcd = (int)((act + 7) / 8);
+    nblk = 8 * g.per_xcd;
+  }
   hipLaunchKernelGGL((kp_tn_gemm_kernel<RA, RB>), dim3(nblk, g.nsplit), dim3(256), Cfg::LDS_BYTES, st, g);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess || g.nsplit <= 1) return e;
@@ -217,26 +270,60 @@ static hipError_t tng_launch_cfg(hipStream_t st, TngArgs g) {
   return hipGetLastError();
 }
 
-// Number of contraction splits that fills the device: `slots` workgroup slots (2 per CU), `tiles` output tiles.
-static inline int tng_pick_splits(int M, int N, int K, int tri, int slots) {
-  const int64_t tiles = (int64_t)((M + 127) / 128) * ((N + 63) / 64) / (tri ? 2 : 1) + 1;
-  int ns = (int)((slots + tiles - 1) / tiles);
-  const int max_by_k = (K + 16 * TNG_KB - 1) / (16 * TNG_KB);      // at least 16 contraction blocks per split
-  if (ns > max_by_k) ns = max_by_k;
-  if (ns > 64) ns = 64;
-  return ns < 1 ? 1 : ns;
+// How many workgroups a product is cut into decides how well it fills the chip: its workgroups all take the same time, so they
+// run in rounds of `slots` (2 per CU) and a product of 1.1 rounds takes as long as one of 2.  (The dense bilinear W = 2 940
+// products ran 370 and 713 workgroups - 0.72 and 1.39 rounds - and the 735-wide weighted products of the Kronecker form 546
+// and 576; measured: the weighted form, 62.5 % of the flops, took 96 % of the time.)  The planner counts the tiles that will
+// actually run, for 96- and 64-column tiles, and picks the contraction split whose last round is fullest; wider tiles and
+// fewer splits win ties (192 instead of 128 MFMAs per wave between two barriers; fewer partial sums to write and add).
+// (M x N in tm x tn tiles, ns splits.)  The workgroups of a launch are dealt to the 8 XCDs round-robin and every XCD has its
+// own slots / 8: what counts is the fullest XCD - full products give XCD x the tile columns x, x + 8, ...; triangular ones
+// ceil(active / 8) tiles each (kp_tn_gemm_kernel).  30 active tiles x 17 splits are 510 workgroups on 512 slots and still
+// TWO rounds: 4 x 17 = 68 on the 64 slots of seven XCDs (measured: as long as the full product's 1 008).
+static inline double tng_score(int M, int N, int tm, int tn, int tri, int ns, int slots, int cols) {
+  const int64_t tiles = tng_count_tiles(M, N, tm, tn, tri);
+  const int nrt = (M + tm - 1) / tm, nct = (N + tn - 1) / tn;
+  const int64_t per_xcd = tri ? (tiles + 7) / 8 : (int64_t)nrt * ((nct + 7) / 8);
+  const int64_t xs = slots / 8 > 0 ? slots / 8 : 1, rounds = (per_xcd * ns + xs - 1) / xs;
+  const double fill = (double)(tiles * ns) / (double)(rounds * xs * 8);
+  return fill * (cols == 96 ? 1.0 : 0.9) * (1.0 - 0.004 * (ns - 1));
 }
-
-// Columns per workgroup of the 128-row form: 96 (192 MFMAs per wave between two barriers instead of 128: the bilinear W = 2 940
-// Gram pass 70.5 -> 64.4 ms per 1e5 pairs) when that still fills the chip's 512 workgroup slots, else 64.  KP_TNG_RB=4 keeps 64.
-static inline int tng_tile_cols(int M, int N, int nsplit, int tri) {
+static inline bool tng_allow_96() {
   static const int wide_cols = [] { const char* e = getenv("KP_TNG_RB"); return e ? atoi(e) : 6; }();
-  return (wide_cols == 6 && (int64_t)((M + 127) / 128) * ((N + 95) / 96) * (nsplit > 1 ? nsplit : 1) / (tri ? 2 : 1) >= 512) ? 96 : 64;
+  return wide_cols == 6;
+}
+// Columns per workgroup of the 128-row form for a product that runs with `nsplit` contraction splits.
+static inline int tng_tile_cols(int M, int N, int nsplit, int tri, int slots = 512) {
+  const int ns = nsplit > 1 ? nsplit : 1;
+  if (!tng_allow_96()) return 64;
+  return tng_score(M, N, 128, 96, tri, ns, slots, 96) >= tng_score(M, N, 128, 64, tri, ns, slots, 64) ? 96 : 64;
+}
+// Number of contraction splits: `slots` workgroup slots (2 per CU); at least 16 contraction blocks per split, at most 64 splits.
+static inline int tng_pick_splits(int M, int N, int K, int tri, int slots) {
+  int max_ns = K / (16 * TNG_KB);
+  max_ns = max_ns < 1 ? 1 : max_ns > 64 ? 64 : max_ns;
+  if (M <= 64) {                                            // the 64 x 64 form
+    int best = 1;
+    double bs = -1.0;
+    for (int ns = 1; ns <= max_ns; ++ns) {
+      const double sc = tng_score(M, N, 64, 64, tri, ns, slots, 96);
+      if (sc > bs) { bs = sc; best = ns; }
+    }
+    return best;
+  }
+  int best = 1;
+  double bs = -1.0;
+  for (int ns = 1; ns <= max_ns; ++ns) {
+    const double sc = std::max(tng_allow_96() ? tng_score(M, N, 128, 96, tri, ns, slots, 96) : -1.0, tng_score(M, N, 128, 64, tri, ns, slots, 64));
+    if (sc > bs) { bs = sc; best = ns; }
+  }
+  return best;
 }
 
 // P (or nullptr): room for nsplit * M * N doubles when nsplit > 1.
+// wa, wb (or nullptr): row weights, see TngArgs.
 static inline hipError_t kp_tn_gemm(hipStream_t st, const double* A, int64_t lda, const double* B, int64_t ldb, int M, int N, int K, double* C, int64_t ldc,
-                                    double alpha, double beta, int tri, int nsplit, double* P) {
+                                    double alpha, double beta, int tri, int nsplit, double* P, const double* wa = nullptr, const double* wb = nullptr) {
   if (M <= 0 || N <= 0) return hipSuccess;
   // tile rows are addressed by 32-bit byte offsets from the tile's base
   if ((uint64_t)128 * (uint64_t)(lda > ldb ? lda : ldb) * 8u + (uint64_t)K * 8u >= (1ull << 32)) return hipErrorInvalidValue;
@@ -252,6 +339,7 @@ static inline hipError_t kp_tn_gemm(hipStream_t st, const double* A, int64_t lda
   g.nrt = g.nct = 0;
   g.tri = tri;
   g.alpha = alpha; g.beta = beta;
+  g.wa = wa; g.wb = wb;
   if (M <= 64) return tng_launch_cfg<4, 4>(st, g);
   if (tng_tile_cols(M, N, g.nsplit, tri) == 96) return tng_launch_cfg<8, 6>(st, g);
   return tng_launch_cfg<8, 4>(st, g);

@@ -72,6 +72,36 @@ def test_wide_gram_accumulates_over_panels(ctx):
     assert np.abs(G3 - Gr).max() <= 1e-12 * s and np.abs(C3 - Cr).max() <= 1e-12 * s
 
 
+def test_wide_bilinear_kronecker_form_equals_the_dense_products(ctx):
+    """Bilinear wide dictionaries go through (m+1)(m+2)/2 weighted products of the N-wide panel of psi (block (a, b) of Px'Px is
+    sum_k ut_a ut_b psi psi', ut = [1; u]); KP_WIDE_DENSE=1 keeps the dense products of the N(m+1)-wide panel.  Same Grams to
+    rounding, over several panels with a ragged last one, exactly symmetric, and block (b, a) of C the bitwise copy of (a, b)."""
+    pairs = synth_pairs(2500, 6, 3, seed=21)
+    dic = ko.build_dictionary("bilinear", 6, 3, ["poly"], [4])
+    b = make_basis(ctx, dic)
+    N, m = b.N, 3
+    assert b.W == N * (m + 1) == 840
+    snaps = kra.Snapshots(ctx, pairs["alpha"], pairs["beta"], pairs["u"])
+    os.environ["KP_WIDE_PANEL_MB"] = "2"                 # 1 248-row panels of psi: 3 panels
+    try:
+        Gk, Ck = kra.fit_gram(ctx, b, snaps)
+        os.environ["KP_WIDE_DENSE"] = "1"
+        Gd, Cd = kra.fit_gram(ctx, b, snaps)
+    finally:
+        os.environ.pop("KP_WIDE_DENSE", None)
+        del os.environ["KP_WIDE_PANEL_MB"]
+    s = np.abs(Gd).max()
+    assert np.abs(Gk - Gd).max() <= 1e-13 * s and np.abs(Ck - Cd).max() <= 1e-13 * s
+    assert (Gk == Gk.T).all()
+    for a in range(m + 1):
+        for c in range(a + 1, m + 1):
+            assert (Ck[a * N:(a + 1) * N, c * N:(c + 1) * N] == Ck[c * N:(c + 1) * N, a * N:(a + 1) * N]).all()
+            assert (Gk[a * N:(a + 1) * N, c * N:(c + 1) * N] == Gk[a * N:(a + 1) * N, c * N:(c + 1) * N].T).all()
+    Px, Py = ko.px_py(dic, pairs)
+    Gr, Cr = ko.gram(Px, Py)
+    assert np.abs(Gk - Gr).max() <= 1e-12 * s and np.abs(Ck - Cr).max() <= 1e-12 * s
+
+
 @pytest.mark.parametrize("W,nc,bs", [(513, 513, None), (600, 7, None), (777, 777, 128), (1000, 1000, None), (1000, 33, 352), (2940, 64, None)])
 def test_wide_solve_random_spd(ctx, W, nc, bs):
     """kp_fit_solve beyond one workgroup's reach: blocked factorisation + substitution, ragged sizes, few and many
