@@ -459,7 +459,7 @@ def bench_wide_points(ctx, kra):
             gram_ms, solve_ms, ex = ctx.timer(0), ctx.timer(1), ctx.timer(10)
             out[f"{mt}_W{W}_Ns{Ns}"] = {"W": W, "snapshots": Ns, "ms_per_fit": dt * 1e3, "pairs_per_s": Ns / dt, "gram_ms": gram_ms, "solve_ms": solve_ms,
                                         "rank": ctx.last_rank(),
-                                        "roofline": roofline_block("kp_lift_kernel + kp_tn_gemm_kernel<8,4> (Px'Px upper tiles, Px'Py)", ex * Ns, F_ * Ns, gram_ms,
+                                        "roofline": roofline_block("kp_lift_kernel + kp_tn_gemm_kernel<8,6|4> (upper tiles of Px'Px, Px'Py; bilinear rows: 10 weighted products each of the psi panel)", ex * Ns, F_ * Ns, gram_ms,
                                                                    note="gram_ms includes the lift of the panel (fourier: 6 sincos per function and snapshot)"),
                                         "solve_flop": W ** 3 / 3.0 + 2.0 * W ** 3, "solve_tflops": (W ** 3 / 3.0 + 2.0 * W ** 3) / (solve_ms * 1e-3) / 1e12}
             sn.close()
