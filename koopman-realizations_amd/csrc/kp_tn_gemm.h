@@ -21,9 +21,13 @@
 #define TNG_KB 16
 #define TNG_RS 20
 
-template <int RA, int RB>
+// NW waves per workgroup (4, two workgroups per CU; or 8, one): wave w owns the rows [4 RA w, 4 RA (w + 1)) of the tile
+template <int RA, int RB, int NW = 4>
 struct TngCfg {
-  static constexpr int TM = 16 * RA, TN = 16 * RB;
+  static constexpr int NT = 64 * NW;
+  static constexpr int TM = 4 * RA * NW, TN = 16 * RB;
+  static constexpr int PB = 4 * RB / NW;                           // staging loads of B per thread (A: RA)
+  static_assert(4 * RB % NW == 0, "tile columns must divide over the staging threads");
   static constexpr int BUF = (TM + TN) * TNG_RS;
   static constexpr int OS = TM + 4;
   static constexpr int ECH = RB < 4 ? RB : 4;
@@ -43,10 +47,11 @@ struct TngArgs {
   const double *wa, *wb;     // optional row weights (length K each, nullptr = 1): C += alpha sum_k wa[k] wb[k] A[k,:]' B[k,:]
 };
 
-template <int RA, int RB>
-__global__ __launch_bounds__(256, 2) void kp_tn_gemm_kernel(TngArgs g) {
-  using Cfg = TngCfg<RA, RB>;
+template <int RA, int RB, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void kp_tn_gemm_kernel(TngArgs g) {
+  using Cfg = TngCfg<RA, RB, NW>;
   constexpr int TM = Cfg::TM, TN = Cfg::TN, BUF = Cfg::BUF, OS = Cfg::OS, RS = TNG_RS, KB = TNG_KB, ECH = Cfg::ECH;
+  constexpr int NT = Cfg::NT, SR = NT / 16, PB = Cfg::PB;          // SR rows of a tile are staged per pass of the workgroup
   extern __shared__ double sm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -77,21 +82,21 @@ __global__ __launch_bounds__(256, 2) void kp_tn_gemm_kernel(TngArgs g) {
   const int klen = max(0, k_hi - k_lo);
 
   const int sk = tid & 15, sr = tid >> 4;
-  unsigned go[RA], xo[RB];
+  unsigned go[RA], xo[PB];
 #pragma unroll
   for (int p = 0; p < RA; ++p) {
-    const int row = sr + 16 * p;
+    const int row = sr + SR * p;
     go[p] = (unsigned)(((int64_t)(r0 + row < g.M ? row : 0) * g.lda + sk) * 8);
   }
 #pragma unroll
-  for (int p = 0; p < RB; ++p) {
-    const int col = sr + 16 * p;
+  for (int p = 0; p < PB; ++p) {
+    const int col = sr + SR * p;
     xo[p] = (unsigned)(((int64_t)(c0 + col < g.N ? col : 0) * g.ldb + sk) * 8);
   }
   const char* Ab = (const char*)(g.A + (int64_t)r0 * g.lda + k_lo);
   const char* Bb = (const char*)(g.B + (int64_t)c0 * g.ldb + k_lo);
   const int so = sr * RS + sk;
-  double sg[RA], sx[RB], swa = 1.0, swb = 1.0;
+  double sg[RA], sx[PB], swa = 1.0, swb = 1.0;
   const int nkb = (klen + KB - 1) / KB, nkb_full = klen / KB;
   const bool weighted = g.wa != nullptr || g.wb != nullptr;
   auto stage_load = [&](int kb) {
@@ -100,7 +105,7 @@ __global__ __launch_bounds__(256, 2) void kp_tn_gemm_kernel(TngArgs g) {
 #pragma unroll
       for (int p = 0; p < RA; ++p) sg[p] = *(const double*)(Ab + (go[p] + ko));
 #pragma unroll
-      for (int p = 0; p < RB; ++p) sx[p] = *(const double*)(Bb + (xo[p] + ko));
+      for (int p = 0; p < PB; ++p) sx[p] = *(const double*)(Bb + (xo[p] + ko));
       if (weighted) {                     // (uniform) the weight of contraction index k rides on the A operand; it is applied
         const int k = k_lo + kb * KB + sk;     // in stage_store: a product here would wait for the loads before the MFMAs they hide behind
         swa = g.wa ? g.wa[k] : 1.0;
@@ -113,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void kp_tn_gemm_kernel(TngArgs g) {
 #pragma unroll
       for (int p = 0; p < RA; ++p) { const double v = *(const double*)(Ab + (go[p] + ko)); sg[p] = kok ? v : 0.0; }
 #pragma unroll
-      for (int p = 0; p < RB; ++p) { const double v = *(const double*)(Bb + (xo[p] + ko)); sx[p] = kok ? v : 0.0; }
+      for (int p = 0; p < PB; ++p) { const double v = *(const double*)(Bb + (xo[p] + ko)); sx[p] = kok ? v : 0.0; }
       if (weighted) {
         const int kc = k_lo + (kok ? k : klen - 1);
         swa = g.wa ? g.wa[kc] : 1.0;
@@ -129,9 +134,9 @@ __global__ __launch_bounds__(256, 2) void kp_tn_gemm_kernel(TngArgs g) {
       for (int p = 0; p < RA; ++p) sg[p] *= w;
     }
 #pragma unroll
-    for (int p = 0; p < RA; ++p) d[16 * p * RS] = sg[p];
+    for (int p = 0; p < RA; ++p) d[SR * p * RS] = sg[p];
 #pragma unroll
-    for (int p = 0; p < RB; ++p) d[(TM + 16 * p) * RS] = sx[p];
+    for (int p = 0; p < PB; ++p) d[(TM + SR * p) * RS] = sx[p];
   };
 
   const int lc = lane & 3, blk = (lane >> 2) & 3, lk = lane >> 4;
@@ -192,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void kp_tn_gemm_kernel(TngArgs g) {
       for (int rb = 0; rb < ECH; ++rb)
         if (ch + rb < RB) sm[(16 * rb + 4 * blk + lc) * OS + wave * 4 * RA + 4 * ra + lk] = acc[ra][ch + rb];
     __syncthreads();
-    for (int e = tid; e < TM * 16 * ECH; e += 256) {
+    for (int e = tid; e < TM * 16 * ECH; e += NT) {
       const int j = e / TM, i = e - j * TM, jc = c0 + 16 * ch + j;
       if (r0 + i < g.M && jc < g.N && 16 * ch + j < TN) {
         const double v = sm[j * OS + i];
@@ -242,14 +247,14 @@ static inline int64_t tng_count_tiles(int M, int N, int tm, int tn, int tri) {
     for (int c = 0; c < nct; ++c) cnt += r * tm <= c * tn + tn - 1 ? 1 : 0;
   return cnt;
 }
-template <int RA, int RB>
+template <int RA, int RB, int NW = 4>
 static hipError_t tng_launch_cfg(hipStream_t st, TngArgs g) {
-  using Cfg = TngCfg<RA, RB>;
+  using Cfg = TngCfg<RA, RB, NW>;
   static bool attr_set[32] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev < 0 || dev >= 32 || !attr_set[dev]) {
-    hipError_t e = hipFuncSetAttribute((const void*)kp_tn_gemm_kernel<RA, RB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)kp_tn_gemm_kernel<RA, RB, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
     if (e != hipSuccess) return e;
     if (dev >= 0 && dev < 32) attr_set[dev] = true;
   }
@@ -262,7 +267,7 @@ static hipError_t tng_launch_cfg(hipStream_t st, TngArgs g) {
     g.per_xcd = (int)((act + 7) / 8);
     nblk = 8 * g.per_xcd;
   }
-  hipLaunchKernelGGL((kp_tn_gemm_kernel<RA, RB>), dim3(nblk, g.nsplit), dim3(256), Cfg::LDS_BYTES, st, g);
+  hipLaunchKernelGGL((kp_tn_gemm_kernel<RA, RB, NW>), dim3(nblk, g.nsplit), dim3(Cfg::NT), Cfg::LDS_BYTES, st, g);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess || g.nsplit <= 1) return e;
   hipLaunchKernelGGL(kp_tn_gemm_reduce_kernel, dim3((unsigned)(((int64_t)g.M * g.N + 255) / 256)), dim3(256), 0, st, g.P, g.nsplit, g.M, g.N, g.C, g.ldc,
@@ -280,43 +285,65 @@ static hipError_t tng_launch_cfg(hipStream_t st, TngArgs g) {
 // own slots / 8: what counts is the fullest XCD - full products give XCD x the tile columns x, x + 8, ...; triangular ones
 // ceil(active / 8) tiles each (kp_tn_gemm_kernel).  30 active tiles x 17 splits are 510 workgroups on 512 slots and still
 // TWO rounds: 4 x 17 = 68 on the 64 slots of seven XCDs (measured: as long as the full product's 1 008).
-static inline double tng_score(int M, int N, int tm, int tn, int tri, int ns, int slots, int cols) {
-  const int64_t tiles = tng_count_tiles(M, N, tm, tn, tri);
-  const int nrt = (M + tm - 1) / tm, nct = (N + tn - 1) / tn;
+// The forms of the 128-row-and-up product: tile, workgroups per CU, relative speed of a FULL round (measured).  The two
+// eight-wave forms (ONE workgroup per CU, 256 x 96 and 192 x 128: 1.3 - 1.4 x fewer operand bytes from L2 per flop) are built
+// and OFF: all eight waves meet at one barrier per contraction block, and the bilinear W = 2 940 Gram pass took 59 - 60 ms
+// with either against 42.6 ms with two independent 128 x 96 workgroups per CU (KP_TNG_FORCE=2 / 3; KP_TNG_BIG=w enables them
+// with weight w) - the same lock-step loss as every one-workgroup-per-CU form measured in rounds 2 - 4.
+struct TngShape { int tm, tn, wg_per_cu; double w; };
+#define TNG_NSHAPES 4
+static inline const TngShape* tng_shapes() {
+  static const double big = [] { const char* e = getenv("KP_TNG_BIG"); return e ? atof(e) : 0.0; }();
+  static const TngShape sh[TNG_NSHAPES] = {{128, 64, 2, 0.9}, {128, 96, 2, 1.0}, {256, 96, 1, big}, {192, 128, 1, big}};
+  return sh;
+}
+static inline bool tng_shape_on(int i) {
+  static const int wide_cols = [] { const char* e = getenv("KP_TNG_RB"); return e ? atoi(e) : 6; }();      // KP_TNG_RB=4: 64 columns only
+  static const int force = [] { const char* e = getenv("KP_TNG_FORCE"); return e ? atoi(e) : -1; }();       // one form only (measurements)
+  if (force >= 0) return i == force;
+  return i == 0 || (wide_cols == 6 && (i == 1 || tng_shapes()[i].w > 0.0));
+}
+static inline double tng_score(int M, int N, const TngShape& sh, int tri, int ns, int slots) {
+  const int64_t tiles = tng_count_tiles(M, N, sh.tm, sh.tn, tri);
+  const int nrt = (M + sh.tm - 1) / sh.tm, nct = (N + sh.tn - 1) / sh.tn;
   const int64_t per_xcd = tri ? (tiles + 7) / 8 : (int64_t)nrt * ((nct + 7) / 8);
-  const int64_t xs = slots / 8 > 0 ? slots / 8 : 1, rounds = (per_xcd * ns + xs - 1) / xs;
+  const int64_t xs = std::max(1, slots * sh.wg_per_cu / 16), rounds = (per_xcd * ns + xs - 1) / xs;
+  // work done per round-slot, in units of the 128 x 96 tile's
   const double fill = (double)(tiles * ns) / (double)(rounds * xs * 8);
-  return fill * (cols == 96 ? 1.0 : 0.9) * (1.0 - 0.004 * (ns - 1));
+  return fill * sh.w * (1.0 - 0.004 * (ns - 1));
 }
-static inline bool tng_allow_96() {
-  static const int wide_cols = [] { const char* e = getenv("KP_TNG_RB"); return e ? atoi(e) : 6; }();
-  return wide_cols == 6;
-}
-// Columns per workgroup of the 128-row form for a product that runs with `nsplit` contraction splits.
-static inline int tng_tile_cols(int M, int N, int nsplit, int tri, int slots = 512) {
+// Form (index into tng_shapes) of a product that runs with `nsplit` contraction splits.
+static inline int tng_pick_shape(int M, int N, int nsplit, int tri, int slots = 512) {
   const int ns = nsplit > 1 ? nsplit : 1;
-  if (!tng_allow_96()) return 64;
-  return tng_score(M, N, 128, 96, tri, ns, slots, 96) >= tng_score(M, N, 128, 64, tri, ns, slots, 64) ? 96 : 64;
+  int best = 0;
+  double bs = -1.0;
+  for (int i = 0; i < TNG_NSHAPES; ++i) {
+    if (!tng_shape_on(i)) continue;
+    const double sc = tng_score(M, N, tng_shapes()[i], tri, ns, slots);
+    if (sc > bs) { bs = sc; best = i; }
+  }
+  return best;
 }
 // Number of contraction splits: `slots` workgroup slots (2 per CU); at least 16 contraction blocks per split, at most 64 splits.
 static inline int tng_pick_splits(int M, int N, int K, int tri, int slots) {
   int max_ns = K / (16 * TNG_KB);
   max_ns = max_ns < 1 ? 1 : max_ns > 64 ? 64 : max_ns;
+  int best = 1;
+  double bs = -1.0;
   if (M <= 64) {                                            // the 64 x 64 form
-    int best = 1;
-    double bs = -1.0;
+    const TngShape small{64, 64, 2, 1.0};
     for (int ns = 1; ns <= max_ns; ++ns) {
-      const double sc = tng_score(M, N, 64, 64, tri, ns, slots, 96);
+      const double sc = tng_score(M, N, small, tri, ns, slots);
       if (sc > bs) { bs = sc; best = ns; }
     }
     return best;
   }
-  int best = 1;
-  double bs = -1.0;
-  for (int ns = 1; ns <= max_ns; ++ns) {
-    const double sc = std::max(tng_allow_96() ? tng_score(M, N, 128, 96, tri, ns, slots, 96) : -1.0, tng_score(M, N, 128, 64, tri, ns, slots, 64));
-    if (sc > bs) { bs = sc; best = ns; }
-  }
+  for (int ns = 1; ns <= max_ns; ++ns)
+    for (int i = 0; i < TNG_NSHAPES; ++i) {
+      if (!tng_shape_on(i)) continue;
+      const double sc = tng_score(M, N, tng_shapes()[i], tri, ns, slots);
+      if (sc > bs) { bs = sc; best = ns; }
+    }
   return best;
 }
 
@@ -326,7 +353,7 @@ static inline hipError_t kp_tn_gemm(hipStream_t st, const double* A, int64_t lda
                                     double alpha, double beta, int tri, int nsplit, double* P, const double* wa = nullptr, const double* wb = nullptr) {
   if (M <= 0 || N <= 0) return hipSuccess;
   // tile rows are addressed by 32-bit byte offsets from the tile's base
-  if ((uint64_t)128 * (uint64_t)(lda > ldb ? lda : ldb) * 8u + (uint64_t)K * 8u >= (1ull << 32)) return hipErrorInvalidValue;
+  if ((uint64_t)256 * (uint64_t)(lda > ldb ? lda : ldb) * 8u + (uint64_t)K * 8u >= (1ull << 32)) return hipErrorInvalidValue;
   TngArgs g;
   g.A = A; g.B = B; g.C = C; g.P = P;
   g.lda = lda; g.ldb = ldb; g.ldc = ldc;
@@ -341,6 +368,10 @@ static inline hipError_t kp_tn_gemm(hipStream_t st, const double* A, int64_t lda
   g.alpha = alpha; g.beta = beta;
   g.wa = wa; g.wb = wb;
   if (M <= 64) return tng_launch_cfg<4, 4>(st, g);
-  if (tng_tile_cols(M, N, g.nsplit, tri) == 96) return tng_launch_cfg<8, 6>(st, g);
-  return tng_launch_cfg<8, 4>(st, g);
+  switch (tng_pick_shape(M, N, g.nsplit, tri)) {
+    case 3: return tng_launch_cfg<6, 8, 8>(st, g);
+    case 2: return tng_launch_cfg<8, 6, 8>(st, g);
+    case 1: return tng_launch_cfg<8, 6>(st, g);
+    default: return tng_launch_cfg<8, 4>(st, g);
+  }
 }

@@ -41,7 +41,7 @@ int kp_gram_wide_launch(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* 
   const int npair = kron ? (b.m + 1) * (b.m + 2) / 2 : 1;
   // panel length: a multiple of 64 rows, at most the budget, at most what 32-bit tile offsets reach
   int64_t nc = (int64_t)(wide_panel_bytes() / ((size_t)8 * Wp));
-  nc = std::max<int64_t>(1024, std::min<int64_t>(nc, (int64_t)3 << 20)) / 64 * 64;
+  nc = std::max<int64_t>(1024, std::min<int64_t>(nc, (int64_t)1 << 20)) / 64 * 64;
   if (nc > Ns) nc = std::max<int64_t>(64, (Ns + 63) / 64 * 64);
   double* Px = (double*)ctx->workspace(15, (size_t)nc * Wp * 8);
   double* Py = (double*)ctx->workspace(16, (size_t)nc * Wp * 8);
@@ -107,7 +107,8 @@ int kp_gram_wide_launch(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* 
     const int K0 = (int)std::min<int64_t>(nc, Ns);
     const int kper = std::max(TNG_KB, ((K0 + nsplit - 1) / nsplit + TNG_KB - 1) / TNG_KB * TNG_KB);
     const int ns_eff = nsplit > 1 ? (K0 + kper - 1) / kper : 1;
-    const double tm = 128.0, tn = (double)tng_tile_cols(Wp, Wp, ns_eff, tri), nrt = std::ceil(Wp / tm), nct = std::ceil(Wp / tn);
+    const TngShape& sh = tng_shapes()[tng_pick_shape(Wp, Wp, ns_eff, tri)];
+    const double tm = sh.tm, tn = sh.tn, nrt = std::ceil(Wp / tm), nct = std::ceil(Wp / tn);
     double cnt = 0;
     for (int r = 0; r < (int)nrt; ++r)
       for (int c = 0; c < (int)nct; ++c) cnt += (!tri || r * tm <= c * tn + tn - 1) ? 1 : 0;
