@@ -27,6 +27,8 @@ WIDE_CASES = [
     ("bilinear", 6, 3, ["fourier"], [1], False),      # the same dictionary in a bilinear row: W = 2 940
     ("linear", 15, 3, ["poly"], [3], False),          # poly-3 on a delay-embedded arm state (nzeta = 15): 816 functions
     ("bilinear", 6, 3, ["poly"], [4], False),         # N = 210, W = 840: beyond the Kronecker kernel's 96 columns
+    ("bilinear", 7, 1, ["poly"], [4], False),         # one input: N = 330, W = 660 - 3 weighted products per Gram
+    ("bilinear", 6, 2, ["poly"], [4], False),         # two inputs: N = 210, W = 630 - 6 weighted products
 ]
 
 
