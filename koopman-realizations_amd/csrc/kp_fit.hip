@@ -649,12 +649,12 @@ static hipError_t wide_trsm(hipStream_t st, const double* Akk, const double* Din
 // Cp := (L L')^-1 Cp for a factor as chol_solve_wide leaves it (L below, L' above the diagonal, Dinv = inverses of the 16 x 16
 // diagonal blocks): per block a forward (then backward) substitution against the diagonal block and one TN product that takes
 // the block's solution out of all remaining rows.
-static int wide_substitute(kp_ctx* ctx, double* Gp, double* Cp, double* Dinv, int n, int ncp, hipStream_t st) {
+static int wide_substitute(kp_ctx* ctx, double* Gp, double* Cp, double* Dinv, int n, int ncp, hipStream_t st, bool forward_done = false) {
   const int bs = wide_block();
   static KpLdsCache trsm_lds;
   KP_HIP(ctx, kp_ensure_lds(trsm_lds, (const void*)kp_trsm2_kernel<4>, (size_t)352 * 16 * 8));
   // forward: L Y = C, block rows ascending; the block's Y leaves all later rows by one product
-  for (int k0 = 0; k0 < n; k0 += bs) {
+  for (int k0 = 0; k0 < n && !forward_done; k0 += bs) {
     const int b = std::min(bs, n - k0), R = n - k0 - b;
     KP_HIP(ctx, wide_trsm(st, Gp + (size_t)k0 * n + k0, Dinv + (size_t)(k0 / 16) * 256, b, ncp, Cp + k0, n, 1));
     if (R > 0) KP_HIP(ctx, kp_tn_gemm(st, Gp + (size_t)(k0 + b) * n + k0, n, Cp + k0, n, R, ncp, b, Cp + k0 + b, n, -1.0, 1.0, 0, 1, nullptr));
@@ -679,6 +679,12 @@ static int chol_solve_wide(kp_ctx* ctx, double* Gp, double* Cp, double* Dinv, in
   int* dummy = (int*)(thr + n);
   static KpLdsCache trsm_lds;
   KP_HIP(ctx, kp_ensure_lds(trsm_lds, (const void*)kp_trsm2_kernel<4>, (size_t)352 * 16 * 8));
+  // The right-hand sides directly behind the matrix (same leading dimension: [Gp | Cp] is ONE n x (n + ncp) array, as
+  // kp_chol_solve_batch_dev lays them out): the forward substitution rides on the factorisation - C is a few more columns of
+  // the block row A12 and of the trailing matrix - instead of repeating its launches afterwards (a W = 2 940 solve: 12 fewer
+  // substitution launches of ~38 us each, and the late, small trailing updates fill the chip with the right-hand sides' tiles).
+  // Same operations per element in the same order.  KP_WIDE_SEPARATE_FORWARD=1 (read per call) keeps the two phases apart.
+  const bool fwd = Cp == Gp + (size_t)n * n && !getenv("KP_WIDE_SEPARATE_FORWARD");
   KP_HIP(ctx, hipMemsetAsync(info, 0, sizeof(int), st));
   hipLaunchKernelGGL(kp_wide_thresh_kernel, dim3((n + 255) / 256), dim3(256), 0, st, Gp, n, thr);
   for (int k0 = 0; k0 < n; k0 += bs) {
@@ -693,7 +699,12 @@ static int chol_solve_wide(kp_ctx* ctx, double* Gp, double* Cp, double* Dinv, in
     }
     hipLaunchKernelGGL(kp_wide_diag_kernel, dim3((b * b + 255) / 256), dim3(256), 0, st, Gp, n, k0, b, D, 1);
     KP_HIP(ctx, hipGetLastError());
-    if (R > 0) {
+    if (fwd) {
+      // [A12 | C_k]: the columns right of the block and the right-hand sides in ONE substitution, [A22 | C_rest] in ONE product
+      // (the right-hand sides lie right of the diagonal of every tile row: never skipped by the upper-tiles rule)
+      KP_HIP(ctx, wide_trsm(st, Akk, Dinv + (size_t)(k0 / 16) * 256, b, R + ncp, A12, n, 1));
+      if (R > 0) KP_HIP(ctx, kp_tn_gemm(st, A12, n, A12, n, R, R + ncp, b, Gp + (size_t)(k0 + b) * n + k0 + b, n, -1.0, 1.0, 1, 1, nullptr));
+    } else if (R > 0) {
       KP_HIP(ctx, wide_trsm(st, Akk, Dinv + (size_t)(k0 / 16) * 256, b, R, A12, n, 1));
       KP_HIP(ctx, kp_tn_gemm(st, A12, n, A12, n, R, R, b, Gp + (size_t)(k0 + b) * n + k0 + b, n, -1.0, 1.0, 1, 1, nullptr));
     }
@@ -703,7 +714,7 @@ static int chol_solve_wide(kp_ctx* ctx, double* Gp, double* Cp, double* Dinv, in
   if (sticky) {   // (the deferred pipeline's word; wide fits run synchronously, so this is only for symmetry with the narrow path)
     KP_HIP(ctx, hipMemcpyAsync(sticky, info, sizeof(int), hipMemcpyDeviceToDevice, st));
   }
-  return wide_substitute(ctx, Gp, Cp, Dinv, n, ncp, st);
+  return wide_substitute(ctx, Gp, Cp, Dinv, n, ncp, st, fwd);
 }
 
 // For a caller that already holds a Cholesky factor (the rank-revealing solve, kp_pivchol.hip): Lp = n x n (n a multiple of
