@@ -1827,6 +1827,7 @@ static int mpc_run(kp_mpc* M, const kp_basis* basis, int nb, const double* z, co
     KP_HIP(ctx, hipMalloc((void**)&M->d_in, cap * in_per * 8));
     KP_HIP(ctx, hipMalloc((void**)&M->d_out, cap * n_out * 8 + cap * sizeof(int) + 8));
     KP_HIP(ctx, hipMalloc((void**)&M->work, (n_ex + 16) * 8));
+    KP_HIP(ctx, hipMemset(M->work, 0, (n_ex + 16) * 8));      // (stamps a step does not reach read as zero, not as stale memory)
     KP_HIP(ctx, hipHostMalloc((void**)&M->h_in, cap * in_per * 8, hipHostMallocDefault));
     KP_HIP(ctx, hipHostMalloc((void**)&M->h_out, cap * n_out * 8 + cap * sizeof(int) + 8, hipHostMallocDefault));
     M->io_problems = cap;
@@ -2033,8 +2034,8 @@ extern "C" int kp_mpc_last_qp(kp_mpc* M, double* Hq, double* f, double* Aq, doub
 // Diagnostics: phase times (microseconds) of the most recent single-problem step:
 // [0] lift + e, [1] Beta/S, [2] H/f, [3] Hinv (Gauss-Jordan), [4] active-set iterations,
 // [5] total kernel; counts[0] = solver iterations, counts[1] = active constraints at the optimum.
-// every stamp of the most recent single step relative to its first, in microseconds (slots a step did not reach hold stale or
-// negative values): [1] tracking error, [2] S_k, [3] H and f, [4] solver entered, [5] solved, [10] inputs landed, [11] lifted
+// every stamp of the most recent single step relative to its first, in microseconds (slots the step did not reach hold the value
+// of an earlier step, or minus the first stamp if no step reached them yet): [1] tracking error, [2] S_k, [3] H and f, [4] solver entered, [5] solved, [10] inputs landed, [11] lifted
 // state, [6] iteration loop entered, [12] H^-1, [13] warm-start products, [14] inverse of the warm set's Schur complement
 extern "C" int kp_mpc_last_stamps(kp_mpc* M, double* us16) {
   if (!M || !M->work || !us16) return KP_ERR_ARG;
