@@ -80,10 +80,16 @@ __global__ __launch_bounds__(PRE_T) void kp_gram3_pcs_transpose_kernel(const dou
 //     will not move a read above an earlier store, so every MFMA pair waited for a read issued just in front of it), 39 us with
 //     the A operands requested four steps ahead in the source, 38 us with a scheduling barrier per step (the scheduler sank the
 //     table reads to their uses).  Consumer round now 4 300 cycles (3 000 of instructions) + 500 of stores, producer 5 000.
+// Measured late in round 5 (-DPM_NS=2 / 1: the same pairs in two / four INDEPENDENT workgroups per CU, each with its own barrier,
+// the arrangement that pays for the dense products of kp_tn_gemm.h): 46.8 and 209 us against 38.9 - with fewer pairs per workgroup
+// the power tables and the raw loads are shared by fewer consumers, and at one pair the 128-register cap spills.
 // What would be next: two producers per slot (table per side) to take the producer off the critical path, and a second look at
 // what the consumer's 1 300 extra cycles per round are.
-#define PM_T 512
+#ifndef PM_NS
 #define PM_NS 4       // tiles (producer / consumer pairs) per workgroup
+#endif
+#define PM_T (128 * PM_NS)
+#define PM_WGPCU (4 / PM_NS)      // workgroups per CU (8 waves per CU either way)
 #define PM_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define PM_ES 20      // doubles per power-table entry: [side 0: 8 snapshots][side 1: 8][4 of padding]
 #define PM_CS 18      // doubles per Psi-tile column: [side 0: 8][side 1: 8][2 of padding]: 16-byte writes of consecutive columns and the
@@ -94,7 +100,7 @@ __global__ __launch_bounds__(PRE_T) void kp_gram3_pcs_transpose_kernel(const dou
 // free (idle lanes of the last round work on a spare column).  The producer wave of the slot is left with what has no vector
 // work to speak of: raw loads, the power table of the tile after next, the entries that are no components.
 template <int BM, int NK, int NRAW>
-__global__ __launch_bounds__(PM_T, 1) void kp_gram3_prelift_mfma_kernel(const double* __restrict__ alpha, const double* __restrict__ beta, const double* __restrict__ u,
+__global__ __launch_bounds__(PM_T, PM_WGPCU) void kp_gram3_prelift_mfma_kernel(const double* __restrict__ alpha, const double* __restrict__ beta, const double* __restrict__ u,
                                                                         int64_t Ns, int64_t ktiles, int nzeta, int D, int nfull, int k_pcs, int N, int G4,
                                                                         const uint32_t* __restrict__ recipes, const double* __restrict__ pcsT,
                                                                         double* __restrict__ out, int rl, int abl) {
@@ -389,7 +395,7 @@ static hipError_t prelift_mfma_launch(const double* alpha, const double* beta, c
   int dev = 0, cus = 256;
   (void)hipGetDevice(&dev);
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-  const int64_t grid = std::max<int64_t>(1, std::min<int64_t>((ktiles + PM_NS - 1) / PM_NS, (int64_t)cus));
+  const int64_t grid = std::max<int64_t>(1, std::min<int64_t>((ktiles + PM_NS - 1) / PM_NS, (int64_t)cus * PM_WGPCU));
   hipLaunchKernelGGL((kp_gram3_prelift_mfma_kernel<BM, NK, NRAW>), dim3((unsigned)grid), dim3(PM_T), lds, st, alpha, beta, u, Ns, ktiles, nzeta, D, nfull, k_pcs, N, G4,
                      recipes, pcsT, out, rl, getenv("KP_PM_ABL") ? atoi(getenv("KP_PM_ABL")) : 0);
   return hipGetLastError();
