@@ -33,7 +33,14 @@
 
 namespace {
 constexpr int P_TPB_LDS = 256;      // threads per column, inverse in LDS
-constexpr int P_TPB_GLOBAL = 1024;  // ... inverse in global memory (supports beyond 128: the products are long)
+#ifndef KP_P_TPB_GLOBAL
+#define KP_P_TPB_GLOBAL 512
+#endif
+// ... inverse in global memory (supports beyond 128: the products are long).  512, not 1024 (round 5): a column's walk is a serial
+// chain, so what counts is that ALL columns walk at once - 336 workgroups of 1024 threads are 1.3 rounds of one per CU, of 512
+// threads two fit a CU and every column is resident: arm Gram at W = 336, budgets 0.5 / 0.2 / 0.1 |K_LS|_1: 90 / 52 / 33 ->
+// 72 / 40 / 27 ms (256 threads: 69 / 41 / 28; tools/lasso_path_time.py)
+constexpr int P_TPB_GLOBAL = KP_P_TPB_GLOBAL;
 constexpr int P_LDS_BYTES = 160 * 1024;   // LDS of a CU: the inverse takes what the vectors leave (128 entries at W = 384, 136 at W = 136)
 constexpr int P_WMAX = 512;         // widest dictionary (the library's own limit; the W-length vectors live in LDS)
 constexpr int P_RESYNC = 16;        // steps between re-synchronisations of r = c - G k and of r_S = theta s_S
