@@ -233,7 +233,20 @@ extern "C" int kp_basis_create(kp_ctx* ctx, const kp_basis_desc* d, kp_basis** o
         double nf = std::pow((double)(2 * cnt + 1), (double)nvars);
         if (nf > 1e6) return ctx->fail(KP_ERR_ARG, "kp_basis_create: fourier block too large");
         int total = (int)std::llround(nf);
-        for (int i = 1; i < total; ++i) cols.push_back({COL_FOURIER, i, cnt, 0});
+        for (int i = 1; i < total; ++i) {
+          // the digits of the mixed-radix index (digit of variable v = harmonic of x_v: 0 none, 2j - 1 cos, 2j sin) packed four
+          // bits each into `pad` when they fit: the lift kernel then shifts instead of dividing - twelve 32-bit integer
+          // divisions per function and point were ~200 of the ~300 instructions of a fourier value
+          uint32_t pk = 0;
+          if (nvars <= 8 && 2 * cnt + 1 <= 16) {
+            int idx = i;
+            for (int v = nvars - 1; v >= 0; --v) {
+              pk |= (uint32_t)(idx % (2 * cnt + 1)) << (4 * v);
+              idx /= 2 * cnt + 1;
+            }
+          }
+          cols.push_back({COL_FOURIER, i, cnt, (int32_t)pk});
+        }
         fourier_deg = fourier_deg == 0 ? cnt : (fourier_deg == cnt ? cnt : -1);   // (blocks of different degrees: generic evaluation)
         break;
       }
@@ -261,6 +274,9 @@ extern "C" int kp_basis_create(kp_ctx* ctx, const kp_basis_desc* d, kp_basis** o
   b->ctx = ctx;
   b->max_degree = max_deg;
   b->fourier_degree = (fourier_deg > 0 && fourier_deg <= 8) ? fourier_deg : 0;
+  b->pure_fourier = b->fourier_degree > 0 && (int)cols.size() > nvars;
+  for (size_t c = (size_t)nvars; c < cols.size() && b->pure_fourier; ++c)
+    b->pure_fourier = cols[c].kind == COL_CONST || (cols[c].kind == COL_FOURIER && cols[c].pad != 0 && cols[c].aux == b->fourier_degree);
   // recipes of the fused Gram kernel's fast lift: column = product of <= 4 entries x_v^e of a
   // power table, id = v*D + (e-1), 255 = the constant 1
   {
@@ -430,13 +446,25 @@ extern "C" int kp_basis_dims(const kp_basis* b, int* nvars, int* nfull, int* N, 
 // states (the lift was half of the wide Gram pass at W = 738).
 template <int LT>
 __device__ __forceinline__ double kp_lift_fourier_col(const BasisDev& b, const ColDesc c, const double* trig, int fdeg, int p) {
+  double v = 1.0;
+  if (c.pad) {                                       // digits packed by kp_basis_create (index >= 1: never all zero)
+    // all (at most eight) table reads requested together, no branch and no select per factor: digit 0 reads the row of ones
+    // that heads every variable's harmonics (digits beyond nvars are zero: the last variable's ones)
+    const uint32_t pk = (uint32_t)c.pad;
+    const int tw = 2 * fdeg + 1, vlast = b.nvars - 1;
+    double t[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = trig[((i < vlast ? i : vlast) * tw + ((pk >> (4 * i)) & 15)) * LT + p];
+#pragma unroll
+    for (int i = 7; i >= 0; --i) v *= t[i];
+    return v;
+  }
   const int radix = 2 * c.aux + 1;
   int idx = c.arg;
-  double v = 1.0;
   for (int i = b.nvars - 1; i >= 0; --i) {
     const int d = idx % radix;
     idx /= radix;
-    if (d) v *= trig[(i * 2 * fdeg + (d - 1)) * LT + p];       // digit 2j - 1: cos(2 pi j x), 2j: sin(2 pi j x)
+    v *= trig[(i * (2 * fdeg + 1) + d) * LT + p];               // digit 0: 1, 2j - 1: cos(2 pi j x), 2j: sin(2 pi j x)
   }
   return v;
 }
@@ -444,13 +472,19 @@ __device__ __forceinline__ double kp_lift_fourier_col(const BasisDev& b, const C
 template <int LT>
 __global__ __launch_bounds__(256) void kp_lift_kernel(BasisDev b, int what, const double* __restrict__ zeta,
                                                       const double* __restrict__ u, int64_t rows, int64_t ldi, int64_t ldo,
-                                                      double* __restrict__ out, int fdeg) {
+                                                      double* __restrict__ out, int fdeg, int stage_cols) {
   extern __shared__ double sm[];
-  // layout: vars[nvars][LT] | um[m][LT] | trig[nvars][2 fdeg][LT] (fourier blocks) | full[nfull][LT] (only when k_pcs)
+  // layout: vars[nvars][LT] | um[m][LT] | trig[nvars][1 + 2 fdeg][LT] (fourier blocks: ones, cos, sin, cos 2, ...) | full[nfull][LT] (only when k_pcs) | the column
+  // descriptors (stage_cols: a value used to start with a 16-byte load from L2 that nothing could hide - ~600 cycles each)
   double* vars = sm;
   double* um = vars + b.nvars * LT;
   double* trig = um + (b.m > 0 ? b.m : 1) * LT;
-  double* full = trig + b.nvars * 2 * fdeg * LT;
+  double* full = trig + b.nvars * (fdeg > 0 ? 2 * fdeg + 1 : 0) * LT;
+  // (two instantiations of the loops below, one per address space: through a generic pointer the descriptor would be a FLAT load,
+  //  whose wait also waits - the vector-memory counter retires in order - for the previous value's store to be acknowledged)
+  ColDesc* const lc = reinterpret_cast<ColDesc*>(full + (b.k_pcs ? b.nfull * LT : 0));
+  if (stage_cols & 1)
+    for (int c = threadIdx.x; c < b.nfull; c += 256) lc[c] = b.cols[c];      // (published by the barrier behind the variables below)
   const int64_t r0 = (int64_t)blockIdx.x * LT;
   const int tid = threadIdx.x;
   const int nl = (int)min((int64_t)LT, rows - r0);
@@ -476,34 +510,68 @@ __global__ __launch_bounds__(256) void kp_lift_kernel(BasisDev b, int what, cons
       const int p = e % LT, vj = e / LT, v = vj / fdeg, j = vj % fdeg + 1;
       double sn, cs;
       sincos(2.0 * 3.14159265358979323846 * (double)j * vars[v * LT + p], &sn, &cs);
-      trig[(v * 2 * fdeg + 2 * j - 2) * LT + p] = cs;
-      trig[(v * 2 * fdeg + 2 * j - 1) * LT + p] = sn;
+      trig[(v * (2 * fdeg + 1) + 2 * j - 1) * LT + p] = cs;
+      trig[(v * (2 * fdeg + 1) + 2 * j) * LT + p] = sn;
+      if (j == 1) trig[v * (2 * fdeg + 1) * LT + p] = 1.0;      // row 0 of a variable: digit 0 = no harmonic of it
     }
     __syncthreads();
   }
   const bool econ = (b.k_pcs > 0) && what != KP_LIFT_FULL;
-  if (!econ) {
-    // column c of the full basis is also column c of psi
+  // Dictionaries that are the variables + ONE fourier block (the reference's fourier dictionaries): a loop with nothing but the
+  // packed digits (4 bytes per function, staged in LDS), the table reads and the product.  The general loop below carries every
+  // column kind's code behind a chain of tests - ~1 000 cycles per value, most of them taken branches - and costs the wide
+  // Gram pass at W = 738 as much as its products do at the arm data's 11 999 pairs.
+  const bool fast_fourier = (stage_cols & 2) && !econ && !(what == KP_LIFT_ROW && b.model_type == KP_MODEL_BILINEAR);
+  if (fast_fourier) {
+    const uint32_t* lp = reinterpret_cast<const uint32_t*>(lc);       // [c].pad of the staged descriptors
     for (int e = tid; e < b.nfull * LT; e += 256) {
-      int c = e / LT, p = e % LT;
+      const int c = e / LT, p = e % LT;
       if (p >= nl) continue;
-      const ColDesc cd = b.cols[c];
-      double val = (fdeg > 0 && cd.kind == COL_FOURIER && cd.aux == fdeg) ? kp_lift_fourier_col<LT>(b, cd, trig, fdeg, p) : kp_eval_col(b, cd, vars + p, LT);
-      int64_t r = r0 + p;
-      if (what == KP_LIFT_ROW && b.model_type == KP_MODEL_BILINEAR) {
-        out[(int64_t)c * ldo + r] = val;
-        for (int i = 0; i < b.m; ++i) out[(int64_t)((i + 1) * b.N + c) * ldo + r] = val * um[i * LT + p];
+      double val;
+      if (c < b.nvars) {
+        val = vars[c * LT + p];
       } else {
-        out[(int64_t)c * ldo + r] = val;
+        const uint32_t pk = lp[4 * c] == (uint32_t)COL_CONST ? 0u : lp[4 * c + 3];      // (the constant: no digit, product of ones)
+        const int tw = 2 * fdeg + 1, vlast = b.nvars - 1;
+        double t[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t[i] = trig[((i < vlast ? i : vlast) * tw + ((pk >> (4 * i)) & 15)) * LT + p];
+        val = 1.0;
+#pragma unroll
+        for (int i = 7; i >= 0; --i) val *= t[i];
+      }
+      out[(int64_t)c * ldo + r0 + p] = val;
+    }
+  }
+  auto eval_full = [&](auto colsp) {
+    if (fast_fourier) return;
+    if (!econ) {
+      // column c of the full basis is also column c of psi
+      for (int e = tid; e < b.nfull * LT; e += 256) {
+        int c = e / LT, p = e % LT;
+        if (p >= nl) continue;
+        const ColDesc cd = colsp[c];
+        double val = (fdeg > 0 && cd.kind == COL_FOURIER && cd.aux == fdeg) ? kp_lift_fourier_col<LT>(b, cd, trig, fdeg, p) : kp_eval_col(b, cd, vars + p, LT);
+        int64_t r = r0 + p;
+        if (what == KP_LIFT_ROW && b.model_type == KP_MODEL_BILINEAR) {
+          out[(int64_t)c * ldo + r] = val;
+          for (int i = 0; i < b.m; ++i) out[(int64_t)((i + 1) * b.N + c) * ldo + r] = val * um[i * LT + p];
+        } else {
+          out[(int64_t)c * ldo + r] = val;
+        }
+      }
+    } else {
+      for (int e = tid; e < b.nfull * LT; e += 256) {
+        int c = e / LT, p = e % LT;
+        const ColDesc cd = colsp[c];
+        full[c * LT + p] = p >= nl ? 0.0
+                           : (fdeg > 0 && cd.kind == COL_FOURIER && cd.aux == fdeg) ? kp_lift_fourier_col<LT>(b, cd, trig, fdeg, p) : kp_eval_col(b, cd, vars + p, LT);
       }
     }
-  } else {
-    for (int e = tid; e < b.nfull * LT; e += 256) {
-      int c = e / LT, p = e % LT;
-      const ColDesc cd = b.cols[c];
-      full[c * LT + p] = p >= nl ? 0.0
-                         : (fdeg > 0 && cd.kind == COL_FOURIER && cd.aux == fdeg) ? kp_lift_fourier_col<LT>(b, cd, trig, fdeg, p) : kp_eval_col(b, cd, vars + p, LT);
-    }
+  };
+  if (stage_cols & 1) eval_full(lc);
+  else eval_full(b.cols);
+  if (econ) {
     __syncthreads();
     // econ = [ v ; pcs' * full ; 1 ]   (Ksysid.m:1615-1618)
     for (int e = tid; e < b.N * LT; e += 256) {
@@ -538,18 +606,24 @@ int kp_lift_dev_ld(kp_ctx* ctx, const kp_basis* basis, int what, const double* d
                    int64_t ldo) {
   const BasisDev& b = basis->dev;
   const int fdeg = basis->fourier_degree;
-  const size_t per_point = (size_t)(b.nvars + (b.m > 0 ? b.m : 1) + b.nvars * 2 * fdeg + (b.k_pcs ? b.nfull : 0)) * 8;
-  const int lt = per_point * 64 <= 160 * 1024 ? 64 : 16;
-  const size_t lds = per_point * lt;
+  const size_t per_point = (size_t)(b.nvars + (b.m > 0 ? b.m : 1) + b.nvars * (fdeg > 0 ? 2 * fdeg + 1 : 0) + (b.k_pcs ? b.nfull : 0)) * 8;
+  // 64 points per workgroup when that still gives every CU several workgroups (the kernel is bound by instruction issue: one
+  // workgroup per CU is one wave per SIMD, a quarter of what a SIMD can issue), else 16
+  const int ncu_ = ctx->num_cu > 0 ? ctx->num_cu : 256;
+  const int lt = (per_point * 64 <= 160 * 1024 && rows >= (int64_t)64 * 4 * ncu_) ? 64 : 16;
+  size_t lds = per_point * lt;
   if (lds > 160 * 1024) return ctx->fail(KP_ERR_ARG, "kp_lift: dictionary too large for the LDS staging of the pcs projection");
+  int stage_cols = lds + (size_t)b.nfull * sizeof(ColDesc) <= 160 * 1024 ? 1 : 0;
+  if (stage_cols) lds += (size_t)b.nfull * sizeof(ColDesc);
+  if (stage_cols && basis->pure_fourier && fdeg > 0 && b.nvars <= 8) stage_cols |= 2;      // bit 1: the fourier-only loop of the kernel
   static KpLdsCache c64, c16;
   const int64_t nblk = (rows + lt - 1) / lt;
   if (lt == 64) {
     KP_HIP(ctx, kp_ensure_lds(c64, (const void*)kp_lift_kernel<64>, lds));
-    hipLaunchKernelGGL(kp_lift_kernel<64>, dim3((unsigned)nblk), dim3(256), lds, ctx->stream, b, what, dz, du, rows, ldi, ldo, dout, fdeg);
+    hipLaunchKernelGGL(kp_lift_kernel<64>, dim3((unsigned)nblk), dim3(256), lds, ctx->stream, b, what, dz, du, rows, ldi, ldo, dout, fdeg, stage_cols);
   } else {
     KP_HIP(ctx, kp_ensure_lds(c16, (const void*)kp_lift_kernel<16>, lds));
-    hipLaunchKernelGGL(kp_lift_kernel<16>, dim3((unsigned)nblk), dim3(256), lds, ctx->stream, b, what, dz, du, rows, ldi, ldo, dout, fdeg);
+    hipLaunchKernelGGL(kp_lift_kernel<16>, dim3((unsigned)nblk), dim3(256), lds, ctx->stream, b, what, dz, du, rows, ldi, ldo, dout, fdeg, stage_cols);
   }
   KP_HIP(ctx, hipGetLastError());
   return KP_OK;

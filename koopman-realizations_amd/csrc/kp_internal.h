@@ -112,7 +112,8 @@ struct ColDesc {
   int32_t arg;  // VAR: variable index; MONO/HERMITE: row in exps; FSPARSE: first of two rows in exps (sin, cos
                 // multipliers); FOURIER: mixed-radix index (>=1); GAUSS: centre
   int32_t aux;  // FOURIER: degree; MONO with <= 8 variables (kp_basis_create): exponent bytes of variables 0-3
-  int32_t pad;  // MONO with <= 8 variables: exponent bytes of variables 4-7
+  int32_t pad;  // MONO with <= 8 variables: exponent bytes of variables 4-7; FOURIER (<= 8 variables, degree <= 7): the digits of the
+                // mixed-radix index, four bits per variable (0: not packed)
 };
 
 // Device view of a dictionary, passed by value to kernels.
@@ -158,6 +159,7 @@ struct kp_basis {
   void* d_recipes = nullptr;   // [nfull] uint32: 4 x 8-bit power-table ids (255 = 1.0)
   void* d_pcsT = nullptr;      // dim_red: pcs as [full column][32 components], zero padded (kp_gram3_prelift_kernel; built on first use)
   int max_degree = 0;
+  bool pure_fourier = false;   // every column behind the variables is the constant or a fourier function of fourier_degree with packed digits (ColDesc::pad)
   int fourier_degree = 0;      // degree of the dictionary's fourier block (0: none, or blocks of different degrees): kp_lift_kernel's harmonic table
   int pow_depth = 1;           // largest single-variable exponent
   bool fast = false;           // every column is a product of <= 4 single-variable powers
