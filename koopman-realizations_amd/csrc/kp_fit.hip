@@ -1171,11 +1171,17 @@ extern "C" int kp_fit(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* sn
   // block and a memcpy from there take 0.05 ms
   const size_t k_bytes = (size_t)n_lasso * W * W * 8;
   double* k_pin = (K_out && k_bytes <= ((size_t)64 << 20)) ? (double*)kp_pinned_scratch(ctx, k_bytes) : nullptr;
-  if (K_out) KP_HIP(ctx, hipMemcpyAsync(k_pin ? k_pin : K_out, ctx->Kres, k_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  // (a dictionary whose previous fit was rank deficient: the copy of a K that will most likely be replaced waits for the verdict)
+  const bool k_late = K_out && ls_index >= 0 && basis->rank_hint > 0;
+  if (K_out && !k_late) KP_HIP(ctx, hipMemcpyAsync(k_pin ? k_pin : K_out, ctx->Kres, k_bytes, hipMemcpyDeviceToHost, ctx->stream));
   int bad = 0;
   if (ls_index >= 0) {
     rc = read_chol_info(ctx, W, W, &bad, Gd);
     if (rc) return rc;
+    if (k_late && !bad) {
+      KP_HIP(ctx, hipMemcpyAsync(k_pin ? k_pin : K_out, ctx->Kres, k_bytes, hipMemcpyDeviceToHost, ctx->stream));
+      KP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
   } else {
     KP_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
@@ -1185,14 +1191,16 @@ extern "C" int kp_fit(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* sn
     if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) ctx->timers[3] = ms;
   }
   ctx->last_rank = W;
+  if (!bad && ls_index >= 0) basis->rank_hint = 0;
   if (k_pin && !bad) memcpy(K_out, k_pin, k_bytes);
   if (bad) {
     // rank-deficient dictionary (Ksysid.m:1069 on the arm data without dim_red): basic solution + rank, like MATLAB's `\`
     int r = 0;
     double* Kls = ctx->Kres + (size_t)ls_index * W * W;
-    rc = kp_pivchol_solve_dev(ctx, Gd, Cd, W, W, Kls, &r);
+    rc = kp_pivchol_solve_dev(ctx, Gd, Cd, W, W, Kls, &r, basis->rank_hint);
     if (rc) return rc;
     ctx->last_rank = r;
+    basis->rank_hint = r < W ? r : 0;
     for (int i = 0; i < n_lasso; ++i)
       if (i != ls_index && (!lasso || !(lasso[i] < 1e6)))
         KP_HIP(ctx, hipMemcpyAsync(ctx->Kres + (size_t)i * W * W, Kls, (size_t)W * W * 8, hipMemcpyDeviceToDevice, ctx->stream));

@@ -159,6 +159,8 @@ struct kp_basis {
   void* d_recipes = nullptr;   // [nfull] uint32: 4 x 8-bit power-table ids (255 = 1.0)
   void* d_pcsT = nullptr;      // dim_red: pcs as [full column][32 components], zero padded (kp_gram3_prelift_kernel; built on first use)
   int max_degree = 0;
+  mutable int rank_hint = 0;   // rank found by the last synchronous fit of this dictionary when its Gram matrix was rank deficient (0: it was not):
+                               // only the ORDER of the next fit's work depends on it (kp_fit), never its result
   bool pure_fourier = false;   // every column behind the variables is the constant or a fourier function of fourier_degree with packed digits (ColDesc::pad)
   int fourier_degree = 0;      // degree of the dictionary's fourier block (0: none, or blocks of different degrees): kp_lift_kernel's harmonic table
   int pow_depth = 1;           // largest single-variable exponent
@@ -323,7 +325,7 @@ bool kp_chol_ll_applicable(int n);
 hipError_t kp_chol_ll_launch(double* Gp, int n, int nb, int* info, int* sticky, int prof, hipStream_t st, const double* thr = nullptr);
 // substitution with a factor the caller already holds (kp_fit.hip)
 int kp_factor_substitute_dev(kp_ctx* ctx, double* Lp, int n, double* Cp, int ncp, double* Dinv, hipStream_t st);
-int kp_pivchol_solve_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, int W, int ncols, double* K_dev, int* rank);
+int kp_pivchol_solve_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, int W, int ncols, double* K_dev, int* rank, int rank_hint = 0);
 int kp_comm_allreduce_dev(kp_ctx* ctx, double* buf_dev, size_t count, hipStream_t s);
 // queued (deferred) solves of the asynchronous pipeline are launched; nothing is waited for, no status is consumed (kp_fit.hip)
 int kp_flush_pending(kp_ctx* ctx);

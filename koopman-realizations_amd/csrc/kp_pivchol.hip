@@ -340,7 +340,10 @@ __global__ void kp_scatter_rows_kernel(const double* __restrict__ Ks, int W, int
 
 // Basic solution of G K = C over the column subset chosen by diagonal pivoting; *rank receives its size.  The stream is
 // synchronised (the rank decides the size of the second stage).
-int kp_pivchol_solve_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, int W, int ncols, double* K_dev, int* rank) {
+// rank_hint > 0: the rank this matrix is expected to have (the previous fit of the same dictionary): only the panels that reach it
+// are queued at first - each panel launched behind the one that finds the rank is an empty launch of ~4 us, and so is its update -
+// and the rest follow, with the second stage repeated, if the factorisation turns out not to be finished.
+int kp_pivchol_solve_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, int W, int ncols, double* K_dev, int* rank, int rank_hint) {
   if (W > 1024 * PC_RPT_MAX) return ctx->fail(KP_ERR_ARG, "rank-revealing solve: W <= 4096");
   hipStream_t s = ctx->stream;
   const int n_max = (W + 15) / 16 * 16, ncp = (ncols + 15) / 16 * 16;
@@ -371,38 +374,59 @@ int kp_pivchol_solve_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, 
                          : kp_ensure_lds(lds4096, (const void*)kp_pivchol_panel_kernel<1024, PC_RPT_MAX>, lds));
   const dim3 ugrid((W + 63) / 64, (W + 63) / 64);
   static const int piv_abl = getenv("KP_PIV_ABL") ? atoi(getenv("KP_PIV_ABL")) : 0;      // timing-only ablations (bit 0: no pivot-column load)
-  for (int k0 = 0; k0 < W; k0 += nb) {
-    const int nbk = std::min(nb, W - k0);
-    if (fast32 && nt == 512)
-      hipLaunchKernelGGL((kp_pivchol_panel32_kernel<512>), dim3(1), dim3(512), lds, s, (const double*)A, W, k0, nbk, rel_tol, L, dg, ipos, perm, stt, piv_abl);
-    else if (fast32)
-      hipLaunchKernelGGL((kp_pivchol_panel32_kernel<1024>), dim3(1), dim3(1024), lds, s, (const double*)A, W, k0, nbk, rel_tol, L, dg, ipos, perm, stt, piv_abl);
-    else if (nt == 512)
-      hipLaunchKernelGGL((kp_pivchol_panel_kernel<512, 1>), dim3(1), dim3(512), lds, s, (const double*)A, W, k0, nbk, rel_tol, L, dg, ipos, perm, stt);
-    else if (rpt == 1)
-      hipLaunchKernelGGL((kp_pivchol_panel_kernel<1024, 1>), dim3(1), dim3(1024), lds, s, (const double*)A, W, k0, nbk, rel_tol, L, dg, ipos, perm, stt);
-    else
-      hipLaunchKernelGGL((kp_pivchol_panel_kernel<1024, PC_RPT_MAX>), dim3(1), dim3(1024), lds, s, (const double*)A, W, k0, nbk, rel_tol, L, dg, ipos, perm, stt);
-    if (k0 + nbk < W) hipLaunchKernelGGL(kp_pivchol_update_kernel, ugrid, dim3(256), 0, s, A, W, k0, nbk, (const double*)L, (const int*)ipos, (const PivState*)stt);
-    KP_HIP(ctx, hipGetLastError());
+  auto run_panels = [&](int k_from, int k_to) -> int {
+    for (int k0 = k_from; k0 < k_to; k0 += nb) {
+      const int nbk = std::min(nb, W - k0);
+      if (fast32 && nt == 512)
+        hipLaunchKernelGGL((kp_pivchol_panel32_kernel<512>), dim3(1), dim3(512), lds, s, (const double*)A, W, k0, nbk, rel_tol, L, dg, ipos, perm, stt, piv_abl);
+      else if (fast32)
+        hipLaunchKernelGGL((kp_pivchol_panel32_kernel<1024>), dim3(1), dim3(1024), lds, s, (const double*)A, W, k0, nbk, rel_tol, L, dg, ipos, perm, stt, piv_abl);
+      else if (nt == 512)
+        hipLaunchKernelGGL((kp_pivchol_panel_kernel<512, 1>), dim3(1), dim3(512), lds, s, (const double*)A, W, k0, nbk, rel_tol, L, dg, ipos, perm, stt);
+      else if (rpt == 1)
+        hipLaunchKernelGGL((kp_pivchol_panel_kernel<1024, 1>), dim3(1), dim3(1024), lds, s, (const double*)A, W, k0, nbk, rel_tol, L, dg, ipos, perm, stt);
+      else
+        hipLaunchKernelGGL((kp_pivchol_panel_kernel<1024, PC_RPT_MAX>), dim3(1), dim3(1024), lds, s, (const double*)A, W, k0, nbk, rel_tol, L, dg, ipos, perm, stt);
+      if (k0 + nbk < W) hipLaunchKernelGGL(kp_pivchol_update_kernel, ugrid, dim3(256), 0, s, A, W, k0, nbk, (const double*)L, (const int*)ipos, (const PivState*)stt);
+      KP_HIP(ctx, hipGetLastError());
+    }
+    return KP_OK;
+  };
+  // the panel in which pivot number rank_hint + 1 is tried is the one that declares the factorisation finished
+  int k_done = (rank_hint > 0 && rank_hint < W) ? std::min(W, (rank_hint / nb + 1) * nb) : W;
+  {
+    int rcp = run_panels(0, k_done);
+    if (rcp) return rcp;
   }
-  // everything behind the factorisation is queued without knowing the rank: the substitution runs at the full (padded) width
-  // with an identity block beyond the rank - ~30 % more substitution work at rank 252 of 336 against two host round trips
-  const int n = n_max;
-  KP_HIP(ctx, hipMemsetAsync(K_dev, 0, (size_t)W * ncols * 8, s));
-  const int64_t tot = (int64_t)n * n + (int64_t)n * ncp;
-  hipLaunchKernelGGL(kp_pivchol_gather_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, (const double*)L, C_dev, W, ncols, (const int*)perm,
-                     (const PivState*)stt, n, ncp, Lp, Cp);
-  KP_HIP(ctx, hipGetLastError());
-  int rc = kp_factor_substitute_dev(ctx, Lp, n, Cp, ncp, Dinv, s);
-  if (rc) return rc;
-  hipLaunchKernelGGL(kp_scatter_rows_kernel, dim3((unsigned)(((int64_t)W * ncols + 255) / 256)), dim3(256), 0, s, (const double*)Cp, W, ncols, (const int*)perm,
-                     (const PivState*)stt, n, K_dev);
-  KP_HIP(ctx, hipGetLastError());
   PivState h{};
   PivState* hp = ctx->pin_small ? reinterpret_cast<PivState*>(ctx->pin_small + 4) : &h;     // (page-locked words of the context: direct DMA)
-  KP_HIP(ctx, hipMemcpyAsync(hp, stt, sizeof(PivState), hipMemcpyDeviceToHost, s));
-  KP_HIP(ctx, hipStreamSynchronize(s));
+  auto second_stage = [&]() -> int {
+    // everything behind the factorisation is queued without knowing the rank: the substitution runs at the full (padded) width
+    // with an identity block beyond the rank - ~30 % more substitution work at rank 252 of 336 against two host round trips
+    const int n = n_max;
+    KP_HIP(ctx, hipMemsetAsync(K_dev, 0, (size_t)W * ncols * 8, s));
+    const int64_t tot = (int64_t)n * n + (int64_t)n * ncp;
+    hipLaunchKernelGGL(kp_pivchol_gather_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, (const double*)L, C_dev, W, ncols, (const int*)perm,
+                       (const PivState*)stt, n, ncp, Lp, Cp);
+    KP_HIP(ctx, hipGetLastError());
+    int rc = kp_factor_substitute_dev(ctx, Lp, n, Cp, ncp, Dinv, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(kp_scatter_rows_kernel, dim3((unsigned)(((int64_t)W * ncols + 255) / 256)), dim3(256), 0, s, (const double*)Cp, W, ncols, (const int*)perm,
+                       (const PivState*)stt, n, K_dev);
+    KP_HIP(ctx, hipGetLastError());
+    KP_HIP(ctx, hipMemcpyAsync(hp, stt, sizeof(PivState), hipMemcpyDeviceToHost, s));
+    KP_HIP(ctx, hipStreamSynchronize(s));
+    return KP_OK;
+  };
+  {
+    int rcs = second_stage();
+    if (rcs) return rcs;
+  }
+  if (!hp->done && k_done < W) {                  // the hint was too small: the remaining panels, and the second stage again
+    int rcp = run_panels(k_done, W);
+    if (!rcp) rcp = second_stage();
+    if (rcp) return rcp;
+  }
   if (rank) *rank = hp->done ? hp->rank : W;
   return KP_OK;
 }

@@ -694,3 +694,39 @@ def test_lifted_tiles_on_random_dictionaries_equal_the_in_kernel_lift():
             assert np.abs(a - b).max() <= 1e-12 * max(np.abs(res["proj"]["G" + k[1:]]).max(), 1e-300), (k, res["pre"]["d" + k[1:]])
             n += 1
     assert n >= 30
+
+
+def test_fits_do_not_depend_on_what_the_dictionary_was_fitted_on_before(ctx):
+    """A dictionary remembers the rank its last synchronous fit found (`rank_hint`: the next fit queues only the pivoting panels
+    that reach that rank and holds back the copy of a K that will most likely be replaced).  Only the ORDER of the work may
+    depend on that: every fit below gives, bit for bit, what a fresh dictionary object gives on the same snapshots -
+    rank-deficient after full rank, full rank after rank-deficient, and a rank far ABOVE the remembered one (more than a
+    panel of 32 pivots: the factorisation continues behind the first synchronisation)."""
+    rng = np.random.default_rng(5)
+    dic = ko.build_dictionary("bilinear", 6, 3, ["poly"], [3])         # W = 336
+    Ns = 4000
+
+    def pairs(nfree):                                                    # states confined to an nfree-dimensional subspace
+        mix = np.linalg.qr(rng.standard_normal((6, 6)))[0][:, :nfree]
+        a = rng.uniform(-1, 1, (Ns, nfree)) @ mix.T
+        b_ = 0.9 * a + 0.05 * rng.uniform(-1, 1, (Ns, nfree)) @ mix.T
+        return {"alpha": a, "beta": b_, "u": rng.uniform(-1, 1, (Ns, 3))}
+
+    sets = [pairs(6), pairs(3), pairs(5), pairs(6), pairs(4), pairs(3)]
+    shared = make_basis(ctx, dic)
+    ranks = []
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for p in sets:
+            s = kra.Snapshots(ctx, p["alpha"], p["beta"], p["u"])
+            K1 = kra.fit(ctx, shared, s)[0]
+            r1 = ctx.last_rank()
+            fresh = make_basis(ctx, dic)
+            K2 = kra.fit(ctx, fresh, s)[0]
+            assert ctx.last_rank() == r1 and np.array_equal(K1, K2)
+            K3 = kra.fit(ctx, shared, s)[0]                             # and once more with the hint now matching
+            assert ctx.last_rank() == r1 and np.array_equal(K1, K3)
+            ranks.append(r1)
+            s.close(); fresh.close()
+    assert ranks[0] == 336 and ranks[3] == 336 and ranks[1] < ranks[2] - 32 and ranks[5] < ranks[4] - 32, ranks
