@@ -842,12 +842,13 @@ static int check_info(kp_ctx* ctx) {
   return KP_OK;
 }
 
-static int read_chol_info(kp_ctx* ctx, int W, int ncols, int* bad, const double* G_dev = nullptr) {
+static int read_chol_info(kp_ctx* ctx, int W, int ncols, int* bad, const double* G_dev = nullptr, hipStream_t st = nullptr) {
+  if (!st) st = ctx->stream;
   const int n = (W + 15) / 16 * 16;
   const size_t off = kp_chol_info_offset(W, ncols);
   double* ratio_dev = (double*)((char*)ctx->ws[5] + off + 8);
   if (G_dev) {     // the factor is still in the padded buffer at the head of workspace 5
-    hipLaunchKernelGGL(kp_pivot_ratio_kernel, dim3(1), dim3(256), 0, ctx->stream, (const double*)ctx->ws[5], n, G_dev, W, ratio_dev,
+    hipLaunchKernelGGL(kp_pivot_ratio_kernel, dim3(1), dim3(256), 0, st, (const double*)ctx->ws[5], n, G_dev, W, ratio_dev,
                        (const int*)((char*)ctx->ws[5] + off), ctx->pin_small);
     KP_HIP(ctx, hipGetLastError());
   }
@@ -855,16 +856,16 @@ static int read_chol_info(kp_ctx* ctx, int W, int ncols, int* bad, const double*
   // page-locked words itself; without it (no G) one 16-byte DMA brings them (two staged copies into pageable words were
   // 25 us of the one-fit latency, tools/fit_timeline.py)
   if (ctx->pin_small) {
-    if (!G_dev) KP_HIP(ctx, hipMemcpyAsync(ctx->pin_small, (char*)ctx->ws[5] + off, 16, hipMemcpyDeviceToHost, ctx->stream));
-    KP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (!G_dev) KP_HIP(ctx, hipMemcpyAsync(ctx->pin_small, (char*)ctx->ws[5] + off, 16, hipMemcpyDeviceToHost, st));
+    KP_HIP(ctx, hipStreamSynchronize(st));
     int info = 0;
     memcpy(&info, ctx->pin_small, sizeof(int));
     *bad = info;
     if (G_dev) ctx->last_pivot_ratio = ctx->pin_small[1];
   } else {
-    if (G_dev) KP_HIP(ctx, hipMemcpyAsync(&ctx->last_pivot_ratio, ratio_dev, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    KP_HIP(ctx, hipMemcpyAsync(bad, (char*)ctx->ws[5] + off, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    KP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (G_dev) KP_HIP(ctx, hipMemcpyAsync(&ctx->last_pivot_ratio, ratio_dev, sizeof(double), hipMemcpyDeviceToHost, st));
+    KP_HIP(ctx, hipMemcpyAsync(bad, (char*)ctx->ws[5] + off, sizeof(int), hipMemcpyDeviceToHost, st));
+    KP_HIP(ctx, hipStreamSynchronize(st));
   }
   (void)check_info;
   return KP_OK;
@@ -1139,6 +1140,13 @@ extern "C" int kp_fit(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* sn
   bool need_ls = false;
   for (int i = 0; i < n_lasso; ++i) need_ls |= (!lasso || !(lasso[i] < 1e6));
   int ls_index = -1;
+  // (see below) least-squares values only, the narrow path, a second stream to run on
+  const bool concurrent = basis->rank_hint > 0 && all_ls && ctx->stream2 && W <= 16 * 4 * TR_MAXJ && !ctx->reduce_grams && !ctx->gc_preloaded &&
+                          !getenv("KP_NO_RANK_HINT");
+  bool conc_done = false, conc_copied = false;
+  int conc_bad = 0, conc_rank = 0;
+  const size_t k_bytes = (size_t)n_lasso * W * W * 8;
+  double* k_pin = (K_out && k_bytes <= ((size_t)64 << 20)) ? (double*)kp_pinned_scratch(ctx, k_bytes) : nullptr;
   // the least-squares solution is also the inactive-constraint answer of the lasso path; all lasso values run as one batch
   std::vector<double> tv;
   std::vector<double*> tdst;
@@ -1148,6 +1156,29 @@ extern "C" int kp_fit(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* sn
     if (is_ls) {
       if (ls_index >= 0) {
         KP_HIP(ctx, hipMemcpyAsync(Ki, ctx->Kres + (size_t)ls_index * W * W, (size_t)W * W * 8, hipMemcpyDeviceToDevice, ctx->stream));
+      } else if (concurrent) {
+        // The dictionary's last fit was rank deficient: the plain factorisation - still what DECIDES, so that no result depends
+        // on the history - runs on the second stream into a scratch K, beside the rank-revealing solve that will most likely
+        // be the answer, instead of in front of it with a host round trip between the two (~50 us of a 0.64 ms fit).
+        double* Ks = (double*)ctx->workspace(19, (size_t)W * W * 8);
+        if (!Ks) return ctx->fail(KP_ERR_HIP, "kp_fit: out of device memory");
+        KP_HIP(ctx, hipEventRecord(ctx->ev_gram_done, ctx->stream));
+        KP_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_gram_done, 0));
+        rc = kp_chol_solve_dev(ctx, Gd, Cd, W, W, Ks, ctx->stream2, nullptr, nullptr);
+        if (rc) return rc;
+        ls_index = i;
+        // (one value: its K goes to the caller's page-locked block in front of the solve's own synchronisation, not behind it)
+        conc_copied = K_out && n_lasso == 1;
+        rc = kp_pivchol_solve_dev(ctx, Gd, Cd, W, W, Ki, &conc_rank, basis->rank_hint, conc_copied ? (k_pin ? (void*)k_pin : (void*)K_out) : nullptr,
+                                  k_bytes, ctx->evp[3]);      // (synchronises the first stream)
+        if (rc) return rc;
+        rc = read_chol_info(ctx, W, W, &conc_bad, Gd, ctx->stream2);                          // (and the second)
+        if (rc) return rc;
+        if (!conc_bad) {                                                                        // full rank after all
+          KP_HIP(ctx, hipMemcpyAsync(Ki, Ks, (size_t)W * W * 8, hipMemcpyDeviceToDevice, ctx->stream));
+          conc_copied = false;
+        }
+        conc_done = true;
       } else {
         rc = kp_chol_solve_dev(ctx, Gd, Cd, W, W, Ki);
         if (rc) return rc;
@@ -1165,17 +1196,18 @@ extern "C" int kp_fit(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* sn
     KP_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   }
   (void)need_ls;
-  KP_HIP(ctx, hipEventRecord(ctx->evp[3], ctx->stream));
+  if (!conc_done) KP_HIP(ctx, hipEventRecord(ctx->evp[3], ctx->stream));
   // K to the caller: the caller's array is pageable, and a device-to-host copy into pageable memory goes through the
   // runtime's own staging (0.16 ms for the 0.9 MB of one W = 336 matrix); a direct DMA into the context's page-locked
   // block and a memcpy from there take 0.05 ms
-  const size_t k_bytes = (size_t)n_lasso * W * W * 8;
-  double* k_pin = (K_out && k_bytes <= ((size_t)64 << 20)) ? (double*)kp_pinned_scratch(ctx, k_bytes) : nullptr;
   // (a dictionary whose previous fit was rank deficient: the copy of a K that will most likely be replaced waits for the verdict)
-  const bool k_late = K_out && ls_index >= 0 && basis->rank_hint > 0;
-  if (K_out && !k_late) KP_HIP(ctx, hipMemcpyAsync(k_pin ? k_pin : K_out, ctx->Kres, k_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  const bool k_late = K_out && ls_index >= 0 && basis->rank_hint > 0 && !conc_done;
+  if (K_out && !k_late && !conc_copied) KP_HIP(ctx, hipMemcpyAsync(k_pin ? k_pin : K_out, ctx->Kres, k_bytes, hipMemcpyDeviceToHost, ctx->stream));
   int bad = 0;
-  if (ls_index >= 0) {
+  if (conc_done) {
+    bad = conc_bad;
+    if (!conc_copied) KP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  } else if (ls_index >= 0) {
     rc = read_chol_info(ctx, W, W, &bad, Gd);
     if (rc) return rc;
     if (k_late && !bad) {
@@ -1192,7 +1224,13 @@ extern "C" int kp_fit(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* sn
   }
   ctx->last_rank = W;
   if (!bad && ls_index >= 0) basis->rank_hint = 0;
-  if (k_pin && !bad) memcpy(K_out, k_pin, k_bytes);
+  if (k_pin && (!bad || conc_done)) memcpy(K_out, k_pin, k_bytes);      // (conc_done: whichever K it is, it is final)
+  if (bad && conc_done) {
+    ctx->last_rank = conc_rank;
+    basis->rank_hint = conc_rank < W ? conc_rank : 0;
+    ctx->err = "warning: Gram matrix is rank deficient; basic solution returned (kp_fit_last_rank)";
+    return KP_OK;
+  }
   if (bad) {
     // rank-deficient dictionary (Ksysid.m:1069 on the arm data without dim_red): basic solution + rank, like MATLAB's `\`
     int r = 0;

@@ -343,7 +343,10 @@ __global__ void kp_scatter_rows_kernel(const double* __restrict__ Ks, int W, int
 // rank_hint > 0: the rank this matrix is expected to have (the previous fit of the same dictionary): only the panels that reach it
 // are queued at first - each panel launched behind the one that finds the rank is an empty launch of ~4 us, and so is its update -
 // and the rest follow, with the second stage repeated, if the factorisation turns out not to be finished.
-int kp_pivchol_solve_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, int W, int ncols, double* K_dev, int* rank, int rank_hint) {
+// k_host (or nullptr): K_dev is also copied there (k_bytes), in front of the synchronisation; ev_solved (or nullptr): recorded behind
+// the last kernel of the solve.
+int kp_pivchol_solve_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, int W, int ncols, double* K_dev, int* rank, int rank_hint, void* k_host,
+                         size_t k_bytes, hipEvent_t ev_solved) {
   if (W > 1024 * PC_RPT_MAX) return ctx->fail(KP_ERR_ARG, "rank-revealing solve: W <= 4096");
   hipStream_t s = ctx->stream;
   const int n_max = (W + 15) / 16 * 16, ncp = (ncols + 15) / 16 * 16;
@@ -414,6 +417,8 @@ int kp_pivchol_solve_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, 
     hipLaunchKernelGGL(kp_scatter_rows_kernel, dim3((unsigned)(((int64_t)W * ncols + 255) / 256)), dim3(256), 0, s, (const double*)Cp, W, ncols, (const int*)perm,
                        (const PivState*)stt, n, K_dev);
     KP_HIP(ctx, hipGetLastError());
+    if (ev_solved) KP_HIP(ctx, hipEventRecord(ev_solved, s));
+    if (k_host) KP_HIP(ctx, hipMemcpyAsync(k_host, K_dev, k_bytes, hipMemcpyDeviceToHost, s));
     KP_HIP(ctx, hipMemcpyAsync(hp, stt, sizeof(PivState), hipMemcpyDeviceToHost, s));
     KP_HIP(ctx, hipStreamSynchronize(s));
     return KP_OK;
