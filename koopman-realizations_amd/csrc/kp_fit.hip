@@ -842,12 +842,14 @@ static int check_info(kp_ctx* ctx) {
   return KP_OK;
 }
 
-static int read_chol_info(kp_ctx* ctx, int W, int ncols, int* bad, const double* G_dev = nullptr, hipStream_t st = nullptr) {
+// phase 1: only queue the ratio kernel (it stores the info word and the ratio into the context's page-locked words itself);
+// phase 2: it was queued before - wait for the stream and read the words; 0: both.
+static int read_chol_info(kp_ctx* ctx, int W, int ncols, int* bad, const double* G_dev = nullptr, hipStream_t st = nullptr, int phase = 0) {
   if (!st) st = ctx->stream;
   const int n = (W + 15) / 16 * 16;
   const size_t off = kp_chol_info_offset(W, ncols);
   double* ratio_dev = (double*)((char*)ctx->ws[5] + off + 8);
-  if (G_dev) {     // the factor is still in the padded buffer at the head of workspace 5
+  if (G_dev && phase != 2) {     // the factor is still in the padded buffer at the head of workspace 5
     hipLaunchKernelGGL(kp_pivot_ratio_kernel, dim3(1), dim3(256), 0, st, (const double*)ctx->ws[5], n, G_dev, W, ratio_dev,
                        (const int*)((char*)ctx->ws[5] + off), ctx->pin_small);
     KP_HIP(ctx, hipGetLastError());
@@ -855,6 +857,7 @@ static int read_chol_info(kp_ctx* ctx, int W, int ncols, int* bad, const double*
   // info word (offset `off`) and pivot ratio (off + 8) sit side by side: the ratio kernel stores both into the context's
   // page-locked words itself; without it (no G) one 16-byte DMA brings them (two staged copies into pageable words were
   // 25 us of the one-fit latency, tools/fit_timeline.py)
+  if (phase == 1) return KP_OK;
   if (ctx->pin_small) {
     if (!G_dev) KP_HIP(ctx, hipMemcpyAsync(ctx->pin_small, (char*)ctx->ws[5] + off, 16, hipMemcpyDeviceToHost, st));
     KP_HIP(ctx, hipStreamSynchronize(st));
@@ -1167,12 +1170,16 @@ extern "C" int kp_fit(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* sn
         rc = kp_chol_solve_dev(ctx, Gd, Cd, W, W, Ks, ctx->stream2, nullptr, nullptr);
         if (rc) return rc;
         ls_index = i;
+        if (ctx->pin_small) {                                                                   // (its verdict is ready long before it is read)
+          rc = read_chol_info(ctx, W, W, &conc_bad, Gd, ctx->stream2, 1);
+          if (rc) return rc;
+        }
         // (one value: its K goes to the caller's page-locked block in front of the solve's own synchronisation, not behind it)
         conc_copied = K_out && n_lasso == 1;
         rc = kp_pivchol_solve_dev(ctx, Gd, Cd, W, W, Ki, &conc_rank, basis->rank_hint, conc_copied ? (k_pin ? (void*)k_pin : (void*)K_out) : nullptr,
-                                  k_bytes, ctx->evp[3]);      // (synchronises the first stream)
+                                  k_bytes, ctx->evp[3], k_pin ? 1 : 0);      // (synchronises the first stream)
         if (rc) return rc;
-        rc = read_chol_info(ctx, W, W, &conc_bad, Gd, ctx->stream2);                          // (and the second)
+        rc = read_chol_info(ctx, W, W, &conc_bad, Gd, ctx->stream2, ctx->pin_small ? 2 : 0);  // (and the second)
         if (rc) return rc;
         if (!conc_bad) {                                                                        // full rank after all
           KP_HIP(ctx, hipMemcpyAsync(Ki, Ks, (size_t)W * W * 8, hipMemcpyDeviceToDevice, ctx->stream));
@@ -1202,6 +1209,7 @@ extern "C" int kp_fit(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* sn
   // block and a memcpy from there take 0.05 ms
   // (a dictionary whose previous fit was rank deficient: the copy of a K that will most likely be replaced waits for the verdict)
   const bool k_late = K_out && ls_index >= 0 && basis->rank_hint > 0 && !conc_done;
+  // (the copy engine here, not kp_copy_to_host_async's stores: it runs beside the ratio kernel that follows - 0.815 against 0.823 ms)
   if (K_out && !k_late && !conc_copied) KP_HIP(ctx, hipMemcpyAsync(k_pin ? k_pin : K_out, ctx->Kres, k_bytes, hipMemcpyDeviceToHost, ctx->stream));
   int bad = 0;
   if (conc_done) {

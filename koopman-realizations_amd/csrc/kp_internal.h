@@ -325,8 +325,9 @@ bool kp_chol_ll_applicable(int n);
 hipError_t kp_chol_ll_launch(double* Gp, int n, int nb, int* info, int* sticky, int prof, hipStream_t st, const double* thr = nullptr);
 // substitution with a factor the caller already holds (kp_fit.hip)
 int kp_factor_substitute_dev(kp_ctx* ctx, double* Lp, int n, double* Cp, int ncp, double* Dinv, hipStream_t st);
+int kp_copy_to_host_async(kp_ctx* ctx, const void* src_dev, void* dst_host, size_t bytes, int mapped, hipStream_t s);
 int kp_pivchol_solve_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, int W, int ncols, double* K_dev, int* rank, int rank_hint = 0,
-                         void* k_host = nullptr, size_t k_bytes = 0, hipEvent_t ev_solved = nullptr);
+                         void* k_host = nullptr, size_t k_bytes = 0, hipEvent_t ev_solved = nullptr, int k_host_mapped = 0);
 int kp_comm_allreduce_dev(kp_ctx* ctx, double* buf_dev, size_t count, hipStream_t s);
 // queued (deferred) solves of the asynchronous pipeline are launched; nothing is waited for, no status is consumed (kp_fit.hip)
 int kp_flush_pending(kp_ctx* ctx);

@@ -329,6 +329,25 @@ __global__ void kp_pivchol_gather_kernel(const double* __restrict__ L, const dou
   }
 }
 
+__global__ __launch_bounds__(256) void kp_copy16_kernel(const double2* __restrict__ src, double2* __restrict__ dst, int64_t n) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e < n) dst[e] = src[e];
+}
+
+// Device -> host copy of a result the caller waits for.  mapped (a page-locked, device-mapped destination such as
+// kp_pinned_scratch's block) and a multiple of 16 bytes of at most 8 MB: plain stores over PCIe by a kernel - the runtime's copy
+// engine moved the 0.9 MB of a W = 336 matrix at ~25 GB/s (36 us), the stores take ~20.  Otherwise hipMemcpyAsync.
+int kp_copy_to_host_async(kp_ctx* ctx, const void* src_dev, void* dst_host, size_t bytes, int mapped, hipStream_t s) {
+  if (mapped && bytes % 16 == 0 && bytes <= ((size_t)8 << 20) && !getenv("KP_NO_STORE_COPY")) {
+    const int64_t nd = (int64_t)(bytes / 16);
+    hipLaunchKernelGGL(kp_copy16_kernel, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, s, (const double2*)src_dev, (double2*)dst_host, nd);
+    KP_HIP(ctx, hipGetLastError());
+    return KP_OK;
+  }
+  KP_HIP(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, s));
+  return KP_OK;
+}
+
 // K (W x ncols, zeroed) [perm[a], c] = Ks[a, c] for a < r  (Ks with leading dimension n)
 __global__ void kp_scatter_rows_kernel(const double* __restrict__ Ks, int W, int ncols, const int* __restrict__ perm, const PivState* __restrict__ stt,
                                        int n, double* __restrict__ K) {
@@ -346,7 +365,7 @@ __global__ void kp_scatter_rows_kernel(const double* __restrict__ Ks, int W, int
 // k_host (or nullptr): K_dev is also copied there (k_bytes), in front of the synchronisation; ev_solved (or nullptr): recorded behind
 // the last kernel of the solve.
 int kp_pivchol_solve_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, int W, int ncols, double* K_dev, int* rank, int rank_hint, void* k_host,
-                         size_t k_bytes, hipEvent_t ev_solved) {
+                         size_t k_bytes, hipEvent_t ev_solved, int k_host_mapped) {
   if (W > 1024 * PC_RPT_MAX) return ctx->fail(KP_ERR_ARG, "rank-revealing solve: W <= 4096");
   hipStream_t s = ctx->stream;
   const int n_max = (W + 15) / 16 * 16, ncp = (ncols + 15) / 16 * 16;
@@ -418,7 +437,10 @@ int kp_pivchol_solve_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, 
                        (const PivState*)stt, n, K_dev);
     KP_HIP(ctx, hipGetLastError());
     if (ev_solved) KP_HIP(ctx, hipEventRecord(ev_solved, s));
-    if (k_host) KP_HIP(ctx, hipMemcpyAsync(k_host, K_dev, k_bytes, hipMemcpyDeviceToHost, s));
+    if (k_host) {
+      int rcc = kp_copy_to_host_async(ctx, K_dev, k_host, k_bytes, k_host_mapped, s);
+      if (rcc) return rcc;
+    }
     KP_HIP(ctx, hipMemcpyAsync(hp, stt, sizeof(PivState), hipMemcpyDeviceToHost, s));
     KP_HIP(ctx, hipStreamSynchronize(s));
     return KP_OK;
