@@ -1143,6 +1143,7 @@ extern "C" int kp_fit(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* sn
   bool need_ls = false;
   for (int i = 0; i < n_lasso; ++i) need_ls |= (!lasso || !(lasso[i] < 1e6));
   int ls_index = -1;
+  if (const char* e = getenv("KP_RANK_HINT_TEST")) basis->rank_hint = atoi(e);      // (tests: a remembered rank that is wrong in a chosen way)
   // (see below) least-squares values only, the narrow path, a second stream to run on
   const bool concurrent = basis->rank_hint > 0 && all_ls && ctx->stream2 && W <= 16 * 4 * TR_MAXJ && !ctx->reduce_grams && !ctx->gc_preloaded &&
                           !getenv("KP_NO_RANK_HINT");

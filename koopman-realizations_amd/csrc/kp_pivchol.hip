@@ -422,10 +422,10 @@ int kp_pivchol_solve_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, 
   }
   PivState h{};
   PivState* hp = ctx->pin_small ? reinterpret_cast<PivState*>(ctx->pin_small + 4) : &h;     // (page-locked words of the context: direct DMA)
-  auto second_stage = [&]() -> int {
-    // everything behind the factorisation is queued without knowing the rank: the substitution runs at the full (padded) width
-    // with an identity block beyond the rank - ~30 % more substitution work at rank 252 of 336 against two host round trips
-    const int n = n_max;
+  auto second_stage = [&](int n) -> int {
+    // everything behind the factorisation is queued without knowing the rank: the substitution runs at width n - the full
+    // (padded) width, or the remembered rank rounded up to 16 (checked afterwards) - with an identity block beyond the rank:
+    // ~30 % more substitution work at rank 252 of 336 without a hint, against two host round trips
     KP_HIP(ctx, hipMemsetAsync(K_dev, 0, (size_t)W * ncols * 8, s));
     const int64_t tot = (int64_t)n * n + (int64_t)n * ncp;
     hipLaunchKernelGGL(kp_pivchol_gather_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, (const double*)L, C_dev, W, ncols, (const int*)perm,
@@ -445,14 +445,18 @@ int kp_pivchol_solve_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, 
     KP_HIP(ctx, hipStreamSynchronize(s));
     return KP_OK;
   };
+  const int n_hint = (rank_hint > 0 && rank_hint < W) ? std::min(n_max, (rank_hint + 15) / 16 * 16) : n_max;
   {
-    int rcs = second_stage();
+    int rcs = second_stage(n_hint);
     if (rcs) return rcs;
   }
   if (!hp->done && k_done < W) {                  // the hint was too small: the remaining panels, and the second stage again
     int rcp = run_panels(k_done, W);
-    if (!rcp) rcp = second_stage();
+    if (!rcp) rcp = second_stage(n_max);
     if (rcp) return rcp;
+  } else if (hp->done && hp->rank > n_hint) {     // finished in the hinted panels, but at a rank beyond the hinted width
+    int rcs = second_stage(n_max);
+    if (rcs) return rcs;
   }
   if (rank) *rank = hp->done ? hp->rank : W;
   return KP_OK;

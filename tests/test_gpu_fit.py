@@ -730,3 +730,26 @@ def test_fits_do_not_depend_on_what_the_dictionary_was_fitted_on_before(ctx):
             ranks.append(r1)
             s.close(); fresh.close()
     assert ranks[0] == 336 and ranks[3] == 336 and ranks[1] < ranks[2] - 32 and ranks[5] < ranks[4] - 32, ranks
+
+
+@pytest.mark.parametrize("hint", [0, 100, 200, 240, 252, 300, 335])
+def test_a_wrong_remembered_rank_changes_nothing(ctx, arm, hint):
+    """The arm data's raw bilinear poly-3 dictionary has rank 252 of 336.  Whatever rank the dictionary 'remembers' (forced here
+    through KP_RANK_HINT_TEST) - far too small (the factorisation continues behind the first synchronisation), a little too
+    small (finished within the queued panels but beyond the width the substitution was queued at: repeated at full width), exact,
+    too large - the fit returns the same K bit for bit, and the rank."""
+    import os, warnings
+    p = arm["pairs"]
+    dic = ko.build_dictionary("bilinear", 6, 3, ["poly"], [3])
+    b = make_basis(ctx, dic)
+    snaps = kra.Snapshots(ctx, p["alpha"], p["beta"], p["u"])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        Kref = kra.fit(ctx, make_basis(ctx, dic), snaps)[0]
+        assert ctx.last_rank() == 252
+        os.environ["KP_RANK_HINT_TEST"] = str(hint)
+        try:
+            K = kra.fit(ctx, b, snaps)[0]
+        finally:
+            del os.environ["KP_RANK_HINT_TEST"]
+    assert ctx.last_rank() == 252 and np.array_equal(K, Kref)
