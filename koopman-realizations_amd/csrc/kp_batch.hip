@@ -982,7 +982,6 @@ __global__ __launch_bounds__(256, 2) void kp_traj_gram_mfma_kernel(BasisDev b, c
   const int tid = threadIdx.x, sys = blockIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid < N) recs[tid] = recipes[tid];
   const int side = tid >> 7, p = tid & (TG_TS - 1);
-  const int Tm1 = tv.T - 1;
   // constant entries of both buffers
   for (int e = tid; e < 2 * 2 * 2 * TGM_STR; e += 256) {
     const int pp = e % TGM_STR, which = (e / TGM_STR) & 1, sd = (e / (2 * TGM_STR)) & 1, bf = e / (4 * TGM_STR);
