@@ -31,6 +31,106 @@ PEAK_F64_MFMA_TFLOPS = 78.6   # MI355X FP64 matrix (vendor datasheet; the guide 
 PEAK_HBM_GBS = 8000.0
 
 
+COMPACT_LINE_LIMIT = 4000     # bytes; the driver parses the LAST stdout line and lost round 5's 21.7 KB one
+
+
+def _r(x, sig=6):
+    """Numbers of the compact line: `sig` significant digits."""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, float):
+        return float(f"{x:.{sig}g}")
+    if isinstance(x, dict):
+        return {k: _r(v, sig) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, sig) for v in x]
+    return x
+
+
+def compact_line(res):
+    """The ONE stdout line: the contract's keys, `roofline`, `cpu_baseline` and a few-number summary of each secondary
+    section, well under COMPACT_LINE_LIMIT bytes.  Everything else (`res` whole) goes to stderr and to bench_detail.json
+    (emit_result).  Pure function of `res` so that tests/test_bench_line.py can size it without a GPU."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data")
+    out = {k: res.get(k) for k in keep}
+    cfg = res.get("config", {})
+    out["config"] = {k: cfg[k] for k in ("workload", "snapshots_per_gpu", "W", "parallelism", "comm") if k in cfg}
+    rf = res.get("roofline")
+    if rf:
+        out["roofline"] = {k: rf[k] for k in ("kernel", "bound", "ms", "achieved", "peak", "unit", "frac", "traffic",
+                                              "executed_flop_per_launch", "dense_equivalent_flop_per_launch", "dense_equivalent_frac",
+                                              "algorithmic_bytes_per_launch") if k in rf}
+    cb = res.get("cpu_baseline")
+    if cb:
+        o = {k: cb[k] for k in ("value", "unit", "cores", "kind") if k in cb}
+        o["sample"] = str(cb.get("sample", ""))[:200]
+        if "one_thread" in cb:
+            o["one_thread_value"] = cb["one_thread"].get("value")
+        if "mpc" in cb:
+            o["mpc_steps_per_s"] = cb["mpc"].get("value")
+        out["cpu_baseline"] = o
+    for k in ("fit_latency_ms", "fit_with_K_fetched_ms"):
+        if k in res:
+            out[k] = res[k]
+    if "kernel_ms" in res:
+        out["kernel_ms"] = {k: res["kernel_ms"].get(k) for k in ("gram", "gram_reduce", "solve")}
+    m = res.get("mpc")
+    if m:
+        out["mpc"] = {k: m[k] for k in ("single_steps_per_s", "single_kernel_us", "closed_loop_steps_per_s", "closed_loop_us_per_step",
+                                        "closed_loop_kernel_us", "batch_problems_per_s") if k in m}
+    a = res.get("mpc_arm_blockM")
+    if a:
+        out["mpc_arm"] = {k: a[k] for k in ("steps_per_s", "controller_us_per_step", "get_koopman_end_to_end_ms") if k in a}
+    pts = {}
+    for sec in ("width_points", "snapshot_count_points", "wide_dictionaries"):
+        for name, w in (res.get(sec) or {}).items():
+            if isinstance(w, dict) and "error" not in w:
+                r_ = w.get("roofline", {})
+                pts[name] = [w.get("gram_ms"), r_.get("frac"), w.get("ms_per_fit")]
+    if pts:
+        out["points"] = dict(pts, _fields="[gram_ms, executed frac of f64 MFMA peak, ms_per_fit]")
+    l = res.get("lasso_grid")
+    if l:
+        out["lasso_grid"] = {k: l[k] for k in ("values", "values_per_s", "seconds", "n_gpus") if k in l}
+    sw = res.get("rand_sweep")
+    if sw:
+        out["rand_sweep"] = {k: sw[k] for k in ("systems", "systems_per_s", "seconds", "n_gpus") if k in sw}
+    sh = res.get("snapshot_sharded_fit")
+    if sh:
+        out["snapshot_sharded_fit"] = {k: (v.get("pairs_per_s") if isinstance(v, dict) else v) for k, v in sh.items()}
+    oc = res.get("one_caller")
+    if oc:
+        out["one_caller"] = ({"error": str(oc["error"])[:120]} if "error" in oc else
+                             {"n_devices": len(oc.get("device_ids", [])),
+                              "lasso_values_per_s": (oc.get("lasso_grid") or {}).get("values_per_s"),
+                              "rand_systems_per_s": (oc.get("rand_sweep") or {}).get("systems_per_s")})
+    out["detail"] = "bench_detail.json (also one line on stderr)"
+    out = _r(out)
+    line = json.dumps(out, separators=(",", ":"))
+    if len(line) > COMPACT_LINE_LIMIT:              # never again a line the driver cannot take: shed the summaries first
+        for k in ("points", "one_caller", "snapshot_sharded_fit", "mpc_arm", "rand_sweep", "lasso_grid", "mpc", "kernel_ms"):
+            out.pop(k, None)
+            line = json.dumps(out, separators=(",", ":"))
+            if len(line) <= COMPACT_LINE_LIMIT:
+                break
+    return line
+
+
+def emit_result(res, compact=True):
+    """Detail -> stderr (one line) and bench_detail.json / gpurun_out/bench_detail.json; the compact line -> stdout, last."""
+    full = json.dumps(res)
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        try:
+            os.makedirs(d, exist_ok=True)
+            with open(os.path.join(d, "bench_detail.json"), "w") as f:
+                f.write(full + "\n")
+        except OSError:
+            pass
+    print(full, file=sys.stderr, flush=True)
+    print(compact_line(res) if compact else full, flush=True)
+
+
 def synth_pairs(Ns, nz=6, m=3, seed=0):
     rng = np.random.default_rng(seed)
     alpha = rng.uniform(-1, 1, (Ns, nz)); u = rng.uniform(-1, 1, (Ns, m))
@@ -944,7 +1044,7 @@ def main():
                 res["cpu_baseline"]["mpc"] = cpu_baseline_mpc(mpc_res.pop("_setup"))
         if mpc_res is not None:
             mpc_res.pop("_setup", None)
-        print(json.dumps(res), flush=True)
+        emit_result(res)
     # ranks other than 0 idle (no collective in flight: an RCCL barrier would spin on their GPUs) until rank 0 is through with
     # its host-only sections and the one-caller block, which uses every GPU of the launch
     flag = os.path.join("/tmp", f"kp_bench_done_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}")
