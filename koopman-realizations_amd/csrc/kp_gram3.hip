@@ -68,9 +68,16 @@
 
 // PCS: econ lift through a projection matrix (dim_red dictionaries)
 // EXT: fourier (def_fourierLift, Ksysid.m:694-731) and gaussian (def_gaussianLift, :790-817) blocks through the same table
-template <int NQ, int BM, bool PCS, bool EXT = false, bool PRE = false>
+// TUP (round 6; BM = 3 only): the four blocks of a weighted A operand carry TWO weights - tuple p = (w_2p, w_2p, w_2p+1, w_2p+1) -
+// against B operands (g0, g1, g0, g1) and (g2, g3, g2, g3) of the quad: the same 10 MFMAs per quad and k-step produce the same
+// 40 (weight, group) blocks, bit for bit, with 5 weight multiplies per A group and k-step instead of 9 (nothing on the vector
+// pipe overlaps the f64 MFMA stream: each costs ~5.5 cycles of it) and 10 operand registers less; the price is a second
+// operand read per quad, which the LDS has room for (it was 31 % busy).  The weights sit at WOFF3 + [0, 10) with w_0 = 1 stored.
+template <int NQ, int BM, bool PCS, bool EXT = false, bool PRE = false, bool TUP = false>
 __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
   constexpr int NWT = (BM + 1) * (BM + 2) / 2;
+  static_assert(!TUP || BM == 3, "paired weights: 10 weights = 5 tuples");
+  constexpr int WSH = TUP ? 1 : 0;                  // TUP: slot 0 of the weight entries holds w_0 = 1
   extern __shared__ __align__(16) double sm[];
   const BasisDev& b = a.b;
   const int tid = threadIdx.x;
@@ -97,12 +104,19 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
   const int ao1 = PSI03 + lrow + 4 * (int)((jh >> 8) & 255u) + lc;
   const int qs = __builtin_amdgcn_readfirstlane((int)((jh >> 16) & 255u));   // wave-uniform
   int bo[NQ];
+  int bo2[TUP ? NQ : 1];
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
-    const int g = (int)((jd[1 + q] >> (8 * blk)) & 255u);
+    // TUP: block b of the first B operand reads group (b & 1) of the quad, of the second one group 2 + (b & 1)
+    const int g = (int)((jd[1 + q] >> (8 * (TUP ? (blk & 1) : blk))) & 255u);
     bo[q] = PSI03 + lrow + (g < a.G4 ? 4 * g : g < 2 * a.G4 ? YOFF3 + 4 * (g - a.G4) : ZOFF3) + lc;
+    if (TUP) {
+      const int g2 = (int)((jd[1 + q] >> (8 * (2 + (blk & 1)))) & 255u);
+      bo2[q] = PSI03 + lrow + (g2 < a.G4 ? 4 * g2 : g2 < 2 * a.G4 ? YOFF3 + 4 * (g2 - a.G4) : ZOFF3) + lc;
+    }
   }
-  const int wo = PSI03 + lrow + WOFF3;
+  // TUP: this lane's weight of tuple p is entry 2 p + (blk >> 1)
+  const int wo = PSI03 + lrow + WOFF3 + (TUP ? (blk >> 1) : 0);
 
   double acc[NQ][NWT];
 #pragma unroll
@@ -112,6 +126,10 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
 
   // ---- one-time LDS setup: everything zero (padding columns and the zero group stay zero) ----
   for (int e = tid; e < LDS3_DOUBLES; e += 256) sm[e] = 0.0;
+  if (TUP) {   // w_0 = 1 in every row of both Psi buffers (rows past Ns have psi = 0: the tail mask needs no weight)
+    __syncthreads();
+    if (tid < 2 * KT3) sm[PSI03 + (tid / KT3) * PSIBUF3 + (tid & (KT3 - 1)) * RS3 + WOFF3] = 1.0;
+  }
   if (EXT) {   // gaussian centres (centre-major, nzeta coordinates each)
     for (int e = tid; e < a.ng * b.nzeta; e += 256) sm[GC03 + e] = a.centres[e];
   }
@@ -153,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
         ++cnt;
       }
   }
-  const int wdst = PSI03 + wts * RS3 + WOFF3 + (is_wt ? wtw : 0);
+  const int wdst = PSI03 + wts * RS3 + WOFF3 + WSH + (is_wt ? wtw : 0);
 
   const int64_t kt0 = (int64_t)split * a.ktiles_per_split;
   const int64_t ktiles_total = (a.Ns + KT3 - 1) / KT3;
@@ -276,7 +294,7 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
       // of this kernel's LDS cycles were conflicts)
       const int e1 = pre_on[j] ? e : 0;
       const int sp = e1 / a.pre_rl, c = e1 - sp * a.pre_rl, srow = 2 * sp;
-      const int off = c < 4 * a.G4 ? c : c < 8 * a.G4 ? YOFF3 + (c - 4 * a.G4) : WOFF3 + (c - 8 * a.G4);
+      const int off = c < 4 * a.G4 ? c : c < 8 * a.G4 ? YOFF3 + (c - 4 * a.G4) : WOFF3 + WSH + (c - 8 * a.G4);
       pre_dst[j] = PSI03 + srow * RS3 + off;
     }
   }
@@ -414,32 +432,43 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
     RawRegs rawreg;
     PreRegs prereg;
     if constexpr (!PRE) lift_begin(NXT{});
+    constexpr int NAW = TUP ? NWT / 2 : NWT;           // weighted A operands per A group (TUP: tuples of two weights)
     double bvs[NSTEP];
-    double aw[NWT];
-    double wt[NWT];
+    double bvs2[TUP ? NSTEP : 1];                      // TUP: the quad's second B operand (groups 2, 3)
+    double aw[NAW];
+    double wt[NAW];
     double av1 = 0.0;
     double avn0, avn1 = 0.0;                           // raw A fragments of the NEXT k-step (prefetched)
     auto weigh = [&](double av) __attribute__((always_inline)) {
 #pragma unroll
-      for (int w = 0; w < NWT; ++w) {
+      for (int w = 0; w < NAW; ++w) {
 #if KP_ABL3 == 7
         aw[w] = av;
 #else
-        aw[w] = w == 0 ? av : av * wt[w];
+        aw[w] = (!TUP && w == 0) ? av : av * wt[w];
 #endif
       }
     };
 #pragma unroll
-    for (int i = 0; i < PF; ++i) bvs[i] = sm[PB + (i / NQ) * 4 * RS3 + bo[i % NQ]];
+    for (int i = 0; i < PF; ++i) {
+      bvs[i] = sm[PB + (i / NQ) * 4 * RS3 + bo[i % NQ]];
+      if constexpr (TUP) bvs2[i] = sm[PB + (i / NQ) * 4 * RS3 + bo2[i % NQ]];
+    }
     avn0 = sm[PB + ao0];
     if (QS < NQ) avn1 = sm[PB + ao1];
-    // the NWT-1 weights of k-step kk, as 16-byte LDS reads (a pair each; immediate offsets, no address arithmetic)
+    // the NWT-1 weights of k-step kk, as 16-byte LDS reads (a pair each; immediate offsets, no address arithmetic);
+    // TUP: this lane's weight of each of the 5 tuples, 8-byte reads at immediate offsets from its own base
     auto load_wt = [&](int kk) __attribute__((always_inline)) {
+      if constexpr (TUP) {
 #pragma unroll
-      for (int w = 0; w < NWT - 1; w += 2) {
-        const double2 v = *reinterpret_cast<const double2*>(&sm[PB + kk * 4 * RS3 + wo + w]);
-        wt[w + 1] = v.x;
-        if (w + 2 < NWT) wt[w + 2] = v.y;
+        for (int w = 0; w < NAW; ++w) wt[w] = sm[PB + kk * 4 * RS3 + wo + 2 * w];
+      } else {
+#pragma unroll
+        for (int w = 0; w < NWT - 1; w += 2) {
+          const double2 v = *reinterpret_cast<const double2*>(&sm[PB + kk * 4 * RS3 + wo + w]);
+          wt[w + 1] = v.x;
+          if (w + 2 < NWT) wt[w + 2] = v.y;
+        }
       }
     };
     load_wt(0);
@@ -463,13 +492,27 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
       if (QS < NQ && QS > 1 && q == QS - 1) load_wt(kk);
       if (q == NQ - 1 && kk + 1 < KT3 / 4) load_wt(kk + 1);
 #if KP_ABL3 != 6
-      if (step + PF < NSTEP) bvs[step + PF] = sm[PB + ((step + PF) / NQ) * 4 * RS3 + bo[(step + PF) % NQ]];
+      if (step + PF < NSTEP) {
+        bvs[step + PF] = sm[PB + ((step + PF) / NQ) * 4 * RS3 + bo[(step + PF) % NQ]];
+        if constexpr (TUP) bvs2[step + PF] = sm[PB + ((step + PF) / NQ) * 4 * RS3 + bo2[(step + PF) % NQ]];
+      }
       const double bv = bvs[step];
+      const double bv2 = TUP ? bvs2[step] : 0.0;
 #else
       const double bv = bvs[step % PF];
+      const double bv2 = TUP ? bvs2[step % PF] : 0.0;
 #endif
+      if constexpr (TUP) {
+        // accumulator 2 p + h: blocks b = (weight 2 p + (b >> 1), group 2 h + (b & 1) of the quad)
 #pragma unroll
-      for (int w = 0; w < NWT; ++w) acc[q][w] = __builtin_amdgcn_mfma_f64_4x4x4f64(aw[w], bv, acc[q][w], 0, 0, 0);
+        for (int w = 0; w < NAW; ++w) {
+          acc[q][2 * w] = __builtin_amdgcn_mfma_f64_4x4x4f64(aw[w], bv, acc[q][2 * w], 0, 0, 0);
+          acc[q][2 * w + 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(aw[w], bv2, acc[q][2 * w + 1], 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int w = 0; w < NWT; ++w) acc[q][w] = __builtin_amdgcn_mfma_f64_4x4x4f64(aw[w], bv, acc[q][w], 0, 0, 0);
+      }
 #if KP_ABL3 != 1 && KP_ABL3 != 6
       // one register set for the chunk in flight: the write of chunk i precedes the read of chunk i+1
       if constexpr (!PRE) {
@@ -520,11 +563,14 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
 
 // Sums the partials of one (job, quad, weight) block vector in split order and scatters the
 // 4 blocks (4x4 each) into G and C.  lane l: block = (l>>2)&3, row r = l>>4, col c = l&3.
+// tup (kp_gram3_kernel<.., TUP = true>): accumulator w' = 2 p + h of a quad holds, in block b, weight 2 p + (b >> 1) against
+// group 2 h + (b & 1) of the quad.
 __global__ __launch_bounds__(256) void kp_gram3_reduce_kernel(const double* __restrict__ part, int nsplit, int njobs, int NQ, int NWT,
                                                              int BM, const uint32_t* __restrict__ desc, int G4, int N, int W,
-                                                             double* __restrict__ G, double* __restrict__ C) {
+                                                             double* __restrict__ G, double* __restrict__ C, int tup) {
   const int idx = blockIdx.x;                 // (job*NQ + q)*NWT + w
-  const int w = idx % NWT, jq = idx / NWT, q = jq % NQ, job = jq / NQ;
+  int w = idx % NWT;
+  const int jq = idx / NWT, q = jq % NQ, job = jq / NQ;
   const int l = threadIdx.x & 63, wv = threadIdx.x >> 6;   // 4 waves share the split sum (fixed order: deterministic)
   __shared__ double red4[4][64];
   const size_t per_split = (size_t)njobs * NQ * NWT * 64;
@@ -536,7 +582,13 @@ __global__ __launch_bounds__(256) void kp_gram3_reduce_kernel(const double* __re
   s = (red4[0][l] + red4[1][l]) + (red4[2][l] + red4[3][l]);
   const uint32_t* jd = desc + (size_t)job * (1 + NQ);
   const int ga = q < (int)((jd[0] >> 16) & 255u) ? (int)(jd[0] & 255u) : (int)((jd[0] >> 8) & 255u);
-  const int gb = (int)((jd[1 + q] >> (8 * ((l >> 2) & 3))) & 255u);
+  int gsel = (l >> 2) & 3;
+  if (tup) {
+    const int b = gsel;
+    gsel = 2 * (w & 1) + (b & 1);
+    w = (w & ~1) + (b >> 1);
+  }
+  const int gb = (int)((jd[1 + q] >> (8 * gsel)) & 255u);
   if (gb >= 2 * G4) return;                   // zero group: padding of the last quad / idle job
   // weight index -> (x, y), x <= y
   int wa = 0, wb = 0, cnt = 0;
@@ -647,16 +699,31 @@ static int make_plan3(kp_ctx* ctx, int N, int nwt, int nq_cap, kp_gram3_plan** o
   return KP_OK;
 }
 
-template <int NQ, int BM, bool PCS, bool EXT = false, bool PRE = false>
-static hipError_t launch3b(const Gram3Args& a, int grid, size_t lds, hipStream_t st) {
+// BM = 3 runs the paired-weight form (TUP) of the kernel; KP_GRAM3_NOTUP=1 (read once) keeps the one-weight-per-operand form for
+// A/B measurements - the two write different partial layouts, the reduction is told which
+static bool gram3_tup(int bm) {
+  static const bool off = getenv("KP_GRAM3_NOTUP") != nullptr;
+  return bm == 3 && !off;
+}
+
+template <int NQ, int BM, bool PCS, bool EXT = false, bool PRE = false, bool TUP = false>
+static hipError_t launch3c(const Gram3Args& a, int grid, size_t lds, hipStream_t st) {
   static KpLdsCache lds_cache;
   {
     const size_t lds_max = (size_t)(LDS3_DOUBLES + (PCS ? LDS3_PCS_DOUBLES : 0) + (EXT ? LDS3_GAUSS_DOUBLES : 0)) * sizeof(double);
-    hipError_t e = kp_ensure_lds(lds_cache, (const void*)kp_gram3_kernel<NQ, BM, PCS, EXT, PRE>, lds_max);
+    hipError_t e = kp_ensure_lds(lds_cache, (const void*)kp_gram3_kernel<NQ, BM, PCS, EXT, PRE, TUP>, lds_max);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL((kp_gram3_kernel<NQ, BM, PCS, EXT, PRE>), dim3(grid), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((kp_gram3_kernel<NQ, BM, PCS, EXT, PRE, TUP>), dim3(grid), dim3(256), lds, st, a);
   return hipGetLastError();
+}
+
+template <int NQ, int BM, bool PCS, bool EXT = false, bool PRE = false>
+static hipError_t launch3b(const Gram3Args& a, int grid, size_t lds, hipStream_t st) {
+  if constexpr (BM == 3) {
+    if (gram3_tup(BM)) return launch3c<NQ, BM, PCS, EXT, PRE, true>(a, grid, lds, st);
+  }
+  return launch3c<NQ, BM, PCS, EXT, PRE, false>(a, grid, lds, st);
 }
 
 template <int NQ>
@@ -839,12 +906,16 @@ int kp_gram3_launch(kp_ctx* ctx, const kp_basis* basis_c, const kp_snapshots* s,
                                         (const uint32_t*)basis->d_recipes, (const double*)basis->d_pcsT, pre_buf, pre_rl, ctx->stream));
   if (plan.wpw == 8) e = kp_gram6_launch_kernel(a, plan.nq, grid, ctx->stream);
   else switch (plan.nq) {
+#ifndef KP_G3_DEV            // (development builds instantiate the headline shape only: the file takes minutes otherwise)
     case 1: e = launch3<1>(a, BM, grid, lds, ctx->stream); break;
     case 2: e = launch3<2>(a, BM, grid, lds, ctx->stream); break;
     case 3: e = launch3<3>(a, BM, grid, lds, ctx->stream); break;
     case 4: e = launch3<4>(a, BM, grid, lds, ctx->stream); break;
     case 5: e = launch3<5>(a, BM, grid, lds, ctx->stream); break;
     default: e = launch3<6>(a, BM, grid, lds, ctx->stream); break;
+#else
+    default: e = launch3b<6, 3, false>(a, grid, lds, ctx->stream); break;
+#endif
   }
   KP_HIP(ctx, e);
   if (timed) KP_HIP(ctx, hipEventRecord(ev_end, ctx->stream));
@@ -857,7 +928,7 @@ int kp_gram3_launch(kp_ctx* ctx, const kp_basis* basis_c, const kp_snapshots* s,
   }
   ctx->reduce_timed_from = ctx->reduce_stream ? 4 : 1;
   hipLaunchKernelGGL(kp_gram3_reduce_kernel, dim3(plan.njobs * plan.nq * NWT), dim3(256), 0, rs, part, nsplit, plan.njobs,
-                     plan.nq, NWT, BM, plan.desc, plan.G4, N, W, GC_dev, GC_dev + (size_t)W * W);
+                     plan.nq, NWT, BM, plan.desc, plan.G4, N, W, GC_dev, GC_dev + (size_t)W * W, plan.wpw != 8 && gram3_tup(BM) ? 1 : 0);
   KP_HIP(ctx, hipGetLastError());
   if (!pipelined) KP_HIP(ctx, hipEventRecord(ctx->ev1, rs));
   if (!ctx->ring_timing) KP_HIP(ctx, hipEventRecord(ctx->evp[2], rs));
