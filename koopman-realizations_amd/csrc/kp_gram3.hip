@@ -42,7 +42,7 @@
 #define ZOFF3 192
 #define WOFF3 196
 #define SOFF3 208
-#define NIDMAX3 128                 // power-table entries per snapshot (last used one: the constant / tail mask)
+#define NIDMAX3 144                 // power-table entries per snapshot (2 x 16 rows x 4 powers + the constant row's 4 fit)
 #define PST3 10                     // doubles per power-table entry: KT3 snapshots + 2 of padding, so that the 16-byte reads of
                                     // 64 lanes with arbitrary ids spread over all banks (a stride of 8 puts them on 4 groups)
 #define POWBUF3 (PST3 * NIDMAX3)    // doubles per power-table buffer
@@ -94,7 +94,13 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
   const int nzm = b.nzeta + b.m;
   const int nrawrows = 2 * nzm;
   const int D = a.D;
-  const int CID = nrawrows * D;                    // power-table id of the constant 1 (0 for snapshots past Ns)
+  // INL (monomial dictionaries lifted in the kernel): the power table of the tile after next is built INSIDE the MFMA loop -
+  // branch-free, four powers per raw value at a compile-time entry stride - instead of behind it (round 6: the end-of-tile
+  // build with its run-time power loop, its exec-mask branches and its wait for the raw load cost 29 of 389 us, timing-only
+  // build KP_ABL3=8).  kp_gram3_applicable admits monomial dictionaries with powers <= 4 only (others: kp_gram2 / general kernel).
+  constexpr bool INL = !EXT && !PRE;
+  const int DS = INL ? 4 : D;                      // table entries per raw row
+  const int CID = nrawrows * DS;                   // power-table id of the constant 1 (0 for snapshots past Ns)
 
   // ---- MFMA operand offsets (doubles, Psi buffer 0): row (lane>>4) of k-step 0 ----
   const uint32_t* jd = a.desc + (size_t)job * (1 + NQ);
@@ -143,35 +149,36 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
 
   // ---- lifting thread constants: thread = one (side, column), all KT3 snapshots of the tile ----
   // power table layout [id][snapshot]: the KT3 values of one entry are contiguous (16-byte reads of snapshot pairs)
+  // The NWT - 1 Kronecker weights ut_x ut_y (pair index w + 1 in (x <= y) order) are lifted like columns: thread 2 nfull + w
+  // multiplies the table entries of u_x and u_y (and the constant) for all KT3 snapshots and writes entry WOFF3 + WSH + w of the
+  // Psi rows.  (Until round 6 a separate step at the head of every tile formed them: an LDS round trip and a branch in front
+  // of the tile's first operand reads.)
   const bool lvalid = tid < 2 * b.nfull;
   const int lside = (lvalid && tid >= b.nfull) ? 1 : 0;
   const int lcol = lvalid ? tid - lside * b.nfull : 0;
+  const int lw = tid - 2 * b.nfull;                // weight thread: 0 <= lw < NWT - 1
+  const bool lwt = lw >= 0 && lw < NWT - 1;
   int fa[NF3];
   {
     const uint32_t r = lvalid ? a.recipes[lcol] : 0xffffffffu;
 #pragma unroll
     for (int f = 0; f < NF3; ++f) {
       const int id = (int)((r >> (8 * f)) & 255u);
-      fa[f] = (id == 255 ? CID : (EXT && id >= 128) ? CID + 1 + lside * a.ng + (id - 128) : lside * nzm * D + id) * PST3;
+      fa[f] = (id == 255 ? CID : (EXT && id >= 128) ? CID + 1 + lside * a.ng + (id - 128) : lside * nzm * DS + (id / D) * DS + id % D) * PST3;
+    }
+    if (lwt) {
+      int cnt = 0;
+      for (int x = 0; x <= BM; ++x)
+        for (int y = x; y <= BM; ++y) {
+          if (cnt == lw + 1) {
+            if (x > 0) fa[0] = (b.nzeta + x - 1) * DS * PST3;
+            if (y > 0) fa[1] = (b.nzeta + y - 1) * DS * PST3;
+          }
+          ++cnt;
+        }
     }
   }
-  const int woff = PSI03 + (lvalid ? lside * YOFF3 + lcol : SOFF3 + (tid & 31));
-  // weight writer: thread tid < KT3 (NWT-1) forms w = ut_x ut_y of snapshot tid % KT3, pair index tid / KT3 + 1 in (x <= y) order
-  const bool is_wt = tid < KT3 * (NWT - 1);
-  const int wts = tid & (KT3 - 1), wtw = tid / KT3;
-  int wsa = CID * PST3 + wts, wsb = wsa;
-  {
-    int cnt = 0;
-    for (int x = 0; x <= BM; ++x)
-      for (int y = x; y <= BM; ++y) {
-        if (cnt == wtw + 1) {
-          if (x > 0) wsa = (b.nzeta + x - 1) * D * PST3 + wts;
-          if (y > 0) wsb = (b.nzeta + y - 1) * D * PST3 + wts;
-        }
-        ++cnt;
-      }
-  }
-  const int wdst = PSI03 + wts * RS3 + WOFF3 + WSH + (is_wt ? wtw : 0);
+  const int woff = PSI03 + (lvalid ? lside * YOFF3 + lcol : lwt ? WOFF3 + WSH + lw : SOFF3 + (tid & 31));
 
   const int64_t kt0 = (int64_t)split * a.ktiles_per_split;
   const int64_t ktiles_total = (a.Ns + KT3 - 1) / KT3;
@@ -188,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
   bool ld_isz[LR];                                  // row of a state variable (EXT: gets the trigonometric entries)
   const double* ld_ptr[LR];
   const int ld_s = tid & (KT3 - 1);                 // the same snapshot for every j (256 is a multiple of KT3)
-  const int ld_dst0 = (tid / KT3) * D * PST3 + ld_s;
+  const int ld_dst0 = (tid / KT3) * DS * PST3 + ld_s;
   int ld_rem = (int)max((int64_t)-1000000, min((int64_t)1 << 30, a.Ns - (kt0 * KT3 + ld_s)));
 #pragma unroll
   for (int j = 0; j < LR; ++j) {
@@ -236,7 +243,7 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
 #pragma unroll
     for (int j = 0; j < LR; ++j) {
       if (j < nld && ld_on[j]) {
-        double* dst = sm + BUF * POWBUF3 + ld_dst0 + j * 32 * D * PST3;
+        double* dst = sm + BUF * POWBUF3 + ld_dst0 + j * 32 * DS * PST3;
         const double xv = x.ok ? x.v[j] : 0.0;        // snapshots past Ns: every power is 0 (the tail mask)
         double p = xv;
         const int Dp = EXT ? a.Dp : D;
@@ -274,6 +281,39 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
         }
     }
     if (tid < KT3) sm[BUF * POWBUF3 + CID * PST3 + tid] = x.ok ? 1.0 : 0.0;
+  };
+
+  // ---- INL with powers <= 4: raw value -> registers a tile ahead, table entries x, x^2, x^3, x^4 inside the next MFMA loop ----
+  // thread tid / KT3 = table row: raw rows, then ONE constant row (value 1: its first entry is the constant / tail mask id CID);
+  // the other threads are masked off.  Whether a raw tile lies wholly inside [0, Ns) is wave-uniform (scalar counter): only the
+  // range's last tile can be partial, and only then does a thread look at its own snapshot index.
+  const bool tb_row = tid < (nrawrows + 1) * KT3;                  // rows of the table this thread fills
+  const bool tb_ld = tid < nrawrows * KT3;                         // ... from memory
+  double tb_v = 1.0;                                               // (the constant row's value; raw rows: the tile in flight)
+  int tb_tile = 2;                                                 // local index of the next tile to load (scalar; tiles 0 and 1: load_raw)
+  const int tb_full = (int)max((int64_t)0, min((int64_t)1 << 30, a.Ns / KT3 - kt0));   // local tiles wholly inside [0, Ns)
+  bool tb_is_full = true;                                          // ... is the tile in tb_v one of them
+  auto load_tb = [&]() __attribute__((always_inline)) {
+    if (tb_ld) tb_v = *ld_ptr[0];
+    ld_ptr[0] += KT3;
+    tb_is_full = tb_tile < tb_full;
+    ++tb_tile;
+  };
+  auto store_tb = [&](auto buf_c) __attribute__((always_inline)) {
+    constexpr int BUF = decltype(buf_c)::value;
+    double xv = tb_v;
+    if (!tb_is_full) {                                             // (scalar branch; at most once per workgroup)
+      const int64_t s_glob = (kt0 + tb_tile - 1) * KT3 + ld_s;
+      if (s_glob >= a.Ns) xv = 0.0;
+    }
+    if (tb_row) {
+      double* dst = sm + BUF * POWBUF3 + ld_dst0;
+      const double x2 = xv * xv;
+      dst[0] = xv;
+      dst[PST3] = x2;
+      dst[2 * PST3] = x2 * xv;
+      dst[3 * PST3] = x2 * x2;
+    }
   };
 
   // ---- PRE: the tile comes lifted from memory (kp_gram3_prelift_kernel): entries [psi_x | psi_y | weights] x KT3 snapshots, two 16-byte pieces per thread ----
@@ -319,10 +359,6 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
   // ---- lift of a snapshot tile: power-table buffer B -> Psi buffer B, in pipelined chunks ----
   constexpr int NCH = KT3 / 2;                       // chunks: snapshot pairs
   double2 lf[NF3];
-  auto lift_begin = [&](auto buf_c) __attribute__((always_inline)) {               // the weights of this snapshot
-    constexpr int BUF = decltype(buf_c)::value;
-    if (is_wt) sm[BUF * PSIBUF3 + wdst] = sm[BUF * POWBUF3 + wsa] * sm[BUF * POWBUF3 + wsb];
-  };
   auto lift_read = [&](int ch, auto buf_c) __attribute__((always_inline)) {
     constexpr int BUF = decltype(buf_c)::value;
 #pragma unroll
@@ -403,7 +439,6 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
   } else {
     store_raw(B0{}, load_raw());
     __syncthreads();
-    lift_begin(B0{});
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       lift_read(i, B0{});
@@ -412,6 +447,7 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
     store_raw(B1{}, load_raw());
     __syncthreads();
     if (PCS) project(B0{});
+    if constexpr (INL) load_tb();                       // raw tile 2 (load_raw has advanced the pointer past tiles 0 and 1)
   }
 
   constexpr int NSTEP = (KT3 / 4) * NQ;                 // quad steps (NWT MFMAs each) per snapshot tile
@@ -431,7 +467,6 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
     // load too (vmcnt counts in order) - with the load up here every wave sat out its HBM latency at the start of every tile.
     RawRegs rawreg;
     PreRegs prereg;
-    if constexpr (!PRE) lift_begin(NXT{});
     constexpr int NAW = TUP ? NWT / 2 : NWT;           // weighted A operands per A group (TUP: tuples of two weights)
     double bvs[NSTEP];
     double bvs2[TUP ? NSTEP : 1];                      // TUP: the quad's second B operand (groups 2, 3)
@@ -442,7 +477,7 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
     auto weigh = [&](double av) __attribute__((always_inline)) {
 #pragma unroll
       for (int w = 0; w < NAW; ++w) {
-#if KP_ABL3 == 7
+#if KP_ABL3 == 7 || KP_ABL3 == 11
         aw[w] = av;
 #else
         aw[w] = (!TUP && w == 0) ? av : av * wt[w];
@@ -477,7 +512,10 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
       const int kk = step / NQ, q = step % NQ;
       if (step == (NSTEP > KP_RAW_STEP ? KP_RAW_STEP : 0)) {
         if constexpr (PRE) prereg = load_pre();        // the NEXT tile, lifted; stored behind the MFMA loop
-        else rawreg = load_raw();
+        else if constexpr (INL) {                      // table of the tile after next from the value loaded a tile ago, then
+          store_tb(cur_c);                             // the load for the tile behind it
+          load_tb();
+        } else rawreg = load_raw();
       }
       if (q == 0) {
         weigh(avn0);
@@ -502,6 +540,12 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
       const double bv = bvs[step % PF];
       const double bv2 = TUP ? bvs2[step % PF] : 0.0;
 #endif
+#if KP_ABL3 == 10
+      if constexpr (true) {
+#pragma unroll
+        for (int w = 0; w < NAW; ++w) asm volatile("" :: "v"(aw[w]), "v"(bv), "v"(bv2));
+      } else
+#endif
       if constexpr (TUP) {
         // accumulator 2 p + h: blocks b = (weight 2 p + (b >> 1), group 2 h + (b & 1) of the quad)
 #pragma unroll
@@ -513,7 +557,7 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
 #pragma unroll
         for (int w = 0; w < NWT; ++w) acc[q][w] = __builtin_amdgcn_mfma_f64_4x4x4f64(aw[w], bv, acc[q][w], 0, 0, 0);
       }
-#if KP_ABL3 != 1 && KP_ABL3 != 6
+#if KP_ABL3 != 1 && KP_ABL3 != 6 && KP_ABL3 != 11
       // one register set for the chunk in flight: the write of chunk i precedes the read of chunk i+1
       if constexpr (!PRE) {
         if (step >= LAG && (step - LAG) % SP == 0 && (step - LAG) / SP < NCH) lift_write((step - LAG) / SP, NXT{});
@@ -522,7 +566,7 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
 #endif
       __builtin_amdgcn_sched_barrier(0);   // keep the hand-made software pipeline: no hoisting of later steps' LDS reads
     }
-#if KP_ABL3 != 1 && KP_ABL3 != 6
+#if KP_ABL3 != 1 && KP_ABL3 != 6 && KP_ABL3 != 11
     if constexpr (!PRE) {
 #pragma unroll
       for (int i = 0; i < NCH; ++i) {
@@ -531,9 +575,13 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
       }
     }
 #endif
+#if KP_ABL3 != 8 && KP_ABL3 != 11
     if constexpr (PRE) store_pre(NXT{}, prereg);
-    else store_raw(cur_c, rawreg);
+    else if constexpr (!INL) store_raw(cur_c, rawreg);
+#endif
+#if KP_ABL3 != 9 && KP_ABL3 != 11
     __syncthreads();
+#endif
     if (PCS) project(NXT{});
   };
   auto run_tiles = [&](auto qs_c) __attribute__((always_inline)) {
@@ -787,8 +835,9 @@ bool kp_gram3_applicable(const kp_basis* basis) {
            2 * (b.nzeta + b.m) * (basis->ext_Dp + 2 * basis->ext_df) + 1 + 2 * basis->ext_ng <= NIDMAX3;
   // dim_red dictionaries: econ layout [zeta | k_pcs principal components | 1], at most 32 components
   if (b.k_pcs > 0 && (b.k_pcs > PCSMAX3 || b.N != b.nzeta + b.k_pcs + 1 || getenv("KP_NO_GRAM3_PCS"))) return false;
-  return b.model_type == KP_MODEL_BILINEAR && basis->fast && basis->max_factors <= NF3 && b.nfull <= YOFF3 &&
-         b.m >= 1 && b.m <= 3 && 2 * (b.nzeta + b.m) * KT3 <= 256 && 2 * (b.nzeta + b.m) * basis->pow_depth + 1 <= NIDMAX3;
+  // (powers <= 4: the in-loop table build writes x .. x^4 at an entry stride of 4; the constant row's 4 entries follow the raw rows)
+  return b.model_type == KP_MODEL_BILINEAR && basis->fast && basis->max_factors <= NF3 && b.nfull <= YOFF3 && basis->pow_depth <= 4 &&
+         b.m >= 1 && b.m <= 3 && 2 * (b.nzeta + b.m) * KT3 <= 256 && 2 * (b.nzeta + b.m) * 4 + 4 <= NIDMAX3;
 }
 
 int kp_gram3_launch(kp_ctx* ctx, const kp_basis* basis_c, const kp_snapshots* s, double* GC_dev) {
