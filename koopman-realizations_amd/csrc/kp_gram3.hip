@@ -77,7 +77,10 @@ template <int NQ, int BM, bool PCS, bool EXT = false, bool PRE = false, bool TUP
 __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
   constexpr int NWT = (BM + 1) * (BM + 2) / 2;
   static_assert(!TUP || BM == 3, "paired weights: 10 weights = 5 tuples");
-  constexpr int WSH = TUP ? 1 : 0;                  // TUP: slot 0 of the weight entries holds w_0 = 1
+  // TUP: weight w sits in slot 6 (w & 1) + (w >> 1) of the 12 weight entries of a Psi row (w_0 = 1 stored in slot 0): the five
+  // weights a lane multiplies in - w_{2p+h}, p = 0..4, h = blk >> 1 - are contiguous and 16-byte aligned (two ds_read_b128 and a
+  // ds_read_b64; as 8-byte reads at stride 2 the compiler paired them into ds_read2_b64, half the LDS rate)
+  auto wslot = [](int w) { return TUP ? 6 * (w & 1) + (w >> 1) : w - 1; };
   extern __shared__ __align__(16) double sm[];
   const BasisDev& b = a.b;
   const int tid = threadIdx.x;
@@ -99,8 +102,13 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
   // build with its run-time power loop, its exec-mask branches and its wait for the raw load cost 29 of 389 us, timing-only
   // build KP_ABL3=8).  kp_gram3_applicable admits monomial dictionaries with powers <= 4 only (others: kp_gram2 / general kernel).
   constexpr bool INL = !EXT && !PRE;
-  const int DS = INL ? 4 : D;                      // table entries per raw row
-  const int CID = nrawrows * DS;                   // power-table id of the constant 1 (0 for snapshots past Ns)
+  // Table layout (doubles): row r (raw rows, then the constant's row) at r * RB, its entry e at + e * PST3, KT3 snapshots each.
+  // EXT keeps the dense id order of its recipes (RB = D entries).  INL: 4 entries per row and, when the table has the room, a row
+  // stride of 62 doubles - the lift's 16-byte reads of 64 columns with unrelated ids then spread over the banks as well as the
+  // 3-entry rows of rounds 1-5 did (57 LDS cycles per chunk of a workgroup for the poly-3 dictionary on 6 states against 77 at
+  // the dense stride 40; tools/lds_layout_sim.py).
+  const int RB = !INL ? D * PST3 : ((nrawrows + 1) * 62 + 4 * PST3 <= POWBUF3 ? 62 : 4 * PST3);
+  const int CA = nrawrows * RB;                    // address of the constant 1 (0 for snapshots past Ns: the tail mask)
 
   // ---- MFMA operand offsets (doubles, Psi buffer 0): row (lane>>4) of k-step 0 ----
   const uint32_t* jd = a.desc + (size_t)job * (1 + NQ);
@@ -122,7 +130,7 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
     }
   }
   // TUP: this lane's weight of tuple p is entry 2 p + (blk >> 1)
-  const int wo = PSI03 + lrow + WOFF3 + (TUP ? (blk >> 1) : 0);
+  const int wo = PSI03 + lrow + WOFF3 + (TUP ? 6 * (blk >> 1) : 0);
 
   double acc[NQ][NWT];
 #pragma unroll
@@ -164,21 +172,21 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
 #pragma unroll
     for (int f = 0; f < NF3; ++f) {
       const int id = (int)((r >> (8 * f)) & 255u);
-      fa[f] = (id == 255 ? CID : (EXT && id >= 128) ? CID + 1 + lside * a.ng + (id - 128) : lside * nzm * DS + (id / D) * DS + id % D) * PST3;
+      fa[f] = id == 255 ? CA : (EXT && id >= 128) ? CA + (1 + lside * a.ng + (id - 128)) * PST3 : (lside * nzm + id / D) * RB + (id % D) * PST3;
     }
     if (lwt) {
       int cnt = 0;
       for (int x = 0; x <= BM; ++x)
         for (int y = x; y <= BM; ++y) {
           if (cnt == lw + 1) {
-            if (x > 0) fa[0] = (b.nzeta + x - 1) * DS * PST3;
-            if (y > 0) fa[1] = (b.nzeta + y - 1) * DS * PST3;
+            if (x > 0) fa[0] = (b.nzeta + x - 1) * RB;
+            if (y > 0) fa[1] = (b.nzeta + y - 1) * RB;
           }
           ++cnt;
         }
     }
   }
-  const int woff = PSI03 + (lvalid ? lside * YOFF3 + lcol : lwt ? WOFF3 + WSH + lw : SOFF3 + (tid & 31));
+  const int woff = PSI03 + (lvalid ? lside * YOFF3 + lcol : lwt ? WOFF3 + wslot(lw + 1) : SOFF3 + (tid & 31));
 
   const int64_t kt0 = (int64_t)split * a.ktiles_per_split;
   const int64_t ktiles_total = (a.Ns + KT3 - 1) / KT3;
@@ -195,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
   bool ld_isz[LR];                                  // row of a state variable (EXT: gets the trigonometric entries)
   const double* ld_ptr[LR];
   const int ld_s = tid & (KT3 - 1);                 // the same snapshot for every j (256 is a multiple of KT3)
-  const int ld_dst0 = (tid / KT3) * DS * PST3 + ld_s;
+  const int ld_dst0 = (tid / KT3) * RB + ld_s;
   int ld_rem = (int)max((int64_t)-1000000, min((int64_t)1 << 30, a.Ns - (kt0 * KT3 + ld_s)));
 #pragma unroll
   for (int j = 0; j < LR; ++j) {
@@ -219,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
       g_on[q] = gi < 2 * a.ng * KT3;
       const int gc = g_on[q] ? (gi / KT3) % a.ng : 0, gside = g_on[q] ? gi / (KT3 * a.ng) : 0;
       g_ptr[q] = (gside ? a.beta : a.alpha) + kt0 * KT3 + ld_s;
-      g_dst[q] = (CID + 1 + gside * a.ng + gc) * PST3 + ld_s;
+      g_dst[q] = CA + (1 + gside * a.ng + gc) * PST3 + ld_s;
       g_cen[q] = GC03 + gc * b.nzeta;
     }
   }
@@ -243,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
 #pragma unroll
     for (int j = 0; j < LR; ++j) {
       if (j < nld && ld_on[j]) {
-        double* dst = sm + BUF * POWBUF3 + ld_dst0 + j * 32 * DS * PST3;
+        double* dst = sm + BUF * POWBUF3 + ld_dst0 + j * 32 * RB;
         const double xv = x.ok ? x.v[j] : 0.0;        // snapshots past Ns: every power is 0 (the tail mask)
         double p = xv;
         const int Dp = EXT ? a.Dp : D;
@@ -280,7 +288,7 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
           sm[BUF * POWBUF3 + g_dst[q]] = x.ok ? exp(-r2) : 0.0;
         }
     }
-    if (tid < KT3) sm[BUF * POWBUF3 + CID * PST3 + tid] = x.ok ? 1.0 : 0.0;
+    if (tid < KT3) sm[BUF * POWBUF3 + CA + tid] = x.ok ? 1.0 : 0.0;
   };
 
   // ---- INL with powers <= 4: raw value -> registers a tile ahead, table entries x, x^2, x^3, x^4 inside the next MFMA loop ----
@@ -334,7 +342,9 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
       // of this kernel's LDS cycles were conflicts)
       const int e1 = pre_on[j] ? e : 0;
       const int sp = e1 / a.pre_rl, c = e1 - sp * a.pre_rl, srow = 2 * sp;
-      const int off = c < 4 * a.G4 ? c : c < 8 * a.G4 ? YOFF3 + (c - 4 * a.G4) : WOFF3 + WSH + (c - 8 * a.G4);
+      // (the lifted rows carry w_1 .. w_9 and three zeros: the zeros go to the two unused weight slots and the scratch entry behind them)
+      const int cw = c - 8 * a.G4;
+      const int off = c < 4 * a.G4 ? c : c < 8 * a.G4 ? YOFF3 + (c - 4 * a.G4) : WOFF3 + (!TUP ? cw : cw < 9 ? wslot(cw + 1) : cw == 9 ? 5 : cw == 10 ? 11 : 12);
       pre_dst[j] = PSI03 + srow * RS3 + off;
     }
   }
@@ -362,7 +372,8 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
   auto lift_read = [&](int ch, auto buf_c) __attribute__((always_inline)) {
     constexpr int BUF = decltype(buf_c)::value;
 #pragma unroll
-    for (int f = 0; f < NF3; ++f) lf[f] = *reinterpret_cast<const double2*>(&sm[BUF * POWBUF3 + fa[f] + 2 * ch]);
+    for (int f = 0; f < NF3; ++f)      // (RB, PST3 and CA are even: 16-byte aligned, one ds_read_b128)
+      lf[f] = *reinterpret_cast<const double2*>(__builtin_assume_aligned(&sm[BUF * POWBUF3 + fa[f] + 2 * ch], 16));
   };
   auto lift_write = [&](int ch, auto buf_c) __attribute__((always_inline)) {
     constexpr int BUF = decltype(buf_c)::value;
@@ -496,7 +507,12 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
     auto load_wt = [&](int kk) __attribute__((always_inline)) {
       if constexpr (TUP) {
 #pragma unroll
-        for (int w = 0; w < NAW; ++w) wt[w] = sm[PB + kk * 4 * RS3 + wo + 2 * w];
+        for (int w = 0; w + 1 < NAW; w += 2) {
+          const double2 v = *reinterpret_cast<const double2*>(&sm[PB + kk * 4 * RS3 + wo + w]);
+          wt[w] = v.x;
+          wt[w + 1] = v.y;
+        }
+        wt[NAW - 1] = sm[PB + kk * 4 * RS3 + wo + NAW - 1];
       } else {
 #pragma unroll
         for (int w = 0; w < NWT - 1; w += 2) {
