@@ -31,6 +31,13 @@
 #ifndef KP_ABL3
 #define KP_ABL3 0
 #endif
+#ifndef KP_G3_ASMW
+#define KP_G3_ASMW 0    // 1: lift stores as 8-byte stores at immediate offsets (inline asm) instead of the compiler's ds_write2_b64 + v_add.
+                        // Measured SLOWER (0.3718 against 0.3659 ms): two store instructions cost the wave more than a v_add and one
+#endif
+#ifndef KP_G3_TBASM
+#define KP_G3_TBASM 1   // ... the table stores that way are faster (0.3640 against 0.3659 ms; four entries 80 bytes apart: no ds_write2 pairs them without an add)
+#endif
 #ifndef KP_RAW_STEP
 #define KP_RAW_STEP 1   // MFMA step of a tile behind which the raw loads of the tile after next are issued
 #endif
@@ -65,6 +72,10 @@
 #define LDS3_GAUSS_DOUBLES (GAUSSMAX3 * GNZMAX3)
 
 #include "kp_gram3_args.h"
+
+// the constant row of the in-loop power table "loads" its 1.0 like the raw rows load their values (kp_gram3_kernel, INL); not
+// `const`: a pointer that may be this or a kernel argument must stay a GLOBAL pointer (constant address space: flat loads)
+__device__ double kp_gram3_ones[KT3] = {1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0};
 
 // PCS: econ lift through a projection matrix (dim_red dictionaries)
 // EXT: fourier (def_fourierLift, Ksysid.m:694-731) and gaussian (def_gaussianLift, :790-817) blocks through the same table
@@ -291,37 +302,51 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
     if (tid < KT3) sm[BUF * POWBUF3 + CA + tid] = x.ok ? 1.0 : 0.0;
   };
 
-  // ---- INL with powers <= 4: raw value -> registers a tile ahead, table entries x, x^2, x^3, x^4 inside the next MFMA loop ----
-  // thread tid / KT3 = table row: raw rows, then ONE constant row (value 1: its first entry is the constant / tail mask id CID);
-  // the other threads are masked off.  Whether a raw tile lies wholly inside [0, Ns) is wave-uniform (scalar counter): only the
-  // range's last tile can be partial, and only then does a thread look at its own snapshot index.
-  const bool tb_row = tid < (nrawrows + 1) * KT3;                  // rows of the table this thread fills
-  const bool tb_ld = tid < nrawrows * KT3;                         // ... from memory
-  double tb_v = 1.0;                                               // (the constant row's value; raw rows: the tile in flight)
+  // ---- INL: raw value -> register a tile ahead, table entries x, x^2, x^3, x^4 inside the next MFMA loop ----
+  // EVERY thread fills a table row - no exec masking, no branch in the steady state: thread tid / KT3 = row; raw rows, then ONE
+  // constant row (it "loads" 1.0 from a constant buffer with a pointer that does not advance; its first entry is the constant /
+  // tail-mask address CA); the threads behind it repeat rows 0, 1, .. (the same values to the same addresses; within a wave the
+  // addresses stay distinct).  Whether a raw tile lies wholly inside [0, Ns) is wave-uniform (scalar counter): only the range's
+  // last tile can be partial, and only then does a thread look at its own snapshot index.
+  const int tb_r = (tid / KT3) % (nrawrows + 1);
+  const double* tb_ptr;
+  int tb_inc = KT3;
+  {
+    const int rr = tb_r % nzm;
+    tb_ptr = (rr < b.nzeta ? ((tb_r < nzm ? a.alpha : a.beta) + (int64_t)rr * a.Ns) : (a.u + (int64_t)(rr - b.nzeta) * a.Ns)) + (kt0 + 2) * KT3 + ld_s;
+    if (tb_r == nrawrows) { tb_ptr = kp_gram3_ones; tb_inc = 0; }
+  }
+  const uint32_t tb_dst = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) double*)(sm + tb_r * RB + ld_s);
+  double tb_v = 0.0;                                               // the tile in flight
   int tb_tile = 2;                                                 // local index of the next tile to load (scalar; tiles 0 and 1: load_raw)
   const int tb_full = (int)max((int64_t)0, min((int64_t)1 << 30, a.Ns / KT3 - kt0));   // local tiles wholly inside [0, Ns)
   bool tb_is_full = true;                                          // ... is the tile in tb_v one of them
   auto load_tb = [&]() __attribute__((always_inline)) {
-    if (tb_ld) tb_v = *ld_ptr[0];
-    ld_ptr[0] += KT3;
+    tb_v = *tb_ptr;
+    tb_ptr += tb_inc;
     tb_is_full = tb_tile < tb_full;
     ++tb_tile;
   };
   auto store_tb = [&](auto buf_c) __attribute__((always_inline)) {
     constexpr int BUF = decltype(buf_c)::value;
     double xv = tb_v;
-    if (!tb_is_full) {                                             // (scalar branch; at most once per workgroup)
+    if (__builtin_expect(!tb_is_full, 0)) {                        // (scalar branch; at most once per workgroup)
       const int64_t s_glob = (kt0 + tb_tile - 1) * KT3 + ld_s;
       if (s_glob >= a.Ns) xv = 0.0;
     }
-    if (tb_row) {
-      double* dst = sm + BUF * POWBUF3 + ld_dst0;
-      const double x2 = xv * xv;
-      dst[0] = xv;
-      dst[PST3] = x2;
-      dst[2 * PST3] = x2 * xv;
-      dst[3 * PST3] = x2 * x2;
-    }
+    const double x2 = xv * xv, x3 = x2 * xv, x4 = x2 * x2;
+    const uint32_t tb_dst_b = tb_dst;                              // (an asm operand alone does not capture in a generic lambda)
+    // (8-byte stores at immediate offsets from one address register, like the lift's: see lift_write)
+#if !KP_G3_TBASM
+    double* dstp = sm + BUF * POWBUF3 + tb_r * RB + ld_s;
+    dstp[0] = xv; dstp[PST3] = x2; dstp[2 * PST3] = x3; dstp[3 * PST3] = x4;
+    (void)tb_dst_b;
+#else
+    asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(tb_dst_b), "v"(xv), "n"((BUF * POWBUF3) * 8) : "memory");
+    asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(tb_dst_b), "v"(x2), "n"((BUF * POWBUF3 + PST3) * 8) : "memory");
+    asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(tb_dst_b), "v"(x3), "n"((BUF * POWBUF3 + 2 * PST3) * 8) : "memory");
+    asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(tb_dst_b), "v"(x4), "n"((BUF * POWBUF3 + 3 * PST3) * 8) : "memory");
+#endif
   };
 
   // ---- PRE: the tile comes lifted from memory (kp_gram3_prelift_kernel): entries [psi_x | psi_y | weights] x KT3 snapshots, two 16-byte pieces per thread ----
@@ -375,11 +400,32 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
     for (int f = 0; f < NF3; ++f)      // (RB, PST3 and CA are even: 16-byte aligned, one ds_read_b128)
       lf[f] = *reinterpret_cast<const double2*>(__builtin_assume_aligned(&sm[BUF * POWBUF3 + fa[f] + 2 * ch], 16));
   };
+  // The two stores of a chunk go out as ds_write_b64 with 16-bit immediate offsets from ONE address register (every (buffer, row)
+  // of the Psi region lies within 64 KB of it).  Left to the compiler they become a ds_write2_b64, whose 8-bit offsets reach 2 KB:
+  // a v_add_u32 per chunk for the base - a vector instruction in the MFMA stream (~5.5 cycles of it) - for the same LDS time
+  // (13 cycles against 2 x 6).  The compiler does not count these stores: the tile's barrier is preceded by an explicit
+  // s_waitcnt lgkmcnt(0) (wait_lds_stores), and its own counted waits only become more conservative.
+  uint32_t woff_b = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) double*)(sm + woff);
   auto lift_write = [&](int ch, auto buf_c) __attribute__((always_inline)) {
     constexpr int BUF = decltype(buf_c)::value;
-    sm[BUF * PSIBUF3 + woff + (2 * ch) * RS3] = (lf[0].x * lf[1].x) * lf[2].x;
-    sm[BUF * PSIBUF3 + woff + (2 * ch + 1) * RS3] = (lf[0].y * lf[1].y) * lf[2].y;
+    const double v0 = (lf[0].x * lf[1].x) * lf[2].x, v1 = (lf[0].y * lf[1].y) * lf[2].y;
+#define KP_LIFT_STORE(CH)                                                                                                        \
+  case CH:                                                                                                                       \
+    asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(woff_b), "v"(v0), "n"((BUF * PSIBUF3 + (2 * CH) * RS3) * 8) : "memory");     \
+    asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(woff_b), "v"(v1), "n"((BUF * PSIBUF3 + (2 * CH + 1) * RS3) * 8) : "memory"); \
+    break;
+#if KP_G3_ASMW
+    switch (ch) {                                       // (ch is a constant once the tile loop is unrolled; the offset must be an immediate)
+      KP_LIFT_STORE(0) KP_LIFT_STORE(1) KP_LIFT_STORE(2) KP_LIFT_STORE(3)
+    }
+#else
+    sm[BUF * PSIBUF3 + woff + (2 * ch) * RS3] = v0;
+    sm[BUF * PSIBUF3 + woff + (2 * ch + 1) * RS3] = v1;
+#endif
+#undef KP_LIFT_STORE
+    static_assert(KT3 / 2 == 4, "one case per snapshot pair of a tile");
   };
+  auto wait_lds_stores = [&]() __attribute__((always_inline)) { __builtin_amdgcn_s_waitcnt(0xc07f); };   // lgkmcnt(0)
   using B0 = std::integral_constant<int, 0>;
   using B1 = std::integral_constant<int, 1>;
 
@@ -456,6 +502,7 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
       lift_write(i, B0{});
     }
     store_raw(B1{}, load_raw());
+    wait_lds_stores();
     __syncthreads();
     if (PCS) project(B0{});
     if constexpr (INL) load_tb();                       // raw tile 2 (load_raw has advanced the pointer past tiles 0 and 1)
@@ -464,7 +511,10 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
   constexpr int NSTEP = (KT3 / 4) * NQ;                 // quad steps (NWT MFMAs each) per snapshot tile
   constexpr int SP = NSTEP / NCH > 0 ? NSTEP / NCH : 1;
   constexpr int LAG = SP / 2 > 0 ? SP / 2 : 1;
-  constexpr int PF = NSTEP < 3 ? NSTEP : 3;
+#ifndef KP_G3_PF
+#define KP_G3_PF 3
+#endif
+  constexpr int PF = NSTEP < KP_G3_PF ? NSTEP : KP_G3_PF;   // B operands requested this many quad steps ahead
 
   // one snapshot tile: MFMAs on Psi buffer CUR, lift of the next tile into buffer 1-CUR, raw prefetch two ahead.
   // QS = number of leading quads that use A group a0 (wave-uniform, selected once outside the loop).
@@ -596,6 +646,7 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
     else if constexpr (!INL) store_raw(cur_c, rawreg);
 #endif
 #if KP_ABL3 != 9 && KP_ABL3 != 11
+    if constexpr (!PRE) wait_lds_stores();
     __syncthreads();
 #endif
     if (PCS) project(NXT{});
