@@ -40,6 +40,7 @@ extern "C" int kp_create(int device_id, kp_ctx** out) {
   }
   kp_ctx* c = new kp_ctx();
   c->device = device_id;
+  c->test_hooks = getenv("KP_TEST_HOOKS") != nullptr;
   // Events order work between this context's two streams and time kernels; neither needs the system-scope release
   // (L2 write-back towards the host) that a default event performs after every kernel it follows - results reach the
   // host through explicit copies.  KP_EVENT_SYSTEM_FENCE=1 restores the default.

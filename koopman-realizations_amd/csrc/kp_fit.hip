@@ -1143,7 +1143,9 @@ extern "C" int kp_fit(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* sn
   bool need_ls = false;
   for (int i = 0; i < n_lasso; ++i) need_ls |= (!lasso || !(lasso[i] < 1e6));
   int ls_index = -1;
-  if (const char* e = getenv("KP_RANK_HINT_TEST")) basis->rank_hint = atoi(e);      // (tests: a remembered rank that is wrong in a chosen way)
+  if (ctx->test_hooks) {                    // (contexts created with KP_TEST_HOOKS set: a remembered rank that is wrong in a chosen way)
+    if (const char* e = getenv("KP_RANK_HINT_TEST")) basis->rank_hint = atoi(e);
+  }
   // (see below) least-squares values only, the narrow path, a second stream to run on
   const bool concurrent = basis->rank_hint > 0 && all_ls && ctx->stream2 && W <= 16 * 4 * TR_MAXJ && !ctx->reduce_grams && !ctx->gc_preloaded &&
                           !getenv("KP_NO_RANK_HINT");
@@ -1202,6 +1204,9 @@ extern "C" int kp_fit(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* sn
     rc = kp_lasso_batch_dev(ctx, Gd, Cd, W, W, tv.data(), (int)tv.size(), 20000, 1e-10, tdst.data(), nullptr, nullptr);
     if (rc) return rc;
     KP_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    // the lasso solvers take the same growable page-locked block for their records: a request larger than k_bytes has
+    // replaced (and freed) the block k_pin pointed into - take it again (nothing of theirs is live any more)
+    if (k_pin) k_pin = (double*)kp_pinned_scratch(ctx, k_bytes);
   }
   (void)need_ls;
   if (!conc_done) KP_HIP(ctx, hipEventRecord(ctx->evp[3], ctx->stream));

@@ -397,7 +397,7 @@ static hipError_t prelift_mfma_launch(const double* alpha, const double* beta, c
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
   const int64_t grid = std::max<int64_t>(1, std::min<int64_t>((ktiles + PM_NS - 1) / PM_NS, (int64_t)cus * PM_WGPCU));
   hipLaunchKernelGGL((kp_gram3_prelift_mfma_kernel<BM, NK, NRAW>), dim3((unsigned)grid), dim3(PM_T), lds, st, alpha, beta, u, Ns, ktiles, nzeta, D, nfull, k_pcs, N, G4,
-                     recipes, pcsT, out, rl, getenv("KP_PM_ABL") ? atoi(getenv("KP_PM_ABL")) : 0);
+                     recipes, pcsT, out, rl, kp_abl_int("KP_PM_ABL"));
   return hipGetLastError();
 }
 

@@ -64,6 +64,7 @@ struct kp_ctx {
   int part_flip = 0;
   int reduce_timed_from = 1;   // evp index that marks the start of the last partial reduction
   int* sticky_info = nullptr;       // device word: set by any deferred factorisation that hit a non-positive pivot
+  bool test_hooks = false;          // KP_TEST_HOOKS was set when the context was created: kp_fit honours KP_RANK_HINT_TEST (tests only)
   void* pin_scratch = nullptr;      // growable page-locked host scratch (kp_pinned_scratch): small results read back by direct DMA
   size_t pin_scratch_bytes = 0;
   double* pin_small = nullptr;      // 64 bytes of page-locked host memory: small results (info word + pivot ratio) come back in ONE direct DMA
@@ -198,6 +199,13 @@ struct kp_snapshots {
 };
 // page-locked host scratch of at least `bytes` (contents not preserved across calls that grow it); nullptr on failure
 void* kp_pinned_scratch(kp_ctx* ctx, size_t bytes);
+// Timing-only ablation switches (KP_WIDE_NOWEIGHT, KP_PIV_ABL, KP_PM_ABL: they make results WRONG by design) exist only in builds
+// with -DKP_ABLATIONS (tools/*_abl*.sh); the shipped library does not look at those variables.
+#ifdef KP_ABLATIONS
+static inline int kp_abl_int(const char* name) { const char* e = getenv(name); return e ? atoi(e) : 0; }
+#else
+static inline int kp_abl_int(const char*) { return 0; }
+#endif
 void kp_stage_destroy(kp_ctx* ctx);
 void kp_host_free_all(kp_ctx* ctx);
 void kp_traj_pool_free(kp_ctx* ctx);

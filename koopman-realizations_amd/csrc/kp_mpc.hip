@@ -1121,7 +1121,11 @@ __device__ __forceinline__ void mpc_step_body(const MpcArgs& a) {
       __syncthreads();
     }
   };
-    __syncthreads();                                          // (with vmcnt(0): every LDS-DMA above has landed)
+    // every LDS-DMA above (global_load ... lds) must have landed before another wave reads those bytes: that is the vector-memory
+    // counter, which a workgroup-scope __syncthreads() is NOT obliged to wait for (one hipcc build lowered it to
+    // `s_waitcnt lgkmcnt(0); s_barrier`) - so the wait is written out
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     if (WARM && a.warm) warm_q0 = a.warm[0];
     if (WARM && a.warm && a.ell.K <= QP_KLDS) {
 #pragma unroll

@@ -395,7 +395,7 @@ int kp_pivchol_solve_dev(kp_ctx* ctx, const double* G_dev, const double* C_dev, 
               : rpt == 1 ? kp_ensure_lds(lds1024, (const void*)kp_pivchol_panel_kernel<1024, 1>, lds)
                          : kp_ensure_lds(lds4096, (const void*)kp_pivchol_panel_kernel<1024, PC_RPT_MAX>, lds));
   const dim3 ugrid((W + 63) / 64, (W + 63) / 64);
-  static const int piv_abl = getenv("KP_PIV_ABL") ? atoi(getenv("KP_PIV_ABL")) : 0;      // timing-only ablations (bit 0: no pivot-column load)
+  static const int piv_abl = kp_abl_int("KP_PIV_ABL");      // timing-only ablations (bit 0: no pivot-column load; -DKP_ABLATIONS builds)
   auto run_panels = [&](int k_from, int k_to) -> int {
     for (int k0 = k_from; k0 < k_to; k0 += nb) {
       const int nbk = std::min(nb, W - k0);

@@ -6,7 +6,7 @@
 //   * trailing update of the blocked Cholesky factorisation, A22 -= U12' U12 (upper tiles only);
 //   * block substitution, C_rest -= U12' Y_k  and  Y_rest -= L21' K_k  (kp_wide.hip).
 // Same skeleton as kp_symm_gemm2_kernel (kp_symm_gemm.h): 4-wave workgroup, output tile 16 RA x 16 RB, wave w owns 4 RA rows as
-// RA x RB accumulators of v_mfma_f64_4x4x4_4b, contraction in blocks of 16 double-buffered in LDS ([row][k], row stride 20
+// RA x RB accumulators of v_mfma_f64_4x4x4_4b, contraction in blocks of 16 double-buffered in LDS ([row][k], row stride TNG_RS
 // doubles), one barrier per block, operand addresses base + immediate, result tile through LDS so that the stores run along
 // the columns of C, XCD-aware workgroup order.  New here: general leading dimensions (64-bit tile bases + 32-bit offsets),
 // a contraction RANGE per workgroup (split-K over blockIdx.y into partial buffers, summed in split order by
@@ -19,7 +19,9 @@
 #include <algorithm>
 
 #define TNG_KB 16
-#define TNG_RS 20
+#ifndef TNG_RS
+#define TNG_RS 22   // = 2 mod 4: the 16 rows x 2 k of a B-operand read (ds_read_b64: 32 lanes over 64 banks) hit 64 different banks; 20 (rounds
+#endif              // 4-5) put rows r and r + 8 on the same ones (tools/lds_layout_sim.py model; W = 738 Gram pass 4.47 -> 4.26 ms per 1e5 pairs)
 
 // NW waves per workgroup (4, two workgroups per CU; or 8, one): wave w owns the rows [4 RA w, 4 RA (w + 1)) of the tile
 template <int RA, int RB, int NW = 4>

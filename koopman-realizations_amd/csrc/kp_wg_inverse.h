@@ -2,9 +2,11 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-// Barrier between phases that exchange data through LDS only.  __syncthreads() also waits for every global store of the wave
-// to be acknowledged (s_waitcnt vmcnt(0)); in a single-workgroup kernel that has just written results, exports or time stamps
-// - some of them into host memory - that is microseconds of waiting for nothing.
+// Barrier between phases that exchange data through LDS only.  The __syncthreads() of the ROCm 7.2 hipcc also waits for every
+// global store of the wave to be acknowledged (it emits s_waitcnt vmcnt(0) in front of s_barrier; other builds of the compiler
+// lower the same call to s_waitcnt lgkmcnt(0) only - code that NEEDS vmcnt(0) at a barrier, e.g. behind LDS-DMA loads, writes the
+// wait out: kp_mpc.hip); in a single-workgroup kernel that has just written results, exports or time stamps - some of them into
+// host memory - that is microseconds of waiting for nothing.
 __device__ __forceinline__ void wg_lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }

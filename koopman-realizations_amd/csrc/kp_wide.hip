@@ -74,7 +74,7 @@ int kp_gram_wide_launch(kp_ctx* ctx, const kp_basis* basis, const kp_snapshots* 
           const double* wa = ia ? s->u + (int64_t)(ia - 1) * Ns + r0 : nullptr;     // column ia - 1 of u (leading dimension Ns)
           const double* wb = ib ? s->u + (int64_t)(ib - 1) * Ns + r0 : nullptr;
           const size_t blk = (size_t)ia * N + (size_t)ib * N * W;
-          if (getenv("KP_WIDE_NOWEIGHT")) wa = wb = nullptr;      // TIMING EXPERIMENT ONLY (wrong Grams)
+          if (kp_abl_int("KP_WIDE_NOWEIGHT")) wa = wb = nullptr;   // TIMING EXPERIMENT ONLY (wrong Grams; -DKP_ABLATIONS builds)
           KP_HIP(ctx, kp_tn_gemm(st, Px, nc, Px, nc, N, N, (int)rows, G + blk, W, 1.0, beta, 1, nsplit_g, part, wa, wb));
           KP_HIP(ctx, kp_tn_gemm(st, Px, nc, Py, nc, N, N, (int)rows, C + blk, W, 1.0, beta, 0, nsplit_c, part, wa, wb));
         }

@@ -138,22 +138,29 @@ static int slot_of(const kp_ctx* c) {
  * 436-448), copied into another session, or outlive `clear kp_mex`: the value then names memory that was freed, or never was
  * ours.  Every handle handed out is recorded here, every command that takes one checks it, and a *_destroy command on an
  * unknown value is an error MATLAB can catch - not a free() of a stale pointer. */
-static void** g_live;
+enum { H_CTX = 1, H_BASIS, H_SNAPS, H_MPC, H_TRAJ, H_MULTI, H_MTRAJ, H_MMPC };
+static const char* const g_kind_name[] = {"?", "context", "basis", "snapshots", "mpc", "trajectories", "multi", "multi trajectories", "multi mpc"};
+/* every entry carries the KIND of object it names: a live basis handle given to mpc_step, or a context handle given to
+ * basis_destroy, is an error too - not a cast to the wrong struct (and an address the allocator hands out again after a free
+ * validates only for the kind it was registered as) */
+typedef struct { void* p; int kind; } live_rec;
+static live_rec* g_live;
 static size_t g_nlive, g_caplive;
-static void reg_add(void* p) {
+static void reg_add(void* p, int kind) {
   if (!p) return;
   if (g_nlive == g_caplive) {
     const size_t cap = g_caplive ? 2 * g_caplive : 64;
-    void** q = (void**)realloc(g_live, cap * sizeof *q);
+    live_rec* q = (live_rec*)realloc(g_live, cap * sizeof *q);
     if (!q) mexErrMsgIdAndTxt("kp:memory", "out of host memory");
     g_live = q;
     g_caplive = cap;
   }
-  g_live[g_nlive++] = p;
+  g_live[g_nlive].p = p;
+  g_live[g_nlive++].kind = kind;
 }
 static int reg_find(const void* p) {
   for (size_t i = 0; i < g_nlive; ++i)
-    if (g_live[i] == p) return (int)i;
+    if (g_live[i].p == p) return (int)i;
   return -1;
 }
 static void reg_del(void* p) {
@@ -167,22 +174,25 @@ static void reg_clear(void) {
 }
 
 /* ---- argument helpers ------------------------------------------------------------------------------------------------ */
-static void* get_handle(const mxArray* a) {
+static void* get_handle(const mxArray* a, int kind) {
   if (!mxIsUint64(a) || mxGetNumberOfElements(a) != 1) mexErrMsgIdAndTxt("kp:handle", "handle must be a uint64 scalar");
   void* p = (void*)(uintptr_t)(*(uint64_t*)mxGetData(a));
   if (!p) mexErrMsgIdAndTxt("kp:handle", "null handle");
-  if (reg_find(p) < 0)
+  const int i = reg_find(p);
+  if (i < 0)
     mexErrMsgIdAndTxt("kp:handle", "unknown or stale handle (released already, loaded from a MAT file, or from before `clear kp_mex`)");
+  if (g_live[i].kind != kind)
+    mexErrMsgIdAndTxt("kp:handle", "wrong kind of handle: a %s handle where a %s handle is expected", g_kind_name[g_live[i].kind], g_kind_name[kind]);
   return p;
 }
 /* a *_destroy command: the handle leaves the registry before its memory goes */
-static void* take_handle(const mxArray* a) {
-  void* p = get_handle(a);
+static void* take_handle(const mxArray* a, int kind) {
+  void* p = get_handle(a, kind);
   reg_del(p);
   return p;
 }
-static mxArray* put_handle(void* p) {
-  if (reg_find(p) < 0) reg_add(p);                      /* (the shared context and the resident snapshot object are handed out repeatedly) */
+static mxArray* put_handle(void* p, int kind) {
+  if (reg_find(p) < 0) reg_add(p, kind);                /* (the shared context and the resident snapshot object are handed out repeatedly) */
   mxArray* a = mxCreateNumericMatrix(1, 1, mxUINT64_CLASS, mxREAL);
   *(uint64_t*)mxGetData(a) = (uint64_t)(uintptr_t)p;
   return a;
@@ -271,7 +281,7 @@ static void basis_wn(const kp_basis* b, const kp_ctx* c, int* nv, int* nf, int* 
 
 #define ARGS int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]
 #define UNUSED (void)nlhs; (void)plhs; (void)nrhs; (void)prhs
-#define CTX(i) ((kp_ctx*)get_handle(prhs[i]))
+#define CTX(i) ((kp_ctx*)get_handle(prhs[i], H_CTX))
 
 /* ---- context ----------------------------------------------------------------------------------------------------------- */
 static void c_create(ARGS) {
@@ -280,7 +290,7 @@ static void c_create(ARGS) {
   if (dev < 0 || dev >= MAXDEV) mexErrMsgIdAndTxt("kp:usage", "create: device id out of range");
   if (!g_ctx[dev]) check(kp_create(dev, &g_ctx[dev]), NULL);
   ++g_refs[dev];
-  plhs[0] = put_handle(g_ctx[dev]);
+  plhs[0] = put_handle(g_ctx[dev], H_CTX);
 }
 static void c_destroy(ARGS) {
   UNUSED;
@@ -330,7 +340,7 @@ static void c_basis_create(ARGS) {
   basis_desc(prhs[2], &desc);
   kp_basis* b = NULL;
   check(kp_basis_create(c, &desc, &b), c);
-  plhs[0] = put_handle(b);
+  plhs[0] = put_handle(b, H_BASIS);
 }
 static void dims4(mxArray* plhs[], const int v[4]) {
   plhs[0] = mxCreateDoubleMatrix(1, 4, mxREAL);
@@ -339,7 +349,7 @@ static void dims4(mxArray* plhs[], const int v[4]) {
 static void c_basis_dims(ARGS) {
   UNUSED;
   int v[4];
-  check(kp_basis_dims((kp_basis*)get_handle(prhs[1]), &v[0], &v[1], &v[2], &v[3]), NULL);
+  check(kp_basis_dims((kp_basis*)get_handle(prhs[1], H_BASIS), &v[0], &v[1], &v[2], &v[3]), NULL);
   dims4(plhs, v);
 }
 static void c_basis_desc_dims(ARGS) {
@@ -350,9 +360,9 @@ static void c_basis_desc_dims(ARGS) {
   check(kp_basis_desc_dims(&desc, &v[0], &v[1], &v[2], &v[3]), NULL);
   dims4(plhs, v);
 }
-static void c_basis_destroy(ARGS) { UNUSED; kp_basis_destroy((kp_basis*)take_handle(prhs[1])); }
-static void c_snapshots_destroy(ARGS) { UNUSED; kp_snapshots_destroy((kp_snapshots*)take_handle(prhs[1])); }
-static void c_mpc_destroy(ARGS) { UNUSED; kp_mpc_destroy((kp_mpc*)take_handle(prhs[1])); }
+static void c_basis_destroy(ARGS) { UNUSED; kp_basis_destroy((kp_basis*)take_handle(prhs[1], H_BASIS)); }
+static void c_snapshots_destroy(ARGS) { UNUSED; kp_snapshots_destroy((kp_snapshots*)take_handle(prhs[1], H_SNAPS)); }
+static void c_mpc_destroy(ARGS) { UNUSED; kp_mpc_destroy((kp_mpc*)take_handle(prhs[1], H_MPC)); }
 static void c_sym_eig(ARGS) {
   UNUSED;
   kp_ctx* c = CTX(1);
@@ -368,7 +378,7 @@ static void c_sym_eig(ARGS) {
 static void c_lift(ARGS) {
   UNUSED;
   kp_ctx* c = CTX(1);
-  kp_basis* b = (kp_basis*)get_handle(prhs[2]);
+  kp_basis* b = (kp_basis*)get_handle(prhs[2], H_BASIS);
   const int what = int_arg(prhs[3], "what");
   int nv, nf, N, W;
   basis_wn(b, c, &nv, &nf, &N, &W);
@@ -393,7 +403,7 @@ static void c_snapshots_upload(ARGS) {
   pairs_check(prhs[2], prhs[3], prhs[4]);
   check(kp_snapshots_upload(c, dbl(prhs[2]), dbl(prhs[3]), dbl(prhs[4]), (int64_t)mxGetM(prhs[2]), (int)mxGetN(prhs[2]),
                             (int)mxGetN(prhs[4]), &s), c);
-  plhs[0] = put_handle(s);
+  plhs[0] = put_handle(s, H_SNAPS);
 }
 static void c_snapshots_resident(ARGS) {
   UNUSED;
@@ -416,13 +426,13 @@ static void c_snapshots_resident(ARGS) {
   } else {
     check(kp_snapshots_update(c, g_snaps[slot], dbl(prhs[2]), dbl(prhs[3]), dbl(prhs[4]), (int64_t)mxGetM(prhs[2])), c);
   }
-  plhs[0] = put_handle(g_snaps[slot]);
+  plhs[0] = put_handle(g_snaps[slot], H_SNAPS);
 }
 static void c_snapshots_update(ARGS) {
   UNUSED;
   kp_ctx* c = CTX(1);
   pairs_check(prhs[3], prhs[4], prhs[5]);
-  check(kp_snapshots_update(c, (kp_snapshots*)get_handle(prhs[2]), dbl(prhs[3]), dbl(prhs[4]), dbl(prhs[5]), (int64_t)mxGetM(prhs[3])), c);
+  check(kp_snapshots_update(c, (kp_snapshots*)get_handle(prhs[2], H_SNAPS), dbl(prhs[3]), dbl(prhs[4]), dbl(prhs[5]), (int64_t)mxGetM(prhs[3])), c);
 }
 
 /* ---- fit ------------------------------------------------------------------------------------------------------------------------ */
@@ -434,13 +444,13 @@ static void rank_warning(const kp_ctx* c, int W) {               /* like mldivid
 static void fit_common(ARGS, int sharded) {
   UNUSED;
   kp_ctx* c = CTX(1);
-  kp_basis* b = (kp_basis*)get_handle(prhs[2]);
+  kp_basis* b = (kp_basis*)get_handle(prhs[2], H_BASIS);
   int nv, nf, N, W;
   basis_wn(b, c, &nv, &nf, &N, &W);
   const int nl = (int)mxGetNumberOfElements(prhs[4]);
   if (nl < 1) mexErrMsgIdAndTxt("kp:usage", "fit: at least one lasso value");
   plhs[0] = dstack(W, W, nl);
-  kp_snapshots* s = (kp_snapshots*)get_handle(prhs[3]);
+  kp_snapshots* s = (kp_snapshots*)get_handle(prhs[3], H_SNAPS);
   check(sharded ? kp_fit_sharded(c, b, s, dbl(prhs[4]), nl, mxGetPr(plhs[0])) : kp_fit(c, b, s, dbl(prhs[4]), nl, mxGetPr(plhs[0])), c);
   rank_warning(c, W);
 }
@@ -449,7 +459,7 @@ static void c_fit_sharded(ARGS) { fit_common(nlhs, plhs, nrhs, prhs, 1); }
 static void c_fit_async(ARGS) {
   UNUSED;
   kp_ctx* c = CTX(1);
-  check(kp_fit(c, (kp_basis*)get_handle(prhs[2]), (kp_snapshots*)get_handle(prhs[3]), NULL, 1, NULL), c);
+  check(kp_fit(c, (kp_basis*)get_handle(prhs[2], H_BASIS), (kp_snapshots*)get_handle(prhs[3], H_SNAPS), NULL, 1, NULL), c);
 }
 static void c_fit_get_K(ARGS) {
   UNUSED;
@@ -467,12 +477,12 @@ static void c_fit_async_slots(ARGS) {
 static void gram_common(ARGS, int sharded) {
   UNUSED;
   kp_ctx* c = CTX(1);
-  kp_basis* b = (kp_basis*)get_handle(prhs[2]);
+  kp_basis* b = (kp_basis*)get_handle(prhs[2], H_BASIS);
   int nv, nf, N, W;
   basis_wn(b, c, &nv, &nf, &N, &W);
   plhs[0] = mxCreateDoubleMatrix(W, W, mxREAL);
   mxArray* Cm = mxCreateDoubleMatrix(W, W, mxREAL);
-  kp_snapshots* s = (kp_snapshots*)get_handle(prhs[3]);
+  kp_snapshots* s = (kp_snapshots*)get_handle(prhs[3], H_SNAPS);
   check(sharded ? kp_fit_gram_sharded(c, b, s, mxGetPr(plhs[0]), mxGetPr(Cm)) : kp_fit_gram(c, b, s, mxGetPr(plhs[0]), mxGetPr(Cm)), c);
   set_or_drop(nlhs, plhs, 1, Cm);
 }
@@ -519,13 +529,13 @@ static void c_fit_lasso_batch(ARGS) {
 static void c_fit_refine(ARGS) {
   UNUSED;
   kp_ctx* c = CTX(1);
-  kp_basis* b = (kp_basis*)get_handle(prhs[2]);
+  kp_basis* b = (kp_basis*)get_handle(prhs[2], H_BASIS);
   int nv, nf, N, W;
   basis_wn(b, c, &nv, &nf, &N, &W);
   const double* K0 = dbl_n(prhs[4], (size_t)W * W, "fit_refine: K");
   plhs[0] = mxCreateDoubleMatrix(W, W, mxREAL);
   memcpy(mxGetPr(plhs[0]), K0, (size_t)W * W * sizeof(double));
-  check(kp_fit_refine(c, b, (kp_snapshots*)get_handle(prhs[3]), int_arg(prhs[5], "steps"), mxGetPr(plhs[0])), c);
+  check(kp_fit_refine(c, b, (kp_snapshots*)get_handle(prhs[3], H_SNAPS), int_arg(prhs[5], "steps"), mxGetPr(plhs[0])), c);
 }
 static void c_last_rank(ARGS) {
   UNUSED;
@@ -542,7 +552,7 @@ static void c_last_pivot_ratio(ARGS) {
 static void c_fit_batch(ARGS) {
   UNUSED;
   kp_ctx* c = CTX(1);
-  kp_basis* b = (kp_basis*)get_handle(prhs[2]);
+  kp_basis* b = (kp_basis*)get_handle(prhs[2], H_BASIS);
   int nv, nf, N, W;
   basis_wn(b, c, &nv, &nf, &N, &W);
   const int nb = int_arg(prhs[4], "nb");
@@ -551,7 +561,7 @@ static void c_fit_batch(ARGS) {
   plhs[0] = dstack(W, W, nb);
   mxArray* G = dstack(W, W, nb);
   mxArray* Cm = dstack(W, W, nb);
-  const int rc = kp_fit_batch(c, b, (kp_snapshots*)get_handle(prhs[3]), nb, (int64_t)mxGetScalar(prhs[5]), mxGetPr(plhs[0]), mxGetPr(G), mxGetPr(Cm), st);
+  const int rc = kp_fit_batch(c, b, (kp_snapshots*)get_handle(prhs[3], H_SNAPS), nb, (int64_t)mxGetScalar(prhs[5]), mxGetPr(plhs[0]), mxGetPr(G), mxGetPr(Cm), st);
   mxArray* so = ints_out(st, (size_t)nb, (size_t)nb, 1);
   free(st);
   check(rc, c);
@@ -616,7 +626,7 @@ static void c_rollout_nl(ARGS) {
   UNUSED;
   /* Z = kp_mex('rollout_nl', h, b, Kf, zeta0, U): Kf nzeta x N x batch, zeta0 nzeta x batch, U T x m x batch -> Z T x nzeta x batch */
   kp_ctx* c = CTX(1);
-  kp_basis* b = (kp_basis*)get_handle(prhs[2]);
+  kp_basis* b = (kp_basis*)get_handle(prhs[2], H_BASIS);
   int nv, nf, N, W;
   basis_wn(b, c, &nv, &nf, &N, &W);
   const int nz = (int)mxGetM(prhs[3]), batch = (int)mxGetN(prhs[4]), T = (int)mxGetM(prhs[5]);
@@ -649,7 +659,7 @@ static void c_traj_upload(ARGS) {
   traj_shapes(prhs + 2, ntrials, &nb, &T, &n, &m, &Tv);
   kp_traj* t = NULL;
   check(kp_traj_upload(c, dbl(prhs[2]), dbl(prhs[3]), nb, ntrials, T, n, m, dbl(prhs[4]), dbl(prhs[5]), Tv, &t), c);
-  plhs[0] = put_handle(t);
+  plhs[0] = put_handle(t, H_TRAJ);
 }
 static void c_traj_create(ARGS) {
   UNUSED;
@@ -657,12 +667,12 @@ static void c_traj_create(ARGS) {
   kp_traj* t = NULL;
   check(kp_traj_create(c, int_arg(prhs[2], "nb"), int_arg(prhs[3], "ntrials"), int_arg(prhs[4], "T"), int_arg(prhs[5], "n"), int_arg(prhs[6], "m"),
                        int_arg(prhs[7], "Tv"), &t), c);
-  plhs[0] = put_handle(t);
+  plhs[0] = put_handle(t, H_TRAJ);
 }
 static void traj_dims(const kp_traj* t, int d[6]) { check(kp_traj_dims(t, &d[0], &d[1], &d[2], &d[3], &d[4], &d[5]), NULL); }
 static void c_traj_put(ARGS) {
   UNUSED;
-  kp_traj* t = (kp_traj*)get_handle(prhs[1]);
+  kp_traj* t = (kp_traj*)get_handle(prhs[1], H_TRAJ);
   const int which = int_arg(prhs[2], "which");
   int d[6];
   traj_dims(t, d);                                    /* nb ntrials T n m Tv */
@@ -672,17 +682,17 @@ static void c_traj_put(ARGS) {
   /* the mxArray is pageable memory: the library's copy has returned from it when this call returns */
   check(kp_traj_put(t, which, blk), NULL);
 }
-static void c_traj_finish(ARGS) { UNUSED; check(kp_traj_finish((kp_traj*)get_handle(prhs[1])), NULL); }
-static void c_traj_destroy(ARGS) { UNUSED; kp_traj_destroy((kp_traj*)take_handle(prhs[1])); }
+static void c_traj_finish(ARGS) { UNUSED; check(kp_traj_finish((kp_traj*)get_handle(prhs[1], H_TRAJ)), NULL); }
+static void c_traj_destroy(ARGS) { UNUSED; kp_traj_destroy((kp_traj*)take_handle(prhs[1], H_TRAJ)); }
 static void c_traj_dims(ARGS) {
   UNUSED;
   int d[6];
-  traj_dims((kp_traj*)get_handle(prhs[1]), d);
+  traj_dims((kp_traj*)get_handle(prhs[1], H_TRAJ), d);
   plhs[0] = ints_out(d, 6, 1, 6);
 }
 static void c_traj_scale(ARGS) {
   UNUSED;
-  kp_traj* t = (kp_traj*)get_handle(prhs[1]);
+  kp_traj* t = (kp_traj*)get_handle(prhs[1], H_TRAJ);
   int d[6];
   traj_dims(t, d);
   plhs[0] = mxCreateDoubleMatrix((mwSize)(2 * (d[3] + d[4])), (mwSize)d[0], mxREAL);
@@ -691,8 +701,8 @@ static void c_traj_scale(ARGS) {
 static void c_sweep_eval(ARGS) {
   UNUSED;
   kp_ctx* c = CTX(1);
-  kp_traj* t = (kp_traj*)get_handle(prhs[2]);
-  kp_basis* b = (kp_basis*)get_handle(prhs[3]);
+  kp_traj* t = (kp_traj*)get_handle(prhs[2], H_TRAJ);
+  kp_basis* b = (kp_basis*)get_handle(prhs[3], H_BASIS);
   int d[6], nv, nf, N, W;
   traj_dims(t, d);
   basis_wn(b, c, &nv, &nf, &N, &W);
@@ -710,14 +720,14 @@ static void c_sweep_eval(ARGS) {
 static void c_sweep_eval_nested(ARGS) {
   UNUSED;
   kp_ctx* c = CTX(1);
-  kp_traj* t = (kp_traj*)get_handle(prhs[2]);
+  kp_traj* t = (kp_traj*)get_handle(prhs[2], H_TRAJ);
   int d[6];
   traj_dims(t, d);
   const int nb = d[0], n = d[3], nd = int_arg(prhs[5], "n_deg");
   if (nd < 1) mexErrMsgIdAndTxt("kp:usage", "sweep_eval_nested: n_deg");
   int* st = (int*)calloc((size_t)nb * nd, sizeof(int));
   plhs[0] = dstack(n, nb, nd);
-  const int rc = kp_sweep_eval_nested(c, t, (kp_basis*)get_handle(prhs[3]), mxGetScalar(prhs[4]), nd, mxGetPr(plhs[0]), st);
+  const int rc = kp_sweep_eval_nested(c, t, (kp_basis*)get_handle(prhs[3], H_BASIS), mxGetScalar(prhs[4]), nd, mxGetPr(plhs[0]), st);
   mxArray* so = ints_out(st, (size_t)nb * nd, (size_t)nb, (size_t)nd);
   free(st);
   check(rc, c);
@@ -760,24 +770,24 @@ static void c_mpc_create(ARGS) {
   mpc_parse(prhs + 2, &p);
   kp_mpc* mp = NULL;
   check(kp_mpc_create(c, p.mt, p.A, p.B, p.N, p.m, p.Np, p.proj, p.nproj, p.q_run, p.q_term, p.r, p.lo, p.hi, p.slope, p.smooth, &mp), c);
-  plhs[0] = put_handle(mp);
+  plhs[0] = put_handle(mp, H_MPC);
 }
 static void c_mpc_set_state_bounds(ARGS) {
   UNUSED;
   const int n = (int)mxGetNumberOfElements(prhs[2]);
   if ((int)mxGetNumberOfElements(prhs[3]) != n) mexErrMsgIdAndTxt("kp:size", "mpc_set_state_bounds: lo and hi differ in length");
-  check(kp_mpc_set_state_bounds((kp_mpc*)get_handle(prhs[1]), n, dbl(prhs[2]), dbl(prhs[3])), NULL);
+  check(kp_mpc_set_state_bounds((kp_mpc*)get_handle(prhs[1], H_MPC), n, dbl(prhs[2]), dbl(prhs[3])), NULL);
 }
 static void c_mpc_dims(ARGS) {
   UNUSED;
   int d[2];
-  check(kp_mpc_dims((kp_mpc*)get_handle(prhs[1]), &d[0], &d[1]), NULL);
+  check(kp_mpc_dims((kp_mpc*)get_handle(prhs[1], H_MPC), &d[0], &d[1]), NULL);
   plhs[0] = ints_out(d, 2, 1, 2);
 }
 static void c_mpc_step_zeta(ARGS) {
   UNUSED;
-  kp_mpc* mp = (kp_mpc*)get_handle(prhs[1]);
-  kp_basis* b = (kp_basis*)get_handle(prhs[2]);
+  kp_mpc* mp = (kp_mpc*)get_handle(prhs[1], H_MPC);
+  kp_basis* b = (kp_basis*)get_handle(prhs[2], H_BASIS);
   int nvar, nrows, nv, nf, N, W, status = 0;
   check(kp_mpc_dims(mp, &nvar, &nrows), NULL);
   basis_wn(b, NULL, &nv, &nf, &N, &W);
@@ -797,7 +807,7 @@ static void c_mpc_step(ARGS) {
   UNUSED;
   /* the step from an already lifted state (loaded models lift with the current load estimate on the host side of the
    * boundary, Kmpc.m:347-348) */
-  kp_mpc* mp = (kp_mpc*)get_handle(prhs[1]);
+  kp_mpc* mp = (kp_mpc*)get_handle(prhs[1], H_MPC);
   int nvar, nrows, status = 0;
   check(kp_mpc_dims(mp, &nvar, &nrows), NULL);
   const int m = (int)mxGetNumberOfElements(prhs[3]);
@@ -815,7 +825,7 @@ static void batch_shapes(const mxArray* const* a, int nvar, int* nb, int* m) {  
 }
 static void c_mpc_step_batch(ARGS) {
   UNUSED;
-  kp_mpc* mp = (kp_mpc*)get_handle(prhs[1]);
+  kp_mpc* mp = (kp_mpc*)get_handle(prhs[1], H_MPC);
   int nvar, nrows, nb, m;
   check(kp_mpc_dims(mp, &nvar, &nrows), NULL);
   batch_shapes(prhs + 2, nvar, &nb, &m);
@@ -829,7 +839,7 @@ static void c_mpc_step_batch(ARGS) {
 }
 static void c_mpc_last_qp(ARGS) {
   UNUSED;
-  kp_mpc* mp = (kp_mpc*)get_handle(prhs[1]);
+  kp_mpc* mp = (kp_mpc*)get_handle(prhs[1], H_MPC);
   int nvar, nrows;
   check(kp_mpc_dims(mp, &nvar, &nrows), NULL);
   plhs[0] = mxCreateDoubleMatrix(nvar, nvar, mxREAL);
@@ -845,13 +855,13 @@ static void c_mpc_last_profile(ARGS) {
   UNUSED;
   int counts[2] = {0, 0};
   plhs[0] = mxCreateDoubleMatrix(1, 6, mxREAL);
-  check(kp_mpc_last_profile((kp_mpc*)get_handle(prhs[1]), mxGetPr(plhs[0]), counts), NULL);
+  check(kp_mpc_last_profile((kp_mpc*)get_handle(prhs[1], H_MPC), mxGetPr(plhs[0]), counts), NULL);
   set_or_drop(nlhs, plhs, 1, ints_out(counts, 2, 1, 2));
 }
 static void c_mpc_last_stamps(ARGS) {
   UNUSED;
   plhs[0] = mxCreateDoubleMatrix(1, 16, mxREAL);
-  check(kp_mpc_last_stamps((kp_mpc*)get_handle(prhs[1]), mxGetPr(plhs[0])), NULL);
+  check(kp_mpc_last_stamps((kp_mpc*)get_handle(prhs[1], H_MPC), mxGetPr(plhs[0])), NULL);
 }
 static void c_qp_solve(ARGS) {
   UNUSED;
@@ -945,7 +955,7 @@ static void c_comm_gather_fits(ARGS) {
 
 /* ---- one caller, several GPUs ---------------------------------------------------------------------------------------------------------------------- */
 static kp_multi* multi_handle(const mxArray* a) {
-  kp_multi* g = (kp_multi*)get_handle(a);
+  kp_multi* g = (kp_multi*)get_handle(a, H_MULTI);
   for (int i = 0; i < MAXMULTI; ++i)
     if (g_multi[i] == g) return g;
   mexErrMsgIdAndTxt("kp:handle", "unknown multi-GPU object");
@@ -962,7 +972,7 @@ static void c_multi_create(ARGS) {
     if (!g_multi[i]) slot = i;
   if (slot < 0) mexErrMsgIdAndTxt("kp:usage", "multi_create: too many multi-GPU objects (multi_destroy the old ones)");
   check(kp_multi_create(ids, n, &g_multi[slot]), NULL);
-  plhs[0] = put_handle(g_multi[slot]);
+  plhs[0] = put_handle(g_multi[slot], H_MULTI);
 }
 static void c_multi_destroy(ARGS) {
   UNUSED;
@@ -1017,18 +1027,18 @@ static void c_multi_traj_upload(ARGS) {
   if (rc) { free(r); check_multi(rc, g); }
   r->nb = nb;
   r->n = n;
-  plhs[0] = put_handle(r);
+  plhs[0] = put_handle(r, H_MTRAJ);
 }
 static void c_multi_traj_destroy(ARGS) {
   UNUSED;
-  mtraj_rec* r = (mtraj_rec*)take_handle(prhs[1]);
+  mtraj_rec* r = (mtraj_rec*)take_handle(prhs[1], H_MTRAJ);
   kp_multi_traj_destroy(r->t);
   free(r);
 }
 static void c_multi_sweep_eval_nested(ARGS) {
   UNUSED;
   kp_multi* g = multi_handle(prhs[1]);
-  mtraj_rec* r = (mtraj_rec*)get_handle(prhs[2]);
+  mtraj_rec* r = (mtraj_rec*)get_handle(prhs[2], H_MTRAJ);
   kp_basis_desc desc;
   basis_desc(prhs[3], &desc);
   const int nd = int_arg(prhs[5], "n_deg");
@@ -1052,24 +1062,24 @@ static void c_multi_mpc_create(ARGS) {
   if (rc) { free(r); check_multi(rc, g); }
   r->g = g;
   r->nvar = p.m * p.Np;
-  plhs[0] = put_handle(r);
+  plhs[0] = put_handle(r, H_MMPC);
 }
 static void c_multi_mpc_set_state_bounds(ARGS) {
   UNUSED;
-  mmpc_rec* r = (mmpc_rec*)get_handle(prhs[1]);
+  mmpc_rec* r = (mmpc_rec*)get_handle(prhs[1], H_MMPC);
   const int n = (int)mxGetNumberOfElements(prhs[2]);
   if ((int)mxGetNumberOfElements(prhs[3]) != n) mexErrMsgIdAndTxt("kp:size", "multi_mpc_set_state_bounds: lo and hi differ in length");
   check_multi(kp_multi_mpc_set_state_bounds(r->p, n, dbl(prhs[2]), dbl(prhs[3])), r->g);
 }
 static void c_multi_mpc_destroy(ARGS) {
   UNUSED;
-  mmpc_rec* r = (mmpc_rec*)take_handle(prhs[1]);
+  mmpc_rec* r = (mmpc_rec*)take_handle(prhs[1], H_MMPC);
   kp_multi_mpc_destroy(r->p);
   free(r);
 }
 static void c_multi_mpc_step_batch(ARGS) {
   UNUSED;
-  mmpc_rec* r = (mmpc_rec*)get_handle(prhs[1]);
+  mmpc_rec* r = (mmpc_rec*)get_handle(prhs[1], H_MMPC);
   int nb, m;
   batch_shapes(prhs + 2, r->nvar, &nb, &m);
   int* st = (int*)calloc((size_t)nb, sizeof(int));

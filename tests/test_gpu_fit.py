@@ -741,6 +741,12 @@ def test_a_wrong_remembered_rank_changes_nothing(ctx, arm, hint):
     import os, warnings
     p = arm["pairs"]
     dic = ko.build_dictionary("bilinear", 6, 3, ["poly"], [3])
+    # the hook is honoured only by a context created while KP_TEST_HOOKS is set (the shipped library does not read it per fit)
+    os.environ["KP_TEST_HOOKS"] = "1"
+    try:
+        ctx = kra.Context(0)
+    finally:
+        del os.environ["KP_TEST_HOOKS"]
     b = make_basis(ctx, dic)
     snaps = kra.Snapshots(ctx, p["alpha"], p["beta"], p["u"])
     with warnings.catch_warnings():
@@ -753,3 +759,5 @@ def test_a_wrong_remembered_rank_changes_nothing(ctx, arm, hint):
         finally:
             del os.environ["KP_RANK_HINT_TEST"]
     assert ctx.last_rank() == 252 and np.array_equal(K, Kref)
+    snaps.close()
+    ctx.close()

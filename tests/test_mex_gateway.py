@@ -100,6 +100,16 @@ def test_stale_and_foreign_handles_are_rejected(ctx, h):
     # the context is still usable, and a handle of one kind released through its own command still works afterwards
     b2 = mex("basis_create", h, d)
     assert mex("basis_dims", b2).ravel().tolist()[0] == 2
+    # a LIVE handle of the wrong kind (round-5 advisor finding: the registry checked addresses only): a basis handle where an MPC,
+    # a trajectory set, a snapshot object or a context is expected, and the context's handle where a basis is - refused, nothing
+    # cast, nothing freed; both stay usable
+    for cmd, args in (("mpc_destroy", (b2,)), ("mpc_dims", (b2,)), ("traj_destroy", (b2,)), ("snapshots_destroy", (b2,)), ("synchronize", (b2,)),
+                      ("basis_destroy", (h,)), ("basis_dims", (h,)), ("lift", (b2, h, 1, np.zeros((3, 2))))):
+        with pytest.raises(ms.MexError) as e:
+            mex(cmd, *args, nargout=0)
+        assert e.value.identifier == "kp:handle" and "wrong kind" in str(e.value), (cmd, str(e.value))
+    assert mex("basis_dims", b2).ravel().tolist()[0] == 2
+    mex("synchronize", h, nargout=0)
     mex("basis_destroy", b2, nargout=0)
 
 
