@@ -149,23 +149,6 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
 #pragma unroll
     for (int w = 0; w < NWT; ++w) acc[q][w] = 0.0;
 
-  // ---- one-time LDS setup: everything zero (padding columns and the zero group stay zero) ----
-  for (int e = tid; e < LDS3_DOUBLES; e += 256) sm[e] = 0.0;
-  if (TUP) {   // w_0 = 1 in every row of both Psi buffers (rows past Ns have psi = 0: the tail mask needs no weight)
-    __syncthreads();
-    if (tid < 2 * KT3) sm[PSI03 + (tid / KT3) * PSIBUF3 + (tid & (KT3 - 1)) * RS3 + WOFF3] = 1.0;
-  }
-  if (EXT) {   // gaussian centres (centre-major, nzeta coordinates each)
-    for (int e = tid; e < a.ng * b.nzeta; e += 256) sm[GC03 + e] = a.centres[e];
-  }
-  if (PCS) {   // projection matrix, zero padded to (nfull4 x 32)
-    const int nf4 = a.nfull4;
-    for (int e = tid; e < 2 * nf4 * 16; e += 256) {
-      const int ct = e / (nf4 * 16), r = e - ct * nf4 * 16, c = r >> 4, p = 16 * ct + (r & 15);
-      sm[PCS03 + e] = (c < b.nfull && p < b.k_pcs) ? a.pcs[c + (size_t)p * b.nfull] : 0.0;
-    }
-  }
-
   // ---- lifting thread constants: thread = one (side, column), all KT3 snapshots of the tile ----
   // power table layout [id][snapshot]: the KT3 values of one entry are contiguous (16-byte reads of snapshot pairs)
   // The NWT - 1 Kronecker weights ut_x ut_y (pair index w + 1 in (x <= y) order) are lifted like columns: thread 2 nfull + w
@@ -313,41 +296,65 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
   int tb_inc = KT3;
   {
     const int rr = tb_r % nzm;
-    tb_ptr = (rr < b.nzeta ? ((tb_r < nzm ? a.alpha : a.beta) + (int64_t)rr * a.Ns) : (a.u + (int64_t)(rr - b.nzeta) * a.Ns)) + (kt0 + 2) * KT3 + ld_s;
+    tb_ptr = (rr < b.nzeta ? ((tb_r < nzm ? a.alpha : a.beta) + (int64_t)rr * a.Ns) : (a.u + (int64_t)(rr - b.nzeta) * a.Ns)) + kt0 * KT3 + ld_s;
     if (tb_r == nrawrows) { tb_ptr = kp_gram3_ones; tb_inc = 0; }
   }
   const uint32_t tb_dst = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) double*)(sm + tb_r * RB + ld_s);
   double tb_v = 0.0;                                               // the tile in flight
-  int tb_tile = 2;                                                 // local index of the next tile to load (scalar; tiles 0 and 1: load_raw)
+  int tb_tile = 0;                                                 // local index of the next tile to load (scalar)
   const int tb_full = (int)max((int64_t)0, min((int64_t)1 << 30, a.Ns / KT3 - kt0));   // local tiles wholly inside [0, Ns)
-  bool tb_is_full = true;                                          // ... is the tile in tb_v one of them
   auto load_tb = [&]() __attribute__((always_inline)) {
     tb_v = *tb_ptr;
     tb_ptr += tb_inc;
-    tb_is_full = tb_tile < tb_full;
     ++tb_tile;
   };
-  auto store_tb = [&](auto buf_c) __attribute__((always_inline)) {
+  auto store_tb_v = [&](auto buf_c, double xv, int tile) __attribute__((always_inline)) {   // tile: local index of xv's tile (scalar)
     constexpr int BUF = decltype(buf_c)::value;
-    double xv = tb_v;
-    if (__builtin_expect(!tb_is_full, 0)) {                        // (scalar branch; at most once per workgroup)
-      const int64_t s_glob = (kt0 + tb_tile - 1) * KT3 + ld_s;
+    if (__builtin_expect(tile >= tb_full, 0)) {                    // (scalar branch; at most once per workgroup)
+      const int64_t s_glob = (kt0 + tile) * KT3 + ld_s;
       if (s_glob >= a.Ns) xv = 0.0;
     }
     const double x2 = xv * xv, x3 = x2 * xv, x4 = x2 * x2;
     const uint32_t tb_dst_b = tb_dst;                              // (an asm operand alone does not capture in a generic lambda)
-    // (8-byte stores at immediate offsets from one address register, like the lift's: see lift_write)
 #if !KP_G3_TBASM
     double* dstp = sm + BUF * POWBUF3 + tb_r * RB + ld_s;
     dstp[0] = xv; dstp[PST3] = x2; dstp[2 * PST3] = x3; dstp[3 * PST3] = x4;
     (void)tb_dst_b;
 #else
+    // (8-byte stores at immediate offsets from one address register: four entries 80 bytes apart, no ds_write2 pairs them without an add)
     asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(tb_dst_b), "v"(xv), "n"((BUF * POWBUF3) * 8) : "memory");
     asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(tb_dst_b), "v"(x2), "n"((BUF * POWBUF3 + PST3) * 8) : "memory");
     asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(tb_dst_b), "v"(x3), "n"((BUF * POWBUF3 + 2 * PST3) * 8) : "memory");
     asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(tb_dst_b), "v"(x4), "n"((BUF * POWBUF3 + 3 * PST3) * 8) : "memory");
 #endif
   };
+  auto store_tb = [&](auto buf_c) __attribute__((always_inline)) { store_tb_v(buf_c, tb_v, tb_tile - 1); };
+  // the first three tiles' raw values are requested HERE, in front of the one-time LDS setup and its barriers: the setup runs in
+  // the shadow of their latency (until round 6: setup, load tile 0, wait, table, barrier, lift, load tile 1, wait, ... - three
+  // memory latencies in a row at the head of every workgroup, ~4 us of a 62 us launch at the arm data's 11 999 pairs)
+  double tb_v0 = 0.0, tb_v1 = 0.0;
+  if constexpr (INL) {
+    load_tb(); tb_v0 = tb_v;
+    load_tb(); tb_v1 = tb_v;
+    load_tb();
+  }
+
+  // ---- one-time LDS setup: everything zero (padding columns and the zero group stay zero) ----
+  for (int e = tid; e < LDS3_DOUBLES; e += 256) sm[e] = 0.0;
+  if (TUP) {   // w_0 = 1 in every row of both Psi buffers (rows past Ns have psi = 0: the tail mask needs no weight)
+    __syncthreads();
+    if (tid < 2 * KT3) sm[PSI03 + (tid / KT3) * PSIBUF3 + (tid & (KT3 - 1)) * RS3 + WOFF3] = 1.0;
+  }
+  if (EXT) {   // gaussian centres (centre-major, nzeta coordinates each)
+    for (int e = tid; e < a.ng * b.nzeta; e += 256) sm[GC03 + e] = a.centres[e];
+  }
+  if (PCS) {   // projection matrix, zero padded to (nfull4 x 32)
+    const int nf4 = a.nfull4;
+    for (int e = tid; e < 2 * nf4 * 16; e += 256) {
+      const int ct = e / (nf4 * 16), r = e - ct * nf4 * 16, c = r >> 4, p = 16 * ct + (r & 15);
+      sm[PCS03 + e] = (c < b.nfull && p < b.k_pcs) ? a.pcs[c + (size_t)p * b.nfull] : 0.0;
+    }
+  }
 
   // ---- PRE: the tile comes lifted from memory (kp_gram3_prelift_kernel): entries [psi_x | psi_y | weights] x KT3 snapshots, two 16-byte pieces per thread ----
   struct PreRegs { double2 v[2]; };
@@ -494,18 +501,20 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
     store_pre(B0{}, load_pre());
     __syncthreads();
   } else {
-    store_raw(B0{}, load_raw());
+    if constexpr (INL) store_tb_v(B0{}, tb_v0, 0);
+    else store_raw(B0{}, load_raw());
+    wait_lds_stores();
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       lift_read(i, B0{});
       lift_write(i, B0{});
     }
-    store_raw(B1{}, load_raw());
+    if constexpr (INL) store_tb_v(B1{}, tb_v1, 1);
+    else store_raw(B1{}, load_raw());
     wait_lds_stores();
     __syncthreads();
     if (PCS) project(B0{});
-    if constexpr (INL) load_tb();                       // raw tile 2 (load_raw has advanced the pointer past tiles 0 and 1)
   }
 
   constexpr int NSTEP = (KT3 / 4) * NQ;                 // quad steps (NWT MFMAs each) per snapshot tile
