@@ -35,6 +35,9 @@
 #define KP_G3_ASMW 0    // 1: lift stores as 8-byte stores at immediate offsets (inline asm) instead of the compiler's ds_write2_b64 + v_add.
                         // Measured SLOWER (0.3718 against 0.3659 ms): two store instructions cost the wave more than a v_add and one
 #endif
+#ifndef KP_G3_NLS
+#define KP_G3_NLS 3     // lift steps per tile: 3 = (item, snapshot pair) jobs dealt over 3 x 256 slots; 4 = item per thread, one step per pair
+#endif
 #ifndef KP_G3_TBASM
 #define KP_G3_TBASM 1   // ... the table stores that way are faster (0.3640 against 0.3659 ms; four entries 80 bytes apart: no ds_write2 pairs them without an add)
 #endif
@@ -155,32 +158,56 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
   // multiplies the table entries of u_x and u_y (and the constant) for all KT3 snapshots and writes entry WOFF3 + WSH + w of the
   // Psi rows.  (Until round 6 a separate step at the head of every tile formed them: an LDS round trip and a branch in front
   // of the tile's first operand reads.)
-  const bool lvalid = tid < 2 * b.nfull;
-  const int lside = (lvalid && tid >= b.nfull) ? 1 : 0;
-  const int lcol = lvalid ? tid - lside * b.nfull : 0;
-  const int lw = tid - 2 * b.nfull;                // weight thread: 0 <= lw < NWT - 1
-  const bool lwt = lw >= 0 && lw < NWT - 1;
-  int fa[NF3];
-  {
+  // item -> its three table addresses and its destination column in a Psi row
+  auto item_setup = [&](int item, int (&fa_)[NF3], int& woff_) __attribute__((always_inline)) {
+    const bool lvalid = item >= 0 && item < 2 * b.nfull;
+    const int lside = (lvalid && item >= b.nfull) ? 1 : 0;
+    const int lcol = lvalid ? item - lside * b.nfull : 0;
+    const int lw = item - 2 * b.nfull;             // weight item: 0 <= lw < NWT - 1
+    const bool lwt = lw >= 0 && lw < NWT - 1;
     const uint32_t r = lvalid ? a.recipes[lcol] : 0xffffffffu;
 #pragma unroll
     for (int f = 0; f < NF3; ++f) {
       const int id = (int)((r >> (8 * f)) & 255u);
-      fa[f] = id == 255 ? CA : (EXT && id >= 128) ? CA + (1 + lside * a.ng + (id - 128)) * PST3 : (lside * nzm + id / D) * RB + (id % D) * PST3;
+      fa_[f] = id == 255 ? CA : (EXT && id >= 128) ? CA + (1 + lside * a.ng + (id - 128)) * PST3 : (lside * nzm + id / D) * RB + (id % D) * PST3;
     }
     if (lwt) {
       int cnt = 0;
       for (int x = 0; x <= BM; ++x)
         for (int y = x; y <= BM; ++y) {
           if (cnt == lw + 1) {
-            if (x > 0) fa[0] = (b.nzeta + x - 1) * RB;
-            if (y > 0) fa[1] = (b.nzeta + y - 1) * RB;
+            if (x > 0) fa_[0] = (b.nzeta + x - 1) * RB;
+            if (y > 0) fa_[1] = (b.nzeta + y - 1) * RB;
           }
           ++cnt;
         }
     }
+    woff_ = PSI03 + (lvalid ? lside * YOFF3 + lcol : lwt ? WOFF3 + wslot(lw + 1) : SOFF3 + (tid & 31));
+  };
+#if KP_G3_NLS == 3
+  // The 4 (2 nfull + NWT - 1) (item, snapshot pair) jobs of a tile dealt over 3 x 256 slots: three lift steps per tile instead of
+  // four (item = thread, one step per snapshot pair: 256 lanes for 177 items at N = 84).  A slot's snapshot pair is part of its
+  // addresses, not an immediate: 12 address registers per thread instead of 4.  kp_gram3_applicable: 2 nfull + NWT - 1 <= 192.
+  constexpr int NLS = 3;
+  int fs[NLS][NF3], ws[NLS];
+  {
+    const int nitems = 2 * b.nfull + NWT - 1;
+#pragma unroll
+    for (int j = 0; j < NLS; ++j) {
+      const int e = tid + 256 * j;
+      const bool on = e < 4 * nitems;
+      const int ch = on ? e / nitems : 0;
+      item_setup(on ? e - ch * nitems : -1, fs[j], ws[j]);
+#pragma unroll
+      for (int f = 0; f < NF3; ++f) fs[j][f] += 2 * ch;
+      ws[j] += 2 * ch * RS3;
+    }
   }
-  const int woff = PSI03 + (lvalid ? lside * YOFF3 + lcol : lwt ? WOFF3 + wslot(lw + 1) : SOFF3 + (tid & 31));
+#else
+  int fa[NF3];
+  int woff;
+  item_setup(tid, fa, woff);
+#endif
 
   const int64_t kt0 = (int64_t)split * a.ktiles_per_split;
   const int64_t ktiles_total = (a.Ns + KT3 - 1) / KT3;
@@ -399,6 +426,21 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
   };
 
   // ---- lift of a snapshot tile: power-table buffer B -> Psi buffer B, in pipelined chunks ----
+#if KP_G3_NLS == 3
+  constexpr int NCH = NLS;                           // lift steps per tile
+  double2 lf[NF3];
+  auto lift_read = [&](int j, auto buf_c) __attribute__((always_inline)) {
+    constexpr int BUF = decltype(buf_c)::value;
+#pragma unroll
+    for (int f = 0; f < NF3; ++f)      // (RB, PST3, CA and the pair offset are even: 16-byte aligned, one ds_read_b128)
+      lf[f] = *reinterpret_cast<const double2*>(__builtin_assume_aligned(&sm[BUF * POWBUF3 + fs[j][f]], 16));
+  };
+  auto lift_write = [&](int j, auto buf_c) __attribute__((always_inline)) {
+    constexpr int BUF = decltype(buf_c)::value;
+    sm[BUF * PSIBUF3 + ws[j]] = (lf[0].x * lf[1].x) * lf[2].x;
+    sm[BUF * PSIBUF3 + ws[j] + RS3] = (lf[0].y * lf[1].y) * lf[2].y;
+  };
+#else
   constexpr int NCH = KT3 / 2;                       // chunks: snapshot pairs
   double2 lf[NF3];
   auto lift_read = [&](int ch, auto buf_c) __attribute__((always_inline)) {
@@ -432,6 +474,7 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
 #undef KP_LIFT_STORE
     static_assert(KT3 / 2 == 4, "one case per snapshot pair of a tile");
   };
+#endif
   auto wait_lds_stores = [&]() __attribute__((always_inline)) { __builtin_amdgcn_s_waitcnt(0xc07f); };   // lgkmcnt(0)
   using B0 = std::integral_constant<int, 0>;
   using B1 = std::integral_constant<int, 1>;
@@ -905,6 +948,8 @@ static bool gram3_prelift(const kp_basis* basis) {
 bool kp_gram3_applicable(const kp_basis* basis) {
   const BasisDev& b = basis->dev;
   if (getenv("KP_NO_GRAM3")) return false;
+  // the lift deals 4 (2 nfull + weights) (item, snapshot pair) jobs over 3 x 256 slots (KP_G3_NLS = 3)
+  if (KP_G3_NLS == 3 && 2 * b.nfull + (b.m + 1) * (b.m + 2) / 2 - 1 > 192) return false;
   if (gram3_ext(basis))
     return b.model_type == KP_MODEL_BILINEAR && basis->ext_max_factors <= NF3 && b.nfull <= YOFF3 && b.m >= 1 && b.m <= 3 &&
            2 * (b.nzeta + b.m) * KT3 <= 256 &&

@@ -134,6 +134,54 @@ def test_sweep_and_batched_mpc_dealt_in_contiguous_chunks(ctx):
         tp.close()
 
 
+def test_eight_way_shards_of_the_grid_and_the_sweep_equal_the_single_context(ctx, cfg3):
+    """The shapes an 8-GPU node runs - BASELINE configs[3] (64 lasso values on the bilinear poly-3 fit) and configs[4] (a batch of
+    random systems x {linear, bilinear, nonlinear}) - through the one-caller block with EIGHT workers (the box's one device listed
+    eight times: eight contexts, eight worker threads, eight shards; 61 values and 203 systems are ragged over 8).  Every value
+    / system lands at its position of the caller's stack bit for bit as the single-context path computes it."""
+    from koopman_realizations_amd.device import Traj
+    from test_mex_gateway import _stacks
+    ids = [0] * 8
+    p = cfg3["p"]
+    mg = Multi(ids)
+    try:
+        for nv in (64, 61):
+            vals = np.geomspace(1e-2, 1e2, nv)
+            ref = {}
+            for r in range(8):                                   # worker r's shard (round robin) as ONE kp_fit call of the plain context
+                mine = list(range(r, nv, 8))
+                for i, K in zip(mine, kra.fit(ctx, cfg3["b"], cfg3["s"], vals[mine])):
+                    ref[i] = K
+            Ks = mg.fit(cfg3["dic"], p["alpha"], p["beta"], p["u"], vals)
+            assert Ks.shape == (nv, 336, 336)
+            for i in range(nv):
+                assert np.array_equal(Ks[i].T, ref[i]), (nv, i)
+        tm = mg.timers()
+        assert tm.shape == (8, 4) and (tm[:, 1] > 0).all()
+        # configs[4]: 203 systems in contiguous chunks of 26 / 25 over the eight workers
+        Y, U, Yv, Uv, k = _stacks(nb=203, seed=5)
+        Yn, Un, Yvn, Uvn = (np.ascontiguousarray(np.transpose(x, (2, 0, 1))) for x in (Y, U, Yv, Uv))
+        tp = Traj(ctx, Yn, Un, k, Yvn, Uvn)
+        mt_ = mg.traj_upload(Yn, Un, k, Yvn, Uvn)
+        for mt, D, las in (("linear", 13, np.inf), ("bilinear", 6, np.inf), ("nonlinear", 4, 4.0)):
+            nvar = 1 + (mt == "nonlinear")
+            e = kra.poly_exponent_table(nvar, D)[nvar:]
+            err, st = mt_.sweep_eval_nested((mt, 1, 1, [("poly", e)], None), D, las)
+            b = kra.Basis(ctx, mt, 1, 1, [("poly", e)])
+            err1, st1 = tp.sweep_eval_nested(b, D, las)
+            assert 203 in err.shape and np.array_equal(err, err1, equal_nan=True) and np.array_equal(st, st1), mt
+            b.close()
+        mt_.close()
+        tp.close()
+        # one fit sharded eight ways over its snapshots: rounding-level agreement with the whole-matrix fit, reproducible
+        Kref = kra.fit(ctx, cfg3["b"], cfg3["s"])[0]
+        K1 = mg.fit_sharded(cfg3["dic"], p["alpha"], p["beta"], p["u"])[0].T.copy()
+        K2 = mg.fit_sharded(cfg3["dic"], p["alpha"], p["beta"], p["u"])[0].T.copy()
+        assert np.array_equal(K1, K2) and np.abs(K1 - Kref).max() <= 1e-11 * np.abs(Kref).max()
+    finally:
+        mg.close()
+
+
 def test_multi_errors_name_the_device_and_leave_the_object_usable(ctx, cfg3):
     p = cfg3["p"]
     with pytest.raises(kra.KoopmanHipError):
