@@ -514,7 +514,7 @@ def bench_width_points(ctx, kra, Ns):
     rng = np.random.default_rng(3)
     pcs = np.linalg.qr(rng.standard_normal((84, 27)))[0]
     centres = rng.uniform(-1, 1, (6, 20))
-    shapes = [("W200", kra.Basis(ctx, "bilinear", 6, 3, [("poly", tab[6:49])]), snaps, "kp_gram3_kernel<6,3,false>"),
+    shapes = [("W200", kra.Basis(ctx, "bilinear", 6, 3, [("poly", tab[6:49])]), snaps, "kp_gram3_kernel<6,3,false,false,false,true>"),
               ("W136_pcs", kra.Basis(ctx, "bilinear", 6, 3, [("poly", tab[6:])], pcs), snaps, "kp_gram3_prelift_mfma_kernel + kp_gram3_kernel<.,3,false,false,true>"),
               ("fourier1_nzeta3", kra.Basis(ctx, "bilinear", 3, 3, [("fourier", 1)]), snaps3, "kp_gram3_prelift_ext_kernel + kp_gram3_kernel<.,3,false,false,true>"),
               ("gaussian20", kra.Basis(ctx, "bilinear", 6, 3, [("gaussian", centres)]), snaps, "kp_gram3_prelift_ext_kernel + kp_gram3_kernel<.,3,false,false,true>")]
@@ -942,7 +942,7 @@ def main():
         # HBM traffic of the dominant kernel: PMC counters are collected in separate rocprofv3 passes of this
         # same command (tools/prof_round.sh) and committed under profiles/; null when the workload differs
         traffic, prof_note = None, None
-        for pj in ("r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
+        for pj in ("r06_pmc_summary.json", "r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
             pj = os.path.join(ROOT, "profiles", pj)
             if os.path.exists(pj) and Ns == 100000 and args.degree == 3:
                 try:
@@ -980,7 +980,7 @@ def main():
             "untimed_prewarm_launches": {"pipelined_fits": max(256, args.steps), "gram_only": 32,
                                          "why": "clock ramp: the first ~60 Gram launches after an idle stretch run 470 -> 405 us "
                                                 "(profiles/r02_gram_launch_durations.txt); `warmup` counts only the driver's W"},
-            "roofline": dict(roofline_block("kp_gram3_kernel<6,3,false>", exec_pair * Ns, flops_pair * Ns, g_ms,
+            "roofline": dict(roofline_block("kp_gram3_kernel<6,3,false,false,false,true>", exec_pair * Ns, flops_pair * Ns, g_ms,
                                             note="frac = flop the kernel executes on the matrix pipe / mean kernel time of the timed region (HIP "
                                                  "events on the launch stream) / f64 matrix peak; dense_equivalent_* = SURVEY 8(d)'s W(W+1)+2W^2 "
                                                  "per pair (the Kronecker kernel produces the identical G, C with ~63% of those flop)"),

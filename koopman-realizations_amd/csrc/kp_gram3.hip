@@ -19,6 +19,23 @@
 // index is an immediate too), the weights ut_a ut_b come from LDS (written once per snapshot by the
 // lift) and the tail mask lives in the power table's constant entry.
 //
+// Round 6 (0.396 -> 0.358 ms per 1e5 pairs at W = 336; what each step gave is in DESIGN.md 3.1 "Round 6", measured with the
+// timing-only builds of tools/build_abl3.sh: MFMAs and their operand reads alone take 0.305 ms):
+//  * m = 3: TWO weights per weighted A operand (TUP below) - 5 weight multiplies per A group and k-step instead of 9;
+//  * the power table of the tile after next is built INSIDE the MFMA loop by every thread, branch-free (x .. x^4 at a
+//    compile-time entry stride, raw value loaded a tile ahead; INL), not behind it with a run-time loop and exec masks;
+//  * the Kronecker weights are lifted like columns (no separate step at the head of the tile);
+//  * LDS traffic is NOT free at this instruction mix: table rows at a stride of 62 doubles (bank conflicts of the lift's
+//    16-byte reads 77 -> 57 cycles per chunk), a lane's five tuple weights contiguous (two 16-byte reads and one 8-byte read
+//    instead of the ds_read2_b64 pairs the compiler formed at half the LDS rate);
+//  * the lift's (item, snapshot pair) jobs dealt over 3 x 256 slots: three lift steps per tile instead of four;
+//  * the first three raw tiles requested in front of the one-time LDS setup.
+// Measured and NOT kept: lift stores as two ds_write_b64 at immediate offsets instead of ds_write2_b64 + v_add (slower), the
+// k-step's weights kept in registers across the wave's two A groups (slower), 7 quads per wave (147 spilled registers), the
+// items with three real factors gathered in the last wave so that the others skip a read and a multiply (branches and the
+// scattered stores cost more), B operands 2 / 4 steps ahead and the raw load behind other steps (no difference), cbsz / abid
+// (they do not broadcast blocks on v_mfma_f64_4x4x4_4b: tools/mfma_bcast_probe.hip).
+//
 // Replaces the per-row lift loop of Ksysid.get_Koopman (Ksysid.m:1030-1065) and the products
 // PxTPx, PxTPy (Ksysid.m:1114,1125) for model_type 'bilinear'.
 #include <algorithm>
@@ -37,6 +54,9 @@
 #endif
 #ifndef KP_G3_NLS
 #define KP_G3_NLS 3     // lift steps per tile: 3 = (item, snapshot pair) jobs dealt over 3 x 256 slots; 4 = item per thread, one step per pair
+#endif
+#ifndef KP_G3_KEEPWT
+#define KP_G3_KEEPWT 0   // 1: the k-step's weights stay in registers for the wave's second A group instead of being read again
 #endif
 #ifndef KP_G3_TBASM
 #define KP_G3_TBASM 1   // ... the table stores that way are faster (0.3640 against 0.3659 ms; four entries 80 bytes apart: no ds_write2 pairs them without an add)
@@ -86,7 +106,7 @@ __device__ double kp_gram3_ones[KT3] = {1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0};
 // against B operands (g0, g1, g0, g1) and (g2, g3, g2, g3) of the quad: the same 10 MFMAs per quad and k-step produce the same
 // 40 (weight, group) blocks, bit for bit, with 5 weight multiplies per A group and k-step instead of 9 (nothing on the vector
 // pipe overlaps the f64 MFMA stream: each costs ~5.5 cycles of it) and 10 operand registers less; the price is a second
-// operand read per quad, which the LDS has room for (it was 31 % busy).  The weights sit at WOFF3 + [0, 10) with w_0 = 1 stored.
+// operand read per quad.  The weights sit in the 12 weight entries of a Psi row in tuple order (wslot), w_0 = 1 stored.
 template <int NQ, int BM, bool PCS, bool EXT = false, bool PRE = false, bool TUP = false>
 __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
   constexpr int NWT = (BM + 1) * (BM + 2) / 2;
@@ -645,7 +665,9 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
       }
       if (QS < NQ && q == QS) weigh(av1);
       // fetch the weights one step before they are multiplied in (LDS reads are free, registers are not)
+#if !KP_G3_KEEPWT
       if (QS < NQ && QS > 1 && q == QS - 1) load_wt(kk);
+#endif
       if (q == NQ - 1 && kk + 1 < KT3 / 4) load_wt(kk + 1);
 #if KP_ABL3 != 6
       if (step + PF < NSTEP) {
