@@ -754,21 +754,32 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
 // 4 blocks (4x4 each) into G and C.  lane l: block = (l>>2)&3, row r = l>>4, col c = l&3.
 // tup (kp_gram3_kernel<.., TUP = true>): accumulator w' = 2 p + h of a quad holds, in block b, weight 2 p + (b >> 1) against
 // group 2 h + (b & 1) of the quad.
-__global__ __launch_bounds__(256) void kp_gram3_reduce_kernel(const double* __restrict__ part, int nsplit, int njobs, int NQ, int NWT,
-                                                             int BM, const uint32_t* __restrict__ desc, int G4, int N, int W,
-                                                             double* __restrict__ G, double* __restrict__ C, int tup) {
+// blockDim.x / 64 = 4, 8 or 16 waves share the split sum (the launcher picks by the split count: a dim_red fit at the arm data's
+// size has 167 splits of 184 KB - four waves walked 42 dependent-latency loads each, 14 us for a 23 us Gram kernel), each wave
+// with four loads in flight; every order is fixed: bitwise reproducible.
+__global__ __launch_bounds__(1024) void kp_gram3_reduce_kernel(const double* __restrict__ part, int nsplit, int njobs, int NQ, int NWT,
+                                                              int BM, const uint32_t* __restrict__ desc, int G4, int N, int W,
+                                                              double* __restrict__ G, double* __restrict__ C, int tup) {
   const int idx = blockIdx.x;                 // (job*NQ + q)*NWT + w
   int w = idx % NWT;
   const int jq = idx / NWT, q = jq % NQ, job = jq / NQ;
-  const int l = threadIdx.x & 63, wv = threadIdx.x >> 6;   // 4 waves share the split sum (fixed order: deterministic)
-  __shared__ double red4[4][64];
+  const int l = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+  __shared__ double red[16][64];
   const size_t per_split = (size_t)njobs * NQ * NWT * 64;
-  double s = 0.0;
-  for (int p = wv; p < nsplit; p += 4) s += part[(size_t)p * per_split + (size_t)idx * 64 + l];
-  red4[wv][l] = s;
+  const double* src = part + (size_t)idx * 64 + l;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int p = wv;
+  for (; p + 3 * nwv < nsplit; p += 4 * nwv) {
+    const double v0 = src[(size_t)p * per_split], v1 = src[(size_t)(p + nwv) * per_split];
+    const double v2 = src[(size_t)(p + 2 * nwv) * per_split], v3 = src[(size_t)(p + 3 * nwv) * per_split];
+    s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+  }
+  for (; p < nsplit; p += nwv) s0 += src[(size_t)p * per_split];
+  red[wv][l] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (wv) return;
-  s = (red4[0][l] + red4[1][l]) + (red4[2][l] + red4[3][l]);
+  double s = red[0][l];
+  for (int v = 1; v < nwv; ++v) s += red[v][l];
   const uint32_t* jd = desc + (size_t)job * (1 + NQ);
   const int ga = q < (int)((jd[0] >> 16) & 255u) ? (int)(jd[0] & 255u) : (int)((jd[0] >> 8) & 255u);
   int gsel = (l >> 2) & 3;
@@ -1119,7 +1130,7 @@ int kp_gram3_launch(kp_ctx* ctx, const kp_basis* basis_c, const kp_snapshots* s,
     ctx->solve_chained = true;                      // the solve stream already waits for this Gram kernel
   }
   ctx->reduce_timed_from = ctx->reduce_stream ? 4 : 1;
-  hipLaunchKernelGGL(kp_gram3_reduce_kernel, dim3(plan.njobs * plan.nq * NWT), dim3(256), 0, rs, part, nsplit, plan.njobs,
+  hipLaunchKernelGGL(kp_gram3_reduce_kernel, dim3(plan.njobs * plan.nq * NWT), dim3(nsplit >= 128 ? 1024 : nsplit >= 32 ? 512 : 256), 0, rs, part, nsplit, plan.njobs,
                      plan.nq, NWT, BM, plan.desc, plan.G4, N, W, GC_dev, GC_dev + (size_t)W * W, plan.wpw != 8 && gram3_tup(BM) ? 1 : 0);
   KP_HIP(ctx, hipGetLastError());
   if (!pipelined) KP_HIP(ctx, hipEventRecord(ctx->ev1, rs));
