@@ -49,12 +49,17 @@ struct TngArgs {
   const double *wa, *wb;     // optional row weights (length K each, nullptr = 1): C += alpha sum_k wa[k] wb[k] A[k,:]' B[k,:]
 };
 
-template <int RA, int RB, int NW = 4>
+// VEC (round 6): the staging moves TWO consecutive contraction indices per thread - one 16-byte global load and one ds_write_b128 where
+// the scalar form issues two 8-byte loads and two ds_write_b64 (14 + 14 instructions per thread and contraction block beside the
+// 192 MFMAs of a wave; a store instruction costs a wave more than a vector add, measured on the Gram kernel).  Needs A, B 16-byte
+// aligned and even leading dimensions (the launcher checks; the panels of the wide path and the blocks of the factorisation are).
+template <int RA, int RB, int NW = 4, bool VEC = false>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void kp_tn_gemm_kernel(TngArgs g) {
   using Cfg = TngCfg<RA, RB, NW>;
+  static_assert(!VEC || (RA % 2 == 0 && Cfg::PB % 2 == 0), "VEC: rows of a tile are staged 2 SR per pass");
   constexpr int TM = Cfg::TM, TN = Cfg::TN, BUF = Cfg::BUF, OS = Cfg::OS, RS = TNG_RS, KB = TNG_KB, ECH = Cfg::ECH;
   constexpr int NT = Cfg::NT, SR = NT / 16, PB = Cfg::PB;          // SR rows of a tile are staged per pass of the workgroup
-  extern __shared__ double sm[];
+  extern __shared__ __align__(16) double sm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   int ct, rt;
@@ -83,62 +88,85 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void kp_tn_gemm_kernel(Tn
   const int k_lo = split * g.kper, k_hi = min(g.K, k_lo + g.kper);
   const int klen = max(0, k_hi - k_lo);
 
-  const int sk = tid & 15, sr = tid >> 4;
-  unsigned go[RA], xo[PB];
+  // staging geometry: thread = (row sr of a pass, contraction index sk); VEC: two indices sk, sk + 1 and twice the rows per pass
+  constexpr int KPT = VEC ? 2 : 1, SRV = SR * KPT, RAV = RA / KPT, PBV = PB / KPT;
+  const int sk = VEC ? 2 * (tid & 7) : tid & 15, sr = VEC ? tid >> 3 : tid >> 4;
+  unsigned go[RAV], xo[PBV > 0 ? PBV : 1];
 #pragma unroll
-  for (int p = 0; p < RA; ++p) {
-    const int row = sr + SR * p;
+  for (int p = 0; p < RAV; ++p) {
+    const int row = sr + SRV * p;
     go[p] = (unsigned)(((int64_t)(r0 + row < g.M ? row : 0) * g.lda + sk) * 8);
   }
 #pragma unroll
-  for (int p = 0; p < PB; ++p) {
-    const int col = sr + SR * p;
+  for (int p = 0; p < PBV; ++p) {
+    const int col = sr + SRV * p;
     xo[p] = (unsigned)(((int64_t)(c0 + col < g.N ? col : 0) * g.ldb + sk) * 8);
   }
   const char* Ab = (const char*)(g.A + (int64_t)r0 * g.lda + k_lo);
   const char* Bb = (const char*)(g.B + (int64_t)c0 * g.ldb + k_lo);
   const int so = sr * RS + sk;
-  double sg[RA], sx[PB], swa = 1.0, swb = 1.0;
+  double sg[RA], sx[PB > 0 ? PB : 1], swa = 1.0, swb = 1.0, swa1 = 1.0, swb1 = 1.0;
   const int nkb = (klen + KB - 1) / KB, nkb_full = klen / KB;
   const bool weighted = g.wa != nullptr || g.wb != nullptr;
   auto stage_load = [&](int kb) {
     if (kb < nkb_full) {
       const unsigned ko = (unsigned)kb * (KB * 8u);
+      if constexpr (VEC) {
 #pragma unroll
-      for (int p = 0; p < RA; ++p) sg[p] = *(const double*)(Ab + (go[p] + ko));
+        for (int p = 0; p < RAV; ++p) { const double2 v = *(const double2*)(Ab + (go[p] + ko)); sg[2 * p] = v.x; sg[2 * p + 1] = v.y; }
 #pragma unroll
-      for (int p = 0; p < PB; ++p) sx[p] = *(const double*)(Bb + (xo[p] + ko));
+        for (int p = 0; p < PBV; ++p) { const double2 v = *(const double2*)(Bb + (xo[p] + ko)); sx[2 * p] = v.x; sx[2 * p + 1] = v.y; }
+      } else {
+#pragma unroll
+        for (int p = 0; p < RA; ++p) sg[p] = *(const double*)(Ab + (go[p] + ko));
+#pragma unroll
+        for (int p = 0; p < PB; ++p) sx[p] = *(const double*)(Bb + (xo[p] + ko));
+      }
       if (weighted) {                     // (uniform) the weight of contraction index k rides on the A operand; it is applied
         const int k = k_lo + kb * KB + sk;     // in stage_store: a product here would wait for the loads before the MFMAs they hide behind
         swa = g.wa ? g.wa[k] : 1.0;
         swb = g.wb ? g.wb[k] : 1.0;
+        if (VEC) { swa1 = g.wa ? g.wa[k + 1] : 1.0; swb1 = g.wb ? g.wb[k + 1] : 1.0; }
       }
     } else {
-      const int k = kb * KB + sk;
-      const bool kok = k < klen;
-      const unsigned ko = (unsigned)((kok ? k : klen - 1) - sk) * 8u;
 #pragma unroll
-      for (int p = 0; p < RA; ++p) { const double v = *(const double*)(Ab + (go[p] + ko)); sg[p] = kok ? v : 0.0; }
+      for (int q = 0; q < KPT; ++q) {     // the range's last, partial block: element by element
+        const int k = kb * KB + sk + q;
+        const bool kok = k < klen;
+        const unsigned ko = (unsigned)((kok ? k : klen - 1) - sk) * 8u;
 #pragma unroll
-      for (int p = 0; p < PB; ++p) { const double v = *(const double*)(Bb + (xo[p] + ko)); sx[p] = kok ? v : 0.0; }
-      if (weighted) {
-        const int kc = k_lo + (kok ? k : klen - 1);
-        swa = g.wa ? g.wa[kc] : 1.0;
-        swb = g.wb ? g.wb[kc] : 1.0;
+        for (int p = 0; p < RAV; ++p) { const double v = *(const double*)(Ab + (go[p] + ko)); sg[KPT * p + q] = kok ? v : 0.0; }
+#pragma unroll
+        for (int p = 0; p < PBV; ++p) { const double v = *(const double*)(Bb + (xo[p] + ko)); sx[KPT * p + q] = kok ? v : 0.0; }
+        if (weighted) {
+          const int kc = k_lo + (kok ? k : klen - 1);
+          (q ? swa1 : swa) = g.wa ? g.wa[kc] : 1.0;
+          (q ? swb1 : swb) = g.wb ? g.wb[kc] : 1.0;
+        }
       }
     }
   };
   auto stage_store = [&](int buf) {
     double* d = sm + buf * BUF + so;
     if (weighted) {
-      const double w = swa * swb;
+      const double w = swa * swb, w1 = swa1 * swb1;
 #pragma unroll
-      for (int p = 0; p < RA; ++p) sg[p] *= w;
+      for (int p = 0; p < RAV; ++p) {
+        sg[KPT * p] *= w;
+        if (VEC) sg[2 * p + 1] *= w1;
+      }
     }
+    if constexpr (VEC) {
 #pragma unroll
-    for (int p = 0; p < RA; ++p) d[SR * p * RS] = sg[p];
+      for (int p = 0; p < RAV; ++p) *reinterpret_cast<double2*>(__builtin_assume_aligned(d + SRV * p * RS, 16)) = make_double2(sg[2 * p], sg[2 * p + 1]);
 #pragma unroll
-    for (int p = 0; p < PB; ++p) d[(TM + SR * p) * RS] = sx[p];
+      for (int p = 0; p < PBV; ++p) *reinterpret_cast<double2*>(__builtin_assume_aligned(d + (TM + SRV * p) * RS, 16)) = make_double2(sx[2 * p], sx[2 * p + 1]);
+    } else {
+#pragma unroll
+      for (int p = 0; p < RA; ++p) d[SR * p * RS] = sg[p];
+#pragma unroll
+      for (int p = 0; p < PB; ++p) d[(TM + SR * p) * RS] = sx[p];
+    }
   };
 
   const int lc = lane & 3, blk = (lane >> 2) & 3, lk = lane >> 4;
@@ -249,14 +277,19 @@ static inline int64_t tng_count_tiles(int M, int N, int tm, int tn, int tri) {
     for (int c = 0; c < nct; ++c) cnt += r * tm <= c * tn + tn - 1 ? 1 : 0;
   return cnt;
 }
-template <int RA, int RB, int NW = 4>
+template <int RA, int RB, int NW = 4, bool VEC = false>
 static hipError_t tng_launch_cfg(hipStream_t st, TngArgs g) {
   using Cfg = TngCfg<RA, RB, NW>;
+  if constexpr (!VEC && RA % 2 == 0 && Cfg::PB % 2 == 0) {
+    static const bool no_vec = getenv("KP_TNG_NOVEC") != nullptr;       // (A/B measurements)
+    if (!no_vec && ((uintptr_t)g.A % 16) == 0 && ((uintptr_t)g.B % 16) == 0 && g.lda % 2 == 0 && g.ldb % 2 == 0)
+      return tng_launch_cfg<RA, RB, NW, true>(st, g);
+  }
   static bool attr_set[32] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev < 0 || dev >= 32 || !attr_set[dev]) {
-    hipError_t e = hipFuncSetAttribute((const void*)kp_tn_gemm_kernel<RA, RB, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)kp_tn_gemm_kernel<RA, RB, NW, VEC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
     if (e != hipSuccess) return e;
     if (dev >= 0 && dev < 32) attr_set[dev] = true;
   }
@@ -269,7 +302,7 @@ static hipError_t tng_launch_cfg(hipStream_t st, TngArgs g) {
     g.per_xcd = (int)((act + 7) / 8);
     nblk = 8 * g.per_xcd;
   }
-  hipLaunchKernelGGL((kp_tn_gemm_kernel<RA, RB, NW>), dim3(nblk, g.nsplit), dim3(Cfg::NT), Cfg::LDS_BYTES, st, g);
+  hipLaunchKernelGGL((kp_tn_gemm_kernel<RA, RB, NW, VEC>), dim3(nblk, g.nsplit), dim3(Cfg::NT), Cfg::LDS_BYTES, st, g);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess || g.nsplit <= 1) return e;
   hipLaunchKernelGGL(kp_tn_gemm_reduce_kernel, dim3((unsigned)(((int64_t)g.M * g.N + 255) / 256)), dim3(256), 0, st, g.P, g.nsplit, g.M, g.N, g.C, g.ldc,
