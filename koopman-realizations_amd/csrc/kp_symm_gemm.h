@@ -23,7 +23,7 @@
 // per workgroup, whichever fills the rounds of workgroups best (kp_symm_gemm2)
 #define SG2_SMALL_UNITS 19000
 #define SG2_KB 16        // contraction block
-#define SG2_RS 20        // LDS row stride (doubles): = 4 mod 8 -> the 4-row x 4-k operand reads of the MFMA spread over all banks
+#define SG2_RS 22        // LDS row stride (doubles): = 2 mod 4 -> the 16 rows x 2 k of a B-operand read hit 64 different banks (20: rows r, r + 8 collide; kp_tn_gemm.h)
 
 template <int RA, int RB>
 struct Sg2Cfg {
