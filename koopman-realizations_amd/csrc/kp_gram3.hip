@@ -991,7 +991,7 @@ bool kp_gram3_applicable(const kp_basis* basis) {
   if (b.k_pcs > 0 && (b.k_pcs > PCSMAX3 || b.N != b.nzeta + b.k_pcs + 1 || getenv("KP_NO_GRAM3_PCS"))) return false;
   // (powers <= 4: the in-loop table build writes x .. x^4 at an entry stride of 4; the constant row's 4 entries follow the raw rows)
   return b.model_type == KP_MODEL_BILINEAR && basis->fast && basis->max_factors <= NF3 && b.nfull <= YOFF3 && basis->pow_depth <= 4 &&
-         b.m >= 1 && b.m <= 3 && 2 * (b.nzeta + b.m) * KT3 <= 256 && 2 * (b.nzeta + b.m) * 4 + 4 <= NIDMAX3;
+         b.m >= 1 && b.m <= 3 && (2 * (b.nzeta + b.m) + 1) * KT3 <= 256 && 2 * (b.nzeta + b.m) * 4 + 4 <= NIDMAX3;   // (+ 1: the constant's table row has a thread)
 }
 
 int kp_gram3_launch(kp_ctx* ctx, const kp_basis* basis_c, const kp_snapshots* s, double* GC_dev) {

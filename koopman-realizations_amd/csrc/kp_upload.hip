@@ -183,8 +183,8 @@ static void free_arrays(kp_snapshots* s) {
   s->cap_rows = 0;
 }
 
-// every array carries 64 doubles of zero padding behind its Ns * columns values: the Gram kernels prefetch up to two
-// snapshot tiles past the end of a row without bounds checks (the values are masked, the addresses must be mapped)
+// every array carries 64 doubles of zero padding behind its Ns * columns values: the Gram kernels prefetch up to three
+// snapshot tiles (24 + 7 values) past the end of a row without bounds checks (the values are masked, the addresses must be mapped)
 static const size_t kPad = 64 * sizeof(double);
 
 static hipError_t alloc_arrays(kp_snapshots* s, int64_t rows) {

@@ -54,6 +54,11 @@ CASES = [
     ("bilinear", 3, 3, ["fourier"], [1], False),             # (1 + 2)^3 - 1 = 26 functions, products of <= 3 harmonics
     ("bilinear", 6, 3, ["gaussian"], [20], False),           # def_gaussianLift with 20 centres (Ksysid.m:790-817)
     ("bilinear", 2, 1, ["fourier", "gaussian", "poly"], [2, 7, 3], False),   # second harmonics by the recurrence, all three kinds
+    # round 6 (the Kronecker kernel's in-loop power table and three-step lift): fourth powers; powers beyond 4 (served by kp_gram2);
+    # the widest shape it admits - 15 raw rows per side (the table falls back to its dense row stride), 91 columns = 191 lift items
+    ("bilinear", 3, 3, ["poly"], [4], False),
+    ("bilinear", 2, 1, ["poly"], [5], False),
+    ("bilinear", 12, 3, ["poly"], [2], False),
 ]
 
 
