@@ -114,3 +114,20 @@ def test_emit_result_prints_exactly_one_stdout_line_and_the_detail_elsewhere(tmp
     assert "kernels" in full and "wide_dictionaries" in full
     assert json.load(open(tmp_path / "bench_detail.json")) == full
     assert json.load(open(tmp_path / "gpurun_out" / "bench_detail.json")) == full
+
+
+def test_compact_line_of_the_committed_full_record():
+    """The real thing: the full record of the round's own run (profiles/r06_bench_detail.json, written by emit_result on the GPU box)
+    through compact_line - the size the driver will see, and the headline digits intact."""
+    path = os.path.join(ROOT, "profiles", "r06_bench_detail.json")
+    if not os.path.exists(path):
+        import pytest
+        pytest.skip("no committed record")
+    res = json.loads(open(path).read())
+    line = bench.compact_line(res)
+    assert len(line) < bench.COMPACT_LINE_LIMIT
+    d = json.loads(line)
+    for k in REQUIRED:
+        assert k in d, k
+    assert abs(d["value"] / res["value"] - 1) < 1e-5 and d["roofline"]["bound"] == "mfma" and 0.5 < d["roofline"]["frac"] < 1.0
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
