@@ -1520,8 +1520,8 @@ __global__ __launch_bounds__(64) void kp_sweep_rollout_nested_kernel(BasisDev b,
 template <int CTRL>
 __device__ __forceinline__ double sb_row_ror(double v) {       // lane l of a 16-lane row receives from lane (l - n) mod 16
   int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
-  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double sb_row_sum(double v) {        // sum over the 16 lanes of a row, in every lane
@@ -1648,7 +1648,7 @@ __global__ __launch_bounds__(64) void kp_sweep_rollout4_kernel(BasisDev b, const
         if constexpr (CC < NW) {                                                                                 \
           double w = ak[CC];                                                                                     \
           if constexpr (MT == KP_MODEL_BILINEAR) { w += ut[0] * bk[0][CC]; if (m > 1) w += ut[1] * bk[1][CC]; if (m > 2) w += ut[2] * bk[2][CC]; } \
-          ACC += w * __builtin_amdgcn_update_dpp(0.0, z, 0x150 + (CC), 0xf, 0xf, false);                         \
+          ACC += w * __builtin_amdgcn_update_dpp(0.0, z, 0x150 + (CC), 0xf, 0xf, true);                         \
         }
         KP_COL_STEP(0, zn) KP_COL_STEP(1, zn1) KP_COL_STEP(2, zn) KP_COL_STEP(3, zn1) KP_COL_STEP(4, zn) KP_COL_STEP(5, zn1)
         KP_COL_STEP(6, zn) KP_COL_STEP(7, zn1) KP_COL_STEP(8, zn) KP_COL_STEP(9, zn1) KP_COL_STEP(10, zn) KP_COL_STEP(11, zn1)
@@ -1666,10 +1666,10 @@ __global__ __launch_bounds__(64) void kp_sweep_rollout4_kernel(BasisDev b, const
             const int e_ = (int)((epack >> (4 * (I))) & 15u);                             \
             for (int k_ = 0; k_ < e_; ++k_) psi *= x_;                                    \
           }
-          KP_NL_VAR(0, __builtin_amdgcn_update_dpp(0.0, z, 0x150, 0xf, 0xf, false))
-          if (n > 1) KP_NL_VAR(1, __builtin_amdgcn_update_dpp(0.0, z, 0x151, 0xf, 0xf, false))
-          if (n > 2) KP_NL_VAR(2, __builtin_amdgcn_update_dpp(0.0, z, 0x152, 0xf, 0xf, false))
-          if (n > 3) KP_NL_VAR(3, __builtin_amdgcn_update_dpp(0.0, z, 0x153, 0xf, 0xf, false))
+          KP_NL_VAR(0, __builtin_amdgcn_update_dpp(0.0, z, 0x150, 0xf, 0xf, true))
+          if (n > 1) KP_NL_VAR(1, __builtin_amdgcn_update_dpp(0.0, z, 0x151, 0xf, 0xf, true))
+          if (n > 2) KP_NL_VAR(2, __builtin_amdgcn_update_dpp(0.0, z, 0x152, 0xf, 0xf, true))
+          if (n > 3) KP_NL_VAR(3, __builtin_amdgcn_update_dpp(0.0, z, 0x153, 0xf, 0xf, true))
           KP_NL_VAR(n, ut[0])
           if (m > 1) KP_NL_VAR(n + 1, ut[1])
           if (m > 2) KP_NL_VAR(n + 2, ut[2])

@@ -43,7 +43,7 @@ namespace {
 // value of lane N of every 16-lane row, in all lanes of the row: one DP-ALU DPP move (row_newbcast), no trip through SGPRs
 template <int N>
 __device__ __forceinline__ double ll_rowbc(double v) {
-  return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + N, 0xf, 0xf, false);
+  return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + N, 0xf, 0xf, true);
 }
 
 template <int C, int CC>

@@ -67,13 +67,13 @@ struct kp_mpc {
 // ---- wave-level helpers (64 lanes): DPP inside 16-lane rows, v_readlane across the 4 rows ----
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov(double v) {
-  int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
-  int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+  int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
 }
 template <int CTRL>
 __device__ __forceinline__ int dpp_movi(int v) {
-  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
 }
 __device__ __forceinline__ double lane_get(double v, int lane) {
   int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);

@@ -58,8 +58,8 @@ __global__ __launch_bounds__(256) void kp_pivchol_init_kernel(const double* __re
 // carrying (value, index) pairs through __shfl_xor (three ds_bpermute per step) took > 1000.  Ties go to the lowest lane.
 template <int CTRL>
 __device__ __forceinline__ double pc_dpp_mov(double v) {
-  int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
-  int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+  int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double pc_lane_get(double v, int lane) {
