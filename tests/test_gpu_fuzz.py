@@ -1,5 +1,5 @@
 """Randomised parity of the fused lift+Gram kernels against the numpy oracle (a fixed-seed slice of tools/gram_fuzz.py, which round 6
-ran over 3 750 cases after rebuilding the Kronecker kernel's lift): model types x nzeta x m x degree x dictionary kinds x snapshot
+ran over 21 000 cases after rebuilding the Kronecker kernel's lift): model types x nzeta x m x degree x dictionary kinds x snapshot
 counts around every tile boundary (1 .. 25, 511 .. 513, 5 999 / 6 001: the prelift threshold).  G symmetric bit for bit, repeatable
 bit for bit, 2e-12 of the oracle's Grams."""
 import os
