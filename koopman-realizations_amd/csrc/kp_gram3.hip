@@ -102,7 +102,7 @@ __device__ double kp_gram3_ones[KT3] = {1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0};
 
 // PCS: econ lift through a projection matrix (dim_red dictionaries)
 // EXT: fourier (def_fourierLift, Ksysid.m:694-731) and gaussian (def_gaussianLift, :790-817) blocks through the same table
-// TUP (round 6; BM = 3 only): the four blocks of a weighted A operand carry TWO weights - tuple p = (w_2p, w_2p, w_2p+1, w_2p+1) -
+// TUP (round 6; m = 3 and m = 2: an even number of weights): the four blocks of a weighted A operand carry TWO weights - tuple p = (w_2p, w_2p, w_2p+1, w_2p+1) -
 // against B operands (g0, g1, g0, g1) and (g2, g3, g2, g3) of the quad: the same 10 MFMAs per quad and k-step produce the same
 // 40 (weight, group) blocks, bit for bit, with 5 weight multiplies per A group and k-step instead of 9 (nothing on the vector
 // pipe overlaps the f64 MFMA stream: each costs ~5.5 cycles of it) and 10 operand registers less; the price is a second
@@ -110,7 +110,7 @@ __device__ double kp_gram3_ones[KT3] = {1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0};
 template <int NQ, int BM, bool PCS, bool EXT = false, bool PRE = false, bool TUP = false>
 __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
   constexpr int NWT = (BM + 1) * (BM + 2) / 2;
-  static_assert(!TUP || BM == 3, "paired weights: 10 weights = 5 tuples");
+  static_assert(!TUP || NWT % 2 == 0, "paired weights: an even number of weights (m = 3: 10 = 5 tuples, m = 2: 6 = 3 tuples)");
   // TUP: weight w sits in slot 6 (w & 1) + (w >> 1) of the 12 weight entries of a Psi row (w_0 = 1 stored in slot 0): the five
   // weights a lane multiplies in - w_{2p+h}, p = 0..4, h = blk >> 1 - are contiguous and 16-byte aligned (two ds_read_b128 and a
   // ds_read_b64; as 8-byte reads at stride 2 the compiler paired them into ds_read2_b64, half the LDS rate)
@@ -421,9 +421,9 @@ __global__ __launch_bounds__(256, 2) void kp_gram3_kernel(Gram3Args a) {
       // of this kernel's LDS cycles were conflicts)
       const int e1 = pre_on[j] ? e : 0;
       const int sp = e1 / a.pre_rl, c = e1 - sp * a.pre_rl, srow = 2 * sp;
-      // (the lifted rows carry w_1 .. w_9 and three zeros: the zeros go to the two unused weight slots and the scratch entry behind them)
+      // (the lifted rows carry w_1 .. w_{NWT-1} and zeros up to 12 entries: the zeros go to the unused weight slots and the scratch entry behind them)
       const int cw = c - 8 * a.G4;
-      const int off = c < 4 * a.G4 ? c : c < 8 * a.G4 ? YOFF3 + (c - 4 * a.G4) : WOFF3 + (!TUP ? cw : cw < 9 ? wslot(cw + 1) : cw == 9 ? 5 : cw == 10 ? 11 : 12);
+      const int off = c < 4 * a.G4 ? c : c < 8 * a.G4 ? YOFF3 + (c - 4 * a.G4) : WOFF3 + (!TUP ? cw : cw < NWT - 1 ? wslot(cw + 1) : (cw - (NWT - 1)) < 2 * (6 - NWT / 2) ? ((cw - (NWT - 1)) / (6 - NWT / 2)) * 6 + NWT / 2 + (cw - (NWT - 1)) % (6 - NWT / 2) : 12);
       pre_dst[j] = PSI03 + srow * RS3 + off;
     }
   }
@@ -899,11 +899,11 @@ static int make_plan3(kp_ctx* ctx, int N, int nwt, int nq_cap, kp_gram3_plan** o
   return KP_OK;
 }
 
-// BM = 3 runs the paired-weight form (TUP) of the kernel; KP_GRAM3_NOTUP=1 (read once) keeps the one-weight-per-operand form for
+// m = 3 and m = 2 run the paired-weight form (TUP) of the kernel; KP_GRAM3_NOTUP=1 (read once) keeps the one-weight-per-operand form for
 // A/B measurements - the two write different partial layouts, the reduction is told which
 static bool gram3_tup(int bm) {
   static const bool off = getenv("KP_GRAM3_NOTUP") != nullptr;
-  return bm == 3 && !off;
+  return bm >= 2 && !off;              // (an even number of weights: m = 2 -> 6, m = 3 -> 10)
 }
 
 template <int NQ, int BM, bool PCS, bool EXT = false, bool PRE = false, bool TUP = false>
@@ -920,7 +920,7 @@ static hipError_t launch3c(const Gram3Args& a, int grid, size_t lds, hipStream_t
 
 template <int NQ, int BM, bool PCS, bool EXT = false, bool PRE = false>
 static hipError_t launch3b(const Gram3Args& a, int grid, size_t lds, hipStream_t st) {
-  if constexpr (BM == 3) {
+  if constexpr (BM >= 2) {
     if (gram3_tup(BM)) return launch3c<NQ, BM, PCS, EXT, PRE, true>(a, grid, lds, st);
   }
   return launch3c<NQ, BM, PCS, EXT, PRE, false>(a, grid, lds, st);
